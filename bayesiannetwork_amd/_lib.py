@@ -1,0 +1,98 @@
+"""ctypes loader for libbn_mi355x.so (the C ABI declared in include/bn_mi355x.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises --
+there is no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbn_mi355x.so")
+_LIB = None
+
+BN_OK, BN_ERR_ARG, BN_ERR_HIP, BN_ERR_NO_DEVICE, BN_ERR_ALLOC, BN_ERR_COMM, BN_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
+BN_DEVICE_HOST_ONLY, BN_DEVICE_CURRENT = -2, -1
+
+i32p = ctypes.POINTER(ctypes.c_int32)
+i64p = ctypes.POINTER(ctypes.c_int64)
+f64p = ctypes.POINTER(ctypes.c_double)
+u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("n_nodes", ctypes.c_int32), ("k", i32p), ("in_ptr", i32p), ("in_idx", i32p),
+                ("cpt_off", i64p), ("cpt", f64p), ("device", ctypes.c_int32), ("lanes_per_node", ctypes.c_int32)]
+
+
+class BpStats(ctypes.Structure):
+    _fields_ = [("sweeps", ctypes.c_int32), ("sweep_launches", ctypes.c_int32), ("sweep_kernel_ms", ctypes.c_float),
+                ("total_ms", ctypes.c_float), ("algorithmic_bytes_per_sweep", ctypes.c_int64),
+                ("layout_bytes_per_sweep", ctypes.c_int64), ("messages_per_sweep", ctypes.c_int64)]
+
+
+class LayoutInfo(ctypes.Structure):
+    _fields_ = [("n_nodes", ctypes.c_int32), ("n_edges", ctypes.c_int32), ("n_classes", ctypes.c_int32),
+                ("n_tiles", ctypes.c_int32), ("lanes_per_node_max", ctypes.c_int32),
+                ("cpt_doubles", ctypes.c_int64), ("rec_doubles", ctypes.c_int64), ("node_doubles", ctypes.c_int64),
+                ("algorithmic_bytes_per_sweep", ctypes.c_int64), ("layout_bytes_per_sweep", ctypes.c_int64),
+                ("messages_per_sweep", ctypes.c_int64)]
+
+
+# every symbol include/bn_mi355x.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bn_create", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.POINTER(ctypes.c_void_p)]),
+    ("bn_destroy", None, [ctypes.c_void_p]),
+    ("bn_last_error", ctypes.c_char_p, []),
+    ("bn_version", ctypes.c_char_p, []),
+    ("bn_bp_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p, ctypes.c_double, ctypes.c_int32,
+                                 f64p, i32p, f64p]),
+    ("bn_bp_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p, ctypes.c_double,
+                                        ctypes.c_int32, i32p, f64p]),
+    ("bn_bp_beliefs_device", ctypes.c_void_p, [ctypes.c_void_p]),
+    ("bn_bp_copy_beliefs", ctypes.c_int, [ctypes.c_void_p, f64p]),
+    ("bn_bp_residual_history", ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int32]),
+    ("bn_bp_messages", ctypes.c_int, [ctypes.c_void_p, f64p, f64p]),
+    ("bn_bp_last_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(BpStats)]),
+    ("bn_lw_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, ctypes.c_uint64,
+                                 ctypes.c_uint64, f64p]),
+    ("bn_lw_states", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, u8p, f64p]),
+    ("bn_layout_get", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LayoutInfo)]),
+    ("bn_layout_node_slots", ctypes.c_int, [ctypes.c_void_p, i32p]),
+    ("bn_layout_class", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, i32p, i32p, i32p]),
+]
+
+
+def build(quiet: bool = True) -> str:
+    """Compile every HIP source for gfx950 into the in-tree shared library."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4", "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError = the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+class BnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"bn_mi355x error {code}: {msg}")
+        self.code = code
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise BnError(rc, lib().bn_last_error().decode("utf-8", "replace"))
+    return rc

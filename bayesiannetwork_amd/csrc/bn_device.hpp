@@ -1,0 +1,69 @@
+// bn_device.hpp -- structs shared by the host engine and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+#include "bn_plan.hpp"
+
+namespace bnmi {
+
+constexpr int kResSlots = 256;   // per-sweep residual slots (spread the atomics)
+constexpr int kResRows = 3;      // ring: row (s-1) is read, row s is accumulated, row (s+1) is zeroed
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
+
+// Device-resident control block of one BP run.
+struct Ctl {
+    int32_t done;       // 0 running, 1 converged (maximum_difference < eps), 2 stopped at max_sweeps
+    int32_t n_sweeps;   // iterations of the reference's while(true) loop that were executed
+    double last_res;    // maximum_difference of the last executed sweep
+};
+
+struct BpBuffers {
+    const TileDesc* tiles;
+    const ClassDesc* classes;
+    int32_t n_tiles;
+    const double* cpt;
+    double* rec[2];      // double-buffered message records
+    double* node[2];     // double-buffered pi / lambda node vectors
+    const OutRef* out_refs;
+    uint8_t* frozen;     // per lane-slot evidence marker (preconditional_node_, :69)
+    const int32_t* slot_node;
+    const int64_t* slot_boff;
+    const int32_t* node_tile;
+    const int32_t* node_nl;
+    unsigned long long* res_slots;  // [kResRows][kResSlots] bit patterns of non-negative doubles
+    double* res_hist;
+    int32_t res_cap;
+    Ctl* ctl;
+    double* beliefs;
+};
+
+struct SweepArgs {
+    BpBuffers b;
+    double eps;
+    int32_t sweep;       // 0-based index of this iteration
+};
+
+struct FinishArgs {
+    BpBuffers b;
+    double eps;
+    int32_t sweeps_launched;
+    int32_t final_batch;  // 1: max_sweeps reached with this batch -> stop even if not converged
+};
+
+struct EvidenceArgs {
+    BpBuffers b;
+    int32_t ne;
+    const int32_t* ev_node;
+    const int32_t* ev_off;
+    const double* ev_val;
+};
+
+// launchers (bn_kernels.hip)
+int launch_bp_init(const BpBuffers& b, int grid_blocks, void* stream);
+int launch_bp_evidence(const EvidenceArgs& a, void* stream);
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, void* stream);
+int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream);
+
+}  // namespace bnmi

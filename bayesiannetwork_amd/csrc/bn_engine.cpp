@@ -1,0 +1,416 @@
+// bn_engine.cpp -- C ABI (include/bn_mi355x.h) over the HIP kernels: device memory, the run
+// loop of belief propagation, diagnostics.  No CPU compute path exists here: every result
+// comes from the kernels in bn_kernels.hip / bn_lw_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bn_device.hpp"
+#include "bn_lw.hpp"
+
+using namespace bnmi;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(BN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+struct bn_engine {
+    Plan plan;
+    bool host_only = true;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    // device images
+    TileDesc* d_tiles = nullptr;
+    ClassDesc* d_classes = nullptr;
+    double* d_cpt = nullptr;
+    double* d_rec[2] = {nullptr, nullptr};
+    double* d_node[2] = {nullptr, nullptr};
+    OutRef* d_out = nullptr;
+    uint8_t* d_frozen = nullptr;
+    int32_t* d_slot_node = nullptr;
+    int64_t* d_slot_boff = nullptr;
+    int32_t* d_node_tile = nullptr;
+    int32_t* d_node_nl = nullptr;
+    unsigned long long* d_res_slots = nullptr;
+    double* d_res_hist = nullptr;
+    Ctl* d_ctl = nullptr;
+    double* d_beliefs = nullptr;
+    // evidence staging
+    int32_t* d_ev_node = nullptr;
+    int32_t* d_ev_off = nullptr;
+    double* d_ev_val = nullptr;
+    int32_t ev_cap = 0;
+    int64_t ev_val_cap = 0;
+    Ctl* h_ctl = nullptr;  // pinned
+    // run state
+    int32_t res_cap = 1 << 16;
+    int32_t predicted_sweeps = 0;
+    bool have_run = false;
+    Ctl last_ctl{};
+    bn_bp_stats stats{};
+    std::vector<hipEvent_t> events;  // [0]=start, [1]=end, then (begin,end) per sweep batch
+    int grid_tiles = 0;              // blocks for one-wave-per-tile kernels without remap
+    int grid_sweep = 0;              // same, padded to a multiple of 8 for the XCD mapping
+    LwState lw;
+};
+
+static void free_engine(bn_engine* e) {
+    if (!e) return;
+    if (!e->host_only) {
+        (void)hipSetDevice(e->device);
+        lw_free(e->lw);
+        void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
+                        e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
+                        e->d_res_slots, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev_node, e->d_ev_off,
+                        e->d_ev_val};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+        for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+}
+
+template <class T>
+static int upload(T** dst, const std::vector<T>& src, hipStream_t s) {
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return BN_OK;
+}
+
+template <class T>
+static int dalloc(T** dst, size_t count) {
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(count, 1) * sizeof(T)));
+    return BN_OK;
+}
+
+extern "C" const char* bn_last_error(void) { return g_err.c_str(); }
+extern "C" const char* bn_version(void) { return "bn_mi355x 0.1 (gfx950)"; }
+
+extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) {
+    if (!desc || !out) return fail(BN_ERR_ARG, "null argument");
+    *out = nullptr;
+    bn_engine* e = new (std::nothrow) bn_engine();
+    if (!e) return fail(BN_ERR_ALLOC, "out of host memory");
+    std::string err;
+    try {
+        err = build_plan(*desc, e->plan);
+    } catch (const std::bad_alloc&) {
+        delete e;
+        return fail(BN_ERR_ALLOC, "out of host memory while building the layout plan");
+    }
+    if (!err.empty()) {
+        delete e;
+        return fail(BN_ERR_ARG, err);
+    }
+    const Plan& p = e->plan;
+    e->grid_tiles = std::max(1, (int(p.tiles.size()) + kWavesPerBlock - 1) / kWavesPerBlock);
+    e->grid_sweep = (e->grid_tiles + 7) & ~7;
+    e->stats.algorithmic_bytes_per_sweep = p.algorithmic_bytes;
+    e->stats.layout_bytes_per_sweep = p.layout_bytes;
+    e->stats.messages_per_sweep = p.messages_per_sweep;
+    if (desc->device == BN_DEVICE_HOST_ONLY) {
+        *out = e;
+        return BN_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        delete e;
+        return fail(BN_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    }
+    e->host_only = false;
+    int rc = [&]() -> int {
+        if (desc->device >= 0) {
+            if (desc->device >= ndev) return fail(BN_ERR_ARG, "device ordinal out of range");
+            HIPCHK(hipSetDevice(desc->device));
+            e->device = desc->device;
+        } else {
+            HIPCHK(hipGetDevice(&e->device));
+        }
+        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        int r;
+        if ((r = upload(&e->d_tiles, p.tiles, e->stream))) return r;
+        if ((r = upload(&e->d_classes, p.classes, e->stream))) return r;
+        if ((r = upload(&e->d_cpt, p.cpt_striped, e->stream))) return r;
+        if ((r = upload(&e->d_out, p.out_refs, e->stream))) return r;
+        if ((r = upload(&e->d_slot_node, p.slot_node, e->stream))) return r;
+        if ((r = upload(&e->d_slot_boff, p.slot_boff, e->stream))) return r;
+        if ((r = upload(&e->d_node_tile, p.node_tile, e->stream))) return r;
+        if ((r = upload(&e->d_node_nl, p.node_nl, e->stream))) return r;
+        for (int i = 0; i < 2; ++i) {
+            if ((r = dalloc(&e->d_rec[i], size_t(p.rec_doubles)))) return r;
+            if ((r = dalloc(&e->d_node[i], size_t(p.node_doubles)))) return r;
+            HIPCHK(hipMemsetAsync(e->d_rec[i], 0, std::max<size_t>(p.rec_doubles, 1) * 8, e->stream));
+            HIPCHK(hipMemsetAsync(e->d_node[i], 0, std::max<size_t>(p.node_doubles, 1) * 8, e->stream));
+        }
+        if ((r = dalloc(&e->d_frozen, size_t(p.n_slots)))) return r;
+        if ((r = dalloc(&e->d_res_slots, size_t(kResRows * kResSlots)))) return r;
+        if ((r = dalloc(&e->d_res_hist, size_t(e->res_cap)))) return r;
+        if ((r = dalloc(&e->d_ctl, 1))) return r;
+        if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocDefault));
+        e->events.resize(2);
+        for (auto& ev : e->events) HIPCHK(hipEventCreate(&ev));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
+        return BN_OK;
+    }();
+    if (rc != BN_OK) {
+        std::string keep = g_err;
+        free_engine(e);
+        g_err = keep;
+        return rc;
+    }
+    *out = e;
+    return BN_OK;
+}
+
+extern "C" void bn_destroy(bn_engine* eng) { free_engine(eng); }
+
+static BpBuffers buffers_of(bn_engine* e) {
+    BpBuffers b;
+    b.tiles = e->d_tiles;
+    b.classes = e->d_classes;
+    b.n_tiles = int32_t(e->plan.tiles.size());
+    b.cpt = e->d_cpt;
+    b.rec[0] = e->d_rec[0]; b.rec[1] = e->d_rec[1];
+    b.node[0] = e->d_node[0]; b.node[1] = e->d_node[1];
+    b.out_refs = e->d_out;
+    b.frozen = e->d_frozen;
+    b.slot_node = e->d_slot_node;
+    b.slot_boff = e->d_slot_boff;
+    b.node_tile = e->d_node_tile;
+    b.node_nl = e->d_node_nl;
+    b.res_slots = e->d_res_slots;
+    b.res_hist = e->d_res_hist;
+    b.res_cap = e->res_cap;
+    b.ctl = e->d_ctl;
+    b.beliefs = e->d_beliefs;
+    return b;
+}
+
+static int check_evidence(const Plan& p, int32_t ne, const int32_t* ev_node, const int32_t* ev_off) {
+    if (ne < 0) return fail(BN_ERR_ARG, "negative evidence count");
+    if (ne == 0) return BN_OK;
+    if (!ev_node || !ev_off) return fail(BN_ERR_ARG, "null evidence array");
+    if (ev_off[0] != 0) return fail(BN_ERR_ARG, "ev_off[0] != 0");
+    std::vector<uint8_t> seen(p.n, 0);
+    for (int32_t j = 0; j < ne; ++j) {
+        int32_t v = ev_node[j];
+        if (v < 0 || v >= p.n) return fail(BN_ERR_ARG, "evidence node out of range");
+        if (seen[v]) return fail(BN_ERR_ARG, "evidence node listed twice");
+        seen[v] = 1;
+        if (ev_off[j + 1] - ev_off[j] != p.k[v])
+            return fail(BN_ERR_ARG, "evidence vector of node " + std::to_string(v) + " must have selectable_num entries");
+    }
+    return BN_OK;
+}
+
+static int ensure_events(bn_engine* e, size_t count) {
+    while (e->events.size() < count) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        e->events.push_back(ev);
+    }
+    return BN_OK;
+}
+
+extern "C" int bn_bp_run_device(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                                const double* ev_val, double eps, int32_t max_sweeps, int32_t* sweeps_out,
+                                double* residual_out) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    const Plan& p = e->plan;
+    int rc = check_evidence(p, ne, ev_node, ev_off);
+    if (rc) return rc;
+    if (ne > 0 && !ev_val) return fail(BN_ERR_ARG, "null ev_val");
+    if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    if (ne > e->ev_cap || (ne > 0 && ev_off[ne] > e->ev_val_cap)) {
+        if (e->d_ev_node) (void)hipFree(e->d_ev_node);
+        if (e->d_ev_off) (void)hipFree(e->d_ev_off);
+        if (e->d_ev_val) (void)hipFree(e->d_ev_val);
+        e->d_ev_node = e->d_ev_off = nullptr;
+        e->d_ev_val = nullptr;
+        e->ev_cap = std::max(ne, 64);
+        e->ev_val_cap = std::max<int64_t>(ev_off[ne], 256);
+        if ((rc = dalloc(&e->d_ev_node, size_t(e->ev_cap)))) return rc;
+        if ((rc = dalloc(&e->d_ev_off, size_t(e->ev_cap) + 1))) return rc;
+        if ((rc = dalloc(&e->d_ev_val, size_t(e->ev_val_cap)))) return rc;
+    }
+    BpBuffers b = buffers_of(e);
+    HIPCHK(hipEventRecord(e->events[0], s));
+    if (ne > 0) {
+        HIPCHK(hipMemcpyAsync(e->d_ev_node, ev_node, sizeof(int32_t) * ne, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(e->d_ev_off, ev_off, sizeof(int32_t) * (ne + 1), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(e->d_ev_val, ev_val, sizeof(double) * ev_off[ne], hipMemcpyHostToDevice, s));
+    }
+    if (launch_bp_init(b, e->grid_tiles, s)) return fail(BN_ERR_HIP, "bp_init launch failed");
+    EvidenceArgs ea{b, ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
+    if (launch_bp_evidence(ea, s)) return fail(BN_ERR_HIP, "bp_evidence launch failed");
+
+    int32_t launched = 0, batches = 0;
+    int32_t batch = e->predicted_sweeps > 0 ? e->predicted_sweeps : 8;
+    for (;;) {
+        if (max_sweeps > 0) batch = std::min(batch, max_sweeps - launched);
+        if ((rc = ensure_events(e, 2 + 2 * size_t(batches + 1)))) return rc;
+        HIPCHK(hipEventRecord(e->events[2 + 2 * batches], s));
+        for (int32_t i = 0; i < batch; ++i) {
+            SweepArgs sa{b, eps, launched + i};
+            if (launch_bp_sweep(sa, e->grid_sweep, s)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
+        }
+        launched += batch;
+        HIPCHK(hipEventRecord(e->events[3 + 2 * batches], s));
+        ++batches;
+        FinishArgs fa{b, eps, launched, (max_sweeps > 0 && launched >= max_sweeps) ? 1 : 0};
+        if (launch_bp_finish(fa, e->grid_tiles, s)) return fail(BN_ERR_HIP, "bp_finish launch failed");
+        HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (e->h_ctl->done != 0) break;
+        batch = 8;
+    }
+    HIPCHK(hipEventRecord(e->events[1], s));
+    HIPCHK(hipEventSynchronize(e->events[1]));
+    e->last_ctl = *e->h_ctl;
+    e->have_run = true;
+    e->predicted_sweeps = e->last_ctl.n_sweeps;
+    float ms = 0.f, tot = 0.f;
+    for (int32_t i = 0; i < batches; ++i) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e->events[2 + 2 * i], e->events[3 + 2 * i]));
+        ms += t;
+    }
+    HIPCHK(hipEventElapsedTime(&tot, e->events[0], e->events[1]));
+    e->stats.sweeps = e->last_ctl.n_sweeps;
+    e->stats.sweep_launches = launched;
+    e->stats.sweep_kernel_ms = ms;
+    e->stats.total_ms = tot;
+    if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+    if (residual_out) *residual_out = e->last_ctl.last_res;
+    return BN_OK;
+}
+
+extern "C" const double* bn_bp_beliefs_device(bn_engine* e) { return (e && !e->host_only) ? e->d_beliefs : nullptr; }
+
+extern "C" int bn_bp_copy_beliefs(bn_engine* e, double* beliefs_out) {
+    if (!e || !beliefs_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run to copy from");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(beliefs_out, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n],
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BN_OK;
+}
+
+extern "C" int bn_bp_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                         const double* ev_val, double eps, int32_t max_sweeps, double* beliefs_out,
+                         int32_t* sweeps_out, double* residual_out) {
+    if (!beliefs_out) return fail(BN_ERR_ARG, "null beliefs_out");
+    int rc = bn_bp_run_device(e, ne, ev_node, ev_off, ev_val, eps, max_sweeps, sweeps_out, residual_out);
+    if (rc) return rc;
+    return bn_bp_copy_beliefs(e, beliefs_out);
+}
+
+extern "C" int bn_bp_residual_history(bn_engine* e, double* out, int32_t cap) {
+    if (!e || !out || cap < 0) return fail(BN_ERR_ARG, "bad argument");
+    if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
+    int32_t cnt = std::min({cap, e->last_ctl.n_sweeps, e->res_cap});
+    HIPCHK(hipSetDevice(e->device));
+    if (cnt > 0) HIPCHK(hipMemcpy(out, e->d_res_hist, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    return cnt;
+}
+
+extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_msg_out) {
+    if (!e || !pi_msg_out || !lambda_msg_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<double> rec(std::max<int64_t>(e->plan.rec_doubles, 1));
+    HIPCHK(hipMemcpy(rec.data(), e->d_rec[e->last_ctl.n_sweeps & 1], sizeof(double) * e->plan.rec_doubles,
+                     hipMemcpyDeviceToHost));
+    unstripe_messages(e->plan, rec, pi_msg_out, lambda_msg_out);
+    return BN_OK;
+}
+
+extern "C" int bn_bp_last_stats(bn_engine* e, bn_bp_stats* out) {
+    if (!e || !out) return fail(BN_ERR_ARG, "null argument");
+    *out = e->stats;
+    return BN_OK;
+}
+
+// ---- layout introspection ---------------------------------------------------------------------
+extern "C" int bn_layout_get(bn_engine* e, bn_layout_info* o) {
+    if (!e || !o) return fail(BN_ERR_ARG, "null argument");
+    const Plan& p = e->plan;
+    o->n_nodes = p.n;
+    o->n_edges = int32_t(p.E);
+    o->n_classes = int32_t(p.classes.size());
+    o->n_tiles = int32_t(p.tiles.size());
+    o->lanes_per_node_max = p.g_max;
+    o->cpt_doubles = p.cpt_doubles;
+    o->rec_doubles = p.rec_doubles;
+    o->node_doubles = p.node_doubles;
+    o->algorithmic_bytes_per_sweep = p.algorithmic_bytes;
+    o->layout_bytes_per_sweep = p.layout_bytes;
+    o->messages_per_sweep = p.messages_per_sweep;
+    return BN_OK;
+}
+
+extern "C" int bn_layout_node_slots(bn_engine* e, int32_t* slots_out) {
+    if (!e || !slots_out) return fail(BN_ERR_ARG, "null argument");
+    std::copy(e->plan.node_slot.begin(), e->plan.node_slot.end(), slots_out);
+    return BN_OK;
+}
+
+extern "C" int bn_layout_class(bn_engine* e, int32_t cls, int32_t* kv, int32_t* m, int32_t* lanes_per_node,
+                               int32_t* variant, int32_t* n_nodes) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (cls < 0 || cls >= int32_t(e->plan.classes.size())) return fail(BN_ERR_ARG, "class index out of range");
+    const ClassDesc& c = e->plan.classes[cls];
+    if (kv) *kv = c.kv;
+    if (m) *m = c.m;
+    if (lanes_per_node) *lanes_per_node = c.G;
+    if (variant) *variant = c.variant;
+    if (n_nodes) *n_nodes = c.n_nodes;
+    return BN_OK;
+}
+
+// ---- likelihood weighting -------------------------------------------------------------------------
+extern "C" int bn_lw_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+                         uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double* hist_out) {
+    if (!e || !hist_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad evidence arguments");
+    HIPCHK(hipSetDevice(e->device));
+    std::string err;
+    int rc = lw_run(e->lw, e->plan, e->stream, ne, ev_node, ev_state, sample_begin, n_samples, seed, hist_out, err);
+    if (rc) return fail(rc, err);
+    return BN_OK;
+}
+
+extern "C" int bn_lw_states(bn_engine* e, uint64_t n, uint8_t* states_out, double* weights_out) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->host_only) return fail(BN_ERR_STATE, "host-only engine");
+    HIPCHK(hipSetDevice(e->device));
+    std::string err;
+    int rc = lw_states(e->lw, e->plan, e->stream, n, states_out, weights_out, err);
+    if (rc) return fail(rc, err);
+    return BN_OK;
+}

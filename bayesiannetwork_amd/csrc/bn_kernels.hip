@@ -1,0 +1,573 @@
+// bn_kernels.hip -- hand-written gfx950 kernels for synchronous (Jacobi) loopy belief propagation.
+//
+// One launch = one iteration of the reference's while(true) loop
+// (bayesian/inference/belief_propagation.hpp:75-148): message phase (:78-88), node phase
+// (:91-101), residual (:105-131) and commit (:135-143, here a buffer swap) are fused into a
+// single pass in which every node's CPT is read exactly once.
+//
+// Work decomposition: one 64-lane wavefront per tile (bn_plan.hpp); lane = one node (G = 1).
+// A lane owns everything that is computed from its node's CPT and node vectors:
+//   child role  : pi(v)      = calculate_pi       (:174-200)
+//                 lambda-messages v -> each parent = calculate_lambda_k (:240-266)
+//   parent role : lambda(v)  = calculate_lambda   (:220-238)
+//                 pi-messages v -> each child     = calculate_pi_i     (:202-218)
+// All inputs come from the OLD buffers, all outputs go to the NEW buffers, exactly as the
+// reference reads pi_/lambda_/pi_i_/lambda_k_ and writes new_*.  Arithmetic is fp64 in the
+// reference's operation order; the file is compiled with -ffp-contract=off so the results are
+// bit-identical to the C restatement in oracle/bp_oracle.c.
+//
+// Convergence is decided on the device: sweep s accumulates max|new-old| over messages into a
+// ring of 256 slots (atomic umax on the bit pattern of a non-negative double); the prologue of
+// launch s+1 reduces them, and once maximum_difference < eps (:147) every later launch returns
+// at once, so the host may enqueue launches ahead without synchronising per sweep.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "bn_device.hpp"
+
+namespace bnmi {
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_umax(unsigned long long x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(x, off, 64);
+        x = o > x ? o : x;
+    }
+    return x;
+}
+
+// std::max(md, d) of libstdc++: (md < d) ? d : md -- a NaN d is dropped (:110-128)
+__device__ __forceinline__ double res_acc(double md, double d) { return (md < d) ? d : md; }
+
+template <int K>
+__device__ __forceinline__ void normalize_k(double (&t)[K]) {  // :298-311, no zero guard
+    double sum = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) sum += t[i];
+#pragma unroll
+    for (int i = 0; i < K; ++i) t[i] /= sum;
+}
+
+__host__ __device__ constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+
+// Reduce the previous sweep's residual slots; returns maximum_difference of sweep (s-1).
+__device__ __forceinline__ double previous_residual(const BpBuffers& b, int prev_sweep, int lane) {
+    const unsigned long long* row = b.res_slots + (prev_sweep % kResRows) * kResSlots;
+    unsigned long long m = 0;
+#pragma unroll
+    for (int q = 0; q < kResSlots / kWave; ++q) {
+        unsigned long long x = __hip_atomic_load(row + q * kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = x > m ? x : m;
+    }
+    m = wave_umax(m);
+    double r = __longlong_as_double((long long)m);
+    return r < DBL_MIN ? DBL_MIN : r;  // maximum_difference starts at numeric_limits<double>::min() (:105)
+}
+
+__device__ __forceinline__ void publish_residual(const BpBuffers& b, int sweep, int slot, double wres, int lane) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(wres);
+    bits = wave_umax(bits);
+    if (lane == 0 && bits != 0)
+        __hip_atomic_fetch_max(b.res_slots + (sweep % kResRows) * kResSlots + (slot & (kResSlots - 1)), bits,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// parent role for any shape: lambda(v) and the pi-messages to the children, reading the
+// children's records through the out-edge references.  Used by the generic path and by the
+// register path when a tile has more children per node than it keeps in registers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rd_rec(const double* rec, OutRef r, int chunk, int i) {
+    return rec[(int64_t(r.rec) + int64_t(chunk + (i >> 1)) * r.stride) * 2 + (i & 1)];
+}
+__device__ __forceinline__ void wr_rec(double* rec, OutRef r, int chunk, int i, double x) {
+    rec[(int64_t(r.rec) + int64_t(chunk + (i >> 1)) * r.stride) * 2 + (i & 1)] = x;
+}
+
+__device__ double parent_role_generic(const BpBuffers& b, int cur, const TileDesc& td, int kv, int kvp, int npt,
+                                      int nl, bool writer, bool frozen) {
+    const double* rec_in = b.rec[cur];
+    double* rec_out = b.rec[cur ^ 1];
+    const double* node_in = b.node[cur] + td.node_base;
+    double* node_out = b.node[cur ^ 1] + td.node_base;
+    const OutRef* orf = b.out_refs + td.out_base + nl;
+    const int half = kvp >> 1;
+    double wres = 0.0;
+    auto nidx = [&](int part, int i) { return int64_t(part * half + (i >> 1)) * (npt * 2) + nl * 2 + (i & 1); };
+    // lambda(v): product of the children's lambda-messages from 1.0, ascending child order (:229-235)
+    if (writer) {
+        if (frozen) {
+            for (int i = 0; i < kv; ++i) node_out[nidx(1, i)] = node_in[nidx(1, i)];
+        } else {
+            double sum = 0;
+            for (int i = 0; i < kv; ++i) {
+                double acc = 1.0;
+                for (int c = 0; c < td.cmax; ++c) {
+                    OutRef r = orf[int64_t(c) * npt];
+                    if (r.rec >= 0) acc *= rd_rec(rec_in, r, half, i);
+                }
+                node_out[nidx(1, i)] = acc;
+                sum += acc;
+            }
+            for (int i = 0; i < kv; ++i) node_out[nidx(1, i)] = node_out[nidx(1, i)] / sum;
+        }
+        // pi-message to child c: pi(v) times the OTHER children's lambda-messages (:207-214)
+        for (int c = 0; c < td.cmax; ++c) {
+            OutRef rc = orf[int64_t(c) * npt];
+            if (rc.rec < 0) continue;
+            double sum = 0;
+            for (int i = 0; i < kv; ++i) {
+                double acc = node_in[nidx(0, i)];
+                for (int x = 0; x < td.cmax; ++x) {
+                    if (x == c) continue;
+                    OutRef rx = orf[int64_t(x) * npt];
+                    if (rx.rec >= 0) acc *= rd_rec(rec_in, rx, half, i);
+                }
+                wr_rec(rec_out, rc, 0, i, acc);
+                sum += acc;
+            }
+            for (int i = 0; i < kv; ++i) {
+                double nv = rd_rec(rec_out, rc, 0, i) / sum;
+                wr_rec(rec_out, rc, 0, i, nv);
+                wres = res_acc(wres, fabs(nv - rd_rec(rec_in, rc, 0, i)));
+            }
+        }
+    }
+    return wres;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic tile: any arities, runtime loops, one lane per node, operands re-read through L1.
+// Correctness path for shapes without a register-resident instantiation.
+// ---------------------------------------------------------------------------------------------
+__device__ double tile_generic(const BpBuffers& b, int cur, const TileDesc& td, const ClassDesc& c, int lane) {
+    const bool active = lane < td.n_nodes;
+    double wres = 0.0;
+    if (!active) return wres;
+    const double* cpt = b.cpt + td.cpt_base + lane * 2;
+    const double* rec_in = b.rec[cur] + td.rec_base + lane * 2;
+    double* rec_out = b.rec[cur ^ 1] + td.rec_base + lane * 2;
+    const double* node_in = b.node[cur] + td.node_base + lane * 2;
+    double* node_out = b.node[cur ^ 1] + td.node_base + lane * 2;
+    const bool frozen = b.frozen[td.slot_base + lane] != 0;
+    const int kv = c.kv, m = c.m, rows = c.rows, hv = c.kvp >> 1;
+    auto CPT = [&](int q) { return cpt[int64_t(q >> 1) * 128 + (q & 1)]; };
+    auto PIM = [&](int j, int s) { return rec_in[c.rec_off[j] + int64_t(s >> 1) * 128 + (s & 1)]; };
+    auto LKIDX = [&](int j, int s) { return c.rec_off[j] + int64_t((c.kpp[j] >> 1) + (s >> 1)) * 128 + (s & 1); };
+    auto NIDX = [&](int part, int i) { return int64_t(part * hv + (i >> 1)) * 128 + (i & 1); };
+
+    // pi(v) (:174-200): assignment ascending, value = cpt * pi-messages in ascending parent order
+    if (frozen) {
+        for (int i = 0; i < kv; ++i) node_out[NIDX(0, i)] = node_in[NIDX(0, i)];
+    } else {
+        double sum = 0;
+        for (int i = 0; i < kv; ++i) {
+            double acc = 0.0;
+            for (int cond = 0; cond < rows; ++cond) {
+                double value = CPT(i * rows + cond);
+                for (int j = 0; j < m; ++j) value *= PIM(j, (cond / c.cstride[j]) % c.kp[j]);
+                acc += value;
+            }
+            node_out[NIDX(0, i)] = acc;
+            sum += acc;
+        }
+        for (int i = 0; i < kv; ++i) node_out[NIDX(0, i)] = node_out[NIDX(0, i)] / sum;
+    }
+    // lambda-message to parent jt (:240-266): for each target state, child state outer and
+    // assignment inner -- the order in which the reference adds into matrix[0][cond.at(target)]
+    for (int jt = 0; jt < m; ++jt) {
+        const int kt = c.kp[jt];
+        double sum = 0;
+        for (int ct = 0; ct < kt; ++ct) {
+            double acc = 0.0;
+            for (int i = 0; i < kv; ++i) {
+                const double times = node_in[NIDX(1, i)];
+                for (int cond = 0; cond < rows; ++cond) {
+                    if ((cond / c.cstride[jt]) % kt != ct) continue;
+                    double value = times * CPT(i * rows + cond);
+                    for (int j = 0; j < m; ++j)
+                        if (j != jt) value *= PIM(j, (cond / c.cstride[j]) % c.kp[j]);
+                    acc += value;
+                }
+            }
+            rec_out[LKIDX(jt, ct)] = acc;
+            sum += acc;
+        }
+        for (int ct = 0; ct < kt; ++ct) {
+            double nv = rec_out[LKIDX(jt, ct)] / sum;
+            rec_out[LKIDX(jt, ct)] = nv;
+            wres = res_acc(wres, fabs(nv - rec_in[LKIDX(jt, ct)]));
+        }
+    }
+    wres = res_acc(wres, parent_role_generic(b, cur, td, kv, c.kvp, kWave, lane, true, frozen));
+    return wres;
+}
+
+// ---------------------------------------------------------------------------------------------
+// register-resident tile: node and parents share arity K, M parents, whole CPT (K^(M+1) <= 64
+// doubles) in VGPRs, every loop unrolled at compile time, 16-byte lane-striped loads.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRegChildren = 4;  // children per node kept in registers
+
+template <int K, int M>
+__device__ __forceinline__ double tile_uniform(const BpBuffers& b, int cur, const TileDesc& td, int lane) {
+    constexpr int KP = (K + 1) & ~1, H = KP / 2;
+    constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
+    const bool active = lane < td.n_nodes;
+
+    // ---- issue every load of the child role first: CPT, in-edge records, node vectors
+    const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
+    double cpt[SP];
+#pragma unroll
+    for (int q = 0; q < SP / 2; ++q) {
+        double2_t x = cp[q * kWave];
+        cpt[2 * q] = x.x;
+        cpt[2 * q + 1] = x.y;
+    }
+    const double2_t* rin = reinterpret_cast<const double2_t*>(b.rec[cur] + td.rec_base) + lane;
+    double2_t* rout = reinterpret_cast<double2_t*>(b.rec[cur ^ 1] + td.rec_base) + lane;
+    double pim[M > 0 ? M : 1][KP], lko[M > 0 ? M : 1][KP];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            double2_t x = rin[(j * 2 * H + h) * kWave], y = rin[(j * 2 * H + H + h) * kWave];
+            pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
+            lko[j][2 * h] = y.x; lko[j][2 * h + 1] = y.y;
+        }
+    const double2_t* nin = reinterpret_cast<const double2_t*>(b.node[cur] + td.node_base) + lane;
+    double2_t* nout = reinterpret_cast<double2_t*>(b.node[cur ^ 1] + td.node_base) + lane;
+    double piv[KP], lav[KP];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
+        piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
+        lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+    }
+    const bool frozen = b.frozen[td.slot_base + lane] != 0;
+
+    // ---- parent role loads: out-edge references and the children's records (gather)
+    const OutRef* orf = b.out_refs + td.out_base + lane;
+    const bool reg_children = td.cmax <= kRegChildren;
+    OutRef oref[kRegChildren];
+    double lkc[kRegChildren][KP], pio[kRegChildren][KP];
+    const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(b.rec[cur]);
+    double2_t* rec_out2 = reinterpret_cast<double2_t*>(b.rec[cur ^ 1]);
+#pragma unroll
+    for (int c = 0; c < kRegChildren; ++c) {
+        oref[c] = OutRef{-1, 0};
+        if (reg_children && c < td.cmax) oref[c] = orf[c * kWave];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) { lkc[c][i] = 1.0; pio[c][i] = 0.0; }  // x * 1.0 == x exactly
+        if (oref[c].rec >= 0) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double2_t x = rec_in2[oref[c].rec + int64_t(h) * oref[c].stride];
+                double2_t y = rec_in2[oref[c].rec + int64_t(H + h) * oref[c].stride];
+                pio[c][2 * h] = x.x; pio[c][2 * h + 1] = x.y;
+                lkc[c][2 * h] = y.x; lkc[c][2 * h + 1] = y.y;
+            }
+        }
+    }
+
+    double wres = 0.0;
+
+    // ---- pi(v), calculate_pi (:174-200)
+    double pin[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) pin[i] = 0.0;
+    {
+        double t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int cond = 0; cond < C; ++cond) {
+                double value = cpt[i * C + cond];
+#pragma unroll
+                for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                acc += value;
+            }
+            t[i] = acc;
+        }
+        normalize_k<K>(t);
+#pragma unroll
+        for (int i = 0; i < K; ++i) pin[i] = frozen ? piv[i] : t[i];
+    }
+
+    // ---- lambda-messages to the parents, calculate_lambda_k (:240-266)
+#pragma unroll
+    for (int jt = 0; jt < M; ++jt) {
+        double out[K];
+#pragma unroll
+        for (int ct = 0; ct < K; ++ct) out[ct] = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const double times = lav[i];
+#pragma unroll
+            for (int cond = 0; cond < C; ++cond) {
+                double value = times * cpt[i * C + cond];
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+                    if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                out[(cond / ipow(K, M - 1 - jt)) % K] += value;
+            }
+        }
+        normalize_k<K>(out);
+        double o[KP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) o[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            o[i] = out[i];
+            wres = res_acc(wres, fabs(out[i] - lko[jt][i]));
+        }
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double2_t y;
+                y.x = o[2 * h]; y.y = o[2 * h + 1];
+                rout[(jt * 2 * H + H + h) * kWave] = y;
+            }
+        }
+    }
+
+    // ---- parent role: lambda(v) (:220-238) and pi-messages to the children (:202-218)
+    double lan[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) lan[i] = 0.0;
+    if (reg_children) {
+        double t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double acc = 1.0;
+#pragma unroll
+            for (int c = 0; c < kRegChildren; ++c) acc *= lkc[c][i];
+            t[i] = acc;
+        }
+        normalize_k<K>(t);
+#pragma unroll
+        for (int i = 0; i < K; ++i) lan[i] = frozen ? lav[i] : t[i];
+#pragma unroll
+        for (int c = 0; c < kRegChildren; ++c) {
+            double u[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                double acc = piv[i];
+#pragma unroll
+                for (int x = 0; x < kRegChildren; ++x)
+                    if (x != c) acc *= lkc[x][i];
+                u[i] = acc;
+            }
+            normalize_k<K>(u);
+            if (oref[c].rec >= 0) {
+                double o[KP];
+#pragma unroll
+                for (int i = 0; i < KP; ++i) o[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    o[i] = u[i];
+                    wres = res_acc(wres, fabs(u[i] - pio[c][i]));
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    double2_t y;
+                    y.x = o[2 * h]; y.y = o[2 * h + 1];
+                    rec_out2[oref[c].rec + int64_t(h) * oref[c].stride] = y;
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double2_t y;
+                y.x = lan[2 * h]; y.y = lan[2 * h + 1];
+                nout[(H + h) * kWave] = y;
+            }
+        }
+    } else if (active) {
+        wres = res_acc(wres, parent_role_generic(b, cur, td, K, KP, kWave, lane, true, frozen));
+    }
+    if (active) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            double2_t y;
+            y.x = pin[2 * h]; y.y = pin[2 * h + 1];
+            nout[h * kWave] = y;
+        }
+    }
+    return active ? wres : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// Logical block index with an XCD-contiguous mapping: hardware block b runs on XCD b % 8
+// (observed, speed only), so logical chunk [x*nb/8, (x+1)*nb/8) of the tile list -- spatially
+// adjacent tiles that share message records -- stays inside one XCD's L2.  gridDim.x % 8 == 0.
+__device__ __forceinline__ int logical_block() {
+    const int nb = gridDim.x, b = blockIdx.x;
+    return (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+__global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a) {
+    const BpBuffers& b = a.b;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (__hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (a.sweep > 0) {
+        const double r = previous_residual(b, a.sweep - 1, lane);
+        if (lead && a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
+        if (r < a.eps) {  // strict '<' (:147): sweep (a.sweep-1) was the last one
+            if (lead) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
+            return;
+        }
+    }
+    if (blockIdx.x == 0 && wave == 0) {  // zero the ring row the NEXT sweep accumulates into
+        unsigned long long* row = b.res_slots + ((a.sweep + 1) % kResRows) * kResSlots;
+#pragma unroll
+        for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
+    }
+    const int tile = logical_block() * kWavesPerBlock + wave;
+    if (tile >= b.n_tiles) return;
+    const int cur = a.sweep & 1;
+    const TileDesc td = b.tiles[tile];
+    const ClassDesc& c = b.classes[td.cls];
+    double wres;
+    if (c.variant == kVariantUniform) {
+        switch (c.kv * 8 + c.m) {
+            case 2 * 8 + 0: wres = tile_uniform<2, 0>(b, cur, td, lane); break;
+            case 2 * 8 + 1: wres = tile_uniform<2, 1>(b, cur, td, lane); break;
+            case 2 * 8 + 2: wres = tile_uniform<2, 2>(b, cur, td, lane); break;
+            case 2 * 8 + 3: wres = tile_uniform<2, 3>(b, cur, td, lane); break;
+            case 2 * 8 + 4: wres = tile_uniform<2, 4>(b, cur, td, lane); break;
+            case 3 * 8 + 0: wres = tile_uniform<3, 0>(b, cur, td, lane); break;
+            case 3 * 8 + 1: wres = tile_uniform<3, 1>(b, cur, td, lane); break;
+            case 3 * 8 + 2: wres = tile_uniform<3, 2>(b, cur, td, lane); break;
+            case 4 * 8 + 0: wres = tile_uniform<4, 0>(b, cur, td, lane); break;
+            case 4 * 8 + 1: wres = tile_uniform<4, 1>(b, cur, td, lane); break;
+            case 4 * 8 + 2: wres = tile_uniform<4, 2>(b, cur, td, lane); break;
+            default: wres = tile_generic(b, cur, td, c, lane); break;
+        }
+    } else {
+        wres = tile_generic(b, cur, td, c, lane);
+    }
+    publish_residual(b, a.sweep, blockIdx.x * kWavesPerBlock + wave, wres, lane);
+}
+
+// Initial state, belief_propagation.hpp:33-65 : every message and node vector 1.0, roots take
+// their (un-normalised) CPT row as pi, nothing is frozen; also resets the run's control state.
+__global__ __launch_bounds__(kBlockThreads) void bp_init_kernel(BpBuffers b) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0) {
+        for (int q = threadIdx.x; q < kResRows * kResSlots; q += kBlockThreads) b.res_slots[q] = 0ull;
+        if (threadIdx.x == 0) { b.ctl->done = 0; b.ctl->n_sweeps = 0; b.ctl->last_res = 0.0; }
+    }
+    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= b.n_tiles) return;
+    const TileDesc td = b.tiles[tile];
+    const ClassDesc& c = b.classes[td.cls];
+    double* rec = b.rec[0] + td.rec_base;
+    for (int q = lane; q < c.rec_doubles; q += kWave) rec[q] = 1.0;
+    double* node = b.node[0] + td.node_base;
+    const int nd = 2 * c.kvp * c.npt;
+    for (int q = lane; q < nd; q += kWave) node[q] = 1.0;
+    for (int q = lane; q < c.npt; q += kWave) b.frozen[td.slot_base + q] = 0;
+    if (c.m == 0) {  // root: pi = cpt[{}] as stored (:58-64); G == 1 for roots
+        if (lane < td.n_nodes)
+            for (int i = 0; i < c.kv; ++i)
+                node[int64_t(i >> 1) * (c.npt * 2) + lane * 2 + (i & 1)] =
+                    b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + lane * 2 + (i & 1)];
+    }
+}
+
+// Evidence, belief_propagation.hpp:68-73: pi(v) = lambda(v) = the given vector, node marked.
+__global__ void bp_evidence_kernel(EvidenceArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.ne) return;
+    const BpBuffers& b = a.b;
+    const int v = a.ev_node[j];
+    const TileDesc td = b.tiles[b.node_tile[v]];
+    const ClassDesc& c = b.classes[td.cls];
+    const int nl = b.node_nl[v];
+    double* node = b.node[0] + td.node_base;
+    const int half = c.kvp >> 1;
+    for (int i = 0; i < c.kv; ++i) {
+        const double x = a.ev_val[a.ev_off[j] + i];
+        node[int64_t(i >> 1) * (c.npt * 2) + nl * 2 + (i & 1)] = x;
+        node[int64_t(half + (i >> 1)) * (c.npt * 2) + nl * 2 + (i & 1)] = x;
+    }
+    b.frozen[td.slot_base + nl] = 1;
+}
+
+// After a batch of sweeps: settle the last launched sweep's residual, and once the run is over
+// (converged, or max_sweeps reached) write belief = normalize(pi % lambda) (:151-158).
+__global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) {
+    const BpBuffers& b = a.b;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
+    int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int n_sweeps;
+    if (done != 0) {
+        n_sweeps = b.ctl->n_sweeps;
+    } else {
+        const double r = previous_residual(b, a.sweeps_launched - 1, lane);
+        if (lead && a.sweeps_launched - 1 < b.res_cap) b.res_hist[a.sweeps_launched - 1] = r;
+        n_sweeps = a.sweeps_launched;
+        if (r < a.eps) done = 1;
+        else if (a.final_batch) done = 2;
+        if (lead) { b.ctl->last_res = r; b.ctl->n_sweeps = n_sweeps; b.ctl->done = done; }
+    }
+    if (done == 0) return;
+    const int tile = blockIdx.x * kWavesPerBlock + wave;
+    if (tile >= b.n_tiles) return;
+    const TileDesc td = b.tiles[tile];
+    const ClassDesc& c = b.classes[td.cls];
+    if (lane >= td.n_nodes) return;  // one lane per node writes the belief
+    const double* node = b.node[n_sweeps & 1] + td.node_base;
+    const int64_t boff = b.slot_boff[td.slot_base + lane];
+    const int half = c.kvp >> 1;
+    double sum = 0;
+    for (int i = 0; i < c.kv; ++i) {
+        const double p = node[int64_t(i >> 1) * (c.npt * 2) + lane * 2 + (i & 1)];
+        const double l = node[int64_t(half + (i >> 1)) * (c.npt * 2) + lane * 2 + (i & 1)];
+        const double x = p * l;
+        b.beliefs[boff + i] = x;
+        sum += x;
+    }
+    for (int i = 0; i < c.kv; ++i) b.beliefs[boff + i] = b.beliefs[boff + i] / sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : int(e); }
+
+int launch_bp_init(const BpBuffers& b, int grid_blocks, void* stream) {
+    hipLaunchKernelGGL(bp_init_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, b);
+    return hip_rc(hipGetLastError());
+}
+int launch_bp_evidence(const EvidenceArgs& a, void* stream) {
+    if (a.ne <= 0) return 0;
+    hipLaunchKernelGGL(bp_evidence_kernel, dim3((a.ne + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return hip_rc(hipGetLastError());
+}
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, void* stream) {
+    hipLaunchKernelGGL(bp_sweep_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    return hip_rc(hipGetLastError());
+}
+int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream) {
+    hipLaunchKernelGGL(bp_finish_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    return hip_rc(hipGetLastError());
+}
+
+}  // namespace bnmi

@@ -1,0 +1,155 @@
+// bn_lw.cpp -- host driver of the likelihood-weighting kernel: topological order, device images,
+// batching, histogram read-back.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <queue>
+#include <vector>
+
+#include "bn_lw.hpp"
+
+namespace bnmi {
+
+#define LWCHK(expr)                                                            \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            return BN_ERR_HIP;                                                 \
+        }                                                                      \
+    } while (0)
+
+void lw_free(LwState& s) {
+    void* ptrs[] = {s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo,
+                    s.d_ev_state, s.d_states, s.d_weights, s.d_hist};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    s = LwState();
+}
+
+// Kahn's algorithm with a min-heap on node id: deterministic, and the identity permutation when
+// every parent precedes its children.  Any topological order samples the reference's
+// distribution (its own order is a DFS from the last vertex, likelihood_weighting.hpp:162-170).
+static bool topo_order(const Plan& p, std::vector<int32_t>& topo) {
+    const int32_t n = p.n;
+    std::vector<int32_t> indeg(n), out_ptr(n + 1, 0), out_idx(std::max<int64_t>(p.E, 1));
+    for (int32_t v = 0; v < n; ++v) indeg[v] = p.in_ptr[v + 1] - p.in_ptr[v];
+    for (int64_t e = 0; e < p.E; ++e) out_ptr[p.in_idx[e] + 1]++;
+    for (int32_t v = 0; v < n; ++v) out_ptr[v + 1] += out_ptr[v];
+    std::vector<int32_t> fill(n, 0);
+    for (int32_t v = 0; v < n; ++v)
+        for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+            int32_t u = p.in_idx[e];
+            out_idx[out_ptr[u] + fill[u]++] = v;
+        }
+    std::priority_queue<int32_t, std::vector<int32_t>, std::greater<int32_t>> ready;
+    for (int32_t v = 0; v < n; ++v)
+        if (indeg[v] == 0) ready.push(v);
+    topo.clear();
+    topo.reserve(n);
+    while (!ready.empty()) {
+        int32_t v = ready.top();
+        ready.pop();
+        topo.push_back(v);
+        for (int32_t q = out_ptr[v]; q < out_ptr[v + 1]; ++q)
+            if (--indeg[out_idx[q]] == 0) ready.push(out_idx[q]);
+    }
+    return int32_t(topo.size()) == n;
+}
+
+template <class T>
+static int up(T** dst, const T* src, size_t count, hipStream_t st, std::string& err) {
+    LWCHK(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(count, 1) * sizeof(T)));
+    if (count) LWCHK(hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_samples, std::string& err) {
+    if (!s.ready) {
+        if (!topo_order(p, s.topo)) {
+            err = "the model has a directed cycle: likelihood weighting needs a DAG (graph.hpp:268-291)";
+            return BN_ERR_ARG;
+        }
+        int r;
+        if ((r = up(&s.d_k, p.k.data(), p.k.size(), st, err))) return r;
+        if ((r = up(&s.d_in_ptr, p.in_ptr.data(), p.in_ptr.size(), st, err))) return r;
+        if ((r = up(&s.d_in_idx, p.in_idx.data(), p.in_idx.size(), st, err))) return r;
+        if ((r = up(&s.d_cpt_off, p.cpt_off.data(), p.cpt_off.size(), st, err))) return r;
+        if ((r = up(&s.d_node_off, p.node_off.data(), p.node_off.size(), st, err))) return r;
+        if ((r = up(&s.d_cpt, p.cpt_flat.data(), p.cpt_flat.size(), st, err))) return r;
+        if ((r = up(&s.d_topo, s.topo.data(), s.topo.size(), st, err))) return r;
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_state), std::max<size_t>(p.n, 1) * sizeof(int32_t)));
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double)));
+        s.ready = true;
+    }
+    // batch: enough blocks to fill the chip, bounded so the state matrix stays <= ~8 GiB
+    uint64_t cap = (uint64_t(8) << 30) / std::max<uint64_t>(p.n, 1);
+    cap = std::max<uint64_t>(kLwBlockSamples, cap / kLwBlockSamples * kLwBlockSamples);
+    uint64_t want = (want_samples + kLwBlockSamples - 1) / kLwBlockSamples * kLwBlockSamples;
+    uint64_t batch = std::min<uint64_t>({want, cap, uint64_t(2048) * kLwBlockSamples});
+    batch = std::max<uint64_t>(batch, kLwBlockSamples);
+    if (batch > s.batch) {
+        if (s.d_states) (void)hipFree(s.d_states);
+        if (s.d_weights) (void)hipFree(s.d_weights);
+        s.d_states = nullptr;
+        s.d_weights = nullptr;
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), std::max<uint64_t>(uint64_t(p.n) * batch, 1)));
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_weights), batch * sizeof(double)));
+        s.batch = batch;
+    }
+    return 0;
+}
+
+int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+           uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double* hist_out, std::string& err) {
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> evs(std::max(p.n, 1), -1);
+    for (int32_t j = 0; j < ne; ++j) {
+        int32_t v = ev_node[j];
+        if (v < 0 || v >= p.n) { err = "evidence node out of range"; return BN_ERR_ARG; }
+        // the reference would throw std::out_of_range from .at() (likelihood_weighting.hpp:151)
+        if (ev_state[j] < 0 || ev_state[j] >= p.k[v]) { err = "evidence state out of range"; return BN_ERR_ARG; }
+        if (evs[v] >= 0) { err = "evidence node listed twice"; return BN_ERR_ARG; }
+        evs[v] = ev_state[j];
+    }
+    int r = lw_prepare(s, p, st, n_samples, err);
+    if (r) return r;
+    const size_t hist_n = size_t(p.node_off[p.n]);
+    LWCHK(hipMemcpyAsync(s.d_ev_state, evs.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
+    LWCHK(hipMemsetAsync(s.d_hist, 0, std::max<size_t>(hist_n, 1) * sizeof(double), st));
+    uint64_t done = 0;
+    while (done < n_samples) {
+        const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
+        LwArgs a{p.n, s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo, s.d_ev_state,
+                 s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed};
+        const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
+        if (launch_lw(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
+        s.last_batch_samples = cnt;
+        done += cnt;
+    }
+    LWCHK(hipMemcpyAsync(hist_out, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LWCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int lw_states(LwState& s, const Plan& p, void* stream, uint64_t n, uint8_t* states_out, double* weights_out,
+              std::string& err) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!s.ready || s.last_batch_samples == 0) { err = "no likelihood-weighting run yet"; return BN_ERR_STATE; }
+    if (n > s.last_batch_samples) { err = "more samples requested than the last batch holds"; return BN_ERR_ARG; }
+    if (states_out) {
+        std::vector<uint8_t> col(n);
+        for (int32_t v = 0; v < p.n; ++v) {  // diagnostic path: one strided copy per node
+            LWCHK(hipMemcpyAsync(col.data(), s.d_states + uint64_t(v) * s.batch, n, hipMemcpyDeviceToHost, st));
+            LWCHK(hipStreamSynchronize(st));
+            for (uint64_t i = 0; i < n; ++i) states_out[i * uint64_t(p.n) + v] = col[i];
+        }
+    }
+    if (weights_out) {
+        LWCHK(hipMemcpyAsync(weights_out, s.d_weights, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        LWCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+}  // namespace bnmi

@@ -1,0 +1,61 @@
+// bn_lw.hpp -- likelihood weighting on the GPU (reference: bayesian/inference/likelihood_weighting.hpp).
+#pragma once
+
+#include <cstdint>
+#include <string>
+
+#include "bn_plan.hpp"
+
+namespace bnmi {
+
+constexpr int kLwThreads = 256;      // threads per block
+constexpr int kLwPerThread = 4;      // samples per thread
+constexpr int kLwBlockSamples = kLwThreads * kLwPerThread;
+constexpr int kLwLdsDoubles = 4096;  // CPTs up to this size are staged in LDS (32 KiB)
+
+struct LwState {
+    bool ready = false;
+    int32_t* d_k = nullptr;
+    int32_t* d_in_ptr = nullptr;
+    int32_t* d_in_idx = nullptr;
+    int64_t* d_cpt_off = nullptr;
+    int64_t* d_node_off = nullptr;
+    double* d_cpt = nullptr;       // flat, reference row order (row lookup = k contiguous doubles)
+    int32_t* d_topo = nullptr;
+    int32_t* d_ev_state = nullptr; // [n] clamped state or -1
+    uint8_t* d_states = nullptr;   // [n][batch] sampled states of the current batch
+    double* d_weights = nullptr;   // [batch]
+    double* d_hist = nullptr;      // [sum k]
+    uint64_t batch = 0;            // samples per launch (multiple of kLwBlockSamples)
+    uint64_t last_batch_samples = 0;
+    std::vector<int32_t> topo;
+};
+
+struct LwArgs {
+    int32_t n;
+    const int32_t* k;
+    const int32_t* in_ptr;
+    const int32_t* in_idx;
+    const int64_t* cpt_off;
+    const int64_t* node_off;
+    const double* cpt;
+    const int32_t* topo;
+    const int32_t* ev_state;
+    uint8_t* states;
+    double* weights;
+    double* hist;
+    uint64_t batch;        // row stride of `states`
+    uint64_t sample_base;  // global index of the batch's sample 0
+    uint64_t n_valid;      // samples of this batch that count
+    uint64_t seed;
+};
+
+int launch_lw(const LwArgs& a, int blocks, void* stream);
+
+void lw_free(LwState& s);
+int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+           uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double* hist_out, std::string& err);
+int lw_states(LwState& s, const Plan& p, void* stream, uint64_t n, uint8_t* states_out, double* weights_out,
+              std::string& err);
+
+}  // namespace bnmi

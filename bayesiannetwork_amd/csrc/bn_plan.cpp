@@ -1,0 +1,244 @@
+// bn_plan.cpp -- builds the lane-striped HBM layout from a flat model (host only, no HIP).
+#include "bn_plan.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+namespace bnmi {
+
+static inline int32_t round_even(int32_t x) { return (x + 1) & ~1; }
+
+// Lanes per node for a uniform-arity class.  One lane keeps <= 64 CPT entries in flight where
+// the parent-assignment count allows an even split: k=4: m<=2 -> 1, m=3 -> 4, m=4 -> 16.
+static int pick_lanes(int kv, int m, int64_t rows, int forced) {
+    (void)kv; (void)m; (void)rows; (void)forced;
+    return 1;  // sub-wave groups (G = 4, 16) are not wired into the kernels yet
+}
+
+std::string build_plan(const bn_model_desc& d, Plan& p) {
+    const int32_t n = d.n_nodes;
+    if (n < 0) return "n_nodes < 0";
+    if (n > 0 && (!d.k || !d.in_ptr || !d.cpt_off)) return "null model array";
+    p = Plan();
+    p.n = n;
+    p.k.assign(d.k, d.k + n);
+    p.in_ptr.assign(d.in_ptr, d.in_ptr + n + (n >= 0 ? 1 : 0));
+    if (n == 0 && !d.in_ptr) p.in_ptr.assign(1, 0);
+    if (p.in_ptr[0] != 0) return "in_ptr[0] != 0";
+    for (int32_t v = 0; v < n; ++v) {
+        if (p.k[v] < 1 || p.k[v] > 255) return "selectable_num of node " + std::to_string(v) + " outside [1,255]";
+        int32_t m = p.in_ptr[v + 1] - p.in_ptr[v];
+        if (m < 0) return "in_ptr decreases at node " + std::to_string(v);
+        if (m > BN_MAX_PARENTS)
+            return "node " + std::to_string(v) + " has " + std::to_string(m) + " parents (max " +
+                   std::to_string(BN_MAX_PARENTS) + ")";
+    }
+    p.E = p.in_ptr[n];
+    if (p.E > 0 && !d.in_idx) return "null in_idx";
+    p.in_idx.assign(d.in_idx, d.in_idx + p.E);
+    p.node_off.assign(n + 1, 0);
+    for (int32_t v = 0; v < n; ++v) p.node_off[v + 1] = p.node_off[v] + p.k[v];
+    for (int32_t v = 0; v < n; ++v) {
+        int64_t sz = p.k[v];
+        for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+            int32_t u = p.in_idx[e];
+            if (u < 0 || u >= n) return "parent index out of range at node " + std::to_string(v);
+            if (u == v) return "node " + std::to_string(v) + " is its own parent";
+            if (e > p.in_ptr[v] && p.in_idx[e - 1] >= u)
+                return "parents of node " + std::to_string(v) + " are not strictly ascending";
+            sz *= p.k[u];
+            if (sz > (int64_t(1) << 26)) return "CPT of node " + std::to_string(v) + " exceeds 2^26 entries";
+        }
+        // the reference would hit a missing row (UB, graph.hpp:120-124); here it is an error
+        if (d.cpt_off[v + 1] - d.cpt_off[v] != sz)
+            return "cpt_off of node " + std::to_string(v) + " does not match k * prod k[parents]";
+    }
+    if (n > 0 && d.cpt_off[0] != 0) return "cpt_off[0] != 0";
+    if (n > 0 && d.cpt_off[n] > 0 && !d.cpt) return "null cpt";
+    p.msg_off.assign(p.E + 1, 0);
+    for (int64_t e = 0; e < p.E; ++e) p.msg_off[e + 1] = p.msg_off[e] + p.k[p.in_idx[e]];
+
+    // ---- children (ascending) with the CSR edge id of each out-edge
+    std::vector<int32_t> out_ptr(n + 1, 0), out_edge(std::max<int64_t>(p.E, 1));
+    for (int64_t e = 0; e < p.E; ++e) out_ptr[p.in_idx[e] + 1]++;
+    for (int32_t v = 0; v < n; ++v) out_ptr[v + 1] += out_ptr[v];
+    {
+        std::vector<int32_t> fill(n, 0);
+        for (int32_t v = 0; v < n; ++v)
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+                int32_t u = p.in_idx[e];
+                out_edge[out_ptr[u] + fill[u]++] = e;
+            }
+    }
+
+    // ---- shape classes
+    std::map<std::vector<int32_t>, int32_t> sig2cls;
+    p.node_class.assign(n, -1);
+    std::vector<int32_t> sig;
+    for (int32_t v = 0; v < n; ++v) {
+        sig.clear();
+        sig.push_back(p.k[v]);
+        for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) sig.push_back(p.k[p.in_idx[e]]);
+        auto it = sig2cls.find(sig);
+        if (it == sig2cls.end()) {
+            ClassDesc c;
+            std::memset(&c, 0, sizeof c);
+            c.kv = sig[0];
+            c.m = int32_t(sig.size()) - 1;
+            c.kvp = round_even(c.kv);
+            int64_t rows = 1;
+            bool uniform = (c.kv >= 2 && c.kv <= 4 && c.m <= 4);
+            for (int j = 0; j < c.m; ++j) {
+                c.kp[j] = sig[1 + j];
+                c.kpp[j] = round_even(c.kp[j]);
+                rows *= c.kp[j];
+                if (c.kp[j] != c.kv) uniform = false;
+            }
+            for (int j = c.m - 1, s = 1; j >= 0; --j) { c.cstride[j] = s; s *= c.kp[j]; }
+            c.rows = int32_t(rows);
+            if (int64_t(c.kv) * rows > 64) uniform = false;  // register-resident CPT: <= 64 entries
+            c.variant = uniform ? kVariantUniform : kVariantGeneric;
+            c.G = uniform ? pick_lanes(c.kv, c.m, rows, d.lanes_per_node) : 1;
+            c.npt = kWave / c.G;
+            c.per_lane = int32_t(int64_t(c.kv) * rows / c.G);
+            c.per_lane_pad = round_even(c.per_lane);
+            int32_t off = 0;
+            for (int j = 0; j < c.m; ++j) { c.rec_off[j] = off; off += 2 * c.kpp[j] * c.npt; }
+            c.rec_doubles = off;
+            it = sig2cls.emplace(sig, int32_t(p.classes.size())).first;
+            p.classes.push_back(c);
+        }
+        p.node_class[v] = it->second;
+        p.classes[it->second].n_nodes++;
+        p.g_max = std::max(p.g_max, p.classes[it->second].G);
+    }
+
+    // ---- tiles: per class, ascending node id, NPT nodes each; global order by first node id
+    struct ProtoTile { int32_t cls; std::vector<int32_t> nodes; };
+    std::vector<ProtoTile> proto;
+    {
+        std::vector<int32_t> open(p.classes.size(), -1);
+        for (int32_t v = 0; v < n; ++v) {
+            int32_t c = p.node_class[v];
+            if (open[c] < 0 || int32_t(proto[open[c]].nodes.size()) == p.classes[c].npt) {
+                open[c] = int32_t(proto.size());
+                proto.push_back({c, {}});
+                proto.back().nodes.reserve(p.classes[c].npt);
+            }
+            proto[open[c]].nodes.push_back(v);
+        }
+    }
+    // proto is already ordered by first node id (a tile is opened when its first node is met)
+    const int32_t nt = int32_t(proto.size());
+    p.tiles.assign(nt, TileDesc());
+    p.node_tile.assign(n, -1);
+    p.node_nl.assign(n, -1);
+    p.node_slot.assign(n, -1);
+    int64_t cpt_cur = 0, rec_cur = 0, node_cur = 0, out_cur = 0;
+    int32_t slot_cur = 0;
+    for (int32_t t = 0; t < nt; ++t) {
+        const ClassDesc& c = p.classes[proto[t].cls];
+        TileDesc& td = p.tiles[t];
+        std::memset(&td, 0, sizeof td);
+        td.cls = proto[t].cls;
+        td.n_nodes = int32_t(proto[t].nodes.size());
+        td.slot_base = slot_cur;
+        td.cpt_base = cpt_cur;
+        td.rec_base = rec_cur;
+        td.node_base = node_cur;
+        td.out_base = out_cur;
+        int32_t cmax = 0;
+        for (int32_t nl = 0; nl < td.n_nodes; ++nl) {
+            int32_t v = proto[t].nodes[nl];
+            p.node_tile[v] = t;
+            p.node_nl[v] = nl;
+            p.node_slot[v] = slot_cur + nl;
+            cmax = std::max(cmax, out_ptr[v + 1] - out_ptr[v]);
+        }
+        td.cmax = cmax;
+        cpt_cur += int64_t(c.per_lane_pad) * kWave;
+        rec_cur += c.rec_doubles;
+        node_cur += int64_t(2) * c.kvp * c.npt;
+        out_cur += int64_t(cmax) * c.npt;
+        slot_cur += c.npt;
+    }
+    if (cpt_cur / 2 > INT32_MAX || rec_cur / 2 > INT32_MAX) return "model too large for 32-bit record indices";
+    p.n_slots = slot_cur;
+    p.rec_doubles = rec_cur;
+    p.node_doubles = node_cur;
+    p.slot_node.assign(slot_cur, -1);
+    p.slot_boff.assign(slot_cur, -1);
+    for (int32_t v = 0; v < n; ++v) {
+        p.slot_node[p.node_slot[v]] = v;
+        p.slot_boff[p.node_slot[v]] = p.node_off[v];
+    }
+
+    // ---- CPT image: i-major per node, assignments split over the G lanes of the node
+    p.cpt_striped.assign(cpt_cur, 0.0);
+    p.cpt_doubles = cpt_cur;
+    p.cpt_off.assign(d.cpt_off, d.cpt_off + n + 1);
+    if (n == 0) p.cpt_off.assign(1, 0);
+    p.cpt_flat.assign(d.cpt, d.cpt + (n ? d.cpt_off[n] : 0));
+    for (int32_t v = 0; v < n; ++v) {
+        const ClassDesc& c = p.classes[p.node_class[v]];
+        const TileDesc& td = p.tiles[p.node_tile[v]];
+        const double* src = d.cpt + d.cpt_off[v];
+        const int32_t cpl = c.rows / c.G;  // assignments per lane
+        for (int g = 0; g < c.G; ++g) {
+            const int lane = p.node_nl[v] * c.G + g;
+            double* dst = p.cpt_striped.data() + td.cpt_base + lane * 2;
+            for (int32_t i = 0; i < c.kv; ++i)
+                for (int32_t cl = 0; cl < cpl; ++cl) {
+                    const int32_t q = i * cpl + cl;
+                    const int32_t cond = g * cpl + cl;
+                    dst[int64_t(q >> 1) * 128 + (q & 1)] = src[int64_t(cond) * c.kv + i];
+                }
+        }
+    }
+
+    // ---- where each CSR edge's record lives, and the parents' out-edge references
+    p.edge_rec.assign(std::max<int64_t>(p.E, 1), OutRef{-1, 0});
+    for (int32_t v = 0; v < n; ++v) {
+        const ClassDesc& c = p.classes[p.node_class[v]];
+        const TileDesc& td = p.tiles[p.node_tile[v]];
+        for (int32_t j = 0; j < c.m; ++j)
+            p.edge_rec[p.in_ptr[v] + j] = OutRef{int32_t((td.rec_base + c.rec_off[j]) / 2 + p.node_nl[v]), c.npt};
+    }
+    p.out_refs.assign(std::max<int64_t>(out_cur, 1), OutRef{-1, 0});
+    for (int32_t v = 0; v < n; ++v) {
+        const ClassDesc& c = p.classes[p.node_class[v]];
+        const TileDesc& td = p.tiles[p.node_tile[v]];
+        for (int32_t q = out_ptr[v]; q < out_ptr[v + 1]; ++q)
+            p.out_refs[td.out_base + int64_t(q - out_ptr[v]) * c.npt + p.node_nl[v]] = p.edge_rec[out_edge[q]];
+    }
+
+    // ---- metrics: algorithmic = CPT once + every vector read once, written once
+    int64_t vec = 0;
+    for (int64_t e = 0; e < p.E; ++e) vec += 2 * int64_t(p.k[p.in_idx[e]]);
+    for (int32_t v = 0; v < n; ++v) vec += 2 * int64_t(p.k[v]);
+    p.algorithmic_bytes = 8 * (n ? d.cpt_off[n] : 0) + 16 * vec;
+    p.messages_per_sweep = 2 * p.E;
+    // what the sweep kernel requests: CPT image, each record read by both endpoints and each half
+    // written once, node vectors read + written, out references, tile descriptors, frozen flags
+    p.layout_bytes = 8 * cpt_cur + 8 * (2 * rec_cur + rec_cur) + 8 * 2 * node_cur + 8 * out_cur +
+                     int64_t(sizeof(TileDesc)) * nt + slot_cur;
+    return "";
+}
+
+void unstripe_messages(const Plan& p, const std::vector<double>& rec, double* pi_msg, double* lambda_msg) {
+    for (int64_t e = 0; e < p.E; ++e) {
+        const OutRef r = p.edge_rec[e];
+        const int32_t ku = p.k[p.in_idx[e]];
+        const int32_t half = ((ku + 1) & ~1) / 2;  // chunks per message
+        for (int32_t i = 0; i < ku; ++i) {
+            const int64_t a = (int64_t(r.rec) + int64_t(i >> 1) * r.stride) * 2 + (i & 1);
+            const int64_t b = (int64_t(r.rec) + int64_t(half + (i >> 1)) * r.stride) * 2 + (i & 1);
+            pi_msg[p.msg_off[e] + i] = rec[a];
+            lambda_msg[p.msg_off[e] + i] = rec[b];
+        }
+    }
+}
+
+}  // namespace bnmi

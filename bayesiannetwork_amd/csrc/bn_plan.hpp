@@ -1,0 +1,115 @@
+// bn_plan.hpp -- host-side layout plan: how a flat model (bn_model_desc) is laid out in HBM.
+//
+// The reference keeps a CPT as unordered_map<condition_t, vector<double>> (graph.hpp:57-154)
+// and BP state in eight hash maps (belief_propagation.hpp:320-333).  Here everything is
+// lane-striped for 64-wide wavefronts so that every wave-level load is one contiguous run:
+//
+//   tile      = one wavefront's worth of nodes of ONE shape class (same k, same parent arities),
+//               NPT = 64 / G nodes, G = lanes cooperating on one node (1, 4 or 16)
+//   CPT       = per tile, i-major (own state slowest, parent assignment fastest) so that one
+//               streaming pass visits entries in the reference's accumulation order for both
+//               calculate_pi (:174-200) and calculate_lambda_k (:240-266); lane (node nl, part g)
+//               owns assignments [g*C/G, (g+1)*C/G); its q-th entry sits at
+//               cpt_base + (q/2)*128 + lane*2 + (q&1)      -> 16 B per lane, 1 KiB per wave load
+//   records   = per in-edge (child tile, parent slot j, node nl): the pi-message then the
+//               lambda-message of that edge, each Kp = roundup(k[parent], 2) doubles, striped as
+//               rec + chunk*(NPT*2) + nl*2 ; the child reads/writes them fully coalesced, the
+//               parent reaches them through a per-out-edge {index, stride} pair
+//   node vecs = pi(v) then lambda(v), striped the same way per tile
+//
+// All state that changes per sweep (records, node vectors) is double-buffered: a sweep reads
+// buffer A and writes buffer B (the reference's new_* maps, :328-333), then they swap.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/bn_mi355x.h"
+
+namespace bnmi {
+
+constexpr int kWave = 64;
+
+enum Variant : int32_t {
+    kVariantGeneric = 0,   // runtime loops, any shape, G = 1
+    kVariantUniform = 1,   // templated: node and all parents share k in {2,3,4}, m <= 4
+};
+
+// Device-visible shape class.  POD.
+struct ClassDesc {
+    int32_t kv;                      // own arity
+    int32_t m;                       // number of parents
+    int32_t kp[BN_MAX_PARENTS];      // parent arities (ascending parent id order)
+    int32_t kvp;                     // kv rounded up to even
+    int32_t kpp[BN_MAX_PARENTS];     // kp rounded up to even
+    int32_t rows;                    // C = prod kp
+    int32_t G;                       // lanes per node
+    int32_t npt;                     // nodes per tile = 64 / G
+    int32_t variant;
+    int32_t per_lane;                // CPT entries per lane = kv * rows / G
+    int32_t per_lane_pad;            // rounded up to even
+    int32_t rec_off[BN_MAX_PARENTS]; // doubles from the tile's rec_base to in-edge j's record
+    int32_t rec_doubles;             // per tile
+    int32_t cstride[BN_MAX_PARENTS]; // mixed-radix stride of parent j in the assignment index
+    int32_t n_nodes;
+    int32_t pad_;
+};
+
+// One wavefront of work.  POD, 64 bytes.
+struct TileDesc {
+    int32_t cls;
+    int32_t n_nodes;     // active nodes (<= npt)
+    int32_t cmax;        // max out-degree among the tile's nodes
+    int32_t slot_base;   // index of lane-slot 0 in per-slot arrays (frozen, lane_node, ...)
+    int64_t cpt_base;    // doubles
+    int64_t rec_base;    // doubles
+    int64_t node_base;   // doubles: pi at node_base, lambda at node_base + kvp*npt
+    int64_t out_base;    // int2 entries: out-edge c of node nl at out_base + c*npt + nl
+    int64_t pad_[2];
+};
+static_assert(sizeof(TileDesc) == 64, "TileDesc must stay 64 bytes");
+
+struct OutRef {
+    int32_t rec;     // double2 index of chunk 0 of the child's in-edge record; -1 = none
+    int32_t stride;  // double2 stride between chunks (= child's npt)
+};
+
+struct Plan {
+    // model (kept for un-striping / diagnostics)
+    int32_t n = 0;
+    int64_t E = 0;
+    std::vector<int32_t> k, in_ptr, in_idx;
+    std::vector<int64_t> node_off;   // [n+1] prefix of k
+    std::vector<int64_t> msg_off;    // [E+1] prefix of k[parent]
+    // classes / tiles
+    std::vector<ClassDesc> classes;
+    std::vector<TileDesc> tiles;
+    std::vector<int32_t> node_class; // [n]
+    std::vector<int32_t> node_slot;  // [n]   tile*64... see slot(): tiles[t].slot_base + nl
+    std::vector<int32_t> node_tile;  // [n]
+    std::vector<int32_t> node_nl;    // [n]
+    std::vector<int32_t> slot_node;  // [n_slots] node id or -1
+    std::vector<int64_t> slot_boff;  // [n_slots] node_off[node] or -1
+    int32_t n_slots = 0;
+    // per CSR edge: where its record lives
+    std::vector<OutRef> edge_rec;    // [E]
+    // device images
+    std::vector<double> cpt_striped;  // released after upload (cpt_doubles keeps the size)
+    int64_t cpt_doubles = 0;
+    std::vector<int64_t> cpt_off;     // [n+1] reference-order flat CPT (kept for likelihood weighting)
+    std::vector<double> cpt_flat;
+    std::vector<OutRef> out_refs;    // per tile [c][nl]
+    int64_t rec_doubles = 0, node_doubles = 0;
+    // metrics
+    int64_t algorithmic_bytes = 0, layout_bytes = 0, messages_per_sweep = 0;
+    int32_t g_max = 1;
+};
+
+// Builds the plan.  Returns empty string on success, else an error message (BN_ERR_ARG).
+std::string build_plan(const bn_model_desc& d, Plan& out);
+
+// Host un-striping of a record buffer into CSR edge order (diagnostics, bn_bp_messages).
+void unstripe_messages(const Plan& p, const std::vector<double>& rec, double* pi_msg, double* lambda_msg);
+
+}  // namespace bnmi

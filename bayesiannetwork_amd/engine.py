@@ -1,0 +1,186 @@
+"""Python host mirror of the reference's inference functors over the C ABI.
+
+``BeliefPropagation(model)(evidence, epsilon)`` mirrors
+``bn::inference::belief_propagation`` (reference ``bayesian/inference/belief_propagation.hpp:12-31``:
+constructed from the network, called with evidence and epsilon = 0.001, returns per-node 1 x k
+marginals); ``LikelihoodWeighting(model)(evidence, sample_num)`` mirrors
+``bn::inference::likelihood_weighting`` (``likelihood_weighting.hpp:13-59``, sample_num = 10000).
+All compute happens in the HIP library; numpy only marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .flat import Evidence, FlatModel
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+class Engine:
+    """One flattened network resident on one GPU (bn_create / bn_destroy)."""
+
+    def __init__(self, model: FlatModel, device: int = _lib.BN_DEVICE_CURRENT, lanes_per_node: int = 0):
+        self.model = model
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        d = _lib.ModelDesc(model.n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
+                           _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64),
+                           _p(model.cpt, ctypes.c_double), device, lanes_per_node)
+        _lib.check(L.bn_create(ctypes.byref(d), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().bn_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- belief propagation ------------------------------------------------------------
+    def bp_run(self, evidence: Evidence | None = None, eps: float = 0.001, max_sweeps: int = 0,
+               copy_beliefs: bool = True):
+        ev = evidence if evidence is not None else Evidence.none()
+        L = _lib.lib()
+        sweeps = ctypes.c_int32(0)
+        res = ctypes.c_double(0.0)
+        args = (self._h, ev.ne, _p(ev.node, ctypes.c_int32), _p(ev.off, ctypes.c_int32), _p(ev.val, ctypes.c_double),
+                float(eps), int(max_sweeps))
+        if copy_beliefs:
+            bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
+            _lib.check(L.bn_bp_run(*args, _p(bel, ctypes.c_double), ctypes.byref(sweeps), ctypes.byref(res)))
+        else:
+            bel = None
+            _lib.check(L.bn_bp_run_device(*args, ctypes.byref(sweeps), ctypes.byref(res)))
+        return {"beliefs": bel, "sweeps": sweeps.value, "residual": res.value}
+
+    def bp_beliefs(self) -> np.ndarray:
+        bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
+        _lib.check(_lib.lib().bn_bp_copy_beliefs(self._h, _p(bel, ctypes.c_double)))
+        return bel
+
+    def bp_residuals(self, cap: int = 65536) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.float64)
+        cnt = _lib.check(_lib.lib().bn_bp_residual_history(self._h, _p(out, ctypes.c_double), cap))
+        return out[:cnt].copy()
+
+    def bp_messages(self):
+        nm = int(self.model.k[self.model.in_idx].sum()) if self.model.n_edges else 0
+        pi, lam = np.zeros(max(nm, 1)), np.zeros(max(nm, 1))
+        _lib.check(_lib.lib().bn_bp_messages(self._h, _p(pi, ctypes.c_double), _p(lam, ctypes.c_double)))
+        return pi[:nm], lam[:nm]
+
+    def bp_stats(self) -> dict:
+        st = _lib.BpStats()
+        _lib.check(_lib.lib().bn_bp_last_stats(self._h, ctypes.byref(st)))
+        return {f: getattr(st, f) for f, _ in st._fields_}
+
+    # ---- likelihood weighting ----------------------------------------------------------
+    def lw_run(self, ev_state, n_samples: int, seed: int, sample_begin: int = 0) -> np.ndarray:
+        """Un-normalised weighted histogram [sum k] of samples [sample_begin, +n_samples)."""
+        ev_state = np.asarray(ev_state, dtype=np.int32)
+        nodes = np.ascontiguousarray(np.nonzero(ev_state >= 0)[0], dtype=np.int32)
+        states = np.ascontiguousarray(ev_state[nodes], dtype=np.int32)
+        hist = np.zeros(int(self.model.k.sum()), dtype=np.float64)
+        _lib.check(_lib.lib().bn_lw_run(self._h, nodes.size, _p(nodes, ctypes.c_int32), _p(states, ctypes.c_int32),
+                                        ctypes.c_uint64(sample_begin), ctypes.c_uint64(n_samples),
+                                        ctypes.c_uint64(seed), _p(hist, ctypes.c_double)))
+        return hist
+
+    def lw_states(self, n: int):
+        states = np.zeros((n, self.model.n), dtype=np.uint8)
+        weights = np.zeros(n, dtype=np.float64)
+        _lib.check(_lib.lib().bn_lw_states(self._h, ctypes.c_uint64(n), _p(states, ctypes.c_uint8),
+                                           _p(weights, ctypes.c_double)))
+        return states, weights
+
+    # ---- layout ------------------------------------------------------------------------
+    def layout(self) -> dict:
+        li = _lib.LayoutInfo()
+        _lib.check(_lib.lib().bn_layout_get(self._h, ctypes.byref(li)))
+        return {f: getattr(li, f) for f, _ in li._fields_}
+
+    def layout_classes(self):
+        out = []
+        for c in range(self.layout()["n_classes"]):
+            v = [ctypes.c_int32() for _ in range(5)]
+            _lib.check(_lib.lib().bn_layout_class(self._h, c, *[ctypes.byref(x) for x in v]))
+            out.append(dict(zip(["kv", "m", "lanes_per_node", "variant", "n_nodes"], [x.value for x in v])))
+        return out
+
+    def node_slots(self) -> np.ndarray:
+        s = np.zeros(max(self.model.n, 1), dtype=np.int32)
+        _lib.check(_lib.lib().bn_layout_node_slots(self._h, _p(s, ctypes.c_int32)))
+        return s[:self.model.n]
+
+
+def _split(model: FlatModel, flat: np.ndarray):
+    off = model.node_off
+    return [flat[off[v]:off[v + 1]] for v in range(model.n)]
+
+
+class BeliefPropagation:
+    """``bn::inference::belief_propagation``: ``bp = BeliefPropagation(model); marg = bp(evidence, 0.001)``.
+
+    Returns a list indexed by node (position in ``vertex_list()``) of 1 x k arrays, the python
+    spelling of ``unordered_map<vertex_type, matrix_type>`` (belief_propagation.hpp:14)."""
+
+    def __init__(self, model: FlatModel, device: int = _lib.BN_DEVICE_CURRENT):
+        self.engine = Engine(model, device)
+        self.model = model
+        self.last = None
+
+    def __call__(self, precondition=None, epsilon: float = 0.001):
+        if isinstance(precondition, (int, float)) and not isinstance(precondition, bool):
+            precondition, epsilon = None, float(precondition)  # the by-pass overload bp(epsilon), :24-28
+        if isinstance(precondition, dict):
+            precondition = Evidence.from_dict(self.model, precondition)
+        self.last = self.engine.bp_run(precondition, epsilon)
+        return _split(self.model, self.last["beliefs"])
+
+
+class LikelihoodWeighting:
+    """``bn::inference::likelihood_weighting``: ``lw = LikelihoodWeighting(model); marg = lw({node: state}, 10000)``."""
+
+    def __init__(self, model: FlatModel, device: int = _lib.BN_DEVICE_CURRENT, seed: int = 0x5EED):
+        self.engine = Engine(model, device)
+        self.model = model
+        self.seed = seed
+        self._next = 0
+
+    def __call__(self, evidence=None, sample_num: int = 10000):
+        ev_state = np.full(self.model.n, -1, dtype=np.int32)
+        for v, s in (evidence or {}).items():
+            ev_state[v] = s
+        hist = self.engine.lw_run(ev_state, sample_num, self.seed, self._next)
+        self._next += sample_num  # successive calls continue the stream like the reference's engine
+        return _split(self.model, normalize_histogram(self.model, hist))
+
+
+def normalize_histogram(model: FlatModel, hist: np.ndarray) -> np.ndarray:
+    """likelihood_weighting.hpp:197-221: divide by the sum; uniform when the sum < 1e-20."""
+    out = hist.astype(np.float64).copy()
+    off = model.node_off
+    for v in range(model.n):
+        h = out[off[v]:off[v + 1]]
+        s = 0.0
+        for x in h:
+            s += x
+        if s < 1.0e-20:
+            h[:] = 1.0 / h.size
+        else:
+            h /= s
+    return out

@@ -1,0 +1,137 @@
+/*
+ * bn_mi355x.h -- C ABI of the MI355X-native inference engine (libbn_mi355x.so).
+ *
+ * The reference (godai0519/BayesianNetwork) has no FFI layer: its boundary is the C++ class
+ * surface of bayesian/inference.  These entry points are what a binding underneath that
+ * surface needs, and each one names the reference interface it replaces.  The header-only
+ * C++14 drop-in classes that sit on top are in include/bayesian/inference/ (same names and
+ * signatures as the reference's); INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - Plain C types only; no exceptions cross the boundary.  Every int-returning function
+ *     returns BN_OK (0) or a negative bn_status; bn_last_error() gives the message of the
+ *     calling thread's last failure.
+ *   - The caller keeps ownership of every array it passes; the engine copies what it needs.
+ *   - An engine handle is NOT thread-safe (the reference's functors are not either:
+ *     belief_propagation.hpp:320-333 holds mutable scratch state).
+ *   - Node identity is the position in graph_t::vertex_list() (graph.hpp:214); parents are
+ *     ascending (graph.hpp:389-402); the CPT of a node is row-major with the first parent most
+ *     significant and the node's own state fastest (belief_propagation.hpp:269-295).
+ */
+#ifndef BN_MI355X_H
+#define BN_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bn_status {
+    BN_OK = 0,
+    BN_ERR_ARG = -1,        /* malformed model / evidence / argument            */
+    BN_ERR_HIP = -2,        /* a HIP runtime call failed                         */
+    BN_ERR_NO_DEVICE = -3,  /* no gfx950 device visible                          */
+    BN_ERR_ALLOC = -4,      /* host allocation failed                            */
+    BN_ERR_COMM = -5,       /* RCCL call failed / communicator not initialised   */
+    BN_ERR_STATE = -6       /* call not valid in the engine's current state      */
+} bn_status;
+
+#define BN_MAX_PARENTS 16
+#define BN_DEVICE_HOST_ONLY (-2) /* build the layout plan only; no HIP call is made */
+#define BN_DEVICE_CURRENT (-1)
+
+/*
+ * Flat model = graph_t + every vertex_t::cpt, flattened once.
+ * Replaces: graph_t const& taken by belief_propagation::belief_propagation
+ * (belief_propagation.hpp:16) and likelihood_weighting::likelihood_weighting
+ * (likelihood_weighting.hpp:20), plus cpt_t lookups (graph.hpp:117).
+ */
+typedef struct bn_model_desc {
+    int32_t n_nodes;
+    const int32_t *k;       /* [n]    vertex_t::selectable_num                         */
+    const int32_t *in_ptr;  /* [n+1]  CSR over parents                                 */
+    const int32_t *in_idx;  /* [E]    parents, strictly ascending per node             */
+    const int64_t *cpt_off; /* [n+1]  prefix sums of k[v] * prod k[parents]            */
+    const double *cpt;      /* flat CPTs, reference row order                          */
+    int32_t device;         /* HIP ordinal, BN_DEVICE_CURRENT or BN_DEVICE_HOST_ONLY   */
+    int32_t lanes_per_node; /* 0 = automatic; 1,4,16 force the sub-wave group width    */
+} bn_model_desc;
+
+typedef struct bn_engine bn_engine;
+
+/* Validate the model, build the device layout, upload it.  Replaces the functor constructors. */
+int bn_create(const bn_model_desc *desc, bn_engine **out);
+void bn_destroy(bn_engine *eng);
+const char *bn_last_error(void);
+const char *bn_version(void);
+
+/*
+ * Loopy belief propagation to convergence.
+ * Replaces: belief_propagation::operator()(precondition, epsilon) (belief_propagation.hpp:31-159).
+ *   ev_node[ne], ev_off[ne+1], ev_val[ev_off[ne]] : evidence vectors (1 x k[v] each, used as both
+ *       pi and lambda, :68-73); ne may be 0 (the by-pass overload, :24-28).
+ *   eps        : strict '<' on the maximum absolute message change (:147)
+ *   max_sweeps : 0 = unbounded like the reference
+ *   beliefs_out: [sum k] node-major, normalize(pi % lambda) (:151-158); host memory
+ *   sweeps_out / residual_out : iterations executed and the last maximum_difference (optional)
+ */
+int bn_bp_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_off,
+              const double *ev_val, double eps, int32_t max_sweeps, double *beliefs_out,
+              int32_t *sweeps_out, double *residual_out);
+
+/* Same, but the beliefs stay in device memory (bn_bp_beliefs_device); nothing is copied back
+ * except the sweep count and residual.  This is the HBM-resident path bench.py times. */
+int bn_bp_run_device(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_off,
+                     const double *ev_val, double eps, int32_t max_sweeps, int32_t *sweeps_out,
+                     double *residual_out);
+const double *bn_bp_beliefs_device(bn_engine *eng);
+int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
+
+/* Diagnostics of the last bn_bp_run*: per-sweep maximum_difference (returns the count written),
+ * and the final pi / lambda messages in CSR edge order (each sum_e k[parent(e)] doubles). */
+int bn_bp_residual_history(bn_engine *eng, double *out, int32_t cap);
+int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
+
+typedef struct bn_bp_stats {
+    int32_t sweeps;            /* iterations of the last run                                */
+    int32_t sweep_launches;    /* sweep kernels launched (>= sweeps; extras exit at once)    */
+    float sweep_kernel_ms;     /* HIP-event time over all sweep launches of the last run     */
+    float total_ms;            /* HIP-event time init -> beliefs of the last run             */
+    int64_t algorithmic_bytes_per_sweep; /* SURVEY.md 8(d) formula                           */
+    int64_t layout_bytes_per_sweep;      /* bytes the sweep kernel actually requests         */
+    int64_t messages_per_sweep;          /* 2E                                              */
+} bn_bp_stats;
+int bn_bp_last_stats(bn_engine *eng, bn_bp_stats *out);
+
+/*
+ * Likelihood weighting.
+ * Replaces: likelihood_weighting::operator()(evidence, sample_num) (likelihood_weighting.hpp:28-59).
+ * Returns the UN-normalised weighted histogram [sum k] (node-major) of samples
+ * [sample_begin, sample_begin + n_samples) so that several GPUs / calls can be summed; the
+ * caller applies the reference's normalise rule (:197-221).  The stream is Philox4x32-10 keyed
+ * by `seed` (the reference seeds an mt19937 from std::random_device, :224-244).
+ */
+int bn_lw_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
+              uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double *hist_out);
+/* Sampled states of the first `n` samples of the last bn_lw_run, sample-major [s][node]. */
+int bn_lw_states(bn_engine *eng, uint64_t n, uint8_t *states_out, double *weights_out);
+
+/* ---- layout introspection (host only; valid for BN_DEVICE_HOST_ONLY engines too) ---- */
+typedef struct bn_layout_info {
+    int32_t n_nodes, n_edges, n_classes, n_tiles;
+    int32_t lanes_per_node_max;
+    int64_t cpt_doubles, rec_doubles, node_doubles; /* striped device array sizes (one buffer) */
+    int64_t algorithmic_bytes_per_sweep, layout_bytes_per_sweep, messages_per_sweep;
+} bn_layout_info;
+int bn_layout_get(bn_engine *eng, bn_layout_info *out);
+/* node -> (tile*64 + first lane) slot, [n] */
+int bn_layout_node_slots(bn_engine *eng, int32_t *slots_out);
+/* per-class: kv, m, lanes_per_node, variant (0 = generic, 1 = register-resident template) */
+int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,
+                    int32_t *variant, int32_t *n_nodes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BN_MI355X_H */

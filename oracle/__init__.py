@@ -1,0 +1,160 @@
+"""Python bindings for the CPU checker -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
+package.  ``bp_run`` / ``lw_run`` call the plain-C restatement in ``liboracle.so``
+(``bp_oracle.c`` / ``lw_oracle.c``); ``ref_bp`` / ``ref_lw`` execute ``_ref/ref_driver``,
+the unmodified reference headers compiled where they lie (exists only in the container
+that has ``/root/reference``).
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+REF_DRIVER = os.path.join(_HERE, "_ref", "ref_driver")
+
+
+def build(quiet: bool = True) -> None:
+    """make liboracle.so (and _ref/ref_driver when /root/reference exists)."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        i32p, i64p, f64p = (ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64),
+                            ctypes.POINTER(ctypes.c_double))
+        L.oracle_bp_run_mt.restype = ctypes.c_int
+        L.oracle_bp_run_mt.argtypes = [ctypes.c_int, i32p, i32p, i32p, i64p, f64p, ctypes.c_int, i32p, i32p,
+                                       f64p, ctypes.c_double, ctypes.c_int, f64p, ctypes.POINTER(ctypes.c_int),
+                                       f64p, ctypes.c_int, f64p, ctypes.c_int]
+        L.oracle_lw_run.restype = ctypes.c_int
+        L.oracle_lw_run.argtypes = [ctypes.c_int, i32p, i32p, i32p, i64p, f64p, i32p, i32p, ctypes.c_uint64,
+                                    ctypes.c_uint64, ctypes.c_uint64, f64p, ctypes.POINTER(ctypes.c_uint8),
+                                    f64p, ctypes.c_uint64]
+        L.oracle_philox4x32_10.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def bp_run(model, evidence=None, eps: float = 0.001, max_sweeps: int = 0, threads: int = 1,
+           dump_msgs: bool = False, res_cap: int = 4096):
+    """Restated reference BP.  Returns dict(beliefs, sweeps, residuals[, pi_msg, lambda_msg])."""
+    from bayesiannetwork_amd.flat import Evidence
+    ev = evidence if evidence is not None else Evidence.none()
+    L = lib()
+    bel = np.zeros(int(model.k.sum()), dtype=np.float64)
+    res = np.zeros(res_cap, dtype=np.float64)
+    sweeps = ctypes.c_int(0)
+    nm = int(model.k[model.in_idx].sum()) if model.n_edges else 0
+    dump = np.zeros(2 * nm if dump_msgs else 1, dtype=np.float64)
+    rc = L.oracle_bp_run_mt(model.n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
+                            _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64),
+                            _p(model.cpt, ctypes.c_double), ev.ne, _p(ev.node, ctypes.c_int32),
+                            _p(ev.off, ctypes.c_int32), _p(ev.val, ctypes.c_double), float(eps),
+                            int(max_sweeps), _p(bel, ctypes.c_double), ctypes.byref(sweeps),
+                            _p(res, ctypes.c_double), res_cap,
+                            _p(dump, ctypes.c_double) if dump_msgs else None, int(threads))
+    if rc != 0:
+        raise RuntimeError(f"oracle_bp_run failed: {rc}")
+    out = {"beliefs": bel, "sweeps": sweeps.value, "residuals": res[:min(sweeps.value, res_cap)].copy()}
+    if dump_msgs:
+        out["pi_msg"], out["lambda_msg"] = dump[:nm].copy(), dump[nm:].copy()
+    return out
+
+
+def lw_run(model, ev_state, n_samples: int, seed: int, s_begin: int = 0, topo=None, states_cap: int = 0):
+    """Restated LW with the repository's Philox stream.  Returns dict(hist[, states, weights])."""
+    L = lib()
+    n = model.n
+    topo = np.arange(n, dtype=np.int32) if topo is None else np.ascontiguousarray(topo, dtype=np.int32)
+    ev_state = np.ascontiguousarray(ev_state, dtype=np.int32)
+    hist = np.zeros(int(model.k.sum()), dtype=np.float64)
+    states = np.zeros(max(1, states_cap * n), dtype=np.uint8)
+    weights = np.zeros(max(1, states_cap), dtype=np.float64)
+    rc = L.oracle_lw_run(n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
+                         _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64),
+                         _p(model.cpt, ctypes.c_double), _p(topo, ctypes.c_int32), _p(ev_state, ctypes.c_int32),
+                         ctypes.c_uint64(s_begin), ctypes.c_uint64(n_samples), ctypes.c_uint64(seed),
+                         _p(hist, ctypes.c_double), _p(states, ctypes.c_uint8), _p(weights, ctypes.c_double),
+                         ctypes.c_uint64(states_cap))
+    if rc != 0:
+        raise RuntimeError(f"oracle_lw_run failed: {rc}")
+    out = {"hist": hist}
+    if states_cap:
+        out["states"] = states[:states_cap * n].reshape(states_cap, n)
+        out["weights"] = weights[:states_cap]
+    return out
+
+
+def lw_normalize(model, hist):
+    """likelihood_weighting.hpp:197-221 applied per node."""
+    out = hist.astype(np.float64).copy()
+    off = model.node_off
+    for v in range(model.n):
+        h = out[off[v]:off[v + 1]]
+        s = 0.0
+        for x in h:
+            s += x
+        if s < 1.0e-20:
+            h[:] = 1.0 / h.size
+        else:
+            h /= s
+    return out
+
+
+def philox(ctr, key):
+    c = (ctypes.c_uint32 * 4)(*ctr)
+    k = (ctypes.c_uint32 * 2)(*key)
+    o = (ctypes.c_uint32 * 4)()
+    lib().oracle_philox4x32_10(c, k, o)
+    return list(o)
+
+
+# ---- the real reference (only where /root/reference exists) -------------------------
+
+def ref_available() -> bool:
+    return os.path.exists(REF_DRIVER)
+
+
+def _run_ref(text: str, timeout: float):
+    with tempfile.NamedTemporaryFile("w", suffix=".bnflat", delete=False) as f:
+        f.write(text)
+        path = f.name
+    try:
+        p = subprocess.run([REF_DRIVER, path], capture_output=True, text=True, timeout=timeout)
+    finally:
+        os.unlink(path)
+    if p.returncode != 0:
+        raise RuntimeError(f"ref_driver exit {p.returncode}: {p.stderr[-500:]}")
+    return json.loads(p.stdout)
+
+
+def ref_bp(model, evidence=None, eps: float = 0.001, dump_msgs: bool = False, timeout: float = 3600):
+    from bayesiannetwork_amd.flat import Evidence
+    ev = evidence if evidence is not None else Evidence.none()
+    text = model.to_bnflat_text() + f"bp {eps!r} {1 if dump_msgs else 0}\n" + ev.to_bnflat_text()
+    return _run_ref(text, timeout)
+
+
+def ref_lw(model, ev_state, n_samples: int, seed: int, timeout: float = 3600):
+    pairs = [(v, int(s)) for v, s in enumerate(ev_state) if s >= 0]
+    text = model.to_bnflat_text() + f"lw {n_samples} {seed}\n{len(pairs)}\n" + \
+        "".join(f"{v} {s}\n" for v, s in pairs)
+    return _run_ref(text, timeout)

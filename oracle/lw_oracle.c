@@ -1,0 +1,118 @@
+/*
+ * oracle/lw_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the reference's Likelihood Weighting sampler
+ * (bayesian/inference/likelihood_weighting.hpp) over the flat model of bp_oracle.c.
+ *
+ * What is restated exactly:
+ *   weighted_sample   :122-173  ancestral sampling, evidence nodes clamp and multiply
+ *                               the weight by their CPT entry
+ *   make_random_by_weight :177-193  first i with cum_{i-1} <= u < cum_i, else last state
+ *   accumulate        :33-50    hist[v][state_v] += w for every node of every sample
+ *   normalize         :197-221  divide by the sum; uniform when the sum < 1e-20
+ * What is NOT the reference's: the random stream.  The reference draws from an mt19937
+ * seeded by std::random_device (:224-244) -- non-deterministic by design, so no bitwise
+ * parity exists even reference-vs-reference.  This repository's sampler (oracle and HIP
+ * kernel alike) uses the counter-based Philox4x32-10 generator (Salmon et al., SC'11):
+ *   u(sample s, topological position t) = words [2(t&1), 2(t&1)+1] of
+ *       philox4x32_10(counter = {s_lo, s_hi, t>>1, 0}, key = {seed_lo, seed_hi})
+ *   u = ((hi<<32 | lo) >> 11) * 2^-53
+ * which makes sampled STATES bit-reproducible between this file and the HIP kernel.
+ * Parity with the reference itself is statistical (tests/golden holds the reference's
+ * 1e5-sample marginals under a reseeded mt19937 plus exact BP marginals on polytrees).
+ * Nodes are visited in ascending topological position `topo` (any topological order
+ * yields the reference's distribution; the reference's own order is a DFS from the
+ * last vertex, :162-170).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+/* Philox4x32-10, Random123 definition. */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0, p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static double uniform_at(uint64_t seed, uint64_t s, uint32_t t) {
+    uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), t >> 1, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t o[4];
+    oracle_philox4x32_10(ctr, key, o);
+    uint64_t x = ((uint64_t)o[2 * (t & 1) + 1] << 32) | o[2 * (t & 1)];
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* likelihood_weighting.hpp:177-193 */
+static int pick_state(double u, const double *w, int k) {
+    double total = 0.0;
+    for (int i = 0; i < k; ++i) {
+        double old_total = total;
+        total += w[i];
+        if (old_total <= u && u < total) return i;
+    }
+    return k - 1;
+}
+
+/*
+ * Draw samples [s_begin, s_begin + n_samples) and accumulate the UN-normalised weighted
+ * histogram into hist (sum_v k[v] doubles, node-major; must be zeroed by the caller).
+ * ev_state[v] = clamped state or -1.  topo[t] = node visited at position t.
+ * states_out (optional) receives the sampled states of the first states_cap samples,
+ * sample-major [s][v] as uint8.  weights_out (optional) the first states_cap weights.
+ */
+int oracle_lw_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t *in_idx,
+                  const int64_t *cpt_off, const double *cpt, const int32_t *topo,
+                  const int32_t *ev_state, uint64_t s_begin, uint64_t n_samples, uint64_t seed,
+                  double *hist, uint8_t *states_out, double *weights_out, uint64_t states_cap) {
+    int64_t *node_off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+    int32_t *state = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    if (!node_off || !state) { free(node_off); free(state); return -1; }
+    node_off[0] = 0;
+    for (int v = 0; v < n; ++v) node_off[v + 1] = node_off[v] + k[v];
+    for (uint64_t si = 0; si < n_samples; ++si) {
+        uint64_t s = s_begin + si;
+        double w = 1.0; /* :124 */
+        for (int t = 0; t < n; ++t) {
+            int v = topo[t];
+            int64_t row = 0; /* parent assignment -> CPT row, first parent most significant */
+            for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + state[in_idx[e]];
+            const double *r = cpt + cpt_off[v] + row * k[v];
+            if (ev_state[v] >= 0) { /* :148-153 */
+                w *= r[ev_state[v]];
+                state[v] = ev_state[v];
+            } else { /* :154-158 */
+                state[v] = pick_state(uniform_at(seed, s, (uint32_t)t), r, k[v]);
+            }
+        }
+        for (int v = 0; v < n; ++v) hist[node_off[v] + state[v]] += w; /* :45-49 */
+        if (si < states_cap) {
+            if (states_out) for (int v = 0; v < n; ++v) states_out[si * (uint64_t)n + v] = (uint8_t)state[v];
+            if (weights_out) weights_out[si] = w;
+        }
+    }
+    free(node_off); free(state);
+    return 0;
+}
+
+/* likelihood_weighting.hpp:197-221: normalise one node's histogram in place. */
+void oracle_lw_normalize(double *h, int k) {
+    double sum = 0;
+    for (int i = 0; i < k; ++i) sum += h[i];
+    if (sum < 1.0e-20) for (int i = 0; i < k; ++i) h[i] = 1.00 / k;
+    else for (int i = 0; i < k; ++i) h[i] /= sum;
+}

@@ -1,0 +1,67 @@
+"""The CPU restatement (oracle/bp_oracle.c) pinned against the reference's own outputs.
+
+tests/golden/*.npz were produced by the unmodified reference headers (oracle/ref_driver.cpp,
+tests/golden/make_golden.py).  With <= 2 parents the reference's arithmetic order is fully
+determined and the restatement must be BIT-IDENTICAL; with >= 3 parents the reference multiplies
+in unordered_map iteration order (belief_propagation.hpp:253), so agreement is to ~1e-13."""
+import numpy as np
+import pytest
+
+from helpers import golden_names, load_golden, max_parents, rel_err
+
+
+@pytest.mark.parametrize("name", golden_names("bp_"))
+def test_oracle_matches_reference(oracle_mod, name):
+    model, runs, _ = load_golden(name)
+    exact = max_parents(model) <= 2
+    for r in runs:
+        dump = "pi_msg" in r
+        o = oracle_mod.bp_run(model, r["evidence"], r["eps"], dump_msgs=dump)
+        assert o["sweeps"] == r["sweeps"]
+        if exact:
+            assert np.array_equal(o["beliefs"], r["beliefs"], equal_nan=True)
+            assert np.array_equal(o["residuals"], r["residuals"])
+            if dump:
+                assert np.array_equal(o["pi_msg"], r["pi_msg"], equal_nan=True)
+                assert np.array_equal(o["lambda_msg"], r["lambda_msg"], equal_nan=True)
+        else:
+            assert rel_err(o["beliefs"], r["beliefs"]) < 1e-12
+            assert np.allclose(o["residuals"], r["residuals"], rtol=1e-9, atol=1e-15)
+            if dump:
+                assert rel_err(o["pi_msg"], r["pi_msg"]) < 1e-12
+                assert rel_err(o["lambda_msg"], r["lambda_msg"]) < 1e-12
+
+
+def test_reference_teacher_vectors(oracle_mod):
+    """libs/bayesian/test/belief_propagation.cpp: BOOST_CHECK_CLOSE(value, teacher, pct)."""
+    model, runs, _ = load_golden("bp_pearl")
+    for r in runs[:2]:
+        o = oracle_mod.bp_run(model, r["evidence"], r["eps"])
+        t, pct = r["teacher"], float(r["teacher_pct"])
+        nz = t != 0
+        assert (np.abs(o["beliefs"][nz] - t[nz]) / np.abs(t[nz]) * 100 <= pct).all()
+        assert (np.abs(o["beliefs"][~nz]) < 1e-12).all()
+    model, runs, _ = load_golden("bp_resume_chain")
+    off = model.node_off
+    for r in runs:
+        o = oracle_mod.bp_run(model, r["evidence"], r["eps"])
+        q = int(r["query_node"])
+        got = o["beliefs"][off[q]:off[q + 1]]
+        assert (np.abs(got - r["teacher"]) / r["teacher"] * 100 <= float(r["teacher_pct"])).all()
+
+
+def test_oracle_multithread_identical(oracle_mod):
+    from bayesiannetwork_amd import synth
+    g = synth.grid(24, 24, 4, seed=5)
+    a = oracle_mod.bp_run(g, eps=1e-6, threads=1)
+    b = oracle_mod.bp_run(g, eps=1e-6, threads=4)
+    assert a["sweeps"] == b["sweeps"] and np.array_equal(a["beliefs"], b["beliefs"])
+    assert np.array_equal(a["residuals"], b["residuals"])
+
+
+def test_philox_known_answers(oracle_mod):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert oracle_mod.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert oracle_mod.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert oracle_mod.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
