@@ -24,8 +24,10 @@ struct BpBuffers {
     const ClassDesc* classes;
     int32_t n_tiles;
     const double* cpt;
-    double* rec[2];      // double-buffered message records
-    double* node[2];     // double-buffered pi / lambda node vectors
+    double* rec0;        // double-buffered message records (no arrays here: a dynamically indexed
+    double* rec1;        //   kernarg array forces the whole struct into scratch memory)
+    double* node0;       // double-buffered pi / lambda node vectors
+    double* node1;
     const OutRef* out_refs;
     uint8_t* frozen;     // per lane-slot evidence marker (preconditional_node_, :69)
     const int32_t* slot_node;
@@ -41,8 +43,13 @@ struct BpBuffers {
 
 struct SweepArgs {
     BpBuffers b;
+    const double* rec_in;   // buffer (sweep & 1): the state this iteration reads
+    double* rec_out;        // buffer ((sweep+1) & 1): the reference's new_* maps
+    const double* node_in;
+    double* node_out;
     double eps;
     int32_t sweep;       // 0-based index of this iteration
+    int32_t book_tile;   // first wave index past the tiles: it does the residual bookkeeping
 };
 
 struct FinishArgs {

@@ -122,7 +122,8 @@ extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) {
     }
     const Plan& p = e->plan;
     e->grid_tiles = std::max(1, (int(p.tiles.size()) + kWavesPerBlock - 1) / kWavesPerBlock);
-    e->grid_sweep = (e->grid_tiles + 7) & ~7;
+    // one wave past the tiles does the residual bookkeeping -> at least one spare wave
+    e->grid_sweep = ((int(p.tiles.size()) + 1 + kWavesPerBlock - 1) / kWavesPerBlock + 7) & ~7;
     e->stats.algorithmic_bytes_per_sweep = p.algorithmic_bytes;
     e->stats.layout_bytes_per_sweep = p.layout_bytes;
     e->stats.messages_per_sweep = p.messages_per_sweep;
@@ -190,8 +191,8 @@ static BpBuffers buffers_of(bn_engine* e) {
     b.classes = e->d_classes;
     b.n_tiles = int32_t(e->plan.tiles.size());
     b.cpt = e->d_cpt;
-    b.rec[0] = e->d_rec[0]; b.rec[1] = e->d_rec[1];
-    b.node[0] = e->d_node[0]; b.node[1] = e->d_node[1];
+    b.rec0 = e->d_rec[0]; b.rec1 = e->d_rec[1];
+    b.node0 = e->d_node[0]; b.node1 = e->d_node[1];
     b.out_refs = e->d_out;
     b.frozen = e->d_frozen;
     b.slot_node = e->d_slot_node;
@@ -274,7 +275,9 @@ extern "C" int bn_bp_run_device(bn_engine* e, int32_t ne, const int32_t* ev_node
         if ((rc = ensure_events(e, 2 + 2 * size_t(batches + 1)))) return rc;
         HIPCHK(hipEventRecord(e->events[2 + 2 * batches], s));
         for (int32_t i = 0; i < batch; ++i) {
-            SweepArgs sa{b, eps, launched + i};
+            const int cur = (launched + i) & 1;
+            SweepArgs sa{b, e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, launched + i,
+                         int32_t(p.tiles.size())};
             if (launch_bp_sweep(sa, e->grid_sweep, s)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
         }
         launched += batch;

@@ -78,6 +78,14 @@ __device__ __forceinline__ void publish_residual(const BpBuffers& b, int sweep, 
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The four state pointers of one iteration, resolved on the host.
+struct IO {
+    const double* rec_in;
+    double* rec_out;
+    const double* node_in;
+    double* node_out;
+};
+
 // ---------------------------------------------------------------------------------------------
 // parent role for any shape: lambda(v) and the pi-messages to the children, reading the
 // children's records through the out-edge references.  Used by the generic path and by the
@@ -90,12 +98,12 @@ __device__ __forceinline__ void wr_rec(double* rec, OutRef r, int chunk, int i, 
     rec[(int64_t(r.rec) + int64_t(chunk + (i >> 1)) * r.stride) * 2 + (i & 1)] = x;
 }
 
-__device__ double parent_role_generic(const BpBuffers& b, int cur, const TileDesc& td, int kv, int kvp, int npt,
+__device__ double parent_role_generic(const BpBuffers& b, const IO& io, const TileDesc& td, int kv, int kvp, int npt,
                                       int nl, bool writer, bool frozen) {
-    const double* rec_in = b.rec[cur];
-    double* rec_out = b.rec[cur ^ 1];
-    const double* node_in = b.node[cur] + td.node_base;
-    double* node_out = b.node[cur ^ 1] + td.node_base;
+    const double* rec_in = io.rec_in;
+    double* rec_out = io.rec_out;
+    const double* node_in = io.node_in + td.node_base;
+    double* node_out = io.node_out + td.node_base;
     const OutRef* orf = b.out_refs + td.out_base + nl;
     const int half = kvp >> 1;
     double wres = 0.0;
@@ -146,15 +154,15 @@ __device__ double parent_role_generic(const BpBuffers& b, int cur, const TileDes
 // generic tile: any arities, runtime loops, one lane per node, operands re-read through L1.
 // Correctness path for shapes without a register-resident instantiation.
 // ---------------------------------------------------------------------------------------------
-__device__ double tile_generic(const BpBuffers& b, int cur, const TileDesc& td, const ClassDesc& c, int lane) {
+__device__ double tile_generic(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& c, int lane) {
     const bool active = lane < td.n_nodes;
     double wres = 0.0;
     if (!active) return wres;
     const double* cpt = b.cpt + td.cpt_base + lane * 2;
-    const double* rec_in = b.rec[cur] + td.rec_base + lane * 2;
-    double* rec_out = b.rec[cur ^ 1] + td.rec_base + lane * 2;
-    const double* node_in = b.node[cur] + td.node_base + lane * 2;
-    double* node_out = b.node[cur ^ 1] + td.node_base + lane * 2;
+    const double* rec_in = io.rec_in + td.rec_base + lane * 2;
+    double* rec_out = io.rec_out + td.rec_base + lane * 2;
+    const double* node_in = io.node_in + td.node_base + lane * 2;
+    double* node_out = io.node_out + td.node_base + lane * 2;
     const bool frozen = b.frozen[td.slot_base + lane] != 0;
     const int kv = c.kv, m = c.m, rows = c.rows, hv = c.kvp >> 1;
     auto CPT = [&](int q) { return cpt[int64_t(q >> 1) * 128 + (q & 1)]; };
@@ -205,130 +213,141 @@ __device__ double tile_generic(const BpBuffers& b, int cur, const TileDesc& td, 
             wres = res_acc(wres, fabs(nv - rec_in[LKIDX(jt, ct)]));
         }
     }
-    wres = res_acc(wres, parent_role_generic(b, cur, td, kv, c.kvp, kWave, lane, true, frozen));
+    wres = res_acc(wres, parent_role_generic(b, io, td, kv, c.kvp, kWave, lane, true, frozen));
     return wres;
 }
 
 // ---------------------------------------------------------------------------------------------
 // register-resident tile: node and parents share arity K, M parents, whole CPT (K^(M+1) <= 64
 // doubles) in VGPRs, every loop unrolled at compile time, 16-byte lane-striped loads.
+// RC = children per node held in registers (the tile's cmax <= RC).
 // ---------------------------------------------------------------------------------------------
-constexpr int kRegChildren = 4;  // children per node kept in registers
-
-template <int K, int M>
-__device__ __forceinline__ double tile_uniform(const BpBuffers& b, int cur, const TileDesc& td, int lane) {
+template <int K, int M, int RC>
+__device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
-    const bool active = lane < td.n_nodes;
-
-    // ---- issue every load of the child role first: CPT, in-edge records, node vectors
-    const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
-    double cpt[SP];
+    double wres = 0.0;
+    if (lane < td.n_nodes) {
+        // ---- child-role loads: CPT, pi-messages from the parents, lambda(v)
+        const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
+        double cpt[SP];
 #pragma unroll
-    for (int q = 0; q < SP / 2; ++q) {
-        double2_t x = cp[q * kWave];
-        cpt[2 * q] = x.x;
-        cpt[2 * q + 1] = x.y;
-    }
-    const double2_t* rin = reinterpret_cast<const double2_t*>(b.rec[cur] + td.rec_base) + lane;
-    double2_t* rout = reinterpret_cast<double2_t*>(b.rec[cur ^ 1] + td.rec_base) + lane;
-    double pim[M > 0 ? M : 1][KP], lko[M > 0 ? M : 1][KP];
-#pragma unroll
-    for (int j = 0; j < M; ++j)
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            double2_t x = rin[(j * 2 * H + h) * kWave], y = rin[(j * 2 * H + H + h) * kWave];
-            pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
-            lko[j][2 * h] = y.x; lko[j][2 * h + 1] = y.y;
+        for (int q = 0; q < SP / 2; ++q) {
+            const double2_t x = cp[q * kWave];
+            cpt[2 * q] = x.x;
+            cpt[2 * q + 1] = x.y;
         }
-    const double2_t* nin = reinterpret_cast<const double2_t*>(b.node[cur] + td.node_base) + lane;
-    double2_t* nout = reinterpret_cast<double2_t*>(b.node[cur ^ 1] + td.node_base) + lane;
-    double piv[KP], lav[KP];
+        const double2_t* rin = reinterpret_cast<const double2_t*>(io.rec_in + td.rec_base) + lane;
+        double2_t* rout = reinterpret_cast<double2_t*>(io.rec_out + td.rec_base) + lane;
+        const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + lane;
+        double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + lane;
+        double pim[M > 0 ? M : 1][KP];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-        double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
-        piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
-        lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
-    }
-    const bool frozen = b.frozen[td.slot_base + lane] != 0;
-
-    // ---- parent role loads: out-edge references and the children's records (gather)
-    const OutRef* orf = b.out_refs + td.out_base + lane;
-    const bool reg_children = td.cmax <= kRegChildren;
-    OutRef oref[kRegChildren];
-    double lkc[kRegChildren][KP], pio[kRegChildren][KP];
-    const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(b.rec[cur]);
-    double2_t* rec_out2 = reinterpret_cast<double2_t*>(b.rec[cur ^ 1]);
-#pragma unroll
-    for (int c = 0; c < kRegChildren; ++c) {
-        oref[c] = OutRef{-1, 0};
-        if (reg_children && c < td.cmax) oref[c] = orf[c * kWave];
-#pragma unroll
-        for (int i = 0; i < KP; ++i) { lkc[c][i] = 1.0; pio[c][i] = 0.0; }  // x * 1.0 == x exactly
-        if (oref[c].rec >= 0) {
+        for (int j = 0; j < M; ++j)
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                double2_t x = rec_in2[oref[c].rec + int64_t(h) * oref[c].stride];
-                double2_t y = rec_in2[oref[c].rec + int64_t(H + h) * oref[c].stride];
-                pio[c][2 * h] = x.x; pio[c][2 * h + 1] = x.y;
-                lkc[c][2 * h] = y.x; lkc[c][2 * h + 1] = y.y;
+                const double2_t x = rin[(j * 2 * H + h) * kWave];
+                pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
+            }
+        double piv[KP], lav[KP];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
+            piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
+            lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+        }
+        const bool frozen = b.frozen[td.slot_base + lane] != 0;
+
+        // ---- parent-role loads: out-edge references, then the children's lambda-messages.
+        // A missing child reads record 0 and contributes 1.0 (x * 1.0 == x exactly).
+        const OutRef* orf = b.out_refs + td.out_base + lane;
+        const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
+        double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
+        OutRef oref[RC > 0 ? RC : 1];
+        double lkc[RC > 0 ? RC : 1][KP];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            oref[c] = OutRef{-1, 0};
+            if (c < td.cmax) oref[c] = orf[c * kWave];
+        }
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+#pragma unroll
+            for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
+            if (c < td.cmax) {
+                const bool has = oref[c].rec >= 0;
+                const int64_t base = has ? oref[c].rec : 0;
+                const int64_t st = has ? oref[c].stride : 0;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t y = rec_in2[base + (H + h) * st];
+                    lkc[c][2 * h] = has ? y.x : 1.0;
+                    lkc[c][2 * h + 1] = has ? y.y : 1.0;
+                }
             }
         }
-    }
 
-    double wres = 0.0;
-
-    // ---- pi(v), calculate_pi (:174-200)
-    double pin[KP];
+        // ---- pi(v), calculate_pi (:174-200)
+        {
+            double t[K];
 #pragma unroll
-    for (int i = 0; i < KP; ++i) pin[i] = 0.0;
-    {
-        double t[K];
+            for (int i = 0; i < K; ++i) {
+                double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double acc = 0.0;
+                for (int cond = 0; cond < C; ++cond) {
+                    double value = cpt[i * C + cond];
 #pragma unroll
-            for (int cond = 0; cond < C; ++cond) {
-                double value = cpt[i * C + cond];
-#pragma unroll
-                for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
-                acc += value;
+                    for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                    acc += value;
+                }
+                t[i] = acc;
             }
-            t[i] = acc;
-        }
-        normalize_k<K>(t);
+            normalize_k<K>(t);
+            double o[KP];
 #pragma unroll
-        for (int i = 0; i < K; ++i) pin[i] = frozen ? piv[i] : t[i];
-    }
-
-    // ---- lambda-messages to the parents, calculate_lambda_k (:240-266)
+            for (int i = 0; i < KP; ++i) o[i] = 0.0;
 #pragma unroll
-    for (int jt = 0; jt < M; ++jt) {
-        double out[K];
+            for (int i = 0; i < K; ++i) o[i] = frozen ? piv[i] : t[i];
 #pragma unroll
-        for (int ct = 0; ct < K; ++ct) out[ct] = 0.0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const double times = lav[i];
-#pragma unroll
-            for (int cond = 0; cond < C; ++cond) {
-                double value = times * cpt[i * C + cond];
-#pragma unroll
-                for (int j = 0; j < M; ++j)
-                    if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
-                out[(cond / ipow(K, M - 1 - jt)) % K] += value;
+            for (int h = 0; h < H; ++h) {
+                double2_t y;
+                y.x = o[2 * h]; y.y = o[2 * h + 1];
+                nout[h * kWave] = y;
             }
         }
-        normalize_k<K>(out);
-        double o[KP];
+
+        // ---- lambda-messages to the parents, calculate_lambda_k (:240-266)
 #pragma unroll
-        for (int i = 0; i < KP; ++i) o[i] = 0.0;
+        for (int jt = 0; jt < M; ++jt) {
+            double out[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            o[i] = out[i];
-            wres = res_acc(wres, fabs(out[i] - lko[jt][i]));
-        }
-        if (active) {
+            for (int ct = 0; ct < K; ++ct) out[ct] = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const double times = lav[i];
+#pragma unroll
+                for (int cond = 0; cond < C; ++cond) {
+                    double value = times * cpt[i * C + cond];
+#pragma unroll
+                    for (int j = 0; j < M; ++j)
+                        if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                    out[(cond / ipow(K, M - 1 - jt)) % K] += value;
+                }
+            }
+            normalize_k<K>(out);
+            double o[KP], old[KP];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {  // previous lambda-message of this edge, for the residual
+                const double2_t y = rin[(jt * 2 * H + H + h) * kWave];
+                old[2 * h] = y.x; old[2 * h + 1] = y.y;
+            }
+#pragma unroll
+            for (int i = 0; i < KP; ++i) o[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                o[i] = out[i];
+                wres = res_acc(wres, fabs(out[i] - old[i]));
+            }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double2_t y;
@@ -336,73 +355,85 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, int cur, cons
                 rout[(jt * 2 * H + H + h) * kWave] = y;
             }
         }
-    }
 
-    // ---- parent role: lambda(v) (:220-238) and pi-messages to the children (:202-218)
-    double lan[KP];
-#pragma unroll
-    for (int i = 0; i < KP; ++i) lan[i] = 0.0;
-    if (reg_children) {
-        double t[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double acc = 1.0;
-#pragma unroll
-            for (int c = 0; c < kRegChildren; ++c) acc *= lkc[c][i];
-            t[i] = acc;
-        }
-        normalize_k<K>(t);
-#pragma unroll
-        for (int i = 0; i < K; ++i) lan[i] = frozen ? lav[i] : t[i];
-#pragma unroll
-        for (int c = 0; c < kRegChildren; ++c) {
-            double u[K];
+        // ---- parent role: lambda(v) (:220-238) and pi-messages to the children (:202-218)
+        {
+            double t[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                double acc = piv[i];
+                double acc = 1.0;
 #pragma unroll
-                for (int x = 0; x < kRegChildren; ++x)
-                    if (x != c) acc *= lkc[x][i];
-                u[i] = acc;
+                for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
+                t[i] = acc;
             }
-            normalize_k<K>(u);
-            if (oref[c].rec >= 0) {
-                double o[KP];
+            normalize_k<K>(t);
+            double o[KP];
 #pragma unroll
-                for (int i = 0; i < KP; ++i) o[i] = 0.0;
+            for (int i = 0; i < KP; ++i) o[i] = 0.0;
 #pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    o[i] = u[i];
-                    wres = res_acc(wres, fabs(u[i] - pio[c][i]));
-                }
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    double2_t y;
-                    y.x = o[2 * h]; y.y = o[2 * h + 1];
-                    rec_out2[oref[c].rec + int64_t(h) * oref[c].stride] = y;
-                }
-            }
-        }
-        if (active) {
+            for (int i = 0; i < K; ++i) o[i] = frozen ? lav[i] : t[i];
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double2_t y;
-                y.x = lan[2 * h]; y.y = lan[2 * h + 1];
+                y.x = o[2 * h]; y.y = o[2 * h + 1];
                 nout[(H + h) * kWave] = y;
             }
         }
-    } else if (active) {
-        wres = res_acc(wres, parent_role_generic(b, cur, td, K, KP, kWave, lane, true, frozen));
-    }
-    if (active) {
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            double2_t y;
-            y.x = pin[2 * h]; y.y = pin[2 * h + 1];
-            nout[h * kWave] = y;
+        for (int c = 0; c < RC; ++c) {
+            if (c < td.cmax) {  // wave-uniform
+                double u[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    double acc = piv[i];
+#pragma unroll
+                    for (int x = 0; x < RC; ++x)
+                        if (x != c) acc *= lkc[x][i];
+                    u[i] = acc;
+                }
+                normalize_k<K>(u);
+                if (oref[c].rec >= 0) {
+                    double o[KP];
+#pragma unroll
+                    for (int i = 0; i < KP; ++i) o[i] = 0.0;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
+                        const double2_t x = rec_in2[oref[c].rec + int64_t(h) * oref[c].stride];
+                        if (2 * h < K) wres = res_acc(wres, fabs(u[2 * h] - x.x));
+                        if (2 * h + 1 < K) wres = res_acc(wres, fabs(u[2 * h + 1] - x.y));
+                    }
+#pragma unroll
+                    for (int i = 0; i < K; ++i) o[i] = u[i];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        double2_t y;
+                        y.x = o[2 * h]; y.y = o[2 * h + 1];
+                        rec_out2[oref[c].rec + int64_t(h) * oref[c].stride] = y;
+                    }
+                }
+            }
         }
     }
-    return active ? wres : 0.0;
+    return wres;
+}
+
+// Same child role, but the parent role goes through memory (tiles whose nodes have more
+// children than the register path holds).
+template <int K, int M>
+__device__ __forceinline__ double tile_uniform_fanout(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
+    double wres = tile_uniform<K, M, 0>(b, io, td, lane);
+    if (lane < td.n_nodes) {
+        const bool frozen = b.frozen[td.slot_base + lane] != 0;
+        wres = res_acc(wres, parent_role_generic(b, io, td, K, (K + 1) & ~1, kWave, lane, true, frozen));
+    }
+    return wres;
+}
+
+template <int K, int M>
+__device__ __forceinline__ double tile_uniform_dispatch(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
+    if (td.cmax <= 2) return tile_uniform<K, M, 2>(b, io, td, lane);
+    if (td.cmax <= 4) return tile_uniform<K, M, 4>(b, io, td, lane);
+    return tile_uniform_fanout<K, M>(b, io, td, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,50 +447,58 @@ __device__ __forceinline__ int logical_block() {
     return (b & 7) * (nb >> 3) + (b >> 3);
 }
 
+// Residual bookkeeping of launch s, done by ONE wave that carries no tile: settle sweep s-1
+// (record maximum_difference, raise `done` when it is < eps, :147) and zero the ring row that
+// sweep s+1 will accumulate into.  Tile waves never wait for it: a launch that starts after
+// convergence only writes the buffer that is no longer current, and the launch after that sees
+// `done` and returns at once.
+__device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) {
+    const BpBuffers& b = a.b;
+    if (a.sweep > 0) {
+        const double r = previous_residual(b, a.sweep - 1, lane);
+        if (lane == 0) {
+            if (a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
+            if (r < a.eps) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
+        }
+    }
+    unsigned long long* row = b.res_slots + ((a.sweep + 1) % kResRows) * kResSlots;
+#pragma unroll
+    for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
+}
+
 __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a) {
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (__hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (a.sweep > 0) {
-        const double r = previous_residual(b, a.sweep - 1, lane);
-        if (lead && a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
-        if (r < a.eps) {  // strict '<' (:147): sweep (a.sweep-1) was the last one
-            if (lead) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
-            return;
-        }
+    const int lb = logical_block();
+    const int tile = lb * kWavesPerBlock + wave;
+    if (tile >= b.n_tiles) {
+        if (tile == a.book_tile) sweep_bookkeeping(a, lane);
+        return;
     }
-    if (blockIdx.x == 0 && wave == 0) {  // zero the ring row the NEXT sweep accumulates into
-        unsigned long long* row = b.res_slots + ((a.sweep + 1) % kResRows) * kResSlots;
-#pragma unroll
-        for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
-    }
-    const int tile = logical_block() * kWavesPerBlock + wave;
-    if (tile >= b.n_tiles) return;
-    const int cur = a.sweep & 1;
+    const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out};
     const TileDesc td = b.tiles[tile];
-    const ClassDesc& c = b.classes[td.cls];
     double wres;
-    if (c.variant == kVariantUniform) {
-        switch (c.kv * 8 + c.m) {
-            case 2 * 8 + 0: wres = tile_uniform<2, 0>(b, cur, td, lane); break;
-            case 2 * 8 + 1: wres = tile_uniform<2, 1>(b, cur, td, lane); break;
-            case 2 * 8 + 2: wres = tile_uniform<2, 2>(b, cur, td, lane); break;
-            case 2 * 8 + 3: wres = tile_uniform<2, 3>(b, cur, td, lane); break;
-            case 2 * 8 + 4: wres = tile_uniform<2, 4>(b, cur, td, lane); break;
-            case 3 * 8 + 0: wres = tile_uniform<3, 0>(b, cur, td, lane); break;
-            case 3 * 8 + 1: wres = tile_uniform<3, 1>(b, cur, td, lane); break;
-            case 3 * 8 + 2: wres = tile_uniform<3, 2>(b, cur, td, lane); break;
-            case 4 * 8 + 0: wres = tile_uniform<4, 0>(b, cur, td, lane); break;
-            case 4 * 8 + 1: wres = tile_uniform<4, 1>(b, cur, td, lane); break;
-            case 4 * 8 + 2: wres = tile_uniform<4, 2>(b, cur, td, lane); break;
-            default: wres = tile_generic(b, cur, td, c, lane); break;
+    if (td.variant == kVariantUniform) {
+        switch (td.kv * 8 + td.m) {
+            case 2 * 8 + 0: wres = tile_uniform_dispatch<2, 0>(b, io, td, lane); break;
+            case 2 * 8 + 1: wres = tile_uniform_dispatch<2, 1>(b, io, td, lane); break;
+            case 2 * 8 + 2: wres = tile_uniform_dispatch<2, 2>(b, io, td, lane); break;
+            case 2 * 8 + 3: wres = tile_uniform_dispatch<2, 3>(b, io, td, lane); break;
+            case 2 * 8 + 4: wres = tile_uniform_dispatch<2, 4>(b, io, td, lane); break;
+            case 3 * 8 + 0: wres = tile_uniform_dispatch<3, 0>(b, io, td, lane); break;
+            case 3 * 8 + 1: wres = tile_uniform_dispatch<3, 1>(b, io, td, lane); break;
+            case 3 * 8 + 2: wres = tile_uniform_dispatch<3, 2>(b, io, td, lane); break;
+            case 4 * 8 + 0: wres = tile_uniform_dispatch<4, 0>(b, io, td, lane); break;
+            case 4 * 8 + 1: wres = tile_uniform_dispatch<4, 1>(b, io, td, lane); break;
+            case 4 * 8 + 2: wres = tile_uniform_dispatch<4, 2>(b, io, td, lane); break;
+            default: wres = tile_generic(b, io, td, b.classes[td.cls], lane); break;
         }
     } else {
-        wres = tile_generic(b, cur, td, c, lane);
+        wres = tile_generic(b, io, td, b.classes[td.cls], lane);
     }
-    publish_residual(b, a.sweep, blockIdx.x * kWavesPerBlock + wave, wres, lane);
+    publish_residual(b, a.sweep, tile, wres, lane);
 }
 
 // Initial state, belief_propagation.hpp:33-65 : every message and node vector 1.0, roots take
@@ -475,9 +514,9 @@ __global__ __launch_bounds__(kBlockThreads) void bp_init_kernel(BpBuffers b) {
     if (tile >= b.n_tiles) return;
     const TileDesc td = b.tiles[tile];
     const ClassDesc& c = b.classes[td.cls];
-    double* rec = b.rec[0] + td.rec_base;
+    double* rec = b.rec0 + td.rec_base;
     for (int q = lane; q < c.rec_doubles; q += kWave) rec[q] = 1.0;
-    double* node = b.node[0] + td.node_base;
+    double* node = b.node0 + td.node_base;
     const int nd = 2 * c.kvp * c.npt;
     for (int q = lane; q < nd; q += kWave) node[q] = 1.0;
     for (int q = lane; q < c.npt; q += kWave) b.frozen[td.slot_base + q] = 0;
@@ -498,7 +537,7 @@ __global__ void bp_evidence_kernel(EvidenceArgs a) {
     const TileDesc td = b.tiles[b.node_tile[v]];
     const ClassDesc& c = b.classes[td.cls];
     const int nl = b.node_nl[v];
-    double* node = b.node[0] + td.node_base;
+    double* node = b.node0 + td.node_base;
     const int half = c.kvp >> 1;
     for (int i = 0; i < c.kv; ++i) {
         const double x = a.ev_val[a.ev_off[j] + i];
@@ -533,7 +572,7 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     const TileDesc td = b.tiles[tile];
     const ClassDesc& c = b.classes[td.cls];
     if (lane >= td.n_nodes) return;  // one lane per node writes the belief
-    const double* node = b.node[n_sweeps & 1] + td.node_base;
+    const double* node = ((n_sweeps & 1) ? b.node1 : b.node0) + td.node_base;
     const int64_t boff = b.slot_boff[td.slot_base + lane];
     const int half = c.kvp >> 1;
     double sum = 0;

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
         __syncthreads();  // previous node's LDS reads are finished
         if (in_lds)
             for (int q = tid; q < csz; q += kLwThreads) sh_cpt[q] = a.cpt[coff + q];
-        if (tid < kv) sh_hist[tid] = 0.0;
         __syncthreads();
         if ((t & 1) == 0 && ev < 0) {  // fresh Philox block for positions t and t+1
 #pragma unroll
@@ -81,9 +80,6 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
                 }
             }
         }
-        double acc8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc8[i] = 0.0;
 #pragma unroll
         for (int r = 0; r < kLwPerThread; ++r) {
             const uint64_t col = local0 + uint64_t(r) * kLwThreads;
@@ -98,7 +94,7 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
                 w[r] *= rowp[ev];
                 st = ev;
             } else {
-                const uint32_t lo = rnd[r][2 * (t & 1)], hi = rnd[r][2 * (t & 1) + 1];
+                const uint32_t lo = (t & 1) ? rnd[r][2] : rnd[r][0], hi = (t & 1) ? rnd[r][3] : rnd[r][1];
                 const uint64_t x = (uint64_t(hi) << 32) | lo;
                 const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
                 st = kv - 1;
@@ -111,13 +107,28 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
                 }
             }
             a.states[uint64_t(v) * a.batch + col] = uint8_t(st);
-            if (valid[r]) {
-                if (kv <= 8) {
+        }
+    }
+
+    // ---- second pass: the sample's FINAL weight goes into every node's histogram (:45-49);
+    // it is only known once every evidence node has been visited.
+    for (int v = 0; v < a.n; ++v) {
+        const int kv = a.k[v];
+        __syncthreads();
+        if (tid < kv) sh_hist[tid] = 0.0;
+        __syncthreads();
+        double acc8[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc8[i] += (i == st) ? w[r] : 0.0;
-                } else {
-                    atomicAdd(&sh_hist[st], w[r]);
-                }
+        for (int i = 0; i < 8; ++i) acc8[i] = 0.0;
+#pragma unroll
+        for (int r = 0; r < kLwPerThread; ++r) {
+            if (!valid[r]) continue;
+            const int st = a.states[uint64_t(v) * a.batch + local0 + uint64_t(r) * kLwThreads];
+            if (kv <= 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc8[i] += (i == st) ? w[r] : 0.0;
+            } else {
+                atomicAdd(&sh_hist[st], w[r]);
             }
         }
         if (kv <= 8) {

@@ -149,6 +149,7 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
         td.rec_base = rec_cur;
         td.node_base = node_cur;
         td.out_base = out_cur;
+        td.kv = c.kv; td.m = c.m; td.variant = c.variant; td.npt = c.npt;
         int32_t cmax = 0;
         for (int32_t nl = 0; nl < td.n_nodes; ++nl) {
             int32_t v = proto[t].nodes[nl];

@@ -66,7 +66,8 @@ struct TileDesc {
     int64_t rec_base;    // doubles
     int64_t node_base;   // doubles: pi at node_base, lambda at node_base + kvp*npt
     int64_t out_base;    // int2 entries: out-edge c of node nl at out_base + c*npt + nl
-    int64_t pad_[2];
+    // copy of the class fields the kernel dispatches on (saves a dependent load per wave)
+    int32_t kv, m, variant, npt;
 };
 static_assert(sizeof(TileDesc) == 64, "TileDesc must stay 64 bytes");
 

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""bench.py -- edge-messages/sec to BP convergence on the BASELINE.json grid (config 3).
+
+A "step" is one belief-propagation run to convergence (init, evidence, sweeps until
+maximum_difference < eps, beliefs) on the 316x316 k=4 grid BN with 1 % hard evidence, model and
+evidence already resident in HBM.  value = 2E * sweeps * steps / wall time, whole job.
+One JSON line on stdout (rank 0).  See DESIGN.md "Measurement" for the definitions.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(model, ev, eps, budget_s=12.0):
+    """The oracle (plain-C port of the reference algorithm), 1 thread like the reference, timed on
+    this box's host cores on a bounded number of full runs of the same workload."""
+    import oracle
+    t0 = time.perf_counter()
+    runs, msgs = 0, 0
+    while True:
+        r = oracle.bp_run(model, ev, eps, threads=1)
+        runs += 1
+        msgs += model.messages_per_sweep() * r["sweeps"]
+        if time.perf_counter() - t0 > budget_s or runs >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": msgs / dt, "unit": "edge-messages/s", "cores": 1, "kind": "port",
+            "sample": f"{runs} full runs of the same workload ({r['sweeps']} sweeps each), oracle/bp_oracle.c, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=316)
+    ap.add_argument("--cols", type=int, default=316)
+    ap.add_argument("--eps", type=float, default=1e-3)
+    ap.add_argument("--evidence", type=float, default=0.01)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch  # device plumbing only: barrier / synchronize around the timed region
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+
+    if world > 1:
+        from bayesiannetwork_amd import multigpu
+        return multigpu.bench_main(a, rank, world, local_rank)
+
+    torch.cuda.set_device(local_rank)
+    g = synth.grid(a.rows, a.cols, 4, seed=2)
+    ev = synth.random_evidence(g, a.evidence, seed=7)
+    eng = Engine(g, device=local_rank)
+    for _ in range(max(a.warmup, 1)):
+        r = eng.bp_run(ev, a.eps, copy_beliefs=False)
+    torch.cuda.synchronize()
+    sweeps_total, kern_ms, launches = 0, 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        r = eng.bp_run(ev, a.eps, copy_beliefs=False)
+        st = eng.bp_stats()
+        sweeps_total += r["sweeps"]
+        kern_ms += st["sweep_kernel_ms"]
+        launches += st["sweep_launches"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.bp_stats()
+    msgs = g.messages_per_sweep() * sweeps_total
+    avg_launch_s = kern_ms * 1e-3 / max(launches, 1)
+    achieved = st["algorithmic_bytes_per_sweep"] / avg_launch_s / 1e9
+    out = {
+        "metric": "edge-messages/sec to BP convergence", "value": msgs / dt, "unit": "edge-messages/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{a.rows}x{a.cols} 2D-grid BN, k=4, {g.n} nodes, {g.n_edges} edges "
+                               f"(BASELINE.json configs[2]), {ev.ne} evidence nodes, eps={a.eps:g}",
+                   "sweeps_per_step": sweeps_total / a.steps, "messages_per_sweep": g.messages_per_sweep(),
+                   "parallelism": "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "bp_sweep_kernel", "avg_launch_us": avg_launch_s * 1e6,
+                     "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"],
+                     "layout_bytes_per_launch": st["layout_bytes_per_sweep"]},
+        "sweep_only_msgs_per_s": g.messages_per_sweep() / avg_launch_s,
+    }
+    if not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(g, ev, a.eps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
