@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbn_mi355x.so")
+# BN_MI355X_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("BN_MI355X_LIB") or os.path.join(_HERE, "libbn_mi355x.so")
 _LIB = None
 
 BN_OK, BN_ERR_ARG, BN_ERR_HIP, BN_ERR_NO_DEVICE, BN_ERR_ALLOC, BN_ERR_COMM, BN_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -48,8 +49,8 @@ SYMBOLS = [
     ("bn_version", ctypes.c_char_p, []),
     ("bn_bp_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p, ctypes.c_double, ctypes.c_int32,
                                  f64p, i32p, f64p]),
-    ("bn_bp_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p, ctypes.c_double,
-                                        ctypes.c_int32, i32p, f64p]),
+    ("bn_bp_set_evidence", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p]),
+    ("bn_bp_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, i32p, f64p]),
     ("bn_bp_beliefs_device", ctypes.c_void_p, [ctypes.c_void_p]),
     ("bn_bp_copy_beliefs", ctypes.c_int, [ctypes.c_void_p, f64p]),
     ("bn_bp_residual_history", ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int32]),

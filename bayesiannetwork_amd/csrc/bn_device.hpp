@@ -57,6 +57,8 @@ struct FinishArgs {
     double eps;
     int32_t sweeps_launched;
     int32_t final_batch;  // 1: max_sweeps reached with this batch -> stop even if not converged
+    int32_t ne;           // evidence marks to clear once the run is over
+    const int32_t* ev_node;
 };
 
 struct EvidenceArgs {
@@ -68,9 +70,8 @@ struct EvidenceArgs {
 };
 
 // launchers (bn_kernels.hip)
-int launch_bp_init(const BpBuffers& b, int grid_blocks, void* stream);
-int launch_bp_evidence(const EvidenceArgs& a, void* stream);
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, void* stream);
+int launch_bp_begin(const EvidenceArgs& a, void* stream);
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream);
 int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream);
 
 }  // namespace bnmi

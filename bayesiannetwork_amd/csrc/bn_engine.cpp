@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -50,12 +51,16 @@ struct bn_engine {
     double* d_res_hist = nullptr;
     Ctl* d_ctl = nullptr;
     double* d_beliefs = nullptr;
-    // evidence staging
+    // evidence staging: one device block + one pinned host block, sub-pointers into d_ev
+    char* d_ev = nullptr;
+    char* h_ev = nullptr;
+    size_t ev_bytes_cap = 0;
+    int32_t ev_ne = 0;
     int32_t* d_ev_node = nullptr;
     int32_t* d_ev_off = nullptr;
     double* d_ev_val = nullptr;
-    int32_t ev_cap = 0;
-    int64_t ev_val_cap = 0;
+    bool frozen_dirty = false;
+    bool nontemporal = false;
     Ctl* h_ctl = nullptr;  // pinned
     // run state
     int32_t res_cap = 1 << 16;
@@ -63,7 +68,7 @@ struct bn_engine {
     bool have_run = false;
     Ctl last_ctl{};
     bn_bp_stats stats{};
-    std::vector<hipEvent_t> events;  // [0]=start, [1]=end, then (begin,end) per sweep batch
+    std::vector<hipEvent_t> events;  // (begin, end) per sweep batch
     int grid_tiles = 0;              // blocks for one-wave-per-tile kernels without remap
     int grid_sweep = 0;              // same, padded to a multiple of 8 for the XCD mapping
     LwState lw;
@@ -76,11 +81,11 @@ static void free_engine(bn_engine* e) {
         lw_free(e->lw);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_res_slots, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev_node, e->d_ev_off,
-                        e->d_ev_val};
+                        e->d_res_slots, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+        if (e->h_ev) (void)hipHostFree(e->h_ev);
         for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
@@ -162,13 +167,14 @@ extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) {
             HIPCHK(hipMemsetAsync(e->d_node[i], 0, std::max<size_t>(p.node_doubles, 1) * 8, e->stream));
         }
         if ((r = dalloc(&e->d_frozen, size_t(p.n_slots)))) return r;
+        HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), e->stream));
+        // store policy: working sets beyond the Infinity Cache stream their outputs non-temporally
+        e->nontemporal = 8 * (p.cpt_doubles + 2 * p.rec_doubles + 2 * p.node_doubles) > (int64_t(192) << 20);
         if ((r = dalloc(&e->d_res_slots, size_t(kResRows * kResSlots)))) return r;
         if ((r = dalloc(&e->d_res_hist, size_t(e->res_cap)))) return r;
         if ((r = dalloc(&e->d_ctl, 1))) return r;
         if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocDefault));
-        e->events.resize(2);
-        for (auto& ev : e->events) HIPCHK(hipEventCreate(&ev));
         HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
         return BN_OK;
@@ -233,79 +239,98 @@ static int ensure_events(bn_engine* e, size_t count) {
     return BN_OK;
 }
 
-extern "C" int bn_bp_run_device(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
-                                const double* ev_val, double eps, int32_t max_sweeps, int32_t* sweeps_out,
-                                double* residual_out) {
+// Evidence staging: one pinned host block [ev_node | ev_off | ev_val] -> one H2D copy.
+extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                                  const double* ev_val) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     const Plan& p = e->plan;
     int rc = check_evidence(p, ne, ev_node, ev_off);
     if (rc) return rc;
     if (ne > 0 && !ev_val) return fail(BN_ERR_ARG, "null ev_val");
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t nval = ne > 0 ? ev_off[ne] : 0;
+    const size_t off_node = 0, off_off = size_t(ne) * 4, off_val = (off_off + size_t(ne + 1) * 4 + 7) & ~size_t(7);
+    const size_t bytes = off_val + size_t(nval) * 8;
+    if (bytes > e->ev_bytes_cap) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->d_ev) (void)hipFree(e->d_ev);
+        if (e->h_ev) (void)hipHostFree(e->h_ev);
+        e->d_ev = nullptr; e->h_ev = nullptr;
+        e->ev_bytes_cap = std::max<size_t>(bytes * 2, 4096);
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_ev), e->ev_bytes_cap));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ev), e->ev_bytes_cap, hipHostMallocDefault));
+    }
+    if (ne > 0) {
+        std::memcpy(e->h_ev + off_node, ev_node, size_t(ne) * 4);
+        std::memcpy(e->h_ev + off_off, ev_off, size_t(ne + 1) * 4);
+        std::memcpy(e->h_ev + off_val, ev_val, size_t(nval) * 8);
+        HIPCHK(hipMemcpyAsync(e->d_ev, e->h_ev, bytes, hipMemcpyHostToDevice, e->stream));
+    }
+    e->ev_ne = ne;
+    e->d_ev_node = reinterpret_cast<int32_t*>(e->d_ev + off_node);
+    e->d_ev_off = reinterpret_cast<int32_t*>(e->d_ev + off_off);
+    e->d_ev_val = reinterpret_cast<double*>(e->d_ev + off_val);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BN_OK;
+}
+
+extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
+                                double* residual_out) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
+    const Plan& p = e->plan;
+    const auto t_begin = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
-    if (ne > e->ev_cap || (ne > 0 && ev_off[ne] > e->ev_val_cap)) {
-        if (e->d_ev_node) (void)hipFree(e->d_ev_node);
-        if (e->d_ev_off) (void)hipFree(e->d_ev_off);
-        if (e->d_ev_val) (void)hipFree(e->d_ev_val);
-        e->d_ev_node = e->d_ev_off = nullptr;
-        e->d_ev_val = nullptr;
-        e->ev_cap = std::max(ne, 64);
-        e->ev_val_cap = std::max<int64_t>(ev_off[ne], 256);
-        if ((rc = dalloc(&e->d_ev_node, size_t(e->ev_cap)))) return rc;
-        if ((rc = dalloc(&e->d_ev_off, size_t(e->ev_cap) + 1))) return rc;
-        if ((rc = dalloc(&e->d_ev_val, size_t(e->ev_val_cap)))) return rc;
-    }
     BpBuffers b = buffers_of(e);
-    HIPCHK(hipEventRecord(e->events[0], s));
-    if (ne > 0) {
-        HIPCHK(hipMemcpyAsync(e->d_ev_node, ev_node, sizeof(int32_t) * ne, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(e->d_ev_off, ev_off, sizeof(int32_t) * (ne + 1), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(e->d_ev_val, ev_val, sizeof(double) * ev_off[ne], hipMemcpyHostToDevice, s));
+    if (e->frozen_dirty) {  // a previous run ended abnormally: restore the all-clear invariant
+        HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), s));
+        e->frozen_dirty = false;
     }
-    if (launch_bp_init(b, e->grid_tiles, s)) return fail(BN_ERR_HIP, "bp_init launch failed");
-    EvidenceArgs ea{b, ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
-    if (launch_bp_evidence(ea, s)) return fail(BN_ERR_HIP, "bp_evidence launch failed");
+    e->frozen_dirty = true;
+    EvidenceArgs ea{b, e->ev_ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
+    if (launch_bp_begin(ea, s)) return fail(BN_ERR_HIP, "bp_begin launch failed");
 
+    int rc;
     int32_t launched = 0, batches = 0;
     int32_t batch = e->predicted_sweeps > 0 ? e->predicted_sweeps : 8;
     for (;;) {
         if (max_sweeps > 0) batch = std::min(batch, max_sweeps - launched);
-        if ((rc = ensure_events(e, 2 + 2 * size_t(batches + 1)))) return rc;
-        HIPCHK(hipEventRecord(e->events[2 + 2 * batches], s));
+        if ((rc = ensure_events(e, 2 * size_t(batches + 1)))) return rc;
+        HIPCHK(hipEventRecord(e->events[2 * batches], s));
         for (int32_t i = 0; i < batch; ++i) {
             const int cur = (launched + i) & 1;
             SweepArgs sa{b, e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, launched + i,
                          int32_t(p.tiles.size())};
-            if (launch_bp_sweep(sa, e->grid_sweep, s)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
+            if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, s)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
         }
         launched += batch;
-        HIPCHK(hipEventRecord(e->events[3 + 2 * batches], s));
+        HIPCHK(hipEventRecord(e->events[2 * batches + 1], s));
         ++batches;
-        FinishArgs fa{b, eps, launched, (max_sweeps > 0 && launched >= max_sweeps) ? 1 : 0};
+        FinishArgs fa{b, eps, launched, (max_sweeps > 0 && launched >= max_sweeps) ? 1 : 0, e->ev_ne, e->d_ev_node};
         if (launch_bp_finish(fa, e->grid_tiles, s)) return fail(BN_ERR_HIP, "bp_finish launch failed");
         HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (e->h_ctl->done != 0) break;
         batch = 8;
     }
-    HIPCHK(hipEventRecord(e->events[1], s));
-    HIPCHK(hipEventSynchronize(e->events[1]));
+    e->frozen_dirty = false;  // the finish kernel cleared this run's evidence marks
     e->last_ctl = *e->h_ctl;
     e->have_run = true;
     e->predicted_sweeps = e->last_ctl.n_sweeps;
-    float ms = 0.f, tot = 0.f;
+    float ms = 0.f;
     for (int32_t i = 0; i < batches; ++i) {
         float t = 0.f;
-        HIPCHK(hipEventElapsedTime(&t, e->events[2 + 2 * i], e->events[3 + 2 * i]));
+        HIPCHK(hipEventElapsedTime(&t, e->events[2 * i], e->events[2 * i + 1]));
         ms += t;
     }
-    HIPCHK(hipEventElapsedTime(&tot, e->events[0], e->events[1]));
     e->stats.sweeps = e->last_ctl.n_sweeps;
     e->stats.sweep_launches = launched;
     e->stats.sweep_kernel_ms = ms;
-    e->stats.total_ms = tot;
+    e->stats.total_ms =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
     if (residual_out) *residual_out = e->last_ctl.last_res;
     return BN_OK;
@@ -327,7 +352,9 @@ extern "C" int bn_bp_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
                          const double* ev_val, double eps, int32_t max_sweeps, double* beliefs_out,
                          int32_t* sweeps_out, double* residual_out) {
     if (!beliefs_out) return fail(BN_ERR_ARG, "null beliefs_out");
-    int rc = bn_bp_run_device(e, ne, ev_node, ev_off, ev_val, eps, max_sweeps, sweeps_out, residual_out);
+    int rc = bn_bp_set_evidence(e, ne, ev_node, ev_off, ev_val);
+    if (rc) return rc;
+    rc = bn_bp_run_device(e, eps, max_sweeps, sweeps_out, residual_out);
     if (rc) return rc;
     return bn_bp_copy_beliefs(e, beliefs_out);
 }

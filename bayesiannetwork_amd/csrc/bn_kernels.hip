@@ -16,10 +16,14 @@
 // reference's operation order; the file is compiled with -ffp-contract=off so the results are
 // bit-identical to the C restatement in oracle/bp_oracle.c.
 //
+// Iteration 0 reads nothing but the CPT and the evidence: the reference's initial state (:33-73)
+// is all-ones messages, pi = lambda = 1 (roots: their CPT row), so it is synthesised in registers
+// instead of being written to HBM by an initialisation pass and read back.
+//
 // Convergence is decided on the device: sweep s accumulates max|new-old| over messages into a
-// ring of 256 slots (atomic umax on the bit pattern of a non-negative double); the prologue of
-// launch s+1 reduces them, and once maximum_difference < eps (:147) every later launch returns
-// at once, so the host may enqueue launches ahead without synchronising per sweep.
+// ring of 256 slots (atomic umax on the bit pattern of a non-negative double); ONE extra wave of
+// launch s+1 reduces them and raises `done` once maximum_difference < eps (:147); every later
+// launch returns at once, so the host enqueues launches ahead without synchronising per sweep.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -29,6 +33,25 @@
 namespace bnmi {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// NT = non-temporal output stores.  Measured on MI355X: on a working set that fits the 256 MiB
+// Infinity Cache plain stores are faster (the next sweep re-reads them from cache); on an
+// HBM-resident working set non-temporal stores are ~5 % faster.  The host picks per engine.
+template <bool NT>
+__device__ __forceinline__ void bn_store(double2_t* p, double2_t v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// The four state pointers of one iteration, resolved on the host (a dynamically indexed kernarg
+// array would push the whole argument struct into scratch memory).
+struct IO {
+    const double* rec_in;
+    double* rec_out;
+    const double* node_in;
+    double* node_out;
+    bool first;  // iteration 0: see the file comment
+};
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
@@ -56,9 +79,9 @@ __device__ __forceinline__ void normalize_k(double (&t)[K]) {  // :298-311, no z
 
 __host__ __device__ constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 
-// Reduce the previous sweep's residual slots; returns maximum_difference of sweep (s-1).
-__device__ __forceinline__ double previous_residual(const BpBuffers& b, int prev_sweep, int lane) {
-    const unsigned long long* row = b.res_slots + (prev_sweep % kResRows) * kResSlots;
+// Reduce one sweep's residual slots; returns that sweep's maximum_difference.
+__device__ __forceinline__ double reduce_residual(const BpBuffers& b, int sweep, int lane) {
+    const unsigned long long* row = b.res_slots + (sweep % kResRows) * kResSlots;
     unsigned long long m = 0;
 #pragma unroll
     for (int q = 0; q < kResSlots / kWave; ++q) {
@@ -78,97 +101,93 @@ __device__ __forceinline__ void publish_residual(const BpBuffers& b, int sweep, 
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The four state pointers of one iteration, resolved on the host.
-struct IO {
-    const double* rec_in;
-    double* rec_out;
-    const double* node_in;
-    double* node_out;
-};
-
-// ---------------------------------------------------------------------------------------------
-// parent role for any shape: lambda(v) and the pi-messages to the children, reading the
-// children's records through the out-edge references.  Used by the generic path and by the
-// register path when a tile has more children per node than it keeps in registers.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double rd_rec(const double* rec, OutRef r, int chunk, int i) {
-    return rec[(int64_t(r.rec) + int64_t(chunk + (i >> 1)) * r.stride) * 2 + (i & 1)];
+// striped element address helpers (doubles): element i of a vector whose chunks are `stride2`
+// double2 apart, for node-lane nl
+__device__ __forceinline__ int64_t vidx(int chunk0, int i, int stride2, int nl) {
+    return int64_t(chunk0 + (i >> 1)) * (stride2 * 2) + nl * 2 + (i & 1);
 }
-__device__ __forceinline__ void wr_rec(double* rec, OutRef r, int chunk, int i, double x) {
-    rec[(int64_t(r.rec) + int64_t(chunk + (i >> 1)) * r.stride) * 2 + (i & 1)] = x;
+__device__ __forceinline__ int64_t ridx(OutRef r, int chunk0, int i) {
+    return (int64_t(r.rec) + int64_t(chunk0 + (i >> 1)) * r.stride) * 2 + (i & 1);
 }
 
-__device__ double parent_role_generic(const BpBuffers& b, const IO& io, const TileDesc& td, int kv, int kvp, int npt,
-                                      int nl, bool writer, bool frozen) {
-    const double* rec_in = io.rec_in;
-    double* rec_out = io.rec_out;
+// ---------------------------------------------------------------------------------------------
+// parent role for any shape: lambda(v) and the pi-messages to the children, operands re-read
+// through L1.  Used by the generic path and by the register path when a tile has more
+// children per node than it keeps in registers.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const IO& io, const TileDesc& td, int kv, int kvp,
+                                      int nl, bool frozen) {
+    const int npt = td.npt, half = kvp >> 1;
     const double* node_in = io.node_in + td.node_base;
     double* node_out = io.node_out + td.node_base;
     const OutRef* orf = b.out_refs + td.out_base + nl;
-    const int half = kvp >> 1;
+    const bool synth = io.first && !frozen;  // initial state instead of memory
+    auto LK = [&](OutRef r, int i) { return io.first ? 1.0 : io.rec_in[ridx(r, half, i)]; };
+    auto PIV = [&](int i) {
+        if (!synth) return node_in[vidx(0, i, npt, nl)];
+        return td.m == 0 ? b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)] : 1.0;  // :58-64
+    };
     double wres = 0.0;
-    auto nidx = [&](int part, int i) { return int64_t(part * half + (i >> 1)) * (npt * 2) + nl * 2 + (i & 1); };
     // lambda(v): product of the children's lambda-messages from 1.0, ascending child order (:229-235)
-    if (writer) {
-        if (frozen) {
-            for (int i = 0; i < kv; ++i) node_out[nidx(1, i)] = node_in[nidx(1, i)];
-        } else {
-            double sum = 0;
-            for (int i = 0; i < kv; ++i) {
-                double acc = 1.0;
-                for (int c = 0; c < td.cmax; ++c) {
-                    OutRef r = orf[int64_t(c) * npt];
-                    if (r.rec >= 0) acc *= rd_rec(rec_in, r, half, i);
-                }
-                node_out[nidx(1, i)] = acc;
-                sum += acc;
+    if (frozen) {
+        for (int i = 0; i < kv; ++i) node_out[vidx(half, i, npt, nl)] = node_in[vidx(half, i, npt, nl)];
+    } else {
+        double sum = 0;
+        for (int i = 0; i < kv; ++i) {
+            double acc = 1.0;
+            for (int c = 0; c < td.cmax; ++c) {
+                const OutRef r = orf[int64_t(c) * npt];
+                if (r.rec >= 0) acc *= LK(r, i);
             }
-            for (int i = 0; i < kv; ++i) node_out[nidx(1, i)] = node_out[nidx(1, i)] / sum;
+            node_out[vidx(half, i, npt, nl)] = acc;
+            sum += acc;
         }
-        // pi-message to child c: pi(v) times the OTHER children's lambda-messages (:207-214)
-        for (int c = 0; c < td.cmax; ++c) {
-            OutRef rc = orf[int64_t(c) * npt];
-            if (rc.rec < 0) continue;
-            double sum = 0;
-            for (int i = 0; i < kv; ++i) {
-                double acc = node_in[nidx(0, i)];
-                for (int x = 0; x < td.cmax; ++x) {
-                    if (x == c) continue;
-                    OutRef rx = orf[int64_t(x) * npt];
-                    if (rx.rec >= 0) acc *= rd_rec(rec_in, rx, half, i);
-                }
-                wr_rec(rec_out, rc, 0, i, acc);
-                sum += acc;
+        for (int i = 0; i < kv; ++i) node_out[vidx(half, i, npt, nl)] = node_out[vidx(half, i, npt, nl)] / sum;
+    }
+    // pi-message to child c: pi(v) times the OTHER children's lambda-messages (:207-214)
+    for (int c = 0; c < td.cmax; ++c) {
+        const OutRef rc = orf[int64_t(c) * npt];
+        if (rc.rec < 0) continue;
+        double sum = 0;
+        for (int i = 0; i < kv; ++i) {
+            double acc = PIV(i);
+            for (int x = 0; x < td.cmax; ++x) {
+                if (x == c) continue;
+                const OutRef rx = orf[int64_t(x) * npt];
+                if (rx.rec >= 0) acc *= LK(rx, i);
             }
-            for (int i = 0; i < kv; ++i) {
-                double nv = rd_rec(rec_out, rc, 0, i) / sum;
-                wr_rec(rec_out, rc, 0, i, nv);
-                wres = res_acc(wres, fabs(nv - rd_rec(rec_in, rc, 0, i)));
-            }
+            io.rec_out[ridx(rc, 0, i)] = acc;
+            sum += acc;
+        }
+        for (int i = 0; i < kv; ++i) {
+            const double nv = io.rec_out[ridx(rc, 0, i)] / sum;
+            io.rec_out[ridx(rc, 0, i)] = nv;
+            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : io.rec_in[ridx(rc, 0, i)])));
         }
     }
     return wres;
 }
 
 // ---------------------------------------------------------------------------------------------
-// generic tile: any arities, runtime loops, one lane per node, operands re-read through L1.
-// Correctness path for shapes without a register-resident instantiation.
+// generic tile: any arities, runtime loops, one lane per node.  Correctness path for shapes
+// without a register-resident instantiation.
 // ---------------------------------------------------------------------------------------------
-__device__ double tile_generic(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& c, int lane) {
-    const bool active = lane < td.n_nodes;
+__device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& c, int lane) {
     double wres = 0.0;
-    if (!active) return wres;
+    if (lane >= td.n_nodes) return wres;
     const double* cpt = b.cpt + td.cpt_base + lane * 2;
     const double* rec_in = io.rec_in + td.rec_base + lane * 2;
     double* rec_out = io.rec_out + td.rec_base + lane * 2;
     const double* node_in = io.node_in + td.node_base + lane * 2;
     double* node_out = io.node_out + td.node_base + lane * 2;
     const bool frozen = b.frozen[td.slot_base + lane] != 0;
+    const bool synth = io.first && !frozen;
     const int kv = c.kv, m = c.m, rows = c.rows, hv = c.kvp >> 1;
     auto CPT = [&](int q) { return cpt[int64_t(q >> 1) * 128 + (q & 1)]; };
-    auto PIM = [&](int j, int s) { return rec_in[c.rec_off[j] + int64_t(s >> 1) * 128 + (s & 1)]; };
+    auto PIM = [&](int j, int s) { return io.first ? 1.0 : rec_in[c.rec_off[j] + int64_t(s >> 1) * 128 + (s & 1)]; };
     auto LKIDX = [&](int j, int s) { return c.rec_off[j] + int64_t((c.kpp[j] >> 1) + (s >> 1)) * 128 + (s & 1); };
     auto NIDX = [&](int part, int i) { return int64_t(part * hv + (i >> 1)) * 128 + (i & 1); };
+    auto LAV = [&](int i) { return synth ? 1.0 : node_in[NIDX(1, i)]; };
 
     // pi(v) (:174-200): assignment ascending, value = cpt * pi-messages in ascending parent order
     if (frozen) {
@@ -195,7 +214,7 @@ __device__ double tile_generic(const BpBuffers& b, const IO& io, const TileDesc&
         for (int ct = 0; ct < kt; ++ct) {
             double acc = 0.0;
             for (int i = 0; i < kv; ++i) {
-                const double times = node_in[NIDX(1, i)];
+                const double times = LAV(i);
                 for (int cond = 0; cond < rows; ++cond) {
                     if ((cond / c.cstride[jt]) % kt != ct) continue;
                     double value = times * CPT(i * rows + cond);
@@ -208,27 +227,27 @@ __device__ double tile_generic(const BpBuffers& b, const IO& io, const TileDesc&
             sum += acc;
         }
         for (int ct = 0; ct < kt; ++ct) {
-            double nv = rec_out[LKIDX(jt, ct)] / sum;
+            const double nv = rec_out[LKIDX(jt, ct)] / sum;
             rec_out[LKIDX(jt, ct)] = nv;
-            wres = res_acc(wres, fabs(nv - rec_in[LKIDX(jt, ct)]));
+            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : rec_in[LKIDX(jt, ct)])));
         }
     }
-    wres = res_acc(wres, parent_role_generic(b, io, td, kv, c.kvp, kWave, lane, true, frozen));
-    return wres;
+    return res_acc(wres, parent_role_generic(b, io, td, kv, c.kvp, lane, frozen));
 }
 
 // ---------------------------------------------------------------------------------------------
 // register-resident tile: node and parents share arity K, M parents, whole CPT (K^(M+1) <= 64
 // doubles) in VGPRs, every loop unrolled at compile time, 16-byte lane-striped loads.
-// RC = children per node held in registers (the tile's cmax <= RC).
+// RC = children per node held in registers (the tile's cmax <= RC; RC = 0: parent role elsewhere).
 // ---------------------------------------------------------------------------------------------
-template <int K, int M, int RC>
+template <int K, int M, int RC, bool NT>
 __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
+    constexpr int CB = (M > 0) ? C / K : 0;  // assignments per lambda bucket and own state
     double wres = 0.0;
     if (lane < td.n_nodes) {
-        // ---- child-role loads: CPT, pi-messages from the parents, lambda(v)
+        // ---- child-role loads: CPT, pi-messages from the parents, pi(v), lambda(v)
         const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
         double cpt[SP];
 #pragma unroll
@@ -241,22 +260,35 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
         double2_t* rout = reinterpret_cast<double2_t*>(io.rec_out + td.rec_base) + lane;
         const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + lane;
         double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + lane;
+        const bool frozen = b.frozen[td.slot_base + lane] != 0;
         double pim[M > 0 ? M : 1][KP];
 #pragma unroll
         for (int j = 0; j < M; ++j)
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const double2_t x = rin[(j * 2 * H + h) * kWave];
-                pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
-            }
+            for (int i = 0; i < KP; ++i) pim[j][i] = 1.0;
+        if (!io.first) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t x = rin[(j * 2 * H + h) * kWave];
+                    pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
+                }
+        }
         double piv[KP], lav[KP];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
-            piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
-            lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+        for (int i = 0; i < KP; ++i) {  // initial state (:38-64): roots start from their CPT row
+            piv[i] = (M == 0 && i < K) ? cpt[i] : 1.0;
+            lav[i] = 1.0;
         }
-        const bool frozen = b.frozen[td.slot_base + lane] != 0;
+        if (!io.first || frozen) {  // evidence nodes hold their vector as pi and lambda (:68-73)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
+                piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
+                lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+            }
+        }
 
         // ---- parent-role loads: out-edge references, then the children's lambda-messages.
         // A missing child reads record 0 and contributes 1.0 (x * 1.0 == x exactly).
@@ -274,7 +306,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
         for (int c = 0; c < RC; ++c) {
 #pragma unroll
             for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
-            if (c < td.cmax) {
+            if (c < td.cmax && !io.first) {
                 const bool has = oref[c].rec >= 0;
                 const int64_t base = has ? oref[c].rec : 0;
                 const int64_t st = has ? oref[c].stride : 0;
@@ -287,98 +319,111 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             }
         }
 
-        // ---- pi(v), calculate_pi (:174-200)
-        {
-            double t[K];
+        // ---- child role.  calculate_pi (:174-200): pi[i] = sum over assignments (ascending) of
+        // cpt * pi-messages (ascending parent order).  calculate_lambda_k (:240-266): bucket
+        // out[jt][ct] receives, own state outer and assignment inner, (lambda[i] * cpt) * the
+        // OTHER parents' pi-messages.  Each accumulator sees its terms in exactly that order;
+        // the K + M*K independent chains are interleaved round-robin.
+        double pin[K];
+        double out[M > 0 ? M : 1][K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
+        for (int jt = 0; jt < M; ++jt)
+#pragma unroll
+            for (int ct = 0; ct < K; ++ct) out[jt][ct] = 0.0;
+#pragma unroll
+        for (int ib = 0; ib < K; ++ib) {  // own state i: the CPT image is i-major
+            if constexpr (M == 0) {
+                pin[ib] = 0.0 + cpt[ib];
+            } else {
                 double acc = 0.0;
+                double tc[C];  // lambda(v)[i] * cpt[cond][i], shared by the M lambda-messages
 #pragma unroll
-                for (int cond = 0; cond < C; ++cond) {
-                    double value = cpt[i * C + cond];
+                for (int c = 0; c < C; ++c) tc[c] = lav[ib] * cpt[ib * C + c];
 #pragma unroll
-                    for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
-                    acc += value;
+                for (int rr = 0; rr < CB; ++rr) {
+#pragma unroll
+                    for (int x = 0; x < K; ++x) {  // pi chain: assignments rr*K .. rr*K+K-1
+                        const int cond = rr * K + x;
+                        double value = cpt[ib * C + cond];
+#pragma unroll
+                        for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                        acc += value;
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < M; ++jt) {
+                        const int stride = ipow(K, M - 1 - jt);
+#pragma unroll
+                        for (int ct = 0; ct < K; ++ct) {  // rr-th assignment whose digit jt equals ct
+                            const int cond = (rr / stride) * stride * K + ct * stride + (rr % stride);
+                            double value = tc[cond];
+#pragma unroll
+                            for (int j = 0; j < M; ++j)
+                                if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                            out[jt][ct] += value;
+                        }
+                    }
                 }
-                t[i] = acc;
-            }
-            normalize_k<K>(t);
-            double o[KP];
-#pragma unroll
-            for (int i = 0; i < KP; ++i) o[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < K; ++i) o[i] = frozen ? piv[i] : t[i];
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t y;
-                y.x = o[2 * h]; y.y = o[2 * h + 1];
-                nout[h * kWave] = y;
+                pin[ib] = acc;
             }
         }
 
-        // ---- lambda-messages to the parents, calculate_lambda_k (:240-266)
+        // ---- parent role: lambda(v) (:220-238), products in ascending child order from 1.0
+        double lan[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double acc = 1.0;
+#pragma unroll
+            for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
+            lan[i] = acc;
+        }
+        // ---- normalise everything (:298-311), residual (:105-131), stores
+        normalize_k<K>(pin);
+        normalize_k<K>(lan);
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt) normalize_k<K>(out[jt]);
+        {
+            double o[KP], l[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) { o[i] = 0.0; l[i] = 0.0; }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {  // evidence nodes keep pi and lambda (:177, :223)
+                o[i] = frozen ? piv[i] : pin[i];
+                l[i] = frozen ? lav[i] : lan[i];
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double2_t y, z;
+                y.x = o[2 * h]; y.y = o[2 * h + 1];
+                z.x = l[2 * h]; z.y = l[2 * h + 1];
+                bn_store<NT>(&nout[h * kWave], y);
+                if (RC > 0) bn_store<NT>(&nout[(H + h) * kWave], z);
+            }
+        }
 #pragma unroll
         for (int jt = 0; jt < M; ++jt) {
-            double out[K];
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) out[ct] = 0.0;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const double times = lav[i];
-#pragma unroll
-                for (int cond = 0; cond < C; ++cond) {
-                    double value = times * cpt[i * C + cond];
-#pragma unroll
-                    for (int j = 0; j < M; ++j)
-                        if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
-                    out[(cond / ipow(K, M - 1 - jt)) % K] += value;
-                }
-            }
-            normalize_k<K>(out);
             double o[KP], old[KP];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {  // previous lambda-message of this edge, for the residual
-                const double2_t y = rin[(jt * 2 * H + H + h) * kWave];
-                old[2 * h] = y.x; old[2 * h + 1] = y.y;
+            for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
+            if (!io.first) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {  // previous lambda-message of this edge, for the residual
+                    const double2_t y = rin[(jt * 2 * H + H + h) * kWave];
+                    old[2 * h] = y.x; old[2 * h + 1] = y.y;
+                }
             }
 #pragma unroll
-            for (int i = 0; i < KP; ++i) o[i] = 0.0;
-#pragma unroll
             for (int i = 0; i < K; ++i) {
-                o[i] = out[i];
-                wres = res_acc(wres, fabs(out[i] - old[i]));
+                o[i] = out[jt][i];
+                wres = res_acc(wres, fabs(out[jt][i] - old[i]));
             }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 double2_t y;
                 y.x = o[2 * h]; y.y = o[2 * h + 1];
-                rout[(jt * 2 * H + H + h) * kWave] = y;
+                bn_store<NT>(&rout[(jt * 2 * H + H + h) * kWave], y);
             }
         }
-
-        // ---- parent role: lambda(v) (:220-238) and pi-messages to the children (:202-218)
-        {
-            double t[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                double acc = 1.0;
-#pragma unroll
-                for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
-                t[i] = acc;
-            }
-            normalize_k<K>(t);
-            double o[KP];
-#pragma unroll
-            for (int i = 0; i < KP; ++i) o[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < K; ++i) o[i] = frozen ? lav[i] : t[i];
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t y;
-                y.x = o[2 * h]; y.y = o[2 * h + 1];
-                nout[(H + h) * kWave] = y;
-            }
-        }
+        // pi-message to child c (:202-218): pi(v) times the OTHER children's lambda-messages
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
             if (c < td.cmax) {  // wave-uniform
@@ -393,47 +438,41 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                 }
                 normalize_k<K>(u);
                 if (oref[c].rec >= 0) {
-                    double o[KP];
+                    double o[KP], old[KP];
 #pragma unroll
-                    for (int i = 0; i < KP; ++i) o[i] = 0.0;
+                    for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
+                    if (!io.first) {
 #pragma unroll
-                    for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
-                        const double2_t x = rec_in2[oref[c].rec + int64_t(h) * oref[c].stride];
-                        if (2 * h < K) wres = res_acc(wres, fabs(u[2 * h] - x.x));
-                        if (2 * h + 1 < K) wres = res_acc(wres, fabs(u[2 * h + 1] - x.y));
+                        for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
+                            const double2_t x = rec_in2[oref[c].rec + int64_t(h) * oref[c].stride];
+                            old[2 * h] = x.x; old[2 * h + 1] = x.y;
+                        }
                     }
 #pragma unroll
-                    for (int i = 0; i < K; ++i) o[i] = u[i];
+                    for (int i = 0; i < K; ++i) {
+                        o[i] = u[i];
+                        wres = res_acc(wres, fabs(u[i] - old[i]));
+                    }
 #pragma unroll
                     for (int h = 0; h < H; ++h) {
                         double2_t y;
                         y.x = o[2 * h]; y.y = o[2 * h + 1];
-                        rec_out2[oref[c].rec + int64_t(h) * oref[c].stride] = y;
+                        bn_store<NT>(&rec_out2[oref[c].rec + int64_t(h) * oref[c].stride], y);
                     }
                 }
             }
         }
+        if constexpr (RC == 0)  // fan-out beyond the register path: parent role through memory
+            wres = res_acc(wres, parent_role_generic(b, io, td, K, KP, lane, frozen));
     }
     return wres;
 }
 
-// Same child role, but the parent role goes through memory (tiles whose nodes have more
-// children than the register path holds).
-template <int K, int M>
-__device__ __forceinline__ double tile_uniform_fanout(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    double wres = tile_uniform<K, M, 0>(b, io, td, lane);
-    if (lane < td.n_nodes) {
-        const bool frozen = b.frozen[td.slot_base + lane] != 0;
-        wres = res_acc(wres, parent_role_generic(b, io, td, K, (K + 1) & ~1, kWave, lane, true, frozen));
-    }
-    return wres;
-}
-
-template <int K, int M>
+template <int K, int M, bool NT>
 __device__ __forceinline__ double tile_uniform_dispatch(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    if (td.cmax <= 2) return tile_uniform<K, M, 2>(b, io, td, lane);
-    if (td.cmax <= 4) return tile_uniform<K, M, 4>(b, io, td, lane);
-    return tile_uniform_fanout<K, M>(b, io, td, lane);
+    if (td.cmax <= 2) return tile_uniform<K, M, 2, NT>(b, io, td, lane);
+    if (td.cmax <= 4) return tile_uniform<K, M, 4, NT>(b, io, td, lane);
+    return tile_uniform<K, M, 0, NT>(b, io, td, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,7 +494,7 @@ __device__ __forceinline__ int logical_block() {
 __device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) {
     const BpBuffers& b = a.b;
     if (a.sweep > 0) {
-        const double r = previous_residual(b, a.sweep - 1, lane);
+        const double r = reduce_residual(b, a.sweep - 1, lane);
         if (lane == 0) {
             if (a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
             if (r < a.eps) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
@@ -466,89 +505,70 @@ __device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) 
     for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a) {
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (__hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    const int lb = logical_block();
-    const int tile = lb * kWavesPerBlock + wave;
+    const int tile = logical_block() * kWavesPerBlock + wave;
     if (tile >= b.n_tiles) {
         if (tile == a.book_tile) sweep_bookkeeping(a, lane);
         return;
     }
-    const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out};
+    const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
     const TileDesc td = b.tiles[tile];
-    double wres;
+    double wres = 0.0;
+    bool handled = false;
     if (td.variant == kVariantUniform) {
+        handled = true;
         switch (td.kv * 8 + td.m) {
-            case 2 * 8 + 0: wres = tile_uniform_dispatch<2, 0>(b, io, td, lane); break;
-            case 2 * 8 + 1: wres = tile_uniform_dispatch<2, 1>(b, io, td, lane); break;
-            case 2 * 8 + 2: wres = tile_uniform_dispatch<2, 2>(b, io, td, lane); break;
-            case 2 * 8 + 3: wres = tile_uniform_dispatch<2, 3>(b, io, td, lane); break;
-            case 2 * 8 + 4: wres = tile_uniform_dispatch<2, 4>(b, io, td, lane); break;
-            case 3 * 8 + 0: wres = tile_uniform_dispatch<3, 0>(b, io, td, lane); break;
-            case 3 * 8 + 1: wres = tile_uniform_dispatch<3, 1>(b, io, td, lane); break;
-            case 3 * 8 + 2: wres = tile_uniform_dispatch<3, 2>(b, io, td, lane); break;
-            case 4 * 8 + 0: wres = tile_uniform_dispatch<4, 0>(b, io, td, lane); break;
-            case 4 * 8 + 1: wres = tile_uniform_dispatch<4, 1>(b, io, td, lane); break;
-            case 4 * 8 + 2: wres = tile_uniform_dispatch<4, 2>(b, io, td, lane); break;
-            default: wres = tile_generic(b, io, td, b.classes[td.cls], lane); break;
+            case 2 * 8 + 0: wres = tile_uniform_dispatch<2, 0, NT>(b, io, td, lane); break;
+            case 2 * 8 + 1: wres = tile_uniform_dispatch<2, 1, NT>(b, io, td, lane); break;
+            case 2 * 8 + 2: wres = tile_uniform_dispatch<2, 2, NT>(b, io, td, lane); break;
+            case 2 * 8 + 3: wres = tile_uniform_dispatch<2, 3, NT>(b, io, td, lane); break;
+            case 2 * 8 + 4: wres = tile_uniform_dispatch<2, 4, NT>(b, io, td, lane); break;
+            case 3 * 8 + 0: wres = tile_uniform_dispatch<3, 0, NT>(b, io, td, lane); break;
+            case 3 * 8 + 1: wres = tile_uniform_dispatch<3, 1, NT>(b, io, td, lane); break;
+            case 3 * 8 + 2: wres = tile_uniform_dispatch<3, 2, NT>(b, io, td, lane); break;
+            case 4 * 8 + 0: wres = tile_uniform_dispatch<4, 0, NT>(b, io, td, lane); break;
+            case 4 * 8 + 1: wres = tile_uniform_dispatch<4, 1, NT>(b, io, td, lane); break;
+            case 4 * 8 + 2: wres = tile_uniform_dispatch<4, 2, NT>(b, io, td, lane); break;
+            default: handled = false; break;
         }
-    } else {
-        wres = tile_generic(b, io, td, b.classes[td.cls], lane);
     }
+    if (!handled) wres = tile_generic(b, io, td, b.classes[td.cls], lane);
     publish_residual(b, a.sweep, tile, wres, lane);
 }
 
-// Initial state, belief_propagation.hpp:33-65 : every message and node vector 1.0, roots take
-// their (un-normalised) CPT row as pi, nothing is frozen; also resets the run's control state.
-__global__ __launch_bounds__(kBlockThreads) void bp_init_kernel(BpBuffers b) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+// Start of a run: reset the control block and the residual ring, then apply the evidence
+// (belief_propagation.hpp:68-73): pi(v) = lambda(v) = the given vector in the buffer iteration 0
+// reads, node marked (preconditional_node_).  `frozen` is all-zero on entry (the previous run's
+// finish kernel cleared its own marks).
+__global__ __launch_bounds__(kBlockThreads) void bp_begin_kernel(EvidenceArgs a) {
+    const BpBuffers& b = a.b;
     if (blockIdx.x == 0) {
         for (int q = threadIdx.x; q < kResRows * kResSlots; q += kBlockThreads) b.res_slots[q] = 0ull;
         if (threadIdx.x == 0) { b.ctl->done = 0; b.ctl->n_sweeps = 0; b.ctl->last_res = 0.0; }
     }
-    const int tile = blockIdx.x * kWavesPerBlock + wave;
-    if (tile >= b.n_tiles) return;
-    const TileDesc td = b.tiles[tile];
-    const ClassDesc& c = b.classes[td.cls];
-    double* rec = b.rec0 + td.rec_base;
-    for (int q = lane; q < c.rec_doubles; q += kWave) rec[q] = 1.0;
-    double* node = b.node0 + td.node_base;
-    const int nd = 2 * c.kvp * c.npt;
-    for (int q = lane; q < nd; q += kWave) node[q] = 1.0;
-    for (int q = lane; q < c.npt; q += kWave) b.frozen[td.slot_base + q] = 0;
-    if (c.m == 0) {  // root: pi = cpt[{}] as stored (:58-64); G == 1 for roots
-        if (lane < td.n_nodes)
-            for (int i = 0; i < c.kv; ++i)
-                node[int64_t(i >> 1) * (c.npt * 2) + lane * 2 + (i & 1)] =
-                    b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + lane * 2 + (i & 1)];
-    }
-}
-
-// Evidence, belief_propagation.hpp:68-73: pi(v) = lambda(v) = the given vector, node marked.
-__global__ void bp_evidence_kernel(EvidenceArgs a) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.ne) return;
-    const BpBuffers& b = a.b;
     const int v = a.ev_node[j];
     const TileDesc td = b.tiles[b.node_tile[v]];
-    const ClassDesc& c = b.classes[td.cls];
     const int nl = b.node_nl[v];
     double* node = b.node0 + td.node_base;
-    const int half = c.kvp >> 1;
-    for (int i = 0; i < c.kv; ++i) {
+    const int half = ((td.kv + 1) & ~1) >> 1;
+    for (int i = 0; i < td.kv; ++i) {
         const double x = a.ev_val[a.ev_off[j] + i];
-        node[int64_t(i >> 1) * (c.npt * 2) + nl * 2 + (i & 1)] = x;
-        node[int64_t(half + (i >> 1)) * (c.npt * 2) + nl * 2 + (i & 1)] = x;
+        node[vidx(0, i, td.npt, nl)] = x;
+        node[vidx(half, i, td.npt, nl)] = x;
     }
     b.frozen[td.slot_base + nl] = 1;
 }
 
 // After a batch of sweeps: settle the last launched sweep's residual, and once the run is over
-// (converged, or max_sweeps reached) write belief = normalize(pi % lambda) (:151-158).
+// (converged, or max_sweeps reached) write belief = normalize(pi % lambda) (:151-158) and clear
+// this run's evidence marks.
 __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) {
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
@@ -559,7 +579,7 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     if (done != 0) {
         n_sweeps = b.ctl->n_sweeps;
     } else {
-        const double r = previous_residual(b, a.sweeps_launched - 1, lane);
+        const double r = reduce_residual(b, a.sweeps_launched - 1, lane);
         if (lead && a.sweeps_launched - 1 < b.res_cap) b.res_hist[a.sweeps_launched - 1] = r;
         n_sweeps = a.sweeps_launched;
         if (r < a.eps) done = 1;
@@ -567,23 +587,25 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
         if (lead) { b.ctl->last_res = r; b.ctl->n_sweeps = n_sweeps; b.ctl->done = done; }
     }
     if (done == 0) return;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = gid; j < a.ne; j += gridDim.x * blockDim.x) {
+        const int v = a.ev_node[j];
+        b.frozen[b.tiles[b.node_tile[v]].slot_base + b.node_nl[v]] = 0;
+    }
     const int tile = blockIdx.x * kWavesPerBlock + wave;
     if (tile >= b.n_tiles) return;
     const TileDesc td = b.tiles[tile];
-    const ClassDesc& c = b.classes[td.cls];
     if (lane >= td.n_nodes) return;  // one lane per node writes the belief
     const double* node = ((n_sweeps & 1) ? b.node1 : b.node0) + td.node_base;
     const int64_t boff = b.slot_boff[td.slot_base + lane];
-    const int half = c.kvp >> 1;
+    const int half = ((td.kv + 1) & ~1) >> 1;
     double sum = 0;
-    for (int i = 0; i < c.kv; ++i) {
-        const double p = node[int64_t(i >> 1) * (c.npt * 2) + lane * 2 + (i & 1)];
-        const double l = node[int64_t(half + (i >> 1)) * (c.npt * 2) + lane * 2 + (i & 1)];
-        const double x = p * l;
+    for (int i = 0; i < td.kv; ++i) {
+        const double x = node[vidx(0, i, td.npt, lane)] * node[vidx(half, i, td.npt, lane)];
         b.beliefs[boff + i] = x;
         sum += x;
     }
-    for (int i = 0; i < c.kv; ++i) b.beliefs[boff + i] = b.beliefs[boff + i] / sum;
+    for (int i = 0; i < td.kv; ++i) b.beliefs[boff + i] = b.beliefs[boff + i] / sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,17 +613,16 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
 // ---------------------------------------------------------------------------------------------
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : int(e); }
 
-int launch_bp_init(const BpBuffers& b, int grid_blocks, void* stream) {
-    hipLaunchKernelGGL(bp_init_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, b);
+int launch_bp_begin(const EvidenceArgs& a, void* stream) {
+    const int blocks = a.ne > 0 ? (a.ne + kBlockThreads - 1) / kBlockThreads : 1;
+    hipLaunchKernelGGL(bp_begin_kernel, dim3(blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }
-int launch_bp_evidence(const EvidenceArgs& a, void* stream) {
-    if (a.ne <= 0) return 0;
-    hipLaunchKernelGGL(bp_evidence_kernel, dim3((a.ne + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    return hip_rc(hipGetLastError());
-}
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, void* stream) {
-    hipLaunchKernelGGL(bp_sweep_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream) {
+    if (nontemporal)
+        hipLaunchKernelGGL(bp_sweep_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(bp_sweep_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }
 int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream) {

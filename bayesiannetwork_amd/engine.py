@@ -51,20 +51,29 @@ class Engine:
         self.close()
 
     # ---- belief propagation ------------------------------------------------------------
-    def bp_run(self, evidence: Evidence | None = None, eps: float = 0.001, max_sweeps: int = 0,
-               copy_beliefs: bool = True):
+    def bp_set_evidence(self, evidence: Evidence | None = None) -> None:
+        """Validate + upload an evidence set once (bn_bp_set_evidence); it stays resident in HBM."""
         ev = evidence if evidence is not None else Evidence.none()
-        L = _lib.lib()
+        _lib.check(_lib.lib().bn_bp_set_evidence(self._h, ev.ne, _p(ev.node, ctypes.c_int32),
+                                                 _p(ev.off, ctypes.c_int32), _p(ev.val, ctypes.c_double)))
+
+    def bp_run_device(self, eps: float = 0.001, max_sweeps: int = 0):
+        """Run on the staged evidence; beliefs stay in device memory (bn_bp_run_device)."""
         sweeps = ctypes.c_int32(0)
         res = ctypes.c_double(0.0)
-        args = (self._h, ev.ne, _p(ev.node, ctypes.c_int32), _p(ev.off, ctypes.c_int32), _p(ev.val, ctypes.c_double),
-                float(eps), int(max_sweeps))
-        if copy_beliefs:
-            bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
-            _lib.check(L.bn_bp_run(*args, _p(bel, ctypes.c_double), ctypes.byref(sweeps), ctypes.byref(res)))
-        else:
-            bel = None
-            _lib.check(L.bn_bp_run_device(*args, ctypes.byref(sweeps), ctypes.byref(res)))
+        _lib.check(_lib.lib().bn_bp_run_device(self._h, float(eps), int(max_sweeps), ctypes.byref(sweeps),
+                                               ctypes.byref(res)))
+        return {"beliefs": None, "sweeps": sweeps.value, "residual": res.value}
+
+    def bp_run(self, evidence: Evidence | None = None, eps: float = 0.001, max_sweeps: int = 0):
+        """Evidence in, host beliefs out (bn_bp_run)."""
+        ev = evidence if evidence is not None else Evidence.none()
+        sweeps = ctypes.c_int32(0)
+        res = ctypes.c_double(0.0)
+        bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
+        _lib.check(_lib.lib().bn_bp_run(self._h, ev.ne, _p(ev.node, ctypes.c_int32), _p(ev.off, ctypes.c_int32),
+                                        _p(ev.val, ctypes.c_double), float(eps), int(max_sweeps),
+                                        _p(bel, ctypes.c_double), ctypes.byref(sweeps), ctypes.byref(res)))
         return {"beliefs": bel, "sweeps": sweeps.value, "residual": res.value}
 
     def bp_beliefs(self) -> np.ndarray:

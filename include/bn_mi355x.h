@@ -80,10 +80,16 @@ int bn_bp_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t 
               const double *ev_val, double eps, int32_t max_sweeps, double *beliefs_out,
               int32_t *sweeps_out, double *residual_out);
 
-/* Same, but the beliefs stay in device memory (bn_bp_beliefs_device); nothing is copied back
- * except the sweep count and residual.  This is the HBM-resident path bench.py times. */
-int bn_bp_run_device(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_off,
-                     const double *ev_val, double eps, int32_t max_sweeps, int32_t *sweeps_out,
+/*
+ * The same in two steps, for callers that keep inputs and outputs resident in HBM (bench.py times
+ * this path): bn_bp_set_evidence validates and uploads an evidence set once; bn_bp_run_device
+ * runs belief propagation on it -- any number of times -- and leaves the beliefs in device
+ * memory (bn_bp_beliefs_device, node-major [sum k]); only the sweep count and the last
+ * maximum_difference come back.  bn_bp_run == set_evidence + run_device + copy_beliefs.
+ */
+int bn_bp_set_evidence(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_off,
+                       const double *ev_val);
+int bn_bp_run_device(bn_engine *eng, double eps, int32_t max_sweeps, int32_t *sweeps_out,
                      double *residual_out);
 const double *bn_bp_beliefs_device(bn_engine *eng);
 int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
@@ -97,7 +103,7 @@ typedef struct bn_bp_stats {
     int32_t sweeps;            /* iterations of the last run                                */
     int32_t sweep_launches;    /* sweep kernels launched (>= sweeps; extras exit at once)    */
     float sweep_kernel_ms;     /* HIP-event time over all sweep launches of the last run     */
-    float total_ms;            /* HIP-event time init -> beliefs of the last run             */
+    float total_ms;            /* host wall time of the last bn_bp_run_device call           */
     int64_t algorithmic_bytes_per_sweep; /* SURVEY.md 8(d) formula                           */
     int64_t layout_bytes_per_sweep;      /* bytes the sweep kernel actually requests         */
     int64_t messages_per_sweep;          /* 2E                                              */
