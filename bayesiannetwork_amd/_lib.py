@@ -38,12 +38,19 @@ class LayoutInfo(ctypes.Structure):
                 ("n_tiles", ctypes.c_int32), ("lanes_per_node_max", ctypes.c_int32),
                 ("cpt_doubles", ctypes.c_int64), ("rec_doubles", ctypes.c_int64), ("node_doubles", ctypes.c_int64),
                 ("algorithmic_bytes_per_sweep", ctypes.c_int64), ("layout_bytes_per_sweep", ctypes.c_int64),
-                ("messages_per_sweep", ctypes.c_int64)]
+                ("messages_per_sweep", ctypes.c_int64), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
+                ("n_owned", ctypes.c_int32), ("pad_", ctypes.c_int32), ("n_cut_edges", ctypes.c_int64),
+                ("segment_bytes", ctypes.c_int64), ("segment_used_bytes", ctypes.c_int64),
+                ("exchange_base", ctypes.c_int64)]
 
 
 # every symbol include/bn_mi355x.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("bn_create", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.POINTER(ctypes.c_void_p)]),
+    ("bn_create_sharded", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int32, ctypes.c_int32, i32p,
+                                         ctypes.POINTER(ctypes.c_void_p)]),
+    ("bn_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
+    ("bn_comm_init", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("bn_destroy", None, [ctypes.c_void_p]),
     ("bn_last_error", ctypes.c_char_p, []),
     ("bn_version", ctypes.c_char_p, []),
@@ -55,11 +62,17 @@ SYMBOLS = [
     ("bn_bp_copy_beliefs", ctypes.c_int, [ctypes.c_void_p, f64p]),
     ("bn_bp_residual_history", ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int32]),
     ("bn_bp_messages", ctypes.c_int, [ctypes.c_void_p, f64p, f64p]),
+    ("bn_bp_step_begin", ctypes.c_int, [ctypes.c_void_p]),
+    ("bn_bp_step_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double]),
+    ("bn_bp_step_finish", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, i32p, i32p,
+                                         f64p]),
+    ("bn_debug_allgather", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32]),
     ("bn_bp_last_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(BpStats)]),
     ("bn_lw_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, ctypes.c_uint64,
                                  ctypes.c_uint64, f64p]),
     ("bn_lw_states", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, u8p, f64p]),
     ("bn_layout_get", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LayoutInfo)]),
+    ("bn_layout_edge_refs", ctypes.c_int, [ctypes.c_void_p, i32p, i32p]),
     ("bn_layout_node_slots", ctypes.c_int, [ctypes.c_void_p, i32p]),
     ("bn_layout_class", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, i32p, i32p, i32p]),
 ]

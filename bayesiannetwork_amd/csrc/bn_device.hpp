@@ -7,8 +7,6 @@
 
 namespace bnmi {
 
-constexpr int kResSlots = 256;   // per-sweep residual slots (spread the atomics)
-constexpr int kResRows = 3;      // ring: row (s-1) is read, row s is accumulated, row (s+1) is zeroed
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
 
@@ -28,13 +26,16 @@ struct BpBuffers {
     double* rec1;        //   kernarg array forces the whole struct into scratch memory)
     double* node0;       // double-buffered pi / lambda node vectors
     double* node1;
-    const OutRef* out_refs;
+    const MsgRef* out_refs;
+    const MsgRef* in_refs;
     uint8_t* frozen;     // per lane-slot evidence marker (preconditional_node_, :69)
     const int32_t* slot_node;
     const int64_t* slot_boff;
     const int32_t* node_tile;
     const int32_t* node_nl;
-    unsigned long long* res_slots;  // [kResRows][kResSlots] bit patterns of non-negative doubles
+    // exchange region of the record buffers (bn_plan.hpp), double2 units
+    int64_t g_base, seg_d2, seg_data_d2;
+    int32_t rank, nranks;
     double* res_hist;
     int32_t res_cap;
     Ctl* ctl;

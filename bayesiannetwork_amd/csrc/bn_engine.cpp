@@ -11,6 +11,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is loaded lazily with dlopen (no link dependency)
+
 #include "bn_device.hpp"
 #include "bn_lw.hpp"
 
@@ -30,6 +33,37 @@ static int fail(int code, const std::string& msg) {
             return fail(BN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
     } while (0)
 
+// RCCL entry points, resolved at the first bn_comm_* call.  In a process that already loaded
+// librccl.so.1 (e.g. through torch) the same copy is reused.
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl() {
+    if (g_rccl.handle) return BN_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(BN_ERR_COMM, std::string("cannot load librccl: ") + dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString)
+        return fail(BN_ERR_COMM, "librccl lacks a required symbol");
+    g_rccl = a;
+    return BN_OK;
+}
+
 struct bn_engine {
     Plan plan;
     bool host_only = true;
@@ -41,13 +75,14 @@ struct bn_engine {
     double* d_cpt = nullptr;
     double* d_rec[2] = {nullptr, nullptr};
     double* d_node[2] = {nullptr, nullptr};
-    OutRef* d_out = nullptr;
+    MsgRef* d_out = nullptr;
+    MsgRef* d_inrefs = nullptr;
+    ncclComm_t comm = nullptr;
     uint8_t* d_frozen = nullptr;
     int32_t* d_slot_node = nullptr;
     int64_t* d_slot_boff = nullptr;
     int32_t* d_node_tile = nullptr;
     int32_t* d_node_nl = nullptr;
-    unsigned long long* d_res_slots = nullptr;
     double* d_res_hist = nullptr;
     Ctl* d_ctl = nullptr;
     double* d_beliefs = nullptr;
@@ -79,9 +114,10 @@ static void free_engine(bn_engine* e) {
     if (!e->host_only) {
         (void)hipSetDevice(e->device);
         lw_free(e->lw);
+        if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_res_slots, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev};
+                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -109,14 +145,14 @@ static int dalloc(T** dst, size_t count) {
 extern "C" const char* bn_last_error(void) { return g_err.c_str(); }
 extern "C" const char* bn_version(void) { return "bn_mi355x 0.1 (gfx950)"; }
 
-extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) {
+static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_engine** out) {
     if (!desc || !out) return fail(BN_ERR_ARG, "null argument");
     *out = nullptr;
     bn_engine* e = new (std::nothrow) bn_engine();
     if (!e) return fail(BN_ERR_ALLOC, "out of host memory");
     std::string err;
     try {
-        err = build_plan(*desc, e->plan);
+        err = build_plan(*desc, shard, e->plan);
     } catch (const std::bad_alloc&) {
         delete e;
         return fail(BN_ERR_ALLOC, "out of host memory while building the layout plan");
@@ -156,24 +192,25 @@ extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) {
         if ((r = upload(&e->d_classes, p.classes, e->stream))) return r;
         if ((r = upload(&e->d_cpt, p.cpt_striped, e->stream))) return r;
         if ((r = upload(&e->d_out, p.out_refs, e->stream))) return r;
+        if ((r = upload(&e->d_inrefs, p.in_refs, e->stream))) return r;
         if ((r = upload(&e->d_slot_node, p.slot_node, e->stream))) return r;
         if ((r = upload(&e->d_slot_boff, p.slot_boff, e->stream))) return r;
         if ((r = upload(&e->d_node_tile, p.node_tile, e->stream))) return r;
         if ((r = upload(&e->d_node_nl, p.node_nl, e->stream))) return r;
         for (int i = 0; i < 2; ++i) {
-            if ((r = dalloc(&e->d_rec[i], size_t(p.rec_doubles)))) return r;
+            if ((r = dalloc(&e->d_rec[i], size_t(p.rec_total_doubles)))) return r;
             if ((r = dalloc(&e->d_node[i], size_t(p.node_doubles)))) return r;
-            HIPCHK(hipMemsetAsync(e->d_rec[i], 0, std::max<size_t>(p.rec_doubles, 1) * 8, e->stream));
+            HIPCHK(hipMemsetAsync(e->d_rec[i], 0, std::max<size_t>(p.rec_total_doubles, 1) * 8, e->stream));
             HIPCHK(hipMemsetAsync(e->d_node[i], 0, std::max<size_t>(p.node_doubles, 1) * 8, e->stream));
         }
         if ((r = dalloc(&e->d_frozen, size_t(p.n_slots)))) return r;
         HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), e->stream));
         // store policy: working sets beyond the Infinity Cache stream their outputs non-temporally
         e->nontemporal = 8 * (p.cpt_doubles + 2 * p.rec_doubles + 2 * p.node_doubles) > (int64_t(192) << 20);
-        if ((r = dalloc(&e->d_res_slots, size_t(kResRows * kResSlots)))) return r;
         if ((r = dalloc(&e->d_res_hist, size_t(e->res_cap)))) return r;
         if ((r = dalloc(&e->d_ctl, 1))) return r;
         if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
+        HIPCHK(hipMemsetAsync(e->d_beliefs, 0, std::max<size_t>(p.node_off[p.n], 1) * 8, e->stream));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocDefault));
         HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
@@ -187,6 +224,17 @@ extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) {
     }
     *out = e;
     return BN_OK;
+}
+
+extern "C" int bn_create(const bn_model_desc* desc, bn_engine** out) { return create_impl(desc, ShardSpec(), out); }
+
+extern "C" int bn_create_sharded(const bn_model_desc* desc, int32_t rank, int32_t nranks, const int32_t* owner,
+                                 bn_engine** out) {
+    ShardSpec sh;
+    sh.rank = rank;
+    sh.nranks = nranks;
+    sh.owner = owner;
+    return create_impl(desc, sh, out);
 }
 
 extern "C" void bn_destroy(bn_engine* eng) { free_engine(eng); }
@@ -205,7 +253,12 @@ static BpBuffers buffers_of(bn_engine* e) {
     b.slot_boff = e->d_slot_boff;
     b.node_tile = e->d_node_tile;
     b.node_nl = e->d_node_nl;
-    b.res_slots = e->d_res_slots;
+    b.in_refs = e->d_inrefs;
+    b.g_base = e->plan.g_base;
+    b.seg_d2 = e->plan.seg_d2;
+    b.seg_data_d2 = e->plan.seg_data_d2;
+    b.rank = e->plan.rank;
+    b.nranks = e->plan.nranks;
     b.res_hist = e->d_res_hist;
     b.res_cap = e->res_cap;
     b.ctl = e->d_ctl;
@@ -275,64 +328,179 @@ extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_no
     return BN_OK;
 }
 
-extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
-                                double* residual_out) {
-    if (!e) return fail(BN_ERR_ARG, "null engine");
-    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
-    if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
+// ---- the four steps of a run; bn_bp_run_device chains them, the bn_bp_step_* entry points
+// expose them one by one (tests drive several shards on one GPU with an emulated all-gather).
+static int step_begin(bn_engine* e) {
     const Plan& p = e->plan;
-    const auto t_begin = std::chrono::steady_clock::now();
-    HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
-    BpBuffers b = buffers_of(e);
     if (e->frozen_dirty) {  // a previous run ended abnormally: restore the all-clear invariant
         HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), s));
         e->frozen_dirty = false;
     }
     e->frozen_dirty = true;
-    EvidenceArgs ea{b, e->ev_ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
+    EvidenceArgs ea{buffers_of(e), e->ev_ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
     if (launch_bp_begin(ea, s)) return fail(BN_ERR_HIP, "bp_begin launch failed");
+    return BN_OK;
+}
 
+static int step_sweep(bn_engine* e, int32_t sweep, double eps) {
+    const int cur = sweep & 1;
+    SweepArgs sa{buffers_of(e), e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, sweep,
+                 int32_t(e->plan.tiles.size())};
+    if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, e->stream)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
+    return BN_OK;
+}
+
+// Halo exchange after sweep `sweep`: in-place all-gather of every rank's segment of the buffer
+// that sweep wrote.  One collective per sweep; it also carries the residual slots.
+static int step_exchange(bn_engine* e, int32_t sweep) {
+    const Plan& p = e->plan;
+    if (p.nranks == 1) return BN_OK;
+    if (!e->comm) return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init before running");
+    double* g = e->d_rec[(sweep + 1) & 1] + 2 * p.g_base;
+    const size_t count = size_t(2 * p.seg_d2);
+    ncclResult_t rc = g_rccl.AllGather(g + size_t(p.rank) * count, g, count, ncclDouble, e->comm, e->stream);
+    if (rc != ncclSuccess) return fail(BN_ERR_COMM, std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc));
+    return BN_OK;
+}
+
+static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps) {
+    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->ev_ne, e->d_ev_node};
+    if (launch_bp_finish(fa, e->grid_tiles, e->stream)) return fail(BN_ERR_HIP, "bp_finish launch failed");
+    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, e->stream));
+    return BN_OK;
+}
+
+static void note_run_result(bn_engine* e) {
+    e->frozen_dirty = false;  // the finish kernel cleared this run's evidence marks
+    e->last_ctl = *e->h_ctl;
+    e->have_run = true;
+    e->predicted_sweeps = e->last_ctl.n_sweeps;
+    e->stats.sweeps = e->last_ctl.n_sweeps;
+}
+
+extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
+                                double* residual_out) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
+    if (e->plan.nranks > 1 && !e->comm) return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init before running");
+    const auto t_begin = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t s = e->stream;
     int rc;
+    if ((rc = step_begin(e))) return rc;
     int32_t launched = 0, batches = 0;
+    // every rank takes the same decisions: they all see the same sweep counts
     int32_t batch = e->predicted_sweeps > 0 ? e->predicted_sweeps : 8;
     for (;;) {
         if (max_sweeps > 0) batch = std::min(batch, max_sweeps - launched);
         if ((rc = ensure_events(e, 2 * size_t(batches + 1)))) return rc;
         HIPCHK(hipEventRecord(e->events[2 * batches], s));
         for (int32_t i = 0; i < batch; ++i) {
-            const int cur = (launched + i) & 1;
-            SweepArgs sa{b, e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, launched + i,
-                         int32_t(p.tiles.size())};
-            if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, s)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
+            if ((rc = step_sweep(e, launched + i, eps))) return rc;
+            if ((rc = step_exchange(e, launched + i))) return rc;
         }
         launched += batch;
         HIPCHK(hipEventRecord(e->events[2 * batches + 1], s));
         ++batches;
-        FinishArgs fa{b, eps, launched, (max_sweeps > 0 && launched >= max_sweeps) ? 1 : 0, e->ev_ne, e->d_ev_node};
-        if (launch_bp_finish(fa, e->grid_tiles, s)) return fail(BN_ERR_HIP, "bp_finish launch failed");
-        HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s));
+        if ((rc = step_finish(e, launched, max_sweeps > 0 && launched >= max_sweeps, eps))) return rc;
         HIPCHK(hipStreamSynchronize(s));
         if (e->h_ctl->done != 0) break;
         batch = 8;
     }
-    e->frozen_dirty = false;  // the finish kernel cleared this run's evidence marks
-    e->last_ctl = *e->h_ctl;
-    e->have_run = true;
-    e->predicted_sweeps = e->last_ctl.n_sweeps;
+    note_run_result(e);
     float ms = 0.f;
     for (int32_t i = 0; i < batches; ++i) {
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, e->events[2 * i], e->events[2 * i + 1]));
         ms += t;
     }
-    e->stats.sweeps = e->last_ctl.n_sweeps;
     e->stats.sweep_launches = launched;
     e->stats.sweep_kernel_ms = ms;
     e->stats.total_ms =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
     if (residual_out) *residual_out = e->last_ctl.last_res;
+    return BN_OK;
+}
+
+// ---- single steps (diagnostics / tests) -------------------------------------------------------
+extern "C" int bn_bp_step_begin(bn_engine* e) {
+    if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
+    HIPCHK(hipSetDevice(e->device));
+    return step_begin(e);
+}
+extern "C" int bn_bp_step_sweep(bn_engine* e, int32_t sweep, double eps) {
+    if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
+    HIPCHK(hipSetDevice(e->device));
+    return step_sweep(e, sweep, eps);
+}
+extern "C" int bn_bp_step_finish(bn_engine* e, int32_t launched, int32_t final_batch, double eps, int32_t* done_out,
+                                 int32_t* sweeps_out, double* residual_out) {
+    if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
+    HIPCHK(hipSetDevice(e->device));
+    int rc = step_finish(e, launched, final_batch != 0, eps);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (done_out) *done_out = e->h_ctl->done;
+    if (sweeps_out) *sweeps_out = e->h_ctl->n_sweeps;
+    if (residual_out) *residual_out = e->h_ctl->last_res;
+    if (e->h_ctl->done != 0) note_run_result(e);
+    return BN_OK;
+}
+// Emulates the per-sweep all-gather between `n` shard engines that live on ONE device (tests on
+// a single-GPU box): every engine's own segment of the buffer written by `sweep` is copied into
+// all the others.  The data path proper uses RCCL (step_exchange).
+extern "C" int bn_debug_allgather(bn_engine** engs, int32_t n, int32_t sweep) {
+    if (!engs || n < 1) return fail(BN_ERR_ARG, "bad argument");
+    for (int32_t i = 0; i < n; ++i)
+        if (!engs[i] || engs[i]->host_only || engs[i]->plan.nranks != n || engs[i]->plan.rank != i)
+            return fail(BN_ERR_ARG, "engine i must be shard i of n on a device");
+    const int buf = (sweep + 1) & 1;
+    for (int32_t i = 0; i < n; ++i) HIPCHK(hipStreamSynchronize(engs[i]->stream));
+    const Plan& p0 = engs[0]->plan;
+    const size_t seg_bytes = size_t(p0.seg_d2) * 16;
+    for (int32_t src = 0; src < n; ++src)
+        for (int32_t dst = 0; dst < n; ++dst) {
+            if (src == dst) continue;
+            const Plan& ps = engs[src]->plan;
+            const Plan& pd = engs[dst]->plan;
+            if (ps.seg_d2 != pd.seg_d2) return fail(BN_ERR_ARG, "shards disagree on the segment size");
+            const char* from = reinterpret_cast<const char*>(engs[src]->d_rec[buf] + 2 * ps.g_base) + size_t(src) * seg_bytes;
+            char* to = reinterpret_cast<char*>(engs[dst]->d_rec[buf] + 2 * pd.g_base) + size_t(src) * seg_bytes;
+            HIPCHK(hipMemcpy(to, from, seg_bytes, hipMemcpyDeviceToDevice));
+        }
+    HIPCHK(hipDeviceSynchronize());
+    return BN_OK;
+}
+
+// ---- RCCL communicator ---------------------------------------------------------------------------
+extern "C" int bn_comm_unique_id(void* id_out128) {
+    if (!id_out128) return fail(BN_ERR_ARG, "null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(BN_ERR_COMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+    std::memcpy(id_out128, &id, sizeof id);
+    return BN_OK;
+}
+
+extern "C" int bn_comm_init(bn_engine* e, const void* id128) {
+    if (!e || !id128) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only) return fail(BN_ERR_STATE, "host-only engine");
+    int rc = load_rccl();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    if (e->comm) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclResult_t r = g_rccl.CommInitRank(&e->comm, e->plan.nranks, id, e->plan.rank);
+    if (r != ncclSuccess) {
+        e->comm = nullptr;
+        return fail(BN_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
     return BN_OK;
 }
 
@@ -372,8 +540,8 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
     if (!e || !pi_msg_out || !lambda_msg_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
     HIPCHK(hipSetDevice(e->device));
-    std::vector<double> rec(std::max<int64_t>(e->plan.rec_doubles, 1));
-    HIPCHK(hipMemcpy(rec.data(), e->d_rec[e->last_ctl.n_sweeps & 1], sizeof(double) * e->plan.rec_doubles,
+    std::vector<double> rec(std::max<int64_t>(e->plan.rec_total_doubles, 1));
+    HIPCHK(hipMemcpy(rec.data(), e->d_rec[e->last_ctl.n_sweeps & 1], sizeof(double) * e->plan.rec_total_doubles,
                      hipMemcpyDeviceToHost));
     unstripe_messages(e->plan, rec, pi_msg_out, lambda_msg_out);
     return BN_OK;
@@ -400,12 +568,25 @@ extern "C" int bn_layout_get(bn_engine* e, bn_layout_info* o) {
     o->algorithmic_bytes_per_sweep = p.algorithmic_bytes;
     o->layout_bytes_per_sweep = p.layout_bytes;
     o->messages_per_sweep = p.messages_per_sweep;
+    o->rank = p.rank;
+    o->nranks = p.nranks;
+    o->n_owned = p.n_owned;
+    o->n_cut_edges = p.n_cut_edges;
+    o->segment_bytes = p.seg_d2 * 16;
+    o->segment_used_bytes = p.seg_used_d2.empty() ? 0 : p.seg_used_d2[p.rank] * 16;
+    o->exchange_base = p.g_base;
     return BN_OK;
 }
 
 extern "C" int bn_layout_node_slots(bn_engine* e, int32_t* slots_out) {
     if (!e || !slots_out) return fail(BN_ERR_ARG, "null argument");
     std::copy(e->plan.node_slot.begin(), e->plan.node_slot.end(), slots_out);
+    return BN_OK;
+}
+
+extern "C" int bn_layout_edge_refs(bn_engine* e, int32_t* pi_out, int32_t* lam_out) {
+    if (!e || !pi_out || !lam_out) return fail(BN_ERR_ARG, "null argument");
+    for (int64_t i = 0; i < e->plan.E; ++i) { pi_out[i] = e->plan.edge_ref[i].pi; lam_out[i] = e->plan.edge_ref[i].lam; }
     return BN_OK;
 }
 

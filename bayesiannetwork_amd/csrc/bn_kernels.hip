@@ -79,26 +79,53 @@ __device__ __forceinline__ void normalize_k(double (&t)[K]) {  // :298-311, no z
 
 __host__ __device__ constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 
-// Reduce one sweep's residual slots; returns that sweep's maximum_difference.
-__device__ __forceinline__ double reduce_residual(const BpBuffers& b, int sweep, int lane) {
-    const unsigned long long* row = b.res_slots + (sweep % kResRows) * kResSlots;
+// The residual slots of rank q inside a record buffer's exchange region (bit patterns of
+// non-negative doubles; a row is accumulated with atomic umax by the sweep that WRITES the buffer).
+__device__ __forceinline__ unsigned long long* res_row(const BpBuffers& b, const double* rec, int q) {
+    return reinterpret_cast<unsigned long long*>(const_cast<double*>(rec)) +
+           2 * (b.g_base + int64_t(q) * b.seg_d2 + b.seg_data_d2);
+}
+
+// maximum_difference of the sweep that wrote `rec`: max over every rank's slots (after the
+// all-gather each rank holds all rows, so all ranks compute the same value).
+__device__ __forceinline__ double reduce_residual(const BpBuffers& b, const double* rec, int lane) {
     unsigned long long m = 0;
+    for (int q = 0; q < b.nranks; ++q) {
+        const unsigned long long* row = res_row(b, rec, q);
 #pragma unroll
-    for (int q = 0; q < kResSlots / kWave; ++q) {
-        unsigned long long x = __hip_atomic_load(row + q * kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        m = x > m ? x : m;
+        for (int i = 0; i < kResSlots / kWave; ++i) {
+            unsigned long long x = __hip_atomic_load(row + i * kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = x > m ? x : m;
+        }
     }
     m = wave_umax(m);
     double r = __longlong_as_double((long long)m);
     return r < DBL_MIN ? DBL_MIN : r;  // maximum_difference starts at numeric_limits<double>::min() (:105)
 }
 
-__device__ __forceinline__ void publish_residual(const BpBuffers& b, int sweep, int slot, double wres, int lane) {
+__device__ __forceinline__ void publish_residual(const BpBuffers& b, double* rec_out, int slot, double wres, int lane) {
     unsigned long long bits = (unsigned long long)__double_as_longlong(wres);
     bits = wave_umax(bits);
     if (lane == 0 && bits != 0)
-        __hip_atomic_fetch_max(b.res_slots + (sweep % kResRows) * kResSlots + (slot & (kResSlots - 1)), bits,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(res_row(b, rec_out, b.rank) + (slot & (kResSlots - 1)), bits, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Location of one edge's two messages (bn_plan.hpp MsgRef), double2 units from the buffer start.
+struct Loc {
+    int64_t pi, lam;
+    int32_t stride;
+    bool has;
+};
+__device__ __forceinline__ Loc decode_ref(MsgRef r, int h) {
+    Loc l;
+    l.has = r.pi >= 0;
+    const bool cut = r.lam < 0;
+    const int64_t lam = cut ? int64_t(~r.lam) : int64_t(r.lam);
+    l.pi = l.has ? r.pi : 0;
+    l.lam = l.has ? lam : 0;
+    l.stride = !l.has ? 0 : (cut ? 1 : int32_t((lam - r.pi) / h));
+    return l;
 }
 
 // striped element address helpers (doubles): element i of a vector whose chunks are `stride2`
@@ -106,9 +133,9 @@ __device__ __forceinline__ void publish_residual(const BpBuffers& b, int sweep, 
 __device__ __forceinline__ int64_t vidx(int chunk0, int i, int stride2, int nl) {
     return int64_t(chunk0 + (i >> 1)) * (stride2 * 2) + nl * 2 + (i & 1);
 }
-__device__ __forceinline__ int64_t ridx(OutRef r, int chunk0, int i) {
-    return (int64_t(r.rec) + int64_t(chunk0 + (i >> 1)) * r.stride) * 2 + (i & 1);
-}
+// element i of the pi-message / lambda-message of an edge (doubles from the buffer start)
+__device__ __forceinline__ int64_t pidx(const Loc& l, int i) { return (l.pi + int64_t(i >> 1) * l.stride) * 2 + (i & 1); }
+__device__ __forceinline__ int64_t lidx(const Loc& l, int i) { return (l.lam + int64_t(i >> 1) * l.stride) * 2 + (i & 1); }
 
 // ---------------------------------------------------------------------------------------------
 // parent role for any shape: lambda(v) and the pi-messages to the children, operands re-read
@@ -116,13 +143,14 @@ __device__ __forceinline__ int64_t ridx(OutRef r, int chunk0, int i) {
 // children per node than it keeps in registers.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const IO& io, const TileDesc& td, int kv, int kvp,
-                                      int nl, bool frozen) {
+                                                     int nl, bool frozen) {
     const int npt = td.npt, half = kvp >> 1;
     const double* node_in = io.node_in + td.node_base;
     double* node_out = io.node_out + td.node_base;
-    const OutRef* orf = b.out_refs + td.out_base + nl;
+    const MsgRef* orf = b.out_refs + td.out_base + nl;
     const bool synth = io.first && !frozen;  // initial state instead of memory
-    auto LK = [&](OutRef r, int i) { return io.first ? 1.0 : io.rec_in[ridx(r, half, i)]; };
+    auto REF = [&](int c) { return decode_ref(orf[int64_t(c) * npt], half); };
+    auto LK = [&](const Loc& l, int i) { return io.first ? 1.0 : io.rec_in[lidx(l, i)]; };
     auto PIV = [&](int i) {
         if (!synth) return node_in[vidx(0, i, npt, nl)];
         return td.m == 0 ? b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)] : 1.0;  // :58-64
@@ -136,8 +164,8 @@ __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const 
         for (int i = 0; i < kv; ++i) {
             double acc = 1.0;
             for (int c = 0; c < td.cmax; ++c) {
-                const OutRef r = orf[int64_t(c) * npt];
-                if (r.rec >= 0) acc *= LK(r, i);
+                const Loc l = REF(c);
+                if (l.has) acc *= LK(l, i);
             }
             node_out[vidx(half, i, npt, nl)] = acc;
             sum += acc;
@@ -146,23 +174,23 @@ __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const 
     }
     // pi-message to child c: pi(v) times the OTHER children's lambda-messages (:207-214)
     for (int c = 0; c < td.cmax; ++c) {
-        const OutRef rc = orf[int64_t(c) * npt];
-        if (rc.rec < 0) continue;
+        const Loc lc = REF(c);
+        if (!lc.has) continue;
         double sum = 0;
         for (int i = 0; i < kv; ++i) {
             double acc = PIV(i);
             for (int x = 0; x < td.cmax; ++x) {
                 if (x == c) continue;
-                const OutRef rx = orf[int64_t(x) * npt];
-                if (rx.rec >= 0) acc *= LK(rx, i);
+                const Loc lx = REF(x);
+                if (lx.has) acc *= LK(lx, i);
             }
-            io.rec_out[ridx(rc, 0, i)] = acc;
+            io.rec_out[pidx(lc, i)] = acc;
             sum += acc;
         }
         for (int i = 0; i < kv; ++i) {
-            const double nv = io.rec_out[ridx(rc, 0, i)] / sum;
-            io.rec_out[ridx(rc, 0, i)] = nv;
-            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : io.rec_in[ridx(rc, 0, i)])));
+            const double nv = io.rec_out[pidx(lc, i)] / sum;
+            io.rec_out[pidx(lc, i)] = nv;
+            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : io.rec_in[pidx(lc, i)])));
         }
     }
     return wres;
@@ -176,16 +204,23 @@ __device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io,
     double wres = 0.0;
     if (lane >= td.n_nodes) return wres;
     const double* cpt = b.cpt + td.cpt_base + lane * 2;
-    const double* rec_in = io.rec_in + td.rec_base + lane * 2;
-    double* rec_out = io.rec_out + td.rec_base + lane * 2;
     const double* node_in = io.node_in + td.node_base + lane * 2;
     double* node_out = io.node_out + td.node_base + lane * 2;
     const bool frozen = b.frozen[td.slot_base + lane] != 0;
     const bool synth = io.first && !frozen;
     const int kv = c.kv, m = c.m, rows = c.rows, hv = c.kvp >> 1;
+    // in-edge j: inside the tile's record block, or wherever the reference says (boundary tile)
+    auto IN = [&](int j) {
+        if (td.in_ref_base >= 0) return decode_ref(b.in_refs[td.in_ref_base + int64_t(j) * kWave + lane], c.kpp[j] >> 1);
+        Loc l;
+        l.has = true;
+        l.pi = (td.rec_base + c.rec_off[j]) / 2 + lane;
+        l.stride = kWave;
+        l.lam = l.pi + int64_t(c.kpp[j] >> 1) * kWave;
+        return l;
+    };
     auto CPT = [&](int q) { return cpt[int64_t(q >> 1) * 128 + (q & 1)]; };
-    auto PIM = [&](int j, int s) { return io.first ? 1.0 : rec_in[c.rec_off[j] + int64_t(s >> 1) * 128 + (s & 1)]; };
-    auto LKIDX = [&](int j, int s) { return c.rec_off[j] + int64_t((c.kpp[j] >> 1) + (s >> 1)) * 128 + (s & 1); };
+    auto PIM = [&](int j, int s) { return io.first ? 1.0 : io.rec_in[pidx(IN(j), s)]; };
     auto NIDX = [&](int part, int i) { return int64_t(part * hv + (i >> 1)) * 128 + (i & 1); };
     auto LAV = [&](int i) { return synth ? 1.0 : node_in[NIDX(1, i)]; };
 
@@ -210,6 +245,7 @@ __device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io,
     // assignment inner -- the order in which the reference adds into matrix[0][cond.at(target)]
     for (int jt = 0; jt < m; ++jt) {
         const int kt = c.kp[jt];
+        const Loc lt = IN(jt);
         double sum = 0;
         for (int ct = 0; ct < kt; ++ct) {
             double acc = 0.0;
@@ -223,13 +259,13 @@ __device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io,
                     acc += value;
                 }
             }
-            rec_out[LKIDX(jt, ct)] = acc;
+            io.rec_out[lidx(lt, ct)] = acc;
             sum += acc;
         }
         for (int ct = 0; ct < kt; ++ct) {
-            const double nv = rec_out[LKIDX(jt, ct)] / sum;
-            rec_out[LKIDX(jt, ct)] = nv;
-            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : rec_in[LKIDX(jt, ct)])));
+            const double nv = io.rec_out[lidx(lt, ct)] / sum;
+            io.rec_out[lidx(lt, ct)] = nv;
+            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : io.rec_in[lidx(lt, ct)])));
         }
     }
     return res_acc(wres, parent_role_generic(b, io, td, kv, c.kvp, lane, frozen));
@@ -256,8 +292,22 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             cpt[2 * q] = x.x;
             cpt[2 * q + 1] = x.y;
         }
-        const double2_t* rin = reinterpret_cast<const double2_t*>(io.rec_in + td.rec_base) + lane;
-        double2_t* rout = reinterpret_cast<double2_t*>(io.rec_out + td.rec_base) + lane;
+        const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
+        double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
+        // in-edge j's record: inside the tile's own block (arithmetic), or -- boundary tile, some
+        // parent lives on another rank -- wherever its reference says (exchange region for cut edges)
+        Loc in[M > 0 ? M : 1];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            in[j].has = true;
+            in[j].pi = td.rec_base / 2 + (j * 2 * H) * kWave + lane;
+            in[j].lam = in[j].pi + H * kWave;
+            in[j].stride = kWave;
+        }
+        if (td.in_ref_base >= 0) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) in[j] = decode_ref(b.in_refs[td.in_ref_base + j * kWave + lane], H);
+        }
         const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + lane;
         double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + lane;
         const bool frozen = b.frozen[td.slot_base + lane] != 0;
@@ -271,7 +321,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             for (int j = 0; j < M; ++j)
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const double2_t x = rin[(j * 2 * H + h) * kWave];
+                    const double2_t x = rec_in2[in[j].pi + h * in[j].stride];
                     pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
                 }
         }
@@ -292,29 +342,25 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
 
         // ---- parent-role loads: out-edge references, then the children's lambda-messages.
         // A missing child reads record 0 and contributes 1.0 (x * 1.0 == x exactly).
-        const OutRef* orf = b.out_refs + td.out_base + lane;
-        const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
-        double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
-        OutRef oref[RC > 0 ? RC : 1];
+        const MsgRef* orf = b.out_refs + td.out_base + lane;
+        Loc oref[RC > 0 ? RC : 1];
         double lkc[RC > 0 ? RC : 1][KP];
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
-            oref[c] = OutRef{-1, 0};
-            if (c < td.cmax) oref[c] = orf[c * kWave];
+            MsgRef r{-1, 0};
+            if (c < td.cmax) r = orf[c * kWave];
+            oref[c] = decode_ref(r, H);
         }
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
 #pragma unroll
             for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
             if (c < td.cmax && !io.first) {
-                const bool has = oref[c].rec >= 0;
-                const int64_t base = has ? oref[c].rec : 0;
-                const int64_t st = has ? oref[c].stride : 0;
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const double2_t y = rec_in2[base + (H + h) * st];
-                    lkc[c][2 * h] = has ? y.x : 1.0;
-                    lkc[c][2 * h + 1] = has ? y.y : 1.0;
+                    const double2_t y = rec_in2[oref[c].lam + h * oref[c].stride];
+                    lkc[c][2 * h] = oref[c].has ? y.x : 1.0;
+                    lkc[c][2 * h + 1] = oref[c].has ? y.y : 1.0;
                 }
             }
         }
@@ -407,7 +453,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             if (!io.first) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {  // previous lambda-message of this edge, for the residual
-                    const double2_t y = rin[(jt * 2 * H + H + h) * kWave];
+                    const double2_t y = rec_in2[in[jt].lam + h * in[jt].stride];
                     old[2 * h] = y.x; old[2 * h + 1] = y.y;
                 }
             }
@@ -420,7 +466,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             for (int h = 0; h < H; ++h) {
                 double2_t y;
                 y.x = o[2 * h]; y.y = o[2 * h + 1];
-                bn_store<NT>(&rout[(jt * 2 * H + H + h) * kWave], y);
+                bn_store<NT>(&rec_out2[in[jt].lam + h * in[jt].stride], y);
             }
         }
         // pi-message to child c (:202-218): pi(v) times the OTHER children's lambda-messages
@@ -437,14 +483,14 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                     u[i] = acc;
                 }
                 normalize_k<K>(u);
-                if (oref[c].rec >= 0) {
+                if (oref[c].has) {
                     double o[KP], old[KP];
 #pragma unroll
                     for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
                     if (!io.first) {
 #pragma unroll
                         for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
-                            const double2_t x = rec_in2[oref[c].rec + int64_t(h) * oref[c].stride];
+                            const double2_t x = rec_in2[oref[c].pi + h * oref[c].stride];
                             old[2 * h] = x.x; old[2 * h + 1] = x.y;
                         }
                     }
@@ -457,7 +503,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                     for (int h = 0; h < H; ++h) {
                         double2_t y;
                         y.x = o[2 * h]; y.y = o[2 * h + 1];
-                        bn_store<NT>(&rec_out2[oref[c].rec + int64_t(h) * oref[c].stride], y);
+                        bn_store<NT>(&rec_out2[oref[c].pi + h * oref[c].stride], y);
                     }
                 }
             }
@@ -487,20 +533,19 @@ __device__ __forceinline__ int logical_block() {
 }
 
 // Residual bookkeeping of launch s, done by ONE wave that carries no tile: settle sweep s-1
-// (record maximum_difference, raise `done` when it is < eps, :147) and zero the ring row that
-// sweep s+1 will accumulate into.  Tile waves never wait for it: a launch that starts after
-// convergence only writes the buffer that is no longer current, and the launch after that sees
-// `done` and returns at once.
+// (record maximum_difference, raise `done` when it is < eps, :147), then zero this rank's slots
+// in the buffer it just read -- sweep s+1 accumulates into them.  Tile waves never wait for it:
+// a launch that starts after convergence only writes the buffer that is no longer current, and
+// the launch after that sees `done` and returns at once.
 __device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) {
     const BpBuffers& b = a.b;
-    if (a.sweep > 0) {
-        const double r = reduce_residual(b, a.sweep - 1, lane);
-        if (lane == 0) {
-            if (a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
-            if (r < a.eps) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
-        }
+    if (a.sweep == 0) return;
+    const double r = reduce_residual(b, a.rec_in, lane);
+    if (lane == 0) {
+        if (a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
+        if (r < a.eps) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
     }
-    unsigned long long* row = b.res_slots + ((a.sweep + 1) % kResRows) * kResSlots;
+    unsigned long long* row = res_row(b, a.rec_in, b.rank);
 #pragma unroll
     for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
 }
@@ -538,23 +583,28 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a)
         }
     }
     if (!handled) wres = tile_generic(b, io, td, b.classes[td.cls], lane);
-    publish_residual(b, a.sweep, tile, wres, lane);
+    publish_residual(b, a.rec_out, tile, wres, lane);
 }
 
-// Start of a run: reset the control block and the residual ring, then apply the evidence
-// (belief_propagation.hpp:68-73): pi(v) = lambda(v) = the given vector in the buffer iteration 0
-// reads, node marked (preconditional_node_).  `frozen` is all-zero on entry (the previous run's
-// finish kernel cleared its own marks).
+// Start of a run: reset the control block and this rank's residual slots in both buffers, then
+// apply the evidence (belief_propagation.hpp:68-73) to the nodes this rank owns: pi(v) =
+// lambda(v) = the given vector in the buffer iteration 0 reads, node marked
+// (preconditional_node_).  `frozen` is all-zero on entry (the previous run's finish kernel
+// cleared its own marks).
 __global__ __launch_bounds__(kBlockThreads) void bp_begin_kernel(EvidenceArgs a) {
     const BpBuffers& b = a.b;
     if (blockIdx.x == 0) {
-        for (int q = threadIdx.x; q < kResRows * kResSlots; q += kBlockThreads) b.res_slots[q] = 0ull;
+        unsigned long long* r0 = res_row(b, b.rec0, b.rank);
+        unsigned long long* r1 = res_row(b, b.rec1, b.rank);
+        for (int q = threadIdx.x; q < kResSlots; q += kBlockThreads) { r0[q] = 0ull; r1[q] = 0ull; }
         if (threadIdx.x == 0) { b.ctl->done = 0; b.ctl->n_sweeps = 0; b.ctl->last_res = 0.0; }
     }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.ne) return;
     const int v = a.ev_node[j];
-    const TileDesc td = b.tiles[b.node_tile[v]];
+    const int t = b.node_tile[v];
+    if (t < 0) return;  // owned by another rank
+    const TileDesc td = b.tiles[t];
     const int nl = b.node_nl[v];
     double* node = b.node0 + td.node_base;
     const int half = ((td.kv + 1) & ~1) >> 1;
@@ -566,9 +616,9 @@ __global__ __launch_bounds__(kBlockThreads) void bp_begin_kernel(EvidenceArgs a)
     b.frozen[td.slot_base + nl] = 1;
 }
 
-// After a batch of sweeps: settle the last launched sweep's residual, and once the run is over
-// (converged, or max_sweeps reached) write belief = normalize(pi % lambda) (:151-158) and clear
-// this run's evidence marks.
+// After a batch of sweeps (and their exchanges): settle the last launched sweep's residual, and
+// once the run is over (converged, or max_sweeps reached) write belief = normalize(pi % lambda)
+// (:151-158) for the owned nodes and clear this run's evidence marks.
 __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) {
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
@@ -579,7 +629,8 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     if (done != 0) {
         n_sweeps = b.ctl->n_sweeps;
     } else {
-        const double r = reduce_residual(b, a.sweeps_launched - 1, lane);
+        // sweep (launched-1) wrote buffer (launched & 1)
+        const double r = reduce_residual(b, (a.sweeps_launched & 1) ? b.rec1 : b.rec0, lane);
         if (lead && a.sweeps_launched - 1 < b.res_cap) b.res_hist[a.sweeps_launched - 1] = r;
         n_sweeps = a.sweeps_launched;
         if (r < a.eps) done = 1;
@@ -590,7 +641,8 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     for (int j = gid; j < a.ne; j += gridDim.x * blockDim.x) {
         const int v = a.ev_node[j];
-        b.frozen[b.tiles[b.node_tile[v]].slot_base + b.node_nl[v]] = 0;
+        const int t = b.node_tile[v];
+        if (t >= 0) b.frozen[b.tiles[t].slot_base + b.node_nl[v]] = 0;
     }
     const int tile = blockIdx.x * kWavesPerBlock + wave;
     if (tile >= b.n_tiles) return;

@@ -5,27 +5,46 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <unordered_map>
 
 namespace bnmi {
 
 static inline int32_t round_even(int32_t x) { return (x + 1) & ~1; }
 
-// Lanes per node for a uniform-arity class.  One lane keeps <= 64 CPT entries in flight where
-// the parent-assignment count allows an even split: k=4: m<=2 -> 1, m=3 -> 4, m=4 -> 16.
+// Lanes per node for a uniform-arity class.
 static int pick_lanes(int kv, int m, int64_t rows, int forced) {
     (void)kv; (void)m; (void)rows; (void)forced;
     return 1;  // sub-wave groups (G = 4, 16) are not wired into the kernels yet
 }
 
-std::string build_plan(const bn_model_desc& d, Plan& p) {
+void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>& owner) {
+    const int32_t n = d.n_nodes;
+    owner.assign(std::max(n, 0), 0);
+    if (n <= 0 || nranks <= 1) return;
+    // weight = bytes a sweep moves for the node: its CPT plus a few k-vectors
+    auto weight = [&](int32_t v) { return double(d.cpt_off[v + 1] - d.cpt_off[v]) + 8.0 * d.k[v]; };
+    double total = 0;
+    for (int32_t v = 0; v < n; ++v) total += weight(v);
+    double cum = 0;
+    for (int32_t v = 0; v < n; ++v) {
+        int32_t r = int32_t(cum * nranks / total);
+        owner[v] = std::min(std::max(r, 0), nranks - 1);
+        cum += weight(v);
+    }
+}
+
+std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) {
     const int32_t n = d.n_nodes;
     if (n < 0) return "n_nodes < 0";
     if (n > 0 && (!d.k || !d.in_ptr || !d.cpt_off)) return "null model array";
+    if (shard.nranks < 1 || shard.rank < 0 || shard.rank >= shard.nranks) return "bad rank / nranks";
     p = Plan();
     p.n = n;
+    p.rank = shard.rank;
+    p.nranks = shard.nranks;
     p.k.assign(d.k, d.k + n);
-    p.in_ptr.assign(d.in_ptr, d.in_ptr + n + (n >= 0 ? 1 : 0));
-    if (n == 0 && !d.in_ptr) p.in_ptr.assign(1, 0);
+    if (d.in_ptr) p.in_ptr.assign(d.in_ptr, d.in_ptr + n + 1);
+    else p.in_ptr.assign(1, 0);
     if (p.in_ptr[0] != 0) return "in_ptr[0] != 0";
     for (int32_t v = 0; v < n; ++v) {
         if (p.k[v] < 1 || p.k[v] > 255) return "selectable_num of node " + std::to_string(v) + " outside [1,255]";
@@ -60,6 +79,22 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
     p.msg_off.assign(p.E + 1, 0);
     for (int64_t e = 0; e < p.E; ++e) p.msg_off[e + 1] = p.msg_off[e] + p.k[p.in_idx[e]];
 
+    // ---- ownership
+    const int32_t me = p.rank;
+    if (p.nranks > 1) {
+        if (shard.owner) {
+            p.owner.assign(shard.owner, shard.owner + n);
+            for (int32_t v = 0; v < n; ++v)
+                if (p.owner[v] < 0 || p.owner[v] >= p.nranks) return "owner[] entry out of range";
+        } else {
+            default_owner(d, p.nranks, p.owner);
+        }
+    }
+    auto own = [&](int32_t v) { return p.nranks == 1 ? 0 : p.owner[v]; };
+    std::vector<int32_t> edge_child(std::max<int64_t>(p.E, 1));
+    for (int32_t v = 0; v < n; ++v)
+        for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) edge_child[e] = v;
+
     // ---- children (ascending) with the CSR edge id of each out-edge
     std::vector<int32_t> out_ptr(n + 1, 0), out_edge(std::max<int64_t>(p.E, 1));
     for (int64_t e = 0; e < p.E; ++e) out_ptr[p.in_idx[e] + 1]++;
@@ -73,11 +108,13 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
             }
     }
 
-    // ---- shape classes
+    // ---- shape classes over the owned nodes
     std::map<std::vector<int32_t>, int32_t> sig2cls;
     p.node_class.assign(n, -1);
     std::vector<int32_t> sig;
     for (int32_t v = 0; v < n; ++v) {
+        if (own(v) != me) continue;
+        ++p.n_owned;
         sig.clear();
         sig.push_back(p.k[v]);
         for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) sig.push_back(p.k[p.in_idx[e]]);
@@ -115,28 +152,30 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
         p.g_max = std::max(p.g_max, p.classes[it->second].G);
     }
 
-    // ---- tiles: per class, ascending node id, NPT nodes each; global order by first node id
-    struct ProtoTile { int32_t cls; std::vector<int32_t> nodes; };
+    // ---- tiles: per class, ascending node id, NPT nodes each; tile order by first node id
+    struct ProtoTile { int32_t cls; std::vector<int32_t> nodes; bool boundary; };
     std::vector<ProtoTile> proto;
     {
         std::vector<int32_t> open(p.classes.size(), -1);
         for (int32_t v = 0; v < n; ++v) {
             int32_t c = p.node_class[v];
+            if (c < 0) continue;
             if (open[c] < 0 || int32_t(proto[open[c]].nodes.size()) == p.classes[c].npt) {
                 open[c] = int32_t(proto.size());
-                proto.push_back({c, {}});
+                proto.push_back({c, {}, false});
                 proto.back().nodes.reserve(p.classes[c].npt);
             }
             proto[open[c]].nodes.push_back(v);
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e)
+                if (own(p.in_idx[e]) != me) proto[open[c]].boundary = true;
         }
     }
-    // proto is already ordered by first node id (a tile is opened when its first node is met)
     const int32_t nt = int32_t(proto.size());
     p.tiles.assign(nt, TileDesc());
     p.node_tile.assign(n, -1);
     p.node_nl.assign(n, -1);
     p.node_slot.assign(n, -1);
-    int64_t cpt_cur = 0, rec_cur = 0, node_cur = 0, out_cur = 0;
+    int64_t cpt_cur = 0, rec_cur = 0, node_cur = 0, out_cur = 0, inref_cur = 0;
     int32_t slot_cur = 0;
     for (int32_t t = 0; t < nt; ++t) {
         const ClassDesc& c = p.classes[proto[t].cls];
@@ -149,7 +188,8 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
         td.rec_base = rec_cur;
         td.node_base = node_cur;
         td.out_base = out_cur;
-        td.kv = c.kv; td.m = c.m; td.variant = c.variant; td.npt = c.npt;
+        td.in_ref_base = proto[t].boundary ? inref_cur : -1;
+        td.kv = uint8_t(c.kv); td.m = uint8_t(c.m); td.variant = uint8_t(c.variant); td.npt = uint8_t(c.npt);
         int32_t cmax = 0;
         for (int32_t nl = 0; nl < td.n_nodes; ++nl) {
             int32_t v = proto[t].nodes[nl];
@@ -163,26 +203,58 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
         rec_cur += c.rec_doubles;
         node_cur += int64_t(2) * c.kvp * c.npt;
         out_cur += int64_t(cmax) * c.npt;
+        if (proto[t].boundary) inref_cur += int64_t(c.m) * c.npt;
         slot_cur += c.npt;
     }
-    if (cpt_cur / 2 > INT32_MAX || rec_cur / 2 > INT32_MAX) return "model too large for 32-bit record indices";
     p.n_slots = slot_cur;
     p.rec_doubles = rec_cur;
     p.node_doubles = node_cur;
     p.slot_node.assign(slot_cur, -1);
     p.slot_boff.assign(slot_cur, -1);
-    for (int32_t v = 0; v < n; ++v) {
-        p.slot_node[p.node_slot[v]] = v;
-        p.slot_boff[p.node_slot[v]] = p.node_off[v];
+    for (int32_t v = 0; v < n; ++v)
+        if (p.node_slot[v] >= 0) {
+            p.slot_node[p.node_slot[v]] = v;
+            p.slot_boff[p.node_slot[v]] = p.node_off[v];
+        }
+
+    // ---- exchange region: every rank derives the same segment layout from the global graph.
+    // Halves are enumerated in CSR edge order; the pi-half of a cut edge belongs to the parent's
+    // owner, the lambda-half to the child's owner.
+    p.seg_used_d2.assign(p.nranks, 0);
+    std::unordered_map<int64_t, std::pair<int64_t, int64_t>> cut_off;  // e -> (pi off, lambda off), incident only
+    if (p.nranks > 1) {
+        for (int64_t e = 0; e < p.E; ++e) {
+            const int32_t u = p.in_idx[e], v = edge_child[e];
+            const int32_t a = own(u), b = own(v);
+            if (a == b) continue;
+            const int64_t h = round_even(p.k[u]) / 2;
+            const int64_t po = p.seg_used_d2[a];
+            p.seg_used_d2[a] += h;
+            const int64_t lo = p.seg_used_d2[b];
+            p.seg_used_d2[b] += h;
+            if (a == me || b == me) {
+                cut_off.emplace(e, std::make_pair(po, lo));
+                ++p.n_cut_edges;
+            }
+        }
     }
+    int64_t seg_data = 0;
+    for (int64_t s : p.seg_used_d2) seg_data = std::max(seg_data, s);
+    seg_data = (seg_data + 7) & ~int64_t(7);  // 128-byte granularity
+    p.seg_data_d2 = seg_data;
+    p.seg_d2 = seg_data + kResSlotsD2;
+    p.g_base = rec_cur / 2;
+    p.rec_total_doubles = rec_cur + 2 * p.seg_d2 * p.nranks;
+    if (cpt_cur / 2 > INT32_MAX || p.rec_total_doubles / 2 > INT32_MAX) return "model too large for 32-bit record indices";
 
     // ---- CPT image: i-major per node, assignments split over the G lanes of the node
     p.cpt_striped.assign(cpt_cur, 0.0);
     p.cpt_doubles = cpt_cur;
-    p.cpt_off.assign(d.cpt_off, d.cpt_off + n + 1);
-    if (n == 0) p.cpt_off.assign(1, 0);
+    if (n > 0) p.cpt_off.assign(d.cpt_off, d.cpt_off + n + 1);
+    else p.cpt_off.assign(1, 0);
     p.cpt_flat.assign(d.cpt, d.cpt + (n ? d.cpt_off[n] : 0));
     for (int32_t v = 0; v < n; ++v) {
+        if (p.node_class[v] < 0) continue;
         const ClassDesc& c = p.classes[p.node_class[v]];
         const TileDesc& td = p.tiles[p.node_tile[v]];
         const double* src = d.cpt + d.cpt_off[v];
@@ -199,45 +271,68 @@ std::string build_plan(const bn_model_desc& d, Plan& p) {
         }
     }
 
-    // ---- where each CSR edge's record lives, and the parents' out-edge references
-    p.edge_rec.assign(std::max<int64_t>(p.E, 1), OutRef{-1, 0});
-    for (int32_t v = 0; v < n; ++v) {
-        const ClassDesc& c = p.classes[p.node_class[v]];
-        const TileDesc& td = p.tiles[p.node_tile[v]];
-        for (int32_t j = 0; j < c.m; ++j)
-            p.edge_rec[p.in_ptr[v] + j] = OutRef{int32_t((td.rec_base + c.rec_off[j]) / 2 + p.node_nl[v]), c.npt};
+    // ---- where each edge's messages live on this rank
+    auto seg_index = [&](int32_t r, int64_t off) { return int32_t(p.g_base + int64_t(r) * p.seg_d2 + off); };
+    p.edge_ref.assign(std::max<int64_t>(p.E, 1), MsgRef{-1, 0});
+    for (int64_t e = 0; e < p.E; ++e) {
+        const int32_t u = p.in_idx[e], v = edge_child[e];
+        const int32_t a = own(u), b = own(v);
+        if (a != me && b != me) continue;
+        if (a == b) {  // both endpoints here: the record sits in the child's tile
+            const ClassDesc& c = p.classes[p.node_class[v]];
+            const TileDesc& td = p.tiles[p.node_tile[v]];
+            const int32_t j = int32_t(e - p.in_ptr[v]);
+            const int32_t pi = int32_t((td.rec_base + c.rec_off[j]) / 2 + p.node_nl[v]);
+            p.edge_ref[e] = MsgRef{pi, pi + (c.kpp[j] / 2) * c.npt};
+        } else {  // cut edge: pi-half in the parent owner's segment, lambda-half in the child owner's
+            const auto& off = cut_off.at(e);
+            p.edge_ref[e] = MsgRef{seg_index(a, off.first), ~seg_index(b, off.second)};
+        }
     }
-    p.out_refs.assign(std::max<int64_t>(out_cur, 1), OutRef{-1, 0});
+    p.out_refs.assign(std::max<int64_t>(out_cur, 1), MsgRef{-1, 0});
+    p.in_refs.assign(std::max<int64_t>(inref_cur, 1), MsgRef{-1, 0});
     for (int32_t v = 0; v < n; ++v) {
+        if (p.node_class[v] < 0) continue;
         const ClassDesc& c = p.classes[p.node_class[v]];
         const TileDesc& td = p.tiles[p.node_tile[v]];
         for (int32_t q = out_ptr[v]; q < out_ptr[v + 1]; ++q)
-            p.out_refs[td.out_base + int64_t(q - out_ptr[v]) * c.npt + p.node_nl[v]] = p.edge_rec[out_edge[q]];
+            p.out_refs[td.out_base + int64_t(q - out_ptr[v]) * c.npt + p.node_nl[v]] = p.edge_ref[out_edge[q]];
+        if (td.in_ref_base >= 0)
+            for (int32_t j = 0; j < c.m; ++j)
+                p.in_refs[td.in_ref_base + int64_t(j) * c.npt + p.node_nl[v]] = p.edge_ref[p.in_ptr[v] + j];
     }
 
-    // ---- metrics: algorithmic = CPT once + every vector read once, written once
-    int64_t vec = 0;
-    for (int64_t e = 0; e < p.E; ++e) vec += 2 * int64_t(p.k[p.in_idx[e]]);
-    for (int32_t v = 0; v < n; ++v) vec += 2 * int64_t(p.k[v]);
-    p.algorithmic_bytes = 8 * (n ? d.cpt_off[n] : 0) + 16 * vec;
-    p.messages_per_sweep = 2 * p.E;
+    // ---- metrics, this rank's share: CPT of owned nodes once; every message it
+    // produces and every owned node vector read once and written once
+    int64_t vec = 0, cpt_owned = 0, msgs = 0;
+    for (int64_t e = 0; e < p.E; ++e) {
+        const int32_t u = p.in_idx[e], v = edge_child[e];
+        if (own(u) == me) { vec += p.k[u]; ++msgs; }
+        if (own(v) == me) { vec += p.k[u]; ++msgs; }
+    }
+    for (int32_t v = 0; v < n; ++v)
+        if (own(v) == me) { vec += 2 * int64_t(p.k[v]); cpt_owned += d.cpt_off[v + 1] - d.cpt_off[v]; }
+    p.algorithmic_bytes = 8 * cpt_owned + 16 * vec;
+    p.messages_per_sweep = msgs;
     // what the sweep kernel requests: CPT image, each record read by both endpoints and each half
-    // written once, node vectors read + written, out references, tile descriptors, frozen flags
-    p.layout_bytes = 8 * cpt_cur + 8 * (2 * rec_cur + rec_cur) + 8 * 2 * node_cur + 8 * out_cur +
+    // written once, node vectors read + written, message references, tile descriptors, flags
+    p.layout_bytes = 8 * cpt_cur + 8 * (2 * rec_cur + rec_cur) + 8 * 2 * node_cur + 8 * out_cur + 8 * inref_cur +
                      int64_t(sizeof(TileDesc)) * nt + slot_cur;
     return "";
 }
 
 void unstripe_messages(const Plan& p, const std::vector<double>& rec, double* pi_msg, double* lambda_msg) {
     for (int64_t e = 0; e < p.E; ++e) {
-        const OutRef r = p.edge_rec[e];
+        const MsgRef r = p.edge_ref[e];
+        if (r.pi < 0) continue;
         const int32_t ku = p.k[p.in_idx[e]];
-        const int32_t half = ((ku + 1) & ~1) / 2;  // chunks per message
+        const int32_t h = ((ku + 1) & ~1) / 2;  // chunks per message
+        const bool cut = r.lam < 0;
+        const int64_t lam = cut ? ~r.lam : r.lam;
+        const int64_t stride = cut ? 1 : (lam - r.pi) / h;
         for (int32_t i = 0; i < ku; ++i) {
-            const int64_t a = (int64_t(r.rec) + int64_t(i >> 1) * r.stride) * 2 + (i & 1);
-            const int64_t b = (int64_t(r.rec) + int64_t(half + (i >> 1)) * r.stride) * 2 + (i & 1);
-            pi_msg[p.msg_off[e] + i] = rec[a];
-            lambda_msg[p.msg_off[e] + i] = rec[b];
+            pi_msg[p.msg_off[e] + i] = rec[(int64_t(r.pi) + int64_t(i >> 1) * stride) * 2 + (i & 1)];
+            lambda_msg[p.msg_off[e] + i] = rec[(lam + int64_t(i >> 1) * stride) * 2 + (i & 1)];
         }
     }
 }

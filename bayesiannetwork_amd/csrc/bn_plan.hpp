@@ -5,7 +5,7 @@
 // lane-striped for 64-wide wavefronts so that every wave-level load is one contiguous run:
 //
 //   tile      = one wavefront's worth of nodes of ONE shape class (same k, same parent arities),
-//               NPT = 64 / G nodes, G = lanes cooperating on one node (1, 4 or 16)
+//               NPT = 64 / G nodes, G = lanes cooperating on one node
 //   CPT       = per tile, i-major (own state slowest, parent assignment fastest) so that one
 //               streaming pass visits entries in the reference's accumulation order for both
 //               calculate_pi (:174-200) and calculate_lambda_k (:240-266); lane (node nl, part g)
@@ -14,11 +14,24 @@
 //   records   = per in-edge (child tile, parent slot j, node nl): the pi-message then the
 //               lambda-message of that edge, each Kp = roundup(k[parent], 2) doubles, striped as
 //               rec + chunk*(NPT*2) + nl*2 ; the child reads/writes them fully coalesced, the
-//               parent reaches them through a per-out-edge {index, stride} pair
+//               parent reaches them through a per-out-edge MsgRef
 //   node vecs = pi(v) then lambda(v), striped the same way per tile
 //
 // All state that changes per sweep (records, node vectors) is double-buffered: a sweep reads
 // buffer A and writes buffer B (the reference's new_* maps, :328-333), then they swap.
+//
+// Sharding (one process per GPU): nodes are partitioned by an edge cut (owner[v]).  A rank lays
+// out only the nodes it owns.  The pi-message of edge u->v is computed by owner(u), the
+// lambda-message by owner(v) (each needs only state stored at that node).  For a CUT edge both
+// message halves live in the EXCHANGE region appended to every record buffer:
+//
+//   [ tile records | segment of rank 0 | segment of rank 1 | ... ]      segment = halves + slots
+//
+// The layout of the exchange region is identical on every rank and each half has exactly one
+// writer (its producer), so one in-place all-gather of the segments per sweep IS the halo
+// exchange -- no pack / unpack kernels.  Each segment ends with the rank's 256 residual slots,
+// so the same collective also carries max|new-old| to every rank and all ranks stop on the
+// same sweep.  With one rank the region holds just the residual slots.
 #pragma once
 
 #include <cstdint>
@@ -30,10 +43,12 @@
 namespace bnmi {
 
 constexpr int kWave = 64;
+constexpr int kResSlots = 256;              // residual slots per rank (spread the atomics)
+constexpr int kResSlotsD2 = kResSlots / 2;  // ... in double2 units (8 B each)
 
 enum Variant : int32_t {
     kVariantGeneric = 0,   // runtime loops, any shape, G = 1
-    kVariantUniform = 1,   // templated: node and all parents share k in {2,3,4}, m <= 4
+    kVariantUniform = 1,   // templated: node and all parents share k in {2,3,4}, CPT <= 64 entries
 };
 
 // Device-visible shape class.  POD.
@@ -59,21 +74,31 @@ struct ClassDesc {
 // One wavefront of work.  POD, 64 bytes.
 struct TileDesc {
     int32_t cls;
-    int32_t n_nodes;     // active nodes (<= npt)
-    int32_t cmax;        // max out-degree among the tile's nodes
-    int32_t slot_base;   // index of lane-slot 0 in per-slot arrays (frozen, lane_node, ...)
-    int64_t cpt_base;    // doubles
-    int64_t rec_base;    // doubles
-    int64_t node_base;   // doubles: pi at node_base, lambda at node_base + kvp*npt
-    int64_t out_base;    // int2 entries: out-edge c of node nl at out_base + c*npt + nl
+    int32_t n_nodes;      // active nodes (<= npt)
+    int32_t cmax;         // max out-degree among the tile's nodes
+    int32_t slot_base;    // index of lane-slot 0 in per-slot arrays (frozen, slot_boff, ...)
+    int64_t cpt_base;     // doubles
+    int64_t rec_base;     // doubles
+    int64_t node_base;    // doubles: pi at node_base, lambda at node_base + kvp*npt
+    int64_t out_base;     // MsgRef entries: out-edge c of node nl at out_base + c*npt + nl
+    int64_t in_ref_base;  // -1: in-edge records at rec_base (arithmetic); else MsgRef entries
+                          //     [j][nl] -- the tile has a parent on another rank
     // copy of the class fields the kernel dispatches on (saves a dependent load per wave)
-    int32_t kv, m, variant, npt;
+    uint8_t kv, m, variant, npt;
+    int32_t pad_;
 };
 static_assert(sizeof(TileDesc) == 64, "TileDesc must stay 64 bytes");
 
-struct OutRef {
-    int32_t rec;     // double2 index of chunk 0 of the child's in-edge record; -1 = none
-    int32_t stride;  // double2 stride between chunks (= child's npt)
+// Where the two messages of one edge live, in double2 units from the start of a record buffer.
+//   pi  < 0          : no edge
+//   lam >= 0         : tile-resident record; chunk c of the pi-message at pi + c*stride and of
+//                      the lambda-message at lam + c*stride, stride = (lam - pi) / H where
+//                      H = chunks per message = roundup(k[parent], 2) / 2
+//   lam <  0         : cut edge, halves in the exchange region, contiguous chunks:
+//                      pi-message at pi + c, lambda-message at ~lam + c
+struct MsgRef {
+    int32_t pi;
+    int32_t lam;
 };
 
 struct Plan {
@@ -83,34 +108,57 @@ struct Plan {
     std::vector<int32_t> k, in_ptr, in_idx;
     std::vector<int64_t> node_off;   // [n+1] prefix of k
     std::vector<int64_t> msg_off;    // [E+1] prefix of k[parent]
-    // classes / tiles
+    // sharding
+    int32_t rank = 0, nranks = 1;
+    std::vector<int32_t> owner;      // [n] (empty when nranks == 1)
+    int32_t n_owned = 0;
+    int64_t n_cut_edges = 0;         // cut edges incident to this rank
+    // classes / tiles (owned nodes only)
     std::vector<ClassDesc> classes;
     std::vector<TileDesc> tiles;
-    std::vector<int32_t> node_class; // [n]
-    std::vector<int32_t> node_slot;  // [n]   tile*64... see slot(): tiles[t].slot_base + nl
+    std::vector<int32_t> node_class; // [n]   -1 for nodes of other ranks
+    std::vector<int32_t> node_slot;  // [n]   tiles[t].slot_base + nl, or -1
     std::vector<int32_t> node_tile;  // [n]
     std::vector<int32_t> node_nl;    // [n]
     std::vector<int32_t> slot_node;  // [n_slots] node id or -1
     std::vector<int64_t> slot_boff;  // [n_slots] node_off[node] or -1
     int32_t n_slots = 0;
-    // per CSR edge: where its record lives
-    std::vector<OutRef> edge_rec;    // [E]
+    // per CSR edge: where its messages live on this rank ({-1,0} when neither endpoint is owned)
+    std::vector<MsgRef> edge_ref;    // [E]
+    // exchange region (double2 units)
+    int64_t g_base = 0;              // start of the exchange region in a record buffer
+    int64_t seg_d2 = kResSlotsD2;    // segment size per rank, residual slots included
+    int64_t seg_data_d2 = 0;         // message halves per segment (max over ranks, padded)
+    std::vector<int64_t> seg_used_d2;  // [nranks] halves actually produced by each rank
     // device images
     std::vector<double> cpt_striped;  // released after upload (cpt_doubles keeps the size)
     int64_t cpt_doubles = 0;
     std::vector<int64_t> cpt_off;     // [n+1] reference-order flat CPT (kept for likelihood weighting)
     std::vector<double> cpt_flat;
-    std::vector<OutRef> out_refs;    // per tile [c][nl]
-    int64_t rec_doubles = 0, node_doubles = 0;
-    // metrics
+    std::vector<MsgRef> out_refs;    // per tile [c][nl]
+    std::vector<MsgRef> in_refs;     // per boundary tile [j][nl]
+    int64_t rec_doubles = 0;         // tile records only
+    int64_t rec_total_doubles = 0;   // tile records + exchange region (one buffer)
+    int64_t node_doubles = 0;
+    // metrics (this rank's share)
     int64_t algorithmic_bytes = 0, layout_bytes = 0, messages_per_sweep = 0;
     int32_t g_max = 1;
 };
 
+struct ShardSpec {
+    int32_t rank = 0;
+    int32_t nranks = 1;
+    const int32_t* owner = nullptr;  // [n]; nullptr with nranks > 1 -> balanced contiguous ranges
+};
+
+// Balanced contiguous node ranges by CPT bytes (grid, row-major ids -> row stripes).
+void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>& owner);
+
 // Builds the plan.  Returns empty string on success, else an error message (BN_ERR_ARG).
-std::string build_plan(const bn_model_desc& d, Plan& out);
+std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& out);
 
 // Host un-striping of a record buffer into CSR edge order (diagnostics, bn_bp_messages).
+// Edges without an owned endpoint are left untouched.
 void unstripe_messages(const Plan& p, const std::vector<double>& rec, double* pi_msg, double* lambda_msg);
 
 }  // namespace bnmi

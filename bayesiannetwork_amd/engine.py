@@ -24,14 +24,23 @@ def _p(a, ct):
 class Engine:
     """One flattened network resident on one GPU (bn_create / bn_destroy)."""
 
-    def __init__(self, model: FlatModel, device: int = _lib.BN_DEVICE_CURRENT, lanes_per_node: int = 0):
+    def __init__(self, model: FlatModel, device: int = _lib.BN_DEVICE_CURRENT, lanes_per_node: int = 0,
+                 rank: int = 0, nranks: int = 1, owner=None):
+        """rank/nranks/owner: shard `rank` of an edge-cut partition (bn_create_sharded);
+        owner[v] in [0, nranks), None = balanced contiguous node ranges."""
         self.model = model
+        self.rank, self.nranks = rank, nranks
         self._h = ctypes.c_void_p()
         L = _lib.lib()
         d = _lib.ModelDesc(model.n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
                            _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64),
                            _p(model.cpt, ctypes.c_double), device, lanes_per_node)
-        _lib.check(L.bn_create(ctypes.byref(d), ctypes.byref(self._h)))
+        if nranks == 1:
+            _lib.check(L.bn_create(ctypes.byref(d), ctypes.byref(self._h)))
+        else:
+            own = None if owner is None else np.ascontiguousarray(owner, dtype=np.int32)
+            _lib.check(L.bn_create_sharded(ctypes.byref(d), rank, nranks,
+                                           None if own is None else _p(own, ctypes.c_int32), ctypes.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -97,6 +106,36 @@ class Engine:
         _lib.check(_lib.lib().bn_bp_last_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    # ---- multi-GPU ---------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib().bn_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes) -> None:
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(_lib.lib().bn_comm_init(self._h, buf))
+
+    # single steps (tests): begin / sweep without exchange / finish
+    def step_begin(self):
+        _lib.check(_lib.lib().bn_bp_step_begin(self._h))
+
+    def step_sweep(self, sweep: int, eps: float):
+        _lib.check(_lib.lib().bn_bp_step_sweep(self._h, sweep, float(eps)))
+
+    def step_finish(self, launched: int, final: bool, eps: float):
+        done, sw, res = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0.0)
+        _lib.check(_lib.lib().bn_bp_step_finish(self._h, launched, 1 if final else 0, float(eps), ctypes.byref(done),
+                                                ctypes.byref(sw), ctypes.byref(res)))
+        return done.value, sw.value, res.value
+
+    def edge_refs(self):
+        pi = np.zeros(max(self.model.n_edges, 1), dtype=np.int32)
+        lam = np.zeros(max(self.model.n_edges, 1), dtype=np.int32)
+        _lib.check(_lib.lib().bn_layout_edge_refs(self._h, _p(pi, ctypes.c_int32), _p(lam, ctypes.c_int32)))
+        return pi[:self.model.n_edges], lam[:self.model.n_edges]
+
     # ---- likelihood weighting ----------------------------------------------------------
     def lw_run(self, ev_state, n_samples: int, seed: int, sample_begin: int = 0) -> np.ndarray:
         """Un-normalised weighted histogram [sum k] of samples [sample_begin, +n_samples)."""
@@ -134,6 +173,34 @@ class Engine:
         s = np.zeros(max(self.model.n, 1), dtype=np.int32)
         _lib.check(_lib.lib().bn_layout_node_slots(self._h, _p(s, ctypes.c_int32)))
         return s[:self.model.n]
+
+
+def debug_allgather(engines, sweep: int) -> None:
+    """Emulated exchange between shard engines living on one device (bn_debug_allgather)."""
+    arr = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    _lib.check(_lib.lib().bn_debug_allgather(arr, len(engines), sweep))
+
+
+def run_shards_on_one_device(engines, evidence, eps: float, max_sweeps: int = 0):
+    """Drive n shard engines on ONE GPU through the step API with the emulated all-gather:
+    the same kernels, layout and stopping logic as the RCCL path, minus the collective itself."""
+    for e in engines:
+        e.bp_set_evidence(evidence)
+        e.step_begin()
+    launched, batch = 0, 4
+    while True:
+        if max_sweeps > 0:
+            batch = min(batch, max_sweeps - launched)
+        for i in range(batch):
+            for e in engines:
+                e.step_sweep(launched + i, eps)
+            debug_allgather(engines, launched + i)
+        launched += batch
+        outs = [e.step_finish(launched, max_sweeps > 0 and launched >= max_sweeps, eps) for e in engines]
+        if len({o[0] != 0 for o in outs}) != 1 or len({o[1] for o in outs if o[0]}) > 1:
+            raise RuntimeError(f"shards disagree on convergence: {outs}")
+        if outs[0][0] != 0:
+            return {"sweeps": outs[0][1], "residual": outs[0][2]}
 
 
 def _split(model: FlatModel, flat: np.ndarray):

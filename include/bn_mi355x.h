@@ -63,6 +63,22 @@ typedef struct bn_engine bn_engine;
 /* Validate the model, build the device layout, upload it.  Replaces the functor constructors. */
 int bn_create(const bn_model_desc *desc, bn_engine **out);
 void bn_destroy(bn_engine *eng);
+
+/*
+ * Multi-GPU: one process per GPU, each creating shard `rank` of `nranks` from the SAME global
+ * model.  owner[v] in [0,nranks) is the edge-cut partition (NULL = contiguous ranges balanced by
+ * CPT bytes: row stripes on a row-major grid).  The pi-message of an edge is computed by the
+ * parent's owner, the lambda-message by the child's owner; cut edges are exchanged by ONE
+ * in-place RCCL all-gather per sweep, which also carries the residual so that every rank stops on
+ * the same sweep.  Bootstrap: rank 0 calls bn_comm_unique_id, ships the 128 bytes to the other
+ * ranks by any means (bench.py: torch.distributed broadcast), every rank calls bn_comm_init.
+ * Beliefs of a sharded engine are node-major over ALL nodes with zeros for nodes of other ranks
+ * (summing the ranks' arrays gives the global result).
+ */
+int bn_create_sharded(const bn_model_desc *desc, int32_t rank, int32_t nranks, const int32_t *owner,
+                      bn_engine **out);
+int bn_comm_unique_id(void *id_out128);
+int bn_comm_init(bn_engine *eng, const void *id128);
 const char *bn_last_error(void);
 const char *bn_version(void);
 
@@ -99,6 +115,14 @@ int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
 int bn_bp_residual_history(bn_engine *eng, double *out, int32_t cap);
 int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
 
+/* Single steps of a run (tests / diagnostics): begin, one sweep (without exchange), finish.
+ * bn_debug_allgather emulates the exchange between n shard engines living on ONE device. */
+int bn_bp_step_begin(bn_engine *eng);
+int bn_bp_step_sweep(bn_engine *eng, int32_t sweep, double eps);
+int bn_bp_step_finish(bn_engine *eng, int32_t launched, int32_t final_batch, double eps,
+                      int32_t *done_out, int32_t *sweeps_out, double *residual_out);
+int bn_debug_allgather(bn_engine **engs, int32_t n, int32_t sweep);
+
 typedef struct bn_bp_stats {
     int32_t sweeps;            /* iterations of the last run                                */
     int32_t sweep_launches;    /* sweep kernels launched (>= sweeps; extras exit at once)    */
@@ -129,9 +153,17 @@ typedef struct bn_layout_info {
     int32_t lanes_per_node_max;
     int64_t cpt_doubles, rec_doubles, node_doubles; /* striped device array sizes (one buffer) */
     int64_t algorithmic_bytes_per_sweep, layout_bytes_per_sweep, messages_per_sweep;
+    int32_t rank, nranks, n_owned;  /* sharding: this rank's share */
+    int32_t pad_;
+    int64_t n_cut_edges;            /* cut edges incident to this rank */
+    int64_t segment_bytes;          /* all-gather payload per rank per sweep (residual slots included) */
+    int64_t segment_used_bytes;     /* message halves this rank actually produces */
+    int64_t exchange_base;          /* start of the exchange region in a record buffer, 16-byte units */
 } bn_layout_info;
 int bn_layout_get(bn_engine *eng, bn_layout_info *out);
-/* node -> (tile*64 + first lane) slot, [n] */
+/* per CSR edge: MsgRef {pi, lam} of bn_plan.hpp on this rank ({-1,0}: no owned endpoint) */
+int bn_layout_edge_refs(bn_engine *eng, int32_t *pi_out, int32_t *lam_out);
+/* node -> lane slot on this rank, -1 for nodes of other ranks, [n] */
 int bn_layout_node_slots(bn_engine *eng, int32_t *slots_out);
 /* per-class: kv, m, lanes_per_node, variant (0 = generic, 1 = register-resident template) */
 int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,

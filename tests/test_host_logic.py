@@ -1,0 +1,147 @@
+"""CPU-only tests: the C ABI library loads and exports every symbol include/bn_mi355x.h declares,
+argument validation, and the host-side layout / partition plan (no compute: there is no GPU here
+and the product has no CPU path)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from bayesiannetwork_amd import Evidence, from_parent_lists, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def E(bnlib):
+    from bayesiannetwork_amd import _lib, engine
+    return lambda m, **kw: engine.Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, **kw)
+
+
+def test_header_symbols_are_exported(bnlib):
+    from bayesiannetwork_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "bn_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(bn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, f"header vs python binding mismatch: {declared ^ bound}"
+    for name in declared:
+        assert hasattr(bnlib, name), f"libbn_mi355x.so does not export {name}"
+    assert b"gfx950" in bnlib.bn_version()
+
+
+def test_no_compute_without_gpu(E, bnlib):
+    from bayesiannetwork_amd import _lib
+    e = E(synth.pearl())
+    with pytest.raises(_lib.BnError) as ei:
+        e.bp_run(None, 1e-3)
+    assert ei.value.code == _lib.BN_ERR_STATE
+    with pytest.raises(_lib.BnError):
+        e.lw_run(np.full(4, -1, np.int32), 10, 1)
+
+
+def test_model_validation_errors(bnlib):
+    from bayesiannetwork_amd import FlatModel, _lib, engine
+    m = synth.pearl()
+
+    def bad(**kw):
+        d = dict(k=m.k.copy(), in_ptr=m.in_ptr.copy(), in_idx=m.in_idx.copy(), cpt_off=m.cpt_off.copy(), cpt=m.cpt.copy())
+        d.update(kw)
+        with pytest.raises(_lib.BnError) as ei:
+            engine.Engine(FlatModel(**d), device=_lib.BN_DEVICE_HOST_ONLY)
+        assert ei.value.code == _lib.BN_ERR_ARG
+    bad(k=np.array([2, 2, 0, 2], np.int32))                        # arity 0
+    bad(in_idx=np.array([0, 1, 0], np.int32))                      # parents of H not ascending
+    bad(in_idx=np.array([0, 0, 7], np.int32))                      # parent out of range
+    bad(in_idx=np.array([2, 0, 1], np.int32))                      # node 2 its own parent
+    bad(cpt_off=np.array([0, 2, 4, 8, 15], np.int64))              # the reference's missing-row UB -> error
+    with pytest.raises(_lib.BnError):
+        engine.Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, rank=3, nranks=2)
+
+
+def test_layout_invariants(E):
+    for model in (synth.grid(23, 31, 4, seed=1), synth.random_dag(700, 4, 32, [2, 3, 4], seed=2), synth.pearl()):
+        e = E(model)
+        li = e.layout()
+        assert li["n_nodes"] == model.n and li["n_edges"] == model.n_edges
+        assert li["algorithmic_bytes_per_sweep"] == model.algorithmic_bytes_per_sweep()
+        assert li["messages_per_sweep"] == model.messages_per_sweep()
+        assert li["layout_bytes_per_sweep"] >= li["algorithmic_bytes_per_sweep"]
+        slots = e.node_slots()
+        assert len(set(slots.tolist())) == model.n and slots.min() >= 0   # integer node indexing is a bijection
+        cls = e.layout_classes()
+        assert sum(c["n_nodes"] for c in cls) == model.n
+        pi, lam = e.edge_refs()
+        assert (pi >= 0).all() and (lam > pi).all()                       # unsharded: every record is tile-resident
+        assert len(set(pi.tolist())) == model.n_edges
+
+
+def test_config3_bytes_match_survey(E):
+    """316x316 grid -> 89.15 MB per sweep, 398 160 messages, 223.9 B per message."""
+    g = synth.grid(316, 316, 4, seed=2)
+    li = E(g).layout()
+    assert li["messages_per_sweep"] == 398160
+    assert abs(li["algorithmic_bytes_per_sweep"] / 1e6 - 89.15) < 0.01
+    assert abs(li["algorithmic_bytes_per_sweep"] / li["messages_per_sweep"] - 223.9) < 0.05
+
+
+@pytest.mark.parametrize("nranks", [2, 5, 8])
+def test_partition_plan_consistent_across_ranks(E, nranks):
+    """Every rank derives the exchange layout independently; they must agree, and every message
+    half of a cut edge must have exactly one slot that no other half shares."""
+    model = synth.random_dag(1500, 4, 64, [4, 3, 2, 4], seed=13)
+    shards = [E(model, rank=r, nranks=nranks) for r in range(nranks)]
+    infos = [s.layout() for s in shards]
+    assert sum(i["n_owned"] for i in infos) == model.n
+    assert sum(i["messages_per_sweep"] for i in infos) == model.messages_per_sweep()
+    assert sum(i["algorithmic_bytes_per_sweep"] for i in infos) == model.algorithmic_bytes_per_sweep()
+    assert len({i["segment_bytes"] for i in infos}) == 1
+    slots = np.stack([s.node_slots() for s in shards])
+    assert ((slots >= 0).sum(axis=0) == 1).all(), "each node is owned by exactly one rank"
+    owner = (slots >= 0).argmax(axis=0)
+    refs = [s.edge_refs() for s in shards]
+    child = np.repeat(np.arange(model.n), np.diff(model.in_ptr))
+    cut = owner[model.in_idx] != owner[child]
+    assert sum(i["n_cut_edges"] for i in infos) == 2 * int(cut.sum())
+    for e in np.nonzero(cut)[0]:
+        a, b = owner[model.in_idx[e]], owner[child[e]]
+        ga, gb = infos[a]["exchange_base"], infos[b]["exchange_base"]
+        ra = (int(refs[a][0][e]) - ga, int(~refs[a][1][e]) - ga)
+        rb = (int(refs[b][0][e]) - gb, int(~refs[b][1][e]) - gb)
+        assert refs[a][1][e] < 0 and refs[b][1][e] < 0 and ra == rb and min(ra) >= 0   # same exchange slots from both ends
+    for r in range(nranks):                                   # non-incident ranks hold no reference
+        inc = (owner[model.in_idx] == r) | (owner[child] == r)
+        assert (refs[r][0][~inc] == -1).all() and (refs[r][0][inc] >= 0).all()
+    # exchange slots are disjoint: [start, start + chunks) intervals of all halves never overlap
+    h = (model.k[model.in_idx] + 1) // 2
+    starts, ends = [], []
+    for e in np.nonzero(cut)[0]:
+        a = owner[model.in_idx[e]]
+        ga = infos[a]["exchange_base"]   # slots relative to the (rank-independent) exchange region
+        pi, lam = int(refs[a][0][e]) - ga, int(~refs[a][1][e]) - ga
+        starts += [pi, lam]
+        ends += [pi + int(h[e]), lam + int(h[e])]
+    order = np.argsort(starts)
+    s, t = np.asarray(starts)[order], np.asarray(ends)[order]
+    assert (s[1:] >= t[:-1]).all()
+
+
+def test_default_partition_is_row_stripes_on_a_grid(E):
+    g = synth.grid(64, 64, 4, seed=3)
+    shards = [E(g, rank=r, nranks=8) for r in range(8)]
+    owner = np.stack([s.node_slots() >= 0 for s in shards]).argmax(axis=0)
+    assert (np.diff(owner) >= 0).all()                        # contiguous id ranges = row stripes
+    counts = np.bincount(owner, minlength=8)
+    assert counts.min() > 0.8 * g.n / 8 and counts.max() < 1.2 * g.n / 8
+
+
+def test_evidence_helpers():
+    m = synth.resume_chain()
+    ev = Evidence.from_dict(m, {1: [0, 0, 1], 3: 0})
+    assert ev.ne == 2 and ev.off.tolist() == [0, 3, 6] and ev.hard_states(m).tolist() == [-1, 2, -1, 0]
+    with pytest.raises(ValueError):
+        Evidence.from_dict(m, {2: [1.0, 0.0, 0.0]})
+    with pytest.raises(ValueError):
+        from_parent_lists([2, 2], [[1], []], [[.5, .5, .5, .5], [.5, .5]]).validate() or \
+            from_parent_lists([2, 2], [[], [1]], [[.5, .5], [.5, .5, .5, .5]])
