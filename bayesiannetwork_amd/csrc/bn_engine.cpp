@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -355,7 +356,9 @@ static int step_sweep(bn_engine* e, int32_t sweep, double eps) {
 // that sweep wrote.  One collective per sweep; it also carries the residual slots.
 static int step_exchange(bn_engine* e, int32_t sweep) {
     const Plan& p = e->plan;
-    if (p.nranks == 1) return BN_OK;
+    // BN_EXCHANGE_ALWAYS: issue the (then trivial) collective on a 1-rank communicator too, so the
+    // RCCL call can be exercised on a single-GPU box
+    if (p.nranks == 1 && !(e->comm && std::getenv("BN_EXCHANGE_ALWAYS"))) return BN_OK;
     if (!e->comm) return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init before running");
     double* g = e->d_rec[(sweep + 1) & 1] + 2 * p.g_base;
     const size_t count = size_t(2 * p.seg_d2);

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--evidence", type=float, default=0.01)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-weak", dest="no_weak", action="store_true", help="N>1: skip the weak-scaling extra")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -59,7 +60,7 @@ def main():
     from bayesiannetwork_amd import synth
     from bayesiannetwork_amd.engine import Engine
 
-    if world > 1:
+    if world > 1 or os.environ.get("BN_FORCE_MULTI"):
         from bayesiannetwork_amd import multigpu
         return multigpu.bench_main(a, rank, world, local_rank)
 

@@ -299,3 +299,77 @@ int oracle_bp_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
     return oracle_bp_run_mt(n, k, in_ptr, in_idx, cpt_off, cpt, ne, ev_node, ev_off, ev_val, eps,
                             max_sweeps, beliefs_out, sweeps_out, res_hist, res_cap, msg_dump, 1);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Stateful API for the multi-process tests (tests/test_dist_cpu.py): the same sweep, but a rank
+ * computes only what it OWNS under an edge-cut partition -- the pi-message of edge p->v when it
+ * owns p, the lambda-message when it owns v, pi(v)/lambda(v) when it owns v -- and leaves the
+ * rest of the next-state arrays untouched for the exchange to fill in.  Jacobi: the union over
+ * ranks equals oracle_sweep exactly.
+ * ------------------------------------------------------------------------------------------- */
+void *oracle_bp_open(int n, const int32_t *k, const int32_t *in_ptr, const int32_t *in_idx,
+                     const int64_t *cpt_off, const double *cpt) {
+    oracle_bp *o = (oracle_bp *)calloc(1, sizeof(oracle_bp));
+    if (!o) return NULL;
+    o->n = n; o->k = k; o->in_ptr = in_ptr; o->in_idx = in_idx; o->cpt_off = cpt_off; o->cpt = cpt;
+    if (oracle_build(o) != 0) { oracle_free(o); free(o); return NULL; }
+    return o;
+}
+
+void oracle_bp_close(void *h) {
+    if (!h) return;
+    oracle_free((oracle_bp *)h);
+    free(h);
+}
+
+void oracle_bp_reset(void *h, int ne, const int32_t *ev_node, const int32_t *ev_off, const double *ev_val) {
+    oracle_init((oracle_bp *)h, ne, ev_node, ev_off, ev_val);
+}
+
+/* which: 0 pi, 1 lambda, 2 pi-messages, 3 lambda-messages, 4..7 the same for the NEXT state */
+double *oracle_bp_array(void *h, int which) {
+    oracle_bp *o = (oracle_bp *)h;
+    double *a[8] = {o->pi, o->lam, o->pim, o->lkm, o->npi, o->nlam, o->npim, o->nlkm};
+    return (which >= 0 && which < 8) ? a[which] : NULL;
+}
+
+/* Computes this rank's share of the next state; returns its share of maximum_difference. */
+double oracle_bp_sweep_owned(void *h, const int32_t *owner, int rank) {
+    oracle_bp *o = (oracle_bp *)h;
+    double md = DBL_MIN;
+    for (int v = 0; v < o->n; ++v) {
+        int m = o->in_ptr[v + 1] - o->in_ptr[v];
+        for (int j = 0; j < m; ++j) {
+            int32_t e = o->in_ptr[v] + j;
+            int p = o->in_idx[e];
+            if (owner[p] == rank) {
+                calc_pi_i(o, v, e);
+                for (int i = 0; i < o->k[p]; ++i)
+                    md = std_max(md, fabs(o->npim[o->msg_off[e] + i] - o->pim[o->msg_off[e] + i]));
+            }
+            if (owner[v] == rank) {
+                calc_lambda_k(o, v, j);
+                for (int i = 0; i < o->k[p]; ++i)
+                    md = std_max(md, fabs(o->nlkm[o->msg_off[e] + i] - o->lkm[o->msg_off[e] + i]));
+            }
+        }
+        if (owner[v] == rank) { calc_pi(o, v); calc_lambda(o, v); }
+    }
+    return md;
+}
+
+void oracle_bp_commit(void *h) {
+    oracle_bp *o = (oracle_bp *)h;
+    double *t;
+    t = o->pi; o->pi = o->npi; o->npi = t;
+    t = o->lam; o->lam = o->nlam; o->nlam = t;
+    t = o->pim; o->pim = o->npim; o->npim = t;
+    t = o->lkm; o->lkm = o->nlkm; o->nlkm = t;
+}
+
+/* belief of node v from the current state (belief_propagation.hpp:151-158) */
+void oracle_bp_belief(void *h, int v, double *out) {
+    oracle_bp *o = (oracle_bp *)h;
+    for (int i = 0; i < o->k[v]; ++i) out[i] = o->pi[o->node_off[v] + i] * o->lam[o->node_off[v] + i];
+    normalize(out, o->k[v]);
+}

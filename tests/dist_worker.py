@@ -1,0 +1,120 @@
+"""Worker of tests/test_dist_cpu.py: one rank of a world_size-N gloo job on CPU.
+
+Exercises the N>1 control flow and the EXCHANGE LAYOUT of the product's partition plan without a
+GPU: each rank computes only what it owns (oracle/bp_oracle.c partial sweep -- checker code, used
+here in tests only), writes the message halves it produces into its exchange segment at the
+offsets the plan (libbn_mi355x.so, host-only engine) assigns, the segments are all-gathered with
+torch.distributed(gloo) exactly like the device path does with RCCL, and every rank reads the
+halves it needs from the gathered region.  The result must equal the unsharded oracle bit for bit."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import oracle  # noqa: E402
+from bayesiannetwork_amd import _lib, synth  # noqa: E402
+from bayesiannetwork_amd.engine import Engine  # noqa: E402
+
+
+def main():
+    case = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    if case == "grid":
+        model, owner_arg = synth.grid(20, 17, 4, seed=3), None
+    else:
+        model = synth.random_dag(400, 4, 32, [2, 3, 4], seed=8)
+        owner_arg = (synth.splitmix64(5, 0, model.n) % np.uint64(world)).astype(np.int32)
+    ev = synth.random_evidence(model, 0.05, seed=2)
+    eps = 1e-6
+
+    # ---- the product's partition plan (host only: no GPU here, and it does no compute)
+    eng = Engine(model, device=_lib.BN_DEVICE_HOST_ONLY, rank=rank, nranks=world, owner=owner_arg)
+    li = eng.layout()
+    gbase, seg_d2 = li["exchange_base"], li["segment_bytes"] // 16
+    ref_pi, ref_lam = eng.edge_refs()
+    owned = eng.node_slots() >= 0
+    t = torch.from_numpy(owned.astype(np.int32) * (rank + 1))
+    dist.all_reduce(t)                      # every node owned exactly once -> owner map on every rank
+    owner = (t.numpy() - 1).astype(np.int32)
+    assert (owner >= 0).all() and (owner < world).all()
+    digest = torch.tensor([li["segment_bytes"], int(owner.sum())], dtype=torch.int64)
+    alld = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(alld, digest)
+    assert all(torch.equal(d, alld[0]) for d in alld), "ranks disagree on the exchange layout"
+
+    # ---- oracle state + owned-part sweeps
+    L = oracle.lib()
+    L.oracle_bp_open.restype = ctypes.c_void_p
+    L.oracle_bp_array.restype = ctypes.POINTER(ctypes.c_double)
+    L.oracle_bp_sweep_owned.restype = ctypes.c_double
+    p = lambda a, ct: a.ctypes.data_as(ctypes.POINTER(ct))  # noqa: E731
+    h = ctypes.c_void_p(L.oracle_bp_open(model.n, p(model.k, ctypes.c_int32), p(model.in_ptr, ctypes.c_int32),
+                                         p(model.in_idx, ctypes.c_int32), p(model.cpt_off, ctypes.c_int64),
+                                         p(model.cpt, ctypes.c_double)))
+    L.oracle_bp_reset(h, ev.ne, p(ev.node, ctypes.c_int32), p(ev.off, ctypes.c_int32), p(ev.val, ctypes.c_double))
+    nm = int(model.msg_off[-1])
+    arr = lambda which, n: np.ctypeslib.as_array(L.oracle_bp_array(h, which), shape=(n,))  # noqa: E731
+    child = np.repeat(np.arange(model.n), np.diff(model.in_ptr))
+    cut = np.nonzero(owner[model.in_idx] != owner[child])[0]
+    moff, kpar = model.msg_off, model.k[model.in_idx]
+
+    sweeps = 0
+    while True:
+        md = L.oracle_bp_sweep_owned(h, p(owner, ctypes.c_int32), rank)
+        npim, nlkm = arr(6, nm), arr(7, nm)
+        # pack: halves this rank produced, at the plan's offsets inside ITS segment
+        seg = np.zeros(seg_d2 * 2, dtype=np.float64)
+        for e in cut:
+            a, b = owner[model.in_idx[e]], owner[child[e]]
+            if a == rank:
+                o = (int(ref_pi[e]) - gbase - rank * seg_d2) * 2
+                seg[o:o + kpar[e]] = npim[moff[e]:moff[e + 1]]
+            if b == rank:
+                o = (int(~ref_lam[e]) - gbase - rank * seg_d2) * 2
+                seg[o:o + kpar[e]] = nlkm[moff[e]:moff[e + 1]]
+        seg[-256:] = 0.0
+        seg[-256] = md                                   # residual rides in the segment's slots
+        gathered = [torch.zeros(seg.size, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(seg))  # the device path: in-place ncclAllGather
+        G = torch.cat(gathered).numpy()
+        # unpack: halves produced by the other endpoint's owner
+        for e in cut:
+            a, b = owner[model.in_idx[e]], owner[child[e]]
+            if b == rank:
+                o = (int(ref_pi[e]) - gbase) * 2
+                npim[moff[e]:moff[e + 1]] = G[o:o + kpar[e]]
+            if a == rank:
+                o = (int(~ref_lam[e]) - gbase) * 2
+                nlkm[moff[e]:moff[e + 1]] = G[o:o + kpar[e]]
+        res = max(float(G[(q + 1) * seg_d2 * 2 - 256]) for q in range(world))
+        L.oracle_bp_commit(h)
+        sweeps += 1
+        if res < eps:
+            break
+    bel = np.zeros(int(model.k.sum()))
+    off = model.node_off
+    buf = (ctypes.c_double * 256)()
+    for v in np.nonzero(owner == rank)[0]:
+        L.oracle_bp_belief(h, int(v), buf)
+        bel[off[v]:off[v + 1]] = np.frombuffer(buf, dtype=np.float64, count=int(model.k[v]))
+    tb = torch.from_numpy(bel)
+    dist.all_reduce(tb)                                  # what multigpu.gather_beliefs does
+    if rank == 0:
+        want = oracle.bp_run(model, ev, eps)
+        assert sweeps == want["sweeps"], (sweeps, want["sweeps"])
+        assert np.array_equal(tb.numpy(), want["beliefs"]), "sharded result differs from the unsharded oracle"
+        print(f"DIST_OK case={case} world={world} sweeps={sweeps} cut_edges={cut.size}")
+    L.oracle_bp_close(h)
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    main()
