@@ -20,6 +20,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def profiled_traffic(rows, cols):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (scripts/profile_bench.sh:
+    FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  Counters cannot be collected from inside this process, so the number comes from
+    the last profile of the same command; None when that workload was not profiled."""
+    label = {(316, 316): "grid316", (2048, 2048): "grid2048"}.get((rows, cols))
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        if name.endswith("_summary.json") and label:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if f"{label}_traffic_bytes_per_launch" in d:
+                best = (d[f"{label}_traffic_bytes_per_launch"], f"profiles/{name}")
+    return best
+
+
 def cpu_baseline(model, ev, eps, budget_s=12.0):
     """The oracle (plain-C port of the reference algorithm), 1 thread like the reference, timed on
     this box's host cores on a bounded number of full runs of the same workload."""
@@ -86,6 +101,7 @@ def main():
     msgs = g.messages_per_sweep() * sweeps_total
     avg_launch_s = kern_ms * 1e-3 / max(launches, 1)
     achieved = st["algorithmic_bytes_per_sweep"] / avg_launch_s / 1e9
+    traffic = profiled_traffic(a.rows, a.cols)
     out = {
         "metric": "edge-messages/sec to BP convergence", "value": msgs / dt, "unit": "edge-messages/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -95,7 +111,8 @@ def main():
                    "sweeps_per_step": sweeps_total / a.steps, "messages_per_sweep": g.messages_per_sweep(),
                    "parallelism": "1 GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                     "traffic_source": traffic[1] if traffic else None,
                      "kernel": "bp_sweep_kernel", "avg_launch_us": avg_launch_s * 1e6,
                      "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"],
                      "layout_bytes_per_launch": st["layout_bytes_per_sweep"]},

@@ -1,0 +1,91 @@
+// bayesian/inference/belief_propagation.hpp -- MI355X drop-in for the reference header of the
+// same path.  Same class, same public surface (reference belief_propagation.hpp:12-31):
+//
+//     bn::inference::belief_propagation bp(graph);
+//     auto marginals = bp(precondition, epsilon);      // epsilon defaults to 0.001
+//     auto marginals = bp(epsilon);                    // no evidence
+//
+// Put this repository's include/ in front of the reference's include path; graph.hpp and
+// matrix.hpp stay the user's.  The functor flattens the graph once (constructor), keeps the
+// network resident on the GPU, and every call runs the HIP kernels behind bn_mi355x.h.
+// Header-only C++14; link with -lbn_mi355x.
+#ifndef BNI_INFERENCE_BELIEF_PROPAGATION_HPP
+#define BNI_INFERENCE_BELIEF_PROPAGATION_HPP
+
+#include <unordered_map>
+#include <vector>
+
+#include "mi355x_flatten.hpp"
+
+namespace bn {
+namespace inference {
+
+class belief_propagation {
+public:
+    typedef std::unordered_map<vertex_type, matrix_type> return_type;
+
+    // The reference copies the graph (graph_t const graph_); vertices are shared_ptrs, so the
+    // keys of the returned map are the caller's vertices either way.
+    explicit belief_propagation(graph_t const& graph)
+        : model_(mi355x::flatten(graph)), engine_(model_)
+    {
+    }
+
+    virtual ~belief_propagation() = default;
+
+    // By-pass (reference :24-28)
+    inline return_type operator()(double const epsilon = 0.001)
+    {
+        std::unordered_map<vertex_type, matrix_type> const precondition;
+        return operator()(precondition, epsilon);
+    }
+
+    // Run: Loopy Belief Propagation (reference :31-159).  Each evidence entry is a 1 x k matrix
+    // that becomes both pi and lambda of its node (:68-73).
+    return_type operator()(std::unordered_map<vertex_type, matrix_type> const& precondition, double const epsilon = 0.001)
+    {
+        std::vector<std::int32_t> ev_node, ev_off(1, 0);
+        std::vector<double> ev_val;
+        for(auto const& p : precondition)
+        {
+            auto const it = model_.index.find(p.first);
+            if(it == model_.index.end()) throw std::runtime_error("belief_propagation: evidence on an unknown vertex");
+            if(p.second.height() != 1) throw std::runtime_error("belief_propagation: evidence must be a 1 x k matrix");
+            ev_node.push_back(it->second);
+            ev_val.insert(ev_val.end(), p.second[0].begin(), p.second[0].end());
+            ev_off.push_back(static_cast<std::int32_t>(ev_val.size()));
+        }
+        std::vector<double> beliefs(static_cast<std::size_t>(model_.node_off.back()));
+        std::int32_t sweeps = 0;
+        double residual = 0;
+        mi355x::engine_handle::check(bn_bp_run(
+            engine_.get(), static_cast<std::int32_t>(ev_node.size()), ev_node.data(), ev_off.data(), ev_val.data(),
+            epsilon, 0 /* unbounded, like the reference */, beliefs.data(), &sweeps, &residual));
+        last_sweeps_ = sweeps;
+        last_residual_ = residual;
+
+        return_type result;
+        for(std::size_t i = 0; i < model_.nodes.size(); ++i)
+        {
+            matrix_type m(1, static_cast<std::size_t>(model_.k[i]));
+            m.assign(beliefs.begin() + model_.node_off[i], beliefs.begin() + model_.node_off[i + 1]);
+            result[model_.nodes[i]] = m;
+        }
+        return result;
+    }
+
+    // Not in the reference (its operator() hides them): iterations and last maximum_difference.
+    int last_sweeps() const { return last_sweeps_; }
+    double last_residual() const { return last_residual_; }
+
+private:
+    mi355x::flat_model model_;
+    mi355x::engine_handle engine_;
+    int last_sweeps_ = 0;
+    double last_residual_ = 0;
+};
+
+} // namespace inference
+} // namespace bn
+
+#endif // #ifndef BNI_INFERENCE_BELIEF_PROPAGATION_HPP

@@ -1,0 +1,131 @@
+// mi355x_flatten.hpp -- graph_t / cpt_t  ->  flat model of bn_mi355x.h, through the PUBLIC
+// interface of the data model only (works with the reference's bayesian/graph.hpp as well as
+// with include/compat/bayesian/graph.hpp).
+//
+// Contract reproduced from the reference:
+//   node id      = position in graph_t::vertex_list()            (graph.hpp:214), never vertex_t::id
+//   parent order = graph_t::in_vertexes(v), i.e. ascending position (graph.hpp:389-413)
+//   CPT row      = mixed radix over the parents, FIRST parent most significant -- the order
+//                  all_combination_pattern enumerates (belief_propagation.hpp:269-295)
+// A missing CPT row, which the reference dereferences as a dangling vector (graph.hpp:120-124),
+// is reported as std::runtime_error here.
+#ifndef BN_MI355X_FLATTEN_HPP
+#define BN_MI355X_FLATTEN_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <bayesian/graph.hpp>
+#include <bayesian/matrix.hpp>
+
+#include "../../bn_mi355x.h"
+
+namespace bn {
+namespace mi355x {
+
+struct flat_model {
+    std::vector<vertex_type> nodes;                    // index -> vertex (copy of vertex_list())
+    std::unordered_map<vertex_type, std::int32_t> index;  // vertex -> index
+    std::vector<std::int32_t> k, in_ptr, in_idx;
+    std::vector<std::int64_t> cpt_off, node_off;
+    std::vector<double> cpt;
+
+    bn_model_desc desc(int device = BN_DEVICE_CURRENT) const
+    {
+        bn_model_desc d;
+        d.n_nodes = static_cast<std::int32_t>(k.size());
+        d.k = k.data();
+        d.in_ptr = in_ptr.data();
+        d.in_idx = in_idx.data();
+        d.cpt_off = cpt_off.data();
+        d.cpt = cpt.data();
+        d.device = device;
+        d.lanes_per_node = 0;
+        return d;
+    }
+};
+
+inline flat_model flatten(graph_t const& graph)
+{
+    flat_model fm;
+    fm.nodes = graph.vertex_list();
+    std::size_t const n = fm.nodes.size();
+    for(std::size_t i = 0; i < n; ++i) fm.index[fm.nodes[i]] = static_cast<std::int32_t>(i);
+
+    fm.k.resize(n);
+    fm.in_ptr.assign(n + 1, 0);
+    fm.cpt_off.assign(n + 1, 0);
+    fm.node_off.assign(n + 1, 0);
+    for(std::size_t i = 0; i < n; ++i)
+    {
+        fm.k[i] = static_cast<std::int32_t>(fm.nodes[i]->selectable_num);
+        fm.node_off[i + 1] = fm.node_off[i] + fm.k[i];
+    }
+    for(std::size_t i = 0; i < n; ++i)
+    {
+        auto const parents = graph.in_vertexes(fm.nodes[i]);
+        std::vector<std::int32_t> radix;
+        for(auto const& p : parents)
+        {
+            auto const it = fm.index.find(p);
+            if(it == fm.index.end()) throw std::runtime_error("bn::mi355x::flatten: parent is not in vertex_list()");
+            fm.in_idx.push_back(it->second);
+            radix.push_back(fm.k[it->second]);
+        }
+        fm.in_ptr[i + 1] = static_cast<std::int32_t>(fm.in_idx.size());
+
+        // every parent assignment, first parent slowest
+        std::vector<int> state(parents.size(), 0);
+        std::size_t rows = 1;
+        for(auto r : radix) rows *= static_cast<std::size_t>(r);
+        for(std::size_t row = 0; row < rows; ++row)
+        {
+            condition_t cond;
+            for(std::size_t j = 0; j < parents.size(); ++j) cond[parents[j]] = state[j];
+            auto const entry = fm.nodes[i]->cpt[cond];
+            if(!entry.first || entry.second.size() != static_cast<std::size_t>(fm.k[i]))
+                throw std::runtime_error("bn::mi355x::flatten: CPT row missing or of wrong length at node "
+                                         + std::to_string(i));
+            fm.cpt.insert(fm.cpt.end(), entry.second.begin(), entry.second.end());
+            for(std::size_t j = parents.size(); j-- > 0;)
+            {
+                if(++state[j] < radix[j]) break;
+                state[j] = 0;
+            }
+        }
+        fm.cpt_off[i + 1] = static_cast<std::int64_t>(fm.cpt.size());
+    }
+    return fm;
+}
+
+// RAII over the C handle; non-zero codes become std::runtime_error (no exception crosses the ABI).
+class engine_handle {
+public:
+    engine_handle() = default;
+    explicit engine_handle(flat_model const& fm, int device = BN_DEVICE_CURRENT)
+    {
+        bn_model_desc const d = fm.desc(device);
+        check(bn_create(&d, &handle_));
+    }
+    engine_handle(engine_handle const&) = delete;
+    engine_handle& operator=(engine_handle const&) = delete;
+    engine_handle(engine_handle&& other) noexcept : handle_(other.handle_) { other.handle_ = nullptr; }
+    ~engine_handle() { if(handle_) bn_destroy(handle_); }
+
+    bn_engine* get() const { return handle_; }
+    static void check(int rc)
+    {
+        if(rc < 0) throw std::runtime_error(std::string("bn_mi355x: ") + bn_last_error());
+    }
+
+private:
+    bn_engine* handle_ = nullptr;
+};
+
+} // namespace mi355x
+} // namespace bn
+
+#endif // BN_MI355X_FLATTEN_HPP

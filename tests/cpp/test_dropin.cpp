@@ -1,0 +1,195 @@
+// tests/cpp/test_dropin.cpp -- the reference's own BP test cases (libs/bayesian/test/
+// belief_propagation.cpp: Pearl R,S->W,H parts 1-2, and the five "resume" chain cases) run through
+// the drop-in class surface bn::inference::belief_propagation of this repository, plus a
+// likelihood-weighting call.  Builds against EITHER data model:
+//     -Iinclude -Iinclude/compat          (this repository's stand-in, GPU box)
+//     -Iinclude -I/root/reference         (the reference's graph.hpp / matrix.hpp: true drop-in)
+// Modes:  --flatten  print the flat model of both networks as JSON (no GPU needed)
+//         (default)  run inference, check the reference's teacher values, print 17-digit marginals
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <bayesian/graph.hpp>
+#include <bayesian/inference/belief_propagation.hpp>
+#include <bayesian/inference/likelihood_weighting.hpp>
+
+namespace {
+
+struct node_spec {
+    int arity;
+    std::vector<int> parents;           // positions in the network
+    std::vector<double> rows;           // row-major, first parent slowest
+};
+
+// table-driven construction through the public graph_t / cpt_t interface
+bn::graph_t build(std::vector<node_spec> const& spec)
+{
+    bn::graph_t g;
+    for(std::size_t i = 0; i < spec.size(); ++i)
+    {
+        auto v = g.add_vertex();
+        v->id = static_cast<int>(i) + 1;
+        v->selectable_num = spec[i].arity;
+    }
+    auto const vl = g.vertex_list();
+    for(std::size_t i = 0; i < spec.size(); ++i)
+        for(int p : spec[i].parents)
+            if(!g.add_edge(vl[p], vl[i])) std::printf("add_edge failed\n");
+    for(std::size_t i = 0; i < spec.size(); ++i)
+    {
+        std::vector<bn::vertex_type> ps;
+        for(int p : spec[i].parents) ps.push_back(vl[p]);
+        vl[i]->cpt.assign(ps, vl[i]);
+        std::vector<int> st(ps.size(), 0);
+        std::size_t const k = spec[i].arity;
+        for(std::size_t r = 0; r * k < spec[i].rows.size(); ++r)
+        {
+            bn::condition_t cond;
+            for(std::size_t j = 0; j < ps.size(); ++j) cond[ps[j]] = st[j];
+            vl[i]->cpt[cond].second.assign(spec[i].rows.begin() + r * k, spec[i].rows.begin() + (r + 1) * k);
+            for(std::size_t j = ps.size(); j-- > 0;)
+            {
+                if(++st[j] < spec[spec[i].parents[j]].arity) break;
+                st[j] = 0;
+            }
+        }
+    }
+    return g;
+}
+
+std::vector<node_spec> pearl_spec()
+{
+    return {{2, {}, {0.2, 0.8}},
+            {2, {}, {0.1, 0.9}},
+            {2, {0}, {1.0, 0.0, 0.2, 0.8}},
+            {2, {0, 1}, {1.0, 0.0, 1.0, 0.0, 0.9, 0.1, 0.0, 1.0}}};
+}
+
+std::vector<node_spec> resume_spec()
+{
+    return {{3, {}, {0.30, 0.60, 0.10}},
+            {3, {0}, {0.20, 0.30, 0.50, 0.30, 0.30, 0.40, 0.80, 0.10, 0.10}},
+            {2, {1}, {0.50, 0.50, 0.70, 0.30, 0.40, 0.60}},
+            {3, {2}, {0.40, 0.30, 0.30, 0.20, 0.60, 0.20}}};
+}
+
+int failures = 0;
+
+void close_pct(double value, double teacher, double pct, char const* what)
+{
+    bool ok = (teacher == 0.0) ? std::fabs(value) < 1e-12 : std::fabs(value - teacher) / std::fabs(teacher) * 100.0 <= pct;
+    if(!ok) { ++failures; std::printf("FAIL %s: %.17g vs teacher %.17g (%g %%)\n", what, value, teacher, pct); }
+}
+
+bn::matrix_type one_hot(std::vector<double> const& v)
+{
+    bn::matrix_type m(1, v.size());
+    m[0] = v;
+    return m;
+}
+
+template<class V> void print_json_array(char const* name, V const& v, bool last = false)
+{
+    std::printf("\"%s\":[", name);
+    for(std::size_t i = 0; i < v.size(); ++i) std::printf("%s%.17g", i ? "," : "", static_cast<double>(v[i]));
+    std::printf("]%s", last ? "" : ",");
+}
+
+void print_flat(char const* name, bn::graph_t const& g, bool last)
+{
+    auto const fm = bn::mi355x::flatten(g);
+    std::printf("\"%s\":{", name);
+    print_json_array("k", fm.k);
+    print_json_array("in_ptr", fm.in_ptr);
+    print_json_array("in_idx", fm.in_idx);
+    print_json_array("cpt_off", fm.cpt_off);
+    print_json_array("cpt", fm.cpt, true);
+    std::printf("}%s", last ? "" : ",");
+}
+
+void print_marginals(char const* name, bn::graph_t const& g,
+                     std::unordered_map<bn::vertex_type, bn::matrix_type> const& res, bool last = false)
+{
+    std::printf("\"%s\":[", name);
+    auto const vl = g.vertex_list();
+    bool first = true;
+    for(auto const& v : vl)
+        for(double x : res.at(v)[0]) { std::printf("%s%.17g", first ? "" : ",", x); first = false; }
+    std::printf("]%s", last ? "" : ",");
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    bn::graph_t const pearl = build(pearl_spec());
+    bn::graph_t const chain = build(resume_spec());
+    if(argc > 1 && std::strcmp(argv[1], "--flatten") == 0)
+    {
+        std::printf("{");
+        print_flat("pearl", pearl, false);
+        print_flat("resume_chain", chain, true);
+        std::printf("}\n");
+        return 0;
+    }
+
+    std::printf("{");
+    {   // belief_propagation_pearl_part1 / part2
+        auto const v = pearl.vertex_list();
+        bn::inference::belief_propagation bp(pearl);
+        auto const r1 = bp();
+        double const t1[4][2] = {{.2, .8}, {.1, .9}, {.36, .64}, {.272, .728}};
+        for(int i = 0; i < 4; ++i)
+            for(int j = 0; j < 2; ++j) close_pct(r1.at(v[i])[0][j], t1[i][j], 0.01, "pearl part1");
+        print_marginals("pearl_part1", pearl, r1);
+        std::unordered_map<bn::vertex_type, bn::matrix_type> pre;
+        pre[v[3]] = one_hot({1, 0});
+        auto const r2 = bp(pre);
+        double const t2[4][2] = {{.7353, .2647}, {.3382, .6618}, {.7882, .2118}, {1.0, 0.0}};
+        for(int i = 0; i < 4; ++i)
+            for(int j = 0; j < 2; ++j) close_pct(r2.at(v[i])[0][j], t2[i][j], 0.1, "pearl part2");
+        print_marginals("pearl_part2", pearl, r2);
+        std::printf("\"pearl_part2_sweeps\":%d,", bp.last_sweeps());
+    }
+    {   // belief_propagation_resume_ex, _sample1 .. _sample4  (3 % tolerance, one queried node each)
+        auto const v = chain.vertex_list();
+        struct rc { std::vector<std::pair<int, std::vector<double>>> ev; int query; std::vector<double> teacher; };
+        std::vector<rc> const cases = {
+            {{{1, {0, 0, 1}}, {3, {1, 0, 0}}}, 2, {0.570, 0.430}},
+            {{{2, {0, 1}}}, 1, {0.330, 0.170, 0.500}},
+            {{{0, {0, 1, 0}}, {2, {0, 1}}}, 1, {0.310, 0.190, 0.500}},
+            {{{3, {0, 0, 1}}}, 0, {0.300, 0.600, 0.100}},
+            {{{0, {1, 0, 0}}}, 1, {0.200, 0.300, 0.500}},
+        };
+        int idx = 0;
+        for(auto const& c : cases)
+        {
+            std::unordered_map<bn::vertex_type, bn::matrix_type> pre;
+            for(auto const& e : c.ev) pre[v[e.first]] = one_hot(e.second);
+            bn::inference::belief_propagation func(chain);
+            auto const res = func(pre);
+            for(std::size_t j = 0; j < c.teacher.size(); ++j) close_pct(res.at(v[c.query])[0][j], c.teacher[j], 3.0, "resume");
+            print_marginals(("resume_" + std::to_string(idx++)).c_str(), chain, res);
+        }
+    }
+    {   // likelihood weighting on Pearl, H = 0: within 2 % of the exact marginals at 4e5 samples
+        auto const v = pearl.vertex_list();
+        bn::inference::likelihood_weighting lw(pearl);
+        lw.seed(2024);
+        bn::inference::likelihood_weighting::evidence_list ev;
+        ev[v[3]] = 0;
+        auto const res = lw(ev, 400000);
+        double const exact[3][2] = {{0.73529411764705888, 0.26470588235294118}, {0.33823529411764708, 0.66176470588235292},
+                                    {0.78823529411764715, 0.21176470588235297}};
+        for(int i = 0; i < 3; ++i)
+            for(int j = 0; j < 2; ++j) close_pct(res.at(v[i])[0][j], exact[i][j], 2.0, "lw pearl");
+        print_marginals("lw_pearl", pearl, res, true);
+    }
+    std::printf("}\n");
+    if(failures) std::printf("%d FAILURES\n", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,65 @@
+"""The header-only C++14 drop-in (include/bayesian/inference/*.hpp) over the C ABI.
+
+CPU: the test program compiles against this repository's stand-in data model AND against the
+reference's own graph.hpp / matrix.hpp (where /root/reference exists), and the flattened networks
+equal the flat models used everywhere else.  GPU: the reference's seven BP test cases run through
+bn::inference::belief_propagation, teacher tolerances of the reference tests, and the marginals are
+bit-identical to the reference's golden outputs."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "test_dropin.cpp")
+LIBDIR = os.path.join(ROOT, "bayesiannetwork_amd")
+
+
+def build(tmp_path, model_include, name):
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", model_include, SRC,
+           "-L", LIBDIR, "-lbn_mi355x", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return exe
+
+
+def check_flatten(exe):
+    from bayesiannetwork_amd import synth
+    out = subprocess.run([exe, "--flatten"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout)
+    for name, model in (("pearl", synth.pearl()), ("resume_chain", synth.resume_chain())):
+        f = d[name]
+        assert f["k"] == model.k.tolist() and f["in_ptr"] == model.in_ptr.tolist()
+        assert f["in_idx"] == model.in_idx.tolist() and f["cpt_off"] == model.cpt_off.tolist()
+        assert np.array_equal(np.asarray(f["cpt"]), model.cpt)
+
+
+def test_flatten_with_compat_model(bnlib, tmp_path):
+    check_flatten(build(tmp_path, os.path.join(ROOT, "include", "compat"), "dropin_compat"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/bayesian"), reason="reference headers not on this box")
+def test_flatten_with_reference_model(bnlib, tmp_path):
+    """True drop-in: the user's include path is the reference's; only bayesian/inference is ours."""
+    check_flatten(build(tmp_path, "/root/reference", "dropin_ref"))
+
+
+@pytest.mark.gpu
+def test_reference_cases_through_cpp_classes(bnlib, tmp_path):
+    exe = build(tmp_path, os.path.join(ROOT, "include", "compat"), "dropin_gpu")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.splitlines()[0])
+    _, pearl_runs, _ = load_golden("bp_pearl")
+    assert np.array_equal(np.asarray(d["pearl_part1"]), pearl_runs[0]["beliefs"])
+    assert np.array_equal(np.asarray(d["pearl_part2"]), pearl_runs[1]["beliefs"])
+    assert d["pearl_part2_sweeps"] == pearl_runs[1]["sweeps"]
+    _, chain_runs, _ = load_golden("bp_resume_chain")
+    for i, r in enumerate(chain_runs):
+        assert np.array_equal(np.asarray(d[f"resume_{i}"]), r["beliefs"])
