@@ -197,6 +197,117 @@ __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// parent role with up to RC children held in registers (k = K for node and messages): each
+// child's lambda-message is loaded ONCE; the O(c^2) products of calculate_pi_i (:207-214) then run
+// on registers in the reference's order (ascending child, skipping the target).  Caller passes
+// pi(v) / lambda(v) as it read them (or synthesised them in iteration 0).
+// ---------------------------------------------------------------------------------------------
+template <int K, int RC, bool NT>
+__device__ __forceinline__ double parent_role_regs(const BpBuffers& b, const IO& io, const TileDesc& td, int nl,
+                                                   bool frozen, const double* piv, const double* lav) {
+    constexpr int KP = (K + 1) & ~1, H = KP / 2;
+    const int npt = td.npt;
+    const MsgRef* orf = b.out_refs + td.out_base + nl;
+    const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
+    double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
+    double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + nl;
+    double wres = 0.0;
+    MsgRef oref[RC];  // kept packed (8 B per child) and decoded at each use: registers matter here
+    double lkc[RC][KP];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+        oref[c] = MsgRef{-1, 0};
+        if (c < td.cmax) oref[c] = orf[int64_t(c) * npt];
+    }
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
+        if (c < td.cmax && !io.first) {
+            const Loc l = decode_ref(oref[c], H);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const double2_t y = rec_in2[l.lam + h * l.stride];
+                lkc[c][2 * h] = l.has ? y.x : 1.0;
+                lkc[c][2 * h + 1] = l.has ? y.y : 1.0;
+            }
+        }
+    }
+    {   // lambda(v) (:220-238)
+        double t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            double acc = 1.0;
+#pragma unroll
+            for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
+            t[i] = acc;
+        }
+        normalize_k<K>(t);
+        double l[KP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) l[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) l[i] = frozen ? lav[i] : t[i];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            double2_t z;
+            z.x = l[2 * h]; z.y = l[2 * h + 1];
+            bn_store<NT>(&nout[(H + h) * npt], z);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+        if (c < td.cmax) {  // wave-uniform
+            double u[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                double acc = piv[i];
+#pragma unroll
+                for (int x = 0; x < RC; ++x)
+                    if (x != c) acc *= lkc[x][i];
+                u[i] = acc;
+            }
+            normalize_k<K>(u);
+            const Loc l = decode_ref(oref[c], H);
+            if (l.has) {
+                double o[KP], old[KP];
+#pragma unroll
+                for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
+                if (!io.first) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const double2_t x = rec_in2[l.pi + h * l.stride];
+                        old[2 * h] = x.x; old[2 * h + 1] = x.y;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    o[i] = u[i];
+                    wres = res_acc(wres, fabs(u[i] - old[i]));
+                }
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    double2_t y;
+                    y.x = o[2 * h]; y.y = o[2 * h + 1];
+                    bn_store<NT>(&rec_out2[l.pi + h * l.stride], y);
+                }
+            }
+        }
+    }
+    return wres;
+}
+
+// parent role for a node of arity K with any number of children: registers up to 16, memory beyond
+template <int K, bool NT>
+__device__ __forceinline__ double parent_role_any(const BpBuffers& b, const IO& io, const TileDesc& td, int nl,
+                                                  bool frozen, const double* piv, const double* lav) {
+    if (td.cmax <= 4) return parent_role_regs<K, 4, NT>(b, io, td, nl, frozen, piv, lav);
+    if (td.cmax <= 8) return parent_role_regs<K, 8, NT>(b, io, td, nl, frozen, piv, lav);
+    if (td.cmax <= 16) return parent_role_regs<K, 16, NT>(b, io, td, nl, frozen, piv, lav);
+    return parent_role_generic(b, io, td, K, (K + 1) & ~1, nl, frozen);
+}
+
+// ---------------------------------------------------------------------------------------------
 // generic tile: any arities, runtime loops, one lane per node.  Correctness path for shapes
 // without a register-resident instantiation.
 // ---------------------------------------------------------------------------------------------
@@ -508,8 +619,203 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                 }
             }
         }
-        if constexpr (RC == 0)  // fan-out beyond the register path: parent role through memory
-            wres = res_acc(wres, parent_role_generic(b, io, td, K, KP, lane, frozen));
+        if constexpr (RC == 0)  // more children than the fused path holds: separate parent role
+            wres = res_acc(wres, parent_role_any<K, NT>(b, io, td, lane, frozen, piv, lav));
+    }
+    return wres;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lane-group tile: k = 4, M = D + 2 parents, G = 4^D lanes per node (NPT = 64 / G nodes per
+// wave).  Lane (nl, g) owns the assignments whose D leading parents are in state digits(g) -- 64
+// CPT entries, the two trailing parents and the own state -- streams them through registers like
+// the register-resident path, and the partial sums are combined inside the G-lane group with
+// shuffles.  Products keep the reference's ascending-parent order (:190-193, :250-258); the SUM
+// over assignments is re-associated across lanes, so results agree with the reference to
+// rounding (not bit-for-bit; with >= 3 parents the reference's own products are unordered, :253).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_xor_d(double x, int mask) { return __shfl_xor(x, mask, kWave); }
+__device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, kWave); }
+__device__ __forceinline__ double pick4(const double (&v)[4], int d) {
+    return d == 0 ? v[0] : (d == 1 ? v[1] : (d == 2 ? v[2] : v[3]));
+}
+
+template <int D, bool NT>
+__device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
+    constexpr int K = 4, H = 2, M = D + 2;
+    constexpr int G = 1 << (2 * D), NPT = kWave / G;
+    const int nl = lane / G, g = lane % G;
+    const bool active = nl < td.n_nodes;
+    double wres = 0.0;
+
+    // ---- loads: this lane's 64 CPT entries (i-major: q = i*16 + c_{M-2}*4 + c_{M-1})
+    const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
+    double cpt[64];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const double2_t x = cp[q * kWave];
+        cpt[2 * q] = x.x;
+        cpt[2 * q + 1] = x.y;
+    }
+    const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
+    double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
+    const int nlc = active ? nl : 0;  // inactive groups shadow node 0 and write nothing
+    Loc in[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        in[j].has = true;
+        in[j].pi = td.rec_base / 2 + (j * 2 * H) * NPT + nlc;
+        in[j].lam = in[j].pi + H * NPT;
+        in[j].stride = NPT;
+    }
+    if (td.in_ref_base >= 0) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) in[j] = decode_ref(b.in_refs[td.in_ref_base + j * NPT + nlc], H);
+    }
+    const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + nlc;
+    double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + nlc;
+    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
+    double pim[M][K];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+#pragma unroll
+        for (int i = 0; i < K; ++i) pim[j][i] = 1.0;
+    if (!io.first) {
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const double2_t x = rec_in2[in[j].pi + h * in[j].stride];
+                pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
+            }
+    }
+    double piv[K], lav[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }
+    if (!io.first || frozen) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const double2_t x = nin[h * NPT], y = nin[(H + h) * NPT];
+            piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
+            lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+        }
+    }
+    // pi-message entries of the lane-fixed parents
+    double pfix[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) pfix[j] = pick4(pim[j], (g >> (2 * (D - 1 - j))) & 3);
+
+    // ---- partial sums over this lane's 64 entries
+    double pp[K];          // pi(v)[i]
+    double ol[2][K];       // lambda-messages to the two trailing parents, by target state
+    double sf[D];          // lambda-messages to the leading parents: this lane's own bucket
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < K; ++ct) ol[t][ct] = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) sf[j] = 0.0;
+#pragma unroll
+    for (int ib = 0; ib < K; ++ib) {
+        double acc = 0.0;
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl) {
+            const int ca = cl >> 2, cb = cl & 3;  // states of parents M-2 and M-1
+            const double e = cpt[ib * 16 + cl];
+            // calculate_pi: cpt * pi-messages, ascending parent order
+            double v = e;
+#pragma unroll
+            for (int j = 0; j < D; ++j) v *= pfix[j];
+            v *= pim[M - 2][ca];
+            v *= pim[M - 1][cb];
+            acc += v;
+            // calculate_lambda_k: (lambda[i] * cpt) * the OTHER parents' pi-messages, ascending
+            const double tc = lav[ib] * e;
+            double pre = tc;  // shared prefix over the leading parents
+#pragma unroll
+            for (int j = 0; j < D; ++j) pre *= pfix[j];
+            ol[0][ca] += pre * pim[M - 1][cb];
+            ol[1][cb] += pre * pim[M - 2][ca];
+#pragma unroll
+            for (int jt = 0; jt < D; ++jt) {
+                double w = tc;
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    if (j != jt) w *= pfix[j];
+                w *= pim[M - 2][ca];
+                w *= pim[M - 1][cb];
+                sf[jt] += w;
+            }
+        }
+        pp[ib] = acc;
+    }
+
+    // ---- combine inside the G-lane group
+#pragma unroll
+    for (int mask = 1; mask < G; mask <<= 1) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) pp[i] += shfl_xor_d(pp[i], mask);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ct = 0; ct < K; ++ct) ol[t][ct] += shfl_xor_d(ol[t][ct], mask);
+    }
+    // leading parent jt: sum over the lanes that share digit jt (all other lane digits), then
+    // collect the four buckets from the lanes whose other digits are zero
+    double of[D][K];
+#pragma unroll
+    for (int jt = 0; jt < D; ++jt) {
+        double x = sf[jt];
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j != jt) {
+                x += shfl_xor_d(x, 1 << (2 * (D - 1 - j)));
+                x += shfl_xor_d(x, 2 << (2 * (D - 1 - j)));
+            }
+#pragma unroll
+        for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
+    }
+
+    // ---- the group's first lane finishes the node: normalise, residual, stores, parent role
+    if (active && g == 0) {
+        normalize_k<K>(pp);
+        {
+            double2_t y0, y1;
+            y0.x = frozen ? piv[0] : pp[0]; y0.y = frozen ? piv[1] : pp[1];
+            y1.x = frozen ? piv[2] : pp[2]; y1.y = frozen ? piv[3] : pp[3];
+            bn_store<NT>(&nout[0 * NPT], y0);
+            bn_store<NT>(&nout[1 * NPT], y1);
+        }
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt) {
+            double o[K];
+#pragma unroll
+            for (int ct = 0; ct < K; ++ct) o[ct] = jt < D ? of[jt < D ? jt : 0][ct] : ol[jt >= D ? jt - D : 0][ct];
+            normalize_k<K>(o);
+            double old[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) old[i] = 1.0;
+            if (!io.first) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t y = rec_in2[in[jt].lam + h * in[jt].stride];
+                    old[2 * h] = y.x; old[2 * h + 1] = y.y;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - old[i]));
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double2_t y;
+                y.x = o[2 * h]; y.y = o[2 * h + 1];
+                bn_store<NT>(&rec_out2[in[jt].lam + h * in[jt].stride], y);
+            }
+        }
+        if (io.first && !frozen) {  // initial state (:38-41); a group node always has parents
+#pragma unroll
+            for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }
+        }
+        wres = res_acc(wres, parent_role_any<K, NT>(b, io, td, nl, frozen, piv, lav));
     }
     return wres;
 }
@@ -579,6 +885,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a)
             case 4 * 8 + 0: wres = tile_uniform_dispatch<4, 0, NT>(b, io, td, lane); break;
             case 4 * 8 + 1: wres = tile_uniform_dispatch<4, 1, NT>(b, io, td, lane); break;
             case 4 * 8 + 2: wres = tile_uniform_dispatch<4, 2, NT>(b, io, td, lane); break;
+            default: handled = false; break;
+        }
+    }
+    if (td.variant == kVariantGroup) {
+        handled = true;
+        switch (td.m) {
+            case 3: wres = tile_group<1, NT>(b, io, td, lane); break;
+            case 4: wres = tile_group<2, NT>(b, io, td, lane); break;
+            case 5: wres = tile_group<3, NT>(b, io, td, lane); break;
             default: handled = false; break;
         }
     }

@@ -11,10 +11,13 @@ namespace bnmi {
 
 static inline int32_t round_even(int32_t x) { return (x + 1) & ~1; }
 
-// Lanes per node for a uniform-arity class.
-static int pick_lanes(int kv, int m, int64_t rows, int forced) {
-    (void)kv; (void)m; (void)rows; (void)forced;
-    return 1;  // sub-wave groups (G = 4, 16) are not wired into the kernels yet
+// Lanes per node.  k = 4 with 3, 4 or 5 parents: 4, 16 or 64 lanes cooperate on one node, each
+// owning the 64 CPT entries of one assignment of the leading parents -- the same per-lane footprint
+// as the register-resident path -- and the partial sums are combined with wave shuffles.
+static int pick_lanes(int kv, int m, bool all_k4, int forced) {
+    if (forced == 1) return 1;
+    if (kv == 4 && all_k4 && m >= 3 && m <= 5) return 1 << (2 * (m - 2));
+    return 1;
 }
 
 void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>& owner) {
@@ -135,9 +138,10 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             }
             for (int j = c.m - 1, s = 1; j >= 0; --j) { c.cstride[j] = s; s *= c.kp[j]; }
             c.rows = int32_t(rows);
+            const bool all_k4 = uniform && c.kv == 4;
             if (int64_t(c.kv) * rows > 64) uniform = false;  // register-resident CPT: <= 64 entries
-            c.variant = uniform ? kVariantUniform : kVariantGeneric;
-            c.G = uniform ? pick_lanes(c.kv, c.m, rows, d.lanes_per_node) : 1;
+            c.G = pick_lanes(c.kv, c.m, all_k4, d.lanes_per_node);
+            c.variant = c.G > 1 ? kVariantGroup : (uniform ? kVariantUniform : kVariantGeneric);
             c.npt = kWave / c.G;
             c.per_lane = int32_t(int64_t(c.kv) * rows / c.G);
             c.per_lane_pad = round_even(c.per_lane);

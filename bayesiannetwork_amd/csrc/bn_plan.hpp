@@ -49,6 +49,7 @@ constexpr int kResSlotsD2 = kResSlots / 2;  // ... in double2 units (8 B each)
 enum Variant : int32_t {
     kVariantGeneric = 0,   // runtime loops, any shape, G = 1
     kVariantUniform = 1,   // templated: node and all parents share k in {2,3,4}, CPT <= 64 entries
+    kVariantGroup = 2,     // k = 4, 3..5 parents: G = 4^(m-2) lanes share a node, 64 entries per lane
 };
 
 // Device-visible shape class.  POD.
