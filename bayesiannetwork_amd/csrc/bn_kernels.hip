@@ -298,12 +298,16 @@ __device__ __forceinline__ double parent_role_regs(const BpBuffers& b, const IO&
 }
 
 // parent role for a node of arity K with any number of children: registers up to 16, memory beyond
-template <int K, bool NT>
+template <int K, bool NT, int RCMAX>
 __device__ __forceinline__ double parent_role_any(const BpBuffers& b, const IO& io, const TileDesc& td, int nl,
                                                   bool frozen, const double* piv, const double* lav) {
     if (td.cmax <= 4) return parent_role_regs<K, 4, NT>(b, io, td, nl, frozen, piv, lav);
     if (td.cmax <= 8) return parent_role_regs<K, 8, NT>(b, io, td, nl, frozen, piv, lav);
-    if (td.cmax <= 16) return parent_role_regs<K, 16, NT>(b, io, td, nl, frozen, piv, lav);
+    if constexpr (RCMAX >= 16) {
+        if (td.cmax <= 16) return parent_role_regs<K, 16, NT>(b, io, td, nl, frozen, piv, lav);
+    } else if constexpr (RCMAX >= 12) {
+        if (td.cmax <= 12) return parent_role_regs<K, 12, NT>(b, io, td, nl, frozen, piv, lav);
+    }
     return parent_role_generic(b, io, td, K, (K + 1) & ~1, nl, frozen);
 }
 
@@ -387,13 +391,31 @@ __device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io,
 // doubles) in VGPRs, every loop unrolled at compile time, 16-byte lane-striped loads.
 // RC = children per node held in registers (the tile's cmax <= RC; RC = 0: parent role elsewhere).
 // ---------------------------------------------------------------------------------------------
-template <int K, int M, int RC, bool NT>
+// IND: boundary tile (sharded run) -- in-edge records are reached through MsgRefs; otherwise
+// they are addressed arithmetically inside the tile's own block with immediate offsets.
+template <int K, int M, int RC, bool NT, bool IND>
 __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
     constexpr int CB = (M > 0) ? C / K : 0;  // assignments per lambda bucket and own state
     double wres = 0.0;
     if (lane < td.n_nodes) {
+        // ---- parent-role loads FIRST: the out-edge references head a dependent chain
+        // (reference -> child record), so they are issued before the 32 CPT loads stream in
+        const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
+        double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
+        // out-edge references, then the children's lambda-messages.
+        // A missing child reads record 0 and contributes 1.0 (x * 1.0 == x exactly).
+        const MsgRef* orf = b.out_refs + td.out_base + lane;
+        Loc oref[RC > 0 ? RC : 1];
+        double lkc[RC > 0 ? RC : 1][KP];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+            MsgRef r{-1, 0};
+            if (c < td.cmax) r = orf[c * kWave];
+            oref[c] = decode_ref(r, H);
+        }
+
         // ---- child-role loads: CPT, pi-messages from the parents, pi(v), lambda(v)
         const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
         double cpt[SP];
@@ -403,22 +425,33 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             cpt[2 * q] = x.x;
             cpt[2 * q + 1] = x.y;
         }
-        const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
-        double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
+        // the children's lambda-messages (second hop of the reference chain)
+#pragma unroll
+        for (int c = 0; c < RC; ++c) {
+#pragma unroll
+            for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
+            if (c < td.cmax && !io.first) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t y = rec_in2[oref[c].lam + h * oref[c].stride];
+                    lkc[c][2 * h] = oref[c].has ? y.x : 1.0;
+                    lkc[c][2 * h + 1] = oref[c].has ? y.y : 1.0;
+                }
+            }
+        }
         // in-edge j's record: inside the tile's own block (arithmetic), or -- boundary tile, some
         // parent lives on another rank -- wherever its reference says (exchange region for cut edges)
         Loc in[M > 0 ? M : 1];
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            in[j].has = true;
-            in[j].pi = td.rec_base / 2 + (j * 2 * H) * kWave + lane;
-            in[j].lam = in[j].pi + H * kWave;
-            in[j].stride = kWave;
-        }
-        if (td.in_ref_base >= 0) {
+        if constexpr (IND) {
 #pragma unroll
             for (int j = 0; j < M; ++j) in[j] = decode_ref(b.in_refs[td.in_ref_base + j * kWave + lane], H);
         }
+        const int64_t rbase = td.rec_base / 2 + lane;  // this lane's slot in the tile's record block
+        // chunk h of the pi-message (part 0) / lambda-message (part 1) of in-edge j
+        auto in_idx = [&](int j, int part, int h) -> int64_t {
+            if constexpr (IND) return (part ? in[j].lam : in[j].pi) + h * in[j].stride;
+            else return rbase + ((j * 2 + part) * H + h) * kWave;
+        };
         const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + lane;
         double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + lane;
         const bool frozen = b.frozen[td.slot_base + lane] != 0;
@@ -432,7 +465,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             for (int j = 0; j < M; ++j)
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const double2_t x = rec_in2[in[j].pi + h * in[j].stride];
+                    const double2_t x = rec_in2[in_idx(j, 0, h)];
                     pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
                 }
         }
@@ -448,31 +481,6 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                 const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
                 piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
                 lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
-            }
-        }
-
-        // ---- parent-role loads: out-edge references, then the children's lambda-messages.
-        // A missing child reads record 0 and contributes 1.0 (x * 1.0 == x exactly).
-        const MsgRef* orf = b.out_refs + td.out_base + lane;
-        Loc oref[RC > 0 ? RC : 1];
-        double lkc[RC > 0 ? RC : 1][KP];
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            MsgRef r{-1, 0};
-            if (c < td.cmax) r = orf[c * kWave];
-            oref[c] = decode_ref(r, H);
-        }
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-#pragma unroll
-            for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
-            if (c < td.cmax && !io.first) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const double2_t y = rec_in2[oref[c].lam + h * oref[c].stride];
-                    lkc[c][2 * h] = oref[c].has ? y.x : 1.0;
-                    lkc[c][2 * h + 1] = oref[c].has ? y.y : 1.0;
-                }
             }
         }
 
@@ -564,7 +572,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             if (!io.first) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {  // previous lambda-message of this edge, for the residual
-                    const double2_t y = rec_in2[in[jt].lam + h * in[jt].stride];
+                    const double2_t y = rec_in2[in_idx(jt, 1, h)];
                     old[2 * h] = y.x; old[2 * h + 1] = y.y;
                 }
             }
@@ -577,7 +585,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             for (int h = 0; h < H; ++h) {
                 double2_t y;
                 y.x = o[2 * h]; y.y = o[2 * h + 1];
-                bn_store<NT>(&rec_out2[in[jt].lam + h * in[jt].stride], y);
+                bn_store<NT>(&rec_out2[in_idx(jt, 1, h)], y);
             }
         }
         // pi-message to child c (:202-218): pi(v) times the OTHER children's lambda-messages
@@ -620,7 +628,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             }
         }
         if constexpr (RC == 0)  // more children than the fused path holds: separate parent role
-            wres = res_acc(wres, parent_role_any<K, NT>(b, io, td, lane, frozen, piv, lav));
+            wres = res_acc(wres, parent_role_any<K, NT, 16>(b, io, td, lane, frozen, piv, lav));
     }
     return wres;
 }
@@ -815,16 +823,17 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 #pragma unroll
             for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }
         }
-        wres = res_acc(wres, parent_role_any<K, NT>(b, io, td, nl, frozen, piv, lav));
+        wres = res_acc(wres, parent_role_any<K, NT, 12>(b, io, td, nl, frozen, piv, lav));
     }
     return wres;
 }
 
 template <int K, int M, bool NT>
 __device__ __forceinline__ double tile_uniform_dispatch(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    if (td.cmax <= 2) return tile_uniform<K, M, 2, NT>(b, io, td, lane);
-    if (td.cmax <= 4) return tile_uniform<K, M, 4, NT>(b, io, td, lane);
-    return tile_uniform<K, M, 0, NT>(b, io, td, lane);
+    if (td.in_ref_base >= 0) return tile_uniform<K, M, 0, NT, true>(b, io, td, lane);  // boundary tile
+    if (td.cmax <= 2) return tile_uniform<K, M, 2, NT, false>(b, io, td, lane);
+    if (td.cmax <= 4) return tile_uniform<K, M, 4, NT, false>(b, io, td, lane);
+    return tile_uniform<K, M, 0, NT, false>(b, io, td, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
