@@ -42,6 +42,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -59,7 +60,8 @@ static int load_rccl() {
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString)
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString)
         return fail(BN_ERR_COMM, "librccl lacks a required symbol");
     g_rccl = a;
     return BN_OK;
@@ -616,6 +618,28 @@ extern "C" int bn_lw_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
     std::string err;
     int rc = lw_run(e->lw, e->plan, e->stream, ne, ev_node, ev_state, sample_begin, n_samples, seed, hist_out, err);
     if (rc) return fail(rc, err);
+    return BN_OK;
+}
+
+// Likelihood weighting over every rank of the communicator: the sample range is split evenly,
+// each GPU draws its share (disjoint Philox counters), ONE RCCL all-reduce sums the histograms.
+extern "C" int bn_lw_run_allreduce(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+                                   uint64_t sample_begin, uint64_t n_samples_total, uint64_t seed, double* hist_out) {
+    if (!e || !hist_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad evidence arguments");
+    if (!e->comm) return fail(BN_ERR_COMM, "call bn_comm_init first");
+    HIPCHK(hipSetDevice(e->device));
+    const uint64_t P = uint64_t(e->plan.nranks), r = uint64_t(e->plan.rank);
+    const uint64_t lo = n_samples_total * r / P, hi = n_samples_total * (r + 1) / P;
+    std::string err;
+    int rc = lw_run(e->lw, e->plan, e->stream, ne, ev_node, ev_state, sample_begin + lo, hi - lo, seed, nullptr, err);
+    if (rc) return fail(rc, err);
+    const size_t hist_n = size_t(e->plan.node_off[e->plan.n]);
+    ncclResult_t nr = g_rccl.AllReduce(e->lw.d_hist, e->lw.d_hist, hist_n, ncclDouble, ncclSum, e->comm, e->stream);
+    if (nr != ncclSuccess) return fail(BN_ERR_COMM, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(nr));
+    HIPCHK(hipMemcpyAsync(hist_out, e->lw.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     return BN_OK;
 }
 

@@ -127,8 +127,10 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
         s.last_batch_samples = cnt;
         done += cnt;
     }
-    LWCHK(hipMemcpyAsync(hist_out, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
-    LWCHK(hipStreamSynchronize(st));
+    if (hist_out) {
+        LWCHK(hipMemcpyAsync(hist_out, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
+        LWCHK(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

@@ -53,6 +53,7 @@ struct LwArgs {
 int launch_lw(const LwArgs& a, int blocks, void* stream);
 
 void lw_free(LwState& s);
+// hist_out == nullptr: leave the histogram in s.d_hist (the caller reduces it across ranks first)
 int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
            uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double* hist_out, std::string& err);
 int lw_states(LwState& s, const Plan& p, void* stream, uint64_t n, uint8_t* states_out, double* weights_out,

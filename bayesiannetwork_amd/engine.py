@@ -148,6 +148,18 @@ class Engine:
                                         ctypes.c_uint64(seed), _p(hist, ctypes.c_double)))
         return hist
 
+    def lw_run_allreduce(self, ev_state, n_samples_total: int, seed: int, sample_begin: int = 0) -> np.ndarray:
+        """All ranks of the communicator share the sample range; returns the summed histogram."""
+        ev_state = np.asarray(ev_state, dtype=np.int32)
+        nodes = np.ascontiguousarray(np.nonzero(ev_state >= 0)[0], dtype=np.int32)
+        states = np.ascontiguousarray(ev_state[nodes], dtype=np.int32)
+        hist = np.zeros(int(self.model.k.sum()), dtype=np.float64)
+        _lib.check(_lib.lib().bn_lw_run_allreduce(self._h, nodes.size, _p(nodes, ctypes.c_int32),
+                                                  _p(states, ctypes.c_int32), ctypes.c_uint64(sample_begin),
+                                                  ctypes.c_uint64(n_samples_total), ctypes.c_uint64(seed),
+                                                  _p(hist, ctypes.c_double)))
+        return hist
+
     def lw_states(self, n: int):
         states = np.zeros((n, self.model.n), dtype=np.uint8)
         weights = np.zeros(n, dtype=np.float64)

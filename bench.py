@@ -52,13 +52,54 @@ def cpu_baseline(model, ev, eps, budget_s=12.0):
             "sample": f"{runs} full runs of the same workload ({r['sweeps']} sweeps each), oracle/bp_oracle.c, 1 thread"}
 
 
+def bench_lw(a, local_rank, torch):
+    """BASELINE configs[4] on one GPU: weighted samples/s on the 10 k-node DAG with 1 % evidence."""
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+    d = synth.random_dag(10000, 4, 64, 4, seed=1)
+    ev = synth.random_evidence(d, a.evidence, seed=7).hard_states(d)
+    eng = Engine(d, device=local_rank)
+    for w in range(max(a.warmup, 1)):
+        eng.lw_run(ev, a.samples, seed=1, sample_begin=w * a.samples)
+    torch.cuda.synchronize()
+    steps = max(1, min(a.steps, 10))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.lw_run(ev, a.samples, seed=1, sample_begin=(i + a.warmup) * a.samples)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rate = a.samples * steps / dt
+    # algorithmic traffic: per node-sample 1 B state written, its parents' states read, 1 B re-read
+    # by the histogram pass (SURVEY 8(d): informational, CPTs are cache-resident)
+    bytes_per_sample = d.n * 2 + d.n_edges
+    out = {"metric": "weighted samples/sec (likelihood weighting)", "value": rate, "unit": "samples/s",
+           "n_gpus": 1, "steps": steps, "warmup": a.warmup, "ms_per_step": dt / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
+                                  f"{a.samples} samples per step (BASELINE.json configs[4])",
+                      "node_samples_per_s": rate * d.n},
+           "roofline": {"bound": "hbm", "achieved": rate * bytes_per_sample / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": rate * bytes_per_sample / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "lw_kernel"}}
+    if not a.no_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        n_cpu = 2000
+        oracle.lw_run(d, ev, n_cpu, seed=1)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n_cpu / dtc, "unit": "samples/s", "cores": 1, "kind": "port",
+                               "sample": f"{n_cpu} samples of the same workload, oracle/lw_oracle.c, 1 thread"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["grid", "dag"], default="grid",
-                    help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG")
+    ap.add_argument("--workload", choices=["grid", "dag", "lw"], default="grid",
+                    help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG; "
+                         "lw = configs[4], likelihood weighting on the 10 k-node DAG")
+    ap.add_argument("--samples", type=int, default=2000000, help="lw: weighted samples per step")
     ap.add_argument("--rows", type=int, default=316)
     ap.add_argument("--cols", type=int, default=316)
     ap.add_argument("--eps", type=float, default=1e-3)
@@ -82,6 +123,8 @@ def main():
         return multigpu.bench_main(a, rank, world, local_rank)
 
     torch.cuda.set_device(local_rank)
+    if a.workload == "lw":
+        return bench_lw(a, local_rank, torch)
     if a.workload == "dag":
         g = synth.random_dag(10000, 4, 64, 4, seed=1)
         wname = (f"10 k-node random DAG, <=4 parents, k=4, {g.n_edges} edges (BASELINE.json configs[1])")

@@ -144,6 +144,11 @@ int bn_bp_last_stats(bn_engine *eng, bn_bp_stats *out);
  */
 int bn_lw_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
               uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double *hist_out);
+/* The same over every rank of the communicator (bn_comm_init): the range [sample_begin,
+ * sample_begin + n_samples_total) is split evenly, each GPU draws its share, one RCCL all-reduce
+ * sums the histograms; every rank receives the total in hist_out. */
+int bn_lw_run_allreduce(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
+                        uint64_t sample_begin, uint64_t n_samples_total, uint64_t seed, double *hist_out);
 /* Sampled states of the first `n` samples of the last bn_lw_run, sample-major [s][node]. */
 int bn_lw_states(bn_engine *eng, uint64_t n, uint8_t *states_out, double *weights_out);
 

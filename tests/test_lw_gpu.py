@@ -83,3 +83,16 @@ def test_lw_error_paths(Engine):
         ev[3] = 7  # state out of range: the reference throws std::out_of_range (:151)
         with pytest.raises(_lib.BnError):
             eng.lw_run(ev, 100, seed=1)
+
+
+def test_lw_allreduce_one_rank_communicator(Engine):
+    """bn_lw_run_allreduce on a 1-rank RCCL communicator equals bn_lw_run (the n-rank split is the
+    sample-range arithmetic covered by test_lw_split_runs_sum)."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(300, 3, 16, 4, seed=4)
+    ev = synth.random_evidence(d, 0.03, seed=2).hard_states(d)
+    with Engine(d) as eng:
+        eng.comm_init(Engine.comm_unique_id())
+        a = eng.lw_run(ev, 5000, seed=9, sample_begin=100)
+        b = eng.lw_run_allreduce(ev, 5000, seed=9, sample_begin=100)
+    assert np.allclose(a, b, rtol=1e-12, atol=0)
