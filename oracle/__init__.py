@@ -153,6 +153,20 @@ def ref_bp(model, evidence=None, eps: float = 0.001, dump_msgs: bool = False, ti
     return _run_ref(text, timeout)
 
 
+def ref_dsc_bp(dsc_path: str, evidence, eps: float, dump_msgs: bool = False, timeout: float = 600):
+    """The reference's own DSC loader (serializer/dsc.hpp) + BP on a .dsc file."""
+    with tempfile.NamedTemporaryFile("w", suffix=".req", delete=False) as f:
+        f.write(f"bp {eps!r} {1 if dump_msgs else 0}\n" + evidence.to_bnflat_text())
+        req = f.name
+    try:
+        p = subprocess.run([REF_DRIVER, "--dsc", dsc_path, req], capture_output=True, text=True, timeout=timeout)
+    finally:
+        os.unlink(req)
+    if p.returncode != 0:
+        raise RuntimeError(f"ref_driver exit {p.returncode}: {p.stderr[-500:]}")
+    return json.loads(p.stdout)
+
+
 def ref_lw(model, ev_state, n_samples: int, seed: int, timeout: float = 3600):
     pairs = [(v, int(s)) for v, s in enumerate(ev_state) if s >= 0]
     text = model.to_bnflat_text() + f"lw {n_samples} {seed}\n{len(pairs)}\n" + \

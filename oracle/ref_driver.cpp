@@ -17,6 +17,9 @@
 //   BNFLAT1  n  k[0..n)  { m p[0..m) } x n   { cpt row-major } x n
 //   then either   bp  eps  dump_msgs  ne  { node kv val[0..kv) } x ne
 //   or            lw  n_samples seed  ne  { node state } x ne
+// DSC mode:  ref_driver --dsc net.dsc request.txt   -- the network comes from the reference's
+//   serializer::dsc loader (dsc.hpp:71), request.txt holds the "bp ..." / "lw ..." part; the JSON
+//   additionally carries the flat model as this repository's flatten() sees the loaded graph.
 #include <algorithm>
 #include <cassert>
 #include <chrono>
@@ -41,6 +44,8 @@
 #include <bayesian/inference/belief_propagation.hpp>
 #include <bayesian/inference/likelihood_weighting.hpp>
 #undef private
+#include <bayesian/serializer/dsc.hpp>                               // the reference's own loader
+#include "../include/bayesian/inference/mi355x_flatten.hpp"          // this repo: graph_t -> flat arrays
 
 struct flat_model {
     int n = 0;
@@ -97,34 +102,51 @@ static void print_vec(std::vector<double> const& v)
 
 int main(int argc, char** argv)
 {
-    if(argc < 2) die("usage: ref_driver model.txt");
-    std::ifstream in(argv[1]);
+    if(argc < 2) die("usage: ref_driver model.txt | --dsc net.dsc request.txt");
+    bool const dsc_mode = std::string(argv[1]) == "--dsc";
+    if(dsc_mode && argc < 4) die("usage: ref_driver --dsc net.dsc request.txt");
+    std::ifstream in(dsc_mode ? argv[3] : argv[1]);
     if(!in) die("cannot open input");
-    std::string magic;
-    in >> magic;
-    if(magic != "BNFLAT1") die("bad magic");
     flat_model fm;
-    in >> fm.n;
-    fm.k.resize(fm.n); fm.parents.resize(fm.n); fm.cpt.resize(fm.n);
-    for(int v = 0; v < fm.n; ++v) in >> fm.k[v];
-    for(int v = 0; v < fm.n; ++v) {
-        int m; in >> m;
-        fm.parents[v].resize(m);
-        for(int j = 0; j < m; ++j) in >> fm.parents[v][j];
-        if(!std::is_sorted(fm.parents[v].begin(), fm.parents[v].end())) die("parents must ascend");
+    bn::graph_t graph;
+    auto t0 = std::chrono::steady_clock::now();
+    if(dsc_mode)
+    {
+        graph = bn::serializer::dsc().from_file(argv[2]);
+        auto const flat = bn::mi355x::flatten(graph);
+        fm.n = static_cast<int>(flat.k.size());
+        fm.k.assign(flat.k.begin(), flat.k.end());
+        fm.parents.resize(fm.n); fm.cpt.resize(fm.n);
+        for(int v = 0; v < fm.n; ++v) {
+            fm.parents[v].assign(flat.in_idx.begin() + flat.in_ptr[v], flat.in_idx.begin() + flat.in_ptr[v + 1]);
+            fm.cpt[v].assign(flat.cpt.begin() + flat.cpt_off[v], flat.cpt.begin() + flat.cpt_off[v + 1]);
+        }
     }
-    for(int v = 0; v < fm.n; ++v) {
-        std::size_t sz = fm.k[v];
-        for(int p : fm.parents[v]) sz *= fm.k[p];
-        fm.cpt[v].resize(sz);
-        for(auto& x : fm.cpt[v]) in >> x;
+    else
+    {
+        std::string magic;
+        in >> magic;
+        if(magic != "BNFLAT1") die("bad magic");
+        in >> fm.n;
+        fm.k.resize(fm.n); fm.parents.resize(fm.n); fm.cpt.resize(fm.n);
+        for(int v = 0; v < fm.n; ++v) in >> fm.k[v];
+        for(int v = 0; v < fm.n; ++v) {
+            int m; in >> m;
+            fm.parents[v].resize(m);
+            for(int j = 0; j < m; ++j) in >> fm.parents[v][j];
+            if(!std::is_sorted(fm.parents[v].begin(), fm.parents[v].end())) die("parents must ascend");
+        }
+        for(int v = 0; v < fm.n; ++v) {
+            std::size_t sz = fm.k[v];
+            for(int p : fm.parents[v]) sz *= fm.k[p];
+            fm.cpt[v].resize(sz);
+            for(auto& x : fm.cpt[v]) in >> x;
+        }
+        graph = build_graph(fm);
     }
     std::string mode;
     in >> mode;
     if(!in) die("truncated input");
-
-    auto t0 = std::chrono::steady_clock::now();
-    bn::graph_t graph = build_graph(fm);
     auto t1 = std::chrono::steady_clock::now();
     auto const vl = graph.vertex_list();
 
@@ -212,6 +234,19 @@ int main(int argc, char** argv)
         }
 
         std::printf("{\"mode\":\"bp\",\"sweeps\":%zu,\"stepped_equals_call\":%s,", residuals.size(), same ? "true" : "false");
+        if(dsc_mode) {
+            std::printf("\"flat\":{\"k\":[");
+            for(int v = 0; v < fm.n; ++v) std::printf("%s%d", v ? "," : "", fm.k[v]);
+            std::printf("],\"parents\":[");
+            for(int v = 0; v < fm.n; ++v) {
+                std::printf("%s[", v ? "," : "");
+                for(std::size_t j = 0; j < fm.parents[v].size(); ++j) std::printf("%s%d", j ? "," : "", fm.parents[v][j]);
+                std::printf("]");
+            }
+            std::printf("],\"cpt\":[");
+            for(int v = 0; v < fm.n; ++v) { if(v) std::printf(","); print_vec(fm.cpt[v]); }
+            std::printf("]},");
+        }
         std::printf("\"build_s\":%.6f,\"sweep_s\":%.6f,", std::chrono::duration<double>(t1 - t0).count(),
                     std::chrono::duration<double>(t3 - t2).count());
         std::printf("\"residuals\":"); print_vec(residuals);

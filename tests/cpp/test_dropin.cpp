@@ -5,6 +5,8 @@
 //     -Iinclude -Iinclude/compat          (this repository's stand-in, GPU box)
 //     -Iinclude -I/root/reference         (the reference's graph.hpp / matrix.hpp: true drop-in)
 // Modes:  --flatten  print the flat model of both networks as JSON (no GPU needed)
+//         --dsc F [--flatten]  load F with bn::serializer::dsc (the reference's loader or the compat one),
+//                    print its flat model, and unless --flatten run BP (no evidence, eps 1e-3)
 //         (default)  run inference, check the reference's teacher values, print 17-digit marginals
 #include <cmath>
 #include <cstdio>
@@ -16,6 +18,7 @@
 #include <bayesian/graph.hpp>
 #include <bayesian/inference/belief_propagation.hpp>
 #include <bayesian/inference/likelihood_weighting.hpp>
+#include <bayesian/serializer/dsc.hpp>
 
 namespace {
 
@@ -133,6 +136,23 @@ int main(int argc, char** argv)
         std::printf("{");
         print_flat("pearl", pearl, false);
         print_flat("resume_chain", chain, true);
+        std::printf("}\n");
+        return 0;
+    }
+
+    if(argc > 2 && std::strcmp(argv[1], "--dsc") == 0)
+    {
+        bn::graph_t const net = bn::serializer::dsc().from_file(argv[2]);
+        std::printf("{");
+        bool const only_flat = argc > 3 && std::strcmp(argv[3], "--flatten") == 0;
+        print_flat("net", net, only_flat);
+        if(!only_flat)
+        {
+            bn::inference::belief_propagation bp(net);
+            auto const res = bp();
+            std::printf(",\"sweeps\":%d,", bp.last_sweeps());
+            print_marginals("beliefs", net, res, true);
+        }
         std::printf("}\n");
         return 0;
     }

@@ -126,6 +126,37 @@ def loopy_cases(big: bool):
     save("bp_soft40", d, [run_bp(d, ev, 1e-6, True)])
 
 
+def alarm_cases():
+    """BASELINE configs[0]: the ALARM-shaped DSC file through the reference's own loader + BP."""
+    print("ALARM-shaped DSC (reference serializer::dsc + belief_propagation)")
+    from bayesiannetwork_amd import FlatModel
+    from bayesiannetwork_amd.dsc import load_dsc
+    path = os.path.join(OUT, "alarm_shaped.dsc")
+    mine, names = load_dsc(path)
+    evs = [Evidence.none(), Evidence.from_dict(mine, {names.index("HRBP"): 2}),
+           Evidence.from_dict(mine, {names.index("HISTORY"): 1, names.index("PRESS"): 3, names.index("BP"): 0})]
+    runs, model = [], None
+    for ev in evs:
+        for eps in (1e-3, 1e-9):
+            r = oracle.ref_dsc_bp(path, ev, eps, dump_msgs=True)
+            assert r["stepped_equals_call"]
+            f = r["flat"]
+            k = np.asarray(f["k"], np.int32)
+            in_ptr = np.zeros(len(k) + 1, np.int32)
+            np.cumsum([len(p) for p in f["parents"]], out=in_ptr[1:])
+            in_idx = np.asarray([x for p in f["parents"] for x in p], np.int32)
+            cpt_off = np.zeros(len(k) + 1, np.int64)
+            np.cumsum([len(c) for c in f["cpt"]], out=cpt_off[1:])
+            model = FlatModel(k, in_ptr, in_idx, cpt_off, np.concatenate([np.asarray(c) for c in f["cpt"]]))
+            flat = lambda xs: np.concatenate([np.asarray(x, np.float64) for x in xs]) if xs else np.zeros(0)
+            runs.append({"ev_node": ev.node, "ev_off": ev.off, "ev_val": ev.val, "eps": np.float64(eps),
+                         "sweeps": np.int32(r["sweeps"]), "residuals": np.asarray(r["residuals"], np.float64),
+                         "beliefs": flat(r["beliefs"]), "pi_msg": flat(r["pi_msg"]), "lambda_msg": flat(r["lambda_msg"]),
+                         "ref_sweep_s": np.float64(r["sweep_s"])})
+            print(f"    ref dsc bp: sweeps={r['sweeps']} ev={ev.ne} eps={eps} ({r['sweep_s']:.3f}s)")
+    save("bp_alarm_shaped", model, runs)
+
+
 def lw_cases():
     print("likelihood weighting (reference engine reseeded to mt19937(seed))")
     pearl = synth.pearl()
@@ -159,3 +190,5 @@ if __name__ == "__main__":
         loopy_cases(a.big)
     if a.only in ("", "lw"):
         lw_cases()
+    if a.only in ("", "alarm"):
+        alarm_cases()

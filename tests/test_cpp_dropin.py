@@ -50,6 +50,39 @@ def test_flatten_with_reference_model(bnlib, tmp_path):
     check_flatten(build(tmp_path, "/root/reference", "dropin_ref"))
 
 
+def check_dsc_flatten(exe):
+    ref, _, _ = load_golden("bp_alarm_shaped")
+    out = subprocess.run([exe, "--dsc", os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"), "--flatten"],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    f = json.loads(out.stdout)["net"]
+    assert f["k"] == ref.k.tolist() and f["in_ptr"] == ref.in_ptr.tolist() and f["in_idx"] == ref.in_idx.tolist()
+    assert np.array_equal(np.asarray(f["cpt"]), ref.cpt)
+
+
+def test_dsc_loader_compat_equals_reference_golden(bnlib, tmp_path):
+    """include/compat's serializer::dsc reads the ALARM-shaped file exactly as the reference's loader did."""
+    check_dsc_flatten(build(tmp_path, os.path.join(ROOT, "include", "compat"), "dropin_compat_dsc"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/bayesian"), reason="reference headers not on this box")
+def test_dsc_loader_reference_with_dropin_headers(bnlib, tmp_path):
+    check_dsc_flatten(build(tmp_path, "/root/reference", "dropin_ref_dsc"))
+
+
+@pytest.mark.gpu
+def test_alarm_dsc_through_cpp_classes(bnlib, tmp_path):
+    """BASELINE configs[0] end to end in C++: DSC file -> graph_t -> bn::inference::belief_propagation."""
+    exe = build(tmp_path, os.path.join(ROOT, "include", "compat"), "dropin_dsc_gpu")
+    out = subprocess.run([exe, "--dsc", os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout)
+    _, runs, _ = load_golden("bp_alarm_shaped")
+    assert d["sweeps"] == runs[0]["sweeps"]
+    assert np.abs(np.asarray(d["beliefs"]) - runs[0]["beliefs"]).max() < 1e-12
+
+
 @pytest.mark.gpu
 def test_reference_cases_through_cpp_classes(bnlib, tmp_path):
     exe = build(tmp_path, os.path.join(ROOT, "include", "compat"), "dropin_gpu")

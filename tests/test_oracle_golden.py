@@ -65,3 +65,58 @@ def test_philox_known_answers(oracle_mod):
     assert oracle_mod.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert oracle_mod.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_dsc_parser_matches_reference_loader():
+    """tests/golden/alarm_shaped.dsc parsed by bayesiannetwork_amd.dsc equals what the reference's own
+    serializer::dsc (dsc.hpp:71) + this repo's flatten produced (golden bp_alarm_shaped.npz)."""
+    import os
+    from bayesiannetwork_amd.dsc import DscError, load_dsc, parse_dsc
+    from helpers import GOLDEN
+    mine, names = load_dsc(os.path.join(GOLDEN, "alarm_shaped.dsc"))
+    ref, runs, _ = load_golden("bp_alarm_shaped")
+    assert len(names) == 37 and mine.n_edges == 46 and int(np.diff(mine.in_ptr).max()) == 4
+    assert np.array_equal(mine.k, ref.k) and np.array_equal(mine.in_ptr, ref.in_ptr)
+    assert np.array_equal(mine.in_idx, ref.in_idx) and np.array_equal(mine.cpt_off, ref.cpt_off)
+    assert np.array_equal(mine.cpt, ref.cpt)
+    assert len(runs) == 6
+    # parents listed in non-ascending order re-key the rows; comments and blank lines are skipped
+    txt = '''belief network "t"
+node A
+{
+  type: discrete[2] = { "a", "b" };
+}
+// a comment line
+node B
+{
+  type: discrete[3] = { "x", "y", "z" };
+}
+
+node C
+{
+  type: discrete[2] = { "0", "1" };
+}
+probability(A)
+{
+  0.25, 0.75;
+}
+probability(B)
+{
+  0.2, 0.3, 0.5;
+}
+probability(C | B, A)
+{
+  (0, 0): 0.1, 0.9;
+  (0, 1): 0.2, 0.8;
+  (1, 0): 0.3, 0.7;
+  (1, 1): 0.4, 0.6;
+  (2, 0): 0.5, 0.5;
+  (2, 1): 0.6, 0.4;
+}
+'''
+    m, nm = parse_dsc(txt)
+    assert nm == ["A", "B", "C"] and m.parents(2).tolist() == [0, 1]
+    # flat rows: A slowest, B fastest -> (A=0,B=0),(A=0,B=1),(A=0,B=2),(A=1,B=0)...
+    assert np.allclose(m.cpt_of(2)[:, 0], [0.1, 0.3, 0.5, 0.2, 0.4, 0.6])
+    with pytest.raises(DscError):
+        parse_dsc(txt.replace("(2, 1): 0.6, 0.4;", ""))          # missing row = the reference's UB
