@@ -643,6 +643,22 @@ extern "C" int bn_lw_run_allreduce(bn_engine* e, int32_t ne, const int32_t* ev_n
     return BN_OK;
 }
 
+// Rejection (logic) sampling, reference rejection_sampling.hpp:33-167.
+extern "C" int bn_rs_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+                         uint64_t sample_begin, uint64_t n_accept, uint64_t max_draw, uint64_t seed, double* counts_out,
+                         uint64_t* drawn_out, uint64_t* accepted_out) {
+    if (!e || !counts_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad condition arguments");
+    if (max_draw == 0) return fail(BN_ERR_ARG, "max_draw must be > 0 (the reference loops forever on impossible evidence)");
+    HIPCHK(hipSetDevice(e->device));
+    std::string err;
+    int rc = rs_run(e->lw, e->plan, e->stream, ne, ev_node, ev_state, sample_begin, n_accept, max_draw, seed,
+                    counts_out, drawn_out, accepted_out, err);
+    if (rc) return fail(rc, err);
+    return BN_OK;
+}
+
 extern "C" int bn_lw_states(bn_engine* e, uint64_t n, uint8_t* states_out, double* weights_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "host-only engine");

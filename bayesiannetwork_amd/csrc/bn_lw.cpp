@@ -121,9 +121,9 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     while (done < n_samples) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
         LwArgs a{p.n, s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo, s.d_ev_state,
-                 s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed};
+                 s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
-        if (launch_lw(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
+        if (launch_lw_sample(a, blocks, st) || launch_lw_hist(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
         s.last_batch_samples = cnt;
         done += cnt;
     }
@@ -131,6 +131,48 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
         LWCHK(hipMemcpyAsync(hist_out, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
         LWCHK(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+           uint64_t sample_begin, uint64_t n_accept, uint64_t max_draw, uint64_t seed, double* counts_out,
+           uint64_t* drawn_out, uint64_t* accepted_out, std::string& err) {
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> evs(std::max(p.n, 1), -1);
+    for (int32_t j = 0; j < ne; ++j) {
+        int32_t v = ev_node[j];
+        if (v < 0 || v >= p.n) { err = "condition node out of range"; return BN_ERR_ARG; }
+        if (ev_state[j] < 0 || ev_state[j] >= p.k[v]) { err = "condition state out of range"; return BN_ERR_ARG; }
+        evs[v] = ev_state[j];  // the reference checks every listed pair; a repeated node just repeats the test
+    }
+    // a few times the wanted count per round: acceptance is usually well below 1
+    int r = lw_prepare(s, p, st, std::min<uint64_t>(std::max<uint64_t>(4 * n_accept, kLwBlockSamples), max_draw), err);
+    if (r) return r;
+    const size_t hist_n = size_t(p.node_off[p.n]);
+    LWCHK(hipMemcpyAsync(s.d_ev_state, evs.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
+    LWCHK(hipMemsetAsync(s.d_hist, 0, std::max<size_t>(hist_n, 1) * sizeof(double), st));
+    std::vector<double> w(s.batch);
+    uint64_t drawn = 0, accepted = 0;
+    while (accepted < n_accept && drawn < max_draw) {
+        const uint64_t cnt = std::min<uint64_t>(s.batch, max_draw - drawn);
+        LwArgs a{p.n, s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo, s.d_ev_state,
+                 s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
+        const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
+        if (launch_lw_sample(a, blocks, st)) { err = "sampling kernel launch failed"; return BN_ERR_HIP; }
+        LWCHK(hipMemcpyAsync(w.data(), s.d_weights, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+        LWCHK(hipStreamSynchronize(st));
+        // samples count in index order until n_accept of them were accepted (rejection_sampling.hpp:93-111)
+        uint64_t use = 0;
+        while (use < cnt && accepted < n_accept) accepted += (w[use++] != 0.0);
+        a.n_valid = use;
+        if (launch_lw_hist(a, blocks, st)) { err = "histogram kernel launch failed"; return BN_ERR_HIP; }
+        s.last_batch_samples = cnt;
+        drawn += use;
+    }
+    LWCHK(hipMemcpyAsync(counts_out, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LWCHK(hipStreamSynchronize(st));
+    if (drawn_out) *drawn_out = drawn;
+    if (accepted_out) *accepted_out = accepted;
     return 0;
 }
 

@@ -48,14 +48,21 @@ struct LwArgs {
     uint64_t sample_base;  // global index of the batch's sample 0
     uint64_t n_valid;      // samples of this batch that count
     uint64_t seed;
+    int32_t mode;          // 0 likelihood weighting, 1 rejection (logic) sampling
 };
 
-int launch_lw(const LwArgs& a, int blocks, void* stream);
+int launch_lw_sample(const LwArgs& a, int blocks, void* stream);
+int launch_lw_hist(const LwArgs& a, int blocks, void* stream);
 
 void lw_free(LwState& s);
 // hist_out == nullptr: leave the histogram in s.d_hist (the caller reduces it across ranks first)
 int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
            uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double* hist_out, std::string& err);
+// Rejection sampling: draw until n_accept samples agree with the evidence (at most max_draw draws);
+// counts_out = un-normalised state counts of the first n_accept accepted samples.
+int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
+           uint64_t sample_begin, uint64_t n_accept, uint64_t max_draw, uint64_t seed, double* counts_out,
+           uint64_t* drawn_out, uint64_t* accepted_out, std::string& err);
 int lw_states(LwState& s, const Plan& p, void* stream, uint64_t n, uint8_t* states_out, double* weights_out,
               std::string& err);
 

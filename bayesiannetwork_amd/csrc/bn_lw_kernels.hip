@@ -6,7 +6,9 @@
 //   row   = parent assignment, first parent most significant, from the state matrix
 //   evidence node  : w *= cpt[row][ev], state = ev                         (:148-153)
 //   otherwise      : state = first i with cum_{i-1} <= u < cum_i, else k-1   (:154-158, :177-193)
-// and hist[v][state] += w (:45-49), pre-reduced per thread, per wave and per block before one
+// (rejection / logic sampling, reference rejection_sampling.hpp:33-167, is the same walk with the
+// evidence nodes sampled like any other and w = 1 if every one of them came out as observed, else 0)
+// and hist[v][state] += w (:45-49), in a second kernel once w is final, pre-reduced per thread, per wave and per block before one
 // fp64 atomicAdd per (block, node, state).  Uniforms come from Philox4x32-10 keyed by the seed
 // and indexed by (global sample id, topological position) -- see oracle/lw_oracle.c for the
 // exact mapping, which this kernel reproduces bit for bit, so sampled states are identical.
@@ -35,20 +37,15 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
-__global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
+__global__ __launch_bounds__(kLwThreads) void lw_sample_kernel(LwArgs a) {
     __shared__ double sh_cpt[kLwLdsDoubles];
-    __shared__ double sh_hist[256];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     const uint64_t local0 = uint64_t(blockIdx.x) * kLwBlockSamples + tid;  // + r * kLwThreads
+    const bool reject = a.mode == 1;
     double w[kLwPerThread];
     uint32_t rnd[kLwPerThread][4];
-    bool valid[kLwPerThread];
 #pragma unroll
-    for (int r = 0; r < kLwPerThread; ++r) {
-        w[r] = 1.0;  // :124
-        valid[r] = (local0 + uint64_t(r) * kLwThreads) < a.n_valid;
-    }
+    for (int r = 0; r < kLwPerThread; ++r) w[r] = 1.0;  // :124
     const uint32_t key0 = uint32_t(a.seed), key1 = uint32_t(a.seed >> 32);
 
     for (int t = 0; t < a.n; ++t) {
@@ -58,21 +55,22 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
         const int64_t coff = a.cpt_off[v];
         const int64_t csz = a.cpt_off[v + 1] - coff;
         const int ev = a.ev_state[v];
+        const bool draws = reject || ev < 0;  // logic sampling draws evidence nodes too
         const bool in_lds = csz <= kLwLdsDoubles;
         __syncthreads();  // previous node's LDS reads are finished
         if (in_lds)
             for (int q = tid; q < csz; q += kLwThreads) sh_cpt[q] = a.cpt[coff + q];
         __syncthreads();
-        if ((t & 1) == 0 && ev < 0) {  // fresh Philox block for positions t and t+1
+        if ((t & 1) == 0 && draws) {  // fresh Philox block for positions t and t+1
 #pragma unroll
             for (int r = 0; r < kLwPerThread; ++r) {
                 const uint64_t s = a.sample_base + local0 + uint64_t(r) * kLwThreads;
                 philox4x32_10(uint32_t(s), uint32_t(s >> 32), uint32_t(t >> 1), 0u, key0, key1, rnd[r]);
             }
-        } else if ((t & 1) == 1 && ev < 0) {
-            // the even position may have been an evidence node (no block drawn yet)
+        } else if ((t & 1) == 1 && draws) {
+            // the even position may have been a clamped evidence node (no block drawn yet)
             const int vprev = a.topo[t - 1];
-            if (a.ev_state[vprev] >= 0) {
+            if (!reject && a.ev_state[vprev] >= 0) {
 #pragma unroll
                 for (int r = 0; r < kLwPerThread; ++r) {
                     const uint64_t s = a.sample_base + local0 + uint64_t(r) * kLwThreads;
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
             }
             const double* rowp = in_lds ? (sh_cpt + row * kv) : (a.cpt + coff + row * kv);
             int st;
-            if (ev >= 0) {
+            if (ev >= 0 && !reject) {
                 w[r] *= rowp[ev];
                 st = ev;
             } else {
@@ -105,13 +103,30 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
                     total += rowp[i];
                     if (!found && old_total <= u && u < total) { st = i; found = true; }
                 }
+                if (ev >= 0 && st != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
             }
             a.states[uint64_t(v) * a.batch + col] = uint8_t(st);
         }
     }
+#pragma unroll
+    for (int r = 0; r < kLwPerThread; ++r) a.weights[local0 + uint64_t(r) * kLwThreads] = w[r];
+}
 
-    // ---- second pass: the sample's FINAL weight goes into every node's histogram (:45-49);
-    // it is only known once every evidence node has been visited.
+// hist[v][state_v] += w for the first n_valid samples of the batch, w being FINAL (every evidence
+// node visited).  Same sample-to-thread mapping as the sampling kernel.
+__global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(LwArgs a) {
+    __shared__ double sh_hist[256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint64_t local0 = uint64_t(blockIdx.x) * kLwBlockSamples + tid;
+    double w[kLwPerThread];
+    bool valid[kLwPerThread];
+#pragma unroll
+    for (int r = 0; r < kLwPerThread; ++r) {
+        valid[r] = (local0 + uint64_t(r) * kLwThreads) < a.n_valid;
+        w[r] = valid[r] ? a.weights[local0 + uint64_t(r) * kLwThreads] : 0.0;
+    }
+
     for (int v = 0; v < a.n; ++v) {
         const int kv = a.k[v];
         __syncthreads();
@@ -146,12 +161,15 @@ __global__ __launch_bounds__(kLwThreads) void lw_kernel(LwArgs a) {
             if (x != 0.0) atomicAdd(&a.hist[a.node_off[v] + tid], x);
         }
     }
-#pragma unroll
-    for (int r = 0; r < kLwPerThread; ++r) a.weights[local0 + uint64_t(r) * kLwThreads] = w[r];
 }
 
-int launch_lw(const LwArgs& a, int blocks, void* stream) {
-    hipLaunchKernelGGL(lw_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
+int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
+    hipLaunchKernelGGL(lw_sample_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+int launch_lw_hist(const LwArgs& a, int blocks, void* stream) {
+    hipLaunchKernelGGL(lw_hist_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }

@@ -160,6 +160,19 @@ class Engine:
                                                   _p(hist, ctypes.c_double)))
         return hist
 
+    def rs_run(self, ev_state, n_accept: int, seed: int, max_draw: int = 1 << 34, sample_begin: int = 0):
+        """Rejection sampling: (state counts of the first n_accept accepted samples, drawn, accepted)."""
+        ev_state = np.asarray(ev_state, dtype=np.int32)
+        nodes = np.ascontiguousarray(np.nonzero(ev_state >= 0)[0], dtype=np.int32)
+        states = np.ascontiguousarray(ev_state[nodes], dtype=np.int32)
+        counts = np.zeros(int(self.model.k.sum()), dtype=np.float64)
+        drawn, acc = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _lib.check(_lib.lib().bn_rs_run(self._h, nodes.size, _p(nodes, ctypes.c_int32), _p(states, ctypes.c_int32),
+                                        ctypes.c_uint64(sample_begin), ctypes.c_uint64(n_accept),
+                                        ctypes.c_uint64(max_draw), ctypes.c_uint64(seed), _p(counts, ctypes.c_double),
+                                        ctypes.byref(drawn), ctypes.byref(acc)))
+        return counts, drawn.value, acc.value
+
     def lw_states(self, n: int):
         states = np.zeros((n, self.model.n), dtype=np.uint8)
         weights = np.zeros(n, dtype=np.float64)
@@ -272,3 +285,24 @@ def normalize_histogram(model: FlatModel, hist: np.ndarray) -> np.ndarray:
         else:
             h /= s
     return out
+
+
+class RejectionSampling:
+    """``bn::inference::rejection_sampling`` (reference rejection_sampling.hpp:13-62):
+    ``rs = RejectionSampling(model); marg = rs({node: state}, 10000)``."""
+
+    def __init__(self, model: FlatModel, device: int = _lib.BN_DEVICE_CURRENT, seed: int = 0x5EED, max_draws: int = 1 << 34):
+        self.engine = Engine(model, device)
+        self.model, self.seed, self.max_draws, self._next = model, seed, max_draws, 0
+        self.last_drawn = 0
+
+    def __call__(self, condition=None, generate_sample_num: int = 10000):
+        ev_state = np.full(self.model.n, -1, dtype=np.int32)
+        for v, s in (condition or {}).items():
+            ev_state[v] = s
+        counts, drawn, acc = self.engine.rs_run(ev_state, generate_sample_num, self.seed, self.max_draws, self._next)
+        self._next += drawn
+        self.last_drawn = drawn
+        if acc < generate_sample_num:
+            raise RuntimeError("rejection sampling: condition too unlikely, gave up after max_draws samples")
+        return _split(self.model, counts / acc)

@@ -10,9 +10,14 @@
 #ifndef BNI_INFERENCE_LIKELIHOOD_WEIGHTING_HPP
 #define BNI_INFERENCE_LIKELIHOOD_WEIGHTING_HPP
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <limits>
 #include <random>
+#include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "mi355x_flatten.hpp"
@@ -69,6 +74,85 @@ public:
             ret[model_.nodes[i]] = m;
         }
         return ret;
+    }
+
+    // Make: accurate sample (reference :62-117).  Units of unit_size weighted samples are drawn
+    // until no normalised marginal moved by epsilon or more between two consecutive units; returns
+    // the (unweighted) histogram of complete joint patterns over all units and the marginals.
+    // The patterns are read back from the GPU's state matrix, so unit_size x nodes must fit the
+    // download budget (4 GiB) -- the joint histogram is meaningless for large networks anyway.
+    std::pair<sample_list, return_type> make_samples(
+        evidence_list const& evidence,
+        std::uint64_t const unit_size = 1000000/* 1'000'000 */,
+        double const epsilon = 0.001
+        )
+    {
+        std::size_t const n = model_.nodes.size();
+        if(static_cast<double>(unit_size) * static_cast<double>(n) > 4294967296.0)
+            throw std::runtime_error("likelihood_weighting::make_samples: unit_size x nodes exceeds 4 GiB of states");
+        std::vector<std::int32_t> ev_node, ev_state;
+        for(auto const& e : evidence)
+        {
+            auto const it = model_.index.find(e.first);
+            if(it == model_.index.end()) throw std::runtime_error("likelihood_weighting: evidence on an unknown vertex");
+            ev_node.push_back(it->second);
+            ev_state.push_back(e.second);
+        }
+        std::size_t const hn = static_cast<std::size_t>(model_.node_off.back());
+        std::vector<double> w_list(hn, 0.0), unit_hist(hn), probabilities(hn, 0.0), next(hn);
+        std::unordered_map<std::string, std::size_t> packed;   // pattern bytes -> occurrences
+        std::vector<std::uint8_t> states(static_cast<std::size_t>(std::min<std::uint64_t>(unit_size, std::uint64_t(1) << 20)) * n);
+
+        while(true)
+        {
+            // Generate one unit (:85-99), in pieces the device keeps in one state matrix
+            for(std::uint64_t done = 0; done < unit_size;)
+            {
+                std::uint64_t const piece = std::min<std::uint64_t>(unit_size - done, std::uint64_t(1) << 20);
+                mi355x::engine_handle::check(bn_lw_run(
+                    engine_.get(), static_cast<std::int32_t>(ev_node.size()), ev_node.data(), ev_state.data(),
+                    next_sample_, piece, seed_, unit_hist.data()));
+                next_sample_ += piece;
+                for(std::size_t i = 0; i < hn; ++i) w_list[i] += unit_hist[i];
+                mi355x::engine_handle::check(bn_lw_states(engine_.get(), piece, states.data(), nullptr));
+                for(std::uint64_t s = 0; s < piece; ++s)
+                    ++packed[std::string(reinterpret_cast<char const*>(states.data() + s * n), n)];
+                done += piece;
+            }
+
+            // largest move of any normalised marginal since the previous unit (:101-112)
+            double max_difference = std::numeric_limits<double>::min();
+            for(std::size_t v = 0; v < n; ++v)
+            {
+                std::size_t const kv = static_cast<std::size_t>(model_.k[v]);
+                double sum = 0;
+                for(std::size_t j = 0; j < kv; ++j) sum += w_list[model_.node_off[v] + j];
+                for(std::size_t j = 0; j < kv; ++j)
+                {
+                    std::size_t const at = static_cast<std::size_t>(model_.node_off[v]) + j;
+                    next[at] = (sum < 1.0e-20) ? 1.00 / kv : w_list[at] / sum;   // normalize, :197-221
+                    max_difference = std::max(max_difference, std::abs(probabilities[at] - next[at]));
+                }
+            }
+            probabilities = next;
+            if(max_difference < epsilon) break;
+        }
+
+        sample_list patterns;
+        for(auto const& kv : packed)
+        {
+            bn::condition_t pattern;
+            for(std::size_t v = 0; v < n; ++v) pattern[model_.nodes[v]] = static_cast<unsigned char>(kv.first[v]);
+            patterns[pattern] = kv.second;
+        }
+        return_type marginals;
+        for(std::size_t v = 0; v < n; ++v)
+        {
+            matrix_type m(1, static_cast<std::size_t>(model_.k[v]));
+            m.assign(probabilities.begin() + model_.node_off[v], probabilities.begin() + model_.node_off[v + 1]);
+            marginals[model_.nodes[v]] = m;
+        }
+        return std::make_pair(std::move(patterns), std::move(marginals));
     }
 
 private:

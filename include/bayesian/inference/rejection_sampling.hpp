@@ -1,0 +1,93 @@
+// bayesian/inference/rejection_sampling.hpp -- MI355X drop-in for the reference header of the same
+// path (reference rejection_sampling.hpp:13-62):
+//
+//     bn::inference::rejection_sampling rs(graph);
+//     auto marginals = rs({{vertex_4, 1}, {vertex_1, 0}}, 10000);   // logic sampling
+//
+// Forward samples are drawn on the GPU (bn_rs_run) until generate_sample_num of them agree with
+// the condition; marginals are the plain state frequencies over those accepted samples.  The
+// reference never returns when the condition has probability zero; this functor gives up after
+// max_draws() samples and throws std::runtime_error.
+#ifndef BNI_INFERENCE_REJECTION_SAMPLING_HPP
+#define BNI_INFERENCE_REJECTION_SAMPLING_HPP
+
+#include <cstdint>
+#include <random>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "mi355x_flatten.hpp"
+
+namespace bn {
+namespace inference {
+
+class rejection_sampling {
+public:
+    typedef std::unordered_map<vertex_type, matrix_type> return_type;
+    typedef std::vector<std::unordered_map<vertex_type, int>> pattern_list;
+
+    explicit rejection_sampling(graph_t const& graph)
+        : model_(mi355x::flatten(graph)), engine_(model_)
+    {
+        std::random_device rand_dev;
+        seed_ = (static_cast<std::uint64_t>(rand_dev()) << 32) ^ rand_dev();
+    }
+
+    virtual ~rejection_sampling() = default;
+
+    void seed(std::uint64_t s) { seed_ = s; next_sample_ = 0; }
+    void max_draws(std::uint64_t m) { max_draws_ = m; }
+    std::uint64_t last_drawn() const { return last_drawn_; }
+
+    // By-pass (reference :26-30)
+    inline return_type operator()(int const generate_sample_num = 10000)
+    {
+        std::vector<std::pair<vertex_type, int>> const condition;
+        return operator()(condition, generate_sample_num);
+    }
+
+    // Run: Logic Sampling (a.k.a. Rejection Sampling) (reference :33-62)
+    return_type operator()(std::vector<std::pair<vertex_type, int>> const& condition, int const generate_sample_num = 10000)
+    {
+        std::vector<std::int32_t> ev_node, ev_state;
+        for(auto const& c : condition)
+        {
+            auto const it = model_.index.find(c.first);
+            // the reference finds no such key in any pattern and rejects every sample (:76-77)
+            if(it == model_.index.end()) throw std::runtime_error("rejection_sampling: condition on an unknown vertex");
+            ev_node.push_back(it->second);
+            ev_state.push_back(c.second);
+        }
+        std::vector<double> counts(static_cast<std::size_t>(model_.node_off.back()));
+        std::uint64_t drawn = 0, accepted = 0;
+        mi355x::engine_handle::check(bn_rs_run(
+            engine_.get(), static_cast<std::int32_t>(ev_node.size()), ev_node.data(), ev_state.data(), next_sample_,
+            static_cast<std::uint64_t>(generate_sample_num), max_draws_, seed_, counts.data(), &drawn, &accepted));
+        next_sample_ += drawn;
+        last_drawn_ = drawn;
+        if(accepted < static_cast<std::uint64_t>(generate_sample_num))
+            throw std::runtime_error("rejection_sampling: condition too unlikely, gave up after max_draws() samples");
+
+        return_type result;
+        for(std::size_t i = 0; i < model_.nodes.size(); ++i)
+        {
+            std::size_t const kv = static_cast<std::size_t>(model_.k[i]);
+            matrix_type mat(1, kv, 0.0);
+            for(std::size_t j = 0; j < kv; ++j) mat[0][j] = counts[model_.node_off[i] + j] / static_cast<double>(accepted);
+            result[model_.nodes[i]] = mat;
+        }
+        return result;
+    }
+
+private:
+    mi355x::flat_model model_;
+    mi355x::engine_handle engine_;
+    std::uint64_t seed_ = 0, next_sample_ = 0, last_drawn_ = 0;
+    std::uint64_t max_draws_ = std::uint64_t(1) << 34;
+};
+
+} // namespace inference
+} // namespace bn
+
+#endif // #ifndef BNI_INFERENCE_REJECTION_SAMPLING_HPP

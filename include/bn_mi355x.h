@@ -149,6 +149,18 @@ int bn_lw_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t 
  * sums the histograms; every rank receives the total in hist_out. */
 int bn_lw_run_allreduce(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
                         uint64_t sample_begin, uint64_t n_samples_total, uint64_t seed, double *hist_out);
+/*
+ * Rejection (logic) sampling.
+ * Replaces: rejection_sampling::operator()(condition, generate_sample_num)
+ * (rejection_sampling.hpp:33-62): forward samples are drawn in index order until n_accept of them
+ * agree with every (node, state) pair; counts_out [sum k] holds the state counts of exactly those
+ * n_accept samples (the caller divides by the accepted count).  The reference loops forever when
+ * the condition has probability zero; here at most max_draw samples are drawn and the numbers
+ * actually drawn / accepted are reported.
+ */
+int bn_rs_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
+              uint64_t sample_begin, uint64_t n_accept, uint64_t max_draw, uint64_t seed,
+              double *counts_out, uint64_t *drawn_out, uint64_t *accepted_out);
 /* Sampled states of the first `n` samples of the last bn_lw_run, sample-major [s][node]. */
 int bn_lw_states(bn_engine *eng, uint64_t n, uint8_t *states_out, double *weights_out);
 

@@ -103,6 +103,25 @@ def lw_run(model, ev_state, n_samples: int, seed: int, s_begin: int = 0, topo=No
     return out
 
 
+def rs_run(model, ev_state, n_accept: int, seed: int, max_draw: int = 1 << 34, s_begin: int = 0, topo=None):
+    """Restated rejection sampling (oracle_rs_run).  Returns (counts, drawn, accepted)."""
+    L = lib()
+    L.oracle_rs_run.restype = ctypes.c_int
+    n = model.n
+    topo = np.arange(n, dtype=np.int32) if topo is None else np.ascontiguousarray(topo, dtype=np.int32)
+    ev_state = np.ascontiguousarray(ev_state, dtype=np.int32)
+    counts = np.zeros(int(model.k.sum()), dtype=np.float64)
+    drawn, acc = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = L.oracle_rs_run(n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
+                         _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64),
+                         _p(model.cpt, ctypes.c_double), _p(topo, ctypes.c_int32), _p(ev_state, ctypes.c_int32),
+                         ctypes.c_uint64(s_begin), ctypes.c_uint64(n_accept), ctypes.c_uint64(max_draw),
+                         ctypes.c_uint64(seed), _p(counts, ctypes.c_double), ctypes.byref(drawn), ctypes.byref(acc))
+    if rc != 0:
+        raise RuntimeError(f"oracle_rs_run failed: {rc}")
+    return counts, drawn.value, acc.value
+
+
 def lw_normalize(model, hist):
     """likelihood_weighting.hpp:197-221 applied per node."""
     out = hist.astype(np.float64).copy()

@@ -116,3 +116,43 @@ void oracle_lw_normalize(double *h, int k) {
     if (sum < 1.0e-20) for (int i = 0; i < k; ++i) h[i] = 1.00 / k;
     else for (int i = 0; i < k; ++i) h[i] /= sum;
 }
+
+/*
+ * Rejection (logic) sampling, reference rejection_sampling.hpp:33-167: every node -- evidence
+ * nodes too -- is sampled (choice_pattern, :115-167), a sample counts only when it agrees with
+ * every condition (:70-84), sampling goes on until n_accept samples were accepted (:93-111;
+ * bounded here by max_draw), and the marginals are plain counts over the accepted samples
+ * (:40-58).  Same Philox stream and topological walk as oracle_lw_run, so the accepted set is
+ * bit-identical to the HIP path's.  counts must be zeroed by the caller.
+ */
+int oracle_rs_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t *in_idx,
+                  const int64_t *cpt_off, const double *cpt, const int32_t *topo, const int32_t *ev_state,
+                  uint64_t s_begin, uint64_t n_accept, uint64_t max_draw, uint64_t seed, double *counts,
+                  uint64_t *drawn_out, uint64_t *accepted_out) {
+    int64_t *node_off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+    int32_t *state = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    if (!node_off || !state) { free(node_off); free(state); return -1; }
+    node_off[0] = 0;
+    for (int v = 0; v < n; ++v) node_off[v + 1] = node_off[v] + k[v];
+    uint64_t drawn = 0, accepted = 0;
+    while (accepted < n_accept && drawn < max_draw) {
+        uint64_t s = s_begin + drawn;
+        int ok = 1;
+        for (int t = 0; t < n; ++t) {
+            int v = topo[t];
+            int64_t row = 0;
+            for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + state[in_idx[e]];
+            state[v] = pick_state(uniform_at(seed, s, (uint32_t)t), cpt + cpt_off[v] + row * k[v], k[v]);
+            if (ev_state[v] >= 0 && state[v] != ev_state[v]) ok = 0;
+        }
+        ++drawn;
+        if (ok) {
+            ++accepted;
+            for (int v = 0; v < n; ++v) counts[node_off[v] + state[v]] += 1.0;
+        }
+    }
+    if (drawn_out) *drawn_out = drawn;
+    if (accepted_out) *accepted_out = accepted;
+    free(node_off); free(state);
+    return 0;
+}

@@ -18,6 +18,7 @@
 #include <bayesian/graph.hpp>
 #include <bayesian/inference/belief_propagation.hpp>
 #include <bayesian/inference/likelihood_weighting.hpp>
+#include <bayesian/inference/rejection_sampling.hpp>
 #include <bayesian/serializer/dsc.hpp>
 
 namespace {
@@ -150,7 +151,7 @@ int main(int argc, char** argv)
         {
             bn::inference::belief_propagation bp(net);
             auto const res = bp();
-            std::printf(",\"sweeps\":%d,", bp.last_sweeps());
+            std::printf("\"sweeps\":%d,", bp.last_sweeps());
             print_marginals("beliefs", net, res, true);
         }
         std::printf("}\n");
@@ -207,7 +208,46 @@ int main(int argc, char** argv)
                                     {0.78823529411764715, 0.21176470588235297}};
         for(int i = 0; i < 3; ++i)
             for(int j = 0; j < 2; ++j) close_pct(res.at(v[i])[0][j], exact[i][j], 2.0, "lw pearl");
-        print_marginals("lw_pearl", pearl, res, true);
+        print_marginals("lw_pearl", pearl, res);
+    }
+    {   // make_samples (reference likelihood_weighting.hpp:62-117) on Pearl, H = 0
+        auto const v = pearl.vertex_list();
+        bn::inference::likelihood_weighting lw(pearl);
+        lw.seed(7);
+        bn::inference::likelihood_weighting::evidence_list ev;
+        ev[v[3]] = 0;
+        auto const made = lw.make_samples(ev, 200000, 0.005);
+        std::size_t total = 0;
+        bool consistent = true;
+        for(auto const& p : made.first)
+        {
+            total += p.second;
+            if(p.first.size() != 4 || p.first.at(v[3]) != 0) consistent = false;   // evidence is clamped
+        }
+        if(total == 0 || total % 200000 != 0 || total < 400000 || !consistent || made.first.size() > 8)
+        { ++failures; std::printf("FAIL make_samples: %zu samples, %zu patterns\n", total, made.first.size()); }
+        double const exact[3][2] = {{0.73529411764705888, 0.26470588235294118}, {0.33823529411764708, 0.66176470588235292},
+                                    {0.78823529411764715, 0.21176470588235297}};
+        for(int i = 0; i < 3; ++i)
+            for(int j = 0; j < 2; ++j) close_pct(made.second.at(v[i])[0][j], exact[i][j], 2.0, "make_samples pearl");
+        std::printf("\"make_samples_total\":%zu,\"make_samples_patterns\":%zu,", total, made.first.size());
+    }
+    {   // rejection_sampling_standard (libs/bayesian/test/rejection_sampling.cpp): 5-node net,
+        // condition {v4 = 1, v1 = 0}, P(v2) ~ {.62, .38} within 10 %
+        std::vector<node_spec> const spec = {{2, {}, {0.5, 0.5}},
+                                             {2, {0}, {0.8, 0.2, 0.1, 0.9}},
+                                             {2, {0}, {0.7, 0.3, 0.4, 0.6}},
+                                             {2, {1}, {0.6, 0.4, 0.1, 0.9}},
+                                             {2, {1, 2}, {0.1, 0.9, 0.2, 0.8, 0.3, 0.7, 0.4, 0.6}}};
+        bn::graph_t const net = build(spec);
+        auto const v = net.vertex_list();
+        bn::inference::rejection_sampling func(net);
+        func.seed(99);
+        auto const result = func({{v[3], 1}, {v[0], 0}});
+        close_pct(result.at(v[1])[0][0], 0.62, 10, "rejection v2[0]");
+        close_pct(result.at(v[1])[0][1], 0.38, 10, "rejection v2[1]");
+        close_pct(result.at(v[3])[0][1], 1.0, 1e-9, "rejection keeps the condition");
+        print_marginals("rejection", net, result, true);
     }
     std::printf("}\n");
     if(failures) std::printf("%d FAILURES\n", failures);

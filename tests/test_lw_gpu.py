@@ -96,3 +96,46 @@ def test_lw_allreduce_one_rank_communicator(Engine):
         a = eng.lw_run(ev, 5000, seed=9, sample_begin=100)
         b = eng.lw_run_allreduce(ev, 5000, seed=9, sample_begin=100)
     assert np.allclose(a, b, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("n,maxp,k,ne,want", [(40, 3, [2, 3], 2, 3000), (12, 2, 4, 1, 5000), (200, 4, 2, 0, 1000)])
+def test_rejection_sampling_bit_exact_vs_oracle(Engine, oracle_mod, n, maxp, k, ne, want):
+    """Counts of accepted samples are integer work: bit-identical to the oracle, as are the
+    numbers of samples drawn and accepted (reference rejection_sampling.hpp:93-111 stops at exactly
+    `want` accepted samples)."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(n, maxp, 16, k, seed=n)
+    ev = np.full(d.n, -1, np.int32)
+    for j in range(ne):
+        ev[(7 * j + 3) % d.n] = 0
+    wc, wd, wa = oracle_mod.rs_run(d, ev, want, seed=5, s_begin=11, max_draw=1 << 22)
+    with Engine(d) as eng:
+        c, drawn, acc = eng.rs_run(ev, want, seed=5, max_draw=1 << 22, sample_begin=11)
+    assert (drawn, acc) == (wd, wa) and acc == want
+    assert np.array_equal(c, wc)
+    sums = np.add.reduceat(c, d.node_off[:-1])
+    assert (sums == want).all()
+
+
+def test_rejection_sampling_reference_case_and_cap(Engine):
+    """libs/bayesian/test/rejection_sampling.cpp: condition {v4 = 1, v1 = 0}; the exact posterior is
+    enumerated here (32 joint states) and the estimate must sit within 5 sigma."""
+    from bayesiannetwork_amd import from_parent_lists
+    from bayesiannetwork_amd.engine import RejectionSampling
+    m = from_parent_lists([2] * 5, [[], [0], [0], [1], [1, 2]],
+                          [[.5, .5], [.8, .2, .1, .9], [.7, .3, .4, .6], [.6, .4, .1, .9], [.1, .9, .2, .8, .3, .7, .4, .6]])
+    joint = np.zeros([2] * 5)
+    for s in np.ndindex(*joint.shape):
+        joint[s] = (m.cpt_of(0)[0, s[0]] * m.cpt_of(1)[s[0], s[1]] * m.cpt_of(2)[s[0], s[2]] * m.cpt_of(3)[s[1], s[3]]
+                    * m.cpt_of(4)[s[1] * 2 + s[2], s[4]])
+    post = joint[0, :, :, 1, :].sum(axis=(1, 2))
+    post /= post.sum()
+    assert abs(post[0] - 0.62) < 0.062            # the reference test's teacher value, 10 %
+    rs = RejectionSampling(m, seed=42)
+    n = 200000
+    marg = rs({3: 1, 0: 0}, n)
+    assert np.abs(marg[1] - post).max() < 5 * np.sqrt(0.25 / n)
+    assert marg[3].tolist() == [0.0, 1.0] and marg[0].tolist() == [1.0, 0.0]
+    impossible = from_parent_lists([2, 2], [[], [0]], [[1.0, 0.0], [1.0, 0.0, 0.5, 0.5]])
+    with pytest.raises(RuntimeError):             # the reference would never return
+        RejectionSampling(impossible, max_draws=20000)({1: 1}, 10)
