@@ -43,6 +43,16 @@ __device__ __forceinline__ void bn_store(double2_t* p, double2_t v) {
     else *p = v;
 }
 
+// The CPT image is read exactly once per sweep and never re-used inside a launch.  Measured on
+// MI355X: when the working set is HBM-resident (NT policy) streaming it non-temporally is +6 %
+// (it no longer evicts the message records, which two waves share, from the XCD L2); when the
+// working set fits the Infinity Cache the plain load is 8 % faster.
+template <bool NT>
+__device__ __forceinline__ double2_t cpt_load(const double2_t* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
 // The four state pointers of one iteration, resolved on the host (a dynamically indexed kernarg
 // array would push the whole argument struct into scratch memory).
 struct IO {
@@ -421,7 +431,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
         double cpt[SP];
 #pragma unroll
         for (int q = 0; q < SP / 2; ++q) {
-            const double2_t x = cp[q * kWave];
+            const double2_t x = cpt_load<NT>(&cp[q * kWave]);
             cpt[2 * q] = x.x;
             cpt[2 * q + 1] = x.y;
         }
@@ -661,7 +671,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
     double cpt[64];
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        const double2_t x = cp[q * kWave];
+        const double2_t x = cpt_load<NT>(&cp[q * kWave]);
         cpt[2 * q] = x.x;
         cpt[2 * q + 1] = x.y;
     }
