@@ -82,11 +82,15 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double)));
         s.ready = true;
     }
-    // batch: enough blocks to fill the chip, bounded so the state matrix stays <= ~8 GiB
-    uint64_t cap = (uint64_t(8) << 30) / std::max<uint64_t>(p.n, 1);
+    // batch: enough blocks to fill the chip, bounded so the [node][sample] state matrix stays
+    // within BN_LW_STATE_GIB (default 32 of the 288 GB)
+#ifndef BN_LW_STATE_GIB
+#define BN_LW_STATE_GIB 32
+#endif
+    uint64_t cap = (uint64_t(BN_LW_STATE_GIB) << 30) / std::max<uint64_t>(p.n, 1);
     cap = std::max<uint64_t>(kLwBlockSamples, cap / kLwBlockSamples * kLwBlockSamples);
     uint64_t want = (want_samples + kLwBlockSamples - 1) / kLwBlockSamples * kLwBlockSamples;
-    uint64_t batch = std::min<uint64_t>({want, cap, uint64_t(2048) * kLwBlockSamples});
+    uint64_t batch = std::min<uint64_t>({want, cap, uint64_t(16384) * kLwBlockSamples});
     batch = std::max<uint64_t>(batch, kLwBlockSamples);
     if (batch > s.batch) {
         if (s.d_states) (void)hipFree(s.d_states);

@@ -9,7 +9,10 @@
 namespace bnmi {
 
 constexpr int kLwThreads = 256;      // threads per block
-constexpr int kLwPerThread = 4;      // samples per thread
+#ifndef BN_LW_PER_THREAD
+#define BN_LW_PER_THREAD 4
+#endif
+constexpr int kLwPerThread = BN_LW_PER_THREAD;      // samples per thread
 constexpr int kLwBlockSamples = kLwThreads * kLwPerThread;
 constexpr int kLwLdsDoubles = 4096;  // CPTs up to this size are staged in LDS (32 KiB)
 

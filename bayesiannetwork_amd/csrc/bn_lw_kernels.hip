@@ -56,7 +56,11 @@ __global__ __launch_bounds__(kLwThreads) void lw_sample_kernel(LwArgs a) {
         const int64_t csz = a.cpt_off[v + 1] - coff;
         const int ev = a.ev_state[v];
         const bool draws = reject || ev < 0;  // logic sampling draws evidence nodes too
+#ifdef BN_LW_NOLDS
+        const bool in_lds = false;
+#else
         const bool in_lds = csz <= kLwLdsDoubles;
+#endif
         __syncthreads();  // previous node's LDS reads are finished
         if (in_lds)
             for (int q = tid; q < csz; q += kLwThreads) sh_cpt[q] = a.cpt[coff + q];
