@@ -91,6 +91,25 @@ def bench_lw(a, local_rank, torch):
     print(json.dumps(out))
 
 
+def cpu_reference_small():
+    """The UNMODIFIED reference (oracle/_ref/ref_driver, built where /root/reference exists and
+    shipped as a binary) on the largest grid it finishes in seconds: its dense V x V graph_t makes
+    run time grow like V^3, so the bench workload itself (10^5 nodes, 160 GB of
+    adjacency matrix) is out of its reach.  Informational, next to the port's number."""
+    import oracle
+    from bayesiannetwork_amd import synth
+    if not oracle.ref_available():
+        return None
+    g = synth.grid(16, 16, 4, seed=116)
+    try:
+        r = oracle.ref_bp(g, None, 1e-3, timeout=120)
+    except Exception as ex:  # noqa: BLE001 - informational leg only
+        return {"error": str(ex)[:200]}
+    return {"value": g.messages_per_sweep() * r["sweeps"] / r["sweep_s"], "unit": "edge-messages/s", "cores": 1,
+            "kind": "reference", "sample": f"16x16 k=4 grid ({g.n} nodes), {r['sweeps']} sweeps, "
+                                           "bn::inference::belief_propagation unmodified, 1 thread"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +188,9 @@ def main():
     }
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps)
+        ref = cpu_reference_small()
+        if ref:
+            out["cpu_reference_small"] = ref
     print(json.dumps(out))
 
 
