@@ -62,6 +62,8 @@ SYMBOLS = [
     ("bn_bp_copy_beliefs", ctypes.c_int, [ctypes.c_void_p, f64p]),
     ("bn_bp_residual_history", ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int32]),
     ("bn_bp_messages", ctypes.c_int, [ctypes.c_void_p, f64p, f64p]),
+    ("bn_set_option", ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]),
+    ("bn_bp_last_path", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_bp_step_begin", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_bp_step_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double]),
     ("bn_bp_step_finish", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, i32p, i32p,

@@ -13,6 +13,9 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types only: the library is loaded lazily with dlopen (no link dependency)
 
 #include "bn_device.hpp"
@@ -99,6 +102,15 @@ struct bn_engine {
     double* d_ev_val = nullptr;
     bool frozen_dirty = false;
     bool nontemporal = false;
+    // persistent dataflow path (bn_persist.hip)
+    bool persist_ok = false;        // model eligible and everything resident at once
+    bool persist_enabled = false;   // opt-in (measured slower): BN_PERSISTENT=1 / bn_set_option; cleared after an abort
+    int32_t* d_nbr_ptr = nullptr;
+    int32_t* d_nbr_idx = nullptr;
+    char* d_psync = nullptr;        // PersistSync | flags[n_tiles] | res_tile[4][n_tiles]
+    size_t psync_bytes = 0;
+    int grid_persist = 0;
+    int32_t last_path = 0;          // 0 per-sweep launches, 1 persistent
     Ctl* h_ctl = nullptr;  // pinned
     // run state
     int32_t res_cap = 1 << 16;
@@ -120,7 +132,8 @@ static void free_engine(bn_engine* e) {
         if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev};
+                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_nbr_ptr, e->d_nbr_idx,
+                        e->d_psync};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -148,8 +161,19 @@ static int dalloc(T** dst, size_t count) {
 extern "C" const char* bn_last_error(void) { return g_err.c_str(); }
 extern "C" const char* bn_version(void) { return "bn_mi355x 0.1 (gfx950)"; }
 
+static void debug_segv_handler(int sig) {
+    void* frames[64];
+    int n = backtrace(frames, 64);
+    const char msg[] = "[bn_mi355x] fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_engine** out) {
     if (!desc || !out) return fail(BN_ERR_ARG, "null argument");
+    if (std::getenv("BN_DEBUG")) signal(SIGSEGV, debug_segv_handler);
     *out = nullptr;
     bn_engine* e = new (std::nothrow) bn_engine();
     if (!e) return fail(BN_ERR_ALLOC, "out of host memory");
@@ -215,6 +239,31 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
         HIPCHK(hipMemsetAsync(e->d_beliefs, 0, std::max<size_t>(p.node_off[p.n], 1) * 8, e->stream));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocDefault));
+        // persistent dataflow path: every tile register-resident (tile_uniform shapes, <= 4 children,
+        // no remote parents) and all tiles co-resident -- 8 waves per CU at <= 256 VGPRs
+        {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, e->device));
+            const int64_t capacity = int64_t(prop.multiProcessorCount) * 8;
+            const int64_t nt = int64_t(p.tiles.size());
+            bool ok = p.nranks == 1 && nt > 0 && p.rec_total_doubles * 8 < (int64_t(1) << 31);
+            e->grid_persist = int((nt + 7) & ~int64_t(7));
+            ok = ok && e->grid_persist <= capacity * 9 / 10;  // margin: never rely on the last slot
+            for (const TileDesc& td : p.tiles)
+                ok = ok && td.variant == kVariantUniform && td.cmax <= 4 && td.in_ref_base < 0;
+            e->persist_ok = ok;
+            if (std::getenv("BN_DEBUG"))
+                std::fprintf(stderr, "[bn_mi355x] persistent eligible=%d tiles=%lld capacity=%lld max_nbr=%d\n", int(ok),
+                             (long long)nt, (long long)capacity, p.max_nbr);
+            const char* env = std::getenv("BN_PERSISTENT");
+            if (env) e->persist_enabled = env[0] == '1';
+            if (ok) {
+                if ((r = upload(&e->d_nbr_ptr, p.nbr_ptr, e->stream))) return r;
+                if ((r = upload(&e->d_nbr_idx, p.nbr_idx, e->stream))) return r;
+                e->psync_bytes = sizeof(PersistSync) + size_t(nt) * 4 + 64 + size_t(nt) * 4 * 8;
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_psync), e->psync_bytes));
+            }
+        }
         HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
         return BN_OK;
@@ -260,6 +309,7 @@ static BpBuffers buffers_of(bn_engine* e) {
     b.g_base = e->plan.g_base;
     b.seg_d2 = e->plan.seg_d2;
     b.seg_data_d2 = e->plan.seg_data_d2;
+    b.rec_total_doubles = e->plan.rec_total_doubles;
     b.rank = e->plan.rank;
     b.nranks = e->plan.nranks;
     b.res_hist = e->d_res_hist;
@@ -342,7 +392,8 @@ static int step_begin(bn_engine* e) {
     }
     e->frozen_dirty = true;
     EvidenceArgs ea{buffers_of(e), e->ev_ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
-    if (launch_bp_begin(ea, s)) return fail(BN_ERR_HIP, "bp_begin launch failed");
+    if (int code = launch_bp_begin(ea, s))
+        return fail(BN_ERR_HIP, std::string("bp_begin launch failed: ") + hipGetErrorString(hipError_t(code)));
     return BN_OK;
 }
 
@@ -369,8 +420,8 @@ static int step_exchange(bn_engine* e, int32_t sweep) {
     return BN_OK;
 }
 
-static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps) {
-    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->ev_ne, e->d_ev_node};
+static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps, const PersistSync* psync = nullptr) {
+    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->ev_ne, e->d_ev_node, psync};
     if (launch_bp_finish(fa, e->grid_tiles, e->stream)) return fail(BN_ERR_HIP, "bp_finish launch failed");
     HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, e->stream));
     return BN_OK;
@@ -384,6 +435,51 @@ static void note_run_result(bn_engine* e) {
     e->stats.sweeps = e->last_ctl.n_sweeps;
 }
 
+// One launch for the whole run (bn_persist.hip).  BN_ERR_STATE = a bounded wait inside the kernel
+// timed out (e.g. not every tile became resident): the caller falls back to per-sweep launches.
+static int run_persistent(bn_engine* e, double eps, int32_t max_sweeps) {
+    const Plan& p = e->plan;
+    hipStream_t s = e->stream;
+    const int32_t nt = int32_t(p.tiles.size());
+    int rc;
+    const bool dbg = std::getenv("BN_DEBUG") != nullptr;
+#define PDBG(msg) do { if (dbg) { std::fprintf(stderr, "[bn_mi355x] persist: %s\n", msg); std::fflush(stderr); } } while (0)
+    PDBG("memset");
+    HIPCHK(hipMemsetAsync(e->d_psync, 0, e->psync_bytes, s));
+    if ((rc = step_begin(e))) return rc;
+    PDBG("begin launched");
+    PersistArgs a;
+    a.b = buffers_of(e);
+    a.nbr_ptr = e->d_nbr_ptr;
+    a.nbr_idx = e->d_nbr_idx;
+    a.sync = reinterpret_cast<PersistSync*>(e->d_psync);
+    a.flags = reinterpret_cast<unsigned*>(e->d_psync + sizeof(PersistSync));
+    a.res_tile = reinterpret_cast<unsigned long long*>(e->d_psync + ((sizeof(PersistSync) + size_t(nt) * 4 + 63) & ~size_t(63)));
+    a.eps = eps;
+    a.max_sweeps = max_sweeps;
+    a.n_tiles = nt;
+    a.timeout_ticks = 100000000ull / 5;  // 200 ms of the 100 MHz clock
+    if ((rc = ensure_events(e, 2))) return rc;
+    HIPCHK(hipEventRecord(e->events[0], s));
+    if (int code = launch_bp_persistent(a, e->grid_persist, s))
+        return fail(BN_ERR_HIP, std::string("bp_persistent launch failed: ") + hipGetErrorString(hipError_t(code)));
+    HIPCHK(hipEventRecord(e->events[1], s));
+    PDBG("kernel launched");
+    if (dbg) { hipError_t se = hipStreamSynchronize(s); std::fprintf(stderr, "[bn_mi355x] persist: kernel sync -> %s\n", hipGetErrorString(se)); }
+    if ((rc = step_finish(e, 1, true, eps, a.sync))) return rc;
+    HIPCHK(hipStreamSynchronize(s));
+    PDBG("finished");
+    if (e->h_ctl->p_abort != 0 || e->h_ctl->p_conv == 0 || e->h_ctl->done == 0)
+        return fail(BN_ERR_STATE, "persistent kernel gave up a wait (code " + std::to_string(e->h_ctl->p_abort) + ")");
+    note_run_result(e);
+    e->last_path = 1;
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->events[0], e->events[1]));
+    e->stats.sweep_launches = e->last_ctl.n_sweeps;  // iterations inside the one launch
+    e->stats.sweep_kernel_ms = ms;
+    return BN_OK;
+}
+
 extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
                                 double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -394,6 +490,20 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     HIPCHK(hipSetDevice(e->device));
     hipStream_t s = e->stream;
     int rc;
+    if (e->persist_ok && e->persist_enabled) {
+        rc = run_persistent(e, eps, max_sweeps);
+        if (rc == BN_OK) {
+            e->stats.total_ms =
+                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+            if (residual_out) *residual_out = e->last_ctl.last_res;
+            return BN_OK;
+        }
+        if (rc != BN_ERR_STATE) return rc;  // BN_ERR_STATE: the kernel gave up a wait -> per-sweep launches
+        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] persistent path disabled: %s\n", g_err.c_str());
+        e->persist_enabled = false;
+    }
+    e->last_path = 0;
     if ((rc = step_begin(e))) return rc;
     int32_t launched = 0, batches = 0;
     // every rank takes the same decisions: they all see the same sweep counts
@@ -428,6 +538,18 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
     if (residual_out) *residual_out = e->last_ctl.last_res;
     return BN_OK;
+}
+
+// Engine options: "persistent" = 0/1 (use the one-launch dataflow path when the model is eligible).
+extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
+    if (!e || !name) return fail(BN_ERR_ARG, "null argument");
+    if (std::strcmp(name, "persistent") == 0) { e->persist_enabled = value != 0; return BN_OK; }
+    return fail(BN_ERR_ARG, std::string("unknown option ") + name);
+}
+// 1 when the last run used the persistent kernel, 0 per-sweep launches; <0 error
+extern "C" int bn_bp_last_path(bn_engine* e) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    return e->last_path;
 }
 
 // ---- single steps (diagnostics / tests) -------------------------------------------------------

@@ -960,6 +960,18 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
     int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int n_sweeps;
+    if (a.psync) {  // persistent run: the kernel settled everything itself; report how it ended
+        if (lead) { b.ctl->p_abort = a.psync->abort; b.ctl->p_conv = a.psync->conv; }
+        if (done == 0 || a.psync->abort != 0) {  // it gave up: the host reruns with per-sweep launches
+            const int gid0 = blockIdx.x * blockDim.x + threadIdx.x;
+            for (int j = gid0; j < a.ne; j += gridDim.x * blockDim.x) {
+                const int v = a.ev_node[j];
+                const int t = b.node_tile[v];
+                if (t >= 0) b.frozen[b.tiles[t].slot_base + b.node_nl[v]] = 0;
+            }
+            return;
+        }
+    }
     if (done != 0) {
         n_sweeps = b.ctl->n_sweeps;
     } else {
@@ -1001,10 +1013,12 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : int(e); }
 
 int launch_bp_begin(const EvidenceArgs& a, void* stream) {
     const int blocks = a.ne > 0 ? (a.ne + kBlockThreads - 1) / kBlockThreads : 1;
+    (void)hipGetLastError();  // drop any stale error of this thread
     hipLaunchKernelGGL(bp_begin_kernel, dim3(blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }
 int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
     if (nontemporal)
         hipLaunchKernelGGL(bp_sweep_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     else
@@ -1012,6 +1026,7 @@ int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, void*
     return hip_rc(hipGetLastError());
 }
 int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
     hipLaunchKernelGGL(bp_finish_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }

@@ -168,11 +168,13 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(LwArgs a) {
 }
 
 int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
     hipLaunchKernelGGL(lw_sample_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }
 int launch_lw_hist(const LwArgs& a, int blocks, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
     hipLaunchKernelGGL(lw_hist_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);

@@ -106,6 +106,13 @@ class Engine:
         _lib.check(_lib.lib().bn_bp_last_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    def set_option(self, name: str, value: int) -> None:
+        _lib.check(_lib.lib().bn_set_option(self._h, name.encode(), int(value)))
+
+    def last_path(self) -> int:
+        """1: the last run used the persistent one-launch kernel; 0: one launch per sweep."""
+        return _lib.check(_lib.lib().bn_bp_last_path(self._h))
+
     # ---- multi-GPU ---------------------------------------------------------------------
     @staticmethod
     def comm_unique_id() -> bytes:

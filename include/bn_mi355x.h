@@ -115,6 +115,15 @@ int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
 int bn_bp_residual_history(bn_engine *eng, double *out, int32_t cap);
 int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
 
+/* Options: "persistent" 0/1 -- when every tile of the network can be resident at once (and is
+ * register-resident: uniform arity, CPT <= 64 entries, <= 4 children, one GPU) the whole run is ONE
+ * launch that keeps the CPTs in registers and synchronises tiles through neighbour flags
+ * (bn_persist.hip); otherwise, or after the kernel gave up a wait, one launch per sweep.  Default 0:
+ * the persistent path is bit-identical but measured slower on MI355X (BN_PERSISTENT=1 in the
+ * environment turns it on).  bn_bp_last_path: 1 persistent, 0 per-sweep. */
+int bn_set_option(bn_engine *eng, const char *name, int32_t value);
+int bn_bp_last_path(bn_engine *eng);
+
 /* Single steps of a run (tests / diagnostics): begin, one sweep (without exchange), finish.
  * bn_debug_allgather emulates the exchange between n shard engines living on ONE device. */
 int bn_bp_step_begin(bn_engine *eng);
