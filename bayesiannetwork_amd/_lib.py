@@ -77,6 +77,7 @@ SYMBOLS = [
     ("bn_rs_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, ctypes.c_uint64,
                                  ctypes.c_uint64, ctypes.c_uint64, f64p, ctypes.POINTER(ctypes.c_uint64),
                                  ctypes.POINTER(ctypes.c_uint64)]),
+    ("bn_fit_cpt", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int64, u8p, ctypes.POINTER(ctypes.c_uint64), f64p]),
     ("bn_lw_states", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, u8p, f64p]),
     ("bn_layout_get", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LayoutInfo)]),
     ("bn_layout_edge_refs", ctypes.c_int, [ctypes.c_void_p, i32p, i32p]),

@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>  // types only: the library is loaded lazily with dlopen (no link dependency)
 
 #include "bn_device.hpp"
+#include "bn_fit.hpp"
 #include "bn_lw.hpp"
 
 using namespace bnmi;
@@ -779,6 +780,85 @@ extern "C" int bn_rs_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
                     counts_out, drawn_out, accepted_out, err);
     if (rc) return fail(rc, err);
     return BN_OK;
+}
+
+// CPT fitting from a table of joint patterns, reference sampler.hpp:81-163 (sampler::make_cpt).
+// Stateless: only the structure of `desc` is read (its cpt pointer is ignored and may be null).
+extern "C" int bn_fit_cpt(const bn_model_desc* desc, int64_t n_patterns, const uint8_t* patterns,
+                          const uint64_t* counts, double* cpt_out) {
+    if (!desc || !cpt_out) return fail(BN_ERR_ARG, "null argument");
+    if (desc->n_nodes < 0 || (desc->n_nodes > 0 && (!desc->k || !desc->in_ptr || !desc->cpt_off)))
+        return fail(BN_ERR_ARG, "bad model structure");
+    if (n_patterns < 0 || (n_patterns > 0 && (!patterns || !counts))) return fail(BN_ERR_ARG, "bad pattern table");
+    const int32_t n = desc->n_nodes;
+    std::vector<int32_t> k(desc->k, desc->k + n), in_ptr(desc->in_ptr, desc->in_ptr + n + 1);
+    std::vector<int64_t> cpt_off(desc->cpt_off, desc->cpt_off + n + 1);
+    if (in_ptr[0] != 0 || cpt_off[0] != 0) return fail(BN_ERR_ARG, "in_ptr / cpt_off must start at 0");
+    for (int32_t v = 0; v < n; ++v) {
+        if (k[v] < 1 || k[v] > 255) return fail(BN_ERR_ARG, "node arity must be in 1..255");
+        if (in_ptr[v + 1] < in_ptr[v] || in_ptr[v + 1] - in_ptr[v] > BN_MAX_PARENTS) return fail(BN_ERR_ARG, "bad in_ptr");
+    }
+    if (in_ptr[n] > 0 && !desc->in_idx) return fail(BN_ERR_ARG, "bad model structure");
+    std::vector<int32_t> in_idx(desc->in_idx, desc->in_idx + in_ptr[n]);
+    for (int32_t v = 0; v < n; ++v) {
+        int64_t rows = 1;
+        for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) {
+            if (in_idx[e] < 0 || in_idx[e] >= n || in_idx[e] == v) return fail(BN_ERR_ARG, "parent index out of range");
+            rows *= k[in_idx[e]];
+        }
+        if (cpt_off[v + 1] - cpt_off[v] != rows * k[v]) return fail(BN_ERR_ARG, "cpt_off does not match the arities");
+    }
+    // sampler::make_cpt returns false on an empty table (:83); here that is an argument error
+    uint64_t total = 0;
+    for (int64_t i = 0; i < n_patterns; ++i) total += counts[i];
+    if (total == 0) return fail(BN_ERR_ARG, "empty sample table (sampling_size() == 0)");
+    // [node][pattern] image so that a wave reads contiguous bytes
+    std::vector<uint8_t> tr(std::max<size_t>(size_t(n) * size_t(n_patterns), 1));
+    for (int64_t i = 0; i < n_patterns; ++i)
+        for (int32_t v = 0; v < n; ++v) {
+            if (patterns[i * n + v] >= k[v]) return fail(BN_ERR_ARG, "pattern state out of range");
+            tr[size_t(v) * n_patterns + i] = patterns[i * n + v];
+        }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(BN_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (desc->device >= ndev) return fail(BN_ERR_ARG, "device ordinal out of range");
+    if (desc->device >= 0) HIPCHK(hipSetDevice(desc->device));
+    std::vector<int32_t> row_node;
+    std::vector<int64_t> row_off;
+    for (int32_t v = 0; v < n; ++v)
+        for (int64_t o = cpt_off[v]; o < cpt_off[v + 1]; o += k[v]) { row_node.push_back(v); row_off.push_back(o); }
+    const size_t entries = size_t(cpt_off[n]);
+    hipStream_t s = nullptr;
+    uint8_t* d_pat = nullptr; unsigned long long* d_w = nullptr; unsigned long long* d_cnt = nullptr;
+    int32_t *d_k = nullptr, *d_ptr = nullptr, *d_idx = nullptr, *d_rn = nullptr;
+    int64_t *d_off = nullptr, *d_ro = nullptr; double* d_out = nullptr;
+    int rc = [&]() -> int {
+        int r;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if ((r = upload(&d_pat, tr, s))) return r;
+        std::vector<unsigned long long> w(counts, counts + n_patterns);
+        if ((r = upload(&d_w, w, s))) return r;
+        if ((r = upload(&d_k, k, s))) return r;
+        if ((r = upload(&d_ptr, in_ptr, s))) return r;
+        if ((r = upload(&d_idx, in_idx, s))) return r;
+        if ((r = upload(&d_off, cpt_off, s))) return r;
+        if ((r = upload(&d_rn, row_node, s))) return r;
+        if ((r = upload(&d_ro, row_off, s))) return r;
+        if ((r = dalloc(&d_cnt, entries))) return r;
+        if ((r = dalloc(&d_out, entries))) return r;
+        HIPCHK(hipMemsetAsync(d_cnt, 0, std::max<size_t>(entries, 1) * 8, s));
+        FitArgs a{n, d_k, d_ptr, d_idx, d_off, n_patterns, d_pat, d_w, d_cnt, int64_t(row_node.size()), d_rn, d_ro, d_out};
+        if (launch_fit(a, s)) return fail(BN_ERR_HIP, "fit kernel launch failed");
+        if (entries) HIPCHK(hipMemcpyAsync(cpt_out, d_out, entries * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return BN_OK;
+    }();
+    void* ptrs[] = {d_pat, d_w, d_cnt, d_k, d_ptr, d_idx, d_rn, d_off, d_ro, d_out};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    if (s) (void)hipStreamDestroy(s);
+    return rc;
 }
 
 extern "C" int bn_lw_states(bn_engine* e, uint64_t n, uint8_t* states_out, double* weights_out) {

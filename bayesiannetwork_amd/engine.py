@@ -180,6 +180,10 @@ class Engine:
                                         ctypes.byref(drawn), ctypes.byref(acc)))
         return counts, drawn.value, acc.value
 
+    def fit_cpt(self, patterns, counts) -> np.ndarray:
+        """fit_cpt() on this engine's structure."""
+        return fit_cpt(self.model, patterns, counts)
+
     def lw_states(self, n: int):
         states = np.zeros((n, self.model.n), dtype=np.uint8)
         weights = np.zeros(n, dtype=np.float64)
@@ -205,6 +209,78 @@ class Engine:
         s = np.zeros(max(self.model.n, 1), dtype=np.int32)
         _lib.check(_lib.lib().bn_layout_node_slots(self._h, _p(s, ctypes.c_int32)))
         return s[:self.model.n]
+
+
+def fit_cpt(model: FlatModel, patterns, counts, device: int = _lib.BN_DEVICE_CURRENT) -> np.ndarray:
+    """sampler::make_cpt (reference sampler.hpp:81-163) on the GPU: flat CPTs of `model`'s structure
+    fitted to a pattern table (patterns [P][n] uint8 states, counts [P]); model.cpt is not read."""
+    patterns = np.ascontiguousarray(patterns, dtype=np.uint8).reshape(-1, max(model.n, 1))
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    if counts.shape[0] != patterns.shape[0]:
+        raise ValueError("one count per pattern")
+    out = np.zeros(int(model.cpt_off[-1]), dtype=np.float64)
+    d = _lib.ModelDesc(model.n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
+                       _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64), None, device, 0)
+    _lib.check(_lib.lib().bn_fit_cpt(ctypes.byref(d), patterns.shape[0], _p(patterns, ctypes.c_uint8),
+                                     _p(counts, ctypes.c_uint64), _p(out, ctypes.c_double)))
+    return out
+
+
+class Sampler:
+    """Mirror of bn::sampler (reference bayesian/sampler.hpp:17-215): a table of joint patterns with
+    occurrence counts, and make_cpt() fitting every CPT of a structure to it on the GPU."""
+
+    def __init__(self, filename: str = ""):
+        self._filename, self._table, self._size = filename, {}, 0
+
+    def filename(self) -> str:
+        return self._filename
+
+    def set_filename(self, filename: str) -> None:  # :172-177 resets the table
+        self._filename, self._table, self._size = filename, {}, 0
+
+    def table(self) -> dict:
+        return dict(self._table)
+
+    def sampling_size(self) -> int:
+        return self._size
+
+    def load_sample(self, arg) -> bool:
+        """dict {pattern tuple (state per node id): count} (:29-37) or a node order for the
+        whitespace-separated file "count s_0 s_1 ..." set by set_filename (:42-77; False if unreadable)."""
+        if isinstance(arg, dict):
+            self._table = {tuple(int(x) for x in key): int(c) for key, c in arg.items()}
+            self._size = sum(self._table.values())
+            return True
+        order = [int(v) for v in arg]
+        try:
+            fh = open(self._filename)
+        except OSError:
+            return False
+        table, size = {}, 0
+        with fh:
+            for line in fh:
+                tok = line.split()
+                if not tok:
+                    continue
+                cnt = int(tok[0])
+                pat = [0] * len(order)
+                for pos, v in enumerate(order):
+                    pat[v] = int(tok[1 + pos])
+                key = tuple(pat)
+                table[key] = table.get(key, 0) + cnt
+                size += cnt
+        self._table, self._size = table, size
+        return True
+
+    def make_cpt(self, model: FlatModel) -> bool:
+        """Overwrites model.cpt with the fitted CPTs (:81-163); False when no sample is loaded (:83)."""
+        if self._size == 0:
+            return False
+        pats = np.array(list(self._table.keys()), dtype=np.uint8).reshape(len(self._table), model.n)
+        cnts = np.array(list(self._table.values()), dtype=np.uint64)
+        model.cpt[:] = fit_cpt(model, pats, cnts)
+        return True
 
 
 def debug_allgather(engines, sweep: int) -> None:

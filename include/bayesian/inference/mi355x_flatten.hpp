@@ -48,7 +48,9 @@ struct flat_model {
     }
 };
 
-inline flat_model flatten(graph_t const& graph)
+// Structure only (arities, parents, CPT offsets); fm.cpt stays empty.  with_cpt = true also reads
+// every CPT row.
+inline flat_model flatten_impl(graph_t const& graph, bool const with_cpt)
 {
     flat_model fm;
     fm.nodes = graph.vertex_list();
@@ -77,10 +79,13 @@ inline flat_model flatten(graph_t const& graph)
         }
         fm.in_ptr[i + 1] = static_cast<std::int32_t>(fm.in_idx.size());
 
-        // every parent assignment, first parent slowest
-        std::vector<int> state(parents.size(), 0);
         std::size_t rows = 1;
         for(auto r : radix) rows *= static_cast<std::size_t>(r);
+        fm.cpt_off[i + 1] = fm.cpt_off[i] + static_cast<std::int64_t>(rows) * fm.k[i];
+        if(!with_cpt) continue;
+
+        // every parent assignment, first parent slowest
+        std::vector<int> state(parents.size(), 0);
         for(std::size_t row = 0; row < rows; ++row)
         {
             condition_t cond;
@@ -96,9 +101,36 @@ inline flat_model flatten(graph_t const& graph)
                 state[j] = 0;
             }
         }
-        fm.cpt_off[i + 1] = static_cast<std::int64_t>(fm.cpt.size());
     }
     return fm;
+}
+
+inline flat_model flatten(graph_t const& graph) { return flatten_impl(graph, true); }
+inline flat_model flatten_structure(graph_t const& graph) { return flatten_impl(graph, false); }
+
+// Inverse of flatten for the CPTs: write the flat rows back into every node's cpt_t (which must
+// already hold one row per parent assignment, i.e. cpt.assign(parents, node) was called).
+inline void store_cpts(graph_t const& graph, flat_model const& fm, std::vector<double> const& cpt)
+{
+    for(std::size_t i = 0; i < fm.nodes.size(); ++i)
+    {
+        auto const parents = graph.in_vertexes(fm.nodes[i]);
+        std::vector<int> state(parents.size(), 0);
+        std::size_t const k = static_cast<std::size_t>(fm.k[i]);
+        for(std::int64_t o = fm.cpt_off[i]; o < fm.cpt_off[i + 1]; o += fm.k[i])
+        {
+            condition_t cond;
+            for(std::size_t j = 0; j < parents.size(); ++j) cond[parents[j]] = state[j];
+            auto entry = fm.nodes[i]->cpt[cond];
+            if(!entry.first) throw std::runtime_error("bn::mi355x::store_cpts: CPT row missing at node " + std::to_string(i));
+            entry.second.assign(cpt.begin() + o, cpt.begin() + o + static_cast<std::int64_t>(k));
+            for(std::size_t j = parents.size(); j-- > 0;)
+            {
+                if(++state[j] < fm.k[fm.in_idx[fm.in_ptr[i] + j]]) break;
+                state[j] = 0;
+            }
+        }
+    }
 }
 
 // RAII over the C handle; non-zero codes become std::runtime_error (no exception crosses the ABI).

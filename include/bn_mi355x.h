@@ -170,6 +170,20 @@ int bn_lw_run_allreduce(bn_engine *eng, int32_t ne, const int32_t *ev_node, cons
 int bn_rs_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
               uint64_t sample_begin, uint64_t n_accept, uint64_t max_draw, uint64_t seed,
               double *counts_out, uint64_t *drawn_out, uint64_t *accepted_out);
+/*
+ * Maximum-likelihood CPTs from a table of joint patterns.
+ * Replaces: sampler::load_sample(table) + sampler::make_cpt(graph) (bayesian/sampler.hpp:29-37,
+ * 81-163) -- the consumer of likelihood_weighting::make_samples' pattern table.
+ *   patterns [n_patterns][n_nodes] : state of every node in each distinct pattern
+ *   counts   [n_patterns]          : occurrences of each pattern
+ *   structure                      : k / in_ptr / in_idx / cpt_off / device of the model; its `cpt`
+ *                                    is not read (the graph has no CPTs yet) and may be NULL
+ *   cpt_out                        : the fitted flat CPTs (layout of bn_model_desc.cpt); a row no
+ *                                    pattern supports is uniform (:140-146)
+ * An empty table (the reference's `return false`, :83) is BN_ERR_ARG.
+ */
+int bn_fit_cpt(const bn_model_desc *structure, int64_t n_patterns, const uint8_t *patterns,
+               const uint64_t *counts, double *cpt_out);
 /* Sampled states of the first `n` samples of the last bn_lw_run, sample-major [s][node]. */
 int bn_lw_states(bn_engine *eng, uint64_t n, uint8_t *states_out, double *weights_out);
 

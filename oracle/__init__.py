@@ -122,6 +122,22 @@ def rs_run(model, ev_state, n_accept: int, seed: int, max_draw: int = 1 << 34, s
     return counts, drawn.value, acc.value
 
 
+def make_cpt(model, patterns, counts):
+    """Restated sampler::make_cpt (oracle_make_cpt; parity unpinned: the reference file needs Boost)."""
+    L = lib()
+    L.oracle_make_cpt.restype = ctypes.c_int
+    patterns = np.ascontiguousarray(patterns, dtype=np.uint8).reshape(-1, model.n)
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    out = np.zeros(int(model.cpt_off[-1]), dtype=np.float64)
+    rc = L.oracle_make_cpt(model.n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32),
+                           _p(model.in_idx, ctypes.c_int32), _p(model.cpt_off, ctypes.c_int64),
+                           ctypes.c_int64(patterns.shape[0]), _p(patterns, ctypes.c_uint8),
+                           _p(counts, ctypes.c_uint64), _p(out, ctypes.c_double))
+    if rc != 0:
+        raise RuntimeError(f"oracle_make_cpt failed: {rc}")
+    return out
+
+
 def lw_normalize(model, hist):
     """likelihood_weighting.hpp:197-221 applied per node."""
     out = hist.astype(np.float64).copy()

@@ -156,3 +156,33 @@ int oracle_rs_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
     free(node_off); free(state);
     return 0;
 }
+
+/*
+ * CPT fitting, restated from bayesian/sampler.hpp:81-163 (sampler::make_cpt).  PARITY UNPINNED for
+ * this function: sampler.hpp needs Boost, which this image lacks, so the reference side cannot be
+ * compiled here; the restatement follows the source text: per node and parent assignment the
+ * occurrence counts of the patterns are summed by own state (:96-122); a row is count / row total
+ * (:148-151), or uniform when the total is zero (:140-146).
+ */
+int oracle_make_cpt(int n, const int32_t *k, const int32_t *in_ptr, const int32_t *in_idx,
+                    const int64_t *cpt_off, int64_t n_patterns, const uint8_t *patterns /* [P][n] */,
+                    const uint64_t *counts, double *cpt_out) {
+    int64_t total = cpt_off[n];
+    uint64_t *cnt = (uint64_t *)calloc((size_t)(total ? total : 1), sizeof(uint64_t));
+    if (!cnt) return -1;
+    for (int64_t p = 0; p < n_patterns; ++p)
+        for (int v = 0; v < n; ++v) {
+            int64_t row = 0;
+            for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + patterns[p * n + in_idx[e]];
+            cnt[cpt_off[v] + row * k[v] + patterns[p * n + v]] += counts[p];
+        }
+    for (int v = 0; v < n; ++v)
+        for (int64_t o = cpt_off[v]; o < cpt_off[v + 1]; o += k[v]) {
+            uint64_t s = 0;
+            for (int i = 0; i < k[v]; ++i) s += cnt[o + i];
+            double parameter = (double)s;
+            for (int i = 0; i < k[v]; ++i) cpt_out[o + i] = (s == 0) ? 1.0 / k[v] : (double)cnt[o + i] / parameter;
+        }
+    free(cnt);
+    return 0;
+}

@@ -19,6 +19,7 @@
 #include <bayesian/inference/belief_propagation.hpp>
 #include <bayesian/inference/likelihood_weighting.hpp>
 #include <bayesian/inference/rejection_sampling.hpp>
+#include <bayesian/sampler.hpp>
 #include <bayesian/serializer/dsc.hpp>
 
 namespace {
@@ -247,7 +248,43 @@ int main(int argc, char** argv)
         close_pct(result.at(v[1])[0][0], 0.62, 10, "rejection v2[0]");
         close_pct(result.at(v[1])[0][1], 0.38, 10, "rejection v2[1]");
         close_pct(result.at(v[3])[0][1], 1.0, 1e-9, "rejection keeps the condition");
-        print_marginals("rejection", net, result, true);
+        print_marginals("rejection", net, result);
+    }
+    {   // sampler::make_cpt (reference sampler.hpp:81-163): the pattern table make_samples returns,
+        // loaded into bn::sampler, refits the CPTs of a structure-only copy of the network
+        auto const v = pearl.vertex_list();
+        bn::inference::likelihood_weighting lw(pearl);
+        lw.seed(11);
+        auto const made = lw.make_samples({}, 300000, 0.01);
+        // the table is keyed by pearl's vertices; the structure-only copy shares them through a
+        // second graph over the same vertex objects is not possible, so refit pearl itself on a
+        // saved copy of its CPT rows
+        auto const before = bn::mi355x::flatten(pearl);
+        bn::sampler smp;
+        if(smp.make_cpt(pearl)) { ++failures; std::printf("FAIL make_cpt without samples must return false\n"); }
+        smp.load_sample(made.first);
+        std::size_t total = 0;
+        for(auto const& p : made.first) total += p.second;
+        if(smp.sampling_size() != total) { ++failures; std::printf("FAIL sampling_size\n"); }
+        if(!smp.make_cpt(pearl)) { ++failures; std::printf("FAIL make_cpt returned false\n"); }
+        auto const after = bn::mi355x::flatten(pearl);
+        // rows of W given R=0 and H given (R=0, S=*) are deterministic in the generating CPT;
+        // every row has >= 4 % of the samples, so 0.01 absolute is > 5 sigma
+        for(std::size_t i = 0; i < before.cpt.size(); ++i)
+            if(std::fabs(before.cpt[i] - after.cpt[i]) > 0.01)
+            { ++failures; std::printf("FAIL make_cpt entry %zu: %.6f vs %.6f\n", i, after.cpt[i], before.cpt[i]); }
+        print_json_array("fitted_cpt", after.cpt);
+        // exact host-side recount of the same table
+        std::vector<double> cnt(before.cpt.size(), 0.0);
+        for(auto const& p : made.first)
+            for(std::size_t i = 0; i < v.size(); ++i)
+            {
+                std::size_t row = 0;
+                for(std::int32_t e = before.in_ptr[i]; e < before.in_ptr[i + 1]; ++e)
+                    row = row * before.k[before.in_idx[e]] + p.first.at(v[before.in_idx[e]]);
+                cnt[before.cpt_off[i] + row * before.k[i] + p.first.at(v[i])] += static_cast<double>(p.second);
+            }
+        print_json_array("fit_counts", cnt, true);
     }
     std::printf("}\n");
     if(failures) std::printf("%d FAILURES\n", failures);

@@ -145,3 +145,20 @@ def test_evidence_helpers():
     with pytest.raises(ValueError):
         from_parent_lists([2, 2], [[1], []], [[.5, .5, .5, .5], [.5, .5]]).validate() or \
             from_parent_lists([2, 2], [[], [1]], [[.5, .5], [.5, .5, .5, .5]])
+
+
+def test_sampler_mirror_loads_tables_and_files(tmp_path):
+    """bn::sampler's host side (reference sampler.hpp:29-77, 166-190): table / file loading, counts."""
+    from bayesiannetwork_amd.engine import Sampler
+    smp = Sampler()
+    assert smp.sampling_size() == 0 and smp.make_cpt(synth.pearl()) is False      # :83
+    assert smp.load_sample({(0, 1, 1, 0): 3, (1, 1, 0, 0): 5})
+    assert smp.sampling_size() == 8 and smp.table()[(1, 1, 0, 0)] == 5
+    f = tmp_path / "samples.txt"
+    f.write_text("3 0 1 1 0\n5   1 1 0 0\n2 0 1 1 0\n")                         # runs of blanks compress (:58)
+    smp.set_filename(str(f))
+    assert smp.sampling_size() == 0 and smp.table() == {} and smp.filename() == str(f)
+    assert smp.load_sample([3, 2, 1, 0])                                           # column order = node list
+    assert smp.sampling_size() == 10 and smp.table() == {(0, 1, 1, 0): 5, (0, 0, 1, 1): 5}
+    smp.set_filename(str(tmp_path / "missing.txt"))
+    assert smp.load_sample([0, 1, 2, 3]) is False                                  # :46

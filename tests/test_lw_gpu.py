@@ -139,3 +139,47 @@ def test_rejection_sampling_reference_case_and_cap(Engine):
     impossible = from_parent_lists([2, 2], [[], [0]], [[1.0, 0.0], [1.0, 0.0, 0.5, 0.5]])
     with pytest.raises(RuntimeError):             # the reference would never return
         RejectionSampling(impossible, max_draws=20000)({1: 1}, 10)
+
+
+def test_fit_cpt_matches_restatement_and_recovers_cpts(Engine, oracle_mod):
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd._lib import BnError
+    # sampler::make_cpt (SURVEY f-3): counting is integer work -> CPTs bit-identical to the C
+    # restatement; fitted on many forward samples they approach the generating CPTs; rows no pattern
+    # supports are uniform (reference sampler.hpp:140-146).
+    d = synth.random_dag(60, 3, 12, [2, 3, 4], seed=5)
+    with Engine(d) as eng:
+        n = 200000
+        eng.lw_run(np.full(d.n, -1, np.int32), n, seed=3)           # forward samples (no evidence)
+        states, _ = eng.lw_states(n)
+        pats, cnts = np.unique(states, axis=0, return_counts=True)
+        fit = eng.fit_cpt(pats, cnts)
+        assert np.array_equal(fit, oracle_mod.make_cpt(d, pats, cnts))
+        for v in range(d.n):
+            rows = fit[d.cpt_off[v]:d.cpt_off[v + 1]].reshape(-1, d.k[v])
+            assert np.allclose(rows.sum(axis=1), 1.0, atol=1e-12)
+        assert (np.abs(fit - d.cpt) < 0.08).mean() > 0.9              # well-supported rows are recovered
+        fit2 = eng.fit_cpt(pats[:1], cnts[:1])                        # one pattern: one row per node is seen
+        assert np.array_equal(fit2, oracle_mod.make_cpt(d, pats[:1], cnts[:1]))
+        v = int(np.argmax(np.diff(d.in_ptr)))
+        rows = fit2[d.cpt_off[v]:d.cpt_off[v + 1]].reshape(-1, d.k[v])
+        assert int((rows == 1.0 / d.k[v]).all(axis=1).sum()) == rows.shape[0] - 1
+        with pytest.raises(BnError):
+            eng.fit_cpt(pats[:1], np.zeros(1, np.uint64))             # sampling_size() == 0 (sampler.hpp:83)
+
+
+def test_sampler_mirror_make_cpt(Engine, oracle_mod):
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Sampler
+    m = synth.pearl()
+    truth = m.cpt.copy()
+    with Engine(m) as eng:
+        eng.lw_run(np.full(m.n, -1, np.int32), 100000, seed=9)
+        states, _ = eng.lw_states(100000)
+    pats, cnts = np.unique(states, axis=0, return_counts=True)
+    smp = Sampler()
+    smp.load_sample({tuple(p): int(c) for p, c in zip(pats.tolist(), cnts.tolist())})
+    assert smp.sampling_size() == 100000
+    assert smp.make_cpt(m) is True
+    assert np.array_equal(m.cpt, oracle_mod.make_cpt(m, pats, cnts))
+    assert np.abs(m.cpt - truth).max() < 0.02
