@@ -745,7 +745,7 @@ extern "C" int bn_lw_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
 }
 
 // Likelihood weighting over every rank of the communicator: the sample range is split evenly,
-// each GPU draws its share (disjoint Philox counters), ONE RCCL all-reduce sums the histograms.
+// each GPU draws its share (disjoint sample ids = disjoint streams), ONE RCCL all-reduce sums the histograms.
 extern "C" int bn_lw_run_allreduce(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_state,
                                    uint64_t sample_begin, uint64_t n_samples_total, uint64_t seed, double* hist_out) {
     if (!e || !hist_out) return fail(BN_ERR_ARG, "null argument");

@@ -20,8 +20,7 @@ namespace bnmi {
     } while (0)
 
 void lw_free(LwState& s) {
-    void* ptrs[] = {s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo,
-                    s.d_ev_state, s.d_states, s.d_weights, s.d_hist};
+    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     s = LwState();
@@ -70,15 +69,54 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
             err = "the model has a directed cycle: likelihood weighting needs a DAG (graph.hpp:268-291)";
             return BN_ERR_ARG;
         }
+        // per-position descriptors: the kernel reads them with scalar loads, one position ahead
+        std::vector<LwStep> steps(size_t(p.n) + 1);  // one spare: the kernel reads a position ahead
+        std::vector<LwParent> parents;
+        parents.reserve(size_t(p.E) + size_t(p.n) + 4);
+        s.kmax = 0;
+        s.rows24 = true;
+        s.inline_parents = p.n <= (1 << 24);
+        // the kernel picks a state by counting the running totals u has reached, which equals the
+        // reference's interval test (:177-193) when the totals never decrease
+        for (double x : p.cpt_flat)
+            if (!(x >= 0.0) || x > 1.7976931348623157e308) {
+                err = "likelihood weighting needs finite, non-negative CPT entries";
+                return BN_ERR_ARG;
+            }
+        for (int32_t t = 0; t < p.n; ++t) {
+            const int32_t v = s.topo[t];
+            const int64_t coff = p.cpt_off[v];
+            if ((p.cpt_off[v + 1] - coff) / p.k[v] > int64_t(0xffffffffu) || coff >= (int64_t(1) << 48)) {
+                err = "CPT too large for the sampler";
+                return BN_ERR_ARG;
+            }
+            LwStep& sd = steps[t];
+            sd.coff_lo = uint32_t(uint64_t(coff));
+            sd.coff_hi = uint16_t(uint64_t(coff) >> 32);
+            sd.v = v;
+            sd.par_off = uint32_t(parents.size());
+            sd.kv = uint8_t(p.k[v]);
+            sd.m = uint8_t(p.in_ptr[v + 1] - p.in_ptr[v]);
+            for (int q = 0; q < 4; ++q) sd.par[q] = 0;
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+                parents.push_back(LwParent{uint32_t(p.in_idx[e]), uint32_t(p.k[p.in_idx[e]])});
+                const int32_t j = e - p.in_ptr[v];
+                if (j < 4 && s.inline_parents) sd.par[j] = uint32_t(p.in_idx[e]) | (uint32_t(p.k[p.in_idx[e]]) << 24);
+            }
+            if (parents.size() & 1) parents.push_back(LwParent{0, 1});  // pairs: 16-byte aligned loads
+            s.kmax = std::max(s.kmax, p.k[v]);
+            if ((p.cpt_off[v + 1] - coff) / p.k[v] >= (int64_t(1) << 24)) s.rows24 = false;
+        }
+        for (int q = 0; q < 4; ++q) parents.push_back(LwParent{0, 1});
         int r;
         if ((r = up(&s.d_k, p.k.data(), p.k.size(), st, err))) return r;
-        if ((r = up(&s.d_in_ptr, p.in_ptr.data(), p.in_ptr.size(), st, err))) return r;
-        if ((r = up(&s.d_in_idx, p.in_idx.data(), p.in_idx.size(), st, err))) return r;
-        if ((r = up(&s.d_cpt_off, p.cpt_off.data(), p.cpt_off.size(), st, err))) return r;
         if ((r = up(&s.d_node_off, p.node_off.data(), p.node_off.size(), st, err))) return r;
         if ((r = up(&s.d_cpt, p.cpt_flat.data(), p.cpt_flat.size(), st, err))) return r;
-        if ((r = up(&s.d_topo, s.topo.data(), s.topo.size(), st, err))) return r;
-        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_state), std::max<size_t>(p.n, 1) * sizeof(int32_t)));
+        if ((r = up(&s.d_steps, steps.data(), steps.size(), st, err))) return r;
+        if ((r = up(&s.d_parents, parents.data(), parents.size(), st, err))) return r;
+        LWCHK(hipStreamSynchronize(st));  // steps / parents are locals
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_topo), (size_t(p.n) + 1) * sizeof(int32_t)));
+        LWCHK(hipMemsetAsync(s.d_ev_topo, 0xff, (size_t(p.n) + 1) * sizeof(int32_t), st));
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double)));
         s.ready = true;
     }
@@ -119,12 +157,15 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     int r = lw_prepare(s, p, st, n_samples, err);
     if (r) return r;
     const size_t hist_n = size_t(p.node_off[p.n]);
-    LWCHK(hipMemcpyAsync(s.d_ev_state, evs.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
+    std::vector<int32_t> evt(std::max(p.n, 1));
+    for (int32_t t = 0; t < p.n; ++t) evt[t] = evs[s.topo[t]];
+    LWCHK(hipMemcpyAsync(s.d_ev_topo, evt.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
+    LWCHK(hipStreamSynchronize(st));  // evt is a local
     LWCHK(hipMemsetAsync(s.d_hist, 0, std::max<size_t>(hist_n, 1) * sizeof(double), st));
     uint64_t done = 0;
     while (done < n_samples) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
-        LwArgs a{p.n, s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo, s.d_ev_state,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st) || launch_lw_hist(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
@@ -153,13 +194,15 @@ int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     int r = lw_prepare(s, p, st, std::min<uint64_t>(std::max<uint64_t>(4 * n_accept, kLwBlockSamples), max_draw), err);
     if (r) return r;
     const size_t hist_n = size_t(p.node_off[p.n]);
-    LWCHK(hipMemcpyAsync(s.d_ev_state, evs.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
+    std::vector<int32_t> evt(std::max(p.n, 1));
+    for (int32_t t = 0; t < p.n; ++t) evt[t] = evs[s.topo[t]];
+    LWCHK(hipMemcpyAsync(s.d_ev_topo, evt.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
     LWCHK(hipMemsetAsync(s.d_hist, 0, std::max<size_t>(hist_n, 1) * sizeof(double), st));
     std::vector<double> w(s.batch);
     uint64_t drawn = 0, accepted = 0;
     while (accepted < n_accept && drawn < max_draw) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, max_draw - drawn);
-        LwArgs a{p.n, s.d_k, s.d_in_ptr, s.d_in_idx, s.d_cpt_off, s.d_node_off, s.d_cpt, s.d_topo, s.d_ev_state,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st)) { err = "sampling kernel launch failed"; return BN_ERR_HIP; }

@@ -14,18 +14,34 @@ constexpr int kLwThreads = 256;      // threads per block
 #endif
 constexpr int kLwPerThread = BN_LW_PER_THREAD;      // samples per thread
 constexpr int kLwBlockSamples = kLwThreads * kLwPerThread;
-constexpr int kLwLdsDoubles = 4096;  // CPTs up to this size are staged in LDS (32 KiB)
+
+// One topological position: everything a wave needs about the node, 32 bytes, wave-uniform, read
+// with one scalar load a position ahead.  The first four parents are inline (node | arity << 24,
+// 0 = none) when every node id fits 24 bits (LwState::inline_parents); longer lists and larger
+// networks use the LwParent list.
+struct LwStep {
+    uint32_t coff_lo;  // offset of the node's CPT in the flat array (doubles), 48 bits
+    int32_t v;         // node id (row of the state matrix)
+    uint32_t par_off;  // first entry of the node's parents in LwParent[] (even)
+    uint16_t coff_hi;
+    uint8_t kv, m;     // arity, number of parents
+    uint32_t par[4];   // parents 0..3: node | arity << 24
+};
+struct LwParent {
+    uint32_t node, k;  // parent node id and its arity (mixed-radix digit base)
+};
 
 struct LwState {
     bool ready = false;
     int32_t* d_k = nullptr;
-    int32_t* d_in_ptr = nullptr;
-    int32_t* d_in_idx = nullptr;
-    int64_t* d_cpt_off = nullptr;
     int64_t* d_node_off = nullptr;
     double* d_cpt = nullptr;       // flat, reference row order (row lookup = k contiguous doubles)
-    int32_t* d_topo = nullptr;
-    int32_t* d_ev_state = nullptr; // [n] clamped state or -1
+    LwStep* d_steps = nullptr;     // [n] in topological order
+    LwParent* d_parents = nullptr; // [E] grouped by position, first parent first
+    int32_t* d_ev_topo = nullptr;  // [n] clamped state or -1 of the node at each position
+    int32_t kmax = 0;              // largest arity
+    bool rows24 = false;           // every CPT has < 2^24 rows: 24-bit row arithmetic
+    bool inline_parents = false;   // n <= 2^24: LwStep::par is filled
     uint8_t* d_states = nullptr;   // [n][batch] sampled states of the current batch
     double* d_weights = nullptr;   // [batch]
     double* d_hist = nullptr;      // [sum k]
@@ -36,14 +52,15 @@ struct LwState {
 
 struct LwArgs {
     int32_t n;
+    int32_t kmax;
+    bool rows24;
+    bool inline_parents;
+    const LwStep* steps;
+    const LwParent* parents;
+    const int32_t* ev_topo;
     const int32_t* k;
-    const int32_t* in_ptr;
-    const int32_t* in_idx;
-    const int64_t* cpt_off;
     const int64_t* node_off;
     const double* cpt;
-    const int32_t* topo;
-    const int32_t* ev_state;
     uint8_t* states;
     double* weights;
     double* hist;

@@ -1,34 +1,43 @@
 // bn_lw_kernels.hip -- likelihood weighting, reference bayesian/inference/likelihood_weighting.hpp.
 //
-// One thread draws kLwPerThread ancestral samples; a block walks the nodes in topological order
-// together, so the node, its CPT (staged once per block in LDS) and its evidence flag are
-// block-uniform.  Per node and sample (weighted_sample, :122-173):
+// Sampling (lw_sample_kernel): one thread draws kLwPerThread = 4 CONSECUTIVE ancestral samples, so
+// the four states of a node are one dword of the [node][sample] byte matrix (a wave moves 256
+// contiguous bytes per load/store).  Waves never synchronise: every wave walks the topological
+// order on its own, the per-position metadata (LwStep, parent list) is wave-uniform and comes
+// through scalar loads one position ahead, CPT rows are gathered straight from global memory
+// (a node's table is at most a few KiB and shared by every wave: L1/L2 hits).  Per node and sample
+// (weighted_sample, :122-173):
 //   row   = parent assignment, first parent most significant, from the state matrix
 //   evidence node  : w *= cpt[row][ev], state = ev                         (:148-153)
 //   otherwise      : state = first i with cum_{i-1} <= u < cum_i, else k-1   (:154-158, :177-193)
 // (rejection / logic sampling, reference rejection_sampling.hpp:33-167, is the same walk with the
-// evidence nodes sampled like any other and w = 1 if every one of them came out as observed, else 0)
-// and hist[v][state] += w (:45-49), in a second kernel once w is final, pre-reduced per thread, per wave and per block before one
-// fp64 atomicAdd per (block, node, state).  Uniforms come from Philox4x32-10 keyed by the seed
-// and indexed by (global sample id, topological position) -- see oracle/lw_oracle.c for the
-// exact mapping, which this kernel reproduces bit for bit, so sampled states are identical.
+// evidence nodes sampled like any other and w = 1 if every one of them came out as observed, else 0).
+// Uniforms: every sample owns a xoshiro128++ stream seeded by one Philox4x32-10 block keyed by
+// (seed, global sample id) and advanced by two 32-bit outputs at every topological position -- see
+// oracle/lw_oracle.c for the exact mapping, which this kernel reproduces bit for bit, so sampled
+// states are identical.  (Philox for every draw, 20 quarter-rate 32x32->64 multiplies per pair of
+// positions, made the kernel VALU-bound at 62 % Philox; xoshiro is 20 full-rate ops per uniform.)
+//
+// Histogram (lw_hist_kernel, :45-49, run once the weights are FINAL): lane = node, each lane
+// streams its own row of the state matrix 16 samples at a time and adds the (wave-uniform) weights
+// into per-state accumulators kept in registers -- no cross-lane reduction; one fp64 atomicAdd per
+// (sample range, node, state) at the end.  Nodes with more than 8 states use lw_hist_wide_kernel.
 #include <hip/hip_runtime.h>
 
 #include "bn_lw.hpp"
 
 namespace bnmi {
 
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t (&out)[4]) {
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0, p1 = uint64_t(0xCD9E8D57u) * c2;
+        const uint32_t n0 = uint32_t(p1 >> 32) ^ c1 ^ k0, n2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = uint32_t(p1); c2 = n2; c3 = uint32_t(p0);
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    return make_uint4(c0, c1, c2, c3);
 }
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -37,145 +46,352 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
-__global__ __launch_bounds__(kLwThreads) void lw_sample_kernel(LwArgs a) {
-    __shared__ double sh_cpt[kLwLdsDoubles];
-    const int tid = threadIdx.x;
-    const uint64_t local0 = uint64_t(blockIdx.x) * kLwBlockSamples + tid;  // + r * kLwThreads
-    const bool reject = a.mode == 1;
-    double w[kLwPerThread];
-    uint32_t rnd[kLwPerThread][4];
-#pragma unroll
-    for (int r = 0; r < kLwPerThread; ++r) w[r] = 1.0;  // :124
-    const uint32_t key0 = uint32_t(a.seed), key1 = uint32_t(a.seed >> 32);
-
-    for (int t = 0; t < a.n; ++t) {
-        const int v = a.topo[t];
-        const int kv = a.k[v];
-        const int e0 = a.in_ptr[v], e1 = a.in_ptr[v + 1];
-        const int64_t coff = a.cpt_off[v];
-        const int64_t csz = a.cpt_off[v + 1] - coff;
-        const int ev = a.ev_state[v];
-        const bool draws = reject || ev < 0;  // logic sampling draws evidence nodes too
-#ifdef BN_LW_NOLDS
-        const bool in_lds = false;
-#else
-        const bool in_lds = csz <= kLwLdsDoubles;
-#endif
-        __syncthreads();  // previous node's LDS reads are finished
-        if (in_lds)
-            for (int q = tid; q < csz; q += kLwThreads) sh_cpt[q] = a.cpt[coff + q];
-        __syncthreads();
-        if ((t & 1) == 0 && draws) {  // fresh Philox block for positions t and t+1
-#pragma unroll
-            for (int r = 0; r < kLwPerThread; ++r) {
-                const uint64_t s = a.sample_base + local0 + uint64_t(r) * kLwThreads;
-                philox4x32_10(uint32_t(s), uint32_t(s >> 32), uint32_t(t >> 1), 0u, key0, key1, rnd[r]);
-            }
-        } else if ((t & 1) == 1 && draws) {
-            // the even position may have been a clamped evidence node (no block drawn yet)
-            const int vprev = a.topo[t - 1];
-            if (!reject && a.ev_state[vprev] >= 0) {
-#pragma unroll
-                for (int r = 0; r < kLwPerThread; ++r) {
-                    const uint64_t s = a.sample_base + local0 + uint64_t(r) * kLwThreads;
-                    philox4x32_10(uint32_t(s), uint32_t(s >> 32), uint32_t(t >> 1), 0u, key0, key1, rnd[r]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < kLwPerThread; ++r) {
-            const uint64_t col = local0 + uint64_t(r) * kLwThreads;
-            int64_t row = 0;
-            for (int e = e0; e < e1; ++e) {
-                const int p = a.in_idx[e];
-                row = row * a.k[p] + a.states[uint64_t(p) * a.batch + col];
-            }
-            const double* rowp = in_lds ? (sh_cpt + row * kv) : (a.cpt + coff + row * kv);
-            int st;
-            if (ev >= 0 && !reject) {
-                w[r] *= rowp[ev];
-                st = ev;
-            } else {
-                const uint32_t lo = (t & 1) ? rnd[r][2] : rnd[r][0], hi = (t & 1) ? rnd[r][3] : rnd[r][1];
-                const uint64_t x = (uint64_t(hi) << 32) | lo;
-                const double u = double(x >> 11) * (1.0 / 9007199254740992.0);
-                st = kv - 1;
-                bool found = false;
-                double total = 0.0;
-                for (int i = 0; i < kv; ++i) {
-                    const double old_total = total;
-                    total += rowp[i];
-                    if (!found && old_total <= u && u < total) { st = i; found = true; }
-                }
-                if (ev >= 0 && st != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
-            }
-            a.states[uint64_t(v) * a.batch + col] = uint8_t(st);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < kLwPerThread; ++r) a.weights[local0 + uint64_t(r) * kLwThreads] = w[r];
+// xoshiro128++ 1.0 (Blackman & Vigna): one 32-bit output, state in x/y/z/w
+__device__ __forceinline__ uint32_t xoshiro_next(uint4& g) {
+    const uint32_t sum = g.x + g.w;
+    const uint32_t result = ((sum << 7) | (sum >> 25)) + g.x;
+    const uint32_t t = g.y << 9;
+    g.z ^= g.x; g.w ^= g.y; g.y ^= g.z; g.x ^= g.w;
+    g.z ^= t;
+    g.w = (g.w << 11) | (g.w >> 21);
+    return result;
 }
 
-// hist[v][state_v] += w for the first n_valid samples of the batch, w being FINAL (every evidence
-// node visited).  Same sample-to-thread mapping as the sampling kernel.
-__global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(LwArgs a) {
+__device__ __forceinline__ double to_unit(uint32_t lo, uint32_t hi) {
+    const uint64_t x = (uint64_t(hi) << 32) | lo;
+    return double(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// two outputs per sample and position, low word first
+template <int S>
+__device__ __forceinline__ void draw_uniforms(uint4 (&rng)[S], double (&u)[S]) {
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+        const uint32_t lo = xoshiro_next(rng[r]);
+        const uint32_t hi = xoshiro_next(rng[r]);
+        u[r] = to_unit(lo, hi);
+    }
+}
+
+// States of the S samples of one thread at one node: first i with cum_{i-1} <= u < cum_i, else
+// KV-1 (:177-193).  All rows are loaded before the first compare so the S gathers overlap.
+// The uniforms are drawn between issuing the row gathers and using them (latency cover).
+template <int KV, int S>
+__device__ __forceinline__ void pick_states(const double* __restrict__ base, const uint32_t (&row)[S],
+                                            uint4 (&rng)[S], int kv, int (&st)[S]) {
+    double u[S];
+    if (KV > 0) {
+        double x[S][KV > 0 ? KV : 1];
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const double* rowp = base + uint64_t(row[r]) * KV;
+#pragma unroll
+            for (int i = 0; i < KV; ++i) x[r][i] = rowp[i];
+        }
+        draw_uniforms<S>(rng, u);
+        // The running totals are non-decreasing (the host rejects negative / non-finite entries), so
+        // "first i with cum_{i-1} <= u < cum_i, else KV-1" is the number of totals u has reached.
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            double total = x[r][0];
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < KV - 1; ++i) {
+                c += (u[r] >= total) ? 1 : 0;
+                total += x[r][i + 1];
+            }
+            st[r] = c;
+        }
+    } else {
+        bool found[S];
+        double total[S];
+        const double* rowp[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) { found[r] = false; total[r] = 0.0; st[r] = kv - 1; rowp[r] = base + uint64_t(row[r]) * kv; }
+        draw_uniforms<S>(rng, u);
+        for (int i = 0; i < kv; ++i) {
+            double x[S];
+#pragma unroll
+            for (int r = 0; r < S; ++r) x[r] = rowp[r][i];
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                const double old_total = total[r];
+                total[r] += x[r];
+                if (!found[r] && old_total <= u[r] && u[r] < total[r]) { st[r] = i; found[r] = true; }
+            }
+        }
+    }
+}
+
+struct LwStepWords {  // LwStep as two 16-byte words
+    uint4 a, b;
+};
+
+#ifndef BN_LW_WAVES
+#define BN_LW_WAVES 4
+#endif
+template <bool ROWS24, bool INLINE>
+__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_WAVES, BN_LW_WAVES))) void lw_sample_kernel(
+    const LwStepWords* __restrict__ steps, const uint4* __restrict__ parents, const int32_t* __restrict__ ev_topo,
+    const double* __restrict__ cpt, uint8_t* states, double* __restrict__ weights, int32_t n, uint64_t batch,
+    uint64_t sample_base, uint64_t seed, int32_t mode) {
+    constexpr int S = kLwPerThread;
+    static_assert(S == 4, "one dword of states per thread and node");
+    static_assert(sizeof(LwStep) == 32 && sizeof(LwParent) == 8, "descriptor layout");
+    const uint64_t col = (uint64_t(blockIdx.x) * kLwThreads + threadIdx.x) * S;  // first sample of this thread
+    const bool reject = mode == 1;
+    double w[S];
+    uint4 rng[S];
+    const uint32_t key0 = uint32_t(seed), key1 = uint32_t(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+        w[r] = 1.0;  // :124
+        const uint64_t s = sample_base + col + r;
+        rng[r] = philox4x32_10(uint32_t(s), uint32_t(s >> 32), 0u, 0u, key0, key1);
+        if ((rng[r].x | rng[r].y | rng[r].z | rng[r].w) == 0) rng[r].x = 1;
+    }
+
+    LwStepWords nxt = steps[0];  // both arrays have a spare entry at the end
+    int ev_nxt = ev_topo[0];
+    for (int t = 0; t < n; ++t) {
+        const uint4 sd = nxt.a;  // LwStep: coff_lo, v, par_off, coff_hi | kv << 16 | m << 24
+        const uint4 pin = nxt.b;  // parents 0..3 inline: node | arity << 24
+        const int ev = ev_nxt;
+        nxt = steps[t + 1];
+        ev_nxt = ev_topo[t + 1];
+        const int kv = int((sd.w >> 16) & 0xffu), m = int(sd.w >> 24);
+        const bool draws = reject || ev < 0;  // logic sampling draws evidence nodes too
+        uint32_t row[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) row[r] = 0;
+        uint32_t wd[4] = {0, 0, 0, 0};
+        if (INLINE) {  // the first four parents: one branch-free load group per parent count
+            auto ld = [&](uint32_t pw) {
+                return *reinterpret_cast<const uint32_t*>(states + uint64_t(pw & 0xffffffu) * batch + col);
+            };
+            auto mix = [&](uint32_t pw, uint32_t word) {
+#pragma unroll
+                for (int r = 0; r < S; ++r)
+                    row[r] = (ROWS24 ? __umul24(row[r], pw >> 24) : row[r] * (pw >> 24)) + ((word >> (8 * r)) & 0xffu);
+            };
+            switch (m < 4 ? m : 4) {
+                case 0: break;
+                case 1: wd[0] = ld(pin.x); mix(pin.x, wd[0]); break;
+                case 2: wd[0] = ld(pin.x); wd[1] = ld(pin.y); mix(pin.x, wd[0]); mix(pin.y, wd[1]); break;
+                case 3:
+                    wd[0] = ld(pin.x); wd[1] = ld(pin.y); wd[2] = ld(pin.z);
+                    mix(pin.x, wd[0]); mix(pin.y, wd[1]); mix(pin.z, wd[2]);
+                    break;
+                default:
+                    wd[0] = ld(pin.x); wd[1] = ld(pin.y); wd[2] = ld(pin.z); wd[3] = ld(pin.w);
+                    mix(pin.x, wd[0]); mix(pin.y, wd[1]); mix(pin.z, wd[2]); mix(pin.w, wd[3]);
+                    break;
+            }
+        }
+        for (int j0 = INLINE ? 4 : 0; j0 < m; j0 += 4) {  // parent lists are padded to pairs: two LwParent per uint4
+            const uint4 pa = parents[(sd.z + j0) >> 1];
+            const uint4 pb = (j0 + 2 < m) ? parents[((sd.z + j0) >> 1) + 1] : make_uint4(0, 1, 0, 1);
+            wd[0] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pa.x) * batch + col);
+            wd[1] = wd[2] = wd[3] = 0;
+            if (j0 + 1 < m) wd[1] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pa.z) * batch + col);
+            if (j0 + 2 < m) wd[2] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pb.x) * batch + col);
+            if (j0 + 3 < m) wd[3] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pb.z) * batch + col);
+            const uint32_t kk[4] = {pa.y, (j0 + 1 < m) ? pa.w : 1u, (j0 + 2 < m) ? pb.y : 1u, (j0 + 3 < m) ? pb.w : 1u};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < S; ++r)
+                    row[r] = (ROWS24 ? __umul24(row[r], kk[q]) : row[r] * kk[q]) + ((wd[q] >> (8 * r)) & 0xffu);
+        }
+        const double* base = cpt + ((uint64_t(sd.w & 0xffffu) << 32) | sd.x);
+        uint32_t packed = 0;
+        if (!draws) {
+            double x[S];
+#pragma unroll
+            for (int r = 0; r < S; ++r) x[r] = base[uint64_t(row[r]) * kv + ev];
+            double unused[S];  // the stream advances at every position: u(s, t) does not depend on the evidence
+            draw_uniforms<S>(rng, unused);
+#pragma unroll
+            for (int r = 0; r < S; ++r) w[r] *= x[r];
+            packed = uint32_t(ev) * 0x01010101u;
+        } else {
+            int st[S];
+            switch (kv) {
+                case 2: pick_states<2, S>(base, row, rng, 2, st); break;
+                case 3: pick_states<3, S>(base, row, rng, 3, st); break;
+                case 4: pick_states<4, S>(base, row, rng, 4, st); break;
+                default: pick_states<0, S>(base, row, rng, kv, st); break;
+            }
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                if (ev >= 0 && st[r] != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
+                packed |= uint32_t(st[r]) << (8 * r);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(states + uint64_t(sd.y) * batch + col) = packed;
+    }
+#pragma unroll
+    for (int r = 0; r < S; ++r) weights[col + r] = w[r];
+}
+
+// acc[i] += w on the lanes whose state is i: compare into vcc, run the fp64 add under that mask
+// (2 VALU instructions; a select would need the add plus two v_cndmask per state).
+template <int KMAX>
+__device__ __forceinline__ void masked_add(double (&acc)[KMAX], int i, double w, uint32_t st) {
+    uint64_t saved;
+    asm volatile(
+        "v_cmp_eq_u32_e64 vcc, %2, %3\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "v_add_f64 %0, %0, %4\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(acc[i]), "=&s"(saved)
+        : "v"(st), "s"(uint32_t(i)), "s"(w)
+        : "vcc", "scc");
+}
+
+// hist[v][state_v] += w over samples [range*R, (range+1)*R) of the first n_valid; lane = node.
+template <int KMAX>
+__global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(const uint8_t* __restrict__ states,
+                                                             const double* __restrict__ weights,
+                                                             const int32_t* __restrict__ k,
+                                                             const int64_t* __restrict__ node_off,
+                                                             double* __restrict__ hist, int32_t n, uint64_t batch,
+                                                             uint64_t n_valid, uint64_t range) {
+    const int v = blockIdx.x * kLwThreads + threadIdx.x;
+    const uint64_t s0 = uint64_t(blockIdx.y) * range;
+    const uint64_t s1 = s0 + range < n_valid ? s0 + range : n_valid;
+    if (s0 >= s1) return;
+    const bool live = v < n;
+    const uint8_t* rowp = states + uint64_t(live ? v : 0) * batch;
+    double acc[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) acc[i] = 0.0;
+    // the weights are read-only for this kernel and wave-uniform: constant address space -> s_load
+    typedef double double8 __attribute__((ext_vector_type(8)));
+    typedef const double8 __attribute__((address_space(4))) * const_double8s;
+    uint64_t s = s0;
+    // 64 samples (one 64-byte segment of the lane's row) per trip, the next segment in flight while
+    // this one is accumulated (two register sets, no copies).  s0 and the row stride are multiples of 64.
+    auto fetch = [&](uint4 (&q)[4], uint64_t at) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = *reinterpret_cast<const uint4*>(rowp + at + 16 * c);
+    };
+    auto consume = [&](const uint4 (&q)[4], uint64_t at) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            __builtin_amdgcn_sched_barrier(0);  // keep the scalar weight loads of a chunk with its chunk
+            const const_double8s wp = (const_double8s)(weights + at + 16 * c);
+            const double8 wlo = wp[0], whi = wp[1];
+            const uint32_t word[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double wj = j < 8 ? wlo[j & 7] : whi[j & 7];
+                const uint32_t st = (word[j >> 2] >> (8 * (j & 3))) & 0xffu;
+#pragma unroll
+                for (int i = 0; i < KMAX; ++i) masked_add<KMAX>(acc, i, wj, st);
+            }
+        }
+    };
+    // the segment after the last one is fetched too (clamped to the last): no branch around the
+    // prefetch, so the wait before the first use can leave those four loads outstanding
+    const uint64_t n_seg = (s1 - s0) / 64;
+    uint4 qa[4], qb[4];
+    if (n_seg > 0) fetch(qa, s0);
+    for (uint64_t g = 0; g < n_seg; g += 2) {
+        fetch(qb, s0 + 64 * (g + 1 < n_seg ? g + 1 : n_seg - 1));
+        consume(qa, s0 + 64 * g);
+        if (g + 1 >= n_seg) break;
+        fetch(qa, s0 + 64 * (g + 2 < n_seg ? g + 2 : n_seg - 1));
+        consume(qb, s0 + 64 * (g + 1));
+    }
+    s = s0 + 64 * n_seg;
+    for (; s < s1; ++s) {
+        const double wj = weights[s];
+        const uint32_t st = rowp[s];
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) masked_add<KMAX>(acc, i, wj, st);
+    }
+    if (!live) return;
+    const int kv = k[v];
+    double* h = hist + node_off[v];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+        if (i < kv && acc[i] != 0.0) atomicAdd(h + i, acc[i]);
+}
+
+// Any arity: a block walks the nodes, thread = sample (4 per thread), LDS histogram per node.
+__global__ __launch_bounds__(kLwThreads) void lw_hist_wide_kernel(const uint8_t* __restrict__ states,
+                                                                  const double* __restrict__ weights,
+                                                                  const int32_t* __restrict__ k,
+                                                                  const int64_t* __restrict__ node_off,
+                                                                  double* __restrict__ hist, int32_t n,
+                                                                  uint64_t batch, uint64_t n_valid) {
     __shared__ double sh_hist[256];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const uint64_t local0 = uint64_t(blockIdx.x) * kLwBlockSamples + tid;
+    const uint64_t col = (uint64_t(blockIdx.x) * kLwThreads + tid) * kLwPerThread;
     double w[kLwPerThread];
     bool valid[kLwPerThread];
 #pragma unroll
     for (int r = 0; r < kLwPerThread; ++r) {
-        valid[r] = (local0 + uint64_t(r) * kLwThreads) < a.n_valid;
-        w[r] = valid[r] ? a.weights[local0 + uint64_t(r) * kLwThreads] : 0.0;
+        valid[r] = (col + r) < n_valid;
+        w[r] = valid[r] ? weights[col + r] : 0.0;
     }
-
-    for (int v = 0; v < a.n; ++v) {
-        const int kv = a.k[v];
+    for (int v = 0; v < n; ++v) {
+        const int kv = k[v];
         __syncthreads();
         if (tid < kv) sh_hist[tid] = 0.0;
         __syncthreads();
-        double acc8[8];
+        const uint32_t word = *reinterpret_cast<const uint32_t*>(states + uint64_t(v) * batch + col);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc8[i] = 0.0;
-#pragma unroll
-        for (int r = 0; r < kLwPerThread; ++r) {
-            if (!valid[r]) continue;
-            const int st = a.states[uint64_t(v) * a.batch + local0 + uint64_t(r) * kLwThreads];
-            if (kv <= 8) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc8[i] += (i == st) ? w[r] : 0.0;
-            } else {
-                atomicAdd(&sh_hist[st], w[r]);
-            }
-        }
-        if (kv <= 8) {
-            for (int i = 0; i < kv; ++i) {
-                double x = 0.0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) x = (q == i) ? acc8[q] : x;
-                x = wave_sum(x);
-                if (lane == 0 && x != 0.0) atomicAdd(&sh_hist[i], x);
-            }
-        }
+        for (int r = 0; r < kLwPerThread; ++r)
+            if (valid[r] && w[r] != 0.0) atomicAdd(&sh_hist[(word >> (8 * r)) & 0xffu], w[r]);
         __syncthreads();
         if (tid < kv) {
             const double x = sh_hist[tid];
-            if (x != 0.0) atomicAdd(&a.hist[a.node_off[v] + tid], x);
+            if (x != 0.0) atomicAdd(&hist[node_off[v] + tid], x);
         }
     }
 }
 
 int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    hipLaunchKernelGGL(lw_sample_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
+#define BN_LW_LAUNCH(R24, INL)                                                                                    \
+    hipLaunchKernelGGL((lw_sample_kernel<R24, INL>), dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream,       \
+                       reinterpret_cast<const LwStepWords*>(a.steps), reinterpret_cast<const uint4*>(a.parents),   \
+                       a.ev_topo, a.cpt, a.states, a.weights, a.n, a.batch, a.sample_base, a.seed, a.mode)
+    if (a.rows24 && a.inline_parents) BN_LW_LAUNCH(true, true);
+    else if (a.rows24) BN_LW_LAUNCH(true, false);
+    else if (a.inline_parents) BN_LW_LAUNCH(false, true);
+    else BN_LW_LAUNCH(false, false);
+#undef BN_LW_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }
+
 int launch_lw_hist(const LwArgs& a, int blocks, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    hipLaunchKernelGGL(lw_hist_kernel, dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.kmax > 8) {
+        hipLaunchKernelGGL(lw_hist_wide_kernel, dim3(blocks), dim3(kLwThreads), 0, st, a.states, a.weights, a.k,
+                           a.node_off, a.hist, a.n, a.batch, a.n_valid);
+    } else if (a.n_valid > 0) {
+        // enough (node block, sample range) pairs to fill the chip; ranges are multiples of 1024
+        const unsigned xb = unsigned((a.n + kLwThreads - 1) / kLwThreads);
+        uint64_t ranges = (4096 + xb - 1) / xb;
+        uint64_t range = (a.n_valid + ranges - 1) / ranges;
+        range = (range + 1023) / 1024 * 1024;
+        const unsigned yb = unsigned((a.n_valid + range - 1) / range);
+        const dim3 grid(xb, yb);
+        if (a.kmax <= 2)
+            hipLaunchKernelGGL(lw_hist_kernel<2>, grid, dim3(kLwThreads), 0, st, a.states, a.weights, a.k, a.node_off,
+                               a.hist, a.n, a.batch, a.n_valid, range);
+        else if (a.kmax <= 4)
+            hipLaunchKernelGGL(lw_hist_kernel<4>, grid, dim3(kLwThreads), 0, st, a.states, a.weights, a.k, a.node_off,
+                               a.hist, a.n, a.batch, a.n_valid, range);
+        else
+            hipLaunchKernelGGL(lw_hist_kernel<8>, grid, dim3(kLwThreads), 0, st, a.states, a.weights, a.k, a.node_off,
+                               a.hist, a.n, a.batch, a.n_valid, range);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }

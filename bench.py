@@ -79,7 +79,8 @@ def bench_lw(a, local_rank, torch):
                                   f"{a.samples} samples per step (BASELINE.json configs[4])",
                       "node_samples_per_s": rate * d.n},
            "roofline": {"bound": "hbm", "achieved": rate * bytes_per_sample / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": rate * bytes_per_sample / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "lw_kernel"}}
+                        "frac": rate * bytes_per_sample / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "lw_sample_kernel + lw_hist_kernel",
+                        "note": "informational: the sampler is VALU/latency-bound (DESIGN.md section 4), not HBM-bound"}}
     if not a.no_cpu:
         import oracle
         t0 = time.perf_counter()

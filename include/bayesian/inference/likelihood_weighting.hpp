@@ -6,7 +6,8 @@
 //
 // Sampling runs in the HIP kernel behind bn_lw_run.  The reference seeds an mt19937 from
 // std::random_device (:224-244), so its stream is not reproducible by design; this functor draws
-// its seed the same way once, then walks a Philox4x32-10 stream -- successive calls continue it.
+// its seed the same way once, then numbers its samples consecutively (each sample id owns a Philox-seeded xoshiro128++ stream) --
+// successive calls continue the numbering.
 #ifndef BNI_INFERENCE_LIKELIHOOD_WEIGHTING_HPP
 #define BNI_INFERENCE_LIKELIHOOD_WEIGHTING_HPP
 

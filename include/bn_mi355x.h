@@ -148,8 +148,8 @@ int bn_bp_last_stats(bn_engine *eng, bn_bp_stats *out);
  * Replaces: likelihood_weighting::operator()(evidence, sample_num) (likelihood_weighting.hpp:28-59).
  * Returns the UN-normalised weighted histogram [sum k] (node-major) of samples
  * [sample_begin, sample_begin + n_samples) so that several GPUs / calls can be summed; the
- * caller applies the reference's normalise rule (:197-221).  The stream is Philox4x32-10 keyed
- * by `seed` (the reference seeds an mt19937 from std::random_device, :224-244).
+ * caller applies the reference's normalise rule (:197-221).  Every sample id owns one
+ * xoshiro128++ stream seeded by a Philox4x32-10 block keyed by (`seed`, sample id) (the reference seeds an mt19937 from std::random_device, :224-244).
  */
 int bn_lw_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
               uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double *hist_out);

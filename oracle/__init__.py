@@ -80,7 +80,7 @@ def bp_run(model, evidence=None, eps: float = 0.001, max_sweeps: int = 0, thread
 
 
 def lw_run(model, ev_state, n_samples: int, seed: int, s_begin: int = 0, topo=None, states_cap: int = 0):
-    """Restated LW with the repository's Philox stream.  Returns dict(hist[, states, weights])."""
+    """Restated LW with the repository's random stream (Philox-seeded xoshiro128++ per sample).  Returns dict(hist[, states, weights])."""
     L = lib()
     n = model.n
     topo = np.arange(n, dtype=np.int32) if topo is None else np.ascontiguousarray(topo, dtype=np.int32)
@@ -160,6 +160,22 @@ def philox(ctr, key):
     o = (ctypes.c_uint32 * 4)()
     lib().oracle_philox4x32_10(c, k, o)
     return list(o)
+
+
+def xoshiro128pp(state, n: int):
+    """n 32-bit outputs of xoshiro128++ from `state` (4 words); returns (outputs, final state)."""
+    L = lib()
+    L.oracle_xoshiro128pp_next.restype = ctypes.c_uint32
+    x = (ctypes.c_uint32 * 4)(*state)
+    out = [int(L.oracle_xoshiro128pp_next(x)) for _ in range(n)]
+    return out, list(x)
+
+
+def lw_uniform(seed: int, sample: int, position: int) -> float:
+    """u(sample, position) of the sampler's stream (see lw_oracle.c)."""
+    L = lib()
+    L.oracle_lw_uniform.restype = ctypes.c_double
+    return float(L.oracle_lw_uniform(ctypes.c_uint64(seed), ctypes.c_uint64(sample), ctypes.c_uint32(position)))
 
 
 # ---- the real reference (only where /root/reference exists) -------------------------

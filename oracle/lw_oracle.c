@@ -13,10 +13,13 @@
  * What is NOT the reference's: the random stream.  The reference draws from an mt19937
  * seeded by std::random_device (:224-244) -- non-deterministic by design, so no bitwise
  * parity exists even reference-vs-reference.  This repository's sampler (oracle and HIP
- * kernel alike) uses the counter-based Philox4x32-10 generator (Salmon et al., SC'11):
- *   u(sample s, topological position t) = words [2(t&1), 2(t&1)+1] of
- *       philox4x32_10(counter = {s_lo, s_hi, t>>1, 0}, key = {seed_lo, seed_hi})
- *   u = ((hi<<32 | lo) >> 11) * 2^-53
+ * kernel alike) gives every sample its own xoshiro128++ stream (Blackman & Vigna 2019),
+ * seeded by one block of the counter-based Philox4x32-10 generator (Salmon et al., SC'11):
+ *   state(sample s) = philox4x32_10(counter = {s_lo, s_hi, 0, 0}, key = {seed_lo, seed_hi})
+ *                     (an all-zero state, which xoshiro cannot leave, becomes {1,0,0,0})
+ *   at every topological position t = 0, 1, ... (evidence node or not) the stream yields
+ *   lo = next(), hi = next();   u(s, t) = ((hi<<32 | lo) >> 11) * 2^-53
+ * so u(s, t) depends on (seed, s, t) only -- not on the evidence set, the batch or the GPU --
  * which makes sampled STATES bit-reproducible between this file and the HIP kernel.
  * Parity with the reference itself is statistical (tests/golden holds the reference's
  * 1e5-sample marginals under a reseeded mt19937 plus exact BP marginals on polytrees).
@@ -48,13 +51,38 @@ void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-static double uniform_at(uint64_t seed, uint64_t s, uint32_t t) {
-    uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), t >> 1, 0u};
+/* xoshiro128++ 1.0 (Blackman & Vigna), 32-bit output, state x[4]. */
+static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+uint32_t oracle_xoshiro128pp_next(uint32_t x[4]) {
+    uint32_t result = rotl32(x[0] + x[3], 7) + x[0];
+    uint32_t t = x[1] << 9;
+    x[2] ^= x[0]; x[3] ^= x[1]; x[1] ^= x[2]; x[0] ^= x[3];
+    x[2] ^= t;
+    x[3] = rotl32(x[3], 11);
+    return result;
+}
+
+static void stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]) {
+    uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), 0u, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    uint32_t o[4];
-    oracle_philox4x32_10(ctr, key, o);
-    uint64_t x = ((uint64_t)o[2 * (t & 1) + 1] << 32) | o[2 * (t & 1)];
-    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+    oracle_philox4x32_10(ctr, key, x);
+    if ((x[0] | x[1] | x[2] | x[3]) == 0) x[0] = 1;
+}
+
+static double stream_uniform(uint32_t x[4]) {
+    uint32_t lo = oracle_xoshiro128pp_next(x);
+    uint32_t hi = oracle_xoshiro128pp_next(x);
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* the uniform of (sample s, position t): test hook */
+double oracle_lw_uniform(uint64_t seed, uint64_t s, uint32_t t) {
+    uint32_t x[4];
+    stream_seed(seed, s, x);
+    double u = 0;
+    for (uint32_t i = 0; i <= t; ++i) u = stream_uniform(x);
+    return u;
 }
 
 /* likelihood_weighting.hpp:177-193 */
@@ -87,8 +115,11 @@ int oracle_lw_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
     for (uint64_t si = 0; si < n_samples; ++si) {
         uint64_t s = s_begin + si;
         double w = 1.0; /* :124 */
+        uint32_t rng[4];
+        stream_seed(seed, s, rng);
         for (int t = 0; t < n; ++t) {
             int v = topo[t];
+            double u = stream_uniform(rng); /* drawn at every position */
             int64_t row = 0; /* parent assignment -> CPT row, first parent most significant */
             for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + state[in_idx[e]];
             const double *r = cpt + cpt_off[v] + row * k[v];
@@ -96,7 +127,7 @@ int oracle_lw_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
                 w *= r[ev_state[v]];
                 state[v] = ev_state[v];
             } else { /* :154-158 */
-                state[v] = pick_state(uniform_at(seed, s, (uint32_t)t), r, k[v]);
+                state[v] = pick_state(u, r, k[v]);
             }
         }
         for (int v = 0; v < n; ++v) hist[node_off[v] + state[v]] += w; /* :45-49 */
@@ -122,7 +153,7 @@ void oracle_lw_normalize(double *h, int k) {
  * nodes too -- is sampled (choice_pattern, :115-167), a sample counts only when it agrees with
  * every condition (:70-84), sampling goes on until n_accept samples were accepted (:93-111;
  * bounded here by max_draw), and the marginals are plain counts over the accepted samples
- * (:40-58).  Same Philox stream and topological walk as oracle_lw_run, so the accepted set is
+ * (:40-58).  Same random stream and topological walk as oracle_lw_run, so the accepted set is
  * bit-identical to the HIP path's.  counts must be zeroed by the caller.
  */
 int oracle_rs_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t *in_idx,
@@ -138,11 +169,14 @@ int oracle_rs_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
     while (accepted < n_accept && drawn < max_draw) {
         uint64_t s = s_begin + drawn;
         int ok = 1;
+        uint32_t rng[4];
+        stream_seed(seed, s, rng);
         for (int t = 0; t < n; ++t) {
             int v = topo[t];
+            double u = stream_uniform(rng);
             int64_t row = 0;
             for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + state[in_idx[e]];
-            state[v] = pick_state(uniform_at(seed, s, (uint32_t)t), cpt + cpt_off[v] + row * k[v], k[v]);
+            state[v] = pick_state(u, cpt + cpt_off[v] + row * k[v], k[v]);
             if (ev_state[v] >= 0 && state[v] != ev_state[v]) ok = 0;
         }
         ++drawn;

@@ -1,7 +1,7 @@
 """GPU parity of likelihood weighting (likelihood_weighting.hpp) through the C ABI.
 
 Integer work (sampled states) must be bit-identical to the oracle, which shares the kernel's
-Philox4x32-10 stream; weights and histograms agree to fp64 summation order (1e-9 relative).
+Philox-seeded xoshiro128++ streams; weights and histograms agree to fp64 summation order (1e-9 relative).
 Against the reference itself parity is statistical: its engine is seeded from
 std::random_device (:224-244), so the golden holds a reseeded 1e5-sample run and exact marginals."""
 import numpy as np

@@ -67,6 +67,35 @@ def test_philox_known_answers(oracle_mod):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def test_sampler_stream_definition(oracle_mod):
+    """The sampler's stream, restated independently in Python: xoshiro128++ 1.0 (Blackman & Vigna)
+    seeded per sample by philox4x32_10({s_lo, s_hi, 0, 0}, {seed_lo, seed_hi}); two 32-bit outputs
+    (low word first) per topological position; u = (64 bits >> 11) * 2^-53."""
+    M = 0xffffffff
+    rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M
+
+    def nxt(s):
+        result = (rotl((s[0] + s[3]) & M, 7) + s[0]) & M
+        t = (s[1] << 9) & M
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = rotl(s[3], 11)
+        return result
+
+    st = [1, 2, 3, 4]
+    mine = [nxt(st) for _ in range(50)]
+    outs, final = oracle_mod.xoshiro128pp([1, 2, 3, 4], 50)
+    assert outs == mine and final == st
+    assert mine[:2] == [641, 1573767]            # by hand: rotl(1+4,7)+1 ; second from the updated state
+    for seed, sample in [(0, 0), (1234, 77), (2 ** 63 + 5, 2 ** 40 + 3)]:
+        st = oracle_mod.philox([sample & M, sample >> 32, 0, 0], [seed & M, seed >> 32])
+        for pos in range(6):
+            lo, hi = nxt(st), nxt(st)
+            u = float(((hi << 32) | lo) >> 11) * 2.0 ** -53
+            if pos in (0, 3, 5):
+                assert oracle_mod.lw_uniform(seed, sample, pos) == u
+
+
 def test_dsc_parser_matches_reference_loader():
     """tests/golden/alarm_shaped.dsc parsed by bayesiannetwork_amd.dsc equals what the reference's own
     serializer::dsc (dsc.hpp:71) + this repo's flatten produced (golden bp_alarm_shaped.npz)."""
