@@ -7,7 +7,10 @@
 
 namespace bnmi {
 
-constexpr int kBlockThreads = 256;
+#ifndef BN_BLOCK_THREADS
+#define BN_BLOCK_THREADS 256
+#endif
+constexpr int kBlockThreads = BN_BLOCK_THREADS;  // 8 tile waves per CU at 242 VGPRs whatever the block size
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
 
 // Device-resident control block of one BP run.

@@ -880,14 +880,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a)
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (__hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    // `done` and the tile descriptor are fetched together: one round trip, not two, heads the chain
+    const int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int tile = logical_block() * kWavesPerBlock + wave;
     if (tile >= b.n_tiles) {
-        if (tile == a.book_tile) sweep_bookkeeping(a, lane);
+        if (done == 0 && tile == a.book_tile) sweep_bookkeeping(a, lane);
         return;
     }
     const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
     const TileDesc td = b.tiles[tile];
+    if (done != 0) return;
     double wres = 0.0;
     bool handled = false;
     if (td.variant == kVariantUniform) {
