@@ -111,6 +111,27 @@ def cpu_reference_small():
                                            "bn::inference::belief_propagation unmodified, 1 thread"}
 
 
+def measured_stream_gbs(torch):
+    """Achievable HBM rate on this box (report against the nominal peak AND a measured
+    stream figure): device-to-device copy of 1 GiB (read + write), best of 5, outside the timed region."""
+    try:
+        n = 1 << 27  # doubles
+        src = torch.ones(n, dtype=torch.float64, device="cuda")
+        dst = torch.empty_like(src)
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src)
+            e1.record()
+            e1.synchronize()
+            best = max(best, 2 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del src, dst
+        return best
+    except Exception:  # noqa: BLE001 - informational only
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,7 +205,8 @@ def main():
                      "traffic_source": traffic[1] if traffic else None,
                      "kernel": "bp_sweep_kernel", "avg_launch_us": avg_launch_s * 1e6,
                      "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"],
-                     "layout_bytes_per_launch": st["layout_bytes_per_sweep"]},
+                     "layout_bytes_per_launch": st["layout_bytes_per_sweep"],
+                     "hbm_stream_gbs_measured": measured_stream_gbs(torch)},
         "sweep_only_msgs_per_s": g.messages_per_sweep() / avg_launch_s,
     }
     if not a.no_cpu:
