@@ -69,6 +69,7 @@ struct FinishArgs {
     int32_t ne;           // evidence marks to clear once the run is over
     const int32_t* ev_node;
     const struct PersistSync* psync;  // persistent run: status to fold into Ctl (else nullptr)
+    Ctl* host_ctl;        // pinned host copy of Ctl, written by the kernel itself (no D2H copy command)
 };
 
 struct EvidenceArgs {

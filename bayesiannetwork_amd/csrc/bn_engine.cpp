@@ -105,6 +105,7 @@ struct bn_engine {
     bool nontemporal = false;
     // persistent dataflow path (bn_persist.hip)
     bool persist_ok = false;        // model eligible and everything resident at once
+    bool timing = true;             // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms)
     bool persist_enabled = false;   // opt-in (measured slower): BN_PERSISTENT=1 / bn_set_option; cleared after an abort
     int32_t* d_nbr_ptr = nullptr;
     int32_t* d_nbr_idx = nullptr;
@@ -113,6 +114,7 @@ struct bn_engine {
     int grid_persist = 0;
     int32_t last_path = 0;          // 0 per-sweep launches, 1 persistent
     Ctl* h_ctl = nullptr;  // pinned
+    Ctl* h_ctl_dev = nullptr;  // the same memory as the device sees it
     // run state
     int32_t res_cap = 1 << 16;
     int32_t predicted_sweeps = 0;
@@ -178,6 +180,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     *out = nullptr;
     bn_engine* e = new (std::nothrow) bn_engine();
     if (!e) return fail(BN_ERR_ALLOC, "out of host memory");
+    if (const char* t = std::getenv("BN_TIMING")) e->timing = std::atoi(t) != 0;
     std::string err;
     try {
         err = build_plan(*desc, shard, e->plan);
@@ -239,7 +242,9 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         if ((r = dalloc(&e->d_ctl, 1))) return r;
         if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
         HIPCHK(hipMemsetAsync(e->d_beliefs, 0, std::max<size_t>(p.node_off[p.n], 1) * 8, e->stream));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocMapped));
+        std::memset(e->h_ctl, 0, sizeof(Ctl));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ctl_dev), e->h_ctl, 0));
         // persistent dataflow path: every tile register-resident (tile_uniform shapes, <= 4 children,
         // no remote parents) and all tiles co-resident -- 8 waves per CU at <= 256 VGPRs
         {
@@ -422,9 +427,10 @@ static int step_exchange(bn_engine* e, int32_t sweep) {
 }
 
 static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps, const PersistSync* psync = nullptr) {
-    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->ev_ne, e->d_ev_node, psync};
+    // the lead thread writes the outcome straight into the pinned host Ctl: visible after the stream
+    // synchronises, no copy command in between
+    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->ev_ne, e->d_ev_node, psync, e->h_ctl_dev};
     if (launch_bp_finish(fa, e->grid_tiles, e->stream)) return fail(BN_ERR_HIP, "bp_finish launch failed");
-    HIPCHK(hipMemcpyAsync(e->h_ctl, e->d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, e->stream));
     return BN_OK;
 }
 
@@ -512,13 +518,13 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     for (;;) {
         if (max_sweeps > 0) batch = std::min(batch, max_sweeps - launched);
         if ((rc = ensure_events(e, 2 * size_t(batches + 1)))) return rc;
-        HIPCHK(hipEventRecord(e->events[2 * batches], s));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[2 * batches], s));
         for (int32_t i = 0; i < batch; ++i) {
             if ((rc = step_sweep(e, launched + i, eps))) return rc;
             if ((rc = step_exchange(e, launched + i))) return rc;
         }
         launched += batch;
-        HIPCHK(hipEventRecord(e->events[2 * batches + 1], s));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[2 * batches + 1], s));
         ++batches;
         if ((rc = step_finish(e, launched, max_sweeps > 0 && launched >= max_sweeps, eps))) return rc;
         HIPCHK(hipStreamSynchronize(s));
@@ -527,7 +533,7 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     }
     note_run_result(e);
     float ms = 0.f;
-    for (int32_t i = 0; i < batches; ++i) {
+    for (int32_t i = 0; e->timing && i < batches; ++i) {
         float t = 0.f;
         HIPCHK(hipEventElapsedTime(&t, e->events[2 * i], e->events[2 * i + 1]));
         ms += t;
@@ -541,10 +547,12 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     return BN_OK;
 }
 
-// Engine options: "persistent" = 0/1 (use the one-launch dataflow path when the model is eligible).
+// Engine options: "persistent" = 0/1 (use the one-launch dataflow path when the model is eligible);
+// "timing" = 1/0 (HIP events around the sweep launches; off: sweep_kernel_ms reads 0).
 extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (!e || !name) return fail(BN_ERR_ARG, "null argument");
     if (std::strcmp(name, "persistent") == 0) { e->persist_enabled = value != 0; return BN_OK; }
+    if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
 // 1 when the last run used the persistent kernel, 0 per-sweep launches; <0 error

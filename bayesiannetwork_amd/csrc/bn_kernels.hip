@@ -963,7 +963,11 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int n_sweeps;
     if (a.psync) {  // persistent run: the kernel settled everything itself; report how it ended
-        if (lead) { b.ctl->p_abort = a.psync->abort; b.ctl->p_conv = a.psync->conv; }
+        if (lead) {
+            b.ctl->p_abort = a.psync->abort; b.ctl->p_conv = a.psync->conv;
+            a.host_ctl->p_abort = a.psync->abort; a.host_ctl->p_conv = a.psync->conv;
+            a.host_ctl->done = done; a.host_ctl->n_sweeps = b.ctl->n_sweeps; a.host_ctl->last_res = b.ctl->last_res;
+        }
         if (done == 0 || a.psync->abort != 0) {  // it gave up: the host reruns with per-sweep launches
             const int gid0 = blockIdx.x * blockDim.x + threadIdx.x;
             for (int j = gid0; j < a.ne; j += gridDim.x * blockDim.x) {
@@ -976,6 +980,7 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     }
     if (done != 0) {
         n_sweeps = b.ctl->n_sweeps;
+        if (lead && !a.psync) { a.host_ctl->last_res = b.ctl->last_res; a.host_ctl->n_sweeps = n_sweeps; a.host_ctl->done = done; }
     } else {
         // sweep (launched-1) wrote buffer (launched & 1)
         const double r = reduce_residual(b, (a.sweeps_launched & 1) ? b.rec1 : b.rec0, lane);
@@ -983,7 +988,10 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
         n_sweeps = a.sweeps_launched;
         if (r < a.eps) done = 1;
         else if (a.final_batch) done = 2;
-        if (lead) { b.ctl->last_res = r; b.ctl->n_sweeps = n_sweeps; b.ctl->done = done; }
+        if (lead) {
+            b.ctl->last_res = r; b.ctl->n_sweeps = n_sweeps; b.ctl->done = done;
+            a.host_ctl->last_res = r; a.host_ctl->n_sweeps = n_sweeps; a.host_ctl->done = done;
+        }
     }
     if (done == 0) return;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;

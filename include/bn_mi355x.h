@@ -120,7 +120,9 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * launch that keeps the CPTs in registers and synchronises tiles through neighbour flags
  * (bn_persist.hip); otherwise, or after the kernel gave up a wait, one launch per sweep.  Default 0:
  * the persistent path is bit-identical but measured slower on MI355X (BN_PERSISTENT=1 in the
- * environment turns it on).  bn_bp_last_path: 1 persistent, 0 per-sweep. */
+ * environment turns it on).  bn_bp_last_path: 1 persistent, 0 per-sweep.
+ * "timing" 1/0 -- HIP events around every batch of sweep launches (bn_bp_stats.sweep_kernel_ms);
+ * default 1, BN_TIMING=0 in the environment turns it off (sweep_kernel_ms then reads 0). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 
