@@ -265,18 +265,26 @@ __device__ __forceinline__ double parent_role_regs(const BpBuffers& b, const IO&
             bn_store<NT>(&nout[(H + h) * npt], z);
         }
     }
+    // pi-message to child c (:202-218): pi(v) * the OTHER children's lambda-messages, ascending.
+    // The factors before c are a running prefix shared by all later children (same multiplication
+    // sequence as starting over from pi(v)); children past cmax hold 1.0 and are skipped (x * 1.0 == x).
+    double pre[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) pre[i] = piv[i];
 #pragma unroll
     for (int c = 0; c < RC; ++c) {
         if (c < td.cmax) {  // wave-uniform
             double u[K];
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                double acc = piv[i];
+            for (int i = 0; i < K; ++i) u[i] = pre[i];
 #pragma unroll
-                for (int x = 0; x < RC; ++x)
-                    if (x != c) acc *= lkc[x][i];
-                u[i] = acc;
-            }
+            for (int x = c + 1; x < RC; ++x)
+                if (x < td.cmax) {
+#pragma unroll
+                    for (int i = 0; i < K; ++i) u[i] *= lkc[x][i];
+                }
+#pragma unroll
+            for (int i = 0; i < K; ++i) pre[i] *= lkc[c][i];
             normalize_k<K>(u);
             const Loc l = decode_ref(oref[c], H);
             if (l.has) {
@@ -718,6 +726,84 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
             lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
         }
     }
+    // ---- parent role (:202-238), spread over the group's lanes: lane g serves children g, g+G, ...
+    // of node nl.  It needs only the OLD pi(v)/lambda(v) and the children's records, so its loads
+    // ride behind the CPT stream and its arithmetic is cmax steps for the whole group instead of
+    // cmax^2 on one lane.  Every product keeps the reference's ascending-child order.
+    constexpr int CPL = G >= 16 ? 1 : 2;  // children per lane
+    const bool par_fast = td.cmax <= G * CPL;
+    if (par_fast) {
+        const MsgRef* orf = b.out_refs + td.out_base + nlc;
+        Loc cl[CPL];
+        double clk[CPL][K], cold[CPL][K];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            const int c = g + q * G;
+            MsgRef r{-1, 0};
+            if (active && c < td.cmax) r = orf[int64_t(c) * NPT];
+            cl[q] = decode_ref(r, H);
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) { clk[q][i] = 1.0; cold[q][i] = 1.0; }
+            if (!io.first) {  // a missing child reads record 0 and contributes 1.0
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t y = rec_in2[cl[q].lam + h * cl[q].stride];
+                    const double2_t x = rec_in2[cl[q].pi + h * cl[q].stride];
+                    clk[q][2 * h] = cl[q].has ? y.x : 1.0; clk[q][2 * h + 1] = cl[q].has ? y.y : 1.0;
+                    cold[q][2 * h] = x.x; cold[q][2 * h + 1] = x.y;
+                }
+            }
+        }
+        double lam_all[K], msg[CPL][K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            lam_all[i] = 1.0;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) msg[q][i] = piv[i];
+        }
+        for (int x = 0; x < td.cmax; ++x) {  // ascending child order; wave-uniform trip count
+            const int qx = x / G, src = nl * G + (x % G);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                double mine = clk[0][i];
+#pragma unroll
+                for (int q = 1; q < CPL; ++q) mine = (qx == q) ? clk[q][i] : mine;
+                const double val = shfl_d(mine, src);
+                lam_all[i] *= val;
+#pragma unroll
+                for (int q = 0; q < CPL; ++q)
+                    if (g + q * G != x) msg[q][i] *= val;
+            }
+        }
+        if (active && g == 0) {  // lambda(v) (:220-238)
+            normalize_k<K>(lam_all);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                double2_t z;
+                z.x = frozen ? lav[2 * h] : lam_all[2 * h];
+                z.y = frozen ? lav[2 * h + 1] : lam_all[2 * h + 1];
+                bn_store<NT>(&nout[(H + h) * NPT], z);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            if (active && cl[q].has) {
+                normalize_k<K>(msg[q]);
+#pragma unroll
+                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(msg[q][i] - cold[q][i]));
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    double2_t y;
+                    y.x = msg[q][2 * h]; y.y = msg[q][2 * h + 1];
+                    bn_store<NT>(&rec_out2[cl[q].pi + h * cl[q].stride], y);
+                }
+            }
+        }
+    }
+
     // pi-message entries of the lane-fixed parents
     double pfix[D];
 #pragma unroll
@@ -833,7 +919,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 #pragma unroll
             for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }
         }
-        wres = res_acc(wres, parent_role_any<K, NT, 12>(b, io, td, nl, frozen, piv, lav));
+        if (!par_fast) wres = res_acc(wres, parent_role_any<K, NT, 12>(b, io, td, nl, frozen, piv, lav));
     }
     return wres;
 }
