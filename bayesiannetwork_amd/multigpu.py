@@ -66,7 +66,19 @@ def _timed_runs(eng, eps, steps, warmup, dist, torch):
 def bench_main(a, rank: int, world: int, local_rank: int) -> None:
     """bench.py --gpus N (N > 1): BASELINE.json configs[3] -- the SAME 316x316 grid cut into N row
     stripes (strong scaling) -- plus, as an extra key, the weak-scaling variant (316 rows per GPU)."""
+    import threading
     import torch
+    # a collective that never completes (a rank lost, RCCL unable to bring up a link) must not hang
+    # the box: give up loudly after BN_BENCH_WATCHDOG_S seconds
+    limit = float(os.environ.get("BN_BENCH_WATCHDOG_S", "600"))
+
+    def _give_up():
+        print(f"[bench] rank {rank}: multi-GPU bench exceeded {limit:.0f} s -- aborting", flush=True)
+        os._exit(124)
+
+    dog = threading.Timer(limit, _give_up)
+    dog.daemon = True
+    dog.start()
     dist = init_control_plane()
     torch.cuda.set_device(local_rank)
     out = None
@@ -111,3 +123,4 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.barrier()
+    dog.cancel()
