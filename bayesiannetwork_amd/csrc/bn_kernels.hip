@@ -153,7 +153,7 @@ __device__ __forceinline__ int64_t lidx(const Loc& l, int i) { return (l.lam + i
 // children per node than it keeps in registers.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const IO& io, const TileDesc& td, int kv, int kvp,
-                                                     int nl, bool frozen) {
+                                                     int nl, bool frozen, bool flat_cpt = false) {
     const int npt = td.npt, half = kvp >> 1;
     const double* node_in = io.node_in + td.node_base;
     double* node_out = io.node_out + td.node_base;
@@ -163,7 +163,9 @@ __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const 
     auto LK = [&](const Loc& l, int i) { return io.first ? 1.0 : io.rec_in[lidx(l, i)]; };
     auto PIV = [&](int i) {
         if (!synth) return node_in[vidx(0, i, npt, nl)];
-        return td.m == 0 ? b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)] : 1.0;  // :58-64
+        if (td.m != 0) return 1.0;
+        // a root starts from its CPT row (:58-64); flat tiles keep entry i in lane i, slot 0
+        return flat_cpt ? b.cpt[td.cpt_base + int64_t(i) * 2] : b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)];
     };
     double wres = 0.0;
     // lambda(v): product of the children's lambda-messages from 1.0, ascending child order (:229-235)
@@ -924,6 +926,263 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
     return wres;
 }
 
+// ---------------------------------------------------------------------------------------------
+// flat tile: ANY arities, one wavefront per node (NPT = 1).  Entry e of the reference's row-major
+// CPT (parent assignment slowest, own state fastest) sits in lane e % 64, slot e / 64.  Vectors
+// live spread over the lanes: lane x of `pim` / `out` is element x of the in-edge messages
+// concatenated in parent order, lane i of piv / lav / pin is element i of the node vectors.
+//   S <= 128 entries: every term is staged in LDS and each accumulator lane adds its own terms in
+//     the reference's order (own state outer, assignment inner, :174-200, :240-266) -- bit-identical
+//     to the reference wherever the reference is deterministic (<= 2 parents);
+//   larger tables: LDS fp64 atomics (sum re-associated, agrees to rounding).
+// Products always keep the reference's ascending parent / child order.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFlatW = 128;    // doubles per wave: staged terms (S <= 128) or the accumulators
+constexpr int kFlatLK = 256;   // doubles per wave: the children's lambda-messages (parent role)
+constexpr int kFlatLds = kFlatW + kFlatLK;
+
+__device__ __forceinline__ double readlane_d(double x, int src) {  // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+template <bool NT>
+__device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& c,
+                                            int lane, double* lds) {
+    constexpr int MM = kFlatMaxParents;
+    double* W = lds;
+    double* LK = lds + kFlatW;
+    const int kv = c.kv, m = c.m, rows = c.rows, kvp = c.kvp;
+    const int S = kv * rows;
+    const bool frozen = b.frozen[td.slot_base] != 0;
+    double wres = 0.0;
+
+    // ---- node vectors (old), lane i < kv
+    const double* nin = io.node_in + td.node_base;
+    double* nout = io.node_out + td.node_base;
+    double piv = 1.0, lav = 1.0;
+    if (lane < kv && (!io.first || frozen)) { piv = nin[lane]; lav = nin[kvp + lane]; }
+    else if (lane < kv && m == 0) piv = b.cpt[td.cpt_base + lane * 2];  // a root starts from its CPT row (:58-64)
+
+    // ---- in-edge records: lane x <-> (parent j, state d), x = offs[j] + d
+    int offs[MM + 1];
+    int myj = -1;
+    int64_t my_pi = 0, my_lam = 0;  // doubles from the start of a record buffer
+    {
+        int off = 0;
+#pragma unroll
+        for (int j = 0; j < MM; ++j) {
+            offs[j] = off;
+            if (j < m) {
+                const int kj = c.kp[j], hj = c.kpp[j] / 2;
+                Loc l;
+                if (td.in_ref_base >= 0) {
+                    l = decode_ref(b.in_refs[td.in_ref_base + j], hj);
+                } else {
+                    l.has = true; l.pi = (td.rec_base + c.rec_off[j]) / 2; l.lam = l.pi + hj; l.stride = 1;
+                }
+                if (lane >= off && lane < off + kj) {
+                    const int dd = lane - off;
+                    myj = j;
+                    my_pi = (l.pi + int64_t(dd >> 1) * l.stride) * 2 + (dd & 1);
+                    my_lam = (l.lam + int64_t(dd >> 1) * l.stride) * 2 + (dd & 1);
+                }
+                off += kj;
+            }
+        }
+        offs[MM] = off;
+    }
+    const int sumk = offs[MM];
+    double pim = 1.0, oldlam = 1.0;
+    if (myj >= 0 && !io.first) { pim = io.rec_in[my_pi]; oldlam = io.rec_in[my_lam]; }
+
+    // digits, factors and CPT value of entry e (all lanes take part in the shuffles)
+    auto entry = [&](int e, bool valid, double cval, double (&pj)[MM], int (&dj)[MM], int& ei, double& li, double& cv) {
+        const int ee = valid ? e : 0;
+        ei = ee % kv;
+        int cond = ee / kv;
+#pragma unroll
+        for (int j = MM - 1; j >= 0; --j) {
+            dj[j] = 0; pj[j] = 1.0;
+            if (j < m) {
+                dj[j] = cond % c.kp[j];
+                cond /= c.kp[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MM; ++j)
+            if (j < m) pj[j] = shfl_d(pim, offs[j] + dj[j]);
+        li = shfl_d(lav, ei);
+        cv = valid ? cval : 0.0;
+    };
+    const double* cp = b.cpt + td.cpt_base + lane * 2;
+    double outl = 0.0;  // lane x: un-normalised lambda-message element x (concatenated)
+    double pin = 0.0;   // lane i: un-normalised pi(v)[i]
+
+    if (S <= kFlatW) {
+        // ---- ordered path: at most two entries per lane
+        double pj[2][MM], li[2], cv[2];
+        int dj[2][MM], ei[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int e = lane + kWave * t;
+            const bool valid = e < S;
+            const double cval = valid ? cp[t] : 0.0;
+            entry(e, valid, cval, pj[t], dj[t], ei[t], li[t], cv[t]);
+        }
+        // calculate_pi (:174-200): cpt * pi-messages (ascending parents), summed over assignments ascending
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            double v = cv[t];
+#pragma unroll
+            for (int j = 0; j < MM; ++j)
+                if (j < m) v *= pj[t][j];
+            W[lane + kWave * t] = v;
+        }
+        wave_lds_fence();
+        if (lane < kv) {
+            double acc = 0.0;
+            for (int cond = 0; cond < rows; ++cond) acc += W[cond * kv + lane];
+            pin = acc;
+        }
+        wave_lds_fence();
+        // calculate_lambda_k (:240-266) per target parent: (lambda[i] * cpt) * the OTHER parents'
+        // pi-messages; bucket s of parent jt receives its terms own state outer, assignment inner
+#pragma unroll
+        for (int jt = 0; jt < MM; ++jt) {
+            if (jt < m) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    double w = li[t] * cv[t];
+#pragma unroll
+                    for (int j = 0; j < MM; ++j)
+                        if (j < m && j != jt) w *= pj[t][j];
+                    W[lane + kWave * t] = w;
+                }
+                wave_lds_fence();
+                const int kj = c.kp[jt], stride = c.cstride[jt], nhi = rows / (stride * kj);
+                if (lane >= offs[jt] && lane < offs[jt] + kj) {
+                    const int sidx = lane - offs[jt];
+                    double acc = 0.0;
+                    for (int i = 0; i < kv; ++i)
+                        for (int hi = 0; hi < nhi; ++hi)
+                            for (int lo = 0; lo < stride; ++lo) acc += W[((hi * kj + sidx) * stride + lo) * kv + i];
+                    outl = acc;
+                }
+                wave_lds_fence();
+            }
+        }
+    } else {
+        // ---- large table: LDS atomics into [ lambda buckets (sumk) | pi (kv) ]
+        for (int x = lane; x < sumk + kv; x += kWave) W[x] = 0.0;
+        wave_lds_fence();
+        const int T = c.per_lane;
+        for (int t = 0; t < T; ++t) {
+            const int e = lane + kWave * t;
+            const bool valid = e < S;
+            const double cval = valid ? cp[int64_t(t >> 1) * 128 + (t & 1)] : 0.0;
+            double pj[MM], li, cv;
+            int dj[MM], ei;
+            entry(e, valid, cval, pj, dj, ei, li, cv);
+            double v = cv;
+#pragma unroll
+            for (int j = 0; j < MM; ++j)
+                if (j < m) v *= pj[j];
+            if (valid) unsafeAtomicAdd(&W[sumk + ei], v);
+            const double tc = li * cv;
+#pragma unroll
+            for (int jt = 0; jt < MM; ++jt) {
+                if (jt < m) {
+                    double w = tc;
+#pragma unroll
+                    for (int j = 0; j < MM; ++j)
+                        if (j < m && j != jt) w *= pj[j];
+                    if (valid) unsafeAtomicAdd(&W[offs[jt] + dj[jt]], w);
+                }
+            }
+        }
+        wave_lds_fence();
+        if (lane < sumk) outl = W[lane];
+        if (lane < kv) pin = W[sumk + lane];
+        wave_lds_fence();
+    }
+
+    // ---- normalise (:298-311: divide by the plain left-to-right sum), residual (:105-131), stores
+    {
+        double sum = 0.0;
+        for (int i = 0; i < kv; ++i) sum += readlane_d(pin, i);
+        pin /= sum;
+        if (lane < kv) nout[lane] = frozen ? piv : pin;
+        if (lane == kv && kvp > kv) nout[lane] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        if (j < m) {
+            double sum = 0.0;
+            for (int dd = 0; dd < c.kp[j]; ++dd) sum += readlane_d(outl, offs[j] + dd);
+            if (myj == j) outl /= sum;
+        }
+    }
+    if (myj >= 0) {
+        wres = res_acc(wres, fabs(outl - oldlam));
+        io.rec_out[my_lam] = outl;
+    }
+
+    // ---- parent role (:202-238): the children's lambda-messages staged in LDS, element (c, i) at c*kv + i
+    const int cmax = td.cmax;
+    if (cmax * kv <= kFlatLK) {
+        const int total = cmax * kv;
+        const int chunk = (kWave / kv) * kv;  // whole children per pass
+        for (int base = 0; base < total; base += chunk) {
+            const int idx = base + lane;
+            if (lane < chunk && idx < total) {
+                const int cc = idx / kv, ii = idx - cc * kv;
+                const Loc l = decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
+                double val = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
+                if (l.has && !io.first) val = io.rec_in[(l.lam + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1)];
+                LK[idx] = val;
+            }
+        }
+        wave_lds_fence();
+        {   // lambda(v): product of the children's lambda-messages from 1.0, ascending (:220-238)
+            double acc = 1.0;
+            if (lane < kv)
+                for (int x = 0; x < cmax; ++x) acc *= LK[x * kv + lane];
+            double sum = 0.0;
+            for (int i = 0; i < kv; ++i) sum += readlane_d(acc, i);
+            acc /= sum;
+            if (lane < kv) nout[kvp + lane] = frozen ? lav : acc;
+            if (lane == kv && kvp > kv) nout[kvp + lane] = 0.0;
+        }
+        for (int base = 0; base < total; base += chunk) {
+            const int idx = base + lane;
+            const bool mine = lane < chunk && idx < total;
+            const int cc = mine ? idx / kv : 0, ii = mine ? idx - cc * kv : 0;
+            // pi-message to child cc (:202-218): pi(v)[i] * the OTHER children's lambda-messages, ascending
+            double u = shfl_d(piv, ii);
+            for (int x = 0; x < cmax; ++x)
+                if (x != cc) u *= LK[x * kv + ii];
+            double sum = 0.0;
+            for (int dd = 0; dd < kv; ++dd) sum += shfl_d(u, lane - ii + dd);
+            u /= sum;
+            if (mine) {
+                const Loc l = decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
+                if (l.has) {
+                    const int64_t at = (l.pi + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1);
+                    const double old = io.first ? 1.0 : io.rec_in[at];
+                    wres = res_acc(wres, fabs(u - old));
+                    io.rec_out[at] = u;
+                }
+            }
+        }
+    } else if (lane == 0) {
+        wres = res_acc(wres, parent_role_generic(b, io, td, kv, kvp, 0, frozen, true));
+    }
+    return wres;
+}
+
 template <int K, int M, bool NT>
 __device__ __forceinline__ double tile_uniform_dispatch(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
     if (td.in_ref_base >= 0) return tile_uniform<K, M, 0, NT, true>(b, io, td, lane);  // boundary tile
@@ -963,6 +1222,7 @@ __device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) 
 
 template <bool NT>
 __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a) {
+    __shared__ double flat_lds[kWavesPerBlock][kFlatLds];  // flat tiles only: staged terms, children's messages
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1003,6 +1263,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a)
             case 5: wres = tile_group<3, NT>(b, io, td, lane); break;
             default: handled = false; break;
         }
+    }
+    if (td.variant == kVariantFlat) {
+        handled = true;
+        wres = tile_flat<NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]);
     }
     if (!handled) wres = tile_generic(b, io, td, b.classes[td.cls], lane);
     publish_residual(b, a.rec_out, tile, wres, lane);

@@ -142,8 +142,17 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             if (int64_t(c.kv) * rows > 64) uniform = false;  // register-resident CPT: <= 64 entries
             c.G = pick_lanes(c.kv, c.m, all_k4, d.lanes_per_node);
             c.variant = c.G > 1 ? kVariantGroup : (uniform ? kVariantUniform : kVariantGeneric);
+            // every other shape: one wavefront per node (lanes_per_node == 1 keeps the
+            // one-lane-per-node generic path, for A/B tests)
+            int32_t sum_kp = 0;
+            for (int j = 0; j < c.m; ++j) sum_kp += c.kp[j];
+            if (c.variant == kVariantGeneric && d.lanes_per_node != 1 && c.m <= kFlatMaxParents &&
+                sum_kp <= kWave && c.kv <= kWave && int64_t(c.kv) * rows < (int64_t(1) << 22)) {
+                c.variant = kVariantFlat;
+                c.G = kWave;
+            }
             c.npt = kWave / c.G;
-            c.per_lane = int32_t(int64_t(c.kv) * rows / c.G);
+            c.per_lane = int32_t((int64_t(c.kv) * rows + c.G - 1) / c.G);
             c.per_lane_pad = round_even(c.per_lane);
             int32_t off = 0;
             for (int j = 0; j < c.m; ++j) { c.rec_off[j] = off; off += 2 * c.kpp[j] * c.npt; }
@@ -262,6 +271,15 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         const ClassDesc& c = p.classes[p.node_class[v]];
         const TileDesc& td = p.tiles[p.node_tile[v]];
         const double* src = d.cpt + d.cpt_off[v];
+        if (c.variant == kVariantFlat) {  // entry e of the reference's row-major table: lane e % 64, slot e / 64
+            double* dst = p.cpt_striped.data() + td.cpt_base;
+            const int64_t S = int64_t(c.kv) * c.rows;
+            for (int64_t e = 0; e < S; ++e) {
+                const int64_t q = e / kWave, lane = e % kWave;
+                dst[(q >> 1) * 128 + lane * 2 + (q & 1)] = src[e];
+            }
+            continue;
+        }
         const int32_t cpl = c.rows / c.G;  // assignments per lane
         for (int g = 0; g < c.G; ++g) {
             const int lane = p.node_nl[v] * c.G + g;

@@ -6,6 +6,8 @@
 //
 //   tile      = one wavefront's worth of nodes of ONE shape class (same k, same parent arities),
 //               NPT = 64 / G nodes, G = lanes cooperating on one node
+//               (G = 1: register-resident / generic; 4..64: lane groups for k = 4; 64 with the flat
+//               row-major image: any arities, see tile_flat)
 //   CPT       = per tile, i-major (own state slowest, parent assignment fastest) so that one
 //               streaming pass visits entries in the reference's accumulation order for both
 //               calculate_pi (:174-200) and calculate_lambda_k (:240-266); lane (node nl, part g)
@@ -50,7 +52,10 @@ enum Variant : int32_t {
     kVariantGeneric = 0,   // runtime loops, any shape, G = 1
     kVariantUniform = 1,   // templated: node and all parents share k in {2,3,4}, CPT <= 64 entries
     kVariantGroup = 2,     // k = 4, 3..5 parents: G = 4^(m-2) lanes share a node, 64 entries per lane
+    kVariantFlat = 3,      // any arities: one wavefront per node, entry e of the reference's row-major
+                           // CPT in lane e % 64; <= 8 parents, arities summing to <= 64
 };
+constexpr int kFlatMaxParents = 8;
 
 // Device-visible shape class.  POD.
 struct ClassDesc {

@@ -55,7 +55,8 @@ typedef struct bn_model_desc {
     const int64_t *cpt_off; /* [n+1]  prefix sums of k[v] * prod k[parents]            */
     const double *cpt;      /* flat CPTs, reference row order                          */
     int32_t device;         /* HIP ordinal, BN_DEVICE_CURRENT or BN_DEVICE_HOST_ONLY   */
-    int32_t lanes_per_node; /* 0 = automatic; 1,4,16 force the sub-wave group width    */
+    int32_t lanes_per_node; /* 0 = automatic; 1 = one lane per node everywhere (no lane  */
+                            /* groups, no wavefront-per-node variant: A/B tests)      */
 } bn_model_desc;
 
 typedef struct bn_engine bn_engine;
@@ -207,7 +208,8 @@ int bn_layout_get(bn_engine *eng, bn_layout_info *out);
 int bn_layout_edge_refs(bn_engine *eng, int32_t *pi_out, int32_t *lam_out);
 /* node -> lane slot on this rank, -1 for nodes of other ranks, [n] */
 int bn_layout_node_slots(bn_engine *eng, int32_t *slots_out);
-/* per-class: kv, m, lanes_per_node, variant (0 = generic, 1 = register-resident template) */
+/* per-class: kv, m, lanes_per_node, variant (0 = one-lane generic, 1 = register-resident template,
+ * 2 = lane group (k = 4, 3-5 parents), 3 = one wavefront per node, any arities) */
 int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,
                     int32_t *variant, int32_t *n_nodes);
 

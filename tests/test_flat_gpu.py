@@ -1,0 +1,103 @@
+"""The any-arity tile variant (one wavefront per node, `tile_flat`): mixed arities, arities above 4,
+tables above the ordered-path limit, many children, evidence, shards.
+
+Versus the C restatement: bit-identical where the reference's arithmetic order is deterministic
+(every node has <= 2 parents AND <= 128 CPT entries: the ordered path), to rounding otherwise (>= 3
+parents multiply in unordered_map order in the reference itself, and tables above 128 entries are
+accumulated with LDS atomics); the stopping sweep is the same everywhere."""
+import numpy as np
+import pytest
+
+from bayesiannetwork_amd import Evidence, from_parent_lists, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(bnlib):
+    from bayesiannetwork_amd.engine import Engine
+    return Engine
+
+
+def variants(eng):
+    return sorted({c["variant"] for c in eng.layout_classes()})
+
+
+def star(n_children, k_root, k_child, seed):
+    """One root with many children (parent role beyond the staged 256 doubles when n*k > 256)."""
+    rng = np.random.default_rng(seed)
+    parents = [[]] + [[0] for _ in range(n_children)]
+    ks = [k_root] + [k_child] * n_children
+    cpts = []
+    for v, ps in enumerate(parents):
+        rows = int(np.prod([ks[p] for p in ps])) if ps else 1
+        t = 0.1 + 0.9 * rng.random((rows, ks[v]))
+        cpts.append(t / t.sum(axis=1, keepdims=True))
+    return from_parent_lists(ks, parents, cpts)
+
+
+CASES = [
+    # name, model factory, exact (bit-identical to the oracle expected)
+    ("mixed_le2", lambda: synth.random_dag(300, 2, 24, [2, 3, 4, 5, 3, 2, 4], seed=31), True),
+    ("k5_le2", lambda: synth.random_dag(200, 2, 16, 5, seed=32), True),       # 5*25 = 125 entries: ordered path
+    ("k7_le2", lambda: synth.random_dag(120, 2, 16, 7, seed=33), False),      # 343 entries: atomics
+    ("mixed_le4", lambda: synth.random_dag(400, 4, 32, [2, 3, 4, 3, 2, 4, 4], seed=34), False),
+    ("k3_le5", lambda: synth.random_dag(300, 5, 32, 3, seed=35), False),      # up to 729 entries
+    ("k2_le8", lambda: synth.random_dag(300, 8, 32, 2, seed=36), False),      # 8 parents: the variant's limit
+    ("k9_le1", lambda: synth.random_dag(150, 1, 16, 9, seed=37), True),
+    ("star_small", lambda: star(40, 5, 3, seed=38), True),                   # 40 * 5 = 200 staged doubles
+    ("star_big", lambda: star(120, 3, 5, seed=39), True),                    # 360 > 256: memory fallback
+]
+
+
+@pytest.mark.parametrize("name,make,exact", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("frac,eps", [(0.0, 1e-3), (0.1, 1e-7)])
+def test_flat_variant_matches_oracle(Engine, oracle_mod, name, make, exact, frac, eps):
+    m = make()
+    ev = synth.random_evidence(m, frac, seed=5) if frac else Evidence.none()
+    want = oracle_mod.bp_run(m, ev, eps=eps, dump_msgs=True)
+    with Engine(m) as eng:
+        assert 3 in variants(eng), "the case is meant to exercise the flat variant"
+        got = eng.bp_run(ev, eps)
+        res = eng.bp_residuals()
+        pi, lam = eng.bp_messages()
+    assert got["sweeps"] == want["sweeps"]
+    if exact:
+        assert np.array_equal(got["beliefs"], want["beliefs"], equal_nan=True)
+        assert np.array_equal(res, want["residuals"])
+        assert np.array_equal(pi, want["pi_msg"], equal_nan=True) and np.array_equal(lam, want["lambda_msg"], equal_nan=True)
+    else:
+        assert np.allclose(got["beliefs"], want["beliefs"], rtol=1e-11, atol=1e-14)
+        assert np.allclose(res, want["residuals"], rtol=1e-8, atol=1e-15)
+        assert np.allclose(pi, want["pi_msg"], rtol=1e-11, atol=1e-14) and np.allclose(lam, want["lambda_msg"], rtol=1e-11, atol=1e-14)
+
+
+def test_flat_equals_one_lane_generic_path(Engine):
+    """lanes_per_node = 1 keeps the old one-lane-per-node generic path: same sweeps, same marginals."""
+    m = synth.random_dag(250, 3, 24, [2, 3, 4, 5], seed=41)
+    ev = synth.random_evidence(m, 0.05, seed=6)
+    with Engine(m) as a, Engine(m, lanes_per_node=1) as b:
+        assert 3 in variants(a) and 3 not in variants(b)
+        ra, rb = a.bp_run(ev, 1e-6), b.bp_run(ev, 1e-6)
+    assert ra["sweeps"] == rb["sweeps"]
+    assert np.allclose(ra["beliefs"], rb["beliefs"], rtol=1e-11, atol=1e-14)
+
+
+def test_flat_tiles_in_shards(Engine):
+    """Flat tiles with parents on another rank (in-edge references into the exchange region)."""
+    from bayesiannetwork_amd.engine import run_shards_on_one_device
+    m = synth.random_dag(240, 3, 40, [2, 3, 5, 4], seed=43)
+    ev = synth.random_evidence(m, 0.05, seed=7)
+    with Engine(m) as one:
+        want = one.bp_run(ev, 1e-6)
+    for nranks in (2, 3):
+        owner = (np.arange(m.n) * nranks // m.n).astype(np.int32)
+        engines = [Engine(m, rank=r, nranks=nranks, owner=owner) for r in range(nranks)]
+        try:
+            got = run_shards_on_one_device(engines, ev, 1e-6)
+            bel = sum(e.bp_beliefs() for e in engines)  # zeros for nodes of other ranks
+        finally:
+            for e in engines:
+                e.close()
+        assert got["sweeps"] == want["sweeps"]
+        assert np.array_equal(bel, want["beliefs"], equal_nan=True)

@@ -162,3 +162,27 @@ def test_sampler_mirror_loads_tables_and_files(tmp_path):
     assert smp.sampling_size() == 10 and smp.table() == {(0, 1, 1, 0): 5, (0, 0, 1, 1): 5}
     smp.set_filename(str(tmp_path / "missing.txt"))
     assert smp.load_sample([0, 1, 2, 3]) is False                                  # :46
+
+
+def test_any_arity_shapes_get_one_wavefront_per_node():
+    """Shapes without a register-resident instantiation (mixed arities, arity > 4, > 64 CPT entries)
+    are laid out for the flat variant: 64 lanes per node, one node per tile; lanes_per_node = 1 keeps
+    the one-lane-per-node generic path; more than 8 parents stays generic."""
+    from bayesiannetwork_amd import _lib
+    from bayesiannetwork_amd.engine import Engine
+    m = synth.random_dag(120, 3, 16, [2, 3, 5, 4], seed=3)
+    with Engine(m, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        cls = e.layout_classes()
+        assert any(c["variant"] == 3 for c in cls) and not any(c["variant"] == 0 for c in cls)
+        for c in cls:
+            if c["variant"] == 3:
+                assert c["lanes_per_node"] == 64
+        flat_nodes = sum(c["n_nodes"] for c in cls if c["variant"] == 3)
+        other_tiles = sum(-(-c["n_nodes"] // (64 // c["lanes_per_node"])) for c in cls if c["variant"] != 3)
+        assert e.layout()["n_tiles"] == flat_nodes + other_tiles
+    with Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, lanes_per_node=1) as e:
+        assert not any(c["variant"] in (2, 3) for c in e.layout_classes())
+    big = synth.random_dag(40, 10, 20, 2, seed=4)   # up to 10 parents
+    with Engine(big, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        for c in e.layout_classes():
+            assert (c["variant"] == 0) == (c["m"] > 8) or c["variant"] in (1, 2)
