@@ -124,3 +124,46 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
         print(json.dumps(out), flush=True)
     dist.barrier()
     dog.cancel()
+
+
+def bench_lw_main(a, rank: int, world: int, local_rank: int) -> None:
+    """bench.py --workload lw --gpus N: BASELINE.json configs[4] -- every GPU draws its share of the
+    samples (disjoint sample ids = disjoint streams), ONE RCCL all-reduce sums the histograms.
+    Weak scaling: a.samples per GPU and step."""
+    import threading
+    import torch
+    limit = float(os.environ.get("BN_BENCH_WATCHDOG_S", "600"))
+    dog = threading.Timer(limit, lambda: (print(f"[bench] rank {rank}: exceeded {limit:.0f} s", flush=True), os._exit(124)))
+    dog.daemon = True
+    dog.start()
+    dist = init_control_plane()
+    torch.cuda.set_device(local_rank)
+    d = synth.random_dag(10000, 4, 64, 4, seed=1)
+    ev = synth.random_evidence(d, a.evidence, seed=7).hard_states(d)
+    eng = make_shard(d, rank, world, local_rank)
+    total = a.samples * world
+    for w in range(max(a.warmup, 1)):
+        eng.lw_run_allreduce(ev, total, seed=1, sample_begin=w * total)
+    torch.cuda.synchronize()
+    dist.barrier()
+    steps = max(1, min(a.steps, 10))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.lw_run_allreduce(ev, total, seed=1, sample_begin=(i + a.warmup) * total)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        rate = total * steps / float(dt[0])
+        print(json.dumps({
+            "metric": "weighted samples/sec (likelihood weighting)", "value": rate, "unit": "samples/s",
+            "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": float(dt[0]) / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
+                                   f"{a.samples} samples per GPU and step (BASELINE.json configs[4])",
+                       "parallelism": f"sample ranges x{world}, one RCCL all-reduce of {int(d.k.sum())} doubles per step",
+                       "node_samples_per_s": rate * d.n}}), flush=True)
+    eng.close()
+    dist.barrier()
+    dog.cancel()

@@ -161,6 +161,8 @@ def main():
 
     if world > 1 or os.environ.get("BN_FORCE_MULTI"):
         from bayesiannetwork_amd import multigpu
+        if a.workload == "lw":
+            return multigpu.bench_lw_main(a, rank, world, local_rank)
         return multigpu.bench_main(a, rank, world, local_rank)
 
     torch.cuda.set_device(local_rank)
