@@ -934,7 +934,9 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 //   S <= 128 entries: every term is staged in LDS and each accumulator lane adds its own terms in
 //     the reference's order (own state outer, assignment inner, :174-200, :240-266) -- bit-identical
 //     to the reference wherever the reference is deterministic (<= 2 parents);
-//   larger tables: LDS fp64 atomics (sum re-associated, agrees to rounding).
+//   larger tables: LDS fp64 atomics (sum re-associated, agrees to rounding).  (Tried: the ordered
+//     scheme for up to 1024 entries, re-deriving the factors in every pass -- 1.5x slower than the
+//     atomics at 243 and 625 entries.)
 // Products always keep the reference's ascending parent / child order.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFlatW = 128;    // doubles per wave: staged terms (S <= 128) or the accumulators
@@ -949,11 +951,20 @@ __device__ __forceinline__ double readlane_d(double x, int src) {  // src wave-u
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 template <bool NT>
-__device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& c,
+__device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& cg,
                                             int lane, double* lds) {
     constexpr int MM = kFlatMaxParents;
     double* W = lds;
     double* LK = lds + kFlatW;
+    // the class fields used below, copied once into (scalar) registers: the wave-scope fences
+    // between the LDS phases would otherwise make every later use a fresh load
+    struct {
+        int kv, m, rows, kvp, per_lane;
+        int kp[MM], kpp[MM], rec_off[MM], cstride[MM];
+    } c;
+    c.kv = cg.kv; c.m = cg.m; c.rows = cg.rows; c.kvp = cg.kvp; c.per_lane = cg.per_lane;
+#pragma unroll
+    for (int j = 0; j < MM; ++j) { c.kp[j] = cg.kp[j]; c.kpp[j] = cg.kpp[j]; c.rec_off[j] = cg.rec_off[j]; c.cstride[j] = cg.cstride[j]; }
     const int kv = c.kv, m = c.m, rows = c.rows, kvp = c.kvp;
     const int S = kv * rows;
     const bool frozen = b.frozen[td.slot_base] != 0;
@@ -965,6 +976,26 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     double piv = 1.0, lav = 1.0;
     if (lane < kv && (!io.first || frozen)) { piv = nin[lane]; lav = nin[kvp + lane]; }
     else if (lane < kv && m == 0) piv = b.cpt[td.cpt_base + lane * 2];  // a root starts from its CPT row (:58-64)
+
+    // ---- parent role, first pass: child (c, i) <-> lane c*kv + i.  Its reference, lambda-message
+    // element and previous pi-message element are requested now, so that these two dependent round
+    // trips overlap with the child role below instead of following it.
+    const int cmax = td.cmax;
+    const int ptotal = cmax * kv;
+    const int pchunk = (kWave / kv) * kv;  // whole children per pass
+    const bool pstaged = ptotal <= kFlatLK;
+    int pc0 = 0, pi0 = 0;
+    Loc pl0;
+    pl0.has = false; pl0.pi = 0; pl0.lam = 0; pl0.stride = 0;
+    double plk0 = 1.0, pold0 = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
+    if (pstaged && lane < pchunk && lane < ptotal) {
+        pc0 = lane / kv; pi0 = lane - pc0 * kv;
+        pl0 = decode_ref(b.out_refs[td.out_base + pc0], kvp / 2);
+        if (pl0.has && !io.first) {
+            plk0 = io.rec_in[(pl0.lam + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
+            pold0 = io.rec_in[(pl0.pi + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
+        }
+    }
 
     // ---- in-edge records: lane x <-> (parent j, state d), x = offs[j] + d
     int offs[MM + 1];
@@ -999,16 +1030,19 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     if (myj >= 0 && !io.first) { pim = io.rec_in[my_pi]; oldlam = io.rec_in[my_lam]; }
 
     // digits, factors and CPT value of entry e (all lanes take part in the shuffles)
-    auto entry = [&](int e, bool valid, double cval, double (&pj)[MM], int (&dj)[MM], int& ei, double& li, double& cv) {
+    auto entry = [&](int e, bool valid, double cval, double (&pj)[MM], int (&dj)[MM], int& ei, int& econd, double& li,
+                     double& cv) {
         const int ee = valid ? e : 0;
-        ei = ee % kv;
         int cond = ee / kv;
+        ei = ee - cond * kv;
+        econd = cond;
 #pragma unroll
         for (int j = MM - 1; j >= 0; --j) {
             dj[j] = 0; pj[j] = 1.0;
             if (j < m) {
-                dj[j] = cond % c.kp[j];
-                cond /= c.kp[j];
+                const int q = cond / c.kp[j];
+                dj[j] = cond - q * c.kp[j];
+                cond = q;
             }
         }
 #pragma unroll
@@ -1022,15 +1056,18 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     double pin = 0.0;   // lane i: un-normalised pi(v)[i]
 
     if (S <= kFlatW) {
-        // ---- ordered path: at most two entries per lane
+        // ---- ordered path: at most two entries per lane.  Every term is written to LDS at the
+        // position it has in ITS accumulator's summation order, so each accumulator lane then adds
+        // one contiguous run front to back (reads pipelined, additions strictly in the reference's order).
         double pj[2][MM], li[2], cv[2];
-        int dj[2][MM], ei[2];
+        int dj[2][MM], ei[2], ec[2];
+        bool ok[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int e = lane + kWave * t;
-            const bool valid = e < S;
-            const double cval = valid ? cp[t] : 0.0;
-            entry(e, valid, cval, pj[t], dj[t], ei[t], li[t], cv[t]);
+            ok[t] = e < S;
+            const double cval = ok[t] ? cp[t] : 0.0;
+            entry(e, ok[t], cval, pj[t], dj[t], ei[t], ec[t], li[t], cv[t]);
         }
         // calculate_pi (:174-200): cpt * pi-messages (ascending parents), summed over assignments ascending
 #pragma unroll
@@ -1039,12 +1076,14 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
 #pragma unroll
             for (int j = 0; j < MM; ++j)
                 if (j < m) v *= pj[t][j];
-            W[lane + kWave * t] = v;
+            if (ok[t]) W[ei[t] * rows + ec[t]] = v;
         }
         wave_lds_fence();
         if (lane < kv) {
+            const double* run = W + lane * rows;
             double acc = 0.0;
-            for (int cond = 0; cond < rows; ++cond) acc += W[cond * kv + lane];
+#pragma unroll 8
+            for (int r = 0; r < rows; ++r) acc += run[r];
             pin = acc;
         }
         wave_lds_fence();
@@ -1053,22 +1092,27 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
 #pragma unroll
         for (int jt = 0; jt < MM; ++jt) {
             if (jt < m) {
+                const int kj = c.kp[jt], per_state = rows / kj;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     double w = li[t] * cv[t];
 #pragma unroll
                     for (int j = 0; j < MM; ++j)
                         if (j < m && j != jt) w *= pj[t][j];
-                    W[lane + kWave * t] = w;
+                    // rank inside the bucket = i * (rows / kj) + (assignment with digit jt removed)
+                    int rest = 0;
+#pragma unroll
+                    for (int j = 0; j < MM; ++j)
+                        if (j < m && j != jt) rest += dj[t][j] * (j < jt ? c.cstride[j] / kj : c.cstride[j]);
+                    if (ok[t]) W[dj[t][jt] * (kv * per_state) + ei[t] * per_state + rest] = w;
                 }
                 wave_lds_fence();
-                const int kj = c.kp[jt], stride = c.cstride[jt], nhi = rows / (stride * kj);
                 if (lane >= offs[jt] && lane < offs[jt] + kj) {
-                    const int sidx = lane - offs[jt];
+                    const int R = kv * per_state;
+                    const double* run = W + (lane - offs[jt]) * R;
                     double acc = 0.0;
-                    for (int i = 0; i < kv; ++i)
-                        for (int hi = 0; hi < nhi; ++hi)
-                            for (int lo = 0; lo < stride; ++lo) acc += W[((hi * kj + sidx) * stride + lo) * kv + i];
+#pragma unroll 8
+                    for (int r = 0; r < R; ++r) acc += run[r];
                     outl = acc;
                 }
                 wave_lds_fence();
@@ -1079,13 +1123,57 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
         for (int x = lane; x < sumk + kv; x += kWave) W[x] = 0.0;
         wave_lds_fence();
         const int T = c.per_lane;
+        double cvals[4] = {0.0, 0.0, 0.0, 0.0};
+        // digits of this lane's entry, advanced by 64 per step with carries (one set of divisions
+        // per tile instead of one per entry): own state fastest, last parent next, first parent slowest
+        int inc_i, inc_j[MM], cur_i, cur_j[MM];
+        {
+            int q = kWave, e0 = lane;
+            inc_i = q % kv; q /= kv;
+            cur_i = e0 % kv; e0 /= kv;
+#pragma unroll
+            for (int j = MM - 1; j >= 0; --j) {
+                inc_j[j] = 0; cur_j[j] = 0;
+                if (j < m) {
+                    inc_j[j] = q % c.kp[j]; q /= c.kp[j];
+                    cur_j[j] = e0 % c.kp[j]; e0 /= c.kp[j];
+                }
+            }
+        }
         for (int t = 0; t < T; ++t) {
+            if ((t & 3) == 0) {  // the CPT values of four entries are requested together
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = t + q;
+                    cvals[q] = (tq < T && lane + kWave * tq < S) ? cp[int64_t(tq >> 1) * 128 + (tq & 1)] : 0.0;
+                }
+            }
             const int e = lane + kWave * t;
             const bool valid = e < S;
-            const double cval = valid ? cp[int64_t(t >> 1) * 128 + (t & 1)] : 0.0;
+            const double cval = (t & 3) == 0 ? cvals[0] : ((t & 3) == 1 ? cvals[1] : ((t & 3) == 2 ? cvals[2] : cvals[3]));
             double pj[MM], li, cv;
             int dj[MM], ei;
-            entry(e, valid, cval, pj, dj, ei, li, cv);
+            ei = valid ? cur_i : 0;
+#pragma unroll
+            for (int j = 0; j < MM; ++j) {
+                dj[j] = valid ? cur_j[j] : 0;
+                pj[j] = 1.0;
+                if (j < m) pj[j] = shfl_d(pim, offs[j] + dj[j]);
+            }
+            li = shfl_d(lav, ei);
+            cv = valid ? cval : 0.0;
+            {   // e += 64 in mixed radix
+                int x = cur_i + inc_i;
+                int carry = x >= kv ? 1 : 0;
+                cur_i = x - (carry ? kv : 0);
+#pragma unroll
+                for (int j = MM - 1; j >= 0; --j)
+                    if (j < m) {
+                        x = cur_j[j] + inc_j[j] + carry;
+                        carry = x >= c.kp[j] ? 1 : 0;
+                        cur_j[j] = x - (carry ? c.kp[j] : 0);
+                    }
+            }
             double v = cv;
 #pragma unroll
             for (int j = 0; j < MM; ++j)
@@ -1131,16 +1219,15 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     }
 
     // ---- parent role (:202-238): the children's lambda-messages staged in LDS, element (c, i) at c*kv + i
-    const int cmax = td.cmax;
-    if (cmax * kv <= kFlatLK) {
-        const int total = cmax * kv;
-        const int chunk = (kWave / kv) * kv;  // whole children per pass
-        for (int base = 0; base < total; base += chunk) {
+    if (pstaged) {
+        const int total = ptotal, chunk = pchunk;
+        if (lane < chunk && lane < total) LK[lane] = plk0;
+        for (int base = chunk; base < total; base += chunk) {
             const int idx = base + lane;
             if (lane < chunk && idx < total) {
                 const int cc = idx / kv, ii = idx - cc * kv;
                 const Loc l = decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
-                double val = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
+                double val = 1.0;
                 if (l.has && !io.first) val = io.rec_in[(l.lam + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1)];
                 LK[idx] = val;
             }
@@ -1168,10 +1255,10 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
             for (int dd = 0; dd < kv; ++dd) sum += shfl_d(u, lane - ii + dd);
             u /= sum;
             if (mine) {
-                const Loc l = decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
+                const Loc l = base == 0 ? pl0 : decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
                 if (l.has) {
                     const int64_t at = (l.pi + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1);
-                    const double old = io.first ? 1.0 : io.rec_in[at];
+                    const double old = io.first ? 1.0 : (base == 0 ? pold0 : io.rec_in[at]);
                     wres = res_acc(wres, fabs(u - old));
                     io.rec_out[at] = u;
                 }
