@@ -939,7 +939,9 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 //     atomics at 243 and 625 entries.)
 // Products always keep the reference's ascending parent / child order.
 // ---------------------------------------------------------------------------------------------
-constexpr int kFlatW = 128;    // doubles per wave: staged terms (S <= 128) or the accumulators
+constexpr int kFlatOrdered = 128;  // tables up to this many entries take the ordered path
+constexpr int kFlatCopies = 8;     // atomics path: accumulator copies (lane & 7), fewer same-address conflicts
+constexpr int kFlatW = 128 * kFlatCopies;  // doubles per wave: staged terms or the accumulator copies
 constexpr int kFlatLK = 256;   // doubles per wave: the children's lambda-messages (parent role)
 constexpr int kFlatLds = kFlatW + kFlatLK;
 
@@ -1055,7 +1057,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     double outl = 0.0;  // lane x: un-normalised lambda-message element x (concatenated)
     double pin = 0.0;   // lane i: un-normalised pi(v)[i]
 
-    if (S <= kFlatW) {
+    if (S <= kFlatOrdered) {
         // ---- ordered path: at most two entries per lane.  Every term is written to LDS at the
         // position it has in ITS accumulator's summation order, so each accumulator lane then adds
         // one contiguous run front to back (reads pipelined, additions strictly in the reference's order).
@@ -1120,8 +1122,10 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
         }
     } else {
         // ---- large table: LDS atomics into [ lambda buckets (sumk) | pi (kv) ]
-        for (int x = lane; x < sumk + kv; x += kWave) W[x] = 0.0;
+        const int nacc = sumk + kv;  // <= 128
+        for (int x = lane; x < nacc * kFlatCopies; x += kWave) W[x] = 0.0;
         wave_lds_fence();
+        double* Wc = W + (lane & (kFlatCopies - 1)) * nacc;  // this lane's accumulator copy
         const int T = c.per_lane;
         double cvals[4] = {0.0, 0.0, 0.0, 0.0};
         // digits of this lane's entry, advanced by 64 per step with carries (one set of divisions
@@ -1178,7 +1182,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
 #pragma unroll
             for (int j = 0; j < MM; ++j)
                 if (j < m) v *= pj[j];
-            if (valid) unsafeAtomicAdd(&W[sumk + ei], v);
+            if (valid) unsafeAtomicAdd(&Wc[sumk + ei], v);
             const double tc = li * cv;
 #pragma unroll
             for (int jt = 0; jt < MM; ++jt) {
@@ -1187,13 +1191,23 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
 #pragma unroll
                     for (int j = 0; j < MM; ++j)
                         if (j < m && j != jt) w *= pj[j];
-                    if (valid) unsafeAtomicAdd(&W[offs[jt] + dj[jt]], w);
+                    if (valid) unsafeAtomicAdd(&Wc[offs[jt] + dj[jt]], w);
                 }
             }
         }
         wave_lds_fence();
-        if (lane < sumk) outl = W[lane];
-        if (lane < kv) pin = W[sumk + lane];
+        if (lane < sumk) {
+            double acc = W[lane];
+#pragma unroll
+            for (int q = 1; q < kFlatCopies; ++q) acc += W[q * nacc + lane];
+            outl = acc;
+        }
+        if (lane < kv) {
+            double acc = W[sumk + lane];
+#pragma unroll
+            for (int q = 1; q < kFlatCopies; ++q) acc += W[q * nacc + sumk + lane];
+            pin = acc;
+        }
         wave_lds_fence();
     }
 
