@@ -101,3 +101,39 @@ def test_flat_tiles_in_shards(Engine):
                 e.close()
         assert got["sweeps"] == want["sweeps"]
         assert np.array_equal(bel, want["beliefs"], equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_match_oracle(Engine, oracle_mod, seed):
+    """Small random networks with arities 1..7 (arity 1 included), 0..6 parents, random hard and
+    soft evidence: same stopping sweep, marginals to rounding (bit-identical when no node has more
+    than two parents and no table exceeds the ordered path's 128 entries)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(5, 60))
+    maxp = int(rng.integers(1, 7))
+    ks = [int(x) for x in rng.integers(1, 8, size=n)]
+    parents, cpts = [], []
+    for v in range(n):
+        m = int(rng.integers(0, min(maxp, v) + 1))
+        ps = sorted(rng.choice(v, size=m, replace=False).tolist()) if m else []
+        while ps and ks[v] * int(np.prod([ks[p] for p in ps])) > 20000:
+            ps.pop()
+        parents.append(ps)
+        rows = int(np.prod([ks[p] for p in ps])) if ps else 1
+        t = 0.05 + rng.random((rows, ks[v]))
+        cpts.append(t / t.sum(axis=1, keepdims=True))
+    m = from_parent_lists(ks, parents, cpts)
+    evd = {}
+    for v in rng.choice(n, size=max(1, n // 8), replace=False):
+        v = int(v)
+        evd[v] = int(rng.integers(0, ks[v])) if rng.random() < 0.7 else (0.1 + rng.random(ks[v]))
+    ev = Evidence.from_dict(m, evd)
+    want = oracle_mod.bp_run(m, ev, eps=1e-6, max_sweeps=200)
+    with Engine(m) as eng:
+        got = eng.bp_run(ev, 1e-6, max_sweeps=200)
+    assert got["sweeps"] == want["sweeps"]
+    exact = max(len(p) for p in parents) <= 2 and max(c.size for c in cpts) <= 128
+    if exact:
+        assert np.array_equal(got["beliefs"], want["beliefs"], equal_nan=True)
+    else:
+        assert np.allclose(got["beliefs"], want["beliefs"], rtol=1e-10, atol=1e-13, equal_nan=True)
