@@ -165,7 +165,7 @@ __device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const 
         if (!synth) return node_in[vidx(0, i, npt, nl)];
         if (td.m != 0) return 1.0;
         // a root starts from its CPT row (:58-64); flat tiles keep entry i in lane i, slot 0
-        return flat_cpt ? b.cpt[td.cpt_base + int64_t(i) * 2] : b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)];
+        return flat_cpt ? b.cpt[td.cpt_base + (int64_t(nl) * (kWave / npt) + i) * 2] : b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)];
     };
     double wres = 0.0;
     // lambda(v): product of the children's lambda-messages from 1.0, ascending child order (:229-235)
@@ -952,12 +952,23 @@ __device__ __forceinline__ double readlane_d(double x, int src) {  // src wave-u
 }
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-template <bool NT>
+// G lanes per node (NPT = 64 / G nodes per wave): G < 64 only for tables of at most 2 G entries
+// whose vectors fit G lanes (the ordered path); every "lane" below is then a lane of the node's group.
+template <int G, bool NT>
 __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& cg,
-                                            int lane, double* lds) {
+                                            int wlane, double* lds) {
     constexpr int MM = kFlatMaxParents;
-    double* W = lds;
-    double* LK = lds + kFlatW;
+    constexpr int NPT = kWave / G;
+    const int nl = wlane / G, lane = wlane % G, gb = nl * G;  // node of the tile, lane inside its group, first lane
+    const bool active = nl < td.n_nodes;
+    const int nlc = active ? nl : 0;  // idle groups shadow node 0 (they take part in the shuffles, store nothing)
+    double* W = lds + (G == kWave ? 0 : nl * 2 * G);
+    double* LK = lds + kFlatW + nl * (kFlatLK / NPT);
+    // element x of a lane-spread vector of this node's group; x is the same for the whole group
+    auto bcast = [&](double x, int idx) {
+        if constexpr (G == kWave) return readlane_d(x, idx);
+        else return shfl_d(x, gb + idx);
+    };
     // the class fields used below, copied once into (scalar) registers: the wave-scope fences
     // between the LDS phases would otherwise make every later use a fresh load
     struct {
@@ -969,30 +980,32 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     for (int j = 0; j < MM; ++j) { c.kp[j] = cg.kp[j]; c.kpp[j] = cg.kpp[j]; c.rec_off[j] = cg.rec_off[j]; c.cstride[j] = cg.cstride[j]; }
     const int kv = c.kv, m = c.m, rows = c.rows, kvp = c.kvp;
     const int S = kv * rows;
-    const bool frozen = b.frozen[td.slot_base] != 0;
+    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
     double wres = 0.0;
 
     // ---- node vectors (old), lane i < kv
     const double* nin = io.node_in + td.node_base;
     double* nout = io.node_out + td.node_base;
+    // element i of pi(v) / lambda(v) in the tile's striped node block
+    auto nidx = [&](int half, int i) { return int64_t(half + (i >> 1)) * (NPT * 2) + nlc * 2 + (i & 1); };
     double piv = 1.0, lav = 1.0;
-    if (lane < kv && (!io.first || frozen)) { piv = nin[lane]; lav = nin[kvp + lane]; }
-    else if (lane < kv && m == 0) piv = b.cpt[td.cpt_base + lane * 2];  // a root starts from its CPT row (:58-64)
+    if (lane < kv && (!io.first || frozen)) { piv = nin[nidx(0, lane)]; lav = nin[nidx(kvp / 2, lane)]; }
+    else if (lane < kv && m == 0) piv = b.cpt[td.cpt_base + (nlc * G + lane) * 2];  // a root starts from its CPT row (:58-64)
 
     // ---- parent role, first pass: child (c, i) <-> lane c*kv + i.  Its reference, lambda-message
     // element and previous pi-message element are requested now, so that these two dependent round
     // trips overlap with the child role below instead of following it.
     const int cmax = td.cmax;
     const int ptotal = cmax * kv;
-    const int pchunk = (kWave / kv) * kv;  // whole children per pass
-    const bool pstaged = ptotal <= kFlatLK;
+    const int pchunk = (G / kv) * kv;  // whole children per pass
+    const bool pstaged = ptotal <= kFlatLK / NPT;
     int pc0 = 0, pi0 = 0;
     Loc pl0;
     pl0.has = false; pl0.pi = 0; pl0.lam = 0; pl0.stride = 0;
     double plk0 = 1.0, pold0 = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
     if (pstaged && lane < pchunk && lane < ptotal) {
         pc0 = lane / kv; pi0 = lane - pc0 * kv;
-        pl0 = decode_ref(b.out_refs[td.out_base + pc0], kvp / 2);
+        pl0 = decode_ref(b.out_refs[td.out_base + int64_t(pc0) * NPT + nlc], kvp / 2);
         if (pl0.has && !io.first) {
             plk0 = io.rec_in[(pl0.lam + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
             pold0 = io.rec_in[(pl0.pi + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
@@ -1012,9 +1025,9 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
                 const int kj = c.kp[j], hj = c.kpp[j] / 2;
                 Loc l;
                 if (td.in_ref_base >= 0) {
-                    l = decode_ref(b.in_refs[td.in_ref_base + j], hj);
+                    l = decode_ref(b.in_refs[td.in_ref_base + j * NPT + nlc], hj);
                 } else {
-                    l.has = true; l.pi = (td.rec_base + c.rec_off[j]) / 2; l.lam = l.pi + hj; l.stride = 1;
+                    l.has = true; l.pi = (td.rec_base + c.rec_off[j]) / 2 + nlc; l.lam = l.pi + hj * NPT; l.stride = NPT;
                 }
                 if (lane >= off && lane < off + kj) {
                     const int dd = lane - off;
@@ -1049,15 +1062,15 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
         }
 #pragma unroll
         for (int j = 0; j < MM; ++j)
-            if (j < m) pj[j] = shfl_d(pim, offs[j] + dj[j]);
-        li = shfl_d(lav, ei);
+            if (j < m) pj[j] = shfl_d(pim, gb + offs[j] + dj[j]);
+        li = shfl_d(lav, gb + ei);
         cv = valid ? cval : 0.0;
     };
-    const double* cp = b.cpt + td.cpt_base + lane * 2;
+    const double* cp = b.cpt + td.cpt_base + (nlc * G + lane) * 2;
     double outl = 0.0;  // lane x: un-normalised lambda-message element x (concatenated)
     double pin = 0.0;   // lane i: un-normalised pi(v)[i]
 
-    if (S <= kFlatOrdered) {
+    if (G < kWave || S <= kFlatOrdered) {
         // ---- ordered path: at most two entries per lane.  Every term is written to LDS at the
         // position it has in ITS accumulator's summation order, so each accumulator lane then adds
         // one contiguous run front to back (reads pipelined, additions strictly in the reference's order).
@@ -1066,7 +1079,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
         bool ok[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int e = lane + kWave * t;
+            const int e = lane + G * t;
             ok[t] = e < S;
             const double cval = ok[t] ? cp[t] : 0.0;
             entry(e, ok[t], cval, pj[t], dj[t], ei[t], ec[t], li[t], cv[t]);
@@ -1162,9 +1175,9 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
             for (int j = 0; j < MM; ++j) {
                 dj[j] = valid ? cur_j[j] : 0;
                 pj[j] = 1.0;
-                if (j < m) pj[j] = shfl_d(pim, offs[j] + dj[j]);
+                if (j < m) pj[j] = shfl_d(pim, gb + offs[j] + dj[j]);
             }
-            li = shfl_d(lav, ei);
+            li = shfl_d(lav, gb + ei);
             cv = valid ? cval : 0.0;
             {   // e += 64 in mixed radix
                 int x = cur_i + inc_i;
@@ -1214,20 +1227,20 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     // ---- normalise (:298-311: divide by the plain left-to-right sum), residual (:105-131), stores
     {
         double sum = 0.0;
-        for (int i = 0; i < kv; ++i) sum += readlane_d(pin, i);
+        for (int i = 0; i < kv; ++i) sum += bcast(pin, i);
         pin /= sum;
-        if (lane < kv) nout[lane] = frozen ? piv : pin;
-        if (lane == kv && kvp > kv) nout[lane] = 0.0;
+        if (active && lane < kv) nout[nidx(0, lane)] = frozen ? piv : pin;
+        if (active && lane == kv && kvp > kv) nout[nidx(0, lane)] = 0.0;
     }
 #pragma unroll
     for (int j = 0; j < MM; ++j) {
         if (j < m) {
             double sum = 0.0;
-            for (int dd = 0; dd < c.kp[j]; ++dd) sum += readlane_d(outl, offs[j] + dd);
+            for (int dd = 0; dd < c.kp[j]; ++dd) sum += bcast(outl, offs[j] + dd);
             if (myj == j) outl /= sum;
         }
     }
-    if (myj >= 0) {
+    if (active && myj >= 0) {
         wres = res_acc(wres, fabs(outl - oldlam));
         io.rec_out[my_lam] = outl;
     }
@@ -1240,7 +1253,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
             const int idx = base + lane;
             if (lane < chunk && idx < total) {
                 const int cc = idx / kv, ii = idx - cc * kv;
-                const Loc l = decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
+                const Loc l = decode_ref(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], kvp / 2);
                 double val = 1.0;
                 if (l.has && !io.first) val = io.rec_in[(l.lam + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1)];
                 LK[idx] = val;
@@ -1252,24 +1265,24 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
             if (lane < kv)
                 for (int x = 0; x < cmax; ++x) acc *= LK[x * kv + lane];
             double sum = 0.0;
-            for (int i = 0; i < kv; ++i) sum += readlane_d(acc, i);
+            for (int i = 0; i < kv; ++i) sum += bcast(acc, i);
             acc /= sum;
-            if (lane < kv) nout[kvp + lane] = frozen ? lav : acc;
-            if (lane == kv && kvp > kv) nout[kvp + lane] = 0.0;
+            if (active && lane < kv) nout[nidx(kvp / 2, lane)] = frozen ? lav : acc;
+            if (active && lane == kv && kvp > kv) nout[nidx(kvp / 2, lane)] = 0.0;
         }
         for (int base = 0; base < total; base += chunk) {
             const int idx = base + lane;
             const bool mine = lane < chunk && idx < total;
             const int cc = mine ? idx / kv : 0, ii = mine ? idx - cc * kv : 0;
             // pi-message to child cc (:202-218): pi(v)[i] * the OTHER children's lambda-messages, ascending
-            double u = shfl_d(piv, ii);
+            double u = shfl_d(piv, gb + ii);
             for (int x = 0; x < cmax; ++x)
                 if (x != cc) u *= LK[x * kv + ii];
             double sum = 0.0;
-            for (int dd = 0; dd < kv; ++dd) sum += shfl_d(u, lane - ii + dd);
+            for (int dd = 0; dd < kv; ++dd) sum += shfl_d(u, gb + lane - ii + dd);
             u /= sum;
-            if (mine) {
-                const Loc l = base == 0 ? pl0 : decode_ref(b.out_refs[td.out_base + cc], kvp / 2);
+            if (mine && active) {
+                const Loc l = base == 0 ? pl0 : decode_ref(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], kvp / 2);
                 if (l.has) {
                     const int64_t at = (l.pi + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1);
                     const double old = io.first ? 1.0 : (base == 0 ? pold0 : io.rec_in[at]);
@@ -1278,8 +1291,8 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
                 }
             }
         }
-    } else if (lane == 0) {
-        wres = res_acc(wres, parent_role_generic(b, io, td, kv, kvp, 0, frozen, true));
+    } else if (lane == 0 && active) {
+        wres = res_acc(wres, parent_role_generic(b, io, td, kv, kvp, nl, frozen, true));
     }
     return wres;
 }
@@ -1367,7 +1380,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a)
     }
     if (td.variant == kVariantFlat) {
         handled = true;
-        wres = tile_flat<NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]);
+        switch (td.npt) {  // 64 / npt lanes per node
+            case 1: wres = tile_flat<64, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+            case 2: wres = tile_flat<32, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+            case 4: wres = tile_flat<16, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+            default: wres = tile_flat<8, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+        }
     }
     if (!handled) wres = tile_generic(b, io, td, b.classes[td.cls], lane);
     publish_residual(b, a.rec_out, tile, wres, lane);

@@ -149,7 +149,11 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             if (c.variant == kVariantGeneric && d.lanes_per_node != 1 && c.m <= kFlatMaxParents &&
                 sum_kp <= kWave && c.kv <= kWave && int64_t(c.kv) * rows < (int64_t(1) << 22)) {
                 c.variant = kVariantFlat;
+                // the smallest group that holds the table at two entries per lane and every vector
+                // in one register across the group; tables above 128 entries: the whole wave
                 c.G = kWave;
+                for (int g = 8; g < kWave; g *= 2)
+                    if (int64_t(c.kv) * rows <= 2 * g && sum_kp <= g && c.kv <= g) { c.G = g; break; }
             }
             c.npt = kWave / c.G;
             c.per_lane = int32_t((int64_t(c.kv) * rows + c.G - 1) / c.G);
@@ -271,11 +275,11 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         const ClassDesc& c = p.classes[p.node_class[v]];
         const TileDesc& td = p.tiles[p.node_tile[v]];
         const double* src = d.cpt + d.cpt_off[v];
-        if (c.variant == kVariantFlat) {  // entry e of the reference's row-major table: lane e % 64, slot e / 64
+        if (c.variant == kVariantFlat) {  // entry e of the reference's row-major table: lane e % G of the node's group, slot e / G
             double* dst = p.cpt_striped.data() + td.cpt_base;
             const int64_t S = int64_t(c.kv) * c.rows;
             for (int64_t e = 0; e < S; ++e) {
-                const int64_t q = e / kWave, lane = e % kWave;
+                const int64_t q = e / c.G, lane = int64_t(p.node_nl[v]) * c.G + e % c.G;
                 dst[(q >> 1) * 128 + lane * 2 + (q & 1)] = src[e];
             }
             continue;

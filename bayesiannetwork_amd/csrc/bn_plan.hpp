@@ -52,8 +52,8 @@ enum Variant : int32_t {
     kVariantGeneric = 0,   // runtime loops, any shape, G = 1
     kVariantUniform = 1,   // templated: node and all parents share k in {2,3,4}, CPT <= 64 entries
     kVariantGroup = 2,     // k = 4, 3..5 parents: G = 4^(m-2) lanes share a node, 64 entries per lane
-    kVariantFlat = 3,      // any arities: one wavefront per node, entry e of the reference's row-major
-                           // CPT in lane e % 64; <= 8 parents, arities summing to <= 64
+    kVariantFlat = 3,      // any arities: G = 8..64 lanes per node, entry e of the reference's row-major
+                           // CPT in lane e % G of the group; <= 8 parents, arities summing to <= 64
 };
 constexpr int kFlatMaxParents = 8;
 
