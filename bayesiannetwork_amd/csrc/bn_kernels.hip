@@ -927,8 +927,9 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// flat tile: ANY arities, one wavefront per node (NPT = 1).  Entry e of the reference's row-major
-// CPT (parent assignment slowest, own state fastest) sits in lane e % 64, slot e / 64.  Vectors
+// flat tile: ANY arities, a group of G = 8..64 lanes per node (NPT = 64 / G nodes per wavefront).
+// Entry e of the reference's row-major CPT (parent assignment slowest, own state fastest) sits in
+// lane e % G of the node's group, slot e / G.  Vectors
 // live spread over the lanes: lane x of `pim` / `out` is element x of the in-edge messages
 // concatenated in parent order, lane i of piv / lav / pin is element i of the node vectors.
 //   S <= 128 entries: every term is staged in LDS and each accumulator lane adds its own terms in

@@ -209,7 +209,7 @@ int bn_layout_edge_refs(bn_engine *eng, int32_t *pi_out, int32_t *lam_out);
 /* node -> lane slot on this rank, -1 for nodes of other ranks, [n] */
 int bn_layout_node_slots(bn_engine *eng, int32_t *slots_out);
 /* per-class: kv, m, lanes_per_node, variant (0 = one-lane generic, 1 = register-resident template,
- * 2 = lane group (k = 4, 3-5 parents), 3 = one wavefront per node, any arities) */
+ * 2 = lane group (k = 4, 3-5 parents), 3 = any arities, a group of 8..64 lanes per node) */
 int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,
                     int32_t *variant, int32_t *n_nodes);
 
