@@ -121,12 +121,33 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         sig.clear();
         sig.push_back(p.k[v]);
         for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) sig.push_back(p.k[p.in_idx[e]]);
+        // flat tiles stage the children's lambda-messages in the group's share of LDS (4 doubles per
+        // lane): a node with many children needs a wider group than its table does, so the width
+        // wanted by the out-degree is part of the class key (ignored by the other variants)
+        int32_t g_children = 0;
+        {
+            const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
+            bool same = kv >= 2 && kv <= 4 && m <= 4;
+            int64_t S = kv, sum_kp = 0;
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+                const int32_t ku = p.k[p.in_idx[e]];
+                if (ku != kv) same = false;
+                S *= ku;
+                sum_kp += ku;
+            }
+            const bool templated = (same && S <= 64) || (same && kv == 4 && m >= 3 && m <= 5 && d.lanes_per_node != 1);
+            if (!templated && d.lanes_per_node != 1 && m <= kFlatMaxParents && sum_kp <= kWave && kv <= kWave) {
+                g_children = 8;
+                while (g_children < kWave && int64_t(out_ptr[v + 1] - out_ptr[v]) * kv > 4 * g_children) g_children *= 2;
+            }
+        }
+        sig.push_back(g_children);
         auto it = sig2cls.find(sig);
         if (it == sig2cls.end()) {
             ClassDesc c;
             std::memset(&c, 0, sizeof c);
             c.kv = sig[0];
-            c.m = int32_t(sig.size()) - 1;
+            c.m = int32_t(sig.size()) - 2;
             c.kvp = round_even(c.kv);
             int64_t rows = 1;
             bool uniform = (c.kv >= 2 && c.kv <= 4 && c.m <= 4);
@@ -154,6 +175,7 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
                 c.G = kWave;
                 for (int g = 8; g < kWave; g *= 2)
                     if (int64_t(c.kv) * rows <= 2 * g && sum_kp <= g && c.kv <= g) { c.G = g; break; }
+                c.G = std::max(c.G, g_children);
             }
             c.npt = kWave / c.G;
             c.per_lane = int32_t((int64_t(c.kv) * rows + c.G - 1) / c.G);
