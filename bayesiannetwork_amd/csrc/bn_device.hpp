@@ -106,7 +106,7 @@ int launch_bp_persistent(const PersistArgs& a, int grid_blocks, void* stream);
 
 // launchers (bn_kernels.hip)
 int launch_bp_begin(const EvidenceArgs& a, void* stream);
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream);
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, void* stream);
 int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream);
 
 }  // namespace bnmi

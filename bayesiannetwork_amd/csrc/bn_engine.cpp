@@ -407,7 +407,9 @@ static int step_sweep(bn_engine* e, int32_t sweep, double eps) {
     const int cur = sweep & 1;
     SweepArgs sa{buffers_of(e), e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, sweep,
                  int32_t(e->plan.tiles.size())};
-    if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, e->stream)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
+    static const bool no_light = std::getenv("BN_NO_LIGHT") != nullptr;  // A/B switch
+    if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, e->plan.light && !no_light, e->stream))
+        return fail(BN_ERR_HIP, "bp_sweep launch failed");
     return BN_OK;
 }
 

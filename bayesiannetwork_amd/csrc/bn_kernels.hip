@@ -1392,6 +1392,37 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a)
     publish_residual(b, a.rec_out, tile, wres, lane);
 }
 
+// The same iteration for networks WITHOUT register-resident tiles (any-arity and one-lane tiles
+// only): those tiles need a third of the registers and are latency-bound, so this instantiation
+// runs at twice the occupancy (4 waves per SIMD).
+__global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepArgs a) {
+    __shared__ double flat_lds[kWavesPerBlock][kFlatLds];
+    const BpBuffers& b = a.b;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int tile = logical_block() * kWavesPerBlock + wave;
+    if (tile >= b.n_tiles) {
+        if (done == 0 && tile == a.book_tile) sweep_bookkeeping(a, lane);
+        return;
+    }
+    const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
+    const TileDesc td = b.tiles[tile];
+    if (done != 0) return;
+    double wres = 0.0;
+    if (td.variant == kVariantFlat) {
+        switch (td.npt) {  // 64 / npt lanes per node
+            case 1: wres = tile_flat<64, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+            case 2: wres = tile_flat<32, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+            case 4: wres = tile_flat<16, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+            default: wres = tile_flat<8, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
+        }
+    } else {
+        wres = tile_generic(b, io, td, b.classes[td.cls], lane);
+    }
+    publish_residual(b, a.rec_out, tile, wres, lane);
+}
+
 // Start of a run: reset the control block and this rank's residual slots in both buffers, then
 // apply the evidence (belief_propagation.hpp:68-73) to the nodes this rank owns: pi(v) =
 // lambda(v) = the given vector in the buffer iteration 0 reads, node marked
@@ -1497,9 +1528,11 @@ int launch_bp_begin(const EvidenceArgs& a, void* stream) {
     hipLaunchKernelGGL(bp_begin_kernel, dim3(blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream) {
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    if (nontemporal)
+    if (light)
+        hipLaunchKernelGGL(bp_sweep_light_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    else if (nontemporal)
         hipLaunchKernelGGL(bp_sweep_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(bp_sweep_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);

@@ -111,6 +111,34 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             }
     }
 
+    // ---- which nodes have a templated variant, which can take the any-arity variant
+    auto shape_of = [&](int32_t v, bool& templated, bool& flat_ok) {
+        const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
+        bool same = kv >= 2 && kv <= 4 && m <= 4;
+        int64_t S = kv, sum_kp = 0;
+        for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+            const int32_t ku = p.k[p.in_idx[e]];
+            if (ku != kv) same = false;
+            S *= ku;
+            sum_kp += ku;
+        }
+        templated = (same && S <= 64) || (same && kv == 4 && m >= 3 && m <= 5 && d.lanes_per_node != 1);
+        flat_ok = d.lanes_per_node != 1 && m <= kFlatMaxParents && sum_kp <= kWave && kv <= kWave && S < (int64_t(1) << 22);
+    };
+    // A network made mostly of any-arity tiles runs them all that way: the launch without
+    // register-resident tiles has twice the occupancy, which is what those latency-bound tiles need.
+    bool prefer_flat = false;
+    if (d.lanes_per_node == 0) {
+        int64_t n_templ = 0, n_flat_only = 0, n_convertible = 0;
+        for (int32_t v = 0; v < n; ++v) {  // the whole model, not this rank's share: every rank decides alike
+            bool t, f;
+            shape_of(v, t, f);
+            if (t) { ++n_templ; if (f) ++n_convertible; }
+            else if (f) ++n_flat_only;
+        }
+        prefer_flat = n_flat_only >= 2 * n_templ && n_convertible == n_templ && n_flat_only > 0;
+    }
+
     // ---- shape classes over the owned nodes
     std::map<std::vector<int32_t>, int32_t> sig2cls;
     p.node_class.assign(n, -1);
@@ -125,21 +153,12 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         // lane): a node with many children needs a wider group than its table does, so the width
         // wanted by the out-degree is part of the class key (ignored by the other variants)
         int32_t g_children = 0;
-        {
-            const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
-            bool same = kv >= 2 && kv <= 4 && m <= 4;
-            int64_t S = kv, sum_kp = 0;
-            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
-                const int32_t ku = p.k[p.in_idx[e]];
-                if (ku != kv) same = false;
-                S *= ku;
-                sum_kp += ku;
-            }
-            const bool templated = (same && S <= 64) || (same && kv == 4 && m >= 3 && m <= 5 && d.lanes_per_node != 1);
-            if (!templated && d.lanes_per_node != 1 && m <= kFlatMaxParents && sum_kp <= kWave && kv <= kWave) {
-                g_children = 8;
-                while (g_children < kWave && int64_t(out_ptr[v + 1] - out_ptr[v]) * kv > 4 * g_children) g_children *= 2;
-            }
+        bool templated, flat_ok;
+        shape_of(v, templated, flat_ok);
+        if (prefer_flat && flat_ok) templated = false;
+        if (!templated && flat_ok) {
+            g_children = 8;
+            while (g_children < kWave && int64_t(out_ptr[v + 1] - out_ptr[v]) * p.k[v] > 4 * g_children) g_children *= 2;
         }
         sig.push_back(g_children);
         auto it = sig2cls.find(sig);
@@ -163,12 +182,12 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             if (int64_t(c.kv) * rows > 64) uniform = false;  // register-resident CPT: <= 64 entries
             c.G = pick_lanes(c.kv, c.m, all_k4, d.lanes_per_node);
             c.variant = c.G > 1 ? kVariantGroup : (uniform ? kVariantUniform : kVariantGeneric);
+            if (g_children > 0) { c.G = 1; c.variant = kVariantGeneric; }  // the any-arity variant was chosen above
             // every other shape: one wavefront per node (lanes_per_node == 1 keeps the
             // one-lane-per-node generic path, for A/B tests)
             int32_t sum_kp = 0;
             for (int j = 0; j < c.m; ++j) sum_kp += c.kp[j];
-            if (c.variant == kVariantGeneric && d.lanes_per_node != 1 && c.m <= kFlatMaxParents &&
-                sum_kp <= kWave && c.kv <= kWave && int64_t(c.kv) * rows < (int64_t(1) << 22)) {
+            if (g_children > 0) {
                 c.variant = kVariantFlat;
                 // the smallest group that holds the table at two entries per lane and every vector
                 // in one register across the group; tables above 128 entries: the whole wave
@@ -245,6 +264,9 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         if (proto[t].boundary) inref_cur += int64_t(c.m) * c.npt;
         slot_cur += c.npt;
     }
+    p.light = nt > 0;
+    for (const ClassDesc& c : p.classes)
+        if (c.variant == kVariantUniform || c.variant == kVariantGroup) p.light = false;
     p.n_slots = slot_cur;
     p.rec_doubles = rec_cur;
     p.node_doubles = node_cur;
