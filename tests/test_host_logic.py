@@ -187,3 +187,20 @@ def test_any_arity_shapes_get_one_wavefront_per_node():
     with Engine(big, device=_lib.BN_DEVICE_HOST_ONLY) as e:
         for c in e.layout_classes():
             assert (c["variant"] == 0) == (c["m"] > 8) or c["variant"] in (1, 2)
+
+
+def test_mostly_any_arity_network_is_laid_out_uniformly():
+    """When at least two thirds of the nodes only fit the any-arity variant, the templated shapes join
+    it (the launch without register-resident tiles runs at twice the occupancy); every shard decides on
+    the WHOLE model, so sharded and unsharded layouts agree."""
+    from bayesiannetwork_amd import _lib
+    from bayesiannetwork_amd.engine import Engine
+    m = synth.random_dag(400, 3, 32, [5, 5, 5, 2, 5], seed=8)       # the k = 2 roots / chains are the minority
+    with Engine(m, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert {c["variant"] for c in e.layout_classes()} == {3}
+    for r in range(2):
+        with Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, rank=r, nranks=2) as e:
+            assert {c["variant"] for c in e.layout_classes()} == {3}
+    g = synth.grid(6, 6, 4, seed=1)                                   # templated shapes only: unchanged
+    with Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert {c["variant"] for c in e.layout_classes()} == {1}
