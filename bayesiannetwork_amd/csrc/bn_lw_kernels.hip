@@ -128,7 +128,7 @@ struct LwStepWords {  // LwStep as two 16-byte words
 };
 
 #ifndef BN_LW_WAVES
-#define BN_LW_WAVES 4
+#define BN_LW_WAVES 5
 #endif
 template <bool ROWS24, bool INLINE>
 __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_WAVES, BN_LW_WAVES))) void lw_sample_kernel(
