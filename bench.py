@@ -35,21 +35,23 @@ def profiled_traffic(rows, cols):
     return best
 
 
-def cpu_baseline(model, ev, eps, budget_s=12.0):
-    """The oracle (plain-C port of the reference algorithm), 1 thread like the reference, timed on
-    this box's host cores on a bounded number of full runs of the same workload."""
+def cpu_baseline(model, ev, eps, budget_s=12.0, threads=1):
+    """The oracle (plain-C port of the reference algorithm) timed on this box's host cores on a
+    bounded number of full runs of the same workload: 1 thread like the reference, or OpenMP over
+    the nodes of a sweep (both are reported)."""
     import oracle
     t0 = time.perf_counter()
     runs, msgs = 0, 0
     while True:
-        r = oracle.bp_run(model, ev, eps, threads=1)
+        r = oracle.bp_run(model, ev, eps, threads=threads)
         runs += 1
         msgs += model.messages_per_sweep() * r["sweeps"]
         if time.perf_counter() - t0 > budget_s or runs >= 8:
             break
     dt = time.perf_counter() - t0
-    return {"value": msgs / dt, "unit": "edge-messages/s", "cores": 1, "kind": "port",
-            "sample": f"{runs} full runs of the same workload ({r['sweeps']} sweeps each), oracle/bp_oracle.c, 1 thread"}
+    return {"value": msgs / dt, "unit": "edge-messages/s", "cores": threads, "kind": "port",
+            "sample": f"{runs} full runs of the same workload ({r['sweeps']} sweeps each), oracle/bp_oracle.c, "
+                      f"{threads} thread{'s' if threads > 1 else ''}"}
 
 
 def bench_lw(a, local_rank, torch):
@@ -215,6 +217,9 @@ def main():
     }
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps)
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if ncpu > 1:
+            out["cpu_baseline_all_cores"] = cpu_baseline(g, ev, a.eps, budget_s=8.0, threads=min(ncpu, 64))
         ref = cpu_reference_small()
         if ref:
             out["cpu_reference_small"] = ref
