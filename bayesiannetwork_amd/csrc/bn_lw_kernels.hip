@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_wide_kernel(const uint8_t*
         const uint32_t word = *reinterpret_cast<const uint32_t*>(states + uint64_t(v) * batch + col);
 #pragma unroll
         for (int r = 0; r < kLwPerThread; ++r)
-            if (valid[r] && w[r] != 0.0) atomicAdd(&sh_hist[(word >> (8 * r)) & 0xffu], w[r]);
+            if (valid[r] && w[r] != 0.0) unsafeAtomicAdd(&sh_hist[(word >> (8 * r)) & 0xffu], w[r]);  // ds_add_f64
         __syncthreads();
         if (tid < kv) {
             const double x = sh_hist[tid];
