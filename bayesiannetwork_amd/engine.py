@@ -344,6 +344,7 @@ class LikelihoodWeighting:
         self.model = model
         self.seed = seed
         self._next = 0
+        self.last_units = 0
 
     def __call__(self, evidence=None, sample_num: int = 10000):
         ev_state = np.full(self.model.n, -1, dtype=np.int32)
@@ -352,6 +353,43 @@ class LikelihoodWeighting:
         hist = self.engine.lw_run(ev_state, sample_num, self.seed, self._next)
         self._next += sample_num  # successive calls continue the stream like the reference's engine
         return _split(self.model, normalize_histogram(self.model, hist))
+
+
+    def make_samples(self, evidence=None, unit_size: int = 1000000, epsilon: float = 0.001):
+        """``likelihood_weighting::make_samples`` (likelihood_weighting.hpp:62-117): units of
+        ``unit_size`` weighted samples are drawn until no normalised marginal moved by ``epsilon`` or
+        more between two consecutive units.  Returns ``(patterns, marginals)``: the occurrence count of
+        every complete joint pattern over all units (dict: state tuple -> count, the python spelling
+        of ``unordered_map<condition_t, size_t>``) and the marginals of the last unit.  The patterns are
+        read back from the GPU's state matrix piece by piece; ``self.last_units`` = units executed."""
+        ev_state = np.full(self.model.n, -1, dtype=np.int32)
+        for v, s in (evidence or {}).items():
+            ev_state[v] = s
+        n, hn = self.model.n, int(self.model.k.sum())
+        w_list, prob = np.zeros(hn), np.zeros(hn)
+        table: dict = {}
+        piece_cap = max(1, min(unit_size, (1 << 28) // max(n, 1), 1 << 20))
+        self.last_units = 0
+        while True:
+            done = 0
+            while done < unit_size:  # one unit (:82-99), in pieces the device keeps in one state matrix
+                piece = min(unit_size - done, piece_cap)
+                w_list += self.engine.lw_run(ev_state, piece, self.seed, self._next)
+                self._next += piece
+                states, _ = self.engine.lw_states(piece)
+                pats, cnts = np.unique(states, axis=0, return_counts=True)
+                for pat, c in zip(pats, cnts):
+                    key = pat.tobytes()
+                    table[key] = table.get(key, 0) + int(c)
+                done += piece
+            self.last_units += 1
+            nxt = normalize_histogram(self.model, w_list)  # :101-112
+            diff = max(np.finfo(np.float64).tiny, float(np.abs(prob - nxt).max())) if hn else np.finfo(np.float64).tiny
+            prob = nxt
+            if diff < epsilon:
+                break
+        patterns = {tuple(np.frombuffer(key, dtype=np.uint8).tolist()): c for key, c in table.items()}
+        return patterns, _split(self.model, prob)
 
 
 def normalize_histogram(model: FlatModel, hist: np.ndarray) -> np.ndarray:

@@ -48,6 +48,28 @@ def _random_cpts(k: np.ndarray, in_ptr: np.ndarray, in_idx: np.ndarray, seed: in
     cpt_off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(sizes, out=cpt_off[1:])
     total = int(cpt_off[-1])
+    if n and total >= (1 << 22) and int(k.min()) == int(k.max()):
+        # uniform arity, large model (the 2048x2048 grid is 2.1 GB of CPTs): same numbers, built in
+        # 128 MiB chunks with no whole-array temporaries.  np.add.reduceat over a run of kk entries
+        # evaluates ((r1 + r2) + ... + r_{kk-1}) + r0, reproduced here term by term (asserted equal
+        # to the general path in tests/test_host_logic.py).
+        kk = int(k[0])
+        cpt = np.empty(total, dtype=np.float64)
+        chunk = (1 << 24) - (1 << 24) % kk
+        for s0 in range(0, total, chunk):
+            c = min(chunk, total - s0)
+            r = uniform01(seed, s0, c)
+            r *= 0.9
+            r += 0.1
+            q = r.reshape(-1, kk)
+            sm = q[:, 1 if kk > 1 else 0].copy()
+            for i in range(2, kk):
+                sm += q[:, i]
+            if kk > 1:
+                sm += q[:, 0]
+            q /= sm[:, None]
+            cpt[s0:s0 + c] = r
+        return cpt_off, cpt
     r = 0.1 + 0.9 * uniform01(seed, 0, total)
     # per-row sums: rows are contiguous runs of k[v] entries
     row_len = np.repeat(k.astype(np.int64), rows)

@@ -44,6 +44,9 @@ public:
 
     // deterministic runs (tests)
     void seed(std::uint64_t s) { seed_ = s; next_sample_ = 0; }
+    // units the last make_samples call executed (the reference does not report it; tests compare it
+    // with the oracle's count)
+    std::uint64_t last_units() const { return last_units_; }
 
     // Run: Likelihood Weighting (reference :28-59)
     return_type operator()(evidence_list const& evidence, std::uint64_t const sample_num = 10000)
@@ -104,6 +107,7 @@ public:
         std::unordered_map<std::string, std::size_t> packed;   // pattern bytes -> occurrences
         std::vector<std::uint8_t> states(static_cast<std::size_t>(std::min<std::uint64_t>(unit_size, std::uint64_t(1) << 20)) * n);
 
+        last_units_ = 0;
         while(true)
         {
             // Generate one unit (:85-99), in pieces the device keeps in one state matrix
@@ -121,6 +125,7 @@ public:
                 done += piece;
             }
 
+            ++last_units_;
             // largest move of any normalised marginal since the previous unit (:101-112)
             double max_difference = std::numeric_limits<double>::min();
             for(std::size_t v = 0; v < n; ++v)
@@ -161,6 +166,7 @@ private:
     mi355x::engine_handle engine_;
     std::uint64_t seed_ = 0;
     std::uint64_t next_sample_ = 0;
+    std::uint64_t last_units_ = 0;
 };
 
 } // namespace inference

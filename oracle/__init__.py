@@ -178,6 +178,96 @@ def lw_uniform(seed: int, sample: int, position: int) -> float:
     return float(L.oracle_lw_uniform(ctypes.c_uint64(seed), ctypes.c_uint64(sample), ctypes.c_uint32(position)))
 
 
+# ---- replay of the reference's sampler family (ref_replay.c) -------------------------
+
+def _model_args(model):
+    return (model.n, _p(model.k, ctypes.c_int32), _p(model.in_ptr, ctypes.c_int32), _p(model.in_idx, ctypes.c_int32),
+            _p(model.cpt_off, ctypes.c_int64), _p(model.cpt, ctypes.c_double))
+
+
+def mt19937_words(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.uint32)
+    lib().oracle_mt19937_words(ctypes.c_uint32(seed), n, _p(out, ctypes.c_uint32))
+    return out
+
+
+def mt19937_uniforms(seed: int, n: int) -> np.ndarray:
+    """std::uniform_real_distribution<double>(0,1) on std::mt19937(seed), libstdc++."""
+    out = np.zeros(n, dtype=np.float64)
+    lib().oracle_mt19937_uniforms(ctypes.c_uint32(seed), n, _p(out, ctypes.c_double))
+    return out
+
+
+def ref_visit_order(model) -> np.ndarray:
+    """Order in which weighted_sample / generate_pattern sample the vertices (likelihood_weighting.hpp:162-170)."""
+    out = np.zeros(max(model.n, 1), dtype=np.int32)
+    rc = lib().oracle_ref_visit_order(model.n, _p(model.in_ptr, ctypes.c_int32), _p(model.in_idx, ctypes.c_int32),
+                                      _p(out, ctypes.c_int32))
+    if rc != 0:
+        raise RuntimeError(f"oracle_ref_visit_order failed: {rc}")
+    return out[:model.n]
+
+
+def ref_lw_replay(model, ev_state, n_samples: int, mt_seed: int) -> np.ndarray:
+    """likelihood_weighting::operator() replayed with mt19937(mt_seed): the reference's marginals, bit for bit."""
+    ev_state = np.ascontiguousarray(ev_state, dtype=np.int32)
+    out = np.zeros(int(model.k.sum()), dtype=np.float64)
+    L = lib()
+    L.oracle_ref_lw_run.restype = ctypes.c_int
+    rc = L.oracle_ref_lw_run(*_model_args(model), _p(ev_state, ctypes.c_int32), ctypes.c_uint64(n_samples),
+                             ctypes.c_uint32(mt_seed), _p(out, ctypes.c_double))
+    if rc != 0:
+        raise RuntimeError(f"oracle_ref_lw_run failed: {rc}")
+    return out
+
+
+def make_samples(model, ev_state, unit_size: int, eps: float, seed: int, stream: str = "mt19937",
+                 order=None, sample_begin: int = 0, max_units: int = 0, pat_cap: int = 1 << 20):
+    """likelihood_weighting::make_samples (:62-117).  stream "mt19937": replay of the reference with its
+    engine reseeded mt19937(seed) and its own visiting order; stream "repo": the same loop fed with this
+    repository's per-sample streams in visiting order `order` (default: identity = the GPU's order for
+    models whose parents precede their children).  Returns dict(units, marginals, patterns [P][n], counts [P])."""
+    ev_state = np.ascontiguousarray(ev_state, dtype=np.int32)
+    kind = {"mt19937": 0, "repo": 1}[stream]
+    if kind == 1 and order is None:
+        order = np.arange(model.n, dtype=np.int32)
+    ordp = None if order is None else _p(np.ascontiguousarray(order, dtype=np.int32), ctypes.c_int32)
+    marg = np.zeros(int(model.k.sum()), dtype=np.float64)
+    pats = np.zeros((pat_cap, max(model.n, 1)), dtype=np.uint8)
+    cnts = np.zeros(pat_cap, dtype=np.uint64)
+    units, npat = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    L = lib()
+    L.oracle_make_samples.restype = ctypes.c_int
+    rc = L.oracle_make_samples(*_model_args(model), ordp, _p(ev_state, ctypes.c_int32), ctypes.c_uint64(unit_size),
+                               ctypes.c_double(eps), ctypes.c_uint64(max_units), kind, ctypes.c_uint64(seed),
+                               ctypes.c_uint64(sample_begin), ctypes.byref(units), _p(marg, ctypes.c_double),
+                               ctypes.c_uint64(pat_cap), _p(pats, ctypes.c_uint8), _p(cnts, ctypes.c_uint64),
+                               ctypes.byref(npat))
+    if rc not in (0, 1):
+        raise RuntimeError(f"oracle_make_samples failed: {rc}")
+    if npat.value > pat_cap:
+        raise RuntimeError("pattern table truncated: raise pat_cap")
+    return {"units": units.value, "marginals": marg, "patterns": pats[:npat.value, :model.n].copy(),
+            "counts": cnts[:npat.value].copy(), "hit_max_units": rc == 1}
+
+
+def ref_rs_replay(model, cond_state, num: int, mt_seed: int, max_draw: int = 0):
+    """rejection_sampling::operator() replayed with mt19937(mt_seed).  Returns (marginals, drawn)."""
+    cond_state = np.ascontiguousarray(cond_state, dtype=np.int32)
+    out = np.zeros(int(model.k.sum()), dtype=np.float64)
+    drawn = ctypes.c_uint64(0)
+    L = lib()
+    L.oracle_ref_rs_run.restype = ctypes.c_int
+    rc = L.oracle_ref_rs_run(*_model_args(model), _p(cond_state, ctypes.c_int32), ctypes.c_uint64(num),
+                             ctypes.c_uint32(mt_seed), ctypes.c_uint64(max_draw), _p(out, ctypes.c_double),
+                             ctypes.byref(drawn))
+    if rc == 2:
+        raise IndexError("choice_pattern: uniform not below the row total (the reference throws std::out_of_range)")
+    if rc not in (0, 1):
+        raise RuntimeError(f"oracle_ref_rs_run failed: {rc}")
+    return out, drawn.value
+
+
 # ---- the real reference (only where /root/reference exists) -------------------------
 
 def ref_available() -> bool:
@@ -222,4 +312,26 @@ def ref_lw(model, ev_state, n_samples: int, seed: int, timeout: float = 3600):
     pairs = [(v, int(s)) for v, s in enumerate(ev_state) if s >= 0]
     text = model.to_bnflat_text() + f"lw {n_samples} {seed}\n{len(pairs)}\n" + \
         "".join(f"{v} {s}\n" for v, s in pairs)
+    return _run_ref(text, timeout)
+
+
+def _pairs_text(ev_state):
+    pairs = [(v, int(s)) for v, s in enumerate(ev_state) if s >= 0]
+    return f"{len(pairs)}\n" + "".join(f"{v} {s}\n" for v, s in pairs)
+
+
+def ref_make_samples(model, ev_state, unit_size: int, eps: float, seed: int, timeout: float = 3600):
+    """The reference's own likelihood_weighting::make_samples, engine reseeded mt19937(seed)."""
+    text = model.to_bnflat_text() + f"lwms {unit_size} {eps!r} {seed}\n" + _pairs_text(ev_state)
+    r = _run_ref(text, timeout)
+    tab = np.asarray(r["patterns"], dtype=np.int64).reshape(-1, model.n + 1)
+    order = np.lexsort(tab[:, :model.n].T[::-1])
+    r["patterns"] = tab[order, :model.n].astype(np.uint8)
+    r["counts"] = tab[order, model.n].astype(np.uint64)
+    return r
+
+
+def ref_rs(model, cond_state, num: int, seed: int, timeout: float = 3600):
+    """The reference's own rejection_sampling::operator(), engine reseeded mt19937(seed)."""
+    text = model.to_bnflat_text() + f"rs {num} {seed}\n" + _pairs_text(cond_state)
     return _run_ref(text, timeout)

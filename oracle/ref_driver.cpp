@@ -17,6 +17,8 @@
 //   BNFLAT1  n  k[0..n)  { m p[0..m) } x n   { cpt row-major } x n
 //   then either   bp  eps  dump_msgs  ne  { node kv val[0..kv) } x ne
 //   or            lw  n_samples seed  ne  { node state } x ne
+//   or            lwms unit_size eps seed  ne  { node state } x ne     (likelihood_weighting::make_samples)
+//   or            rs  n_accept seed  ne  { node state } x ne           (rejection_sampling::operator())
 // DSC mode:  ref_driver --dsc net.dsc request.txt   -- the network comes from the reference's
 //   serializer::dsc loader (dsc.hpp:71), request.txt holds the "bp ..." / "lw ..." part; the JSON
 //   additionally carries the flat model as this repository's flatten() sees the loaded graph.
@@ -43,6 +45,7 @@
 #include <bayesian/matrix.hpp>
 #include <bayesian/inference/belief_propagation.hpp>
 #include <bayesian/inference/likelihood_weighting.hpp>
+#include <bayesian/inference/rejection_sampling.hpp>
 #undef private
 #include <bayesian/serializer/dsc.hpp>                               // the reference's own loader
 #include "../include/bayesian/inference/mi355x_flatten.hpp"          // this repo: graph_t -> flat arrays
@@ -283,6 +286,52 @@ int main(int argc, char** argv)
         auto const res = lw(ev, ns);
         auto t3 = std::chrono::steady_clock::now();
         std::printf("{\"mode\":\"lw\",\"samples\":%llu,\"seed\":%u,\"run_s\":%.6f,\"marginals\":[", ns, seed,
+                    std::chrono::duration<double>(t3 - t2).count());
+        for(int v = 0; v < fm.n; ++v) { if(v) std::printf(","); print_vec(res.at(vl[v])[0]); }
+        std::printf("]}\n");
+        return 0;
+    }
+    else if(mode == "lwms") {
+        // likelihood_weighting::make_samples (hpp:62-117) with the engine reseeded: the joint-pattern
+        // table, the marginals of the last unit and (from the table's total) the units executed
+        unsigned long long unit; double eps; unsigned seed; int ne;
+        in >> unit >> eps >> seed >> ne;
+        bn::inference::likelihood_weighting::evidence_list ev;
+        for(int j = 0; j < ne; ++j) { int node, st; in >> node >> st; ev[vl[node]] = st; }
+        if(!in) die("truncated evidence");
+        bn::inference::likelihood_weighting lw(graph);
+        lw.probability_generator_.engine_.reset(new std::mt19937(seed));
+        auto t2 = std::chrono::steady_clock::now();
+        auto const res = lw.make_samples(ev, unit, eps);
+        auto t3 = std::chrono::steady_clock::now();
+        unsigned long long total = 0;
+        for(auto const& p : res.first) total += p.second;
+        std::printf("{\"mode\":\"lwms\",\"unit_size\":%llu,\"eps\":%.17g,\"seed\":%u,\"units\":%llu,\"run_s\":%.6f,\"marginals\":[",
+                    unit, eps, seed, total / unit, std::chrono::duration<double>(t3 - t2).count());
+        for(int v = 0; v < fm.n; ++v) { if(v) std::printf(","); print_vec(res.second.at(vl[v])[0]); }
+        std::printf("],\"patterns\":[");
+        bool first = true;
+        for(auto const& p : res.first) {
+            std::printf("%s[", first ? "" : ","); first = false;
+            for(int v = 0; v < fm.n; ++v) std::printf("%d,", p.first.at(vl[v]));
+            std::printf("%zu]", p.second);   // last entry = occurrence count
+        }
+        std::printf("]}\n");
+        return 0;
+    }
+    else if(mode == "rs") {
+        // rejection_sampling::operator()(condition, generate_sample_num) (hpp:33-62), engine reseeded
+        int num; unsigned seed; int ne;
+        in >> num >> seed >> ne;
+        std::vector<std::pair<bn::vertex_type, int>> cond;
+        for(int j = 0; j < ne; ++j) { int node, st; in >> node >> st; cond.emplace_back(vl[node], st); }
+        if(!in) die("truncated condition");
+        bn::inference::rejection_sampling rs(graph);
+        rs.probability_generator_.engine_.reset(new std::mt19937(seed));
+        auto t2 = std::chrono::steady_clock::now();
+        auto const res = rs(cond, num);
+        auto t3 = std::chrono::steady_clock::now();
+        std::printf("{\"mode\":\"rs\",\"num\":%d,\"seed\":%u,\"run_s\":%.6f,\"marginals\":[", num, seed,
                     std::chrono::duration<double>(t3 - t2).count());
         for(int v = 0; v < fm.n; ++v) { if(v) std::printf(","); print_vec(res.at(vl[v])[0]); }
         std::printf("]}\n");

@@ -232,6 +232,18 @@ int main(int argc, char** argv)
         for(int i = 0; i < 3; ++i)
             for(int j = 0; j < 2; ++j) close_pct(made.second.at(v[i])[0][j], exact[i][j], 2.0, "make_samples pearl");
         std::printf("\"make_samples_total\":%zu,\"make_samples_patterns\":%zu,", total, made.first.size());
+        // units executed, the joint-pattern table and the marginals: compared by the python side with
+        // an oracle run of the same loop fed with the GPU's own stream (oracle/ref_replay.c)
+        std::printf("\"make_samples_units\":%llu,\"make_samples_table\":[", static_cast<unsigned long long>(lw.last_units()));
+        bool first_row = true;
+        for(auto const& p : made.first)
+        {
+            std::printf("%s[", first_row ? "" : ","); first_row = false;
+            for(std::size_t i = 0; i < v.size(); ++i) std::printf("%d,", static_cast<int>(p.first.at(v[i])));
+            std::printf("%zu]", p.second);
+        }
+        std::printf("],");
+        print_marginals("make_samples_marginals", pearl, made.second);
     }
     {   // rejection_sampling_standard (libs/bayesian/test/rejection_sampling.cpp): 5-node net,
         // condition {v4 = 1, v1 = 0}, P(v2) ~ {.62, .38} within 10 %
@@ -249,6 +261,7 @@ int main(int argc, char** argv)
         close_pct(result.at(v[1])[0][1], 0.38, 10, "rejection v2[1]");
         close_pct(result.at(v[3])[0][1], 1.0, 1e-9, "rejection keeps the condition");
         print_marginals("rejection", net, result);
+        std::printf("\"rejection_drawn\":%llu,", static_cast<unsigned long long>(func.last_drawn()));
     }
     {   // sampler::make_cpt (reference sampler.hpp:81-163): the pattern table make_samples returns,
         // loaded into bn::sampler, refits the CPTs of a structure-only copy of the network

@@ -177,6 +177,54 @@ def lw_cases():
                              "ref_marginals": np.concatenate([np.asarray(x) for x in r["marginals"]])})
 
 
+def rs_reference_net():
+    """libs/bayesian/test/rejection_sampling.cpp:9-67: the five-vertex network of the reference's only
+    rejection-sampling test (vertex_1..5 = nodes 0..4)."""
+    from bayesiannetwork_amd import from_parent_lists
+    return from_parent_lists([2] * 5, [[], [0], [0], [1], [1, 2]],
+                             [[.5, .5], [.8, .2, .1, .9], [.7, .3, .4, .6], [.6, .4, .1, .9],
+                              [.1, .9, .2, .8, .3, .7, .4, .6]], name="rs_reference_net")
+
+
+def make_samples_cases():
+    """likelihood_weighting::make_samples (likelihood_weighting.hpp:62-117) with the engine reseeded:
+    units executed, joint-pattern table (sorted), marginals of the last unit."""
+    print("make_samples (reference engine reseeded to mt19937(seed))")
+    cases = [("ms_pearl", synth.pearl(), np.array([-1, -1, -1, 0], np.int32), 2000, 0.01, 11),
+             ("ms_pearl_noev", synth.pearl(), np.array([-1, -1, -1, -1], np.int32), 500, 0.02, 5)]
+    d = synth.random_dag(12, 3, 6, [2, 3, 2, 2], seed=33)
+    ev = np.full(d.n, -1, np.int32)
+    ev[4], ev[9] = 1, 0
+    cases.append(("ms_dag12", d, ev, 3000, 0.005, 3))
+    for name, model, ev_state, unit, eps, seed in cases:
+        t = time.time()
+        r = oracle.ref_make_samples(model, ev_state, unit, eps, seed)
+        print(f"    {name}: units={r['units']} patterns={len(r['counts'])} ({time.time() - t:.1f}s)")
+        save(name, model, [], {"ev_state": ev_state, "unit_size": np.int64(unit), "eps": np.float64(eps),
+                               "seed": np.int64(seed), "units": np.int64(r["units"]),
+                               "ref_marginals": np.concatenate([np.asarray(x) for x in r["marginals"]]),
+                               "ref_patterns": r["patterns"], "ref_counts": r["counts"]})
+
+
+def rs_cases():
+    """rejection_sampling::operator() (rejection_sampling.hpp:33-62) with the engine reseeded."""
+    print("rejection sampling (reference engine reseeded to mt19937(seed))")
+    net = rs_reference_net()
+    cond = np.array([0, -1, -1, 1, -1], np.int32)   # {vertex_4 = 1, vertex_1 = 0}, rejection_sampling.cpp:69
+    cases = [("rs_reference_net", net, cond, 10000, 17),
+             ("rs_reference_net_nocond", net, np.full(5, -1, np.int32), 4000, 2)]
+    d = synth.random_dag(14, 3, 6, [2, 3, 4], seed=44)
+    c = np.full(d.n, -1, np.int32)
+    c[2], c[11] = 0, 1
+    cases.append(("rs_dag14", d, c, 3000, 9))
+    for name, model, cond_state, num, seed in cases:
+        t = time.time()
+        r = oracle.ref_rs(model, cond_state, num, seed)
+        print(f"    {name}: ({time.time() - t:.1f}s)")
+        save(name, model, [], {"cond_state": cond_state, "num": np.int64(num), "seed": np.int64(seed),
+                               "ref_marginals": np.concatenate([np.asarray(x) for x in r["marginals"]])})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also the minutes-long cases (32x32 grid, 1000-node DAG)")
@@ -192,3 +240,7 @@ if __name__ == "__main__":
         lw_cases()
     if a.only in ("", "alarm"):
         alarm_cases()
+    if a.only in ("", "ms"):
+        make_samples_cases()
+    if a.only in ("", "rs"):
+        rs_cases()

@@ -36,6 +36,45 @@ def test_lw_states_bit_exact_vs_oracle(Engine, oracle_mod, n, maxp, k, frac, ns)
         assert np.array_equal(hist, want["hist"])
 
 
+def test_lw_config5_full_size(Engine, oracle_mod):
+    """BASELINE.json configs[4] at its workload: the 10 k-node DAG with 1 % evidence.
+    (a) integer work: the first 2048 sampled states are bit-equal to the oracle;
+    (b) a 2 M-sample batch (the bench step) on the GPU: split-range additivity at that size, and a
+        subset of the same sample ids re-drawn in isolation equals the oracle's histogram of those ids
+        (the oracle draws 3e3 samples/s, so the subset is what it finishes in seconds);
+    (c) size-independent properties of the 2 M-sample histogram: every node's bins sum to the total
+        weight, evidence nodes hold all of it in the observed state.
+    Reference path: likelihood_weighting.hpp:28-59."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(10000, 4, 64, 4, seed=1)
+    ev = synth.random_evidence(d, 0.01, seed=7).hard_states(d)
+    assert int((ev >= 0).sum()) == 100
+    n_big, seed = 2 * 1024 * 1024, 1
+    with Engine(d) as eng:
+        head = oracle_mod.lw_run(d, ev, 2048, seed=seed, states_cap=2048)
+        h_head = eng.lw_run(ev, 2048, seed=seed)
+        states, weights = eng.lw_states(2048)
+        assert np.array_equal(states, head["states"])
+        assert np.allclose(weights, head["weights"], rtol=1e-12, atol=0)
+        assert np.allclose(h_head, head["hist"], rtol=1e-9, atol=1e-300)
+        whole = eng.lw_run(ev, n_big, seed=seed)
+        a = eng.lw_run(ev, n_big // 2, seed=seed)
+        b = eng.lw_run(ev, n_big // 2, seed=seed, sample_begin=n_big // 2)
+        assert np.allclose(whole, a + b, rtol=1e-9, atol=1e-300)
+        # a window of ids from the middle of the big batch, alone, against the oracle on the same ids
+        lo, cnt = 1234567, 4096
+        sub = eng.lw_run(ev, cnt, seed=seed, sample_begin=lo)
+        want = oracle_mod.lw_run(d, ev, cnt, seed=seed, s_begin=lo)
+        assert np.allclose(sub, want["hist"], rtol=1e-9, atol=1e-300)
+        st_sub, _ = eng.lw_states(64)
+        assert np.array_equal(st_sub, oracle_mod.lw_run(d, ev, 64, seed=seed, s_begin=lo, states_cap=64)["states"])
+    sums = np.add.reduceat(whole, d.node_off[:-1])
+    assert np.allclose(sums, sums[0], rtol=1e-9)
+    for v in np.nonzero(ev >= 0)[0]:
+        row = whole[d.node_off[v]:d.node_off[v + 1]]
+        assert row[ev[v]] > 0 and np.count_nonzero(row) == 1
+
+
 def test_lw_split_runs_sum(Engine):
     """Histograms of disjoint sample ranges add up (what a multi-GPU reduce relies on)."""
     from bayesiannetwork_amd import synth
@@ -183,3 +222,61 @@ def test_sampler_mirror_make_cpt(Engine, oracle_mod):
     assert smp.make_cpt(m) is True
     assert np.array_equal(m.cpt, oracle_mod.make_cpt(m, pats, cnts))
     assert np.abs(m.cpt - truth).max() < 0.02
+
+
+def _kahn_min_order(model):
+    """The sampler's visiting order (csrc/bn_lw.cpp: Kahn's algorithm, smallest ready node first)."""
+    import heapq
+    indeg = np.diff(model.in_ptr).astype(int)
+    children = [[] for _ in range(model.n)]
+    for v in range(model.n):
+        for p in model.parents(v):
+            children[int(p)].append(v)
+    ready = [v for v in range(model.n) if indeg[v] == 0]
+    heapq.heapify(ready)
+    order = []
+    while ready:
+        v = heapq.heappop(ready)
+        order.append(v)
+        for c in children[v]:
+            indeg[c] -= 1
+            if indeg[c] == 0:
+                heapq.heappush(ready, c)
+    return np.asarray(order, np.int32)
+
+
+@pytest.mark.parametrize("case", ["pearl", "dag12", "reversed_chain"])
+def test_make_samples_stops_like_the_oracle(Engine, oracle_mod, case):
+    """likelihood_weighting::make_samples (likelihood_weighting.hpp:62-117) on the GPU: the units
+    executed, the joint-pattern table and the marginals equal the oracle's restatement of that loop fed
+    with the GPU's own stream (the same restatement reproduces the reference's reseeded runs bit for bit,
+    tests/test_oracle_golden.py) -- so the adaptive stop rule and the pattern table are pinned, not
+    just the marginals."""
+    from bayesiannetwork_amd import from_parent_lists, synth
+    from bayesiannetwork_amd.engine import LikelihoodWeighting
+    if case == "pearl":
+        model, ev, unit, eps = synth.pearl(), {3: 0}, 20000, 0.004
+    elif case == "dag12":
+        model = synth.random_dag(12, 3, 6, [2, 3, 2, 2], seed=33)
+        ev, unit, eps = {4: 1, 9: 0}, 3000, 0.005
+    else:  # vertex order is NOT topological: 3 <- 2 <- 1 <- 0 reversed, node 0 is the leaf
+        model = from_parent_lists([2, 3, 2, 2], [[1], [2], [3], []],
+                                  [[.3, .7, .6, .4, .5, .5], [.2, .3, .5, .6, .3, .1], [.9, .1, .4, .6], [.35, .65]])
+        ev, unit, eps = {0: 1}, 5000, 0.006
+    ev_state = np.full(model.n, -1, np.int32)
+    for v, s in ev.items():
+        ev_state[v] = s
+    lw = LikelihoodWeighting(model, seed=4242)
+    pats, marg = lw.make_samples(ev, unit, eps)
+    want = oracle_mod.make_samples(model, ev_state, unit, eps, seed=4242, stream="repo", order=_kahn_min_order(model))
+    assert lw.last_units == want["units"] and want["units"] >= 2
+    got = sorted(pats.items())
+    assert [list(k) for k, _ in got] == want["patterns"].tolist()
+    assert [c for _, c in got] == want["counts"].tolist()
+    assert np.allclose(np.concatenate(marg), want["marginals"], rtol=1e-9, atol=1e-15)
+    # a second call continues the sample numbering, like the reference's engine keeps its state
+    pats2, _ = lw.make_samples(ev, unit, eps)
+    want2 = oracle_mod.make_samples(model, ev_state, unit, eps, seed=4242, stream="repo", order=_kahn_min_order(model),
+                                    sample_begin=want["units"] * unit)
+    assert lw.last_units == want2["units"] and sorted(pats2.items())[0][1] == int(want2["counts"][0])
+    lw.engine.close()
