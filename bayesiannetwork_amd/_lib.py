@@ -30,7 +30,8 @@ class ModelDesc(ctypes.Structure):
 class BpStats(ctypes.Structure):
     _fields_ = [("sweeps", ctypes.c_int32), ("sweep_launches", ctypes.c_int32), ("sweep_kernel_ms", ctypes.c_float),
                 ("total_ms", ctypes.c_float), ("algorithmic_bytes_per_sweep", ctypes.c_int64),
-                ("layout_bytes_per_sweep", ctypes.c_int64), ("messages_per_sweep", ctypes.c_int64)]
+                ("layout_bytes_per_sweep", ctypes.c_int64), ("messages_per_sweep", ctypes.c_int64),
+                ("sweep_devclock_ms", ctypes.c_float), ("pad_", ctypes.c_float)]
 
 
 class LayoutInfo(ctypes.Structure):

@@ -13,16 +13,18 @@ namespace bnmi {
 constexpr int kBlockThreads = BN_BLOCK_THREADS;  // 8 tile waves per CU at 242 VGPRs whatever the block size
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
 
-// Device-resident control block of one BP run.
+// Device-resident control block.  A run is identified by its run id (1, 2, ... per engine): the
+// run is over for the kernels once done_run == the id their launch carries, so nothing has to be
+// reset between runs (a stale block belongs to an older id).
 struct Ctl {
-    int32_t done;       // 0 running, 1 converged (maximum_difference < eps), 2 stopped at max_sweeps
+    uint32_t done_run;  // id of the last run whose sweeps decided the stop themselves (maximum_difference < eps)
+    int32_t done;       // host copy only: 0 running, 1 converged, 2 stopped at max_sweeps
     int32_t n_sweeps;   // iterations of the reference's while(true) loop that were executed
+    uint32_t run_id;    // host copy only: the run the other fields describe
     double last_res;    // maximum_difference of the last executed sweep
-    uint32_t p_abort;   // persistent kernel: non-zero = a bounded wait gave up (copied by the finish kernel)
-    uint32_t p_conv;    // persistent kernel: iteration count at which it ended, 0 = it did not end
+    unsigned long long t_first;  // wall_clock64() (100 MHz) when sweep 0 of the run started
+    unsigned long long t_last;   // ... when the launch after the last executed sweep started
 };
-
-struct PersistSync;
 
 struct BpBuffers {
     const TileDesc* tiles;
@@ -59,6 +61,7 @@ struct SweepArgs {
     double eps;
     int32_t sweep;       // 0-based index of this iteration
     int32_t book_tile;   // first wave index past the tiles: it does the residual bookkeeping
+    uint32_t run_id;
 };
 
 struct FinishArgs {
@@ -66,9 +69,7 @@ struct FinishArgs {
     double eps;
     int32_t sweeps_launched;
     int32_t final_batch;  // 1: max_sweeps reached with this batch -> stop even if not converged
-    int32_t ne;           // evidence marks to clear once the run is over
-    const int32_t* ev_node;
-    const struct PersistSync* psync;  // persistent run: status to fold into Ctl (else nullptr)
+    uint32_t run_id;
     Ctl* host_ctl;        // pinned host copy of Ctl, written by the kernel itself (no D2H copy command)
 };
 
@@ -80,33 +81,28 @@ struct EvidenceArgs {
     const double* ev_val;
 };
 
-// Synchronisation block of the persistent dataflow kernel (bn_persist.hip); zeroed before each run.
-struct PersistSync {
-    unsigned completed;  // iterations every tile has finished
-    unsigned conv;       // iteration count at which the run ended (converged / capped), 0 = running
-    unsigned abort;      // non-zero: a bounded wait gave up (1 global slack, 2 neighbour flag, 3 bad tile)
-    unsigned pad_;
-    unsigned count[4];   // arrivals per iteration (mod 4)
-};
-
-struct PersistArgs {
+// All sweeps of a small network in one launch of one workgroup (bn_multi.hip).
+constexpr int kMultiWaves = 8;        // 512 threads, <= 256 VGPRs: every tile variant
+constexpr int kMultiWavesLight = 15;  // 960 threads, <= 128 VGPRs: any-arity / one-lane tiles only (15 x 10 KiB of LDS)
+struct MultiArgs {
     BpBuffers b;
-    const int32_t* nbr_ptr;         // tile adjacency (bn_plan.hpp)
-    const int32_t* nbr_idx;
-    PersistSync* sync;
-    unsigned* flags;                // [n_tiles] iterations finished by each tile
-    unsigned long long* res_tile;   // [4][n_tiles] per-tile residual bit patterns, by iteration mod 4
     double eps;
-    int32_t max_sweeps;
-    int32_t n_tiles;
-    unsigned long long timeout_ticks;  // 100 MHz ticks
+    int32_t max_sweeps;   // 0 = unbounded like the reference
+    int32_t sweep_begin;  // first iteration of this launch (0 unless a previous launch ran out of budget)
+    int32_t budget;       // iterations this launch may execute
+    uint32_t run_id;
+    Ctl* host_ctl;
 };
-
-int launch_bp_persistent(const PersistArgs& a, int grid_blocks, void* stream);
+int launch_bp_multi(const MultiArgs& a, bool light, void* stream);
 
 // launchers (bn_kernels.hip)
-int launch_bp_begin(const EvidenceArgs& a, void* stream);
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, void* stream);
+int launch_bp_evidence(const EvidenceArgs& a, void* stream);  // bn_bp_set_evidence: marks + vectors
+int launch_bp_reset(const BpBuffers& b, void* stream);         // residual slots; after an abnormal end only
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, int variants, void* stream);
+// per-variant-set instantiations (bn_sweep_*.hip)
+int launch_bp_sweep_u(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream);
+int launch_bp_sweep_ug(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream);
+int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, void* stream);
 int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream);
 
 }  // namespace bnmi

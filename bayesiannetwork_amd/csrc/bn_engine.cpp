@@ -26,6 +26,27 @@ using namespace bnmi;
 
 static thread_local std::string g_err;
 
+// Entry points run on the engine's device and leave the calling thread's current device as they
+// found it (a caller may drive another GPU from the same thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int device) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev == device) return hipSuccess;
+        e = hipSetDevice(device);
+        switched = e == hipSuccess;
+        return e;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define ON_DEVICE(e)            \
+    DeviceGuard guard_;         \
+    HIPCHK(guard_.enter((e)->device))
+
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -101,18 +122,16 @@ struct bn_engine {
     int32_t* d_ev_node = nullptr;
     int32_t* d_ev_off = nullptr;
     double* d_ev_val = nullptr;
-    bool frozen_dirty = false;
+    bool ev_applied_dirty = false;  // an evidence launch failed: marks unknown, clear them at the next set
+    bool rows_clean = true;         // residual slots are zero (left so by the last finish kernel / the reset kernel)
+    uint32_t run_id = 0;            // id of the current / last run (bn_device.hpp Ctl)
     bool nontemporal = false;
-    // persistent dataflow path (bn_persist.hip)
-    bool persist_ok = false;        // model eligible and everything resident at once
-    bool timing = true;             // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms)
-    bool persist_enabled = false;   // opt-in (measured slower): BN_PERSISTENT=1 / bn_set_option; cleared after an abort
-    int32_t* d_nbr_ptr = nullptr;
-    int32_t* d_nbr_idx = nullptr;
-    char* d_psync = nullptr;        // PersistSync | flags[n_tiles] | res_tile[4][n_tiles]
-    size_t psync_bytes = 0;
-    int grid_persist = 0;
-    int32_t last_path = 0;          // 0 per-sweep launches, 1 persistent
+    bool timing = false;            // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms); opt-in:
+                                    // an event record between two launches opens a ~6 us bubble in the queue
+    bool multi_ok = false;          // the network is small enough for the one-launch path
+    bool multisweep = false;        // small networks: one launch for the whole run (BN_MULTISWEEP=1 / bn_set_option);
+                                    // measured slower than per-sweep launches so far, hence opt-in
+    int32_t last_path = 0;          // 0 per-sweep launches, 1 one launch for the whole run
     Ctl* h_ctl = nullptr;  // pinned
     Ctl* h_ctl_dev = nullptr;  // the same memory as the device sees it
     // run state
@@ -130,13 +149,13 @@ struct bn_engine {
 static void free_engine(bn_engine* e) {
     if (!e) return;
     if (!e->host_only) {
-        (void)hipSetDevice(e->device);
+        DeviceGuard guard;
+        (void)guard.enter(e->device);
         lw_free(e->lw);
         if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_nbr_ptr, e->d_nbr_idx,
-                        e->d_psync};
+                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -180,7 +199,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     *out = nullptr;
     bn_engine* e = new (std::nothrow) bn_engine();
     if (!e) return fail(BN_ERR_ALLOC, "out of host memory");
-    if (const char* t = std::getenv("BN_TIMING")) e->timing = std::atoi(t) != 0;
+    if (const char* t = std::getenv("BN_TIMING")) e->timing = std::atoi(t) != 0;  // default off, see bn_engine::timing
     std::string err;
     try {
         err = build_plan(*desc, shard, e->plan);
@@ -209,14 +228,15 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         return fail(BN_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
     }
     e->host_only = false;
+    DeviceGuard guard;
     int rc = [&]() -> int {
         if (desc->device >= 0) {
             if (desc->device >= ndev) return fail(BN_ERR_ARG, "device ordinal out of range");
-            HIPCHK(hipSetDevice(desc->device));
             e->device = desc->device;
         } else {
             HIPCHK(hipGetDevice(&e->device));
         }
+        HIPCHK(guard.enter(e->device));
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
         int r;
         if ((r = upload(&e->d_tiles, p.tiles, e->stream))) return r;
@@ -240,35 +260,20 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         e->nontemporal = 8 * (p.cpt_doubles + 2 * p.rec_doubles + 2 * p.node_doubles) > (int64_t(192) << 20);
         if ((r = dalloc(&e->d_res_hist, size_t(e->res_cap)))) return r;
         if ((r = dalloc(&e->d_ctl, 1))) return r;
+        HIPCHK(hipMemsetAsync(e->d_ctl, 0, sizeof(Ctl), e->stream));  // done_run = 0: no run is marked done
         if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
         HIPCHK(hipMemsetAsync(e->d_beliefs, 0, std::max<size_t>(p.node_off[p.n], 1) * 8, e->stream));
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocMapped));
         std::memset(e->h_ctl, 0, sizeof(Ctl));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ctl_dev), e->h_ctl, 0));
-        // persistent dataflow path: every tile register-resident (tile_uniform shapes, <= 4 children,
-        // no remote parents) and all tiles co-resident -- 8 waves per CU at <= 256 VGPRs
-        {
-            hipDeviceProp_t prop;
-            HIPCHK(hipGetDeviceProperties(&prop, e->device));
-            const int64_t capacity = int64_t(prop.multiProcessorCount) * 8;
+        {   // small network: all sweeps in one launch of one workgroup (bn_multi.hip); wave w runs
+            // tiles w, w + W, ...: up to kMultiMaxRounds tiles per wave and sweep
             const int64_t nt = int64_t(p.tiles.size());
-            bool ok = p.nranks == 1 && nt > 0 && p.rec_total_doubles * 8 < (int64_t(1) << 31);
-            e->grid_persist = int((nt + 7) & ~int64_t(7));
-            ok = ok && e->grid_persist <= capacity * 9 / 10;  // margin: never rely on the last slot
-            for (const TileDesc& td : p.tiles)
-                ok = ok && td.variant == kVariantUniform && td.cmax <= 4 && td.in_ref_base < 0;
-            e->persist_ok = ok;
-            if (std::getenv("BN_DEBUG"))
-                std::fprintf(stderr, "[bn_mi355x] persistent eligible=%d tiles=%lld capacity=%lld max_nbr=%d\n", int(ok),
-                             (long long)nt, (long long)capacity, p.max_nbr);
-            const char* env = std::getenv("BN_PERSISTENT");
-            if (env) e->persist_enabled = env[0] == '1';
-            if (ok) {
-                if ((r = upload(&e->d_nbr_ptr, p.nbr_ptr, e->stream))) return r;
-                if ((r = upload(&e->d_nbr_idx, p.nbr_idx, e->stream))) return r;
-                e->psync_bytes = sizeof(PersistSync) + size_t(nt) * 4 + 64 + size_t(nt) * 4 * 8;
-                HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_psync), e->psync_bytes));
-            }
+            const int64_t waves = p.light ? kMultiWavesLight : kMultiWaves;
+            int64_t rounds_max = 3;
+            if (const char* r = std::getenv("BN_MULTISWEEP_ROUNDS")) rounds_max = std::atoi(r);
+            e->multi_ok = p.nranks == 1 && nt > 0 && nt <= waves * rounds_max;
+            if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::atoi(m) != 0;
         }
         HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
@@ -351,7 +356,9 @@ static int ensure_events(bn_engine* e, size_t count) {
     return BN_OK;
 }
 
-// Evidence staging: one pinned host block [ev_node | ev_off | ev_val] -> one H2D copy.
+// Evidence staging: one pinned host block [ev_node | ev_off | ev_val] -> one H2D copy, then the
+// evidence is APPLIED (marks cleared, new marks and vectors written): it stays in force for every
+// following run until the next call, so a run itself starts with its first sweep.
 extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
                                   const double* ev_val) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -360,7 +367,7 @@ extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_no
     int rc = check_evidence(p, ne, ev_node, ev_off);
     if (rc) return rc;
     if (ne > 0 && !ev_val) return fail(BN_ERR_ARG, "null ev_val");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     const int64_t nval = ne > 0 ? ev_off[ne] : 0;
     const size_t off_node = 0, off_off = size_t(ne) * 4, off_val = (off_off + size_t(ne + 1) * 4 + 7) & ~size_t(7);
     const size_t bytes = off_val + size_t(nval) * 8;
@@ -379,36 +386,42 @@ extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_no
         std::memcpy(e->h_ev + off_val, ev_val, size_t(nval) * 8);
         HIPCHK(hipMemcpyAsync(e->d_ev, e->h_ev, bytes, hipMemcpyHostToDevice, e->stream));
     }
-    e->ev_ne = ne;
     e->d_ev_node = reinterpret_cast<int32_t*>(e->d_ev + off_node);
     e->d_ev_off = reinterpret_cast<int32_t*>(e->d_ev + off_off);
     e->d_ev_val = reinterpret_cast<double*>(e->d_ev + off_val);
+    if (e->ev_ne > 0 || e->ev_applied_dirty)  // drop the previous set's marks
+        HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), e->stream));
+    e->ev_ne = ne;
+    e->ev_applied_dirty = false;
+    EvidenceArgs ea{buffers_of(e), ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
+    if (int code = launch_bp_evidence(ea, e->stream)) {
+        e->ev_applied_dirty = true;
+        return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
+    // bn_bp_run's contract is "evidence uploaded when the call returns" (h_ev is reused by the next call)
     HIPCHK(hipStreamSynchronize(e->stream));
     return BN_OK;
 }
 
-// ---- the four steps of a run; bn_bp_run_device chains them, the bn_bp_step_* entry points
-// expose them one by one (tests drive several shards on one GPU with an emulated all-gather).
+// ---- the steps of a run; bn_bp_run_device chains them, the bn_bp_step_* entry points expose
+// them one by one (tests drive several shards on one GPU with an emulated all-gather).
 static int step_begin(bn_engine* e) {
-    const Plan& p = e->plan;
-    hipStream_t s = e->stream;
-    if (e->frozen_dirty) {  // a previous run ended abnormally: restore the all-clear invariant
-        HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), s));
-        e->frozen_dirty = false;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    if (!e->rows_clean) {  // the previous run did not end through a finish kernel that saw it over
+        if (int code = launch_bp_reset(buffers_of(e), e->stream))
+            return fail(BN_ERR_HIP, std::string("bp_reset launch failed: ") + hipGetErrorString(hipError_t(code)));
     }
-    e->frozen_dirty = true;
-    EvidenceArgs ea{buffers_of(e), e->ev_ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
-    if (int code = launch_bp_begin(ea, s))
-        return fail(BN_ERR_HIP, std::string("bp_begin launch failed: ") + hipGetErrorString(hipError_t(code)));
+    e->rows_clean = false;
     return BN_OK;
 }
 
 static int step_sweep(bn_engine* e, int32_t sweep, double eps) {
     const int cur = sweep & 1;
     SweepArgs sa{buffers_of(e), e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, sweep,
-                 int32_t(e->plan.tiles.size())};
+                 int32_t(e->plan.tiles.size()), e->run_id};
     static const bool no_light = std::getenv("BN_NO_LIGHT") != nullptr;  // A/B switch
-    if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, e->plan.light && !no_light, e->stream))
+    if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, e->plan.light && !no_light, e->plan.variants, e->stream))
         return fail(BN_ERR_HIP, "bp_sweep launch failed");
     return BN_OK;
 }
@@ -428,64 +441,65 @@ static int step_exchange(bn_engine* e, int32_t sweep) {
     return BN_OK;
 }
 
-static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps, const PersistSync* psync = nullptr) {
-    // the lead thread writes the outcome straight into the pinned host Ctl: visible after the stream
+static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps) {
+    // wave 0 writes the outcome straight into the pinned host Ctl: visible after the stream
     // synchronises, no copy command in between
-    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->ev_ne, e->d_ev_node, psync, e->h_ctl_dev};
+    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->run_id, e->h_ctl_dev};
     if (launch_bp_finish(fa, e->grid_tiles, e->stream)) return fail(BN_ERR_HIP, "bp_finish launch failed");
     return BN_OK;
 }
 
 static void note_run_result(bn_engine* e) {
-    e->frozen_dirty = false;  // the finish kernel cleared this run's evidence marks
+    e->rows_clean = true;  // the finish kernel that saw the run over left the residual slots zero
     e->last_ctl = *e->h_ctl;
     e->have_run = true;
     e->predicted_sweeps = e->last_ctl.n_sweeps;
     e->stats.sweeps = e->last_ctl.n_sweeps;
+    // device clock (100 MHz): start of sweep 0 -> start of the launch after the last executed sweep
+    const unsigned long long t0 = e->last_ctl.t_first, t1 = e->last_ctl.t_last;
+    e->stats.sweep_devclock_ms = t1 > t0 ? float(double(t1 - t0) * 1e-5) : 0.f;
 }
 
-// One launch for the whole run (bn_persist.hip).  BN_ERR_STATE = a bounded wait inside the kernel
-// timed out (e.g. not every tile became resident): the caller falls back to per-sweep launches.
-static int run_persistent(bn_engine* e, double eps, int32_t max_sweeps) {
-    const Plan& p = e->plan;
+// Small networks: ONE launch of one workgroup runs every sweep, decides the stop and writes the
+// beliefs (bn_multi.hip).  A launch executes at most kMultiBudget iterations; a run that needs more
+// is continued by the next launch, so no evidence set can keep the GPU inside one kernel.
+static int run_multi(bn_engine* e, double eps, int32_t max_sweeps) {
+    constexpr int32_t kMultiBudget = 2048;
     hipStream_t s = e->stream;
-    const int32_t nt = int32_t(p.tiles.size());
-    int rc;
-    const bool dbg = std::getenv("BN_DEBUG") != nullptr;
-#define PDBG(msg) do { if (dbg) { std::fprintf(stderr, "[bn_mi355x] persist: %s\n", msg); std::fflush(stderr); } } while (0)
-    PDBG("memset");
-    HIPCHK(hipMemsetAsync(e->d_psync, 0, e->psync_bytes, s));
-    if ((rc = step_begin(e))) return rc;
-    PDBG("begin launched");
-    PersistArgs a;
-    a.b = buffers_of(e);
-    a.nbr_ptr = e->d_nbr_ptr;
-    a.nbr_idx = e->d_nbr_idx;
-    a.sync = reinterpret_cast<PersistSync*>(e->d_psync);
-    a.flags = reinterpret_cast<unsigned*>(e->d_psync + sizeof(PersistSync));
-    a.res_tile = reinterpret_cast<unsigned long long*>(e->d_psync + ((sizeof(PersistSync) + size_t(nt) * 4 + 63) & ~size_t(63)));
-    a.eps = eps;
-    a.max_sweeps = max_sweeps;
-    a.n_tiles = nt;
-    a.timeout_ticks = 100000000ull / 5;  // 200 ms of the 100 MHz clock
-    if ((rc = ensure_events(e, 2))) return rc;
-    HIPCHK(hipEventRecord(e->events[0], s));
-    if (int code = launch_bp_persistent(a, e->grid_persist, s))
-        return fail(BN_ERR_HIP, std::string("bp_persistent launch failed: ") + hipGetErrorString(hipError_t(code)));
-    HIPCHK(hipEventRecord(e->events[1], s));
-    PDBG("kernel launched");
-    if (dbg) { hipError_t se = hipStreamSynchronize(s); std::fprintf(stderr, "[bn_mi355x] persist: kernel sync -> %s\n", hipGetErrorString(se)); }
-    if ((rc = step_finish(e, 1, true, eps, a.sync))) return rc;
-    HIPCHK(hipStreamSynchronize(s));
-    PDBG("finished");
-    if (e->h_ctl->p_abort != 0 || e->h_ctl->p_conv == 0 || e->h_ctl->done == 0)
-        return fail(BN_ERR_STATE, "persistent kernel gave up a wait (code " + std::to_string(e->h_ctl->p_abort) + ")");
-    note_run_result(e);
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
     e->last_path = 1;
+    int32_t begin = 0, launches = 0;
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e->events[0], e->events[1]));
-    e->stats.sweep_launches = e->last_ctl.n_sweeps;  // iterations inside the one launch
+    double dev_ticks = 0.0;
+    for (;;) {
+        MultiArgs a{buffers_of(e), eps, max_sweeps, begin, kMultiBudget, e->run_id, e->h_ctl_dev};
+        if (e->timing) {
+            int rc = ensure_events(e, 2);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->events[0], s));
+        }
+        if (int code = launch_bp_multi(a, e->plan.light, s))
+            return fail(BN_ERR_HIP, std::string("bp_multi launch failed: ") + hipGetErrorString(hipError_t(code)));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
+        HIPCHK(hipStreamSynchronize(s));
+        ++launches;
+        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "multi-sweep kernel did not report (stale control block)");
+        if (e->timing) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
+            ms += t;
+        }
+        dev_ticks += double(e->h_ctl->t_last - e->h_ctl->t_first);
+        if (e->h_ctl->done != 0) break;
+        begin = e->h_ctl->n_sweeps;
+    }
+    const bool rows_were_clean = e->rows_clean;  // this path never touches the residual slots
+    note_run_result(e);
+    e->rows_clean = rows_were_clean;
+    e->stats.sweep_launches = launches;
     e->stats.sweep_kernel_ms = ms;
+    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
     return BN_OK;
 }
 
@@ -496,21 +510,17 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
     if (e->plan.nranks > 1 && !e->comm) return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init before running");
     const auto t_begin = std::chrono::steady_clock::now();
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     hipStream_t s = e->stream;
     int rc;
-    if (e->persist_ok && e->persist_enabled) {
-        rc = run_persistent(e, eps, max_sweeps);
-        if (rc == BN_OK) {
-            e->stats.total_ms =
-                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
-            if (residual_out) *residual_out = e->last_ctl.last_res;
-            return BN_OK;
-        }
-        if (rc != BN_ERR_STATE) return rc;  // BN_ERR_STATE: the kernel gave up a wait -> per-sweep launches
-        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] persistent path disabled: %s\n", g_err.c_str());
-        e->persist_enabled = false;
+    if (e->multi_ok && e->multisweep) {
+        rc = run_multi(e, eps, max_sweeps);
+        if (rc) return rc;
+        e->stats.total_ms =
+            std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+        if (residual_out) *residual_out = e->last_ctl.last_res;
+        return BN_OK;
     }
     e->last_path = 0;
     if ((rc = step_begin(e))) return rc;
@@ -519,8 +529,10 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     int32_t batch = e->predicted_sweeps > 0 ? e->predicted_sweeps : 8;
     for (;;) {
         if (max_sweeps > 0) batch = std::min(batch, max_sweeps - launched);
-        if ((rc = ensure_events(e, 2 * size_t(batches + 1)))) return rc;
-        if (e->timing) HIPCHK(hipEventRecord(e->events[2 * batches], s));
+        if (e->timing) {
+            if ((rc = ensure_events(e, 2 * size_t(batches + 1)))) return rc;
+            HIPCHK(hipEventRecord(e->events[2 * batches], s));
+        }
         for (int32_t i = 0; i < batch; ++i) {
             if ((rc = step_sweep(e, launched + i, eps))) return rc;
             if ((rc = step_exchange(e, launched + i))) return rc;
@@ -530,6 +542,7 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
         ++batches;
         if ((rc = step_finish(e, launched, max_sweeps > 0 && launched >= max_sweeps, eps))) return rc;
         HIPCHK(hipStreamSynchronize(s));
+        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "finish kernel did not report (stale control block)");
         if (e->h_ctl->done != 0) break;
         batch = 8;
     }
@@ -549,15 +562,15 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     return BN_OK;
 }
 
-// Engine options: "persistent" = 0/1 (use the one-launch dataflow path when the model is eligible);
-// "timing" = 1/0 (HIP events around the sweep launches; off: sweep_kernel_ms reads 0).
+// Engine options: "timing" = 1/0 (HIP events around the sweep launches; off: sweep_kernel_ms reads 0);
+// "multisweep" = 1/0 (networks small enough run all their sweeps in ONE launch; 0 forces one launch per sweep).
 extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (!e || !name) return fail(BN_ERR_ARG, "null argument");
-    if (std::strcmp(name, "persistent") == 0) { e->persist_enabled = value != 0; return BN_OK; }
     if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
+    if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value != 0; return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
-// 1 when the last run used the persistent kernel, 0 per-sweep launches; <0 error
+// 1 when the last run was one launch for the whole run, 0 per-sweep launches; <0 error
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;
@@ -566,21 +579,22 @@ extern "C" int bn_bp_last_path(bn_engine* e) {
 // ---- single steps (diagnostics / tests) -------------------------------------------------------
 extern "C" int bn_bp_step_begin(bn_engine* e) {
     if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     return step_begin(e);
 }
 extern "C" int bn_bp_step_sweep(bn_engine* e, int32_t sweep, double eps) {
     if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     return step_sweep(e, sweep, eps);
 }
 extern "C" int bn_bp_step_finish(bn_engine* e, int32_t launched, int32_t final_batch, double eps, int32_t* done_out,
                                  int32_t* sweeps_out, double* residual_out) {
     if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     int rc = step_finish(e, launched, final_batch != 0, eps);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "finish kernel did not report (stale control block)");
     if (done_out) *done_out = e->h_ctl->done;
     if (sweeps_out) *sweeps_out = e->h_ctl->n_sweeps;
     if (residual_out) *residual_out = e->h_ctl->last_res;
@@ -630,7 +644,7 @@ extern "C" int bn_comm_init(bn_engine* e, const void* id128) {
     if (e->host_only) return fail(BN_ERR_STATE, "host-only engine");
     int rc = load_rccl();
     if (rc) return rc;
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     if (e->comm) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; }
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
@@ -647,7 +661,7 @@ extern "C" const double* bn_bp_beliefs_device(bn_engine* e) { return (e && !e->h
 extern "C" int bn_bp_copy_beliefs(bn_engine* e, double* beliefs_out) {
     if (!e || !beliefs_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run to copy from");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     HIPCHK(hipMemcpyAsync(beliefs_out, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n],
                           hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -669,7 +683,7 @@ extern "C" int bn_bp_residual_history(bn_engine* e, double* out, int32_t cap) {
     if (!e || !out || cap < 0) return fail(BN_ERR_ARG, "bad argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
     int32_t cnt = std::min({cap, e->last_ctl.n_sweeps, e->res_cap});
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     if (cnt > 0) HIPCHK(hipMemcpy(out, e->d_res_hist, sizeof(double) * cnt, hipMemcpyDeviceToHost));
     return cnt;
 }
@@ -677,7 +691,7 @@ extern "C" int bn_bp_residual_history(bn_engine* e, double* out, int32_t cap) {
 extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_msg_out) {
     if (!e || !pi_msg_out || !lambda_msg_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     std::vector<double> rec(std::max<int64_t>(e->plan.rec_total_doubles, 1));
     HIPCHK(hipMemcpy(rec.data(), e->d_rec[e->last_ctl.n_sweeps & 1], sizeof(double) * e->plan.rec_total_doubles,
                      hipMemcpyDeviceToHost));
@@ -747,7 +761,7 @@ extern "C" int bn_lw_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
     if (!e || !hist_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad evidence arguments");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     std::string err;
     int rc = lw_run(e->lw, e->plan, e->stream, ne, ev_node, ev_state, sample_begin, n_samples, seed, hist_out, err);
     if (rc) return fail(rc, err);
@@ -762,7 +776,7 @@ extern "C" int bn_lw_run_allreduce(bn_engine* e, int32_t ne, const int32_t* ev_n
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad evidence arguments");
     if (!e->comm) return fail(BN_ERR_COMM, "call bn_comm_init first");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     const uint64_t P = uint64_t(e->plan.nranks), r = uint64_t(e->plan.rank);
     const uint64_t lo = n_samples_total * r / P, hi = n_samples_total * (r + 1) / P;
     std::string err;
@@ -784,7 +798,7 @@ extern "C" int bn_rs_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad condition arguments");
     if (max_draw == 0) return fail(BN_ERR_ARG, "max_draw must be > 0 (the reference loops forever on impossible evidence)");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     std::string err;
     int rc = rs_run(e->lw, e->plan, e->stream, ne, ev_node, ev_state, sample_begin, n_accept, max_draw, seed,
                     counts_out, drawn_out, accepted_out, err);
@@ -874,7 +888,7 @@ extern "C" int bn_fit_cpt(const bn_model_desc* desc, int64_t n_patterns, const u
 extern "C" int bn_lw_states(bn_engine* e, uint64_t n, uint8_t* states_out, double* weights_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "host-only engine");
-    HIPCHK(hipSetDevice(e->device));
+    ON_DEVICE(e);
     std::string err;
     int rc = lw_states(e->lw, e->plan, e->stream, n, states_out, weights_out, err);
     if (rc) return fail(rc, err);

@@ -1,20 +1,11 @@
-// bn_kernels.hip -- hand-written gfx950 kernels for synchronous (Jacobi) loopy belief propagation.
+// bn_kernels.hip -- hand-written gfx950 kernels for synchronous (Jacobi) loopy belief propagation,
+// one launch per sweep.
 //
 // One launch = one iteration of the reference's while(true) loop
 // (bayesian/inference/belief_propagation.hpp:75-148): message phase (:78-88), node phase
 // (:91-101), residual (:105-131) and commit (:135-143, here a buffer swap) are fused into a
-// single pass in which every node's CPT is read exactly once.
-//
-// Work decomposition: one 64-lane wavefront per tile (bn_plan.hpp); lane = one node (G = 1).
-// A lane owns everything that is computed from its node's CPT and node vectors:
-//   child role  : pi(v)      = calculate_pi       (:174-200)
-//                 lambda-messages v -> each parent = calculate_lambda_k (:240-266)
-//   parent role : lambda(v)  = calculate_lambda   (:220-238)
-//                 pi-messages v -> each child     = calculate_pi_i     (:202-218)
-// All inputs come from the OLD buffers, all outputs go to the NEW buffers, exactly as the
-// reference reads pi_/lambda_/pi_i_/lambda_k_ and writes new_*.  Arithmetic is fp64 in the
-// reference's operation order; the file is compiled with -ffp-contract=off so the results are
-// bit-identical to the C restatement in oracle/bp_oracle.c.
+// single pass in which every node's CPT is read exactly once.  Work decomposition: one 64-lane
+// wavefront per tile (bn_plan.hpp); the tile code is in bn_tiles.hpp.
 //
 // Iteration 0 reads nothing but the CPT and the evidence: the reference's initial state (:33-73)
 // is all-ones messages, pi = lambda = 1 (roots: their CPT row), so it is synthesised in registers
@@ -22,1375 +13,11 @@
 //
 // Convergence is decided on the device: sweep s accumulates max|new-old| over messages into a
 // ring of 256 slots (atomic umax on the bit pattern of a non-negative double); ONE extra wave of
-// launch s+1 reduces them and raises `done` once maximum_difference < eps (:147); every later
+// launch s+1 reduces them and marks the run done once maximum_difference < eps (:147); every later
 // launch returns at once, so the host enqueues launches ahead without synchronising per sweep.
-#include <hip/hip_runtime.h>
-
-#include <cfloat>
-
-#include "bn_device.hpp"
+#include "bn_sweep.hpp"
 
 namespace bnmi {
-
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// NT = non-temporal output stores.  Measured on MI355X: on a working set that fits the 256 MiB
-// Infinity Cache plain stores are faster (the next sweep re-reads them from cache); on an
-// HBM-resident working set non-temporal stores are ~5 % faster.  The host picks per engine.
-template <bool NT>
-__device__ __forceinline__ void bn_store(double2_t* p, double2_t v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
-
-// The CPT image is read exactly once per sweep and never re-used inside a launch.  Measured on
-// MI355X: when the working set is HBM-resident (NT policy) streaming it non-temporally is +6 %
-// (it no longer evicts the message records, which two waves share, from the XCD L2); when the
-// working set fits the Infinity Cache the plain load is 8 % faster.
-template <bool NT>
-__device__ __forceinline__ double2_t cpt_load(const double2_t* p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-
-// The four state pointers of one iteration, resolved on the host (a dynamically indexed kernarg
-// array would push the whole argument struct into scratch memory).
-struct IO {
-    const double* rec_in;
-    double* rec_out;
-    const double* node_in;
-    double* node_out;
-    bool first;  // iteration 0: see the file comment
-};
-
-// ---------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long wave_umax(unsigned long long x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        unsigned long long o = __shfl_xor(x, off, 64);
-        x = o > x ? o : x;
-    }
-    return x;
-}
-
-// std::max(md, d) of libstdc++: (md < d) ? d : md -- a NaN d is dropped (:110-128)
-__device__ __forceinline__ double res_acc(double md, double d) { return (md < d) ? d : md; }
-
-template <int K>
-__device__ __forceinline__ void normalize_k(double (&t)[K]) {  // :298-311, no zero guard
-    double sum = 0;
-#pragma unroll
-    for (int i = 0; i < K; ++i) sum += t[i];
-#pragma unroll
-    for (int i = 0; i < K; ++i) t[i] /= sum;
-}
-
-__host__ __device__ constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
-
-// The residual slots of rank q inside a record buffer's exchange region (bit patterns of
-// non-negative doubles; a row is accumulated with atomic umax by the sweep that WRITES the buffer).
-__device__ __forceinline__ unsigned long long* res_row(const BpBuffers& b, const double* rec, int q) {
-    return reinterpret_cast<unsigned long long*>(const_cast<double*>(rec)) +
-           2 * (b.g_base + int64_t(q) * b.seg_d2 + b.seg_data_d2);
-}
-
-// maximum_difference of the sweep that wrote `rec`: max over every rank's slots (after the
-// all-gather each rank holds all rows, so all ranks compute the same value).
-__device__ __forceinline__ double reduce_residual(const BpBuffers& b, const double* rec, int lane) {
-    unsigned long long m = 0;
-    for (int q = 0; q < b.nranks; ++q) {
-        const unsigned long long* row = res_row(b, rec, q);
-#pragma unroll
-        for (int i = 0; i < kResSlots / kWave; ++i) {
-            unsigned long long x = __hip_atomic_load(row + i * kWave + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m = x > m ? x : m;
-        }
-    }
-    m = wave_umax(m);
-    double r = __longlong_as_double((long long)m);
-    return r < DBL_MIN ? DBL_MIN : r;  // maximum_difference starts at numeric_limits<double>::min() (:105)
-}
-
-__device__ __forceinline__ void publish_residual(const BpBuffers& b, double* rec_out, int slot, double wres, int lane) {
-    unsigned long long bits = (unsigned long long)__double_as_longlong(wres);
-    bits = wave_umax(bits);
-    if (lane == 0 && bits != 0)
-        __hip_atomic_fetch_max(res_row(b, rec_out, b.rank) + (slot & (kResSlots - 1)), bits, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Location of one edge's two messages (bn_plan.hpp MsgRef), double2 units from the buffer start.
-struct Loc {
-    int64_t pi, lam;
-    int32_t stride;
-    bool has;
-};
-__device__ __forceinline__ Loc decode_ref(MsgRef r, int h) {
-    Loc l;
-    l.has = r.pi >= 0;
-    const bool cut = r.lam < 0;
-    const int64_t lam = cut ? int64_t(~r.lam) : int64_t(r.lam);
-    l.pi = l.has ? r.pi : 0;
-    l.lam = l.has ? lam : 0;
-    l.stride = !l.has ? 0 : (cut ? 1 : int32_t((lam - r.pi) / h));
-    return l;
-}
-
-// striped element address helpers (doubles): element i of a vector whose chunks are `stride2`
-// double2 apart, for node-lane nl
-__device__ __forceinline__ int64_t vidx(int chunk0, int i, int stride2, int nl) {
-    return int64_t(chunk0 + (i >> 1)) * (stride2 * 2) + nl * 2 + (i & 1);
-}
-// element i of the pi-message / lambda-message of an edge (doubles from the buffer start)
-__device__ __forceinline__ int64_t pidx(const Loc& l, int i) { return (l.pi + int64_t(i >> 1) * l.stride) * 2 + (i & 1); }
-__device__ __forceinline__ int64_t lidx(const Loc& l, int i) { return (l.lam + int64_t(i >> 1) * l.stride) * 2 + (i & 1); }
-
-// ---------------------------------------------------------------------------------------------
-// parent role for any shape: lambda(v) and the pi-messages to the children, operands re-read
-// through L1.  Used by the generic path and by the register path when a tile has more
-// children per node than it keeps in registers.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double parent_role_generic(const BpBuffers& b, const IO& io, const TileDesc& td, int kv, int kvp,
-                                                     int nl, bool frozen, bool flat_cpt = false) {
-    const int npt = td.npt, half = kvp >> 1;
-    const double* node_in = io.node_in + td.node_base;
-    double* node_out = io.node_out + td.node_base;
-    const MsgRef* orf = b.out_refs + td.out_base + nl;
-    const bool synth = io.first && !frozen;  // initial state instead of memory
-    auto REF = [&](int c) { return decode_ref(orf[int64_t(c) * npt], half); };
-    auto LK = [&](const Loc& l, int i) { return io.first ? 1.0 : io.rec_in[lidx(l, i)]; };
-    auto PIV = [&](int i) {
-        if (!synth) return node_in[vidx(0, i, npt, nl)];
-        if (td.m != 0) return 1.0;
-        // a root starts from its CPT row (:58-64); flat tiles keep entry i in lane i, slot 0
-        return flat_cpt ? b.cpt[td.cpt_base + (int64_t(nl) * (kWave / npt) + i) * 2] : b.cpt[td.cpt_base + int64_t(i >> 1) * 128 + nl * 2 + (i & 1)];
-    };
-    double wres = 0.0;
-    // lambda(v): product of the children's lambda-messages from 1.0, ascending child order (:229-235)
-    if (frozen) {
-        for (int i = 0; i < kv; ++i) node_out[vidx(half, i, npt, nl)] = node_in[vidx(half, i, npt, nl)];
-    } else {
-        double sum = 0;
-        for (int i = 0; i < kv; ++i) {
-            double acc = 1.0;
-            for (int c = 0; c < td.cmax; ++c) {
-                const Loc l = REF(c);
-                if (l.has) acc *= LK(l, i);
-            }
-            node_out[vidx(half, i, npt, nl)] = acc;
-            sum += acc;
-        }
-        for (int i = 0; i < kv; ++i) node_out[vidx(half, i, npt, nl)] = node_out[vidx(half, i, npt, nl)] / sum;
-    }
-    // pi-message to child c: pi(v) times the OTHER children's lambda-messages (:207-214)
-    for (int c = 0; c < td.cmax; ++c) {
-        const Loc lc = REF(c);
-        if (!lc.has) continue;
-        double sum = 0;
-        for (int i = 0; i < kv; ++i) {
-            double acc = PIV(i);
-            for (int x = 0; x < td.cmax; ++x) {
-                if (x == c) continue;
-                const Loc lx = REF(x);
-                if (lx.has) acc *= LK(lx, i);
-            }
-            io.rec_out[pidx(lc, i)] = acc;
-            sum += acc;
-        }
-        for (int i = 0; i < kv; ++i) {
-            const double nv = io.rec_out[pidx(lc, i)] / sum;
-            io.rec_out[pidx(lc, i)] = nv;
-            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : io.rec_in[pidx(lc, i)])));
-        }
-    }
-    return wres;
-}
-
-// ---------------------------------------------------------------------------------------------
-// parent role with up to RC children held in registers (k = K for node and messages): each
-// child's lambda-message is loaded ONCE; the O(c^2) products of calculate_pi_i (:207-214) then run
-// on registers in the reference's order (ascending child, skipping the target).  Caller passes
-// pi(v) / lambda(v) as it read them (or synthesised them in iteration 0).
-// ---------------------------------------------------------------------------------------------
-template <int K, int RC, bool NT>
-__device__ __forceinline__ double parent_role_regs(const BpBuffers& b, const IO& io, const TileDesc& td, int nl,
-                                                   bool frozen, const double* piv, const double* lav) {
-    constexpr int KP = (K + 1) & ~1, H = KP / 2;
-    const int npt = td.npt;
-    const MsgRef* orf = b.out_refs + td.out_base + nl;
-    const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
-    double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
-    double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + nl;
-    double wres = 0.0;
-    MsgRef oref[RC];  // kept packed (8 B per child) and decoded at each use: registers matter here
-    double lkc[RC][KP];
-#pragma unroll
-    for (int c = 0; c < RC; ++c) {
-        oref[c] = MsgRef{-1, 0};
-        if (c < td.cmax) oref[c] = orf[int64_t(c) * npt];
-    }
-#pragma unroll
-    for (int c = 0; c < RC; ++c) {
-#pragma unroll
-        for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
-        if (c < td.cmax && !io.first) {
-            const Loc l = decode_ref(oref[c], H);
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const double2_t y = rec_in2[l.lam + h * l.stride];
-                lkc[c][2 * h] = l.has ? y.x : 1.0;
-                lkc[c][2 * h + 1] = l.has ? y.y : 1.0;
-            }
-        }
-    }
-    {   // lambda(v) (:220-238)
-        double t[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double acc = 1.0;
-#pragma unroll
-            for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
-            t[i] = acc;
-        }
-        normalize_k<K>(t);
-        double l[KP];
-#pragma unroll
-        for (int i = 0; i < KP; ++i) l[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) l[i] = frozen ? lav[i] : t[i];
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            double2_t z;
-            z.x = l[2 * h]; z.y = l[2 * h + 1];
-            bn_store<NT>(&nout[(H + h) * npt], z);
-        }
-    }
-    // pi-message to child c (:202-218): pi(v) * the OTHER children's lambda-messages, ascending.
-    // The factors before c are a running prefix shared by all later children (same multiplication
-    // sequence as starting over from pi(v)); children past cmax hold 1.0 and are skipped (x * 1.0 == x).
-    double pre[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) pre[i] = piv[i];
-#pragma unroll
-    for (int c = 0; c < RC; ++c) {
-        if (c < td.cmax) {  // wave-uniform
-            double u[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) u[i] = pre[i];
-#pragma unroll
-            for (int x = c + 1; x < RC; ++x)
-                if (x < td.cmax) {
-#pragma unroll
-                    for (int i = 0; i < K; ++i) u[i] *= lkc[x][i];
-                }
-#pragma unroll
-            for (int i = 0; i < K; ++i) pre[i] *= lkc[c][i];
-            normalize_k<K>(u);
-            const Loc l = decode_ref(oref[c], H);
-            if (l.has) {
-                double o[KP], old[KP];
-#pragma unroll
-                for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
-                if (!io.first) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const double2_t x = rec_in2[l.pi + h * l.stride];
-                        old[2 * h] = x.x; old[2 * h + 1] = x.y;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    o[i] = u[i];
-                    wres = res_acc(wres, fabs(u[i] - old[i]));
-                }
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    double2_t y;
-                    y.x = o[2 * h]; y.y = o[2 * h + 1];
-                    bn_store<NT>(&rec_out2[l.pi + h * l.stride], y);
-                }
-            }
-        }
-    }
-    return wres;
-}
-
-// parent role for a node of arity K with any number of children: registers up to 16, memory beyond
-template <int K, bool NT, int RCMAX>
-__device__ __forceinline__ double parent_role_any(const BpBuffers& b, const IO& io, const TileDesc& td, int nl,
-                                                  bool frozen, const double* piv, const double* lav) {
-    if (td.cmax <= 4) return parent_role_regs<K, 4, NT>(b, io, td, nl, frozen, piv, lav);
-    if (td.cmax <= 8) return parent_role_regs<K, 8, NT>(b, io, td, nl, frozen, piv, lav);
-    if constexpr (RCMAX >= 16) {
-        if (td.cmax <= 16) return parent_role_regs<K, 16, NT>(b, io, td, nl, frozen, piv, lav);
-    } else if constexpr (RCMAX >= 12) {
-        if (td.cmax <= 12) return parent_role_regs<K, 12, NT>(b, io, td, nl, frozen, piv, lav);
-    }
-    return parent_role_generic(b, io, td, K, (K + 1) & ~1, nl, frozen);
-}
-
-// ---------------------------------------------------------------------------------------------
-// generic tile: any arities, runtime loops, one lane per node.  Correctness path for shapes
-// without a register-resident instantiation.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& c, int lane) {
-    double wres = 0.0;
-    if (lane >= td.n_nodes) return wres;
-    const double* cpt = b.cpt + td.cpt_base + lane * 2;
-    const double* node_in = io.node_in + td.node_base + lane * 2;
-    double* node_out = io.node_out + td.node_base + lane * 2;
-    const bool frozen = b.frozen[td.slot_base + lane] != 0;
-    const bool synth = io.first && !frozen;
-    const int kv = c.kv, m = c.m, rows = c.rows, hv = c.kvp >> 1;
-    // in-edge j: inside the tile's record block, or wherever the reference says (boundary tile)
-    auto IN = [&](int j) {
-        if (td.in_ref_base >= 0) return decode_ref(b.in_refs[td.in_ref_base + int64_t(j) * kWave + lane], c.kpp[j] >> 1);
-        Loc l;
-        l.has = true;
-        l.pi = (td.rec_base + c.rec_off[j]) / 2 + lane;
-        l.stride = kWave;
-        l.lam = l.pi + int64_t(c.kpp[j] >> 1) * kWave;
-        return l;
-    };
-    auto CPT = [&](int q) { return cpt[int64_t(q >> 1) * 128 + (q & 1)]; };
-    auto PIM = [&](int j, int s) { return io.first ? 1.0 : io.rec_in[pidx(IN(j), s)]; };
-    auto NIDX = [&](int part, int i) { return int64_t(part * hv + (i >> 1)) * 128 + (i & 1); };
-    auto LAV = [&](int i) { return synth ? 1.0 : node_in[NIDX(1, i)]; };
-
-    // pi(v) (:174-200): assignment ascending, value = cpt * pi-messages in ascending parent order
-    if (frozen) {
-        for (int i = 0; i < kv; ++i) node_out[NIDX(0, i)] = node_in[NIDX(0, i)];
-    } else {
-        double sum = 0;
-        for (int i = 0; i < kv; ++i) {
-            double acc = 0.0;
-            for (int cond = 0; cond < rows; ++cond) {
-                double value = CPT(i * rows + cond);
-                for (int j = 0; j < m; ++j) value *= PIM(j, (cond / c.cstride[j]) % c.kp[j]);
-                acc += value;
-            }
-            node_out[NIDX(0, i)] = acc;
-            sum += acc;
-        }
-        for (int i = 0; i < kv; ++i) node_out[NIDX(0, i)] = node_out[NIDX(0, i)] / sum;
-    }
-    // lambda-message to parent jt (:240-266): for each target state, child state outer and
-    // assignment inner -- the order in which the reference adds into matrix[0][cond.at(target)]
-    for (int jt = 0; jt < m; ++jt) {
-        const int kt = c.kp[jt];
-        const Loc lt = IN(jt);
-        double sum = 0;
-        for (int ct = 0; ct < kt; ++ct) {
-            double acc = 0.0;
-            for (int i = 0; i < kv; ++i) {
-                const double times = LAV(i);
-                for (int cond = 0; cond < rows; ++cond) {
-                    if ((cond / c.cstride[jt]) % kt != ct) continue;
-                    double value = times * CPT(i * rows + cond);
-                    for (int j = 0; j < m; ++j)
-                        if (j != jt) value *= PIM(j, (cond / c.cstride[j]) % c.kp[j]);
-                    acc += value;
-                }
-            }
-            io.rec_out[lidx(lt, ct)] = acc;
-            sum += acc;
-        }
-        for (int ct = 0; ct < kt; ++ct) {
-            const double nv = io.rec_out[lidx(lt, ct)] / sum;
-            io.rec_out[lidx(lt, ct)] = nv;
-            wres = res_acc(wres, fabs(nv - (io.first ? 1.0 : io.rec_in[lidx(lt, ct)])));
-        }
-    }
-    return res_acc(wres, parent_role_generic(b, io, td, kv, c.kvp, lane, frozen));
-}
-
-// ---------------------------------------------------------------------------------------------
-// register-resident tile: node and parents share arity K, M parents, whole CPT (K^(M+1) <= 64
-// doubles) in VGPRs, every loop unrolled at compile time, 16-byte lane-striped loads.
-// RC = children per node held in registers (the tile's cmax <= RC; RC = 0: parent role elsewhere).
-// ---------------------------------------------------------------------------------------------
-// IND: boundary tile (sharded run) -- in-edge records are reached through MsgRefs; otherwise
-// they are addressed arithmetically inside the tile's own block with immediate offsets.
-template <int K, int M, int RC, bool NT, bool IND>
-__device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    constexpr int KP = (K + 1) & ~1, H = KP / 2;
-    constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
-    constexpr int CB = (M > 0) ? C / K : 0;  // assignments per lambda bucket and own state
-    double wres = 0.0;
-    if (lane < td.n_nodes) {
-        // ---- parent-role loads FIRST: the out-edge references head a dependent chain
-        // (reference -> child record), so they are issued before the 32 CPT loads stream in
-        const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
-        double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
-        // out-edge references, then the children's lambda-messages.
-        // A missing child reads record 0 and contributes 1.0 (x * 1.0 == x exactly).
-        const MsgRef* orf = b.out_refs + td.out_base + lane;
-        Loc oref[RC > 0 ? RC : 1];
-        double lkc[RC > 0 ? RC : 1][KP];
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            MsgRef r{-1, 0};
-            if (c < td.cmax) r = orf[c * kWave];
-            oref[c] = decode_ref(r, H);
-        }
-
-        // ---- child-role loads: CPT, pi-messages from the parents, pi(v), lambda(v)
-        const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
-        double cpt[SP];
-#pragma unroll
-        for (int q = 0; q < SP / 2; ++q) {
-            const double2_t x = cpt_load<NT>(&cp[q * kWave]);
-            cpt[2 * q] = x.x;
-            cpt[2 * q + 1] = x.y;
-        }
-        // the children's lambda-messages (second hop of the reference chain)
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-#pragma unroll
-            for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
-            if (c < td.cmax && !io.first) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const double2_t y = rec_in2[oref[c].lam + h * oref[c].stride];
-                    lkc[c][2 * h] = oref[c].has ? y.x : 1.0;
-                    lkc[c][2 * h + 1] = oref[c].has ? y.y : 1.0;
-                }
-            }
-        }
-        // in-edge j's record: inside the tile's own block (arithmetic), or -- boundary tile, some
-        // parent lives on another rank -- wherever its reference says (exchange region for cut edges)
-        Loc in[M > 0 ? M : 1];
-        if constexpr (IND) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) in[j] = decode_ref(b.in_refs[td.in_ref_base + j * kWave + lane], H);
-        }
-        const int64_t rbase = td.rec_base / 2 + lane;  // this lane's slot in the tile's record block
-        // chunk h of the pi-message (part 0) / lambda-message (part 1) of in-edge j
-        auto in_idx = [&](int j, int part, int h) -> int64_t {
-            if constexpr (IND) return (part ? in[j].lam : in[j].pi) + h * in[j].stride;
-            else return rbase + ((j * 2 + part) * H + h) * kWave;
-        };
-        const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + lane;
-        double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + lane;
-        const bool frozen = b.frozen[td.slot_base + lane] != 0;
-        double pim[M > 0 ? M : 1][KP];
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-#pragma unroll
-            for (int i = 0; i < KP; ++i) pim[j][i] = 1.0;
-        if (!io.first) {
-#pragma unroll
-            for (int j = 0; j < M; ++j)
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const double2_t x = rec_in2[in_idx(j, 0, h)];
-                    pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
-                }
-        }
-        double piv[KP], lav[KP];
-#pragma unroll
-        for (int i = 0; i < KP; ++i) {  // initial state (:38-64): roots start from their CPT row
-            piv[i] = (M == 0 && i < K) ? cpt[i] : 1.0;
-            lav[i] = 1.0;
-        }
-        if (!io.first || frozen) {  // evidence nodes hold their vector as pi and lambda (:68-73)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
-                piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
-                lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
-            }
-        }
-
-        // ---- child role.  calculate_pi (:174-200): pi[i] = sum over assignments (ascending) of
-        // cpt * pi-messages (ascending parent order).  calculate_lambda_k (:240-266): bucket
-        // out[jt][ct] receives, own state outer and assignment inner, (lambda[i] * cpt) * the
-        // OTHER parents' pi-messages.  Each accumulator sees its terms in exactly that order;
-        // the K + M*K independent chains are interleaved round-robin.
-        double pin[K];
-        double out[M > 0 ? M : 1][K];
-#pragma unroll
-        for (int jt = 0; jt < M; ++jt)
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) out[jt][ct] = 0.0;
-#pragma unroll
-        for (int ib = 0; ib < K; ++ib) {  // own state i: the CPT image is i-major
-            if constexpr (M == 0) {
-                pin[ib] = 0.0 + cpt[ib];
-            } else {
-                double acc = 0.0;
-                double tc[C];  // lambda(v)[i] * cpt[cond][i], shared by the M lambda-messages
-#pragma unroll
-                for (int c = 0; c < C; ++c) tc[c] = lav[ib] * cpt[ib * C + c];
-#pragma unroll
-                for (int rr = 0; rr < CB; ++rr) {
-#pragma unroll
-                    for (int x = 0; x < K; ++x) {  // pi chain: assignments rr*K .. rr*K+K-1
-                        const int cond = rr * K + x;
-                        double value = cpt[ib * C + cond];
-#pragma unroll
-                        for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
-                        acc += value;
-                    }
-#pragma unroll
-                    for (int jt = 0; jt < M; ++jt) {
-                        const int stride = ipow(K, M - 1 - jt);
-#pragma unroll
-                        for (int ct = 0; ct < K; ++ct) {  // rr-th assignment whose digit jt equals ct
-                            const int cond = (rr / stride) * stride * K + ct * stride + (rr % stride);
-                            double value = tc[cond];
-#pragma unroll
-                            for (int j = 0; j < M; ++j)
-                                if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
-                            out[jt][ct] += value;
-                        }
-                    }
-                }
-                pin[ib] = acc;
-            }
-        }
-
-        // ---- parent role: lambda(v) (:220-238), products in ascending child order from 1.0
-        double lan[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            double acc = 1.0;
-#pragma unroll
-            for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
-            lan[i] = acc;
-        }
-        // ---- normalise everything (:298-311), residual (:105-131), stores
-        normalize_k<K>(pin);
-        normalize_k<K>(lan);
-#pragma unroll
-        for (int jt = 0; jt < M; ++jt) normalize_k<K>(out[jt]);
-        {
-            double o[KP], l[KP];
-#pragma unroll
-            for (int i = 0; i < KP; ++i) { o[i] = 0.0; l[i] = 0.0; }
-#pragma unroll
-            for (int i = 0; i < K; ++i) {  // evidence nodes keep pi and lambda (:177, :223)
-                o[i] = frozen ? piv[i] : pin[i];
-                l[i] = frozen ? lav[i] : lan[i];
-            }
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t y, z;
-                y.x = o[2 * h]; y.y = o[2 * h + 1];
-                z.x = l[2 * h]; z.y = l[2 * h + 1];
-                bn_store<NT>(&nout[h * kWave], y);
-                if (RC > 0) bn_store<NT>(&nout[(H + h) * kWave], z);
-            }
-        }
-#pragma unroll
-        for (int jt = 0; jt < M; ++jt) {
-            double o[KP], old[KP];
-#pragma unroll
-            for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
-            if (!io.first) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {  // previous lambda-message of this edge, for the residual
-                    const double2_t y = rec_in2[in_idx(jt, 1, h)];
-                    old[2 * h] = y.x; old[2 * h + 1] = y.y;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                o[i] = out[jt][i];
-                wres = res_acc(wres, fabs(out[jt][i] - old[i]));
-            }
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t y;
-                y.x = o[2 * h]; y.y = o[2 * h + 1];
-                bn_store<NT>(&rec_out2[in_idx(jt, 1, h)], y);
-            }
-        }
-        // pi-message to child c (:202-218): pi(v) times the OTHER children's lambda-messages
-#pragma unroll
-        for (int c = 0; c < RC; ++c) {
-            if (c < td.cmax) {  // wave-uniform
-                double u[K];
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    double acc = piv[i];
-#pragma unroll
-                    for (int x = 0; x < RC; ++x)
-                        if (x != c) acc *= lkc[x][i];
-                    u[i] = acc;
-                }
-                normalize_k<K>(u);
-                if (oref[c].has) {
-                    double o[KP], old[KP];
-#pragma unroll
-                    for (int i = 0; i < KP; ++i) { o[i] = 0.0; old[i] = 1.0; }
-                    if (!io.first) {
-#pragma unroll
-                        for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
-                            const double2_t x = rec_in2[oref[c].pi + h * oref[c].stride];
-                            old[2 * h] = x.x; old[2 * h + 1] = x.y;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < K; ++i) {
-                        o[i] = u[i];
-                        wres = res_acc(wres, fabs(u[i] - old[i]));
-                    }
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        double2_t y;
-                        y.x = o[2 * h]; y.y = o[2 * h + 1];
-                        bn_store<NT>(&rec_out2[oref[c].pi + h * oref[c].stride], y);
-                    }
-                }
-            }
-        }
-        if constexpr (RC == 0)  // more children than the fused path holds: separate parent role
-            wres = res_acc(wres, parent_role_any<K, NT, 16>(b, io, td, lane, frozen, piv, lav));
-    }
-    return wres;
-}
-
-// ---------------------------------------------------------------------------------------------
-// lane-group tile: k = 4, M = D + 2 parents, G = 4^D lanes per node (NPT = 64 / G nodes per
-// wave).  Lane (nl, g) owns the assignments whose D leading parents are in state digits(g) -- 64
-// CPT entries, the two trailing parents and the own state -- streams them through registers like
-// the register-resident path, and the partial sums are combined inside the G-lane group with
-// shuffles.  Products keep the reference's ascending-parent order (:190-193, :250-258); the SUM
-// over assignments is re-associated across lanes, so results agree with the reference to
-// rounding (not bit-for-bit; with >= 3 parents the reference's own products are unordered, :253).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double shfl_xor_d(double x, int mask) { return __shfl_xor(x, mask, kWave); }
-__device__ __forceinline__ double shfl_d(double x, int src) { return __shfl(x, src, kWave); }
-__device__ __forceinline__ double pick4(const double (&v)[4], int d) {
-    return d == 0 ? v[0] : (d == 1 ? v[1] : (d == 2 ? v[2] : v[3]));
-}
-
-template <int D, bool NT>
-__device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    constexpr int K = 4, H = 2, M = D + 2;
-    constexpr int G = 1 << (2 * D), NPT = kWave / G;
-    const int nl = lane / G, g = lane % G;
-    const bool active = nl < td.n_nodes;
-    double wres = 0.0;
-
-    // ---- loads: this lane's 64 CPT entries (i-major: q = i*16 + c_{M-2}*4 + c_{M-1})
-    const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
-    double cpt[64];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const double2_t x = cpt_load<NT>(&cp[q * kWave]);
-        cpt[2 * q] = x.x;
-        cpt[2 * q + 1] = x.y;
-    }
-    const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
-    double2_t* rec_out2 = reinterpret_cast<double2_t*>(io.rec_out);
-    const int nlc = active ? nl : 0;  // inactive groups shadow node 0 and write nothing
-    Loc in[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        in[j].has = true;
-        in[j].pi = td.rec_base / 2 + (j * 2 * H) * NPT + nlc;
-        in[j].lam = in[j].pi + H * NPT;
-        in[j].stride = NPT;
-    }
-    if (td.in_ref_base >= 0) {
-#pragma unroll
-        for (int j = 0; j < M; ++j) in[j] = decode_ref(b.in_refs[td.in_ref_base + j * NPT + nlc], H);
-    }
-    const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + nlc;
-    double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + nlc;
-    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
-    double pim[M][K];
-#pragma unroll
-    for (int j = 0; j < M; ++j)
-#pragma unroll
-        for (int i = 0; i < K; ++i) pim[j][i] = 1.0;
-    if (!io.first) {
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const double2_t x = rec_in2[in[j].pi + h * in[j].stride];
-                pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
-            }
-    }
-    double piv[K], lav[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }
-    if (!io.first || frozen) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const double2_t x = nin[h * NPT], y = nin[(H + h) * NPT];
-            piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
-            lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
-        }
-    }
-    // ---- parent role (:202-238), spread over the group's lanes: lane g serves children g, g+G, ...
-    // of node nl.  It needs only the OLD pi(v)/lambda(v) and the children's records, so its loads
-    // ride behind the CPT stream and its arithmetic is cmax steps for the whole group instead of
-    // cmax^2 on one lane.  Every product keeps the reference's ascending-child order.
-    constexpr int CPL = G >= 16 ? 1 : 2;  // children per lane
-    const bool par_fast = td.cmax <= G * CPL;
-    if (par_fast) {
-        const MsgRef* orf = b.out_refs + td.out_base + nlc;
-        Loc cl[CPL];
-        double clk[CPL][K], cold[CPL][K];
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            const int c = g + q * G;
-            MsgRef r{-1, 0};
-            if (active && c < td.cmax) r = orf[int64_t(c) * NPT];
-            cl[q] = decode_ref(r, H);
-        }
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-#pragma unroll
-            for (int i = 0; i < K; ++i) { clk[q][i] = 1.0; cold[q][i] = 1.0; }
-            if (!io.first) {  // a missing child reads record 0 and contributes 1.0
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const double2_t y = rec_in2[cl[q].lam + h * cl[q].stride];
-                    const double2_t x = rec_in2[cl[q].pi + h * cl[q].stride];
-                    clk[q][2 * h] = cl[q].has ? y.x : 1.0; clk[q][2 * h + 1] = cl[q].has ? y.y : 1.0;
-                    cold[q][2 * h] = x.x; cold[q][2 * h + 1] = x.y;
-                }
-            }
-        }
-        double lam_all[K], msg[CPL][K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            lam_all[i] = 1.0;
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) msg[q][i] = piv[i];
-        }
-        for (int x = 0; x < td.cmax; ++x) {  // ascending child order; wave-uniform trip count
-            const int qx = x / G, src = nl * G + (x % G);
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                double mine = clk[0][i];
-#pragma unroll
-                for (int q = 1; q < CPL; ++q) mine = (qx == q) ? clk[q][i] : mine;
-                const double val = shfl_d(mine, src);
-                lam_all[i] *= val;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q)
-                    if (g + q * G != x) msg[q][i] *= val;
-            }
-        }
-        if (active && g == 0) {  // lambda(v) (:220-238)
-            normalize_k<K>(lam_all);
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t z;
-                z.x = frozen ? lav[2 * h] : lam_all[2 * h];
-                z.y = frozen ? lav[2 * h + 1] : lam_all[2 * h + 1];
-                bn_store<NT>(&nout[(H + h) * NPT], z);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-            if (active && cl[q].has) {
-                normalize_k<K>(msg[q]);
-#pragma unroll
-                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(msg[q][i] - cold[q][i]));
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    double2_t y;
-                    y.x = msg[q][2 * h]; y.y = msg[q][2 * h + 1];
-                    bn_store<NT>(&rec_out2[cl[q].pi + h * cl[q].stride], y);
-                }
-            }
-        }
-    }
-
-    // pi-message entries of the lane-fixed parents
-    double pfix[D];
-#pragma unroll
-    for (int j = 0; j < D; ++j) pfix[j] = pick4(pim[j], (g >> (2 * (D - 1 - j))) & 3);
-
-    // ---- partial sums over this lane's 64 entries
-    double pp[K];          // pi(v)[i]
-    double ol[2][K];       // lambda-messages to the two trailing parents, by target state
-    double sf[D];          // lambda-messages to the leading parents: this lane's own bucket
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ct = 0; ct < K; ++ct) ol[t][ct] = 0.0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) sf[j] = 0.0;
-#pragma unroll
-    for (int ib = 0; ib < K; ++ib) {
-        double acc = 0.0;
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) {
-            const int ca = cl >> 2, cb = cl & 3;  // states of parents M-2 and M-1
-            const double e = cpt[ib * 16 + cl];
-            // calculate_pi: cpt * pi-messages, ascending parent order
-            double v = e;
-#pragma unroll
-            for (int j = 0; j < D; ++j) v *= pfix[j];
-            v *= pim[M - 2][ca];
-            v *= pim[M - 1][cb];
-            acc += v;
-            // calculate_lambda_k: (lambda[i] * cpt) * the OTHER parents' pi-messages, ascending
-            const double tc = lav[ib] * e;
-            double pre = tc;  // shared prefix over the leading parents
-#pragma unroll
-            for (int j = 0; j < D; ++j) pre *= pfix[j];
-            ol[0][ca] += pre * pim[M - 1][cb];
-            ol[1][cb] += pre * pim[M - 2][ca];
-#pragma unroll
-            for (int jt = 0; jt < D; ++jt) {
-                double w = tc;
-#pragma unroll
-                for (int j = 0; j < D; ++j)
-                    if (j != jt) w *= pfix[j];
-                w *= pim[M - 2][ca];
-                w *= pim[M - 1][cb];
-                sf[jt] += w;
-            }
-        }
-        pp[ib] = acc;
-    }
-
-    // ---- combine inside the G-lane group
-#pragma unroll
-    for (int mask = 1; mask < G; mask <<= 1) {
-#pragma unroll
-        for (int i = 0; i < K; ++i) pp[i] += shfl_xor_d(pp[i], mask);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) ol[t][ct] += shfl_xor_d(ol[t][ct], mask);
-    }
-    // leading parent jt: sum over the lanes that share digit jt (all other lane digits), then
-    // collect the four buckets from the lanes whose other digits are zero
-    double of[D][K];
-#pragma unroll
-    for (int jt = 0; jt < D; ++jt) {
-        double x = sf[jt];
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (j != jt) {
-                x += shfl_xor_d(x, 1 << (2 * (D - 1 - j)));
-                x += shfl_xor_d(x, 2 << (2 * (D - 1 - j)));
-            }
-#pragma unroll
-        for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
-    }
-
-    // ---- the group's first lane finishes the node: normalise, residual, stores, parent role
-    if (active && g == 0) {
-        normalize_k<K>(pp);
-        {
-            double2_t y0, y1;
-            y0.x = frozen ? piv[0] : pp[0]; y0.y = frozen ? piv[1] : pp[1];
-            y1.x = frozen ? piv[2] : pp[2]; y1.y = frozen ? piv[3] : pp[3];
-            bn_store<NT>(&nout[0 * NPT], y0);
-            bn_store<NT>(&nout[1 * NPT], y1);
-        }
-#pragma unroll
-        for (int jt = 0; jt < M; ++jt) {
-            double o[K];
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) o[ct] = jt < D ? of[jt < D ? jt : 0][ct] : ol[jt >= D ? jt - D : 0][ct];
-            normalize_k<K>(o);
-            double old[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) old[i] = 1.0;
-            if (!io.first) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const double2_t y = rec_in2[in[jt].lam + h * in[jt].stride];
-                    old[2 * h] = y.x; old[2 * h + 1] = y.y;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - old[i]));
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t y;
-                y.x = o[2 * h]; y.y = o[2 * h + 1];
-                bn_store<NT>(&rec_out2[in[jt].lam + h * in[jt].stride], y);
-            }
-        }
-        if (io.first && !frozen) {  // initial state (:38-41); a group node always has parents
-#pragma unroll
-            for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }
-        }
-        if (!par_fast) wres = res_acc(wres, parent_role_any<K, NT, 12>(b, io, td, nl, frozen, piv, lav));
-    }
-    return wres;
-}
-
-// ---------------------------------------------------------------------------------------------
-// flat tile: ANY arities, a group of G = 8..64 lanes per node (NPT = 64 / G nodes per wavefront).
-// Entry e of the reference's row-major CPT (parent assignment slowest, own state fastest) sits in
-// lane e % G of the node's group, slot e / G.  Vectors
-// live spread over the lanes: lane x of `pim` / `out` is element x of the in-edge messages
-// concatenated in parent order, lane i of piv / lav / pin is element i of the node vectors.
-//   S <= 128 entries: every term is staged in LDS and each accumulator lane adds its own terms in
-//     the reference's order (own state outer, assignment inner, :174-200, :240-266) -- bit-identical
-//     to the reference wherever the reference is deterministic (<= 2 parents);
-//   larger tables: LDS fp64 atomics (sum re-associated, agrees to rounding).  (Tried: the ordered
-//     scheme for up to 1024 entries, re-deriving the factors in every pass -- 1.5x slower than the
-//     atomics at 243 and 625 entries.)
-// Products always keep the reference's ascending parent / child order.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFlatOrdered = 128;  // tables up to this many entries take the ordered path
-constexpr int kFlatCopies = 8;     // atomics path: accumulator copies (lane & 7), fewer same-address conflicts
-constexpr int kFlatW = 128 * kFlatCopies;  // doubles per wave: staged terms or the accumulator copies
-constexpr int kFlatLK = 256;   // doubles per wave: the children's lambda-messages (parent role)
-constexpr int kFlatLds = kFlatW + kFlatLK;
-
-__device__ __forceinline__ double readlane_d(double x, int src) {  // src wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-
-// G lanes per node (NPT = 64 / G nodes per wave): G < 64 only for tables of at most 2 G entries
-// whose vectors fit G lanes (the ordered path); every "lane" below is then a lane of the node's group.
-template <int G, bool NT>
-__device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& cg,
-                                            int wlane, double* lds) {
-    constexpr int MM = kFlatMaxParents;
-    constexpr int NPT = kWave / G;
-    const int nl = wlane / G, lane = wlane % G, gb = nl * G;  // node of the tile, lane inside its group, first lane
-    const bool active = nl < td.n_nodes;
-    const int nlc = active ? nl : 0;  // idle groups shadow node 0 (they take part in the shuffles, store nothing)
-    double* W = lds + (G == kWave ? 0 : nl * 2 * G);
-    double* LK = lds + kFlatW + nl * (kFlatLK / NPT);
-    // element x of a lane-spread vector of this node's group; x is the same for the whole group
-    auto bcast = [&](double x, int idx) {
-        if constexpr (G == kWave) return readlane_d(x, idx);
-        else return shfl_d(x, gb + idx);
-    };
-    // the class fields used below, copied once into (scalar) registers: the wave-scope fences
-    // between the LDS phases would otherwise make every later use a fresh load
-    struct {
-        int kv, m, rows, kvp, per_lane;
-        int kp[MM], kpp[MM], rec_off[MM], cstride[MM];
-    } c;
-    c.kv = cg.kv; c.m = cg.m; c.rows = cg.rows; c.kvp = cg.kvp; c.per_lane = cg.per_lane;
-#pragma unroll
-    for (int j = 0; j < MM; ++j) { c.kp[j] = cg.kp[j]; c.kpp[j] = cg.kpp[j]; c.rec_off[j] = cg.rec_off[j]; c.cstride[j] = cg.cstride[j]; }
-    const int kv = c.kv, m = c.m, rows = c.rows, kvp = c.kvp;
-    const int S = kv * rows;
-    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
-    double wres = 0.0;
-
-    // ---- node vectors (old), lane i < kv
-    const double* nin = io.node_in + td.node_base;
-    double* nout = io.node_out + td.node_base;
-    // element i of pi(v) / lambda(v) in the tile's striped node block
-    auto nidx = [&](int half, int i) { return int64_t(half + (i >> 1)) * (NPT * 2) + nlc * 2 + (i & 1); };
-    double piv = 1.0, lav = 1.0;
-    if (lane < kv && (!io.first || frozen)) { piv = nin[nidx(0, lane)]; lav = nin[nidx(kvp / 2, lane)]; }
-    else if (lane < kv && m == 0) piv = b.cpt[td.cpt_base + (nlc * G + lane) * 2];  // a root starts from its CPT row (:58-64)
-
-    // ---- parent role, first pass: child (c, i) <-> lane c*kv + i.  Its reference, lambda-message
-    // element and previous pi-message element are requested now, so that these two dependent round
-    // trips overlap with the child role below instead of following it.
-    const int cmax = td.cmax;
-    const int ptotal = cmax * kv;
-    const int pchunk = (G / kv) * kv;  // whole children per pass
-    const bool pstaged = ptotal <= kFlatLK / NPT;
-    int pc0 = 0, pi0 = 0;
-    Loc pl0;
-    pl0.has = false; pl0.pi = 0; pl0.lam = 0; pl0.stride = 0;
-    double plk0 = 1.0, pold0 = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
-    if (pstaged && lane < pchunk && lane < ptotal) {
-        pc0 = lane / kv; pi0 = lane - pc0 * kv;
-        pl0 = decode_ref(b.out_refs[td.out_base + int64_t(pc0) * NPT + nlc], kvp / 2);
-        if (pl0.has && !io.first) {
-            plk0 = io.rec_in[(pl0.lam + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
-            pold0 = io.rec_in[(pl0.pi + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
-        }
-    }
-
-    // ---- in-edge records: lane x <-> (parent j, state d), x = offs[j] + d
-    int offs[MM + 1];
-    int myj = -1;
-    int64_t my_pi = 0, my_lam = 0;  // doubles from the start of a record buffer
-    {
-        int off = 0;
-#pragma unroll
-        for (int j = 0; j < MM; ++j) {
-            offs[j] = off;
-            if (j < m) {
-                const int kj = c.kp[j], hj = c.kpp[j] / 2;
-                Loc l;
-                if (td.in_ref_base >= 0) {
-                    l = decode_ref(b.in_refs[td.in_ref_base + j * NPT + nlc], hj);
-                } else {
-                    l.has = true; l.pi = (td.rec_base + c.rec_off[j]) / 2 + nlc; l.lam = l.pi + hj * NPT; l.stride = NPT;
-                }
-                if (lane >= off && lane < off + kj) {
-                    const int dd = lane - off;
-                    myj = j;
-                    my_pi = (l.pi + int64_t(dd >> 1) * l.stride) * 2 + (dd & 1);
-                    my_lam = (l.lam + int64_t(dd >> 1) * l.stride) * 2 + (dd & 1);
-                }
-                off += kj;
-            }
-        }
-        offs[MM] = off;
-    }
-    const int sumk = offs[MM];
-    double pim = 1.0, oldlam = 1.0;
-    if (myj >= 0 && !io.first) { pim = io.rec_in[my_pi]; oldlam = io.rec_in[my_lam]; }
-
-    // digits, factors and CPT value of entry e (all lanes take part in the shuffles)
-    auto entry = [&](int e, bool valid, double cval, double (&pj)[MM], int (&dj)[MM], int& ei, int& econd, double& li,
-                     double& cv) {
-        const int ee = valid ? e : 0;
-        int cond = ee / kv;
-        ei = ee - cond * kv;
-        econd = cond;
-#pragma unroll
-        for (int j = MM - 1; j >= 0; --j) {
-            dj[j] = 0; pj[j] = 1.0;
-            if (j < m) {
-                const int q = cond / c.kp[j];
-                dj[j] = cond - q * c.kp[j];
-                cond = q;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < MM; ++j)
-            if (j < m) pj[j] = shfl_d(pim, gb + offs[j] + dj[j]);
-        li = shfl_d(lav, gb + ei);
-        cv = valid ? cval : 0.0;
-    };
-    const double* cp = b.cpt + td.cpt_base + (nlc * G + lane) * 2;
-    double outl = 0.0;  // lane x: un-normalised lambda-message element x (concatenated)
-    double pin = 0.0;   // lane i: un-normalised pi(v)[i]
-
-    if (G < kWave || S <= kFlatOrdered) {
-        // ---- ordered path: at most two entries per lane.  Every term is written to LDS at the
-        // position it has in ITS accumulator's summation order, so each accumulator lane then adds
-        // one contiguous run front to back (reads pipelined, additions strictly in the reference's order).
-        double pj[2][MM], li[2], cv[2];
-        int dj[2][MM], ei[2], ec[2];
-        bool ok[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int e = lane + G * t;
-            ok[t] = e < S;
-            const double cval = ok[t] ? cp[t] : 0.0;
-            entry(e, ok[t], cval, pj[t], dj[t], ei[t], ec[t], li[t], cv[t]);
-        }
-        // calculate_pi (:174-200): cpt * pi-messages (ascending parents), summed over assignments ascending
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            double v = cv[t];
-#pragma unroll
-            for (int j = 0; j < MM; ++j)
-                if (j < m) v *= pj[t][j];
-            if (ok[t]) W[ei[t] * rows + ec[t]] = v;
-        }
-        wave_lds_fence();
-        if (lane < kv) {
-            const double* run = W + lane * rows;
-            double acc = 0.0;
-#pragma unroll 8
-            for (int r = 0; r < rows; ++r) acc += run[r];
-            pin = acc;
-        }
-        wave_lds_fence();
-        // calculate_lambda_k (:240-266) per target parent: (lambda[i] * cpt) * the OTHER parents'
-        // pi-messages; bucket s of parent jt receives its terms own state outer, assignment inner
-#pragma unroll
-        for (int jt = 0; jt < MM; ++jt) {
-            if (jt < m) {
-                const int kj = c.kp[jt], per_state = rows / kj;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    double w = li[t] * cv[t];
-#pragma unroll
-                    for (int j = 0; j < MM; ++j)
-                        if (j < m && j != jt) w *= pj[t][j];
-                    // rank inside the bucket = i * (rows / kj) + (assignment with digit jt removed)
-                    int rest = 0;
-#pragma unroll
-                    for (int j = 0; j < MM; ++j)
-                        if (j < m && j != jt) rest += dj[t][j] * (j < jt ? c.cstride[j] / kj : c.cstride[j]);
-                    if (ok[t]) W[dj[t][jt] * (kv * per_state) + ei[t] * per_state + rest] = w;
-                }
-                wave_lds_fence();
-                if (lane >= offs[jt] && lane < offs[jt] + kj) {
-                    const int R = kv * per_state;
-                    const double* run = W + (lane - offs[jt]) * R;
-                    double acc = 0.0;
-#pragma unroll 8
-                    for (int r = 0; r < R; ++r) acc += run[r];
-                    outl = acc;
-                }
-                wave_lds_fence();
-            }
-        }
-    } else {
-        // ---- large table: LDS atomics into [ lambda buckets (sumk) | pi (kv) ]
-        const int nacc = sumk + kv;  // <= 128
-        for (int x = lane; x < nacc * kFlatCopies; x += kWave) W[x] = 0.0;
-        wave_lds_fence();
-        double* Wc = W + (lane & (kFlatCopies - 1)) * nacc;  // this lane's accumulator copy
-        const int T = c.per_lane;
-        double cvals[4] = {0.0, 0.0, 0.0, 0.0};
-        // digits of this lane's entry, advanced by 64 per step with carries (one set of divisions
-        // per tile instead of one per entry): own state fastest, last parent next, first parent slowest
-        int inc_i, inc_j[MM], cur_i, cur_j[MM];
-        {
-            int q = kWave, e0 = lane;
-            inc_i = q % kv; q /= kv;
-            cur_i = e0 % kv; e0 /= kv;
-#pragma unroll
-            for (int j = MM - 1; j >= 0; --j) {
-                inc_j[j] = 0; cur_j[j] = 0;
-                if (j < m) {
-                    inc_j[j] = q % c.kp[j]; q /= c.kp[j];
-                    cur_j[j] = e0 % c.kp[j]; e0 /= c.kp[j];
-                }
-            }
-        }
-        for (int t = 0; t < T; ++t) {
-            if ((t & 3) == 0) {  // the CPT values of four entries are requested together
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int tq = t + q;
-                    cvals[q] = (tq < T && lane + kWave * tq < S) ? cp[int64_t(tq >> 1) * 128 + (tq & 1)] : 0.0;
-                }
-            }
-            const int e = lane + kWave * t;
-            const bool valid = e < S;
-            const double cval = (t & 3) == 0 ? cvals[0] : ((t & 3) == 1 ? cvals[1] : ((t & 3) == 2 ? cvals[2] : cvals[3]));
-            double pj[MM], li, cv;
-            int dj[MM], ei;
-            ei = valid ? cur_i : 0;
-#pragma unroll
-            for (int j = 0; j < MM; ++j) {
-                dj[j] = valid ? cur_j[j] : 0;
-                pj[j] = 1.0;
-                if (j < m) pj[j] = shfl_d(pim, gb + offs[j] + dj[j]);
-            }
-            li = shfl_d(lav, gb + ei);
-            cv = valid ? cval : 0.0;
-            {   // e += 64 in mixed radix
-                int x = cur_i + inc_i;
-                int carry = x >= kv ? 1 : 0;
-                cur_i = x - (carry ? kv : 0);
-#pragma unroll
-                for (int j = MM - 1; j >= 0; --j)
-                    if (j < m) {
-                        x = cur_j[j] + inc_j[j] + carry;
-                        carry = x >= c.kp[j] ? 1 : 0;
-                        cur_j[j] = x - (carry ? c.kp[j] : 0);
-                    }
-            }
-            double v = cv;
-#pragma unroll
-            for (int j = 0; j < MM; ++j)
-                if (j < m) v *= pj[j];
-            if (valid) unsafeAtomicAdd(&Wc[sumk + ei], v);
-            const double tc = li * cv;
-#pragma unroll
-            for (int jt = 0; jt < MM; ++jt) {
-                if (jt < m) {
-                    double w = tc;
-#pragma unroll
-                    for (int j = 0; j < MM; ++j)
-                        if (j < m && j != jt) w *= pj[j];
-                    if (valid) unsafeAtomicAdd(&Wc[offs[jt] + dj[jt]], w);
-                }
-            }
-        }
-        wave_lds_fence();
-        if (lane < sumk) {
-            double acc = W[lane];
-#pragma unroll
-            for (int q = 1; q < kFlatCopies; ++q) acc += W[q * nacc + lane];
-            outl = acc;
-        }
-        if (lane < kv) {
-            double acc = W[sumk + lane];
-#pragma unroll
-            for (int q = 1; q < kFlatCopies; ++q) acc += W[q * nacc + sumk + lane];
-            pin = acc;
-        }
-        wave_lds_fence();
-    }
-
-    // ---- normalise (:298-311: divide by the plain left-to-right sum), residual (:105-131), stores
-    {
-        double sum = 0.0;
-        for (int i = 0; i < kv; ++i) sum += bcast(pin, i);
-        pin /= sum;
-        if (active && lane < kv) nout[nidx(0, lane)] = frozen ? piv : pin;
-        if (active && lane == kv && kvp > kv) nout[nidx(0, lane)] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < MM; ++j) {
-        if (j < m) {
-            double sum = 0.0;
-            for (int dd = 0; dd < c.kp[j]; ++dd) sum += bcast(outl, offs[j] + dd);
-            if (myj == j) outl /= sum;
-        }
-    }
-    if (active && myj >= 0) {
-        wres = res_acc(wres, fabs(outl - oldlam));
-        io.rec_out[my_lam] = outl;
-    }
-
-    // ---- parent role (:202-238): the children's lambda-messages staged in LDS, element (c, i) at c*kv + i
-    if (pstaged) {
-        const int total = ptotal, chunk = pchunk;
-        if (lane < chunk && lane < total) LK[lane] = plk0;
-        for (int base = chunk; base < total; base += chunk) {
-            const int idx = base + lane;
-            if (lane < chunk && idx < total) {
-                const int cc = idx / kv, ii = idx - cc * kv;
-                const Loc l = decode_ref(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], kvp / 2);
-                double val = 1.0;
-                if (l.has && !io.first) val = io.rec_in[(l.lam + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1)];
-                LK[idx] = val;
-            }
-        }
-        wave_lds_fence();
-        {   // lambda(v): product of the children's lambda-messages from 1.0, ascending (:220-238)
-            double acc = 1.0;
-            if (lane < kv)
-                for (int x = 0; x < cmax; ++x) acc *= LK[x * kv + lane];
-            double sum = 0.0;
-            for (int i = 0; i < kv; ++i) sum += bcast(acc, i);
-            acc /= sum;
-            if (active && lane < kv) nout[nidx(kvp / 2, lane)] = frozen ? lav : acc;
-            if (active && lane == kv && kvp > kv) nout[nidx(kvp / 2, lane)] = 0.0;
-        }
-        for (int base = 0; base < total; base += chunk) {
-            const int idx = base + lane;
-            const bool mine = lane < chunk && idx < total;
-            const int cc = mine ? idx / kv : 0, ii = mine ? idx - cc * kv : 0;
-            // pi-message to child cc (:202-218): pi(v)[i] * the OTHER children's lambda-messages, ascending
-            double u = shfl_d(piv, gb + ii);
-            for (int x = 0; x < cmax; ++x)
-                if (x != cc) u *= LK[x * kv + ii];
-            double sum = 0.0;
-            for (int dd = 0; dd < kv; ++dd) sum += shfl_d(u, gb + lane - ii + dd);
-            u /= sum;
-            if (mine && active) {
-                const Loc l = base == 0 ? pl0 : decode_ref(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], kvp / 2);
-                if (l.has) {
-                    const int64_t at = (l.pi + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1);
-                    const double old = io.first ? 1.0 : (base == 0 ? pold0 : io.rec_in[at]);
-                    wres = res_acc(wres, fabs(u - old));
-                    io.rec_out[at] = u;
-                }
-            }
-        }
-    } else if (lane == 0 && active) {
-        wres = res_acc(wres, parent_role_generic(b, io, td, kv, kvp, nl, frozen, true));
-    }
-    return wres;
-}
-
-template <int K, int M, bool NT>
-__device__ __forceinline__ double tile_uniform_dispatch(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    if (td.in_ref_base >= 0) return tile_uniform<K, M, 0, NT, true>(b, io, td, lane);  // boundary tile
-    if (td.cmax <= 2) return tile_uniform<K, M, 2, NT, false>(b, io, td, lane);
-    if (td.cmax <= 4) return tile_uniform<K, M, 4, NT, false>(b, io, td, lane);
-    return tile_uniform<K, M, 0, NT, false>(b, io, td, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------------
-// Logical block index with an XCD-contiguous mapping: hardware block b runs on XCD b % 8
-// (observed, speed only), so logical chunk [x*nb/8, (x+1)*nb/8) of the tile list -- spatially
-// adjacent tiles that share message records -- stays inside one XCD's L2.  gridDim.x % 8 == 0.
-__device__ __forceinline__ int logical_block() {
-    const int nb = gridDim.x, b = blockIdx.x;
-    return (b & 7) * (nb >> 3) + (b >> 3);
-}
-
-// Residual bookkeeping of launch s, done by ONE wave that carries no tile: settle sweep s-1
-// (record maximum_difference, raise `done` when it is < eps, :147), then zero this rank's slots
-// in the buffer it just read -- sweep s+1 accumulates into them.  Tile waves never wait for it:
-// a launch that starts after convergence only writes the buffer that is no longer current, and
-// the launch after that sees `done` and returns at once.
-__device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) {
-    const BpBuffers& b = a.b;
-    if (a.sweep == 0) return;
-    const double r = reduce_residual(b, a.rec_in, lane);
-    if (lane == 0) {
-        if (a.sweep - 1 < b.res_cap) b.res_hist[a.sweep - 1] = r;
-        if (r < a.eps) { b.ctl->n_sweeps = a.sweep; b.ctl->last_res = r; b.ctl->done = 1; }
-    }
-    unsigned long long* row = res_row(b, a.rec_in, b.rank);
-#pragma unroll
-    for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
-}
-
-template <bool NT>
-__global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a) {
-    __shared__ double flat_lds[kWavesPerBlock][kFlatLds];  // flat tiles only: staged terms, children's messages
-    const BpBuffers& b = a.b;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // `done` and the tile descriptor are fetched together: one round trip, not two, heads the chain
-    const int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int tile = logical_block() * kWavesPerBlock + wave;
-    if (tile >= b.n_tiles) {
-        if (done == 0 && tile == a.book_tile) sweep_bookkeeping(a, lane);
-        return;
-    }
-    const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
-    const TileDesc td = b.tiles[tile];
-    if (done != 0) return;
-    double wres = 0.0;
-    bool handled = false;
-    if (td.variant == kVariantUniform) {
-        handled = true;
-        switch (td.kv * 8 + td.m) {
-            case 2 * 8 + 0: wres = tile_uniform_dispatch<2, 0, NT>(b, io, td, lane); break;
-            case 2 * 8 + 1: wres = tile_uniform_dispatch<2, 1, NT>(b, io, td, lane); break;
-            case 2 * 8 + 2: wres = tile_uniform_dispatch<2, 2, NT>(b, io, td, lane); break;
-            case 2 * 8 + 3: wres = tile_uniform_dispatch<2, 3, NT>(b, io, td, lane); break;
-            case 2 * 8 + 4: wres = tile_uniform_dispatch<2, 4, NT>(b, io, td, lane); break;
-            case 3 * 8 + 0: wres = tile_uniform_dispatch<3, 0, NT>(b, io, td, lane); break;
-            case 3 * 8 + 1: wres = tile_uniform_dispatch<3, 1, NT>(b, io, td, lane); break;
-            case 3 * 8 + 2: wres = tile_uniform_dispatch<3, 2, NT>(b, io, td, lane); break;
-            case 4 * 8 + 0: wres = tile_uniform_dispatch<4, 0, NT>(b, io, td, lane); break;
-            case 4 * 8 + 1: wres = tile_uniform_dispatch<4, 1, NT>(b, io, td, lane); break;
-            case 4 * 8 + 2: wres = tile_uniform_dispatch<4, 2, NT>(b, io, td, lane); break;
-            default: handled = false; break;
-        }
-    }
-    if (td.variant == kVariantGroup) {
-        handled = true;
-        switch (td.m) {
-            case 3: wres = tile_group<1, NT>(b, io, td, lane); break;
-            case 4: wres = tile_group<2, NT>(b, io, td, lane); break;
-            case 5: wres = tile_group<3, NT>(b, io, td, lane); break;
-            default: handled = false; break;
-        }
-    }
-    if (td.variant == kVariantFlat) {
-        handled = true;
-        switch (td.npt) {  // 64 / npt lanes per node
-            case 1: wres = tile_flat<64, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-            case 2: wres = tile_flat<32, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-            case 4: wres = tile_flat<16, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-            default: wres = tile_flat<8, NT>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-        }
-    }
-    if (!handled) wres = tile_generic(b, io, td, b.classes[td.cls], lane);
-    publish_residual(b, a.rec_out, tile, wres, lane);
-}
 
 // The same iteration for networks WITHOUT register-resident tiles (any-arity and one-lane tiles
 // only): those tiles need a third of the registers and are latency-bound, so this instantiation
@@ -1400,7 +27,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepA
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int done = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
     const int tile = logical_block() * kWavesPerBlock + wave;
     if (tile >= b.n_tiles) {
         if (done == 0 && tile == a.book_tile) sweep_bookkeeping(a, lane);
@@ -1409,33 +36,17 @@ __global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepA
     const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
     const TileDesc td = b.tiles[tile];
     if (done != 0) return;
-    double wres = 0.0;
-    if (td.variant == kVariantFlat) {
-        switch (td.npt) {  // 64 / npt lanes per node
-            case 1: wres = tile_flat<64, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-            case 2: wres = tile_flat<32, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-            case 4: wres = tile_flat<16, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-            default: wres = tile_flat<8, false>(b, io, td, b.classes[td.cls], lane, flat_lds[wave]); break;
-        }
-    } else {
-        wres = tile_generic(b, io, td, b.classes[td.cls], lane);
-    }
+    const double wres = run_tile_light(b, io, td, lane, flat_lds[wave]);
     publish_residual(b, a.rec_out, tile, wres, lane);
 }
 
-// Start of a run: reset the control block and this rank's residual slots in both buffers, then
-// apply the evidence (belief_propagation.hpp:68-73) to the nodes this rank owns: pi(v) =
-// lambda(v) = the given vector in the buffer iteration 0 reads, node marked
-// (preconditional_node_).  `frozen` is all-zero on entry (the previous run's finish kernel
-// cleared its own marks).
-__global__ __launch_bounds__(kBlockThreads) void bp_begin_kernel(EvidenceArgs a) {
+// bn_bp_set_evidence: apply the evidence (belief_propagation.hpp:68-73) to the nodes this rank owns:
+// pi(v) = lambda(v) = the given vector in the buffer iteration 0 reads, node marked
+// (preconditional_node_).  `frozen` was cleared by the host just before.  The marks and vectors stay
+// until the next bn_bp_set_evidence: a marked node's vectors are copied forward by every sweep, so
+// both buffers keep holding them and any number of runs can follow without touching them again.
+__global__ __launch_bounds__(kBlockThreads) void bp_evidence_kernel(EvidenceArgs a) {
     const BpBuffers& b = a.b;
-    if (blockIdx.x == 0) {
-        unsigned long long* r0 = res_row(b, b.rec0, b.rank);
-        unsigned long long* r1 = res_row(b, b.rec1, b.rank);
-        for (int q = threadIdx.x; q < kResSlots; q += kBlockThreads) { r0[q] = 0ull; r1[q] = 0ull; }
-        if (threadIdx.x == 0) { b.ctl->done = 0; b.ctl->n_sweeps = 0; b.ctl->last_res = 0.0; }
-    }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.ne) return;
     const int v = a.ev_node[j];
@@ -1443,78 +54,62 @@ __global__ __launch_bounds__(kBlockThreads) void bp_begin_kernel(EvidenceArgs a)
     if (t < 0) return;  // owned by another rank
     const TileDesc td = b.tiles[t];
     const int nl = b.node_nl[v];
-    double* node = b.node0 + td.node_base;
     const int half = ((td.kv + 1) & ~1) >> 1;
     for (int i = 0; i < td.kv; ++i) {
         const double x = a.ev_val[a.ev_off[j] + i];
-        node[vidx(0, i, td.npt, nl)] = x;
-        node[vidx(half, i, td.npt, nl)] = x;
+        b.node0[td.node_base + vidx(0, i, td.npt, nl)] = x;
+        b.node0[td.node_base + vidx(half, i, td.npt, nl)] = x;
+        b.node1[td.node_base + vidx(0, i, td.npt, nl)] = x;
+        b.node1[td.node_base + vidx(half, i, td.npt, nl)] = x;
     }
     b.frozen[td.slot_base + nl] = 1;
 }
 
-// After a batch of sweeps (and their exchanges): settle the last launched sweep's residual, and
-// once the run is over (converged, or max_sweeps reached) write belief = normalize(pi % lambda)
-// (:151-158) for the owned nodes and clear this run's evidence marks.
+// This rank's residual slots in both buffers.  A finished run leaves them zero itself
+// (bp_finish_kernel); this kernel runs only after a run that did not end normally.
+__global__ __launch_bounds__(kBlockThreads) void bp_reset_kernel(BpBuffers b) {
+    unsigned long long* r0 = res_row(b, b.rec0, b.rank);
+    unsigned long long* r1 = res_row(b, b.rec1, b.rank);
+    for (int q = threadIdx.x; q < kResSlots; q += kBlockThreads) { r0[q] = 0ull; r1[q] = 0ull; }
+}
+
+// After a batch of sweeps (and their exchanges).  Wave 0 of block 0 settles the run: if no sweep
+// launch marked it done, it reduces the last launched sweep's residual and decides (converged /
+// max_sweeps reached / go on), reports to the pinned host block, and -- once the run is over -- leaves
+// the residual slots zero for the next run.  Every other wave writes belief = normalize(pi % lambda)
+// (:151-158) for its tile's nodes from the buffer the last executed sweep wrote; when the host has to
+// go on (predicted sweep count too low) those beliefs are simply overwritten by the next finish.
 __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) {
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    const bool lead = (blockIdx.x == 0 && threadIdx.x == 0);
-    int done = __hip_atomic_load(&b.ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int n_sweeps;
-    if (a.psync) {  // persistent run: the kernel settled everything itself; report how it ended
-        if (lead) {
-            b.ctl->p_abort = a.psync->abort; b.ctl->p_conv = a.psync->conv;
-            a.host_ctl->p_abort = a.psync->abort; a.host_ctl->p_conv = a.psync->conv;
-            a.host_ctl->done = done; a.host_ctl->n_sweeps = b.ctl->n_sweeps; a.host_ctl->last_res = b.ctl->last_res;
+    // marked by a sweep launch = a previous kernel: every block sees the same value
+    const bool marked = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
+    const int n_sweeps = marked ? b.ctl->n_sweeps : a.sweeps_launched;
+    if (blockIdx.x == 0 && wave == 0) {
+        int done = 1;
+        double r = marked ? b.ctl->last_res : 0.0;
+        unsigned long long t_last = marked ? b.ctl->t_last : wall_clock64();
+        if (!marked) {  // sweep (launched-1) wrote buffer (launched & 1)
+            r = reduce_residual(b, (a.sweeps_launched & 1) ? b.rec1 : b.rec0, lane);
+            if (lane == 0 && a.sweeps_launched - 1 < b.res_cap) b.res_hist[a.sweeps_launched - 1] = r;
+            done = (r < a.eps) ? 1 : (a.final_batch ? 2 : 0);
         }
-        if (done == 0 || a.psync->abort != 0) {  // it gave up: the host reruns with per-sweep launches
-            const int gid0 = blockIdx.x * blockDim.x + threadIdx.x;
-            for (int j = gid0; j < a.ne; j += gridDim.x * blockDim.x) {
-                const int v = a.ev_node[j];
-                const int t = b.node_tile[v];
-                if (t >= 0) b.frozen[b.tiles[t].slot_base + b.node_nl[v]] = 0;
-            }
-            return;
+        if (lane == 0) {
+            a.host_ctl->last_res = r; a.host_ctl->n_sweeps = n_sweeps;
+            a.host_ctl->t_first = b.ctl->t_first; a.host_ctl->t_last = t_last;
+            a.host_ctl->run_id = a.run_id; a.host_ctl->done = done;
         }
-    }
-    if (done != 0) {
-        n_sweeps = b.ctl->n_sweeps;
-        if (lead && !a.psync) { a.host_ctl->last_res = b.ctl->last_res; a.host_ctl->n_sweeps = n_sweeps; a.host_ctl->done = done; }
-    } else {
-        // sweep (launched-1) wrote buffer (launched & 1)
-        const double r = reduce_residual(b, (a.sweeps_launched & 1) ? b.rec1 : b.rec0, lane);
-        if (lead && a.sweeps_launched - 1 < b.res_cap) b.res_hist[a.sweeps_launched - 1] = r;
-        n_sweeps = a.sweeps_launched;
-        if (r < a.eps) done = 1;
-        else if (a.final_batch) done = 2;
-        if (lead) {
-            b.ctl->last_res = r; b.ctl->n_sweeps = n_sweeps; b.ctl->done = done;
-            a.host_ctl->last_res = r; a.host_ctl->n_sweeps = n_sweeps; a.host_ctl->done = done;
+        if (done != 0) {
+            unsigned long long* r0 = res_row(b, b.rec0, b.rank);
+            unsigned long long* r1 = res_row(b, b.rec1, b.rank);
+#pragma unroll
+            for (int q = 0; q < kResSlots / kWave; ++q) { r0[q * kWave + lane] = 0ull; r1[q * kWave + lane] = 0ull; }
         }
-    }
-    if (done == 0) return;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int j = gid; j < a.ne; j += gridDim.x * blockDim.x) {
-        const int v = a.ev_node[j];
-        const int t = b.node_tile[v];
-        if (t >= 0) b.frozen[b.tiles[t].slot_base + b.node_nl[v]] = 0;
     }
     const int tile = blockIdx.x * kWavesPerBlock + wave;
     if (tile >= b.n_tiles) return;
-    const TileDesc td = b.tiles[tile];
-    if (lane >= td.n_nodes) return;  // one lane per node writes the belief
-    const double* node = ((n_sweeps & 1) ? b.node1 : b.node0) + td.node_base;
-    const int64_t boff = b.slot_boff[td.slot_base + lane];
-    const int half = ((td.kv + 1) & ~1) >> 1;
-    double sum = 0;
-    for (int i = 0; i < td.kv; ++i) {
-        const double x = node[vidx(0, i, td.npt, lane)] * node[vidx(half, i, td.npt, lane)];
-        b.beliefs[boff + i] = x;
-        sum += x;
-    }
-    for (int i = 0; i < td.kv; ++i) b.beliefs[boff + i] = b.beliefs[boff + i] / sum;
+    tile_beliefs(b, b.tiles[tile], (n_sweeps & 1) ? b.node1 : b.node0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1522,21 +117,28 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
 // ---------------------------------------------------------------------------------------------
 static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : int(e); }
 
-int launch_bp_begin(const EvidenceArgs& a, void* stream) {
-    const int blocks = a.ne > 0 ? (a.ne + kBlockThreads - 1) / kBlockThreads : 1;
+int launch_bp_evidence(const EvidenceArgs& a, void* stream) {
+    if (a.ne <= 0) return 0;
+    const int blocks = (a.ne + kBlockThreads - 1) / kBlockThreads;
     (void)hipGetLastError();  // drop any stale error of this thread
-    hipLaunchKernelGGL(bp_begin_kernel, dim3(blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bp_evidence_kernel, dim3(blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, void* stream) {
+int launch_bp_reset(const BpBuffers& b, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    if (light)
-        hipLaunchKernelGGL(bp_sweep_light_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
-    else if (nontemporal)
-        hipLaunchKernelGGL(bp_sweep_kernel<true>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(bp_sweep_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bp_reset_kernel, dim3(1), dim3(kBlockThreads), 0, (hipStream_t)stream, b);
     return hip_rc(hipGetLastError());
+}
+// variants: bit v set = the plan has tiles of variant v (bn_plan.hpp); light: any-arity / one-lane tiles only
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, int variants, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
+    if (light) {
+        hipLaunchKernelGGL(bp_sweep_light_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+        return hip_rc(hipGetLastError());
+    }
+    if (variants & ((1 << kVariantFlat) | (1 << kVariantGeneric))) return launch_bp_sweep_all(a, grid_blocks, stream);
+    if (variants & (1 << kVariantGroup)) return launch_bp_sweep_ug(a, grid_blocks, nontemporal, stream);
+    return launch_bp_sweep_u(a, grid_blocks, nontemporal, stream);
 }
 int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread

@@ -265,8 +265,11 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         slot_cur += c.npt;
     }
     p.light = nt > 0;
-    for (const ClassDesc& c : p.classes)
+    p.variants = 0;
+    for (const ClassDesc& c : p.classes) {
         if (c.variant == kVariantUniform || c.variant == kVariantGroup) p.light = false;
+        p.variants |= 1 << c.variant;
+    }
     p.n_slots = slot_cur;
     p.rec_doubles = rec_cur;
     p.node_doubles = node_cur;

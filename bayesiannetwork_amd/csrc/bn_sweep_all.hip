@@ -1,0 +1,14 @@
+// bn_sweep_all.hip -- instantiation of the per-sweep kernel (bn_sweep.hpp) for every tile variant.
+#include "bn_sweep.hpp"
+
+namespace bnmi {
+
+int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
+    // working sets beyond the Infinity Cache made of any-arity tiles are latency-bound either way: plain stores
+    hipLaunchKernelGGL((bp_sweep_kernel<false, kVarAll>), dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+
+}  // namespace bnmi

@@ -1,0 +1,16 @@
+// bn_sweep_ug.hip -- instantiation of the per-sweep kernel (bn_sweep.hpp) for register-resident and k = 4 lane-group tiles.
+#include "bn_sweep.hpp"
+
+namespace bnmi {
+
+int launch_bp_sweep_ug(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
+    if (nontemporal)
+        hipLaunchKernelGGL((bp_sweep_kernel<true, kVarUG>), dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((bp_sweep_kernel<false, kVarUG>), dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+
+}  // namespace bnmi

@@ -117,36 +117,63 @@ def measured_stream_gbs(torch):
         return None
 
 
-def time_bp(eng, g, eps, steps, warmup, torch):
-    """`steps` runs to convergence on the staged evidence, bracketed by synchronize on both sides.
-    The sweep launch duration comes from HIP events the library records on ITS stream around every
-    batch of sweep launches ("timing" option; torch.cuda.Event would only see torch's stream)."""
+def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
+    """`steps` runs to convergence on the staged evidence, bracketed by synchronize on both sides, with
+    nothing but the run itself in the timed region.  Two clocks give the sweep launch duration:
+      * the device's own 100 MHz clock, read by the kernels at the first sweep's start and the last
+        sweep's end of every timed run (bn_bp_stats.sweep_devclock_ms; free, so it covers the timed region);
+      * HIP events the library records on ITS stream around every batch of sweep launches ("timing"
+        option; torch.cuda.Event would only see torch's stream).  An event record between two launches
+        opens a bubble of several microseconds in the queue, so they are taken on a repeat of the same
+        steps right after the timed region instead of inside it."""
+    eng.set_option("timing", 0)
     for _ in range(max(warmup, 1)):
         r = eng.bp_run_device(eps)
     torch.cuda.synchronize()
-    sweeps_total, kern_ms, launches = 0, 0.0, 0
+    sweeps_total, dev_ms = 0, 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         r = eng.bp_run_device(eps)
         st = eng.bp_stats()
         sweeps_total += r["sweeps"]
-        kern_ms += st["sweep_kernel_ms"]
-        launches += st["sweep_launches"]
+        dev_ms += st["sweep_devclock_ms"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    path = eng.last_path()
+    eng.set_option("timing", 1)
+    ev_steps = event_steps if event_steps is not None else min(steps, 20)
+    kern_ms, launches, ev_sweeps = 0.0, 0, 0
+    eng.bp_run_device(eps)
+    t1 = time.perf_counter()
+    for _ in range(ev_steps):
+        r = eng.bp_run_device(eps)
+        st = eng.bp_stats()
+        kern_ms += st["sweep_kernel_ms"]
+        launches += st["sweep_launches"]
+        ev_sweeps += r["sweeps"]
+    torch.cuda.synchronize()
+    dt_ev = time.perf_counter() - t1
+    eng.set_option("timing", 0)
     st = eng.bp_stats()
-    avg_launch_s = kern_ms * 1e-3 / max(launches, 1)
-    if avg_launch_s <= 0:  # BN_TIMING=0: no HIP events; fall back to the whole-run clock (upper bound)
-        avg_launch_s = dt / max(launches, 1)
+    per_launch = max(launches, 1) if path == 0 else max(ev_sweeps, 1)  # one launch per run: per sweep inside it
+    avg_launch_s = kern_ms * 1e-3 / per_launch
+    avg_dev_s = dev_ms * 1e-3 / max(sweeps_total, 1)
+    if avg_launch_s <= 0:
+        avg_launch_s = avg_dev_s
     achieved = st["algorithmic_bytes_per_sweep"] / avg_launch_s / 1e9
     return {"dt": dt, "sweeps_total": sweeps_total, "msgs": g.messages_per_sweep() * sweeps_total,
-            "avg_launch_s": avg_launch_s, "achieved": achieved, "stats": st, "path": eng.last_path()}
+            "avg_launch_s": avg_launch_s, "avg_launch_devclock_s": avg_dev_s, "achieved": achieved, "stats": st,
+            "path": path, "ms_per_step_with_events": dt_ev / max(ev_steps, 1) * 1e3, "event_steps": ev_steps}
 
 
 def roofline_of(t, label, kernel="bp_sweep_kernel"):
     st = t["stats"]
     out = {"bound": "hbm", "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": t["achieved"] / HBM_PEAK_GBS, "kernel": kernel, "avg_launch_us": t["avg_launch_s"] * 1e6,
+           "avg_launch_us_source": f"HIP events on the engine's stream, {t['event_steps']} repeated steps after the timed region "
+                                   f"({t['ms_per_step_with_events']:.4f} ms per step with the events in the queue)",
+           "avg_launch_us_devclock": t["avg_launch_devclock_s"] * 1e6,
+           "achieved_devclock": st["algorithmic_bytes_per_sweep"] / max(t["avg_launch_devclock_s"], 1e-12) / 1e9,
            "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"],
            "layout_bytes_per_launch": st["layout_bytes_per_sweep"]}
     out.update(profiled_traffic(label))
@@ -236,7 +263,7 @@ def leg_grid2048(a, local_rank, torch):
     steps = 3
     with Engine(g, device=local_rank) as eng:
         eng.bp_set_evidence(ev)
-        t = time_bp(eng, g, a.eps, steps, 1, torch)
+        t = time_bp(eng, g, a.eps, steps, 1, torch, event_steps=2)
     out = {"workload": f"2048x2048 2D-grid BN, k=4, {g.n} nodes, {g.n_edges} edges, {ev.ne} evidence nodes, eps={a.eps:g} "
                        "(working set beyond the 256 MiB Infinity Cache)",
            "value": t["msgs"] / t["dt"], "unit": "edge-messages/s", "ms_per_step": t["dt"] / steps * 1e3, "steps": steps,

@@ -31,6 +31,27 @@ public:
     {
     }
 
+    // Copyable like the reference's functor (implicit copy of graph_ and the scratch maps,
+    // belief_propagation.hpp:12-21, :320-333): the copy owns a second device engine built from the
+    // same flat model, so two copies never share mutable state.
+    belief_propagation(belief_propagation const& other)
+        : model_(other.model_), engine_(model_), last_sweeps_(other.last_sweeps_), last_residual_(other.last_residual_)
+    {
+    }
+    belief_propagation& operator=(belief_propagation const& other)
+    {
+        if(this != &other)
+        {
+            model_ = other.model_;
+            engine_ = mi355x::engine_handle(model_);
+            last_sweeps_ = other.last_sweeps_;
+            last_residual_ = other.last_residual_;
+        }
+        return *this;
+    }
+    belief_propagation(belief_propagation&&) = default;
+    belief_propagation& operator=(belief_propagation&&) = default;
+
     virtual ~belief_propagation() = default;
 
     // By-pass (reference :24-28)

@@ -134,6 +134,8 @@ inline void store_cpts(graph_t const& graph, flat_model const& fm, std::vector<d
 }
 
 // RAII over the C handle; non-zero codes become std::runtime_error (no exception crosses the ABI).
+// Move-only: a functor that must be copyable (belief_propagation, like the reference's) builds a
+// second engine from its own flat model, so the copies stay as independent as the reference's.
 class engine_handle {
 public:
     engine_handle() = default;
@@ -145,6 +147,16 @@ public:
     engine_handle(engine_handle const&) = delete;
     engine_handle& operator=(engine_handle const&) = delete;
     engine_handle(engine_handle&& other) noexcept : handle_(other.handle_) { other.handle_ = nullptr; }
+    engine_handle& operator=(engine_handle&& other) noexcept
+    {
+        if(this != &other)
+        {
+            if(handle_) bn_destroy(handle_);
+            handle_ = other.handle_;
+            other.handle_ = nullptr;
+        }
+        return *this;
+    }
     ~engine_handle() { if(handle_) bn_destroy(handle_); }
 
     bn_engine* get() const { return handle_; }

@@ -36,27 +36,33 @@ public:
         return true;
     }
 
+    // Sample file (reference sampler.hpp:42-77): one row per distinct pattern, whitespace separated,
+    //   <occurrences> <state of node_list[0]> <state of node_list[1]> ...
+    // Rows with the same pattern add up.  False when the file cannot be opened; a row with fewer
+    // fields than nodes throws std::out_of_range.
     bool load_sample(std::vector<vertex_type> const& node_list)
     {
-        std::ifstream ifs(filename_);
-        if(!ifs.is_open()) return false;
-        std::size_t sampling_size = 0;
-        std::unordered_map<condition_t, std::size_t> table;
-        std::string line_str;
-        condition_t sample;
-        while(std::getline(ifs, line_str))
+        std::ifstream file(filename_);
+        if(!file.is_open()) return false;
+
+        std::unordered_map<condition_t, std::size_t> counted;
+        std::size_t total = 0;
+        std::size_t const fields = node_list.size() + 1;
+        for(std::string row; std::getline(file, row);)
         {
-            std::istringstream iss(line_str);
-            std::vector<std::string> line;
-            for(std::string tok; iss >> tok;) line.push_back(tok);
-            if(line.size() < node_list.size() + 1) throw std::out_of_range("bn::sampler: short sample row");
-            for(std::size_t i = 0; i < node_list.size(); ++i) sample[node_list[i]] = std::stoi(line[i + 1]);
-            auto const sample_num = static_cast<std::size_t>(std::stoi(line[0]));
-            table[sample] += sample_num;
-            sampling_size += sample_num;
+            std::istringstream in(row);
+            std::vector<long> value;
+            for(long x; in >> x;) value.push_back(x);
+            if(value.size() < fields) throw std::out_of_range("bn::sampler: short sample row");
+
+            condition_t pattern;
+            for(std::size_t col = 1; col < fields; ++col) pattern[node_list[col - 1]] = static_cast<int>(value[col]);
+            std::size_t const occurrences = static_cast<std::size_t>(value[0]);
+            counted[pattern] += occurrences;
+            total += occurrences;
         }
-        sampling_size_ = sampling_size;
-        table_ = std::move(table);
+        table_.swap(counted);
+        sampling_size_ = total;
         return true;
     }
 

@@ -99,8 +99,9 @@ int bn_bp_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t 
 
 /*
  * The same in two steps, for callers that keep inputs and outputs resident in HBM (bench.py times
- * this path): bn_bp_set_evidence validates and uploads an evidence set once; bn_bp_run_device
- * runs belief propagation on it -- any number of times -- and leaves the beliefs in device
+ * this path): bn_bp_set_evidence validates, uploads and applies an evidence set once (it stays in
+ * force until the next call); bn_bp_run_device runs belief propagation on it -- any number of
+ * times, each run starts directly with its first sweep -- and leaves the beliefs in device
  * memory (bn_bp_beliefs_device, node-major [sum k]); only the sweep count and the last
  * maximum_difference come back.  bn_bp_run == set_evidence + run_device + copy_beliefs.
  */
@@ -116,14 +117,12 @@ int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
 int bn_bp_residual_history(bn_engine *eng, double *out, int32_t cap);
 int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
 
-/* Options: "persistent" 0/1 -- when every tile of the network can be resident at once (and is
- * register-resident: uniform arity, CPT <= 64 entries, <= 4 children, one GPU) the whole run is ONE
- * launch that keeps the CPTs in registers and synchronises tiles through neighbour flags
- * (bn_persist.hip); otherwise, or after the kernel gave up a wait, one launch per sweep.  Default 0:
- * the persistent path is bit-identical but measured slower on MI355X (BN_PERSISTENT=1 in the
- * environment turns it on).  bn_bp_last_path: 1 persistent, 0 per-sweep.
- * "timing" 1/0 -- HIP events around every batch of sweep launches (bn_bp_stats.sweep_kernel_ms);
- * default 1, BN_TIMING=0 in the environment turns it off (sweep_kernel_ms then reads 0). */
+/* Options: "timing" 1/0 -- HIP events on the engine's stream around every batch of sweep launches
+ * (bn_bp_stats.sweep_kernel_ms).  Default 0 (BN_TIMING=1 in the environment turns it on): an event
+ * record between two launches opens a bubble of several microseconds in the queue, so a timed run is
+ * slower than an untimed one; bn_bp_stats.sweep_devclock_ms -- the device's 100 MHz clock read by the
+ * kernels themselves at the first sweep's start and the last sweep's end -- costs nothing and is always on.
+ * bn_bp_last_path: 1 = the last run was one launch for the whole run, 0 = one launch per sweep. */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 
@@ -138,11 +137,13 @@ int bn_debug_allgather(bn_engine **engs, int32_t n, int32_t sweep);
 typedef struct bn_bp_stats {
     int32_t sweeps;            /* iterations of the last run                                */
     int32_t sweep_launches;    /* sweep kernels launched (>= sweeps; extras exit at once)    */
-    float sweep_kernel_ms;     /* HIP-event time over all sweep launches of the last run     */
+    float sweep_kernel_ms;     /* HIP-event time over all sweep launches of the last run ("timing" on) */
     float total_ms;            /* host wall time of the last bn_bp_run_device call           */
     int64_t algorithmic_bytes_per_sweep; /* SURVEY.md 8(d) formula                           */
     int64_t layout_bytes_per_sweep;      /* bytes the sweep kernel actually requests         */
     int64_t messages_per_sweep;          /* 2E                                              */
+    float sweep_devclock_ms;   /* device clock: first sweep's start -> last executed sweep's end */
+    float pad_;
 } bn_bp_stats;
 int bn_bp_last_stats(bn_engine *eng, bn_bp_stats *out);
 

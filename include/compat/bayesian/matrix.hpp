@@ -1,7 +1,8 @@
 // compat/bayesian/matrix.hpp -- this repository's own, API-compatible stand-in for the
 // reference's bn::matrix_type (bayesian/matrix.hpp:10-159), so that the drop-in inference headers
-// can be built and tested where the reference is not installed (the GPU box).  Row-major storage
-// in one contiguous buffer; operator[] hands out a row view with vector-like access.
+// can be built and tested where the reference is not installed (the GPU box).  Storage is one
+// std::vector<double> per row, as the public signature `std::vector<double>& operator[](size_t)`
+// requires; test scaffolding, never on the hot path (the C ABI moves flat arrays).
 #ifndef BNI_MATRIX_HPP
 #define BNI_MATRIX_HPP
 

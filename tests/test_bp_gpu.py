@@ -79,16 +79,17 @@ def _vs_oracle(Engine, oracle_mod, model, ev, eps, exact):
         # repeated runs on the same engine start from a clean state
         g2 = eng.bp_run(ev, eps)
         assert g2["sweeps"] == g["sweeps"] and np.array_equal(g2["beliefs"], g["beliefs"], equal_nan=True)
-        # the other execution path (one launch per sweep <-> persistent dataflow kernel) must give
-        # the very same bits: same arithmetic, only the scheduling differs
+        # the other execution path (one launch per sweep <-> one launch for the whole run) must give
+        # the very same bits: same tile arithmetic, only the scheduling differs
         path = eng.last_path()
-        eng.set_option("persistent", 0 if path == 1 else 1)
+        eng.set_option("multisweep", 0 if path == 1 else 1)
         g3 = eng.bp_run(ev, eps)
         assert g3["sweeps"] == g["sweeps"] and np.array_equal(g3["beliefs"], g["beliefs"], equal_nan=True)
         assert np.array_equal(eng.bp_residuals(), res)
+        pi3, lam3 = eng.bp_messages()
+        assert np.array_equal(pi3, pi, equal_nan=True) and np.array_equal(lam3, lam, equal_nan=True)
         if path == 1:
             assert eng.last_path() == 0
-        eng.set_option("persistent", 0)
     return o
 
 
