@@ -95,6 +95,35 @@ struct MultiArgs {
 };
 int launch_bp_multi(const MultiArgs& a, bool light, void* stream);
 
+// The whole run in one launch with every tile resident in registers (bn_resident.hip).
+constexpr int kResidentWaves = 8;       // 512 threads per block, one tile per wave, <= 256 VGPRs
+constexpr int kResidentLdsSlots = 16;   // double2 slots per lane of CPT kept in LDS (upper half of a 64-entry table)
+constexpr int kResidentBudget = 1024;   // iterations one launch may execute (size of ResidentSync::res)
+struct ResidentSync {                   // zeroed by the host before every launch
+    unsigned abort;                     // non-zero: a bounded wait gave up
+    unsigned top;                       // groups that completed their arrivals (monotonic)
+    unsigned pad_[30];
+    struct Group {
+        unsigned count;                 // arrivals of the group's blocks (monotonic)
+        unsigned pad0_[31];
+        unsigned gen;                   // last generation released to this group
+        unsigned pad1_[31];
+    } grp[8];
+    unsigned long long res[kResidentBudget];  // per-iteration maximum_difference, bit patterns
+};
+struct ResidentArgs {
+    BpBuffers b;
+    double eps;
+    int32_t max_sweeps;   // 0 = unbounded like the reference
+    int32_t sweep_begin;  // first iteration of this launch
+    int32_t budget;       // iterations this launch may execute (<= kResidentBudget)
+    uint32_t run_id;
+    unsigned long long timeout_ticks;  // bound of one barrier wait, 100 MHz ticks
+    ResidentSync* sync;
+    Ctl* host_ctl;
+};
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, void* stream);
+
 // launchers (bn_kernels.hip)
 int launch_bp_evidence(const EvidenceArgs& a, void* stream);  // bn_bp_set_evidence: marks + vectors
 int launch_bp_reset(const BpBuffers& b, void* stream);         // residual slots; after an abnormal end only

@@ -128,9 +128,12 @@ struct bn_engine {
     bool nontemporal = false;
     bool timing = false;            // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms); opt-in:
                                     // an event record between two launches opens a ~6 us bubble in the queue
+    bool resident_ok = false;       // every tile register-resident and co-resident: the whole run in one launch (bn_resident.hip)
+    int grid_resident = 0;
+    ResidentSync* d_rsync = nullptr;
     bool multi_ok = false;          // the network is small enough for the one-launch path
-    bool multisweep = false;        // small networks: one launch for the whole run (BN_MULTISWEEP=1 / bn_set_option);
-                                    // measured slower than per-sweep launches so far, hence opt-in
+    int multisweep = 1;             // one-launch paths: 0 never, 1 where they were measured faster (resident tiles on one
+                                    // block or on >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
     int32_t last_path = 0;          // 0 per-sweep launches, 1 one launch for the whole run
     Ctl* h_ctl = nullptr;  // pinned
     Ctl* h_ctl_dev = nullptr;  // the same memory as the device sees it
@@ -155,7 +158,7 @@ static void free_engine(bn_engine* e) {
         if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev};
+                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -266,6 +269,22 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocMapped));
         std::memset(e->h_ctl, 0, sizeof(Ctl));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ctl_dev), e->h_ctl, 0));
+        {   // resident path (bn_resident.hip): uniform tiles of the shapes it instantiates, <= 4 children per
+            // node, one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, e->device));
+            const int64_t nt = int64_t(p.tiles.size());
+            int64_t nb = (nt + kResidentWaves - 1) / kResidentWaves;
+            if (nb > 1) nb = (nb + 7) & ~int64_t(7);
+            bool ok = p.nranks == 1 && nt > 0 && p.variants == (1 << kVariantUniform) &&
+                      nb <= int64_t(prop.multiProcessorCount) * 9 / 10 &&
+                      p.rec_total_doubles * 8 < (int64_t(1) << 31);  // 32-bit byte offsets into a record buffer
+            for (const TileDesc& td : p.tiles)
+                ok = ok && td.variant == kVariantUniform && td.cmax <= 4 && td.in_ref_base < 0 && td.m <= 2;
+            e->resident_ok = ok;
+            e->grid_resident = int(nb);
+            if (ok) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_rsync), sizeof(ResidentSync)));
+        }
         {   // small network: all sweeps in one launch of one workgroup (bn_multi.hip); wave w runs
             // tiles w, w + W, ...: up to kMultiMaxRounds tiles per wave and sweep
             const int64_t nt = int64_t(p.tiles.size());
@@ -273,7 +292,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             int64_t rounds_max = 3;
             if (const char* r = std::getenv("BN_MULTISWEEP_ROUNDS")) rounds_max = std::atoi(r);
             e->multi_ok = p.nranks == 1 && nt > 0 && nt <= waves * rounds_max;
-            if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::atoi(m) != 0;
+            if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         }
         HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
@@ -460,6 +479,51 @@ static void note_run_result(bn_engine* e) {
     e->stats.sweep_devclock_ms = t1 > t0 ? float(double(t1 - t0) * 1e-5) : 0.f;
 }
 
+// Networks of register-resident tiles that fit the chip: ONE launch runs the whole run with the CPTs,
+// references and node vectors resident in registers / LDS and a grid barrier per sweep (bn_resident.hip).
+// BN_ERR_STATE = a bounded wait inside the kernel gave up: the caller redoes the run with per-sweep launches.
+static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
+    hipStream_t s = e->stream;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    int32_t begin = 0, launches = 0;
+    float ms = 0.f;
+    double dev_ticks = 0.0;
+    for (;;) {
+        HIPCHK(hipMemsetAsync(e->d_rsync, 0, sizeof(ResidentSync), s));  // every polled word, before every launch
+        ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id,
+                       5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev};
+        if (e->timing) {
+            int rc = ensure_events(e, 2);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->events[0], s));
+        }
+        if (int code = launch_bp_resident(a, e->grid_resident, s))
+            return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
+        HIPCHK(hipStreamSynchronize(s));
+        ++launches;
+        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
+        if (e->h_ctl->done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
+        if (e->timing) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
+            ms += t;
+        }
+        dev_ticks += double(e->h_ctl->t_last - e->h_ctl->t_first);
+        if (e->h_ctl->done != 0) break;
+        begin = e->h_ctl->n_sweeps;
+    }
+    const bool rows_were_clean = e->rows_clean;  // this path never touches the residual slots
+    note_run_result(e);
+    e->rows_clean = rows_were_clean;
+    e->last_path = 2;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = ms;
+    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
+    return BN_OK;
+}
+
 // Small networks: ONE launch of one workgroup runs every sweep, decides the stop and writes the
 // beliefs (bn_multi.hip).  A launch executes at most kMultiBudget iterations; a run that needs more
 // is continued by the next launch, so no evidence set can keep the GPU inside one kernel.
@@ -513,7 +577,24 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     ON_DEVICE(e);
     hipStream_t s = e->stream;
     int rc;
-    if (e->multi_ok && e->multisweep) {
+    // resident tiles pay on one block (no grid barrier at all) and on large grids (the CPT traffic saved
+    // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
+    constexpr int64_t kResidentMinTiles = 640;
+    const bool resident_pays = e->grid_resident == 1 || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
+    if (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays))) {
+        rc = run_resident(e, eps, max_sweeps);
+        if (rc == BN_OK) {
+            e->stats.total_ms =
+                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+            if (residual_out) *residual_out = e->last_ctl.last_res;
+            return BN_OK;
+        }
+        if (rc != BN_ERR_STATE) return rc;
+        // a barrier wait gave up (e.g. not every block became resident): per-sweep launches from now on
+        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] resident path disabled: %s\n", g_err.c_str());
+        e->resident_ok = false;
+    } else if (e->multi_ok && e->multisweep == 2) {
         rc = run_multi(e, eps, max_sweeps);
         if (rc) return rc;
         e->stats.total_ms =
@@ -567,10 +648,10 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
 extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (!e || !name) return fail(BN_ERR_ARG, "null argument");
     if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
-    if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value != 0; return BN_OK; }
+    if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
-// 1 when the last run was one launch for the whole run, 0 per-sweep launches; <0 error
+// 0 per-sweep launches, 1 one workgroup for the whole run (bn_multi.hip), 2 resident tiles + grid barrier (bn_resident.hip)
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;

@@ -1,0 +1,524 @@
+// bn_resident.hip -- the whole belief-propagation run in ONE launch, tiles resident on the chip.
+//
+// For networks made of register-resident tiles only (uniform arity k in {2,3,4}, CPT <= 64 entries:
+// every grid, chain and tree of the reference's tests, BASELINE.json configs[2]) and small enough that
+// every tile gets its own wavefront (<= 8 waves x 256 CUs).  Each wave keeps, for the whole run,
+//   * its tile's CPT image in VGPRs (loaded once: 57 % of a sweep's bytes on the 316x316 grid),
+//   * its out-edge references and evidence marks,
+//   * pi(v) / lambda(v) of its nodes (never written to memory before the run ends),
+// so one iteration of the reference's while(true) loop (belief_propagation.hpp:75-148) moves the
+// messages only: incoming messages read, outgoing messages written.  The arithmetic is tile_uniform's
+// (bn_tiles.hpp), statement for statement: results are bit-identical to the launch path (asserted).
+//
+// Between iterations stands ONE grid barrier (the Jacobi schedule needs nothing finer):
+//   producer  message stores are 16-byte WRITE-THROUGH (sc1) stores; every wave drains them
+//             (s_waitcnt vmcnt(0)), __syncthreads(), then lane 0 of the block arrives;
+//   barrier   XCD-hierarchical counters: block -> its group's counter -> top counter -> the last
+//             arriver publishes the generation to every group's word; blocks poll their group's word
+//             (relaxed agent-scope loads + s_sleep), then ONE agent-scope acquire, __syncthreads(),
+//             plain loads.  (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md barrier-xcd.)
+//             Nothing depends on dispatch order or on which XCD a block runs; groups = blockIdx % 8
+//             only shard the counters.
+//   residual  every block folds max|new - old| (:105-131) into a per-iteration word with an atomic
+//             max before it arrives; after the barrier everyone reads the same word and takes the same
+//             stop decision (:147).
+// A one-block grid (<= 8 tiles: Pearl's network, small chains) needs no atomics at all: LDS slots and
+// __syncthreads().
+//
+// Every wait is bounded (100 MHz wall clock); a wait that gives up raises `abort`, every block leaves,
+// and the host redoes the run with per-sweep launches.  A launch executes at most `budget` iterations;
+// a run that needs more continues on the launch path from the state this kernel leaves in memory.
+#include "bn_tiles.hpp"
+
+namespace bnmi {
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// Message records are exchanged between CUs / XCDs inside the launch: every record access is a
+// 16-byte sc1 access through a buffer descriptor (aux 16 = sc1) -- stores write through, loads
+// bypass the CU's L1 -- the form of Guideline 16 that needs neither a release nor an acquire fence
+// around the barrier (an agent-scope acquire costs ~1.7 us per block and sweep).  They are ordinary
+// compiler-tracked memory operations; offsets are 32-bit (the host admits record buffers < 2 GiB).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2_t ld_rec(__amdgpu_buffer_rsrc_t r, int64_t idx2) {
+    return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, int(idx2) * 16, 0, 16));
+}
+__device__ __forceinline__ void st_rec(__amdgpu_buffer_rsrc_t r, int64_t idx2, double2_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, int(idx2) * 16, 0, 16);
+}
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Pins a value at this point of the program: the empty asm is opaque to every compiler pass, so nothing
+// that produces `x` can sink below it and nothing that consumes it can rise above.  Used to keep the
+// unrolled CPT contraction in own-state order -- left alone, instruction selection interleaves all
+// K * C products of the unrolled loops and needs far more than 256 registers for their temporaries.
+__device__ __forceinline__ void pin_here(double& x) { asm volatile("" : "+v"(x)); }
+
+struct BlockShared {
+    unsigned long long slot[kResidentWaves];  // per-wave residual bit patterns
+    int verdict;                              // of the iteration: kGoOn / kConverged / kCapped / kAbort
+};
+enum : int { kGoOn = 0, kConverged = 1, kCapped = 2, kAbort = 3 };
+
+// maximum_difference (:105) from the bit pattern accumulated by the atomic max
+__device__ __forceinline__ double residual_of(unsigned long long bits) {
+    const double r = __longlong_as_double((long long)bits);
+    return r < DBL_MIN ? DBL_MIN : r;  // it starts at numeric_limits<double>::min()
+}
+__device__ __forceinline__ int verdict_of(const ResidentArgs& a, double r, int n_done) {
+    if (r < a.eps) return kConverged;                             // strict '<' (:147)
+    if (a.max_sweeps > 0 && n_done >= a.max_sweeps) return kCapped;
+    return kGoOn;
+}
+
+// Barrier + residual reduction + stop decision of iteration s (the it-th of this launch).
+// Every block folds its residual into res[it] BEFORE it arrives, so the last arriver of all reads
+// the final value, decides, and publishes the verdict together with the generation in ONE word per
+// group: nobody else reads the residual on the critical path.  One-block grids decide from LDS.
+__device__ __forceinline__ int sync_and_decide(const ResidentArgs& a, BlockShared& sh, int s, double wres, int lane, int wave) {
+    const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
+    if (lane == 0) sh.slot[wave] = bits;
+    drain_stores();  // this wave's write-through stores have reached memory
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = 0;
+#pragma unroll
+        for (int w = 0; w < kResidentWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
+        const int it = s - a.sweep_begin;
+        const int nb = gridDim.x;
+        int verdict;
+        if (nb == 1) {
+            a.sync->res[it] = m;
+            verdict = verdict_of(a, residual_of(m), s + 1);
+        } else {
+            ResidentSync* sy = a.sync;
+            const unsigned gen = unsigned(it) + 1u;
+            const int groups = nb < 8 ? nb : 8;
+            const int g = blockIdx.x % groups;
+            const unsigned in_group = unsigned((nb - g + groups - 1) / groups);
+            if (m != 0) __hip_atomic_fetch_max(&sy->res[it], m, RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the max is performed before this block arrives
+            const unsigned old = __hip_atomic_fetch_add(&sy->grp[g].count, 1u, RLX_AGENT);
+            if (old + 1u == in_group * gen) {
+                const unsigned t = __hip_atomic_fetch_add(&sy->top, 1u, RLX_AGENT);
+                if (t + 1u == unsigned(groups) * gen) {
+                    const unsigned long long all = __hip_atomic_load(&sy->res[it], RLX_AGENT);
+                    const unsigned word = gen | (unsigned(verdict_of(a, residual_of(all), s + 1)) << 30);
+                    for (int q = 0; q < groups; ++q) __hip_atomic_store(&sy->grp[q].gen, word, RLX_AGENT);
+                }
+            }
+            const unsigned long long t0 = wall_clock64();
+            unsigned word;
+            verdict = kAbort;
+            for (;;) {
+                word = __hip_atomic_load(&sy->grp[g].gen, RLX_AGENT);
+                if ((word & 0x3fffffffu) >= gen) { verdict = int(word >> 30); break; }
+                if (__hip_atomic_load(&sy->abort, RLX_AGENT) != 0) break;
+                if (wall_clock64() - t0 > a.timeout_ticks) {
+                    __hip_atomic_store(&sy->abort, 1u, RLX_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        sh.verdict = verdict;
+    }
+    __syncthreads();
+    return sh.verdict;
+}
+
+struct RunEnd {
+    int n_sweeps;
+    int done;      // 0 budget exhausted, 1 converged, 2 max_sweeps reached
+    bool abort;
+};
+
+// A wave without a tile: takes part in the barriers, contributes nothing.
+__device__ __forceinline__ RunEnd resident_idle(const ResidentArgs& a, BlockShared& sh, int lane, int wave) {
+    RunEnd e{a.sweep_begin, 0, false};
+    for (int it = 0; it < a.budget; ++it) {
+        const int s = a.sweep_begin + it;
+        const int v = sync_and_decide(a, sh, s, 0.0, lane, wave);
+        if (v == kAbort) { e.abort = true; return e; }
+        e.n_sweeps = s + 1;
+        if (v != kGoOn) { e.done = v; return e; }
+    }
+    return e;
+}
+
+// Tables of more than 32 entries (k = 4 with two parents: 64) keep the entries of the upper half of the
+// own states in LDS -- 16 bytes per lane and slot, lane-contiguous: conflict-free ds_read_b128 -- and the
+// lower half in registers; 128 VGPRs of CPT plus the working set do not fit 256 registers, and the
+// compiler's answer, scratch memory, would re-read two thirds of the table through the caches each sweep.
+template <int K, int M, int RC>
+__device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+                                                double2_t* cpt_lds) {
+    constexpr int KP = (K + 1) & ~1, H = KP / 2;
+    constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
+    constexpr int CB = (M > 0) ? C / K : 0;
+    constexpr int KR = (S > 32) ? K / 2 : K;       // own states whose CPT entries stay in registers
+    constexpr int SR = (KR == K) ? SP : KR * C;     // entries in registers (even)
+    static_assert(SR % 2 == 0 && (KR == K || (C % 2 == 0 && (S - SR) / 2 <= kResidentLdsSlots)), "CPT split");
+    const BpBuffers& b = a.b;
+    const bool active = lane < td.n_nodes;
+    const int lc = active ? lane : 0;  // idle lanes shadow lane 0 and store nothing
+
+    // ---- resident state: CPT, evidence mark, references, pi(v), lambda(v)
+    const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lc;
+    double cpt[SR];
+#pragma unroll
+    for (int q = 0; q < SR / 2; ++q) {
+        const double2_t x = cp[q * kWave];
+        cpt[2 * q] = x.x;
+        cpt[2 * q + 1] = x.y;
+    }
+    if constexpr (KR < K) {
+#pragma unroll
+        for (int q = SR / 2; q < S / 2; ++q) cpt_lds[(q - SR / 2) * kWave + lane] = cp[q * kWave];
+    }
+    const bool frozen = b.frozen[td.slot_base + lc] != 0;
+    const int64_t rbase = td.rec_base / 2 + lc;  // this lane's slot in the tile's record block (double2 units)
+    const MsgRef* orf = b.out_refs + td.out_base + lc;
+    MsgRef oref[RC > 0 ? RC : 1];  // kept packed (8 bytes per child) and decoded at each use: registers matter here
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+        oref[c] = MsgRef{-1, 0};
+        if (active && c < td.cmax) oref[c] = orf[c * kWave];
+    }
+    double piv[KP], lav[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {  // initial state (:38-64): roots start from their CPT row
+        piv[i] = (M == 0 && i < K) ? cpt[i] : 1.0;
+        lav[i] = 1.0;
+    }
+    {
+        // evidence nodes hold their vector as pi and lambda (:68-73); a continued run (sweep_begin > 0)
+        // picks up the node vectors the previous launch left in memory
+        const bool from_memory = frozen || a.sweep_begin > 0;
+        const double2_t* nin = reinterpret_cast<const double2_t*>(((a.sweep_begin & 1) ? b.node1 : b.node0) + td.node_base) + lc;
+        if (from_memory) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
+                piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
+                lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+            }
+        }
+    }
+
+    const size_t rec_bytes = size_t(b.rec_total_doubles) * 8;
+    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(b.rec0, 0, int(rec_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(b.rec1, 0, int(rec_bytes), 0x00020000);
+    RunEnd e{a.sweep_begin, 0, false};
+    for (int it = 0; it < a.budget; ++it) {
+        const int s = a.sweep_begin + it;
+        const bool first = s == 0;
+        const __amdgpu_buffer_rsrc_t rin = (s & 1) ? rsrc1 : rsrc0;
+        const __amdgpu_buffer_rsrc_t rout = (s & 1) ? rsrc0 : rsrc1;
+
+        double wres = 0.0;
+        // ---- parent role first (it needs only the OLD pi(v) and the children's lambda-messages; done
+        // before the child role so that its registers are free again when the CPT products start):
+        // lambda(v) (:220-238) and the pi-message to every child (:202-218) = pi(v) times the OTHER
+        // children's lambda-messages, ascending child order
+        double lan[K];
+        {
+            double lkc[RC > 0 ? RC : 1][KP];
+#pragma unroll
+            for (int c = 0; c < RC; ++c)
+#pragma unroll
+                for (int i = 0; i < KP; ++i) lkc[c][i] = 1.0;
+            if (!first) {
+#pragma unroll
+                for (int c = 0; c < RC; ++c)
+                    if (c < td.cmax) {
+                        const Loc l = decode_ref(oref[c], H);  // a missing child reads record 0 and contributes 1.0
+#pragma unroll
+                        for (int h = 0; h < H; ++h) {
+                            const double2_t y = ld_rec(rin, l.lam + h * l.stride);
+                            lkc[c][2 * h] = l.has ? y.x : 1.0;
+                            lkc[c][2 * h + 1] = l.has ? y.y : 1.0;
+                        }
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                double acc = 1.0;
+#pragma unroll
+                for (int c = 0; c < RC; ++c) acc *= lkc[c][i];
+                lan[i] = acc;
+            }
+            normalize_k<K>(lan);
+#pragma unroll
+            for (int c = 0; c < RC; ++c) {
+                if (c < td.cmax) {  // wave-uniform
+                    pin_here(wres);  // one child at a time (see pin_here)
+#pragma unroll
+                    for (int i = 0; i < K; ++i) pin_here(piv[i]);
+
+                    double u[K];
+#pragma unroll
+                    for (int i = 0; i < K; ++i) {
+                        double acc = piv[i];
+#pragma unroll
+                        for (int x = 0; x < RC; ++x)
+                            if (x != c) acc *= lkc[x][i];
+                        u[i] = acc;
+                    }
+                    normalize_k<K>(u);
+                    const Loc l = decode_ref(oref[c], H);
+                    if (l.has) {
+                        double old[KP], o[KP];
+#pragma unroll
+                        for (int i = 0; i < KP; ++i) { old[i] = 1.0; o[i] = 0.0; }
+                        if (!first) {
+#pragma unroll
+                            for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
+                                const double2_t x = ld_rec(rin, l.pi + h * l.stride);
+                                old[2 * h] = x.x; old[2 * h + 1] = x.y;
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < K; ++i) {
+                            o[i] = u[i];
+                            wres = res_acc(wres, fabs(u[i] - old[i]));
+                        }
+#pragma unroll
+                        for (int h = 0; h < H; ++h) {
+                            double2_t y;
+                            y.x = o[2 * h]; y.y = o[2 * h + 1];
+                            st_rec(rout, l.pi + h * l.stride, y);
+                        }
+                    }
+                }
+            }
+        }
+
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- child role, calculate_pi (:174-200) and calculate_lambda_k (:240-266): each accumulator
+        // sees its terms in the reference's order (see tile_uniform); lambda(v)[i] * cpt is formed at each
+        // use instead of being kept (same operation, same bits, 2 C fewer live registers)
+        double pim[M > 0 ? M : 1][KP];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int i = 0; i < KP; ++i) pim[j][i] = 1.0;
+        if (!first) {
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t x = ld_rec(rin, rbase + ((j * 2 + 0) * H + h) * kWave);
+                    pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
+                }
+        }
+        double pin[K];
+        double out[M > 0 ? M : 1][K];
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt)
+#pragma unroll
+            for (int ct = 0; ct < K; ++ct) out[jt][ct] = 0.0;
+#pragma unroll
+        for (int ib = 0; ib < K; ++ib) {
+            if constexpr (M == 0) {
+                pin[ib] = 0.0 + cpt[ib];
+            } else {
+                // one own state at a time: everything this step consumes is pinned here
+                pin_here(lav[ib]);
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+#pragma unroll
+                    for (int i = 0; i < K; ++i) pin_here(pim[j][i]);
+#pragma unroll
+                for (int jt = 0; jt < M; ++jt)
+#pragma unroll
+                    for (int ct = 0; ct < K; ++ct) pin_here(out[jt][ct]);
+                // entry `cond` of own state ib: a register, or this wave's LDS slots (read where it is used:
+                // a copy of the whole row would cost 2 C registers for the length of the step)
+                const double* lds_row = reinterpret_cast<const double*>(cpt_lds + ((ib < KR ? 0 : ib - KR) * (C / 2)) * kWave + lane);
+                auto ROW = [&](int cond) -> double {
+                    if (ib < KR) return cpt[(ib < KR ? ib : 0) * C + cond];
+                    return lds_row[(cond >> 1) * (2 * kWave) + (cond & 1)];
+                };
+                double acc = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < CB; ++rr) {
+                    if (rr > 0) {  // K + M K independent chains per step are plenty; pin the step's boundary
+                        asm volatile("" ::: "memory");
+                        pin_here(acc);
+                        pin_here(lav[ib]);
+#pragma unroll
+                        for (int j = 0; j < M; ++j)
+#pragma unroll
+                            for (int i = 0; i < K; ++i) pin_here(pim[j][i]);
+#pragma unroll
+                        for (int jt = 0; jt < M; ++jt)
+#pragma unroll
+                            for (int ct = 0; ct < K; ++ct) pin_here(out[jt][ct]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < K; ++x) {
+                        const int cond = rr * K + x;
+                        double value = ROW(cond);
+#pragma unroll
+                        for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                        acc += value;
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < M; ++jt) {
+                        const int stride = ipow(K, M - 1 - jt);
+#pragma unroll
+                        for (int ct = 0; ct < K; ++ct) {
+                            const int cond = (rr / stride) * stride * K + ct * stride + (rr % stride);
+                            double value = lav[ib] * ROW(cond);
+#pragma unroll
+                            for (int j = 0; j < M; ++j)
+                                if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                            out[jt][ct] += value;
+                        }
+                    }
+                }
+                pin[ib] = acc;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        normalize_k<K>(pin);
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt) normalize_k<K>(out[jt]);
+
+        // ---- lambda-messages out + residual (:105-131); this lane's previous messages are re-read from the old buffer
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt) {
+            double old[KP], o[KP];
+#pragma unroll
+            for (int i = 0; i < KP; ++i) { old[i] = 1.0; o[i] = 0.0; }
+            if (!first) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const double2_t y = ld_rec(rin, rbase + ((jt * 2 + 1) * H + h) * kWave);
+                    old[2 * h] = y.x; old[2 * h + 1] = y.y;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                o[i] = out[jt][i];
+                wres = res_acc(wres, fabs(out[jt][i] - old[i]));
+            }
+            if (active) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    double2_t y;
+                    y.x = o[2 * h]; y.y = o[2 * h + 1];
+                    st_rec(rout, rbase + ((jt * 2 + 1) * H + h) * kWave, y);
+                }
+            }
+        }
+        if (!active) wres = 0.0;
+        // node vectors stay in registers; evidence nodes keep theirs (:177, :223)
+        if (!frozen) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) { piv[i] = pin[i]; lav[i] = lan[i]; }
+        }
+
+        const int v = sync_and_decide(a, sh, s, wres, lane, wave);
+        if (v == kAbort) { e.abort = true; return e; }
+        e.n_sweeps = s + 1;
+        if (v != kGoOn) { e.done = v; break; }
+    }
+
+    // ---- the run (or this launch's budget) is over: node vectors to the buffer the next reader expects
+    // (parity of the number of executed sweeps), beliefs = normalize(pi % lambda) (:151-158)
+    if (active) {
+        double2_t* nout = reinterpret_cast<double2_t*>(((e.n_sweeps & 1) ? b.node1 : b.node0) + td.node_base) + lane;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            double2_t y, z;
+            y.x = piv[2 * h]; y.y = (2 * h + 1 < K) ? piv[2 * h + 1] : 0.0;
+            z.x = lav[2 * h]; z.y = (2 * h + 1 < K) ? lav[2 * h + 1] : 0.0;
+            nout[h * kWave] = y;
+            nout[(H + h) * kWave] = z;
+        }
+        if (e.done != 0) {
+            const int64_t boff = b.slot_boff[td.slot_base + lane];
+            double bel[K];
+            double sum = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                bel[i] = piv[i] * lav[i];
+                sum += bel[i];
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) b.beliefs[boff + i] = bel[i] / sum;
+        }
+    }
+    return e;
+}
+
+template <int K, int M>
+__device__ __forceinline__ RunEnd resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+                                                    double2_t* cpt_lds) {
+#ifdef BN_RES_ONLY_RC  // experiments: one instantiation only
+    return resident_tile<K, M, BN_RES_ONLY_RC>(a, sh, td, lane, wave, cpt_lds);
+#else
+    if (td.cmax <= 2) return resident_tile<K, M, 2>(a, sh, td, lane, wave, cpt_lds);
+    return resident_tile<K, M, 4>(a, sh, td, lane, wave, cpt_lds);
+#endif
+}
+
+__global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(ResidentArgs a) {
+    __shared__ BlockShared sh;
+    __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // upper CPT halves, 16 KiB per wave
+    const BpBuffers& b = a.b;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long t_first = wall_clock64();
+    // XCD-contiguous tile mapping (speed only), as in the per-sweep kernel
+    const int nb = gridDim.x;
+    const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int tile = lb * kResidentWaves + wave;
+    RunEnd e;
+    if (tile >= b.n_tiles) {
+        e = resident_idle(a, sh, lane, wave);
+    } else {
+        const TileDesc td = b.tiles[tile];
+#ifdef BN_RES_ONLY_K
+        e = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M>(a, sh, td, lane, wave, cpt_lds_all[wave]);
+#else
+        switch (td.kv * 8 + td.m) {
+            case 2 * 8 + 0: e = resident_dispatch<2, 0>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 2 * 8 + 1: e = resident_dispatch<2, 1>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 2 * 8 + 2: e = resident_dispatch<2, 2>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 3 * 8 + 0: e = resident_dispatch<3, 0>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 3 * 8 + 1: e = resident_dispatch<3, 1>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 3 * 8 + 2: e = resident_dispatch<3, 2>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 4 * 8 + 0: e = resident_dispatch<4, 0>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            case 4 * 8 + 1: e = resident_dispatch<4, 1>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
+            default: e = resident_dispatch<4, 2>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;  // host admits only the shapes above
+        }
+#endif
+    }
+    if (blockIdx.x == 0 && wave == 0 && !e.abort) {
+        // per-iteration maximum_difference: final since the barrier of each iteration
+        const int n_it = e.n_sweeps - a.sweep_begin;
+        for (int it = lane; it < n_it; it += kWave)
+            if (a.sweep_begin + it < b.res_cap)
+                b.res_hist[a.sweep_begin + it] = residual_of(__hip_atomic_load(&a.sync->res[it], RLX_AGENT));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int n_it = e.n_sweeps - a.sweep_begin;
+        a.host_ctl->last_res = (!e.abort && n_it > 0) ? residual_of(__hip_atomic_load(&a.sync->res[n_it - 1], RLX_AGENT)) : 0.0;
+        a.host_ctl->n_sweeps = e.n_sweeps;
+        a.host_ctl->t_first = t_first; a.host_ctl->t_last = wall_clock64();
+        a.host_ctl->run_id = a.run_id;
+        a.host_ctl->done = e.abort ? -1 : e.done;
+    }
+}
+
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
+    hipLaunchKernelGGL(bp_resident_kernel, dim3(grid_blocks), dim3(kResidentWaves * kWave), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+
+}  // namespace bnmi

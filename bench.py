@@ -155,27 +155,40 @@ def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
     dt_ev = time.perf_counter() - t1
     eng.set_option("timing", 0)
     st = eng.bp_stats()
-    per_launch = max(launches, 1) if path == 0 else max(ev_sweeps, 1)  # one launch per run: per sweep inside it
-    avg_launch_s = kern_ms * 1e-3 / per_launch
+    # per-sweep launches: one launch = one sweep.  One-launch paths: a launch is the whole run; the
+    # per-sweep figure divides its duration by the sweeps it executed (same bytes-per-second either way).
+    avg_sweep_s = kern_ms * 1e-3 / max(ev_sweeps, 1)
+    avg_launch_s = kern_ms * 1e-3 / max(launches, 1)
     avg_dev_s = dev_ms * 1e-3 / max(sweeps_total, 1)
-    if avg_launch_s <= 0:
-        avg_launch_s = avg_dev_s
-    achieved = st["algorithmic_bytes_per_sweep"] / avg_launch_s / 1e9
+    if avg_sweep_s <= 0:
+        avg_sweep_s = avg_dev_s
+    achieved = st["algorithmic_bytes_per_sweep"] / avg_sweep_s / 1e9
     return {"dt": dt, "sweeps_total": sweeps_total, "msgs": g.messages_per_sweep() * sweeps_total,
-            "avg_launch_s": avg_launch_s, "avg_launch_devclock_s": avg_dev_s, "achieved": achieved, "stats": st,
+            "avg_sweep_s": avg_sweep_s, "avg_launch_s": avg_launch_s, "sweeps_per_launch": ev_sweeps / max(launches, 1),
+            "avg_sweep_devclock_s": avg_dev_s, "achieved": achieved, "stats": st,
             "path": path, "ms_per_step_with_events": dt_ev / max(ev_steps, 1) * 1e3, "event_steps": ev_steps}
 
 
-def roofline_of(t, label, kernel="bp_sweep_kernel"):
+PATH_KERNEL = {0: "bp_sweep_kernel", 1: "bp_multi_kernel", 2: "bp_resident_kernel"}
+PATH_NAME = {0: "one launch per sweep", 1: "one workgroup, one launch for the whole run",
+             2: "resident tiles, one launch for the whole run (grid barrier per sweep)"}
+
+
+def roofline_of(t, label):
+    """achieved = algorithmic bytes of the sweeps one launch executes / that launch's duration."""
     st = t["stats"]
+    spl = t["sweeps_per_launch"]
     out = {"bound": "hbm", "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": t["achieved"] / HBM_PEAK_GBS, "kernel": kernel, "avg_launch_us": t["avg_launch_s"] * 1e6,
+           "frac": t["achieved"] / HBM_PEAK_GBS, "kernel": PATH_KERNEL.get(t["path"], "?"),
+           "avg_launch_us": t["avg_launch_s"] * 1e6, "sweeps_per_launch": spl,
+           "avg_sweep_us": t["avg_sweep_s"] * 1e6,
            "avg_launch_us_source": f"HIP events on the engine's stream, {t['event_steps']} repeated steps after the timed region "
                                    f"({t['ms_per_step_with_events']:.4f} ms per step with the events in the queue)",
-           "avg_launch_us_devclock": t["avg_launch_devclock_s"] * 1e6,
-           "achieved_devclock": st["algorithmic_bytes_per_sweep"] / max(t["avg_launch_devclock_s"], 1e-12) / 1e9,
-           "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"],
-           "layout_bytes_per_launch": st["layout_bytes_per_sweep"]}
+           "avg_sweep_us_devclock": t["avg_sweep_devclock_s"] * 1e6,
+           "achieved_devclock": st["algorithmic_bytes_per_sweep"] / max(t["avg_sweep_devclock_s"], 1e-12) / 1e9,
+           "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"] * spl,
+           "algorithmic_bytes_per_sweep": st["algorithmic_bytes_per_sweep"],
+           "layout_bytes_per_sweep": st["layout_bytes_per_sweep"]}
     out.update(profiled_traffic(label))
     return out
 
@@ -345,9 +358,9 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{wname}, {ev.ne} evidence nodes, eps={a.eps:g}",
                    "sweeps_per_step": t["sweeps_total"] / a.steps, "messages_per_sweep": g.messages_per_sweep(),
-                   "parallelism": "1 GPU", "run_path": "one launch for the whole run" if t["path"] == 1 else "one launch per sweep"},
+                   "parallelism": "1 GPU", "run_path": PATH_NAME.get(t["path"], "?")},
         "roofline": roof,
-        "sweep_only_msgs_per_s": g.messages_per_sweep() / t["avg_launch_s"],
+        "sweep_only_msgs_per_s": g.messages_per_sweep() / t["avg_sweep_s"],
     }
     if not a.no_extras:
         h2h = time_host_to_host(eng, g, ev, a.eps, min(a.steps, 20))

@@ -122,7 +122,13 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * record between two launches opens a bubble of several microseconds in the queue, so a timed run is
  * slower than an untimed one; bn_bp_stats.sweep_devclock_ms -- the device's 100 MHz clock read by the
  * kernels themselves at the first sweep's start and the last sweep's end -- costs nothing and is always on.
- * bn_bp_last_path: 1 = the last run was one launch for the whole run, 0 = one launch per sweep. */
+ * "multisweep" 0/1/2 -- the one-launch paths (BN_MULTISWEEP in the environment sets the default, 1):
+ *   networks of register-resident tiles that fit the chip can run the whole run in ONE launch with
+ *   CPTs, references and node vectors resident in registers / LDS and a grid barrier per sweep; other
+ *   small networks can run all their sweeps in one workgroup.  0 = always one launch per sweep;
+ *   1 = the resident path where it was measured faster (one-block networks, grids of >= 640 tiles);
+ *   2 = every eligible one-launch path (tests, experiments).  Results are bit-identical on every path.
+ * bn_bp_last_path: 0 = one launch per sweep, 1 = one workgroup for the whole run, 2 = resident tiles. */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 

@@ -22,7 +22,10 @@ nets = [("alarm_shaped", alarm), ("pearl", synth.pearl()), ("resume_chain", synt
         ("dag200", synth.random_dag(200, 4, 64, 4, seed=200)), ("dag1000", synth.random_dag(1000, 4, 64, 4, seed=1000)),
         ("mixed60", synth.random_dag(60, 3, 16, [2, 3, 4, 3, 2, 4, 4], seed=9)),
         ("mixed300", synth.random_dag(300, 3, 32, [2, 3, 4, 3, 2, 5], seed=4)),
-        ("mixed2k", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9))]
+        ("mixed2k", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)),
+        ("chain200", synth.grid(200, 1, 4, seed=5)), ("grid64", synth.grid(64, 64, 4, seed=1)),
+        ("grid128", synth.grid(128, 128, 4, seed=1)), ("grid316", synth.grid(316, 316, 4, seed=2)),
+        ("dag2p_3000", synth.random_dag(3000, 2, 64, 4, seed=3))]
 if len(sys.argv) > 1:
     nets = [x for x in nets if x[0] in sys.argv[1:]]
 out = {}
@@ -32,7 +35,7 @@ for name, mod in nets:
         e.bp_set_evidence(Evidence.none())
         res = {}
         for path in (1, 0):
-            e.set_option("multisweep", path)
+            e.set_option("multisweep", 2 * path)
             for _ in range(3):
                 r = e.bp_run_device(1e-6)
             reps = 20

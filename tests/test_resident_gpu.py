@@ -1,0 +1,103 @@
+"""The one-launch paths (bn_resident.hip: tiles resident in registers / LDS + a grid barrier per sweep;
+bn_multi.hip: one workgroup): they must be bit-identical to the per-sweep launch path -- beliefs,
+sweep count, per-sweep residuals, final messages -- on every run, also when runs are repeated back to
+back (stale cache lines of an earlier run are the classic failure of an in-launch exchange), with and
+without evidence, and they must be chosen only for eligible models."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(bnlib):
+    from bayesiannetwork_amd.engine import Engine
+    return Engine
+
+
+def _launch_path(eng, ev, eps, max_sweeps=0):
+    eng.set_option("multisweep", 0)
+    r = eng.bp_run(ev, eps, max_sweeps)
+    assert eng.last_path() == 0
+    return r, eng.bp_residuals(), eng.bp_messages()
+
+
+def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
+    r0, res0, (pi0, lam0) = want
+    eng.set_option("multisweep", 2)
+    for i in range(reps):
+        r = eng.bp_run(ev, eps, max_sweeps)
+        assert eng.last_path() != 0
+        if want_path is not None:
+            assert eng.last_path() == want_path
+        assert r["sweeps"] == r0["sweeps"], f"run {i}"
+        assert np.array_equal(r["beliefs"], r0["beliefs"], equal_nan=True), f"run {i}"
+        assert r["residual"] == r0["residual"] or (np.isnan(r["residual"]) and np.isnan(r0["residual"]))
+    assert np.array_equal(eng.bp_residuals(), res0)
+    pi, lam = eng.bp_messages()
+    assert np.array_equal(pi, pi0, equal_nan=True) and np.array_equal(lam, lam0, equal_nan=True)
+
+
+@pytest.mark.parametrize("rows,cols,k,frac,eps,reps", [
+    (316, 316, 4, 0.01, 1e-3, 40), (316, 316, 4, 0.0, 1e-6, 10), (64, 64, 4, 0.05, 1e-9, 10), (40, 33, 3, 0.02, 1e-6, 10),
+    (50, 50, 2, 0.02, 1e-6, 10), (1, 300, 4, 0.0, 1e-6, 10), (7, 5, 4, 0.1, 1e-3, 10), (128, 128, 4, 0.01, 1e-6, 10),
+])
+def test_resident_equals_launch_path_grids(Engine, rows, cols, k, frac, eps, reps):
+    from bayesiannetwork_amd import synth
+    g = synth.grid(rows, cols, k, seed=rows * 31 + cols)
+    ev = synth.random_evidence(g, frac, seed=3)
+    with Engine(g) as eng:
+        want = _launch_path(eng, ev, eps)
+        _check_same(eng, ev, eps, want, reps, want_path=2)
+        # alternate the paths and the evidence: nothing of one run may leak into the next
+        ev2 = synth.random_evidence(g, max(frac, 0.02), seed=11)
+        want2 = _launch_path(eng, ev2, eps)
+        _check_same(eng, ev2, eps, want2, 3, want_path=2)
+        _check_same(eng, ev, eps, _launch_path(eng, ev, eps), 3, want_path=2)
+
+
+def test_resident_trees_and_dags(Engine):
+    """<= 2 parents, up to 4 children per node (the shapes the resident kernel instantiates)."""
+    from bayesiannetwork_amd import synth
+    for seed in range(6):
+        d = synth.random_dag(700, 2, 8, [4, 3, 2][seed % 3], seed=40 + seed)
+        ev = synth.random_evidence(d, 0.02, seed=seed)
+        with Engine(d) as eng:
+            want = _launch_path(eng, ev, 1e-6)
+            eng.set_option("multisweep", 2)
+            eng.bp_run(ev, 1e-6)
+            if eng.last_path() == 0:  # some node has more than 4 children: not eligible, nothing to compare
+                continue
+            _check_same(eng, ev, 1e-6, want, 5)
+
+
+def test_resident_max_sweeps_and_soft_evidence(Engine):
+    from bayesiannetwork_amd import Evidence, synth
+    g = synth.grid(48, 48, 4, seed=5)
+    ev = synth.random_evidence(g, 0.03, seed=2)
+    with Engine(g) as eng:
+        for cap in (1, 2, 5):
+            want = _launch_path(eng, ev, 1e-12, max_sweeps=cap)
+            assert want[0]["sweeps"] == cap
+            _check_same(eng, ev, 1e-12, want, 2, max_sweeps=cap, want_path=2)
+        soft = Evidence.from_dict(g, {5: np.array([0.2, 0.5, 0.2, 0.1]), 700: np.array([0.0, 0.0, 1.0, 0.0]),
+                                      1500: np.array([0.25, 0.25, 0.25, 0.25])})
+        _check_same(eng, soft, 1e-9, _launch_path(eng, soft, 1e-9), 3, want_path=2)
+        # a zero row: 0/0 -> NaN in the reference (no zero guard, belief_propagation.hpp:298-311)
+        zero = Evidence.from_dict(g, {100: np.array([0.0, 0.0, 0.0, 0.0])})
+        _check_same(eng, zero, 1e-6, _launch_path(eng, zero, 1e-6, max_sweeps=6), 2, max_sweeps=6, want_path=2)
+
+
+def test_paths_are_chosen_by_eligibility(Engine):
+    from bayesiannetwork_amd import synth
+    with Engine(synth.random_dag(300, 4, 32, 4, seed=1)) as eng:  # lane-group tiles: not resident
+        eng.set_option("multisweep", 2)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() in (0, 1)
+    with Engine(synth.grid(20, 20, 4, seed=1)) as eng:
+        eng.set_option("multisweep", 2)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() == 2
+        eng.set_option("multisweep", 0)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() == 0
