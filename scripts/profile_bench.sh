@@ -3,19 +3,49 @@
 # counters in SEPARATE passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass;
 # never combined with other trace domains).  Run on the GPU box from the repo root:
 #   bash scripts/profile_bench.sh [tag]          (outputs under gpurun_out/prof_<tag>/)
+# Every pass puts the program itself after `--` (no env / shell hop); switches travel as exported
+# environment variables.  A pass that fails is recorded in failed_passes.txt and reported by the summary.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
-ARGS="--steps 20 --warmup 3 --no-cpu"
-run() { timeout 180 "$@" < /dev/null; }
-run rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
-run rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o b -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/pmc_fetch.log 2>&1
-run rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o b -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/pmc_write.log 2>&1
-run rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o b -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/pmc_sq.log 2>&1
+: > $OUT/failed_passes.txt
+sha256sum bayesiannetwork_amd/libbn_mi355x.so | cut -d' ' -f1 > $OUT/lib_sha256.txt
+
+pass() {  # name, then the rocprofv3 arguments
+    local name=$1; shift
+    timeout 300 rocprofv3 "$@" > $OUT/$name.log 2>&1 < /dev/null
+    local rc=$?
+    if [ $rc -ne 0 ]; then echo "$name rc=$rc" >> $OUT/failed_passes.txt; fi
+}
+trace() { pass $1 --kernel-trace --stats --output-format csv -d $OUT/$1 -o t -- python3 bench.py "${@:2}"; }
+pmc() { pass $1 --kernel-trace --pmc $2 --output-format csv -d $OUT/$1 -o c -- python3 bench.py "${@:3}"; }
+
+B="--no-extras --no-cpu"
+# headline: 316x316 grid, default path (resident tiles, one launch per run)
+export BN_MULTISWEEP=1
+trace trace_grid316 $B --steps 20 --warmup 3
+pmc fetch_grid316 FETCH_SIZE $B --steps 5 --warmup 2
+pmc write_grid316 WRITE_SIZE $B --steps 5 --warmup 2
+pmc sq_grid316 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --steps 5 --warmup 2
+# the same grid with one launch per sweep
+export BN_MULTISWEEP=0
+trace trace_grid316_launch $B --steps 20 --warmup 3
+pmc fetch_grid316_launch FETCH_SIZE $B --steps 5 --warmup 2
+pmc write_grid316_launch WRITE_SIZE $B --steps 5 --warmup 2
+pmc sq_grid316_launch "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --steps 5 --warmup 2
+export BN_MULTISWEEP=1
+# config 2: 10 k-node DAG
+trace trace_dag10k $B --workload dag --steps 20 --warmup 3
+pmc fetch_dag10k FETCH_SIZE $B --workload dag --steps 5 --warmup 2
+pmc write_dag10k WRITE_SIZE $B --workload dag --steps 5 --warmup 2
+# config 5: likelihood weighting
+trace trace_lw $B --workload lw --steps 3
+pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
+pmc write_lw WRITE_SIZE $B --workload lw --steps 2
 # the HBM-resident point (4M nodes)
-run rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_2048 -o bench -- python3 bench.py --rows 2048 --cols 2048 --steps 5 --warmup 2 --no-cpu > $OUT/bench_trace_2048.log 2>&1
-run rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_2048 -o b -- python3 bench.py --rows 2048 --cols 2048 --steps 3 --warmup 1 --no-cpu > $OUT/pmc_fetch_2048.log 2>&1
-run rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_2048 -o b -- python3 bench.py --rows 2048 --cols 2048 --steps 3 --warmup 1 --no-cpu > $OUT/pmc_write_2048.log 2>&1
+trace trace_grid2048 $B --rows 2048 --cols 2048 --steps 3 --warmup 1
+pmc fetch_grid2048 FETCH_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1
+pmc write_grid2048 WRITE_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1
 python3 scripts/summarize_profile.py $OUT $TAG
