@@ -40,7 +40,7 @@ class LayoutInfo(ctypes.Structure):
                 ("cpt_doubles", ctypes.c_int64), ("rec_doubles", ctypes.c_int64), ("node_doubles", ctypes.c_int64),
                 ("algorithmic_bytes_per_sweep", ctypes.c_int64), ("layout_bytes_per_sweep", ctypes.c_int64),
                 ("messages_per_sweep", ctypes.c_int64), ("rank", ctypes.c_int32), ("nranks", ctypes.c_int32),
-                ("n_owned", ctypes.c_int32), ("pad_", ctypes.c_int32), ("n_cut_edges", ctypes.c_int64),
+                ("n_owned", ctypes.c_int32), ("n_interior_tiles", ctypes.c_int32), ("n_cut_edges", ctypes.c_int64),
                 ("segment_bytes", ctypes.c_int64), ("segment_used_bytes", ctypes.c_int64),
                 ("exchange_base", ctypes.c_int64)]
 
@@ -67,6 +67,7 @@ SYMBOLS = [
     ("bn_bp_last_path", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_bp_step_begin", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_bp_step_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double]),
+    ("bn_bp_step_sweep_part", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32]),
     ("bn_bp_step_finish", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, i32p, i32p,
                                          f64p]),
     ("bn_debug_allgather", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32]),
@@ -83,6 +84,7 @@ SYMBOLS = [
     ("bn_layout_get", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(LayoutInfo)]),
     ("bn_layout_edge_refs", ctypes.c_int, [ctypes.c_void_p, i32p, i32p]),
     ("bn_layout_node_slots", ctypes.c_int, [ctypes.c_void_p, i32p]),
+    ("bn_layout_node_tiles", ctypes.c_int, [ctypes.c_void_p, i32p]),
     ("bn_layout_class", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, i32p, i32p, i32p]),
 ]
 

@@ -60,7 +60,9 @@ struct SweepArgs {
     double* node_out;
     double eps;
     int32_t sweep;       // 0-based index of this iteration
-    int32_t book_tile;   // first wave index past the tiles: it does the residual bookkeeping
+    int32_t tile_begin;  // this launch covers tiles [tile_begin, tile_end) ...
+    int32_t tile_end;
+    int32_t book;        // ... and, if set, the residual bookkeeping (done by the first wave past tile_end)
     uint32_t run_id;
 };
 

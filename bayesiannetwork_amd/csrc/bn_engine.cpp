@@ -106,6 +106,10 @@ struct bn_engine {
     MsgRef* d_out = nullptr;
     MsgRef* d_inrefs = nullptr;
     ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;   // sharded runs: the all-gathers run here, beside the interior tiles' launch
+    hipEvent_t ev_swept = nullptr;       // main stream: every tile of the current sweep has been launched
+    hipEvent_t ev_gathered = nullptr;    // comm stream: the current sweep's all-gather
+    bool overlap = true;                 // BN_OVERLAP=0 / bn_set_option("overlap", 0): kernel and collective back to back
     uint8_t* d_frozen = nullptr;
     int32_t* d_slot_node = nullptr;
     int64_t* d_slot_boff = nullptr;
@@ -145,7 +149,6 @@ struct bn_engine {
     bn_bp_stats stats{};
     std::vector<hipEvent_t> events;  // (begin, end) per sweep batch
     int grid_tiles = 0;              // blocks for one-wave-per-tile kernels without remap
-    int grid_sweep = 0;              // same, padded to a multiple of 8 for the XCD mapping
     LwState lw;
 };
 
@@ -156,6 +159,9 @@ static void free_engine(bn_engine* e) {
         (void)guard.enter(e->device);
         lw_free(e->lw);
         if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
+        if (e->ev_swept) (void)hipEventDestroy(e->ev_swept);
+        if (e->ev_gathered) (void)hipEventDestroy(e->ev_gathered);
+        if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync};
@@ -217,7 +223,6 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     const Plan& p = e->plan;
     e->grid_tiles = std::max(1, (int(p.tiles.size()) + kWavesPerBlock - 1) / kWavesPerBlock);
     // one wave past the tiles does the residual bookkeeping -> at least one spare wave
-    e->grid_sweep = ((int(p.tiles.size()) + 1 + kWavesPerBlock - 1) / kWavesPerBlock + 7) & ~7;
     e->stats.algorithmic_bytes_per_sweep = p.algorithmic_bytes;
     e->stats.layout_bytes_per_sweep = p.layout_bytes;
     e->stats.messages_per_sweep = p.messages_per_sweep;
@@ -241,6 +246,12 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         }
         HIPCHK(guard.enter(e->device));
         HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        if (p.nranks > 1) {
+            HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_swept, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&e->ev_gathered, hipEventDisableTiming));
+            if (const char* o = std::getenv("BN_OVERLAP")) e->overlap = std::atoi(o) != 0;
+        }
         int r;
         if ((r = upload(&e->d_tiles, p.tiles, e->stream))) return r;
         if ((r = upload(&e->d_classes, p.classes, e->stream))) return r;
@@ -435,19 +446,27 @@ static int step_begin(bn_engine* e) {
     return BN_OK;
 }
 
-static int step_sweep(bn_engine* e, int32_t sweep, double eps) {
+// part: 0 = every tile + bookkeeping (one launch); 1 = interior tiles only, no bookkeeping;
+// 2 = the tiles that touch a cut edge + bookkeeping (sharded runs, see bn_plan.cpp / run loop)
+static int step_sweep(bn_engine* e, int32_t sweep, double eps, int part = 0) {
     const int cur = sweep & 1;
+    const int32_t nt = int32_t(e->plan.tiles.size()), ni = e->plan.n_interior_tiles;
+    const int32_t t0 = part == 2 ? ni : 0, t1 = part == 1 ? ni : nt;
+    const int32_t book = part == 1 ? 0 : 1;
+    if (t1 - t0 + book <= 0) return BN_OK;
     SweepArgs sa{buffers_of(e), e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, sweep,
-                 int32_t(e->plan.tiles.size()), e->run_id};
+                 t0, t1, book, e->run_id};
+    // one wave per tile (+ one for the bookkeeping), blocks padded to a multiple of 8 for the XCD mapping
+    const int grid = ((t1 - t0 + book + kWavesPerBlock - 1) / kWavesPerBlock + 7) & ~7;
     static const bool no_light = std::getenv("BN_NO_LIGHT") != nullptr;  // A/B switch
-    if (launch_bp_sweep(sa, e->grid_sweep, e->nontemporal, e->plan.light && !no_light, e->plan.variants, e->stream))
+    if (launch_bp_sweep(sa, grid, e->nontemporal, e->plan.light && !no_light, e->plan.variants, e->stream))
         return fail(BN_ERR_HIP, "bp_sweep launch failed");
     return BN_OK;
 }
 
 // Halo exchange after sweep `sweep`: in-place all-gather of every rank's segment of the buffer
 // that sweep wrote.  One collective per sweep; it also carries the residual slots.
-static int step_exchange(bn_engine* e, int32_t sweep) {
+static int step_exchange(bn_engine* e, int32_t sweep, hipStream_t on) {
     const Plan& p = e->plan;
     // BN_EXCHANGE_ALWAYS: issue the (then trivial) collective on a 1-rank communicator too, so the
     // RCCL call can be exercised on a single-GPU box
@@ -455,8 +474,25 @@ static int step_exchange(bn_engine* e, int32_t sweep) {
     if (!e->comm) return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init before running");
     double* g = e->d_rec[(sweep + 1) & 1] + 2 * p.g_base;
     const size_t count = size_t(2 * p.seg_d2);
-    ncclResult_t rc = g_rccl.AllGather(g + size_t(p.rank) * count, g, count, ncclDouble, e->comm, e->stream);
+    ncclResult_t rc = g_rccl.AllGather(g + size_t(p.rank) * count, g, count, ncclDouble, e->comm, on);
     if (rc != ncclSuccess) return fail(BN_ERR_COMM, std::string("ncclAllGather: ") + g_rccl.GetErrorString(rc));
+    return BN_OK;
+}
+
+// One iteration of a sharded run with the exchange overlapped: the interior tiles of
+// iteration s read nothing the all-gather of iteration s-1 delivers, so their launch goes out first and
+// runs while that collective is still in flight on the comm stream; only the launch over the tiles that
+// touch a cut edge (and the residual bookkeeping, which reads every rank's slots) waits for it.
+// Critical path per iteration: max(interior kernel, all-gather) + boundary kernel, instead of their sum.
+static int step_sweep_overlapped(bn_engine* e, int32_t sweep, double eps, bool gather_pending) {
+    int rc;
+    if ((rc = step_sweep(e, sweep, eps, 1))) return rc;
+    if (gather_pending) HIPCHK(hipStreamWaitEvent(e->stream, e->ev_gathered, 0));
+    if ((rc = step_sweep(e, sweep, eps, 2))) return rc;
+    HIPCHK(hipEventRecord(e->ev_swept, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->comm_stream, e->ev_swept, 0));
+    if ((rc = step_exchange(e, sweep, e->comm_stream))) return rc;
+    HIPCHK(hipEventRecord(e->ev_gathered, e->comm_stream));
     return BN_OK;
 }
 
@@ -614,10 +650,16 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
             if ((rc = ensure_events(e, 2 * size_t(batches + 1)))) return rc;
             HIPCHK(hipEventRecord(e->events[2 * batches], s));
         }
+        const bool overlapped = e->plan.nranks > 1 && e->overlap && e->comm_stream;
         for (int32_t i = 0; i < batch; ++i) {
-            if ((rc = step_sweep(e, launched + i, eps))) return rc;
-            if ((rc = step_exchange(e, launched + i))) return rc;
+            if (overlapped) {
+                if ((rc = step_sweep_overlapped(e, launched + i, eps, launched + i > 0))) return rc;
+            } else {
+                if ((rc = step_sweep(e, launched + i, eps))) return rc;
+                if ((rc = step_exchange(e, launched + i, s))) return rc;
+            }
         }
+        if (overlapped && batch > 0) HIPCHK(hipStreamWaitEvent(s, e->ev_gathered, 0));  // the finish kernel reads every rank's slots
         launched += batch;
         if (e->timing) HIPCHK(hipEventRecord(e->events[2 * batches + 1], s));
         ++batches;
@@ -648,6 +690,7 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
 extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (!e || !name) return fail(BN_ERR_ARG, "null argument");
     if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
+    if (std::strcmp(name, "overlap") == 0) { e->overlap = value != 0; return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -667,6 +710,14 @@ extern "C" int bn_bp_step_sweep(bn_engine* e, int32_t sweep, double eps) {
     if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
     ON_DEVICE(e);
     return step_sweep(e, sweep, eps);
+}
+// part 1: the interior tiles only; part 2: the tiles that touch a cut edge + the residual bookkeeping
+// (together one sweep; the overlapped run launches part 1 before the previous sweep's exchange has landed)
+extern "C" int bn_bp_step_sweep_part(bn_engine* e, int32_t sweep, double eps, int32_t part) {
+    if (!e || e->host_only) return fail(BN_ERR_STATE, "no device engine");
+    if (part < 0 || part > 2) return fail(BN_ERR_ARG, "part must be 0, 1 or 2");
+    ON_DEVICE(e);
+    return step_sweep(e, sweep, eps, part);
 }
 extern "C" int bn_bp_step_finish(bn_engine* e, int32_t launched, int32_t final_batch, double eps, int32_t* done_out,
                                  int32_t* sweeps_out, double* residual_out) {
@@ -804,10 +855,17 @@ extern "C" int bn_layout_get(bn_engine* e, bn_layout_info* o) {
     o->rank = p.rank;
     o->nranks = p.nranks;
     o->n_owned = p.n_owned;
+    o->n_interior_tiles = p.n_interior_tiles;
     o->n_cut_edges = p.n_cut_edges;
     o->segment_bytes = p.seg_d2 * 16;
     o->segment_used_bytes = p.seg_used_d2.empty() ? 0 : p.seg_used_d2[p.rank] * 16;
     o->exchange_base = p.g_base;
+    return BN_OK;
+}
+
+extern "C" int bn_layout_node_tiles(bn_engine* e, int32_t* tiles_out) {
+    if (!e || !tiles_out) return fail(BN_ERR_ARG, "null argument");
+    std::copy(e->plan.node_tile.begin(), e->plan.node_tile.end(), tiles_out);
     return BN_OK;
 }
 

@@ -28,9 +28,9 @@ __global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepA
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int done = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
-    const int tile = logical_block() * kWavesPerBlock + wave;
-    if (tile >= b.n_tiles) {
-        if (done == 0 && tile == a.book_tile) sweep_bookkeeping(a, lane);
+    const int tile = a.tile_begin + logical_block() * kWavesPerBlock + wave;
+    if (tile >= a.tile_end) {
+        if (done == 0 && a.book != 0 && tile == a.tile_end) sweep_bookkeeping(a, lane);
         return;
     }
     const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};

@@ -228,6 +228,34 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
                 if (own(p.in_idx[e]) != me) proto[open[c]].boundary = true;
         }
     }
+    // Sharded plans: tiles none of whose nodes touches a cut edge ("interior": they never read the
+    // exchange region) come first, the others last.  The launch of iteration s+1 over the interior
+    // tiles needs nothing from the all-gather of iteration s and runs while it is in flight; only the
+    // launch over the trailing tiles waits for it (bn_engine.cpp).  Stable: node order is kept inside
+    // both groups, so neighbouring tiles stay neighbours.
+    p.n_interior_tiles = int32_t(proto.size());
+    if (shard.nranks > 1) {
+        std::vector<uint8_t> touches(proto.size(), 0);
+        for (size_t t = 0; t < proto.size(); ++t) {
+            bool cut = proto[t].boundary;
+            for (int32_t v : proto[t].nodes)
+                for (int32_t q = out_ptr[v]; q < out_ptr[v + 1] && !cut; ++q) {
+                    // the child of out-edge q: the node whose in-edge list holds CSR edge out_edge[q]
+                    const int32_t e = out_edge[q];
+                    const int32_t child = int32_t(std::upper_bound(p.in_ptr.begin(), p.in_ptr.end(), e) - p.in_ptr.begin()) - 1;
+                    if (own(child) != me) cut = true;
+                }
+            touches[t] = cut ? 1 : 0;
+        }
+        std::vector<ProtoTile> ordered;
+        ordered.reserve(proto.size());
+        for (size_t t = 0; t < proto.size(); ++t)
+            if (!touches[t]) ordered.push_back(std::move(proto[t]));
+        p.n_interior_tiles = int32_t(ordered.size());
+        for (size_t t = 0; t < proto.size(); ++t)
+            if (touches[t]) ordered.push_back(std::move(proto[t]));
+        proto.swap(ordered);
+    }
     const int32_t nt = int32_t(proto.size());
     p.tiles.assign(nt, TileDesc());
     p.node_tile.assign(n, -1);

@@ -153,6 +153,7 @@ struct Plan {
     // metrics (this rank's share)
     int64_t algorithmic_bytes = 0, layout_bytes = 0, messages_per_sweep = 0;
     int32_t g_max = 1;
+    int32_t n_interior_tiles = 0;    // tiles [0, n_interior_tiles) touch no cut edge (all tiles when nranks == 1)
     int32_t variants = 0;            // bit v set: some class is of Variant v (selects the kernel instantiation)
     bool light = false;              // no register-resident / k = 4 lane-group tile: the high-occupancy launch applies
 };

@@ -128,8 +128,9 @@ class Engine:
     def step_begin(self):
         _lib.check(_lib.lib().bn_bp_step_begin(self._h))
 
-    def step_sweep(self, sweep: int, eps: float):
-        _lib.check(_lib.lib().bn_bp_step_sweep(self._h, sweep, float(eps)))
+    def step_sweep(self, sweep: int, eps: float, part: int = 0):
+        """part 0: the whole sweep; 1: interior tiles; 2: tiles touching a cut edge + bookkeeping."""
+        _lib.check(_lib.lib().bn_bp_step_sweep_part(self._h, sweep, float(eps), part))
 
     def step_finish(self, launched: int, final: bool, eps: float):
         done, sw, res = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0.0)
@@ -204,6 +205,11 @@ class Engine:
             _lib.check(_lib.lib().bn_layout_class(self._h, c, *[ctypes.byref(x) for x in v]))
             out.append(dict(zip(["kv", "m", "lanes_per_node", "variant", "n_nodes"], [x.value for x in v])))
         return out
+
+    def node_tiles(self) -> np.ndarray:
+        t = np.zeros(max(self.model.n, 1), dtype=np.int32)
+        _lib.check(_lib.lib().bn_layout_node_tiles(self._h, _p(t, ctypes.c_int32)))
+        return t[:self.model.n]
 
     def node_slots(self) -> np.ndarray:
         s = np.zeros(max(self.model.n, 1), dtype=np.int32)
@@ -289,9 +295,12 @@ def debug_allgather(engines, sweep: int) -> None:
     _lib.check(_lib.lib().bn_debug_allgather(arr, len(engines), sweep))
 
 
-def run_shards_on_one_device(engines, evidence, eps: float, max_sweeps: int = 0):
+def run_shards_on_one_device(engines, evidence, eps: float, max_sweeps: int = 0, overlapped: bool = True):
     """Drive n shard engines on ONE GPU through the step API with the emulated all-gather:
-    the same kernels, layout and stopping logic as the RCCL path, minus the collective itself."""
+    the same kernels, layout and stopping logic as the RCCL path, minus the collective itself.
+    overlapped: the launch order of the engine's overlapped run -- the interior tiles of sweep s are
+    launched (and here even finished) BEFORE the exchange of sweep s-1 is applied, the tiles that touch
+    a cut edge after it; results must not depend on it (interior tiles read nothing the exchange delivers)."""
     for e in engines:
         e.bp_set_evidence(evidence)
         e.step_begin()
@@ -300,9 +309,20 @@ def run_shards_on_one_device(engines, evidence, eps: float, max_sweeps: int = 0)
         if max_sweeps > 0:
             batch = min(batch, max_sweeps - launched)
         for i in range(batch):
-            for e in engines:
-                e.step_sweep(launched + i, eps)
-            debug_allgather(engines, launched + i)
+            s = launched + i
+            if overlapped:
+                for e in engines:
+                    e.step_sweep(s, eps, part=1)
+                if s > 0:
+                    debug_allgather(engines, s - 1)
+                for e in engines:
+                    e.step_sweep(s, eps, part=2)
+            else:
+                for e in engines:
+                    e.step_sweep(s, eps)
+                debug_allgather(engines, s)
+        if overlapped and batch > 0:
+            debug_allgather(engines, launched + batch - 1)
         launched += batch
         outs = [e.step_finish(launched, max_sweeps > 0 and launched >= max_sweeps, eps) for e in engines]
         if len({o[0] != 0 for o in outs}) != 1 or len({o[1] for o in outs if o[0]}) > 1:

@@ -87,6 +87,7 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
     eng = make_shard(g, rank, world, local_rank)
     eng.bp_set_evidence(ev)
     dt, sweeps, kern_ms, launches = _timed_runs(eng, a.eps, a.steps, a.warmup, dist, torch)
+    path = eng.last_path()
     li = eng.layout()
     seg = li["segment_bytes"]
     if rank == 0:
@@ -104,7 +105,9 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
                                       f"({seg} B per rank incl. residual slots)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": achieved / (8000.0 * world), "traffic": None,
-                         "kernel": "bp_sweep_kernel + all-gather", "avg_launch_us": per_launch_s * 1e6,
+                         "kernel": "bp_sweep_kernel (interior | cut-touching tiles) + all-gather on a second stream"
+                                   if path == 0 else "bp_resident_kernel (one rank: no exchange)",
+                         "avg_launch_us": per_launch_s * 1e6,
                          "avg_launch_us_source": "device clock, sweep start to next sweep start (exchange included)"},
         }
     eng.close()

@@ -122,6 +122,9 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * record between two launches opens a bubble of several microseconds in the queue, so a timed run is
  * slower than an untimed one; bn_bp_stats.sweep_devclock_ms -- the device's 100 MHz clock read by the
  * kernels themselves at the first sweep's start and the last sweep's end -- costs nothing and is always on.
+ * "overlap" 1/0 -- sharded runs: launch the interior tiles of a sweep while the previous sweep's
+ *   all-gather is in flight on a second stream (default 1; BN_OVERLAP=0), or kernel and collective
+ *   back to back on one stream.
  * "multisweep" 0/1/2 -- the one-launch paths (BN_MULTISWEEP in the environment sets the default, 1):
  *   networks of register-resident tiles that fit the chip can run the whole run in ONE launch with
  *   CPTs, references and node vectors resident in registers / LDS and a grid barrier per sweep; other
@@ -136,6 +139,11 @@ int bn_bp_last_path(bn_engine *eng);
  * bn_debug_allgather emulates the exchange between n shard engines living on ONE device. */
 int bn_bp_step_begin(bn_engine *eng);
 int bn_bp_step_sweep(bn_engine *eng, int32_t sweep, double eps);
+/* One sweep in the two launches of a sharded run with the exchange overlapped: part 1 = the interior
+ * tiles (they read nothing the previous sweep's all-gather delivers, so the engine launches them while
+ * that collective is in flight), part 2 = the tiles that touch a cut edge + the residual bookkeeping
+ * (launched once the collective has landed); part 0 = both in one launch (bn_bp_step_sweep). */
+int bn_bp_step_sweep_part(bn_engine *eng, int32_t sweep, double eps, int32_t part);
 int bn_bp_step_finish(bn_engine *eng, int32_t launched, int32_t final_batch, double eps,
                       int32_t *done_out, int32_t *sweeps_out, double *residual_out);
 int bn_debug_allgather(bn_engine **engs, int32_t n, int32_t sweep);
@@ -204,7 +212,7 @@ typedef struct bn_layout_info {
     int64_t cpt_doubles, rec_doubles, node_doubles; /* striped device array sizes (one buffer) */
     int64_t algorithmic_bytes_per_sweep, layout_bytes_per_sweep, messages_per_sweep;
     int32_t rank, nranks, n_owned;  /* sharding: this rank's share */
-    int32_t pad_;
+    int32_t n_interior_tiles;       /* tiles [0, n_interior_tiles) touch no cut edge (== n_tiles on one rank) */
     int64_t n_cut_edges;            /* cut edges incident to this rank */
     int64_t segment_bytes;          /* all-gather payload per rank per sweep (residual slots included) */
     int64_t segment_used_bytes;     /* message halves this rank actually produces */
@@ -215,6 +223,8 @@ int bn_layout_get(bn_engine *eng, bn_layout_info *out);
 int bn_layout_edge_refs(bn_engine *eng, int32_t *pi_out, int32_t *lam_out);
 /* node -> lane slot on this rank, -1 for nodes of other ranks, [n] */
 int bn_layout_node_slots(bn_engine *eng, int32_t *slots_out);
+/* node -> tile on this rank, -1 for nodes of other ranks, [n] */
+int bn_layout_node_tiles(bn_engine *eng, int32_t *tiles_out);
 /* per-class: kv, m, lanes_per_node, variant (0 = one-lane generic, 1 = register-resident template,
  * 2 = lane group (k = 4, 3-5 parents), 3 = any arities, a group of 8..64 lanes per node) */
 int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,

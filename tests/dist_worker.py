@@ -25,6 +25,7 @@ from bayesiannetwork_amd.engine import Engine  # noqa: E402
 
 def main():
     case = sys.argv[1]
+    overlapped = len(sys.argv) > 2 and sys.argv[2] == "overlapped"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     if case == "grid":
@@ -66,11 +67,8 @@ def main():
     cut = np.nonzero(owner[model.in_idx] != owner[child])[0]
     moff, kpar = model.msg_off, model.k[model.in_idx]
 
-    sweeps = 0
-    while True:
-        md = L.oracle_bp_sweep_owned(h, p(owner, ctypes.c_int32), rank)
-        npim, nlkm = arr(6, nm), arr(7, nm)
-        # pack: halves this rank produced, at the plan's offsets inside ITS segment
+    def pack(npim, nlkm, md):
+        """halves this rank produced, at the plan's offsets inside ITS segment; the residual rides in the slots"""
         seg = np.zeros(seg_d2 * 2, dtype=np.float64)
         for e in cut:
             a, b = owner[model.in_idx[e]], owner[child[e]]
@@ -81,24 +79,56 @@ def main():
                 o = (int(~ref_lam[e]) - gbase - rank * seg_d2) * 2
                 seg[o:o + kpar[e]] = nlkm[moff[e]:moff[e + 1]]
         seg[-256:] = 0.0
-        seg[-256] = md                                   # residual rides in the segment's slots
-        gathered = [torch.zeros(seg.size, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, torch.from_numpy(seg))  # the device path: in-place ncclAllGather
-        G = torch.cat(gathered).numpy()
-        # unpack: halves produced by the other endpoint's owner
+        seg[-256] = md
+        return seg
+
+    def unpack(G, pim, lkm):
+        """halves produced by the other endpoint's owner, from the gathered region"""
         for e in cut:
             a, b = owner[model.in_idx[e]], owner[child[e]]
             if b == rank:
                 o = (int(ref_pi[e]) - gbase) * 2
-                npim[moff[e]:moff[e + 1]] = G[o:o + kpar[e]]
+                pim[moff[e]:moff[e + 1]] = G[o:o + kpar[e]]
             if a == rank:
                 o = (int(~ref_lam[e]) - gbase) * 2
-                nlkm[moff[e]:moff[e + 1]] = G[o:o + kpar[e]]
-        res = max(float(G[(q + 1) * seg_d2 * 2 - 256]) for q in range(world))
-        L.oracle_bp_commit(h)
-        sweeps += 1
-        if res < eps:
-            break
+                lkm[moff[e]:moff[e + 1]] = G[o:o + kpar[e]]
+        return max(float(G[(q + 1) * seg_d2 * 2 - 256]) for q in range(world))
+
+    sweeps = 0
+    if not overlapped:
+        while True:
+            md = L.oracle_bp_sweep_owned(h, p(owner, ctypes.c_int32), rank)
+            npim, nlkm = arr(6, nm), arr(7, nm)
+            seg = pack(npim, nlkm, md)
+            gathered = [torch.zeros(seg.size, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(seg))  # the device path: in-place ncclAllGather
+            res = unpack(torch.cat(gathered).numpy(), npim, nlkm)
+            L.oracle_bp_commit(h)
+            sweeps += 1
+            if res < eps:
+                break
+    else:
+        # The engine's overlapped order (bn_engine.cpp step_sweep_overlapped): the nodes of the plan's
+        # INTERIOR tiles of sweep s+1 are computed while the all-gather of sweep s is still in flight
+        # (async gloo op), the nodes of the tiles that touch a cut edge after it has landed.  The split
+        # is the product plan's (node -> tile < n_interior_tiles); a virtual owner id selects each part.
+        tiles = eng.node_tiles()
+        part = owner.copy()
+        part[(owner == rank) & (tiles >= li["n_interior_tiles"])] = rank + world
+        md = max(L.oracle_bp_sweep_owned(h, p(part, ctypes.c_int32), rank),
+                 L.oracle_bp_sweep_owned(h, p(part, ctypes.c_int32), rank + world))
+        while True:
+            seg = pack(arr(6, nm), arr(7, nm), md)
+            gathered = [torch.zeros(seg.size, dtype=torch.float64) for _ in range(world)]
+            work = dist.all_gather(gathered, torch.from_numpy(seg), async_op=True)
+            L.oracle_bp_commit(h)       # the sweep's own results become current; its halo has NOT landed yet
+            sweeps += 1
+            md_int = L.oracle_bp_sweep_owned(h, p(part, ctypes.c_int32), rank)          # interior tiles of the next sweep
+            work.wait()
+            res = unpack(torch.cat(gathered).numpy(), arr(2, nm), arr(3, nm))           # halo lands in the CURRENT state
+            if res < eps:
+                break                   # what the interior launch computed past convergence is simply dropped
+            md = max(md_int, L.oracle_bp_sweep_owned(h, p(part, ctypes.c_int32), rank + world))
     bel = np.zeros(int(model.k.sum()))
     off = model.node_off
     buf = (ctypes.c_double * 256)()
@@ -111,7 +141,7 @@ def main():
         want = oracle.bp_run(model, ev, eps)
         assert sweeps == want["sweeps"], (sweeps, want["sweeps"])
         assert np.array_equal(tb.numpy(), want["beliefs"]), "sharded result differs from the unsharded oracle"
-        print(f"DIST_OK case={case} world={world} sweeps={sweeps} cut_edges={cut.size}")
+        print(f"DIST_OK case={case} world={world} order={'overlapped' if overlapped else 'plain'} sweeps={sweeps} cut_edges={cut.size}")
     L.oracle_bp_close(h)
     dist.barrier()
 

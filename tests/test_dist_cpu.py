@@ -8,13 +8,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("case,world", [("grid", 2), ("dag", 2), ("dag", 3)])
-def test_gloo_sharded_exchange(bnlib, oracle_mod, case, world, tmp_path):
-    port = 29600 + world * 7 + (0 if case == "grid" else 3)
+@pytest.mark.parametrize("case,world,order", [("grid", 2, "plain"), ("dag", 2, "plain"), ("dag", 3, "plain"),
+                                              ("grid", 2, "overlapped"), ("dag", 3, "overlapped")])
+def test_gloo_sharded_exchange(bnlib, oracle_mod, case, world, order, tmp_path):
+    """order "overlapped": the engine's overlapped schedule -- interior tiles of the next sweep computed
+    while the all-gather is in flight, cut-touching tiles after it landed (see dist_worker.py)."""
+    port = 29600 + world * 7 + (0 if case == "grid" else 3) + (20 if order == "overlapped" else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "dist_worker.py"), case]
+           os.path.join(ROOT, "tests", "dist_worker.py"), case, order]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    assert f"DIST_OK case={case} world={world}" in p.stdout
+    assert f"DIST_OK case={case} world={world} order={order}" in p.stdout

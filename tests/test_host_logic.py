@@ -204,3 +204,42 @@ def test_mostly_any_arity_network_is_laid_out_uniformly():
     g = synth.grid(6, 6, 4, seed=1)                                   # templated shapes only: unchanged
     with Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
         assert {c["variant"] for c in e.layout_classes()} == {1}
+
+
+def test_sharded_plan_puts_interior_tiles_first(bnlib):
+    """Sharded plans order the tiles that touch no cut edge first (bn_plan.cpp): the overlapped run
+    launches exactly those before the previous sweep's all-gather has landed, so none of their nodes may
+    have a parent or a child on another rank -- and with one rank every tile is interior."""
+    from bayesiannetwork_amd import _lib, synth
+    from bayesiannetwork_amd.engine import Engine
+    cases = [(synth.grid(40, 37, 4, seed=3), 4, None),
+             (synth.random_dag(1500, 4, 48, [2, 3, 4], seed=12), 3, None)]
+    g = synth.grid(24, 24, 3, seed=1)
+    cases.append((g, 4, (synth.splitmix64(3, 0, g.n) % np.uint64(4)).astype(np.int32)))
+    for model, world, owner_arg in cases:
+        child = np.repeat(np.arange(model.n), np.diff(model.in_ptr))
+        engines = [Engine(model, device=_lib.BN_DEVICE_HOST_ONLY, rank=r, nranks=world, owner=owner_arg) for r in range(world)]
+        owner = np.full(model.n, -1, np.int32)
+        for r, e in enumerate(engines):
+            owner[e.node_slots() >= 0] = r
+        assert (owner >= 0).all()
+        cut_edge = owner[model.in_idx] != owner[child]
+        touches = np.zeros(model.n, bool)
+        touches[child[cut_edge]] = True
+        touches[model.in_idx[cut_edge]] = True
+        total_interior = 0
+        for r, e in enumerate(engines):
+            li, tiles = e.layout(), e.node_tiles()
+            mine = owner == r
+            assert (tiles[mine] >= 0).all() and (tiles[~mine] == -1).all()
+            interior_nodes = mine & (tiles < li["n_interior_tiles"])
+            assert not touches[interior_nodes].any(), "an interior tile holds a node with a cut edge"
+            # every tile past the split does hold such a node
+            late = np.unique(tiles[mine & (tiles >= li["n_interior_tiles"])])
+            assert set(late.tolist()) == set(np.unique(tiles[mine & touches]).tolist())
+            total_interior += li["n_interior_tiles"]
+            e.close()
+        if owner_arg is None:
+            assert total_interior > 0
+    with Engine(synth.grid(12, 12, 4, seed=2), device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.layout()["n_interior_tiles"] == e.layout()["n_tiles"]

@@ -15,10 +15,10 @@ def eng(bnlib):
     return engine
 
 
-def _run_sharded(eng, model, ev, eps, nranks, owner=None, max_sweeps=0):
+def _run_sharded(eng, model, ev, eps, nranks, owner=None, max_sweeps=0, overlapped=True):
     shards = [eng.Engine(model, rank=r, nranks=nranks, owner=owner) for r in range(nranks)]
     try:
-        out = eng.run_shards_on_one_device(shards, ev, eps, max_sweeps)
+        out = eng.run_shards_on_one_device(shards, ev, eps, max_sweeps, overlapped=overlapped)
         bel = sum(s.bp_beliefs() for s in shards)  # zeros for nodes of other ranks
         res = shards[0].bp_residuals()
         for s in shards[1:]:
@@ -36,7 +36,11 @@ def _check(eng, model, ev, eps, nranks, owner=None):
         want = single.bp_run(ev, eps)
         want_res = single.bp_residuals()
         want_pi, want_lam = single.bp_messages()
+    # the launch order of the overlapped run (interior tiles before the previous exchange lands) and the
+    # plain order (whole sweep, then exchange) must both reproduce the unsharded run
+    out_plain = _run_sharded(eng, model, ev, eps, nranks, owner, overlapped=False)
     out, bel, res, msgs, refs = _run_sharded(eng, model, ev, eps, nranks, owner)
+    assert out_plain[0]["sweeps"] == want["sweeps"] and np.array_equal(out_plain[1], want["beliefs"], equal_nan=True)
     assert out["sweeps"] == want["sweeps"]
     assert np.array_equal(res, want_res)
     assert np.array_equal(bel, want["beliefs"], equal_nan=True)
@@ -93,13 +97,19 @@ def test_sharded_full_size_config4(eng):
     _check(eng, g, synth.random_evidence(g, 0.01, seed=7), 1e-3, 8)
 
 
-def test_rccl_single_rank_communicator(eng):
-    """RCCL is loadable and a 1-rank communicator initialises (the n-rank path cannot run here)."""
+def test_rccl_single_rank_communicator(eng, monkeypatch):
+    """RCCL is loadable, a 1-rank communicator initialises, and the per-sweep ncclAllGather itself runs
+    (BN_EXCHANGE_ALWAYS makes the launch path issue the -- then trivial -- collective on one rank; the
+    n-rank path cannot run on a one-GPU box)."""
     from bayesiannetwork_amd import synth
     uid = eng.Engine.comm_unique_id()
     assert len(uid) == 128
-    g = synth.grid(8, 8, 4, seed=1)
+    g = synth.grid(24, 24, 4, seed=1)
     with eng.Engine(g) as e:
+        want = e.bp_run(None, 1e-6)
         e.comm_init(uid)
-        r = e.bp_run(None, 1e-3)
-        assert r["sweeps"] > 0
+        monkeypatch.setenv("BN_EXCHANGE_ALWAYS", "1")
+        e.set_option("multisweep", 0)  # the one-launch paths have no exchange step
+        r = e.bp_run(None, 1e-6)
+        assert e.last_path() == 0
+        assert r["sweeps"] == want["sweeps"] and np.array_equal(r["beliefs"], want["beliefs"])
