@@ -243,3 +243,31 @@ def test_sharded_plan_puts_interior_tiles_first(bnlib):
             assert total_interior > 0
     with Engine(synth.grid(12, 12, 4, seed=2), device=_lib.BN_DEVICE_HOST_ONLY) as e:
         assert e.layout()["n_interior_tiles"] == e.layout()["n_tiles"]
+
+
+def test_hot_kernels_do_not_spill(bnlib):
+    """Code-object metadata of the built kernels (scripts/kernel_resources.py reads the gfx950 image
+    embedded in csrc/*.o): the register-resident sweep instantiation has no spills, no scratch and no LDS;
+    the resident kernel stays within a handful of spilled dwords (4-children instantiation only) and holds
+    its 128 KiB of CPT halves in LDS; the samplers do not spill."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "bayesiannetwork_amd", "csrc")
+    need = ["bn_sweep_u.o", "bn_resident.o", "bn_lw_kernels.o"]
+    if not all(os.path.exists(os.path.join(csrc, f)) for f in need) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("object files / llvm tools not on this box")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    u = kr.kernel_resources(os.path.join(csrc, "bn_sweep_u.o"))
+    assert len(u) == 2
+    for name, r in u.items():
+        assert "bp_sweep_kernel" in name
+        assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0 and r["vgpr"] <= 256, (name, r)
+    res = kr.kernel_resources(os.path.join(csrc, "bn_resident.o"))
+    (name, r), = res.items()
+    assert "bp_resident_kernel" in name and r["vgpr"] <= 256 and r["spill"] <= 8 and r["scratch"] <= 32, r
+    assert r["lds"] >= 128 * 1024
+    for name, r in kr.kernel_resources(os.path.join(csrc, "bn_lw_kernels.o")).items():
+        assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
