@@ -280,18 +280,24 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocMapped));
         std::memset(e->h_ctl, 0, sizeof(Ctl));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ctl_dev), e->h_ctl, 0));
-        {   // resident path (bn_resident.hip): uniform tiles of the shapes it instantiates, <= 4 children per
-            // node, one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
+        {   // resident path (bn_resident.hip): uniform tiles (<= 2 parents, <= 8 children per node) and k = 4 lane
+            // groups (3-4 parents, every child served by a lane of its group), one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, e->device));
             const int64_t nt = int64_t(p.tiles.size());
             int64_t nb = (nt + kResidentWaves - 1) / kResidentWaves;
             if (nb > 1) nb = (nb + 7) & ~int64_t(7);
-            bool ok = p.nranks == 1 && nt > 0 && p.variants == (1 << kVariantUniform) &&
+            bool ok = p.nranks == 1 && nt > 0 && (p.variants & ~((1 << kVariantUniform) | (1 << kVariantGroup))) == 0 &&
                       nb <= int64_t(prop.multiProcessorCount) * 9 / 10 &&
                       p.rec_total_doubles * 8 < (int64_t(1) << 31);  // 32-bit byte offsets into a record buffer
-            for (const TileDesc& td : p.tiles)
-                ok = ok && td.variant == kVariantUniform && td.cmax <= 4 && td.in_ref_base < 0 && td.m <= 2;
+            for (const TileDesc& td : p.tiles) {
+                if (td.variant == kVariantUniform) {
+                    ok = ok && td.cmax <= 8 && td.in_ref_base < 0 && td.m <= 2;
+                } else {  // k = 4 lane group: 3 or 4 parents, every child served by a lane of the group
+                    const int G = td.m == 3 ? 4 : 16, cpl = G >= 16 ? 1 : 2;
+                    ok = ok && td.variant == kVariantGroup && (td.m == 3 || td.m == 4) && td.cmax <= G * cpl && td.in_ref_base < 0;
+                }
+            }
             e->resident_ok = ok;
             e->grid_resident = int(nb);
             if (ok) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_rsync), sizeof(ResidentSync)));
@@ -613,10 +619,12 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     ON_DEVICE(e);
     hipStream_t s = e->stream;
     int rc;
-    // resident tiles pay on one block (no grid barrier at all) and on large grids (the CPT traffic saved
-    // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
+    // resident tiles pay on one block (no grid barrier at all) and on large networks of one-lane tiles (the
+    // CPT traffic saved outweighs the ~4.5 us barrier); in between, and with lane-group tiles (latency-bound:
+    // the CPT stream is not on their critical path), a per-sweep launch is faster (measured)
     constexpr int64_t kResidentMinTiles = 640;
-    const bool resident_pays = e->grid_resident == 1 || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
+    const bool resident_pays = e->grid_resident == 1 || (int64_t(e->plan.tiles.size()) >= kResidentMinTiles &&
+                                                         e->plan.variants == (1 << kVariantUniform));
     if (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays))) {
         rc = run_resident(e, eps, max_sweeps);
         if (rc == BN_OK) {
