@@ -62,6 +62,12 @@ SYMBOLS = [
     ("bn_bp_beliefs_device", ctypes.c_void_p, [ctypes.c_void_p]),
     ("bn_bp_copy_beliefs", ctypes.c_int, [ctypes.c_void_p, f64p]),
     ("bn_bp_residual_history", ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int32]),
+    ("bn_bp_run_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, i32p, f64p, ctypes.c_double, ctypes.c_int32,
+                                       f64p, i32p, f64p]),
+    ("bn_bp_set_evidence_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, i32p, f64p]),
+    ("bn_bp_run_batch_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, i32p, f64p]),
+    ("bn_bp_copy_beliefs_batch", ctypes.c_int, [ctypes.c_void_p, f64p]),
+    ("bn_bp_residual_history_batch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, f64p, ctypes.c_int32]),
     ("bn_bp_messages", ctypes.c_int, [ctypes.c_void_p, f64p, f64p]),
     ("bn_set_option", ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]),
     ("bn_bp_last_path", ctypes.c_int, [ctypes.c_void_p]),

@@ -100,6 +100,7 @@ int launch_bp_multi(const MultiArgs& a, bool light, void* stream);
 // The whole run in one launch with every tile resident in registers (bn_resident.hip).
 constexpr int kResidentWaves = 8;       // 512 threads per block, one tile per wave, <= 256 VGPRs
 constexpr int kResidentLdsSlots = 16;   // double2 slots per lane of CPT kept in LDS (upper half of a 64-entry table)
+constexpr int kResidentMaxSets = 8;     // evidence sets one launch can walk round-robin (bn_bp_run_batch)
 constexpr int kResidentBudget = 1024;   // iterations one launch may execute (size of ResidentSync::res)
 struct ResidentSync {                   // zeroed by the host before every launch
     unsigned abort;                     // non-zero: a bounded wait gave up
@@ -114,17 +115,23 @@ struct ResidentSync {                   // zeroed by the host before every launc
     unsigned long long res[kResidentBudget];  // per-iteration maximum_difference, bit patterns
 };
 struct ResidentArgs {
-    BpBuffers b;
+    BpBuffers b;          // evidence set 0; set q's buffers follow at the strides below
     double eps;
     int32_t max_sweeps;   // 0 = unbounded like the reference
     int32_t sweep_begin;  // first iteration of this launch
     int32_t budget;       // iterations this launch may execute (<= kResidentBudget)
     uint32_t run_id;
     unsigned long long timeout_ticks;  // bound of one barrier wait, 100 MHz ticks
-    ResidentSync* sync;
-    Ctl* host_ctl;
+    ResidentSync* sync;   // [n_sets]
+    Ctl* host_ctl;        // [n_sets], pinned
+    int32_t n_sets;       // 1: node vectors stay in registers; > 1: they go through memory between a set's turns
+    uint32_t set_mask;    // sets still running (a continued launch skips the others)
+    int64_t rec_stride, node_stride;  // doubles between consecutive sets' record / node buffers
+    int64_t slot_stride;              // bytes between their evidence marks
+    int64_t belief_stride;            // doubles between their beliefs
+    int32_t res_hist_stride;          // doubles between their residual histories
 };
-int launch_bp_resident(const ResidentArgs& a, int grid_blocks, void* stream);
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, bool lean, void* stream);  // lean: one-lane tiles, <= 2 children per node
 
 // launchers (bn_kernels.hip)
 int launch_bp_evidence(const EvidenceArgs& a, void* stream);  // bn_bp_set_evidence: marks + vectors

@@ -133,8 +133,29 @@ struct bn_engine {
     bool timing = false;            // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms); opt-in:
                                     // an event record between two launches opens a ~6 us bubble in the queue
     bool resident_ok = false;       // every tile register-resident and co-resident: the whole run in one launch (bn_resident.hip)
+    bool resident_lean = false;     // ... and all its tiles are one-lane tiles with <= 2 children per node
     int grid_resident = 0;
     ResidentSync* d_rsync = nullptr;
+    // several evidence sets per launch (bn_bp_*_batch): per-set records, node vectors, marks, beliefs, histories
+    struct Batch {
+        int32_t n_sets = 0, cap_sets = 0;
+        double* d_rec[2] = {nullptr, nullptr};
+        double* d_node[2] = {nullptr, nullptr};
+        uint8_t* d_frozen = nullptr;
+        double* d_beliefs = nullptr;
+        double* d_res_hist = nullptr;
+        ResidentSync* d_sync = nullptr;
+        Ctl* h_ctl = nullptr;       // pinned, [cap_sets]
+        Ctl* h_ctl_dev = nullptr;
+        char* d_ev = nullptr;       // staging of every set's evidence
+        size_t ev_cap = 0;
+        // host copy of the evidence (sets run one after another when the network is not resident-eligible)
+        std::vector<int32_t> ne, ev_node, ev_off;
+        std::vector<double> ev_val;
+        std::vector<int32_t> sweeps;
+        std::vector<double> residual;
+        bool have_run = false;
+    } batch;
     bool multi_ok = false;          // the network is small enough for the one-launch path
     int multisweep = 1;             // one-launch paths: 0 never, 1 where they were measured faster (resident tiles on one
                                     // block or on >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
@@ -164,10 +185,13 @@ static void free_engine(bn_engine* e) {
         if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync};
+                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync,
+                        e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
+                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+        if (e->batch.h_ctl) (void)hipHostFree(e->batch.h_ctl);
         if (e->h_ev) (void)hipHostFree(e->h_ev);
         for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
         if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -299,6 +323,8 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 }
             }
             e->resident_ok = ok;
+            e->resident_lean = ok && p.variants == (1 << kVariantUniform);
+            for (const TileDesc& td : p.tiles) e->resident_lean = e->resident_lean && td.cmax <= 2;
             e->grid_resident = int(nb);
             if (ok) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_rsync), sizeof(ResidentSync)));
         }
@@ -534,13 +560,14 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     for (;;) {
         HIPCHK(hipMemsetAsync(e->d_rsync, 0, sizeof(ResidentSync), s));  // every polled word, before every launch
         ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id,
-                       5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev};
+                       5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev,
+                       1, 1u, 0, 0, 0, 0, 0};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
             HIPCHK(hipEventRecord(e->events[0], s));
         }
-        if (int code = launch_bp_resident(a, e->grid_resident, s))
+        if (int code = launch_bp_resident(a, e->grid_resident, e->resident_lean, s))
             return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
         HIPCHK(hipStreamSynchronize(s));
@@ -706,6 +733,251 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;
+}
+
+// ---- several evidence sets on one network (extension beside the drop-in: the reference's API takes one
+// query at a time).  Resident-eligible networks run all sets in ONE launch that walks them round-robin
+// (bn_resident.hip): one resident CPT serves every set and each set's barrier completes while the others
+// compute.  Other networks run the sets one after another through the single-query path.  Either way
+// every set's results are bit-identical to running it alone.
+static int batch_reserve(bn_engine* e, int32_t n_sets) {
+    bn_engine::Batch& bt = e->batch;
+    if (n_sets <= bt.cap_sets) return BN_OK;
+    const Plan& p = e->plan;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync};
+    for (void* q : old)
+        if (q) (void)hipFree(q);
+    if (bt.h_ctl) (void)hipHostFree(bt.h_ctl);
+    bt = bn_engine::Batch();
+    int r;
+    const size_t B = size_t(n_sets);
+    for (int i = 0; i < 2; ++i) {
+        if ((r = dalloc(&bt.d_rec[i], B * size_t(p.rec_total_doubles)))) return r;
+        if ((r = dalloc(&bt.d_node[i], B * size_t(p.node_doubles)))) return r;
+        HIPCHK(hipMemsetAsync(bt.d_rec[i], 0, std::max<size_t>(B * p.rec_total_doubles, 1) * 8, e->stream));
+        HIPCHK(hipMemsetAsync(bt.d_node[i], 0, std::max<size_t>(B * p.node_doubles, 1) * 8, e->stream));
+    }
+    if ((r = dalloc(&bt.d_frozen, B * size_t(std::max(p.n_slots, 1))))) return r;
+    if ((r = dalloc(&bt.d_beliefs, B * size_t(p.node_off[p.n])))) return r;
+    if ((r = dalloc(&bt.d_res_hist, B * size_t(e->res_cap)))) return r;
+    if ((r = dalloc(&bt.d_sync, B))) return r;
+    HIPCHK(hipMemsetAsync(bt.d_frozen, 0, B * size_t(std::max(p.n_slots, 1)), e->stream));
+    HIPCHK(hipMemsetAsync(bt.d_beliefs, 0, std::max<size_t>(B * p.node_off[p.n], 1) * 8, e->stream));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bt.h_ctl), sizeof(Ctl) * B, hipHostMallocMapped));
+    std::memset(bt.h_ctl, 0, sizeof(Ctl) * B);
+    HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&bt.h_ctl_dev), bt.h_ctl, 0));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    bt.cap_sets = n_sets;
+    return BN_OK;
+}
+
+// buffers of evidence set q inside the batch arrays
+static BpBuffers batch_buffers_of(bn_engine* e, int32_t q) {
+    const Plan& p = e->plan;
+    const bn_engine::Batch& bt = e->batch;
+    BpBuffers b = buffers_of(e);
+    b.rec0 = bt.d_rec[0] + size_t(q) * p.rec_total_doubles;
+    b.rec1 = bt.d_rec[1] + size_t(q) * p.rec_total_doubles;
+    b.node0 = bt.d_node[0] + size_t(q) * p.node_doubles;
+    b.node1 = bt.d_node[1] + size_t(q) * p.node_doubles;
+    b.frozen = bt.d_frozen + size_t(q) * std::max(p.n_slots, 1);
+    b.beliefs = bt.d_beliefs + size_t(q) * p.node_off[p.n];
+    b.res_hist = bt.d_res_hist + size_t(q) * e->res_cap;
+    return b;
+}
+
+extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int32_t* ne, const int32_t* ev_node,
+                                        const int32_t* ev_off, const double* ev_val) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (n_sets < 1 || n_sets > kResidentMaxSets) return fail(BN_ERR_ARG, "n_sets must be in 1.." + std::to_string(kResidentMaxSets));
+    if (e->plan.nranks > 1) return fail(BN_ERR_STATE, "batched evidence sets are not available on sharded engines");
+    if (!ne) return fail(BN_ERR_ARG, "null ne");
+    const Plan& p = e->plan;
+    // validate every set like bn_bp_set_evidence does; locate its slices of the concatenated arrays
+    std::vector<int64_t> node_at(n_sets + 1, 0), off_at(n_sets + 1, 0), val_at(n_sets + 1, 0);
+    for (int32_t q = 0; q < n_sets; ++q) {
+        if (ne[q] < 0) return fail(BN_ERR_ARG, "negative evidence count");
+        if (ne[q] > 0 && (!ev_node || !ev_off || !ev_val)) return fail(BN_ERR_ARG, "null evidence array");
+        int rc = check_evidence(p, ne[q], ev_node ? ev_node + node_at[q] : nullptr, ev_off ? ev_off + off_at[q] : nullptr);
+        if (rc) return rc;
+        node_at[q + 1] = node_at[q] + ne[q];
+        off_at[q + 1] = off_at[q] + ne[q] + 1;
+        val_at[q + 1] = val_at[q] + (ne[q] > 0 ? ev_off[off_at[q] + ne[q]] : 0);
+    }
+    ON_DEVICE(e);
+    int rc = batch_reserve(e, n_sets);
+    if (rc) return rc;
+    bn_engine::Batch& bt = e->batch;
+    bt.n_sets = n_sets;
+    bt.have_run = false;
+    bt.ne.assign(ne, ne + n_sets);
+    bt.ev_node.assign(ev_node, ev_node + node_at[n_sets]);
+    bt.ev_off.assign(ev_off, ev_off + (node_at[n_sets] > 0 || ev_off ? off_at[n_sets] : 0));
+    bt.ev_val.assign(ev_val, ev_val + val_at[n_sets]);
+    // one staging block [nodes | offs | vals], one H2D copy, then one evidence kernel per set
+    const size_t b_node = 0, b_off = size_t(node_at[n_sets]) * 4, b_val = (b_off + size_t(off_at[n_sets]) * 4 + 7) & ~size_t(7);
+    const size_t bytes = b_val + size_t(val_at[n_sets]) * 8;
+    if (bytes > bt.ev_cap) {
+        if (bt.d_ev) (void)hipFree(bt.d_ev);
+        bt.d_ev = nullptr;
+        bt.ev_cap = std::max<size_t>(bytes * 2, 4096);
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&bt.d_ev), bt.ev_cap));
+    }
+    std::vector<char> host(std::max<size_t>(bytes, 1));
+    if (node_at[n_sets] > 0) {
+        std::memcpy(host.data() + b_node, ev_node, size_t(node_at[n_sets]) * 4);
+        std::memcpy(host.data() + b_val, ev_val, size_t(val_at[n_sets]) * 8);
+    }
+    if (ev_off) std::memcpy(host.data() + b_off, ev_off, size_t(off_at[n_sets]) * 4);
+    if (bytes) HIPCHK(hipMemcpyAsync(bt.d_ev, host.data(), bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(bt.d_frozen, 0, size_t(n_sets) * size_t(std::max(p.n_slots, 1)), e->stream));
+    for (int32_t q = 0; q < n_sets; ++q) {
+        EvidenceArgs ea{batch_buffers_of(e, q), ne[q], reinterpret_cast<int32_t*>(bt.d_ev + b_node) + node_at[q],
+                        reinterpret_cast<int32_t*>(bt.d_ev + b_off) + off_at[q], reinterpret_cast<double*>(bt.d_ev + b_val) + val_at[q]};
+        if (int code = launch_bp_evidence(ea, e->stream))
+            return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));  // `host` is a local
+    return BN_OK;
+}
+
+// every set through the resident kernel, round-robin in one launch
+static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
+    bn_engine::Batch& bt = e->batch;
+    const Plan& p = e->plan;
+    hipStream_t s = e->stream;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    int32_t begin = 0, launches = 0;
+    uint32_t mask = bt.n_sets >= 32 ? ~0u : ((1u << bt.n_sets) - 1u);
+    double dev_ticks = 0.0;
+    float ms = 0.f;
+    for (;;) {
+        HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(bt.n_sets), s));
+        ResidentArgs a{batch_buffers_of(e, 0), eps, max_sweeps, begin, kResidentBudget, e->run_id, 5000000ull, bt.d_sync,
+                       bt.h_ctl_dev, bt.n_sets, mask, p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)),
+                       p.node_off[p.n], e->res_cap};
+        if (e->timing) {
+            int rc = ensure_events(e, 2);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->events[0], s));
+        }
+        if (int code = launch_bp_resident(a, e->grid_resident, e->resident_lean, s))
+            return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
+        HIPCHK(hipStreamSynchronize(s));
+        ++launches;
+        if (e->timing) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
+            ms += t;
+        }
+        uint32_t next = 0;
+        for (int32_t q = 0; q < bt.n_sets; ++q) {
+            if (!((mask >> q) & 1u)) continue;
+            const Ctl& c = bt.h_ctl[q];
+            if (c.run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
+            if (c.done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
+            bt.sweeps[q] = c.n_sweeps;
+            bt.residual[q] = c.last_res;
+            if (c.done == 0) next |= 1u << q;
+        }
+        dev_ticks += double(bt.h_ctl[0].t_last - bt.h_ctl[0].t_first);
+        if (next == 0) break;
+        mask = next;
+        begin += kResidentBudget;
+    }
+    e->last_path = 2;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = ms;
+    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
+    e->stats.sweeps = *std::max_element(bt.sweeps.begin(), bt.sweeps.end());
+    return BN_OK;
+}
+
+extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
+    bn_engine::Batch& bt = e->batch;
+    if (bt.n_sets < 1) return fail(BN_ERR_STATE, "call bn_bp_set_evidence_batch first");
+    const auto t_begin = std::chrono::steady_clock::now();
+    ON_DEVICE(e);
+    const Plan& p = e->plan;
+    bt.sweeps.assign(bt.n_sets, 0);
+    bt.residual.assign(bt.n_sets, 0.0);
+    int rc = BN_ERR_STATE;
+    if (e->resident_ok && e->multisweep != 0) {
+        rc = run_batch_resident(e, eps, max_sweeps);
+        if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
+        if (rc == BN_ERR_STATE) {
+            if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] resident path disabled: %s\n", g_err.c_str());
+            e->resident_ok = false;
+            // the aborted launch may have left marks / vectors half-written: apply the evidence again below
+        }
+    }
+    if (rc != BN_OK) {
+        // one set after another through the single-query path; results land in the batch arrays
+        const size_t nbel = size_t(p.node_off[p.n]);
+        int64_t node_at = 0, off_at = 0, val_at = 0;
+        for (int32_t q = 0; q < bt.n_sets; ++q) {
+            const int32_t neq = bt.ne[q];
+            rc = bn_bp_set_evidence(e, neq, bt.ev_node.data() + node_at, bt.ev_off.data() + off_at, bt.ev_val.data() + val_at);
+            if (rc) return rc;
+            rc = bn_bp_run_device(e, eps, max_sweeps, &bt.sweeps[q], &bt.residual[q]);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(bt.d_beliefs + size_t(q) * nbel, e->d_beliefs, nbel * 8, hipMemcpyDeviceToDevice, e->stream));
+            const int32_t cnt = std::min(bt.sweeps[q], e->res_cap);
+            if (cnt > 0)
+                HIPCHK(hipMemcpyAsync(bt.d_res_hist + size_t(q) * e->res_cap, e->d_res_hist, size_t(cnt) * 8,
+                                      hipMemcpyDeviceToDevice, e->stream));
+            val_at += neq > 0 ? bt.ev_off[off_at + neq] : 0;
+            node_at += neq;
+            off_at += neq + 1;
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    bt.have_run = true;
+    e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    for (int32_t q = 0; q < bt.n_sets; ++q) {
+        if (sweeps_out) sweeps_out[q] = bt.sweeps[q];
+        if (residual_out) residual_out[q] = bt.residual[q];
+    }
+    return BN_OK;
+}
+
+extern "C" int bn_bp_copy_beliefs_batch(bn_engine* e, double* beliefs_out) {
+    if (!e || !beliefs_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->host_only || !e->batch.have_run) return fail(BN_ERR_STATE, "no batched run to copy from");
+    ON_DEVICE(e);
+    HIPCHK(hipMemcpyAsync(beliefs_out, e->batch.d_beliefs, sizeof(double) * size_t(e->batch.n_sets) * e->plan.node_off[e->plan.n],
+                          hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return BN_OK;
+}
+
+extern "C" int bn_bp_residual_history_batch(bn_engine* e, int32_t set, double* out, int32_t cap) {
+    if (!e || !out || cap < 0) return fail(BN_ERR_ARG, "bad argument");
+    if (e->host_only || !e->batch.have_run) return fail(BN_ERR_STATE, "no batched run yet");
+    if (set < 0 || set >= e->batch.n_sets) return fail(BN_ERR_ARG, "set index out of range");
+    const int32_t cnt = std::min({cap, e->batch.sweeps[set], e->res_cap});
+    ON_DEVICE(e);
+    if (cnt > 0)
+        HIPCHK(hipMemcpy(out, e->batch.d_res_hist + size_t(set) * e->res_cap, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    return cnt;
+}
+
+extern "C" int bn_bp_run_batch(bn_engine* e, int32_t n_sets, const int32_t* ne, const int32_t* ev_node, const int32_t* ev_off,
+                               const double* ev_val, double eps, int32_t max_sweeps, double* beliefs_out, int32_t* sweeps_out,
+                               double* residual_out) {
+    if (!beliefs_out) return fail(BN_ERR_ARG, "null beliefs_out");
+    int rc = bn_bp_set_evidence_batch(e, n_sets, ne, ev_node, ev_off, ev_val);
+    if (rc) return rc;
+    rc = bn_bp_run_batch_device(e, eps, max_sweeps, sweeps_out, residual_out);
+    if (rc) return rc;
+    return bn_bp_copy_beliefs_batch(e, beliefs_out);
 }
 
 // ---- single steps (diagnostics / tests) -------------------------------------------------------

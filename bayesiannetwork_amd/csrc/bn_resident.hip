@@ -25,6 +25,15 @@
 // A one-block grid (<= 8 tiles: Pearl's network, small chains) needs no atomics at all: LDS slots and
 // __syncthreads().
 //
+// SEVERAL EVIDENCE SETS PER LAUNCH (bn_bp_run_batch).  The CPT image, the references and the layout are the
+// same for every query on a network; only messages, node vectors and evidence marks are per query.  The
+// kernel walks B sets round-robin -- sweep s of set A, arrive at A's barrier, sweep s of set B, arrive at B's,
+// wait for A's barrier, sweep s+1 of A, ... -- so the ~4.5 us a barrier takes to complete are spent computing
+// the other sets instead of waiting, and one resident CPT serves all of them.  Every set has its own
+// record / node buffers, barrier words, residuals and verdict, and leaves the rotation on the sweep ITS
+// reference run would stop on; node vectors of a set go through memory between its turns (no registers left
+// for B copies).  Results per set are bit-identical to a run of that set alone (asserted).
+//
 // Every wait is bounded (100 MHz wall clock); a wait that gives up raises `abort`, every block leaves,
 // and the host redoes the run with per-sweep launches.  A launch executes at most `budget` iterations;
 // a run that needs more continues on the launch path from the state this kernel leaves in memory.
@@ -55,8 +64,8 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 __device__ __forceinline__ void pin_here(double& x) { asm volatile("" : "+v"(x)); }
 
 struct BlockShared {
-    unsigned long long slot[kResidentWaves];  // per-wave residual bit patterns
-    int verdict;                              // of the iteration: kGoOn / kConverged / kCapped / kAbort
+    unsigned long long slot[kResidentMaxSets][kResidentWaves];  // per-set, per-wave residual bit patterns
+    int verdict[kResidentMaxSets];                              // of a set's last barrier: kGoOn / kConverged / kCapped / kAbort
 };
 enum : int { kGoOn = 0, kConverged = 1, kCapped = 2, kAbort = 3 };
 
@@ -71,27 +80,27 @@ __device__ __forceinline__ int verdict_of(const ResidentArgs& a, double r, int n
     return kGoOn;
 }
 
-// Barrier + residual reduction + stop decision of iteration s (the it-th of this launch).
-// Every block folds its residual into res[it] BEFORE it arrives, so the last arriver of all reads
-// the final value, decides, and publishes the verdict together with the generation in ONE word per
-// group: nobody else reads the residual on the critical path.  One-block grids decide from LDS.
-__device__ __forceinline__ int sync_and_decide(const ResidentArgs& a, BlockShared& sh, int s, double wres, int lane, int wave) {
+// First half of the barrier of iteration `it` (sweep s) of evidence set `set`: the block's residual and its
+// arrival.  Every block folds its residual into res[it] BEFORE it arrives, so the last arriver of all reads
+// the final value, decides, and publishes the verdict together with the generation in ONE word per group:
+// nobody else reads the residual on the critical path.  Nothing is waited for here (but the block's own
+// stores); the caller goes on with another set's sweep and collects the verdict with wait_verdict().
+__device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, int set, int it, int s, double wres, int lane,
+                                       int wave) {
     const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
-    if (lane == 0) sh.slot[wave] = bits;
+    if (lane == 0) sh.slot[set][wave] = bits;
     drain_stores();  // this wave's write-through stores have reached memory
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long m = 0;
 #pragma unroll
-        for (int w = 0; w < kResidentWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
-        const int it = s - a.sweep_begin;
+        for (int w = 0; w < kResidentWaves; ++w) m = sh.slot[set][w] > m ? sh.slot[set][w] : m;
+        ResidentSync* sy = a.sync + set;
         const int nb = gridDim.x;
-        int verdict;
         if (nb == 1) {
-            a.sync->res[it] = m;
-            verdict = verdict_of(a, residual_of(m), s + 1);
+            sy->res[it] = m;
+            sh.verdict[set] = verdict_of(a, residual_of(m), s + 1);
         } else {
-            ResidentSync* sy = a.sync;
             const unsigned gen = unsigned(it) + 1u;
             const int groups = nb < 8 ? nb : 8;
             const int g = blockIdx.x % groups;
@@ -107,52 +116,95 @@ __device__ __forceinline__ int sync_and_decide(const ResidentArgs& a, BlockShare
                     for (int q = 0; q < groups; ++q) __hip_atomic_store(&sy->grp[q].gen, word, RLX_AGENT);
                 }
             }
-            const unsigned long long t0 = wall_clock64();
-            unsigned word;
-            verdict = kAbort;
-            for (;;) {
-                word = __hip_atomic_load(&sy->grp[g].gen, RLX_AGENT);
-                if ((word & 0x3fffffffu) >= gen) { verdict = int(word >> 30); break; }
-                if (__hip_atomic_load(&sy->abort, RLX_AGENT) != 0) break;
-                if (wall_clock64() - t0 > a.timeout_ticks) {
-                    __hip_atomic_store(&sy->abort, 1u, RLX_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
         }
-        sh.verdict = verdict;
     }
-    __syncthreads();
-    return sh.verdict;
 }
 
-struct RunEnd {
-    int n_sweeps;
-    int done;      // 0 budget exhausted, 1 converged, 2 max_sweeps reached
-    bool abort;
-};
+// Second half: the verdict of iteration `it` of `set` once every block has arrived.
+__device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& sh, int set, int it) {
+    if (threadIdx.x == 0 && gridDim.x > 1) {
+        ResidentSync* sy = a.sync + set;
+        const int nb = gridDim.x;
+        const unsigned gen = unsigned(it) + 1u;
+        const int g = blockIdx.x % (nb < 8 ? nb : 8);
+        const unsigned long long t0 = wall_clock64();
+        int verdict = kAbort;
+        for (;;) {
+            const unsigned word = __hip_atomic_load(&sy->grp[g].gen, RLX_AGENT);
+            if ((word & 0x3fffffffu) >= gen) { verdict = int(word >> 30); break; }
+            if (__hip_atomic_load(&a.sync->abort, RLX_AGENT) != 0) break;
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);  // set 0's word is the launch's abort flag
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        sh.verdict[set] = verdict;
+    }
+    __syncthreads();
+    return sh.verdict[set];
+}
+
+// The launch's loop over iterations and evidence sets, shared by every tile kind.
+//   phase(set, s)          one sweep of this wave's tile for `set`; returns the wave's residual contribution
+//   finalize(set, n, done) the set stopped after n sweeps (done = kConverged / kCapped) or the launch's budget
+//                          ran out (done = 0): node vectors to memory where needed, beliefs when done
+// Returns false when a bounded wait gave up.
+template <bool BATCH, class Phase, class Finalize>
+__device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShared& sh, int lane, int wave, Phase&& phase,
+                                               Finalize&& finalize) {
+    unsigned active = BATCH ? a.set_mask : 1u;
+    const int n_sets = BATCH ? a.n_sets : 1;  // one set: everything about sets folds away at compile time
+    for (int it = 0; it <= a.budget; ++it) {  // the pass it == budget only collects verdicts
+        const int s = a.sweep_begin + it;
+        for (int set = 0; set < n_sets; ++set) {
+            if (((active >> set) & 1u) == 0) continue;
+            int v = kGoOn;
+            if (it > 0) {
+                v = wait_verdict(a, sh, set, it - 1);
+                if (v == kAbort) return false;
+            }
+            if (v != kGoOn || it == a.budget) {
+                const int done = v != kGoOn ? v : 0;
+                finalize(set, s, done);
+                if (blockIdx.x == 0 && wave == 0) {  // report: residual history (final since each barrier), outcome
+                    const ResidentSync* sy = a.sync + set;
+                    double* hist = a.b.res_hist + int64_t(set) * a.res_hist_stride;
+                    for (int q = lane; q < it; q += kWave)
+                        if (a.sweep_begin + q < a.b.res_cap)
+                            hist[a.sweep_begin + q] = residual_of(__hip_atomic_load(&sy->res[q], RLX_AGENT));
+                    if (lane == 0) {
+                        Ctl* hc = a.host_ctl + set;
+                        hc->last_res = it > 0 ? residual_of(__hip_atomic_load(&sy->res[it - 1], RLX_AGENT)) : 0.0;
+                        hc->n_sweeps = s;
+                        hc->run_id = a.run_id;
+                        hc->done = done;
+                    }
+                }
+                active &= ~(1u << set);
+                continue;
+            }
+            const double wres = phase(set, s);
+            arrive(a, sh, set, it, s, wres, lane, wave);
+        }
+        if (active == 0) break;
+    }
+    return true;
+}
 
 // A wave without a tile: takes part in the barriers, contributes nothing.
-__device__ __forceinline__ RunEnd resident_idle(const ResidentArgs& a, BlockShared& sh, int lane, int wave) {
-    RunEnd e{a.sweep_begin, 0, false};
-    for (int it = 0; it < a.budget; ++it) {
-        const int s = a.sweep_begin + it;
-        const int v = sync_and_decide(a, sh, s, 0.0, lane, wave);
-        if (v == kAbort) { e.abort = true; return e; }
-        e.n_sweeps = s + 1;
-        if (v != kGoOn) { e.done = v; return e; }
-    }
-    return e;
+template <bool BATCH>
+__device__ __forceinline__ bool resident_idle(const ResidentArgs& a, BlockShared& sh, int lane, int wave) {
+    return resident_drive<BATCH>(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int) {});
 }
 
 // Tables of more than 32 entries (k = 4 with two parents: 64) keep the entries of the upper half of the
 // own states in LDS -- 16 bytes per lane and slot, lane-contiguous: conflict-free ds_read_b128 -- and the
 // lower half in registers; 128 VGPRs of CPT plus the working set do not fit 256 registers, and the
 // compiler's answer, scratch memory, would re-read two thirds of the table through the caches each sweep.
-template <int K, int M, int RC>
-__device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
-                                                double2_t* cpt_lds) {
+template <int K, int M, int RC, bool BATCH>
+__device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+                                              double2_t* cpt_lds) {
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
     constexpr int CB = (M > 0) ? C / K : 0;
@@ -176,7 +228,7 @@ __device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShar
 #pragma unroll
         for (int q = SR / 2; q < S / 2; ++q) cpt_lds[(q - SR / 2) * kWave + lane] = cp[q * kWave];
     }
-    const bool frozen = b.frozen[td.slot_base + lc] != 0;
+    bool frozen = false;  // evidence mark of this lane's node for the set in hand
     const int64_t rbase = td.rec_base / 2 + lc;  // this lane's slot in the tile's record block (double2 units)
     const MsgRef* orf = b.out_refs + td.out_base + lc;
     // Out-edge references, packed (8 bytes per child) and decoded at each use: registers matter here.
@@ -189,18 +241,22 @@ __device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShar
         oref[c] = MsgRef{-1, 0};
         if (kRefsResident && active && c < td.cmax) oref[c] = orf[c * kWave];
     }
+    // pi(v), lambda(v).  One set per launch: they live in these registers from the first sweep to the last.
+    // Several sets: a set's vectors are read from its node buffer at the start of its turn and written back
+    // at the end (buffer parity as on the launch path), the registers are only the turn's working copy.
     double piv[KP], lav[KP];
+    auto load_nodes = [&](int set, int s) {
+        frozen = b.frozen[(BATCH ? int64_t(set) * a.slot_stride : 0) + td.slot_base + lc] != 0;
 #pragma unroll
-    for (int i = 0; i < KP; ++i) {  // initial state (:38-64): roots start from their CPT row
-        piv[i] = (M == 0 && i < K) ? cpt[i] : 1.0;
-        lav[i] = 1.0;
-    }
-    {
-        // evidence nodes hold their vector as pi and lambda (:68-73); a continued run (sweep_begin > 0)
-        // picks up the node vectors the previous launch left in memory
-        const bool from_memory = frozen || a.sweep_begin > 0;
-        const double2_t* nin = reinterpret_cast<const double2_t*>(((a.sweep_begin & 1) ? b.node1 : b.node0) + td.node_base) + lc;
-        if (from_memory) {
+        for (int i = 0; i < KP; ++i) {  // initial state (:38-64): roots start from their CPT row
+            piv[i] = (M == 0 && i < K) ? cpt[i] : 1.0;
+            lav[i] = 1.0;
+        }
+        // evidence nodes hold their vector as pi and lambda (:68-73); from the second sweep on (and in a
+        // continued run) the vectors are what the previous sweep left
+        if (frozen || s > 0) {
+            const double2_t* nin = reinterpret_cast<const double2_t*>(((s & 1) ? b.node1 : b.node0) + (BATCH ? int64_t(set) * a.node_stride : 0) +
+                                                                      td.node_base) + lc;
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 const double2_t x = nin[h * kWave], y = nin[(H + h) * kWave];
@@ -208,15 +264,27 @@ __device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShar
                 lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
             }
         }
-    }
+    };
+    auto store_nodes = [&](int set, int n) {  // into the buffer the reader of state n expects
+        if (!active) return;
+        double2_t* nout = reinterpret_cast<double2_t*>(((n & 1) ? b.node1 : b.node0) + (BATCH ? int64_t(set) * a.node_stride : 0) + td.node_base) + lane;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            double2_t y, z;
+            y.x = piv[2 * h]; y.y = (2 * h + 1 < K) ? piv[2 * h + 1] : 0.0;
+            z.x = lav[2 * h]; z.y = (2 * h + 1 < K) ? lav[2 * h + 1] : 0.0;
+            nout[h * kWave] = y;
+            nout[(H + h) * kWave] = z;
+        }
+    };
+    if constexpr (!BATCH) load_nodes(0, a.sweep_begin);
 
     const size_t rec_bytes = size_t(b.rec_total_doubles) * 8;
-    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(b.rec0, 0, int(rec_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(b.rec1, 0, int(rec_bytes), 0x00020000);
-    RunEnd e{a.sweep_begin, 0, false};
-    for (int it = 0; it < a.budget; ++it) {
-        const int s = a.sweep_begin + it;
+    auto phase = [&](int set, int s) -> double {
+        if constexpr (BATCH) load_nodes(set, s);
         const bool first = s == 0;
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(b.rec0 + (BATCH ? int64_t(set) * a.rec_stride : 0), 0, int(rec_bytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(b.rec1 + (BATCH ? int64_t(set) * a.rec_stride : 0), 0, int(rec_bytes), 0x00020000);
         const __amdgpu_buffer_rsrc_t rin = (s & 1) ? rsrc1 : rsrc0;
         const __amdgpu_buffer_rsrc_t rout = (s & 1) ? rsrc0 : rsrc1;
 
@@ -425,32 +493,22 @@ __device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShar
             }
         }
         if (!active) wres = 0.0;
-        // node vectors stay in registers; evidence nodes keep theirs (:177, :223)
+        // the node's new vectors; evidence nodes keep theirs (:177, :223)
         if (!frozen) {
 #pragma unroll
             for (int i = 0; i < K; ++i) { piv[i] = pin[i]; lav[i] = lan[i]; }
         }
-
-        const int v = sync_and_decide(a, sh, s, wres, lane, wave);
-        if (v == kAbort) { e.abort = true; return e; }
-        e.n_sweeps = s + 1;
-        if (v != kGoOn) { e.done = v; break; }
-    }
-
-    // ---- the run (or this launch's budget) is over: node vectors to the buffer the next reader expects
-    // (parity of the number of executed sweeps), beliefs = normalize(pi % lambda) (:151-158)
-    if (active) {
-        double2_t* nout = reinterpret_cast<double2_t*>(((e.n_sweeps & 1) ? b.node1 : b.node0) + td.node_base) + lane;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            double2_t y, z;
-            y.x = piv[2 * h]; y.y = (2 * h + 1 < K) ? piv[2 * h + 1] : 0.0;
-            z.x = lav[2 * h]; z.y = (2 * h + 1 < K) ? lav[2 * h + 1] : 0.0;
-            nout[h * kWave] = y;
-            nout[(H + h) * kWave] = z;
-        }
-        if (e.done != 0) {
+        if constexpr (BATCH) store_nodes(set, s + 1);
+        return wres;
+    };
+    // the set stopped after n sweeps (or the budget ran out, done == 0): node vectors to the buffer the next
+    // reader expects (parity of n), beliefs = normalize(pi % lambda) (:151-158) when the run is over
+    auto finalize = [&](int set, int n, int done) {
+        if constexpr (BATCH) load_nodes(set, n);
+        else store_nodes(set, n);
+        if (active && done != 0) {
             const int64_t boff = b.slot_boff[td.slot_base + lane];
+            double* beliefs = b.beliefs + (BATCH ? int64_t(set) * a.belief_stride : 0);
             double bel[K];
             double sum = 0;
 #pragma unroll
@@ -459,10 +517,10 @@ __device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShar
                 sum += bel[i];
             }
 #pragma unroll
-            for (int i = 0; i < K; ++i) b.beliefs[boff + i] = bel[i] / sum;
+            for (int i = 0; i < K; ++i) beliefs[boff + i] = bel[i] / sum;
         }
-    }
-    return e;
+    };
+    return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -473,9 +531,9 @@ __device__ __forceinline__ RunEnd resident_tile(const ResidentArgs& a, BlockShar
 // first lane finishes the node each sweep and hands the new vectors to its group with shuffles, where the
 // launch path goes through memory.  Needs the spread parent role (cmax <= G * CPL: checked by the host).
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ RunEnd resident_group(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
-                                                 double2_t* cpt_lds) {
+template <int D, bool BATCH>
+__device__ __forceinline__ bool resident_group(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+                                               double2_t* cpt_lds) {
     constexpr int K = 4, H = 2, M = D + 2;
     constexpr int G = 1 << (2 * D), NPT = kWave / G;
     constexpr int CPL = G >= 16 ? 1 : 2;  // children per lane
@@ -495,7 +553,7 @@ __device__ __forceinline__ RunEnd resident_group(const ResidentArgs& a, BlockSha
     }
 #pragma unroll
     for (int q = 16; q < 32; ++q) cpt_lds[(q - 16) * kWave + lane] = cp[q * kWave];
-    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
+    bool frozen = false;  // evidence mark of this lane's node for the set in hand
     const int64_t in_pi0 = td.rec_base / 2 + nlc;  // pi-message of in-edge j at in_pi0 + j*2*H*NPT (+ h*NPT), lambda H*NPT further
     MsgRef cref[CPL];
 #pragma unroll
@@ -504,26 +562,42 @@ __device__ __forceinline__ RunEnd resident_group(const ResidentArgs& a, BlockSha
         cref[q] = MsgRef{-1, 0};
         if (active && c < td.cmax) cref[q] = b.out_refs[td.out_base + int64_t(c) * NPT + nlc];
     }
-    double piv[K], lav[K];
+    double piv[K], lav[K];  // one set per launch: resident; several sets: the turn's working copy (see resident_tile)
+    auto load_nodes = [&](int set, int s) {
+        frozen = b.frozen[(BATCH ? int64_t(set) * a.slot_stride : 0) + td.slot_base + nlc] != 0;
 #pragma unroll
-    for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }  // a group node always has parents (:38-41)
-    if (frozen || a.sweep_begin > 0) {
-        const double2_t* nin = reinterpret_cast<const double2_t*>(((a.sweep_begin & 1) ? b.node1 : b.node0) + td.node_base) + nlc;
+        for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }  // a group node always has parents (:38-41)
+        if (frozen || s > 0) {
+            const double2_t* nin = reinterpret_cast<const double2_t*>(((s & 1) ? b.node1 : b.node0) + (BATCH ? int64_t(set) * a.node_stride : 0) +
+                                                                      td.node_base) + nlc;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const double2_t x = nin[h * NPT], y = nin[(H + h) * NPT];
+                piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
+                lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+            }
+        }
+    };
+    auto store_nodes = [&](int set, int n) {
+        if (!(active && g == 0)) return;
+        double2_t* nout = reinterpret_cast<double2_t*>(((n & 1) ? b.node1 : b.node0) + (BATCH ? int64_t(set) * a.node_stride : 0) + td.node_base) + nl;
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const double2_t x = nin[h * NPT], y = nin[(H + h) * NPT];
-            piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
-            lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
+            double2_t y, z;
+            y.x = piv[2 * h]; y.y = piv[2 * h + 1];
+            z.x = lav[2 * h]; z.y = lav[2 * h + 1];
+            nout[h * NPT] = y;
+            nout[(H + h) * NPT] = z;
         }
-    }
+    };
+    if constexpr (!BATCH) load_nodes(0, a.sweep_begin);
     const size_t rec_bytes = size_t(b.rec_total_doubles) * 8;
-    const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(b.rec0, 0, int(rec_bytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(b.rec1, 0, int(rec_bytes), 0x00020000);
 
-    RunEnd e{a.sweep_begin, 0, false};
-    for (int it = 0; it < a.budget; ++it) {
-        const int s = a.sweep_begin + it;
+    auto phase = [&](int set, int s) -> double {
+        if constexpr (BATCH) load_nodes(set, s);
         const bool first = s == 0;
+        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(b.rec0 + (BATCH ? int64_t(set) * a.rec_stride : 0), 0, int(rec_bytes), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(b.rec1 + (BATCH ? int64_t(set) * a.rec_stride : 0), 0, int(rec_bytes), 0x00020000);
         const __amdgpu_buffer_rsrc_t rin = (s & 1) ? rsrc1 : rsrc0;
         const __amdgpu_buffer_rsrc_t rout = (s & 1) ? rsrc0 : rsrc1;
         double wres = 0.0;
@@ -726,25 +800,15 @@ __device__ __forceinline__ RunEnd resident_group(const ResidentArgs& a, BlockSha
 #pragma unroll
             for (int i = 0; i < K; ++i) { piv[i] = pp[i]; lav[i] = lan[i]; }
         }
-
-        const int v = sync_and_decide(a, sh, s, wres, lane, wave);
-        if (v == kAbort) { e.abort = true; return e; }
-        e.n_sweeps = s + 1;
-        if (v != kGoOn) { e.done = v; break; }
-    }
-
-    if (active && g == 0) {
-        double2_t* nout = reinterpret_cast<double2_t*>(((e.n_sweeps & 1) ? b.node1 : b.node0) + td.node_base) + nl;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            double2_t y, z;
-            y.x = piv[2 * h]; y.y = piv[2 * h + 1];
-            z.x = lav[2 * h]; z.y = lav[2 * h + 1];
-            nout[h * NPT] = y;
-            nout[(H + h) * NPT] = z;
-        }
-        if (e.done != 0) {
+        if constexpr (BATCH) store_nodes(set, s + 1);
+        return wres;
+    };
+    auto finalize = [&](int set, int n, int done) {
+        if constexpr (BATCH) load_nodes(set, n);
+        else store_nodes(set, n);
+        if (active && g == 0 && done != 0) {
             const int64_t boff = b.slot_boff[td.slot_base + nl];
+            double* beliefs = b.beliefs + (BATCH ? int64_t(set) * a.belief_stride : 0);
             double bel[K];
             double sum = 0;
 #pragma unroll
@@ -753,24 +817,30 @@ __device__ __forceinline__ RunEnd resident_group(const ResidentArgs& a, BlockSha
                 sum += bel[i];
             }
 #pragma unroll
-            for (int i = 0; i < K; ++i) b.beliefs[boff + i] = bel[i] / sum;
+            for (int i = 0; i < K; ++i) beliefs[boff + i] = bel[i] / sum;
         }
-    }
-    return e;
+    };
+    return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
 }
 
-template <int K, int M>
-__device__ __forceinline__ RunEnd resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
-                                                    double2_t* cpt_lds) {
+template <int K, int M, bool BATCH, bool LEAN>
+__device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+                                                  double2_t* cpt_lds) {
 #ifdef BN_RES_ONLY_RC  // experiments: one instantiation only
-    return resident_tile<K, M, BN_RES_ONLY_RC>(a, sh, td, lane, wave, cpt_lds);
+    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH>(a, sh, td, lane, wave, cpt_lds);
 #else
-    if (td.cmax <= 2) return resident_tile<K, M, 2>(a, sh, td, lane, wave, cpt_lds);
-    if (td.cmax <= 4) return resident_tile<K, M, 4>(a, sh, td, lane, wave, cpt_lds);
-    return resident_tile<K, M, 8>(a, sh, td, lane, wave, cpt_lds);  // the host admits <= 8 children per node
+    if constexpr (LEAN) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
+    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
+    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH>(a, sh, td, lane, wave, cpt_lds);
+    return resident_tile<K, M, 8, BATCH>(a, sh, td, lane, wave, cpt_lds);  // the host admits <= 8 children per node
 #endif
 }
 
+// BATCH: several evidence sets per launch (node vectors through memory between a set's turns).
+// LEAN: every tile is a one-lane tile whose nodes have at most 2 children (grids, chains, polytrees of that
+// shape: the headline workload) -- an instantiation that carries no code or registers for the other shapes,
+// so its code-object figures (0 spills, tests/test_host_logic.py) are those of the path that actually runs.
+template <bool BATCH, bool LEAN>
 __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(ResidentArgs a) {
     __shared__ BlockShared sh;
     __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // upper CPT halves, 16 KiB per wave
@@ -782,52 +852,55 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
     const int nb = gridDim.x;
     const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int tile = lb * kResidentWaves + wave;
-    RunEnd e;
+    bool ok;
     if (tile >= b.n_tiles) {
-        e = resident_idle(a, sh, lane, wave);
+        ok = resident_idle<BATCH>(a, sh, lane, wave);
     } else {
         const TileDesc td = b.tiles[tile];
-        if (td.variant == kVariantGroup) {
-            if (td.m == 3) e = resident_group<1>(a, sh, td, lane, wave, cpt_lds_all[wave]);
-            else e = resident_group<2>(a, sh, td, lane, wave, cpt_lds_all[wave]);  // host admits m = 3, 4
-        } else {
+        double2_t* lds = cpt_lds_all[wave];
+#ifndef BN_RES_NO_GROUP
+        if (!LEAN && td.variant == kVariantGroup) {
+            if (td.m == 3) ok = resident_group<1, BATCH>(a, sh, td, lane, wave, lds);
+            else ok = resident_group<2, BATCH>(a, sh, td, lane, wave, lds);  // the host admits m = 3, 4
+        } else
+#endif
+        {
 #ifdef BN_RES_ONLY_K
-        e = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M>(a, sh, td, lane, wave, cpt_lds_all[wave]);
+            ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, BATCH, LEAN>(a, sh, td, lane, wave, lds);
 #else
-        switch (td.kv * 8 + td.m) {
-            case 2 * 8 + 0: e = resident_dispatch<2, 0>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 2 * 8 + 1: e = resident_dispatch<2, 1>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 2 * 8 + 2: e = resident_dispatch<2, 2>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 3 * 8 + 0: e = resident_dispatch<3, 0>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 3 * 8 + 1: e = resident_dispatch<3, 1>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 3 * 8 + 2: e = resident_dispatch<3, 2>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 4 * 8 + 0: e = resident_dispatch<4, 0>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            case 4 * 8 + 1: e = resident_dispatch<4, 1>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;
-            default: e = resident_dispatch<4, 2>(a, sh, td, lane, wave, cpt_lds_all[wave]); break;  // host admits only the shapes above
-        }
+            switch (td.kv * 8 + td.m) {
+                case 2 * 8 + 0: ok = resident_dispatch<2, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 2 * 8 + 1: ok = resident_dispatch<2, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 2 * 8 + 2: ok = resident_dispatch<2, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 3 * 8 + 0: ok = resident_dispatch<3, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 3 * 8 + 1: ok = resident_dispatch<3, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 3 * 8 + 2: ok = resident_dispatch<3, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 4 * 8 + 0: ok = resident_dispatch<4, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                case 4 * 8 + 1: ok = resident_dispatch<4, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                default: ok = resident_dispatch<4, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;  // host admits only the shapes above
+            }
 #endif
         }
     }
-    if (blockIdx.x == 0 && wave == 0 && !e.abort) {
-        // per-iteration maximum_difference: final since the barrier of each iteration
-        const int n_it = e.n_sweeps - a.sweep_begin;
-        for (int it = lane; it < n_it; it += kWave)
-            if (a.sweep_begin + it < b.res_cap)
-                b.res_hist[a.sweep_begin + it] = residual_of(__hip_atomic_load(&a.sync->res[it], RLX_AGENT));
-    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int n_it = e.n_sweeps - a.sweep_begin;
-        a.host_ctl->last_res = (!e.abort && n_it > 0) ? residual_of(__hip_atomic_load(&a.sync->res[n_it - 1], RLX_AGENT)) : 0.0;
-        a.host_ctl->n_sweeps = e.n_sweeps;
-        a.host_ctl->t_first = t_first; a.host_ctl->t_last = wall_clock64();
-        a.host_ctl->run_id = a.run_id;
-        a.host_ctl->done = e.abort ? -1 : e.done;
+        // per-set outcomes were written as the sets stopped; the launch as a whole: timing, and the abort mark
+        const unsigned long long t_last = wall_clock64();
+        for (int set = 0; set < a.n_sets; ++set) {
+            a.host_ctl[set].t_first = t_first;
+            a.host_ctl[set].t_last = t_last;
+            if (!ok) { a.host_ctl[set].run_id = a.run_id; a.host_ctl[set].done = -1; }
+        }
     }
 }
 
-int launch_bp_resident(const ResidentArgs& a, int grid_blocks, void* stream) {
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, bool lean, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    hipLaunchKernelGGL(bp_resident_kernel, dim3(grid_blocks), dim3(kResidentWaves * kWave), 0, (hipStream_t)stream, a);
+    const dim3 g(grid_blocks), t(kResidentWaves * kWave);
+    hipStream_t s = (hipStream_t)stream;
+    if (a.n_sets > 1 && lean) hipLaunchKernelGGL((bp_resident_kernel<true, true>), g, t, 0, s, a);
+    else if (a.n_sets > 1) hipLaunchKernelGGL((bp_resident_kernel<true, false>), g, t, 0, s, a);
+    else if (lean) hipLaunchKernelGGL((bp_resident_kernel<false, true>), g, t, 0, s, a);
+    else hipLaunchKernelGGL((bp_resident_kernel<false, false>), g, t, 0, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }

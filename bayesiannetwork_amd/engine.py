@@ -85,6 +85,46 @@ class Engine:
                                         _p(bel, ctypes.c_double), ctypes.byref(sweeps), ctypes.byref(res)))
         return {"beliefs": bel, "sweeps": sweeps.value, "residual": res.value}
 
+    # ---- several evidence sets per call (bn_bp_*_batch) ------------------------------------
+    @staticmethod
+    def _pack_sets(evidences):
+        evs = [ev if ev is not None else Evidence.none() for ev in evidences]
+        ne = np.asarray([ev.ne for ev in evs], dtype=np.int32)
+        node = np.concatenate([np.asarray(ev.node, np.int32) for ev in evs] + [np.zeros(0, np.int32)]).astype(np.int32)
+        off = np.concatenate([np.asarray(ev.off, np.int32)[:ev.ne + 1] if ev.ne else np.zeros(1, np.int32) for ev in evs]).astype(np.int32)
+        val = np.concatenate([np.asarray(ev.val, np.float64) for ev in evs] + [np.zeros(0)]).astype(np.float64)
+        return ne, np.ascontiguousarray(node), np.ascontiguousarray(off), np.ascontiguousarray(val)
+
+    def bp_set_evidence_batch(self, evidences) -> None:
+        ne, node, off, val = self._pack_sets(evidences)
+        self._n_sets = int(ne.size)
+        _lib.check(_lib.lib().bn_bp_set_evidence_batch(self._h, ne.size, _p(ne, ctypes.c_int32), _p(node, ctypes.c_int32),
+                                                       _p(off, ctypes.c_int32), _p(val, ctypes.c_double)))
+
+    def bp_run_batch_device(self, eps: float = 0.001, max_sweeps: int = 0):
+        sweeps = np.zeros(self._n_sets, dtype=np.int32)
+        res = np.zeros(self._n_sets, dtype=np.float64)
+        _lib.check(_lib.lib().bn_bp_run_batch_device(self._h, float(eps), int(max_sweeps), _p(sweeps, ctypes.c_int32),
+                                                     _p(res, ctypes.c_double)))
+        return {"sweeps": sweeps, "residual": res}
+
+    def bp_beliefs_batch(self) -> np.ndarray:
+        bel = np.empty((self._n_sets, int(self.model.k.sum())), dtype=np.float64)
+        _lib.check(_lib.lib().bn_bp_copy_beliefs_batch(self._h, _p(bel, ctypes.c_double)))
+        return bel
+
+    def bp_residuals_batch(self, set_index: int, cap: int = 65536) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.float64)
+        cnt = _lib.check(_lib.lib().bn_bp_residual_history_batch(self._h, int(set_index), _p(out, ctypes.c_double), cap))
+        return out[:cnt].copy()
+
+    def bp_run_batch(self, evidences, eps: float = 0.001, max_sweeps: int = 0):
+        """Several evidence sets on this network in one call; every set gets the result of running it alone."""
+        self.bp_set_evidence_batch(evidences)
+        out = self.bp_run_batch_device(eps, max_sweeps)
+        out["beliefs"] = self.bp_beliefs_batch()
+        return out
+
     def bp_beliefs(self) -> np.ndarray:
         bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
         _lib.check(_lib.lib().bn_bp_copy_beliefs(self._h, _p(bel, ctypes.c_double)))

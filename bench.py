@@ -11,6 +11,7 @@ The default single-GPU line also carries, as extra keys measured after the timed
   config2_dag        : BASELINE configs[1], the 10 k-node random DAG
   config5_lw         : BASELINE configs[4], likelihood weighting on that DAG
   grid2048           : the HBM-resident point (4.2 M nodes, 3.76 GB per sweep)
+  batch              : 2 / 4 / 8 evidence sets per call on the headline grid (bn_bp_run_batch_device)
 each with its own value / roofline / cpu_baseline (--no-extras skips them).
 """
 from __future__ import annotations
@@ -267,6 +268,36 @@ def leg_lw(a, local_rank, torch):
     return out
 
 
+def leg_batch(a, local_rank, torch):
+    """Several evidence sets per call on the headline grid (bn_bp_run_batch_device: all sets walked round-robin
+    by ONE resident launch, one CPT image in registers / LDS for all of them, each set's barrier hidden behind the
+    others' sweeps).  Throughput over all sets; every set's result is what a run of it alone gives (tests)."""
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+    g = synth.grid(a.rows, a.cols, 4, seed=2)
+    out = {"workload": f"{a.rows}x{a.cols} grid, B evidence sets per call ({a.evidence:g} evidence each, different nodes), eps={a.eps:g}"}
+    with Engine(g, device=local_rank) as eng:
+        for B in (2, 4, 8):
+            evs = [synth.random_evidence(g, a.evidence, seed=7 + q) for q in range(B)]
+            eng.bp_set_evidence_batch(evs)
+            for _ in range(3):
+                r = eng.bp_run_batch_device(a.eps)
+            torch.cuda.synchronize()
+            steps = max(10, a.steps // 2)
+            t0 = time.perf_counter()
+            sweeps = 0
+            for _ in range(steps):
+                r = eng.bp_run_batch_device(a.eps)
+                sweeps += int(r["sweeps"].sum())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            st = eng.bp_stats()
+            out[f"B{B}"] = {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_call": dt / steps * 1e3,
+                           "set_sweeps_per_call": sweeps / steps, "us_per_set_sweep": dt / sweeps * 1e6,
+                           "algorithmic_gbs": st["algorithmic_bytes_per_sweep"] * sweeps / dt / 1e9, "path": PATH_NAME.get(eng.last_path())}
+    return out
+
+
 def leg_grid2048(a, local_rank, torch):
     """The HBM-resident point: 2048x2048 grid, 4.19 M nodes, 3.76 GB per sweep."""
     from bayesiannetwork_amd import synth
@@ -376,7 +407,7 @@ def main():
             out["cpu_reference_small"] = ref
     eng.close()
     if default_run and not a.no_extras:
-        for key, fn in (("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
+        for key, fn in (("batch", leg_batch), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
             try:
                 out[key] = fn(a, local_rank, torch)
             except Exception as ex:  # noqa: BLE001 - an extra must never lose the headline

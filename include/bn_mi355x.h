@@ -112,6 +112,29 @@ int bn_bp_run_device(bn_engine *eng, double eps, int32_t max_sweeps, int32_t *sw
 const double *bn_bp_beliefs_device(bn_engine *eng);
 int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
 
+/*
+ * Several evidence sets on ONE network in one call -- an extension beside the drop-in: the reference's
+ * operator() (belief_propagation.hpp:31) takes one query at a time, and each set here gets exactly the
+ * result that call would give it (same sweep count, same bits).  Networks the resident kernel covers
+ * (bn_set_option "multisweep") run all sets in ONE launch that walks them round-robin: one resident CPT
+ * image serves every set and each set's grid barrier completes while the others compute; other networks
+ * run the sets one after another.  n_sets in 1..8.
+ *   ne[n_sets]           : evidence nodes per set
+ *   ev_node, ev_val      : the sets' arrays concatenated
+ *   ev_off               : per set a block of ne[q] + 1 offsets STARTING AT 0, blocks concatenated
+ *   beliefs_out          : [n_sets][sum k]; sweeps_out / residual_out : [n_sets]
+ * bn_bp_set_evidence_batch + bn_bp_run_batch_device + bn_bp_copy_beliefs_batch == bn_bp_run_batch, with the
+ * inputs and outputs left resident in HBM in between (bench.py times the middle call).
+ */
+int bn_bp_run_batch(bn_engine *eng, int32_t n_sets, const int32_t *ne, const int32_t *ev_node, const int32_t *ev_off,
+                    const double *ev_val, double eps, int32_t max_sweeps, double *beliefs_out, int32_t *sweeps_out,
+                    double *residual_out);
+int bn_bp_set_evidence_batch(bn_engine *eng, int32_t n_sets, const int32_t *ne, const int32_t *ev_node,
+                             const int32_t *ev_off, const double *ev_val);
+int bn_bp_run_batch_device(bn_engine *eng, double eps, int32_t max_sweeps, int32_t *sweeps_out, double *residual_out);
+int bn_bp_copy_beliefs_batch(bn_engine *eng, double *beliefs_out);
+int bn_bp_residual_history_batch(bn_engine *eng, int32_t set, double *out, int32_t cap);
+
 /* Diagnostics of the last bn_bp_run*: per-sweep maximum_difference (returns the count written),
  * and the final pi / lambda messages in CSR edge order (each sum_e k[parent(e)] doubles). */
 int bn_bp_residual_history(bn_engine *eng, double *out, int32_t cap);

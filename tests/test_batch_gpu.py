@@ -1,0 +1,78 @@
+"""Several evidence sets per call (bn_bp_run_batch): an extension beside the drop-in -- the reference runs
+one query per operator() call (belief_propagation.hpp:31) -- so the bar is that every set of a batch gets
+exactly what running it alone gives: same sweep count (sets stop on different sweeps), same residual
+history, same bits in the marginals; on the resident path (all sets walked round-robin in one launch) and
+on the sequential path of networks the resident kernel does not cover."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(bnlib):
+    from bayesiannetwork_amd.engine import Engine
+    return Engine
+
+
+def _alone(eng, ev, eps, max_sweeps=0):
+    eng.set_option("multisweep", 0)
+    r = eng.bp_run(ev, eps, max_sweeps)
+    return r, eng.bp_residuals()
+
+
+def _check_batch(eng, evs, eps, max_sweeps=0, want_path=None, reps=2):
+    want = [_alone(eng, ev, eps, max_sweeps) for ev in evs]
+    eng.set_option("multisweep", 2)
+    for _ in range(reps):
+        out = eng.bp_run_batch(evs, eps, max_sweeps)
+        if want_path is not None:
+            assert eng.last_path() == want_path
+        for q, (r, hist) in enumerate(want):
+            assert out["sweeps"][q] == r["sweeps"], f"set {q}"
+            assert np.array_equal(out["beliefs"][q], r["beliefs"], equal_nan=True), f"set {q}"
+            assert out["residual"][q] == r["residual"] or (np.isnan(out["residual"][q]) and np.isnan(r["residual"]))
+            assert np.array_equal(eng.bp_residuals_batch(q), hist), f"set {q}"
+    return [r["sweeps"] for r, _ in want]
+
+
+@pytest.mark.parametrize("rows,cols,k,n_sets,eps", [(316, 316, 4, 4, 1e-3), (316, 316, 4, 8, 1e-3), (64, 64, 4, 3, 1e-6),
+                                                     (40, 33, 3, 5, 1e-6), (7, 5, 4, 8, 1e-9), (50, 50, 2, 2, 1e-6)])
+def test_batch_equals_single_runs_grids(Engine, rows, cols, k, n_sets, eps):
+    from bayesiannetwork_amd import synth
+    g = synth.grid(rows, cols, k, seed=rows * 7 + cols)
+    # different amounts of evidence -> the sets converge on different sweeps
+    evs = [synth.random_evidence(g, f, seed=11 + q) for q, f in enumerate([0.0, 0.01, 0.05, 0.2, 0.002, 0.1, 0.0, 0.03][:n_sets])]
+    with Engine(g) as eng:
+        sweeps = _check_batch(eng, evs, eps, want_path=2)
+        if rows >= 40:
+            assert len(set(sweeps)) > 1, "the case should exercise sets leaving the rotation at different sweeps"
+
+
+def test_batch_caps_and_reuse(Engine):
+    from bayesiannetwork_amd import Evidence, synth
+    g = synth.grid(48, 48, 4, seed=5)
+    evs = [synth.random_evidence(g, 0.03, seed=2), None, Evidence.from_dict(g, {5: np.array([0.2, 0.5, 0.2, 0.1]), 900: 2})]
+    with Engine(g) as eng:
+        _check_batch(eng, evs, 1e-12, max_sweeps=3, want_path=2)   # every set capped together
+        _check_batch(eng, evs, 1e-3, want_path=2)
+        _check_batch(eng, evs[:1], 1e-6, want_path=2)              # a batch of one
+        _check_batch(eng, list(reversed(evs)) + evs, 1e-6, want_path=2)   # larger batch on the same engine
+        r, _ = _alone(eng, evs[0], 1e-6)                           # single-query calls still work in between
+        eng.set_option("multisweep", 1)
+        assert np.array_equal(eng.bp_run(evs[0], 1e-6)["beliefs"], r["beliefs"])
+
+
+def test_batch_lane_group_dag_and_sequential_fallback(Engine):
+    from bayesiannetwork_amd import _lib, synth
+    d = synth.random_dag(3000, 4, 64, 4, seed=5)                    # uniform + lane-group tiles, resident
+    evs = [synth.random_evidence(d, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
+    with Engine(d) as eng:
+        _check_batch(eng, evs, 1e-6, want_path=2)
+    m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)            # any-arity tiles: the sets run one after another
+    evs = [synth.random_evidence(m, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.02])]
+    with Engine(m) as eng:
+        _check_batch(eng, evs, 1e-6)
+        assert eng.last_path() in (0, 1)
+        with pytest.raises(_lib.BnError):
+            eng.bp_run_batch([None] * 9, 1e-3)                      # more than 8 sets

@@ -248,8 +248,9 @@ def test_sharded_plan_puts_interior_tiles_first(bnlib):
 def test_hot_kernels_do_not_spill(bnlib):
     """Code-object metadata of the built kernels (scripts/kernel_resources.py reads the gfx950 image
     embedded in csrc/*.o): the register-resident sweep instantiation has no spills, no scratch and no LDS;
-    the resident kernel stays within a handful of spilled dwords (4-children instantiation only) and holds
-    its 128 KiB of CPT halves in LDS; the samplers do not spill."""
+    the resident kernel's lean instantiations (what grids and chains run) have no spills and hold their
+    128 KiB of CPT halves in LDS, the all-shapes instantiations stay within a few dozen spilled dwords; the
+    samplers do not spill."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -266,8 +267,12 @@ def test_hot_kernels_do_not_spill(bnlib):
         assert "bp_sweep_kernel" in name
         assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0 and r["vgpr"] <= 256, (name, r)
     res = kr.kernel_resources(os.path.join(csrc, "bn_resident.o"))
-    (name, r), = res.items()
-    assert "bp_resident_kernel" in name and r["vgpr"] <= 256 and r["spill"] <= 24 and r["scratch"] <= 96, r
-    assert r["lds"] >= 128 * 1024
+    assert len(res) == 4
+    for name, r in res.items():
+        assert "bp_resident_kernel" in name and r["vgpr"] <= 256 and r["lds"] >= 128 * 1024, (name, r)
+        if ", true>" in name:   # LEAN: one-lane tiles with <= 2 children per node -- the instantiation the headline grid runs
+            assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+        else:                   # every shape inlined into one kernel: the 4- / 8-children and lane-group paths spill a little
+            assert r["spill"] <= 64, (name, r)
     for name, r in kr.kernel_resources(os.path.join(csrc, "bn_lw_kernels.o")).items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
