@@ -403,26 +403,6 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
                 p.in_refs[td.in_ref_base + int64_t(j) * c.npt + p.node_nl[v]] = p.edge_ref[p.in_ptr[v] + j];
     }
 
-    // ---- tile adjacency (symmetric by construction: an edge links the tiles of both endpoints)
-    {
-        std::vector<std::vector<int32_t>> adj(nt);
-        for (int64_t e = 0; e < p.E; ++e) {
-            const int32_t tu = p.node_tile[p.in_idx[e]], tv = p.node_tile[edge_child[e]];
-            if (tu < 0 || tv < 0 || tu == tv) continue;
-            adj[tu].push_back(tv);
-            adj[tv].push_back(tu);
-        }
-        p.nbr_ptr.assign(nt + 1, 0);
-        for (int32_t t = 0; t < nt; ++t) {
-            std::sort(adj[t].begin(), adj[t].end());
-            adj[t].erase(std::unique(adj[t].begin(), adj[t].end()), adj[t].end());
-            p.nbr_ptr[t + 1] = p.nbr_ptr[t] + int32_t(adj[t].size());
-            p.max_nbr = std::max<int32_t>(p.max_nbr, int32_t(adj[t].size()));
-        }
-        p.nbr_idx.reserve(p.nbr_ptr[nt]);
-        for (int32_t t = 0; t < nt; ++t) p.nbr_idx.insert(p.nbr_idx.end(), adj[t].begin(), adj[t].end());
-    }
-
     // ---- metrics, this rank's share: CPT of owned nodes once; every message it
     // produces and every owned node vector read once and written once
     int64_t vec = 0, cpt_owned = 0, msgs = 0;

@@ -143,10 +143,6 @@ struct Plan {
     std::vector<double> cpt_flat;
     std::vector<MsgRef> out_refs;    // per tile [c][nl]
     std::vector<MsgRef> in_refs;     // per boundary tile [j][nl]
-    // tile adjacency (tiles holding a parent or a child of one of the tile's nodes), for the
-    // persistent dataflow kernel: a tile may run sweep s+1 once these finished sweep s
-    std::vector<int32_t> nbr_ptr, nbr_idx;
-    int32_t max_nbr = 0;
     int64_t rec_doubles = 0;         // tile records only
     int64_t rec_total_doubles = 0;   // tile records + exchange region (one buffer)
     int64_t node_doubles = 0;
