@@ -83,20 +83,6 @@ struct EvidenceArgs {
     const double* ev_val;
 };
 
-// All sweeps of a small network in one launch of one workgroup (bn_multi.hip).
-constexpr int kMultiWaves = 8;        // 512 threads, <= 256 VGPRs: every tile variant
-constexpr int kMultiWavesLight = 15;  // 960 threads, <= 128 VGPRs: any-arity / one-lane tiles only (15 x 10 KiB of LDS)
-struct MultiArgs {
-    BpBuffers b;
-    double eps;
-    int32_t max_sweeps;   // 0 = unbounded like the reference
-    int32_t sweep_begin;  // first iteration of this launch (0 unless a previous launch ran out of budget)
-    int32_t budget;       // iterations this launch may execute
-    uint32_t run_id;
-    Ctl* host_ctl;
-};
-int launch_bp_multi(const MultiArgs& a, bool light, void* stream);
-
 // The whole run in one launch with every tile resident in registers (bn_resident.hip).
 constexpr int kResidentWaves = 8;       // 512 threads per block, one tile per wave, <= 256 VGPRs
 constexpr int kResidentLdsSlots = 16;   // double2 slots per lane of CPT kept in LDS (upper half of a 64-entry table)

@@ -156,9 +156,8 @@ struct bn_engine {
         std::vector<double> residual;
         bool have_run = false;
     } batch;
-    bool multi_ok = false;          // the network is small enough for the one-launch path
-    int multisweep = 1;             // one-launch paths: 0 never, 1 where they were measured faster (resident tiles on one
-                                    // block or on >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
+    int multisweep = 1;             // resident one-launch path: 0 never, 1 where it was measured faster (one block, or
+                                    // >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
     int32_t last_path = 0;          // 0 per-sweep launches, 1 one launch for the whole run
     Ctl* h_ctl = nullptr;  // pinned
     Ctl* h_ctl_dev = nullptr;  // the same memory as the device sees it
@@ -304,39 +303,24 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocMapped));
         std::memset(e->h_ctl, 0, sizeof(Ctl));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ctl_dev), e->h_ctl, 0));
-        {   // resident path (bn_resident.hip): uniform tiles (<= 2 parents, <= 8 children per node) and k = 4 lane
-            // groups (3-4 parents, every child served by a lane of its group), one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
+        {   // resident path (bn_resident.hip): one-lane tiles (<= 2 parents, <= 8 children per node), one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, e->device));
             const int64_t nt = int64_t(p.tiles.size());
             int64_t nb = (nt + kResidentWaves - 1) / kResidentWaves;
             if (nb > 1) nb = (nb + 7) & ~int64_t(7);
-            bool ok = p.nranks == 1 && nt > 0 && (p.variants & ~((1 << kVariantUniform) | (1 << kVariantGroup))) == 0 &&
+            bool ok = p.nranks == 1 && nt > 0 && p.variants == (1 << kVariantUniform) &&
                       nb <= int64_t(prop.multiProcessorCount) * 9 / 10 &&
                       p.rec_total_doubles * 8 < (int64_t(1) << 31);  // 32-bit byte offsets into a record buffer
-            for (const TileDesc& td : p.tiles) {
-                if (td.variant == kVariantUniform) {
-                    ok = ok && td.cmax <= 8 && td.in_ref_base < 0 && td.m <= 2;
-                } else {  // k = 4 lane group: 3 or 4 parents, every child served by a lane of the group
-                    const int G = td.m == 3 ? 4 : 16, cpl = G >= 16 ? 1 : 2;
-                    ok = ok && td.variant == kVariantGroup && (td.m == 3 || td.m == 4) && td.cmax <= G * cpl && td.in_ref_base < 0;
-                }
-            }
+            for (const TileDesc& td : p.tiles)
+                ok = ok && td.variant == kVariantUniform && td.cmax <= 8 && td.in_ref_base < 0 && td.m <= 2;
             e->resident_ok = ok;
             e->resident_lean = ok && p.variants == (1 << kVariantUniform);
             for (const TileDesc& td : p.tiles) e->resident_lean = e->resident_lean && td.cmax <= 2;
             e->grid_resident = int(nb);
             if (ok) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_rsync), sizeof(ResidentSync)));
         }
-        {   // small network: all sweeps in one launch of one workgroup (bn_multi.hip); wave w runs
-            // tiles w, w + W, ...: up to kMultiMaxRounds tiles per wave and sweep
-            const int64_t nt = int64_t(p.tiles.size());
-            const int64_t waves = p.light ? kMultiWavesLight : kMultiWaves;
-            int64_t rounds_max = 3;
-            if (const char* r = std::getenv("BN_MULTISWEEP_ROUNDS")) rounds_max = std::atoi(r);
-            e->multi_ok = p.nranks == 1 && nt > 0 && nt <= waves * rounds_max;
-            if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
-        }
+        if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         HIPCHK(hipStreamSynchronize(e->stream));
         std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
         return BN_OK;
@@ -593,49 +577,6 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     return BN_OK;
 }
 
-// Small networks: ONE launch of one workgroup runs every sweep, decides the stop and writes the
-// beliefs (bn_multi.hip).  A launch executes at most kMultiBudget iterations; a run that needs more
-// is continued by the next launch, so no evidence set can keep the GPU inside one kernel.
-static int run_multi(bn_engine* e, double eps, int32_t max_sweeps) {
-    constexpr int32_t kMultiBudget = 2048;
-    hipStream_t s = e->stream;
-    ++e->run_id;
-    if (e->run_id == 0) e->run_id = 1;
-    e->last_path = 1;
-    int32_t begin = 0, launches = 0;
-    float ms = 0.f;
-    double dev_ticks = 0.0;
-    for (;;) {
-        MultiArgs a{buffers_of(e), eps, max_sweeps, begin, kMultiBudget, e->run_id, e->h_ctl_dev};
-        if (e->timing) {
-            int rc = ensure_events(e, 2);
-            if (rc) return rc;
-            HIPCHK(hipEventRecord(e->events[0], s));
-        }
-        if (int code = launch_bp_multi(a, e->plan.light, s))
-            return fail(BN_ERR_HIP, std::string("bp_multi launch failed: ") + hipGetErrorString(hipError_t(code)));
-        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
-        HIPCHK(hipStreamSynchronize(s));
-        ++launches;
-        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "multi-sweep kernel did not report (stale control block)");
-        if (e->timing) {
-            float t = 0.f;
-            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
-            ms += t;
-        }
-        dev_ticks += double(e->h_ctl->t_last - e->h_ctl->t_first);
-        if (e->h_ctl->done != 0) break;
-        begin = e->h_ctl->n_sweeps;
-    }
-    const bool rows_were_clean = e->rows_clean;  // this path never touches the residual slots
-    note_run_result(e);
-    e->rows_clean = rows_were_clean;
-    e->stats.sweep_launches = launches;
-    e->stats.sweep_kernel_ms = ms;
-    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
-    return BN_OK;
-}
-
 extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
                                 double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -646,12 +587,10 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     ON_DEVICE(e);
     hipStream_t s = e->stream;
     int rc;
-    // resident tiles pay on one block (no grid barrier at all) and on large networks of one-lane tiles (the
-    // CPT traffic saved outweighs the ~4.5 us barrier); in between, and with lane-group tiles (latency-bound:
-    // the CPT stream is not on their critical path), a per-sweep launch is faster (measured)
+    // resident tiles pay on one block (no grid barrier at all) and on large networks (the CPT traffic saved
+    // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
     constexpr int64_t kResidentMinTiles = 640;
-    const bool resident_pays = e->grid_resident == 1 || (int64_t(e->plan.tiles.size()) >= kResidentMinTiles &&
-                                                         e->plan.variants == (1 << kVariantUniform));
+    const bool resident_pays = e->grid_resident == 1 || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
     if (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays))) {
         rc = run_resident(e, eps, max_sweeps);
         if (rc == BN_OK) {
@@ -665,14 +604,6 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
         // a barrier wait gave up (e.g. not every block became resident): per-sweep launches from now on
         if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] resident path disabled: %s\n", g_err.c_str());
         e->resident_ok = false;
-    } else if (e->multi_ok && e->multisweep == 2) {
-        rc = run_multi(e, eps, max_sweeps);
-        if (rc) return rc;
-        e->stats.total_ms =
-            std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-        if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
-        if (residual_out) *residual_out = e->last_ctl.last_res;
-        return BN_OK;
     }
     e->last_path = 0;
     if ((rc = step_begin(e))) return rc;
@@ -729,7 +660,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
-// 0 per-sweep launches, 1 one workgroup for the whole run (bn_multi.hip), 2 resident tiles + grid barrier (bn_resident.hip)
+// 0 per-sweep launches, 2 resident tiles + grid barrier (bn_resident.hip)
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;

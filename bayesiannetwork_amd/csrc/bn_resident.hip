@@ -523,306 +523,6 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Lane-group tile (k = 4, M = D + 2 parents, G = 4^D lanes per node), the whole run.  Same arithmetic
-// and the same shuffle order as tile_group<D, *> (bn_tiles.hpp): bit-identical to the launch path.
-// Resident: the lane's 64 CPT entries (own states 0,1 in registers, 2,3 in LDS), the packed references
-// of the children this lane serves, and -- in EVERY lane of the group -- pi(v) / lambda(v): the group's
-// first lane finishes the node each sweep and hands the new vectors to its group with shuffles, where the
-// launch path goes through memory.  Needs the spread parent role (cmax <= G * CPL: checked by the host).
-// ---------------------------------------------------------------------------------------------
-template <int D, bool BATCH>
-__device__ __forceinline__ bool resident_group(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
-                                               double2_t* cpt_lds) {
-    constexpr int K = 4, H = 2, M = D + 2;
-    constexpr int G = 1 << (2 * D), NPT = kWave / G;
-    constexpr int CPL = G >= 16 ? 1 : 2;  // children per lane
-    const BpBuffers& b = a.b;
-    const int nl = lane / G, g = lane % G;
-    const bool active = nl < td.n_nodes;
-    const int nlc = active ? nl : 0;  // inactive groups shadow node 0 and write nothing
-
-    // ---- resident state
-    const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
-    double cpt[32];  // q = i*16 + c_{M-2}*4 + c_{M-1}, own states i = 0, 1
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const double2_t x = cp[q * kWave];
-        cpt[2 * q] = x.x;
-        cpt[2 * q + 1] = x.y;
-    }
-#pragma unroll
-    for (int q = 16; q < 32; ++q) cpt_lds[(q - 16) * kWave + lane] = cp[q * kWave];
-    bool frozen = false;  // evidence mark of this lane's node for the set in hand
-    const int64_t in_pi0 = td.rec_base / 2 + nlc;  // pi-message of in-edge j at in_pi0 + j*2*H*NPT (+ h*NPT), lambda H*NPT further
-    MsgRef cref[CPL];
-#pragma unroll
-    for (int q = 0; q < CPL; ++q) {
-        const int c = g + q * G;
-        cref[q] = MsgRef{-1, 0};
-        if (active && c < td.cmax) cref[q] = b.out_refs[td.out_base + int64_t(c) * NPT + nlc];
-    }
-    double piv[K], lav[K];  // one set per launch: resident; several sets: the turn's working copy (see resident_tile)
-    auto load_nodes = [&](int set, int s) {
-        frozen = b.frozen[(BATCH ? int64_t(set) * a.slot_stride : 0) + td.slot_base + nlc] != 0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }  // a group node always has parents (:38-41)
-        if (frozen || s > 0) {
-            const double2_t* nin = reinterpret_cast<const double2_t*>(((s & 1) ? b.node1 : b.node0) + (BATCH ? int64_t(set) * a.node_stride : 0) +
-                                                                      td.node_base) + nlc;
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const double2_t x = nin[h * NPT], y = nin[(H + h) * NPT];
-                piv[2 * h] = x.x; piv[2 * h + 1] = x.y;
-                lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
-            }
-        }
-    };
-    auto store_nodes = [&](int set, int n) {
-        if (!(active && g == 0)) return;
-        double2_t* nout = reinterpret_cast<double2_t*>(((n & 1) ? b.node1 : b.node0) + (BATCH ? int64_t(set) * a.node_stride : 0) + td.node_base) + nl;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            double2_t y, z;
-            y.x = piv[2 * h]; y.y = piv[2 * h + 1];
-            z.x = lav[2 * h]; z.y = lav[2 * h + 1];
-            nout[h * NPT] = y;
-            nout[(H + h) * NPT] = z;
-        }
-    };
-    if constexpr (!BATCH) load_nodes(0, a.sweep_begin);
-    const size_t rec_bytes = size_t(b.rec_total_doubles) * 8;
-
-    auto phase = [&](int set, int s) -> double {
-        if constexpr (BATCH) load_nodes(set, s);
-        const bool first = s == 0;
-        const __amdgpu_buffer_rsrc_t rsrc0 = __builtin_amdgcn_make_buffer_rsrc(b.rec0 + (BATCH ? int64_t(set) * a.rec_stride : 0), 0, int(rec_bytes), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(b.rec1 + (BATCH ? int64_t(set) * a.rec_stride : 0), 0, int(rec_bytes), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rin = (s & 1) ? rsrc1 : rsrc0;
-        const __amdgpu_buffer_rsrc_t rout = (s & 1) ? rsrc0 : rsrc1;
-        double wres = 0.0;
-
-        double pim[M][K];
-#pragma unroll
-        for (int j = 0; j < M; ++j)
-#pragma unroll
-            for (int i = 0; i < K; ++i) pim[j][i] = 1.0;
-        if (!first) {
-#pragma unroll
-            for (int j = 0; j < M; ++j)
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const double2_t x = ld_rec(rin, in_pi0 + (j * 2 * H + h) * NPT);
-                    pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
-                }
-        }
-
-        // ---- parent role (:202-238), spread over the group's lanes: lane g serves children g, g+G
-        double lan[K];
-        {
-            Loc cl[CPL];
-            double clk[CPL][K], cold[CPL][K];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                cl[q] = decode_ref(cref[q], H);
-#pragma unroll
-                for (int i = 0; i < K; ++i) { clk[q][i] = 1.0; cold[q][i] = 1.0; }
-                if (!first) {  // a missing child reads record 0 and contributes 1.0
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const double2_t y = ld_rec(rin, cl[q].lam + h * cl[q].stride);
-                        const double2_t x = ld_rec(rin, cl[q].pi + h * cl[q].stride);
-                        clk[q][2 * h] = cl[q].has ? y.x : 1.0; clk[q][2 * h + 1] = cl[q].has ? y.y : 1.0;
-                        cold[q][2 * h] = x.x; cold[q][2 * h + 1] = x.y;
-                    }
-                }
-            }
-            double lam_all[K], msg[CPL][K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                lam_all[i] = 1.0;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) msg[q][i] = piv[i];
-            }
-            for (int x = 0; x < td.cmax; ++x) {  // ascending child order; wave-uniform trip count
-                const int qx = x / G, src = nl * G + (x % G);
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    double mine = clk[0][i];
-#pragma unroll
-                    for (int q = 1; q < CPL; ++q) mine = (qx == q) ? clk[q][i] : mine;
-                    const double val = shfl_d(mine, src);
-                    lam_all[i] *= val;
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q)
-                        if (g + q * G != x) msg[q][i] *= val;
-                }
-            }
-            normalize_k<K>(lam_all);  // every lane of the group holds the same lambda(v) (:220-238)
-#pragma unroll
-            for (int i = 0; i < K; ++i) lan[i] = lam_all[i];
-#pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                if (active && cl[q].has) {
-                    normalize_k<K>(msg[q]);
-#pragma unroll
-                    for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(msg[q][i] - cold[q][i]));
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        double2_t y;
-                        y.x = msg[q][2 * h]; y.y = msg[q][2 * h + 1];
-                        st_rec(rout, cl[q].pi + h * cl[q].stride, y);
-                    }
-                }
-            }
-        }
-
-        // pi-message entries of the lane-fixed parents
-        double pfix[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) pfix[j] = pick4(pim[j], (g >> (2 * (D - 1 - j))) & 3);
-
-        // ---- partial sums over this lane's 64 entries
-        double pp[K];          // pi(v)[i]
-        double ol[2][K];       // lambda-messages to the two trailing parents, by target state
-        double sf[D];          // lambda-messages to the leading parents: this lane's own bucket
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) ol[t][ct] = 0.0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) sf[j] = 0.0;
-#pragma unroll
-        for (int ib = 0; ib < K; ++ib) {
-            // one own state at a time (see pin_here)
-            pin_here(lav[ib]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int ct = 0; ct < K; ++ct) pin_here(ol[t][ct]);
-#pragma unroll
-            for (int j = 0; j < D; ++j) pin_here(sf[j]);
-            asm volatile("" ::: "memory");
-            const double* lds_row = reinterpret_cast<const double*>(cpt_lds + ((ib < 2 ? 0 : ib - 2) * 8) * kWave + lane);
-            auto ROW = [&](int cl) -> double {
-                if (ib < 2) return cpt[(ib < 2 ? ib : 0) * 16 + cl];
-                return lds_row[(cl >> 1) * (2 * kWave) + (cl & 1)];
-            };
-            double acc = 0.0;
-#pragma unroll
-            for (int cl = 0; cl < 16; ++cl) {
-                const int ca = cl >> 2, cb = cl & 3;  // states of parents M-2 and M-1
-                const double ent = ROW(cl);
-                // calculate_pi: cpt * pi-messages, ascending parent order
-                double v = ent;
-#pragma unroll
-                for (int j = 0; j < D; ++j) v *= pfix[j];
-                v *= pim[M - 2][ca];
-                v *= pim[M - 1][cb];
-                acc += v;
-                // calculate_lambda_k: (lambda[i] * cpt) * the OTHER parents' pi-messages, ascending
-                const double tc = lav[ib] * ent;
-                double pre = tc;  // shared prefix over the leading parents
-#pragma unroll
-                for (int j = 0; j < D; ++j) pre *= pfix[j];
-                ol[0][ca] += pre * pim[M - 1][cb];
-                ol[1][cb] += pre * pim[M - 2][ca];
-#pragma unroll
-                for (int jt = 0; jt < D; ++jt) {
-                    double w = tc;
-#pragma unroll
-                    for (int j = 0; j < D; ++j)
-                        if (j != jt) w *= pfix[j];
-                    w *= pim[M - 2][ca];
-                    w *= pim[M - 1][cb];
-                    sf[jt] += w;
-                }
-            }
-            pp[ib] = acc;
-        }
-
-        // ---- combine inside the G-lane group
-#pragma unroll
-        for (int mask = 1; mask < G; mask <<= 1) {
-#pragma unroll
-            for (int i = 0; i < K; ++i) pp[i] += shfl_xor_d(pp[i], mask);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int ct = 0; ct < K; ++ct) ol[t][ct] += shfl_xor_d(ol[t][ct], mask);
-        }
-        double of[D][K];
-#pragma unroll
-        for (int jt = 0; jt < D; ++jt) {
-            double x = sf[jt];
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-                if (j != jt) {
-                    x += shfl_xor_d(x, 1 << (2 * (D - 1 - j)));
-                    x += shfl_xor_d(x, 2 << (2 * (D - 1 - j)));
-                }
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
-        }
-
-        // ---- the group's first lane finishes the node: normalise, residual, stores; every lane of the
-        // group ends up with the same pp (the xor-combine leaves the full sum in all of them)
-        normalize_k<K>(pp);
-        if (active && g == 0) {
-#pragma unroll
-            for (int jt = 0; jt < M; ++jt) {
-                double o[K];
-#pragma unroll
-                for (int ct = 0; ct < K; ++ct) o[ct] = jt < D ? of[jt < D ? jt : 0][ct] : ol[jt >= D ? jt - D : 0][ct];
-                normalize_k<K>(o);
-                double old[K];
-#pragma unroll
-                for (int i = 0; i < K; ++i) old[i] = 1.0;
-                if (!first) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        const double2_t y = ld_rec(rin, in_pi0 + (jt * 2 * H + H + h) * NPT);
-                        old[2 * h] = y.x; old[2 * h + 1] = y.y;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - old[i]));
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    double2_t y;
-                    y.x = o[2 * h]; y.y = o[2 * h + 1];
-                    st_rec(rout, in_pi0 + (jt * 2 * H + H + h) * NPT, y);
-                }
-            }
-        }
-        // node vectors for the next sweep: evidence nodes keep theirs (:177, :223)
-        if (!frozen) {
-#pragma unroll
-            for (int i = 0; i < K; ++i) { piv[i] = pp[i]; lav[i] = lan[i]; }
-        }
-        if constexpr (BATCH) store_nodes(set, s + 1);
-        return wres;
-    };
-    auto finalize = [&](int set, int n, int done) {
-        if constexpr (BATCH) load_nodes(set, n);
-        else store_nodes(set, n);
-        if (active && g == 0 && done != 0) {
-            const int64_t boff = b.slot_boff[td.slot_base + nl];
-            double* beliefs = b.beliefs + (BATCH ? int64_t(set) * a.belief_stride : 0);
-            double bel[K];
-            double sum = 0;
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                bel[i] = piv[i] * lav[i];
-                sum += bel[i];
-            }
-#pragma unroll
-            for (int i = 0; i < K; ++i) beliefs[boff + i] = bel[i] / sum;
-        }
-    };
-    return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
-}
-
 template <int K, int M, bool BATCH, bool LEAN>
 __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
                                                   double2_t* cpt_lds) {
@@ -858,12 +558,6 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
     } else {
         const TileDesc td = b.tiles[tile];
         double2_t* lds = cpt_lds_all[wave];
-#ifndef BN_RES_NO_GROUP
-        if (!LEAN && td.variant == kVariantGroup) {
-            if (td.m == 3) ok = resident_group<1, BATCH>(a, sh, td, lane, wave, lds);
-            else ok = resident_group<2, BATCH>(a, sh, td, lane, wave, lds);  // the host admits m = 3, 4
-        } else
-#endif
         {
 #ifdef BN_RES_ONLY_K
             ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, BATCH, LEAN>(a, sh, td, lane, wave, lds);

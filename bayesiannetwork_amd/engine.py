@@ -150,7 +150,7 @@ class Engine:
         _lib.check(_lib.lib().bn_set_option(self._h, name.encode(), int(value)))
 
     def last_path(self) -> int:
-        """1: the last run was one launch for the whole run (multi-sweep kernel); 0: one launch per sweep."""
+        """2: the last run was one launch for the whole run (resident tiles); 0: one launch per sweep."""
         return _lib.check(_lib.lib().bn_bp_last_path(self._h))
 
     # ---- multi-GPU ---------------------------------------------------------------------

@@ -170,9 +170,8 @@ def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
             "path": path, "ms_per_step_with_events": dt_ev / max(ev_steps, 1) * 1e3, "event_steps": ev_steps}
 
 
-PATH_KERNEL = {0: "bp_sweep_kernel", 1: "bp_multi_kernel", 2: "bp_resident_kernel"}
-PATH_NAME = {0: "one launch per sweep", 1: "one workgroup, one launch for the whole run",
-             2: "resident tiles, one launch for the whole run (grid barrier per sweep)"}
+PATH_KERNEL = {0: "bp_sweep_kernel", 2: "bp_resident_kernel"}
+PATH_NAME = {0: "one launch per sweep", 2: "resident tiles, one launch for the whole run (grid barrier per sweep)"}
 
 
 def roofline_of(t, label):

@@ -148,13 +148,13 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * "overlap" 1/0 -- sharded runs: launch the interior tiles of a sweep while the previous sweep's
  *   all-gather is in flight on a second stream (default 1; BN_OVERLAP=0), or kernel and collective
  *   back to back on one stream.
- * "multisweep" 0/1/2 -- the one-launch paths (BN_MULTISWEEP in the environment sets the default, 1):
- *   networks of register-resident tiles that fit the chip can run the whole run in ONE launch with
- *   CPTs, references and node vectors resident in registers / LDS and a grid barrier per sweep; other
- *   small networks can run all their sweeps in one workgroup.  0 = always one launch per sweep;
- *   1 = the resident path where it was measured faster (one-block networks, grids of >= 640 tiles);
- *   2 = every eligible one-launch path (tests, experiments).  Results are bit-identical on every path.
- * bn_bp_last_path: 0 = one launch per sweep, 1 = one workgroup for the whole run, 2 = resident tiles. */
+ * "multisweep" 0/1/2 -- the one-launch path (BN_MULTISWEEP in the environment sets the default, 1):
+ *   networks of one-lane tiles (uniform arity 2..4, <= 2 parents, <= 8 children per node) that fit the chip
+ *   can run the whole run in ONE launch with CPTs, references and node vectors resident in registers / LDS
+ *   and a grid barrier per sweep.  0 = always one launch per sweep; 1 = that path where it was measured
+ *   faster (one-block networks, networks of >= 640 tiles); 2 = wherever eligible (tests, experiments).
+ *   Results are bit-identical on either path.
+ * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 

@@ -1,4 +1,4 @@
-# Small networks: one launch per sweep vs. all sweeps in one launch (bn_multi.hip); run on the GPU box.
+# Small networks: one launch per sweep vs. the whole run in one launch with resident tiles (bn_resident.hip); run on the GPU box.
 # Prints, per network, sweeps, device-clock microseconds per sweep and host wall microseconds per run
 # on both paths, and checks that the two paths give the same bits.
 import json
@@ -31,7 +31,6 @@ if len(sys.argv) > 1:
     nets = [x for x in nets if x[0] in sys.argv[1:]]
 out = {}
 for name, mod in nets:
-    os.environ["BN_MULTISWEEP_ROUNDS"] = "64"  # make every network here eligible: the script measures where the path pays
     with Engine(mod) as e:
         e.bp_set_evidence(Evidence.none())
         res = {}

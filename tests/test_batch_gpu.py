@@ -65,14 +65,18 @@ def test_batch_caps_and_reuse(Engine):
 
 def test_batch_lane_group_dag_and_sequential_fallback(Engine):
     from bayesiannetwork_amd import _lib, synth
-    d = synth.random_dag(3000, 4, 64, 4, seed=5)                    # uniform + lane-group tiles, resident
+    d = synth.random_dag(3000, 4, 64, 4, seed=5)                    # lane-group tiles: the sets run one after another
     evs = [synth.random_evidence(d, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
     with Engine(d) as eng:
-        _check_batch(eng, evs, 1e-6, want_path=2)
+        _check_batch(eng, evs, 1e-6, want_path=0)
+    t = synth.random_dag(2000, 2, 8, 4, seed=41)                    # <= 2 parents: one-lane tiles, resident if <= 8 children
+    evs = [synth.random_evidence(t, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
+    with Engine(t) as eng:
+        _check_batch(eng, evs, 1e-6)
     m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)            # any-arity tiles: the sets run one after another
     evs = [synth.random_evidence(m, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.02])]
     with Engine(m) as eng:
         _check_batch(eng, evs, 1e-6)
-        assert eng.last_path() in (0, 1)
+        assert eng.last_path() == 0
         with pytest.raises(_lib.BnError):
             eng.bp_run_batch([None] * 9, 1e-3)                      # more than 8 sets
