@@ -85,20 +85,19 @@ struct EvidenceArgs {
 
 // The whole run in one launch with every tile resident in registers (bn_resident.hip).
 constexpr int kResidentWaves = 8;       // 512 threads per block, one tile per wave, <= 256 VGPRs
-constexpr int kResidentLdsSlots = 16;   // double2 slots per lane of CPT kept in LDS (upper half of a 64-entry table)
+constexpr int kResidentLdsSlots = 18;   // double2 slots per lane of CPT kept in LDS (36 of the 64 entries of a k = 4, two-parent table)
 constexpr int kResidentMaxSets = 8;     // evidence sets one launch can walk round-robin (bn_bp_run_batch)
 constexpr int kResidentBudget = 1024;   // iterations one launch may execute (size of ResidentSync::res)
-struct ResidentSync {                   // zeroed by the host before every launch
-    unsigned abort;                     // non-zero: a bounded wait gave up
-    unsigned top;                       // groups that completed their arrivals (monotonic)
-    unsigned pad_[30];
+constexpr int kResidentMaxBlocks = 256;
+struct ResidentSync {                   // one per evidence set; zeroed by the host before every launch
+    unsigned abort;                     // (set 0's) non-zero: a bounded wait gave up
+    unsigned pad_[31];
     struct Group {
-        unsigned count;                 // arrivals of the group's blocks (monotonic)
-        unsigned pad0_[31];
-        unsigned gen;                   // last generation released to this group
-        unsigned pad1_[31];
+        unsigned gen;                   // generation | verdict << 30 of the group's last released barrier
+        unsigned pad_[31];
     } grp[8];
-    unsigned long long res[kResidentBudget];  // per-iteration maximum_difference, bit patterns
+    unsigned long long blk[kResidentMaxBlocks][2];  // per tile block: the same, written by the block
+    unsigned long long res[kResidentBudget];        // per-iteration maximum_difference, bit patterns (service block)
 };
 struct ResidentArgs {
     BpBuffers b;          // evidence set 0; set q's buffers follow at the strides below
@@ -110,6 +109,7 @@ struct ResidentArgs {
     unsigned long long timeout_ticks;  // bound of one barrier wait, 100 MHz ticks
     ResidentSync* sync;   // [n_sets]
     Ctl* host_ctl;        // [n_sets], pinned
+    int32_t n_tile_blocks;  // blocks [0, n_tile_blocks) carry tiles; the launch's further blocks serve the barrier
     int32_t n_sets;       // 1: node vectors stay in registers; > 1: they go through memory between a set's turns
     uint32_t set_mask;    // sets still running (a continued launch skips the others)
     int64_t rec_stride, node_stride;  // doubles between consecutive sets' record / node buffers
@@ -117,7 +117,7 @@ struct ResidentArgs {
     int64_t belief_stride;            // doubles between their beliefs
     int32_t res_hist_stride;          // doubles between their residual histories
 };
-int launch_bp_resident(const ResidentArgs& a, int grid_blocks, bool lean, void* stream);  // lean: one-lane tiles, <= 2 children per node
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // lean_k: uniform arity with <= 2 children per node, else 0
 
 // launchers (bn_kernels.hip)
 int launch_bp_evidence(const EvidenceArgs& a, void* stream);  // bn_bp_set_evidence: marks + vectors

@@ -133,7 +133,7 @@ struct bn_engine {
     bool timing = false;            // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms); opt-in:
                                     // an event record between two launches opens a ~6 us bubble in the queue
     bool resident_ok = false;       // every tile register-resident and co-resident: the whole run in one launch (bn_resident.hip)
-    bool resident_lean = false;     // ... and all its tiles are one-lane tiles with <= 2 children per node
+    int resident_lean = 0;          // ... and every node has this arity (2, 3 or 4) and <= 2 children; else 0
     int grid_resident = 0;
     ResidentSync* d_rsync = nullptr;
     // several evidence sets per launch (bn_bp_*_batch): per-set records, node vectors, marks, beliefs, histories
@@ -310,13 +310,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             int64_t nb = (nt + kResidentWaves - 1) / kResidentWaves;
             if (nb > 1) nb = (nb + 7) & ~int64_t(7);
             bool ok = p.nranks == 1 && nt > 0 && p.variants == (1 << kVariantUniform) &&
-                      nb <= int64_t(prop.multiProcessorCount) * 9 / 10 &&
+                      nb + 1 <= int64_t(prop.multiProcessorCount) * 9 / 10 && nb <= kResidentMaxBlocks &&  // + the barrier's service block
                       p.rec_total_doubles * 8 < (int64_t(1) << 31);  // 32-bit byte offsets into a record buffer
             for (const TileDesc& td : p.tiles)
                 ok = ok && td.variant == kVariantUniform && td.cmax <= 8 && td.in_ref_base < 0 && td.m <= 2;
             e->resident_ok = ok;
-            e->resident_lean = ok && p.variants == (1 << kVariantUniform);
-            for (const TileDesc& td : p.tiles) e->resident_lean = e->resident_lean && td.cmax <= 2;
+            e->resident_lean = ok && !p.tiles.empty() ? int(p.tiles[0].kv) : 0;
+            for (const TileDesc& td : p.tiles)
+                if (td.cmax > 2 || int(td.kv) != e->resident_lean) e->resident_lean = 0;
             e->grid_resident = int(nb);
             if (ok) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_rsync), sizeof(ResidentSync)));
         }
@@ -531,6 +532,9 @@ static void note_run_result(bn_engine* e) {
     e->stats.sweep_devclock_ms = t1 > t0 ? float(double(t1 - t0) * 1e-5) : 0.f;
 }
 
+// blocks the barrier of a resident launch adds to the tile blocks: one, sweeping every tile block's granules
+static int resident_service_blocks(int tile_blocks) { return tile_blocks > 1 ? 1 : 0; }
+
 // Networks of register-resident tiles that fit the chip: ONE launch runs the whole run with the CPTs,
 // references and node vectors resident in registers / LDS and a grid barrier per sweep (bn_resident.hip).
 // BN_ERR_STATE = a bounded wait inside the kernel gave up: the caller redoes the run with per-sweep launches.
@@ -545,13 +549,13 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
         HIPCHK(hipMemsetAsync(e->d_rsync, 0, sizeof(ResidentSync), s));  // every polled word, before every launch
         ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id,
                        5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev,
-                       1, 1u, 0, 0, 0, 0, 0};
+                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
             HIPCHK(hipEventRecord(e->events[0], s));
         }
-        if (int code = launch_bp_resident(a, e->grid_resident, e->resident_lean, s))
+        if (int code = launch_bp_resident(a, e->grid_resident + resident_service_blocks(e->grid_resident), e->resident_lean, s))
             return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
         HIPCHK(hipStreamSynchronize(s));
@@ -788,14 +792,14 @@ static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     for (;;) {
         HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(bt.n_sets), s));
         ResidentArgs a{batch_buffers_of(e, 0), eps, max_sweeps, begin, kResidentBudget, e->run_id, 5000000ull, bt.d_sync,
-                       bt.h_ctl_dev, bt.n_sets, mask, p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)),
+                       bt.h_ctl_dev, e->grid_resident, bt.n_sets, mask, p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)),
                        p.node_off[p.n], e->res_cap};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
             HIPCHK(hipEventRecord(e->events[0], s));
         }
-        if (int code = launch_bp_resident(a, e->grid_resident, e->resident_lean, s))
+        if (int code = launch_bp_resident(a, e->grid_resident + resident_service_blocks(e->grid_resident), e->resident_lean, s))
             return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
         HIPCHK(hipStreamSynchronize(s));

@@ -13,15 +13,15 @@
 // Between iterations stands ONE grid barrier (the Jacobi schedule needs nothing finer):
 //   producer  message stores are 16-byte WRITE-THROUGH (sc1) stores; every wave drains them
 //             (s_waitcnt vmcnt(0)), __syncthreads(), then lane 0 of the block arrives;
-//   barrier   XCD-hierarchical counters: block -> its group's counter -> top counter -> the last
-//             arriver publishes the generation to every group's word; blocks poll their group's word
-//             (relaxed agent-scope loads + s_sleep), then ONE agent-scope acquire, __syncthreads(),
-//             plain loads.  (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md barrier-xcd.)
-//             Nothing depends on dispatch order or on which XCD a block runs; groups = blockIdx % 8
-//             only shard the counters.
-//   residual  every block folds max|new - old| (:105-131) into a per-iteration word with an atomic
-//             max before it arrives; after the barrier everyone reads the same word and takes the same
-//             stop decision (:147).
+//   barrier   hierarchical and atomic-free: a tile block publishes a pair of 8-byte {generation, residual half}
+//             granules and goes on; SERVICE blocks (extra blocks of the launch on CUs the tiles leave free)
+//             collect them per group (blockIdx % 8: sharding only) and then over the groups, decide, and
+//             publish generation + verdict in one word per group, which the tile blocks poll (relaxed
+//             agent-scope loads + s_sleep).  Loads of the records are sc1, so no acquire fence is needed.
+//             (cdna_hip_programming.md Guideline 16 R2 / MI355X_MICROARCH.md barrier-xcd, handoff-1to1.)
+//             Nothing depends on dispatch order or on which XCD a block runs.
+//   residual  max|new - old| (:105-131) travels in the granules; the top service block takes the stop
+//             decision (:147) and every block reads the same verdict.
 // A one-block grid (<= 8 tiles: Pearl's network, small chains) needs no atomics at all: LDS slots and
 // __syncthreads().
 //
@@ -80,11 +80,24 @@ __device__ __forceinline__ int verdict_of(const ResidentArgs& a, double r, int n
     return kGoOn;
 }
 
-// First half of the barrier of iteration `it` (sweep s) of evidence set `set`: the block's residual and its
-// arrival.  Every block folds its residual into res[it] BEFORE it arrives, so the last arriver of all reads
-// the final value, decides, and publishes the verdict together with the generation in ONE word per group:
-// nobody else reads the residual on the critical path.  Nothing is waited for here (but the block's own
-// stores); the caller goes on with another set's sweep and collects the verdict with wait_verdict().
+// ---- the grid barrier -------------------------------------------------------------------------
+// The tile blocks never wait inside an arrival and never execute a returning atomic.  A block that has
+// finished a sweep of a set publishes ONE pair of 8-byte granules {generation | half of its residual's bit
+// pattern} (cdna_hip_programming.md Guideline 16, form R2: the data is the flag, one aligned 8-byte sc1
+// store each, nothing to order).  The granules are collected by SERVICE blocks: extra blocks of the same
+// The granules are collected by a SERVICE block: one extra block of the same launch that carries no tile and
+// sits on a CU the tiles leave free (the host admits the path only when tile blocks + 1 fit the chip): it
+// sweeps the granules of every tile block until all carry the generation, reduces the residual, decides
+// (converged / capped / go on), records the residual and publishes generation + verdict in one word per
+// group of tile blocks (blockIdx % 8: spreads the pollers), which the tile blocks poll when they next need
+// that set.  Round trips on the path from the last tile block's arrival to the verdict: granule store ->
+// sweep -> verdict store -> tile blocks' poll; none of them on a
+// tile block.  With several sets in flight the whole of it runs behind the other sets' sweeps.
+// (A two-level collection -- one service block per group, then a top block -- was measured ~0.3 us slower per
+// barrier than this single sweep over all tile blocks' granules.)
+__device__ __forceinline__ unsigned long long granule(unsigned gen, unsigned half) { return ((unsigned long long)gen << 32) | half; }
+
+// First half of the barrier of iteration `it` (sweep s) of evidence set `set`: publish the block's residual.
 __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, int set, int it, int s, double wres, int lane,
                                        int wave) {
     const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
@@ -96,53 +109,90 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
 #pragma unroll
         for (int w = 0; w < kResidentWaves; ++w) m = sh.slot[set][w] > m ? sh.slot[set][w] : m;
         ResidentSync* sy = a.sync + set;
-        const int nb = gridDim.x;
-        if (nb == 1) {
+        if (a.n_tile_blocks == 1) {
             sy->res[it] = m;
             sh.verdict[set] = verdict_of(a, residual_of(m), s + 1);
         } else {
             const unsigned gen = unsigned(it) + 1u;
-            const int groups = nb < 8 ? nb : 8;
-            const int g = blockIdx.x % groups;
-            const unsigned in_group = unsigned((nb - g + groups - 1) / groups);
-            if (m != 0) __hip_atomic_fetch_max(&sy->res[it], m, RLX_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the max is performed before this block arrives
-            const unsigned old = __hip_atomic_fetch_add(&sy->grp[g].count, 1u, RLX_AGENT);
-            if (old + 1u == in_group * gen) {
-                const unsigned t = __hip_atomic_fetch_add(&sy->top, 1u, RLX_AGENT);
-                if (t + 1u == unsigned(groups) * gen) {
-                    const unsigned long long all = __hip_atomic_load(&sy->res[it], RLX_AGENT);
-                    const unsigned word = gen | (unsigned(verdict_of(a, residual_of(all), s + 1)) << 30);
-                    for (int q = 0; q < groups; ++q) __hip_atomic_store(&sy->grp[q].gen, word, RLX_AGENT);
-                }
-            }
+            __hip_atomic_store(&sy->blk[blockIdx.x][0], granule(gen, unsigned(m >> 32)), RLX_AGENT);
+            __hip_atomic_store(&sy->blk[blockIdx.x][1], granule(gen, unsigned(m)), RLX_AGENT);
         }
+    }
+}
+
+// polls until pred() or abort / timeout; false = give up (abort raised)
+template <class Pred>
+__device__ __forceinline__ bool poll_until(const ResidentArgs& a, Pred&& pred) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (pred()) return true;
+        if (__hip_atomic_load(&a.sync->abort, RLX_AGENT) != 0) return false;  // set 0's word is the launch's abort flag
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+            __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
 // Second half: the verdict of iteration `it` of `set` once every block has arrived.
 __device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& sh, int set, int it) {
-    if (threadIdx.x == 0 && gridDim.x > 1) {
+    if (threadIdx.x == 0 && a.n_tile_blocks > 1) {
         ResidentSync* sy = a.sync + set;
-        const int nb = gridDim.x;
         const unsigned gen = unsigned(it) + 1u;
-        const int g = blockIdx.x % (nb < 8 ? nb : 8);
-        const unsigned long long t0 = wall_clock64();
-        int verdict = kAbort;
-        for (;;) {
-            const unsigned word = __hip_atomic_load(&sy->grp[g].gen, RLX_AGENT);
-            if ((word & 0x3fffffffu) >= gen) { verdict = int(word >> 30); break; }
-            if (__hip_atomic_load(&a.sync->abort, RLX_AGENT) != 0) break;
-            if (wall_clock64() - t0 > a.timeout_ticks) {
-                __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);  // set 0's word is the launch's abort flag
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        sh.verdict[set] = verdict;
+        const int groups = a.n_tile_blocks < 8 ? a.n_tile_blocks : 8;
+        const int g = blockIdx.x % groups;
+        unsigned word = 0;
+        const bool ok = poll_until(a, [&] {
+            word = __hip_atomic_load(&sy->grp[g].gen, RLX_AGENT);
+            return (word & 0x3fffffffu) >= gen;
+        });
+        sh.verdict[set] = ok ? int(word >> 30) : kAbort;
     }
     __syncthreads();
     return sh.verdict[set];
+}
+
+// The service block (one wave; the launch has exactly one when it has more than one tile block): lane l
+// sweeps the granule pairs of tile blocks l, l + 64, l + 128, l + 192 until all carry the generation, the wave
+// reduces the residual, lane 0 decides and publishes.  It follows the same (iteration, set) order as the tile
+// blocks and knows from its own verdicts which sets are still running.
+__device__ __forceinline__ void resident_service(const ResidentArgs& a, int lane) {
+    const int nb = a.n_tile_blocks;
+    const int groups = nb < 8 ? nb : 8;
+    unsigned active = a.set_mask;
+    for (int it = 0; it < a.budget; ++it) {
+        const unsigned gen = unsigned(it) + 1u;
+        for (int set = 0; set < a.n_sets; ++set) {
+            if (((active >> set) & 1u) == 0) continue;
+            ResidentSync* sy = a.sync + set;
+            unsigned long long m = 0;
+            if (!poll_until(a, [&] {
+                    bool mine = true;
+                    unsigned long long acc = 0;
+                    for (int blk = lane; blk < nb; blk += kWave) {
+                        const unsigned long long hi = __hip_atomic_load(&sy->blk[blk][0], RLX_AGENT);
+                        const unsigned long long lo = __hip_atomic_load(&sy->blk[blk][1], RLX_AGENT);
+                        mine = mine && unsigned(hi >> 32) == gen && unsigned(lo >> 32) == gen;
+                        const unsigned long long v = (hi << 32) | (lo & 0xffffffffull);
+                        acc = v > acc ? v : acc;
+                    }
+                    m = acc;
+                    return __all(mine) != 0;
+                }))
+                return;
+            m = wave_umax(m);
+            const int verdict = verdict_of(a, residual_of(m), a.sweep_begin + it + 1);
+            if (lane == 0) {
+                __hip_atomic_store(&sy->res[it], m, RLX_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the residual is recorded before anyone learns the verdict
+                const unsigned word = gen | (unsigned(verdict) << 30);
+                for (int q = 0; q < groups; ++q) __hip_atomic_store(&sy->grp[q].gen, word, RLX_AGENT);
+            }
+            if (verdict != kGoOn) active &= ~(1u << set);
+        }
+        if (active == 0) break;
+    }
 }
 
 // The launch's loop over iterations and evidence sets, shared by every tile kind.
@@ -208,9 +258,10 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
     constexpr int CB = (M > 0) ? C / K : 0;
-    constexpr int KR = (S > 32) ? K / 2 : K;       // own states whose CPT entries stay in registers
-    constexpr int SR = (KR == K) ? SP : KR * C;     // entries in registers (even)
-    static_assert(SR % 2 == 0 && (KR == K || (C % 2 == 0 && (S - SR) / 2 <= kResidentLdsSlots)), "CPT split");
+    // entries [0, SR) of the i-major image stay in registers, the rest in LDS: 28 of 64 (k = 4, two parents) leaves the
+    // working set just enough registers; everything for smaller tables
+    constexpr int SR = (S > 32) ? 28 : SP;
+    static_assert(SR % 2 == 0 && (SR == SP || (S - SR) / 2 <= kResidentLdsSlots), "CPT split");
     const BpBuffers& b = a.b;
     const bool active = lane < td.n_nodes;
     const int lc = active ? lane : 0;  // idle lanes shadow lane 0 and store nothing
@@ -224,7 +275,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
         cpt[2 * q] = x.x;
         cpt[2 * q + 1] = x.y;
     }
-    if constexpr (KR < K) {
+    if constexpr (SR < SP) {
 #pragma unroll
         for (int q = SR / 2; q < S / 2; ++q) cpt_lds[(q - SR / 2) * kWave + lane] = cp[q * kWave];
     }
@@ -414,10 +465,11 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                     for (int ct = 0; ct < K; ++ct) pin_here(out[jt][ct]);
                 // entry `cond` of own state ib: a register, or this wave's LDS slots (read where it is used:
                 // a copy of the whole row would cost 2 C registers for the length of the step)
-                const double* lds_row = reinterpret_cast<const double*>(cpt_lds + ((ib < KR ? 0 : ib - KR) * (C / 2)) * kWave + lane);
+                const double* lds_lane = reinterpret_cast<const double*>(cpt_lds + lane);
                 auto ROW = [&](int cond) -> double {
-                    if (ib < KR) return cpt[(ib < KR ? ib : 0) * C + cond];
-                    return lds_row[(cond >> 1) * (2 * kWave) + (cond & 1)];
+                    const int e = ib * C + cond;  // compile-time after unrolling
+                    if (e < SR) return cpt[e < SR ? e : 0];
+                    return lds_lane[((e - SR) >> 1) * (2 * kWave) + (e & 1)];
                 };
                 double acc = 0.0;
 #pragma unroll
@@ -523,13 +575,13 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
 }
 
-template <int K, int M, bool BATCH, bool LEAN>
+template <int K, int M, bool BATCH, int LEAN>
 __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
                                                   double2_t* cpt_lds) {
 #ifdef BN_RES_ONLY_RC  // experiments: one instantiation only
     return resident_tile<K, M, BN_RES_ONLY_RC, BATCH>(a, sh, td, lane, wave, cpt_lds);
 #else
-    if constexpr (LEAN) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
+    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
     if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
     if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH>(a, sh, td, lane, wave, cpt_lds);
     return resident_tile<K, M, 8, BATCH>(a, sh, td, lane, wave, cpt_lds);  // the host admits <= 8 children per node
@@ -537,19 +589,28 @@ __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockSh
 }
 
 // BATCH: several evidence sets per launch (node vectors through memory between a set's turns).
-// LEAN: every tile is a one-lane tile whose nodes have at most 2 children (grids, chains, polytrees of that
+// LEAN = k in {2, 3, 4}: every node has arity k and at most 2 children (grids, chains, polytrees of that
 // shape: the headline workload) -- an instantiation that carries no code or registers for the other shapes,
 // so its code-object figures (0 spills, tests/test_host_logic.py) are those of the path that actually runs.
-template <bool BATCH, bool LEAN>
+// LEAN = 0: every shape the resident path admits.
+template <bool BATCH, int LEAN>
 __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(ResidentArgs a) {
     __shared__ BlockShared sh;
-    __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // upper CPT halves, 16 KiB per wave
+    __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // the CPT entries not kept in registers, 18 KiB per wave
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long t_first = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // written now rather than kept in registers for the whole run
+        const unsigned long long t_first = wall_clock64();
+        for (int set = 0; set < a.n_sets; ++set) a.host_ctl[set].t_first = t_first;
+    }
+    // blocks past the tile blocks are the barrier's service blocks (one wave each)
+    const int nb = a.n_tile_blocks;
+    if (int(blockIdx.x) >= nb) {
+        if (wave == 0) resident_service(a, lane);
+        return;
+    }
     // XCD-contiguous tile mapping (speed only), as in the per-sweep kernel
-    const int nb = gridDim.x;
     const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     const int tile = lb * kResidentWaves + wave;
     bool ok;
@@ -562,16 +623,24 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
 #ifdef BN_RES_ONLY_K
             ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, BATCH, LEAN>(a, sh, td, lane, wave, lds);
 #else
-            switch (td.kv * 8 + td.m) {
-                case 2 * 8 + 0: ok = resident_dispatch<2, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 2 * 8 + 1: ok = resident_dispatch<2, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 2 * 8 + 2: ok = resident_dispatch<2, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 3 * 8 + 0: ok = resident_dispatch<3, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 3 * 8 + 1: ok = resident_dispatch<3, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 3 * 8 + 2: ok = resident_dispatch<3, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 4 * 8 + 0: ok = resident_dispatch<4, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                case 4 * 8 + 1: ok = resident_dispatch<4, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                default: ok = resident_dispatch<4, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;  // host admits only the shapes above
+            if constexpr (LEAN != 0) {
+                switch (td.m) {
+                    case 0: ok = resident_dispatch<LEAN, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                    case 1: ok = resident_dispatch<LEAN, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                    default: ok = resident_dispatch<LEAN, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                }
+            } else {
+                switch (td.kv * 8 + td.m) {
+                    case 2 * 8 + 0: ok = resident_dispatch<2, 0, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 2 * 8 + 1: ok = resident_dispatch<2, 1, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 2 * 8 + 2: ok = resident_dispatch<2, 2, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 3 * 8 + 0: ok = resident_dispatch<3, 0, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 3 * 8 + 1: ok = resident_dispatch<3, 1, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 3 * 8 + 2: ok = resident_dispatch<3, 2, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 4 * 8 + 0: ok = resident_dispatch<4, 0, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    case 4 * 8 + 1: ok = resident_dispatch<4, 1, BATCH, 0>(a, sh, td, lane, wave, lds); break;
+                    default: ok = resident_dispatch<4, 2, BATCH, 0>(a, sh, td, lane, wave, lds); break;  // host admits only the shapes above
+                }
             }
 #endif
         }
@@ -580,21 +649,26 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
         // per-set outcomes were written as the sets stopped; the launch as a whole: timing, and the abort mark
         const unsigned long long t_last = wall_clock64();
         for (int set = 0; set < a.n_sets; ++set) {
-            a.host_ctl[set].t_first = t_first;
             a.host_ctl[set].t_last = t_last;
             if (!ok) { a.host_ctl[set].run_id = a.run_id; a.host_ctl[set].done = -1; }
         }
     }
 }
 
-int launch_bp_resident(const ResidentArgs& a, int grid_blocks, bool lean, void* stream) {
+// lean_k: 2, 3 or 4 when every node has that arity and at most 2 children, else 0
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
     const dim3 g(grid_blocks), t(kResidentWaves * kWave);
     hipStream_t s = (hipStream_t)stream;
-    if (a.n_sets > 1 && lean) hipLaunchKernelGGL((bp_resident_kernel<true, true>), g, t, 0, s, a);
-    else if (a.n_sets > 1) hipLaunchKernelGGL((bp_resident_kernel<true, false>), g, t, 0, s, a);
-    else if (lean) hipLaunchKernelGGL((bp_resident_kernel<false, true>), g, t, 0, s, a);
-    else hipLaunchKernelGGL((bp_resident_kernel<false, false>), g, t, 0, s, a);
+    const bool batch = a.n_sets > 1;
+#define BN_RES_LAUNCH(B, L) hipLaunchKernelGGL((bp_resident_kernel<B, L>), g, t, 0, s, a)
+    switch (lean_k) {
+        case 2: if (batch) BN_RES_LAUNCH(true, 2); else BN_RES_LAUNCH(false, 2); break;
+        case 3: if (batch) BN_RES_LAUNCH(true, 3); else BN_RES_LAUNCH(false, 3); break;
+        case 4: if (batch) BN_RES_LAUNCH(true, 4); else BN_RES_LAUNCH(false, 4); break;
+        default: if (batch) BN_RES_LAUNCH(true, 0); else BN_RES_LAUNCH(false, 0); break;
+    }
+#undef BN_RES_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }
