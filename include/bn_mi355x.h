@@ -152,7 +152,7 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   networks of one-lane tiles (uniform arity 2..4, <= 2 parents, <= 8 children per node) that fit the chip
  *   can run the whole run in ONE launch with CPTs, references and node vectors resident in registers / LDS
  *   and a grid barrier per sweep.  0 = always one launch per sweep; 1 = that path where it was measured
- *   faster (one-block networks, networks of >= 640 tiles); 2 = wherever eligible (tests, experiments).
+ *   faster (one-block networks, networks of >= 600 tiles); 2 = wherever eligible (tests, experiments).
  *   Results are bit-identical on either path.
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);

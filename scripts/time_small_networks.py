@@ -24,7 +24,9 @@ nets = [("alarm_shaped", alarm), ("pearl", synth.pearl()), ("resume_chain", synt
         ("mixed300", synth.random_dag(300, 3, 32, [2, 3, 4, 3, 2, 5], seed=4)),
         ("mixed2k", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)),
         ("chain200", synth.grid(200, 1, 4, seed=5)), ("grid64", synth.grid(64, 64, 4, seed=1)),
-        ("grid128", synth.grid(128, 128, 4, seed=1)), ("grid316", synth.grid(316, 316, 4, seed=2)),
+        ("grid128", synth.grid(128, 128, 4, seed=1)), ("grid160", synth.grid(160, 160, 4, seed=1)),
+        ("grid200", synth.grid(200, 200, 4, seed=1)), ("grid250", synth.grid(250, 250, 4, seed=1)),
+        ("grid316", synth.grid(316, 316, 4, seed=2)),
         ("dag2p_3000", synth.random_dag(3000, 2, 64, 4, seed=3)), ("dag10k", synth.random_dag(10000, 4, 64, 4, seed=1)),
         ("dag3000", synth.random_dag(3000, 4, 64, 4, seed=5))]
 if len(sys.argv) > 1:
