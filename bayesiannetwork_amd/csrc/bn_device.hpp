@@ -89,7 +89,8 @@ constexpr int kResidentLdsSlots = 18;   // double2 slots per lane of CPT kept in
 constexpr int kResidentMaxSets = 8;     // evidence sets one launch can walk round-robin (bn_bp_run_batch)
 constexpr int kResidentBudget = 1024;   // iterations one launch may execute (size of ResidentSync::res)
 constexpr int kResidentMaxBlocks = 256;
-struct ResidentSync {                   // one per evidence set; zeroed by the host before every launch
+struct ResidentSync {                   // one per evidence set; zeroed at creation, after an aborted launch and when the
+                                        // generation counter would wrap (generations count on across launches)
     unsigned abort;                     // (set 0's) non-zero: a bounded wait gave up
     unsigned pad_[31];
     struct Group {
@@ -106,6 +107,7 @@ struct ResidentArgs {
     int32_t sweep_begin;  // first iteration of this launch
     int32_t budget;       // iterations this launch may execute (<= kResidentBudget)
     uint32_t run_id;
+    uint32_t gen_base;    // generations used by earlier launches on these sync blocks (< 2^29)
     unsigned long long timeout_ticks;  // bound of one barrier wait, 100 MHz ticks
     ResidentSync* sync;   // [n_sets]
     Ctl* host_ctl;        // [n_sets], pinned

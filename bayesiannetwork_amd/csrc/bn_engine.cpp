@@ -136,6 +136,8 @@ struct bn_engine {
     int resident_lean = 0;          // ... and every node has this arity (2, 3 or 4) and <= 2 children; else 0
     int grid_resident = 0;
     ResidentSync* d_rsync = nullptr;
+    bool rsync_dirty = true;        // the sync block must be zeroed before the next launch
+    uint32_t gen_base = 0;          // barrier generations used so far on d_rsync
     // several evidence sets per launch (bn_bp_*_batch): per-set records, node vectors, marks, beliefs, histories
     struct Batch {
         int32_t n_sets = 0, cap_sets = 0;
@@ -145,6 +147,8 @@ struct bn_engine {
         double* d_beliefs = nullptr;
         double* d_res_hist = nullptr;
         ResidentSync* d_sync = nullptr;
+        bool sync_dirty = true;
+        uint32_t gen_base = 0;
         Ctl* h_ctl = nullptr;       // pinned, [cap_sets]
         Ctl* h_ctl_dev = nullptr;
         char* d_ev = nullptr;       // staging of every set's evidence
@@ -546,8 +550,14 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     float ms = 0.f;
     double dev_ticks = 0.0;
     for (;;) {
-        HIPCHK(hipMemsetAsync(e->d_rsync, 0, sizeof(ResidentSync), s));  // every polled word, before every launch
-        ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id,
+        // polled words: generations count on from launch to launch, so they are zeroed only at creation, after an
+        // aborted launch and before the 30-bit generation would wrap
+        if (e->rsync_dirty || e->gen_base > (1u << 29)) {
+            HIPCHK(hipMemsetAsync(e->d_rsync, 0, sizeof(ResidentSync), s));
+            e->rsync_dirty = false;
+            e->gen_base = 0;
+        }
+        ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id, e->gen_base,
                        5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev,
                        e->grid_resident, 1, 1u, 0, 0, 0, 0, 0};
         if (e->timing) {
@@ -560,6 +570,8 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
         HIPCHK(hipStreamSynchronize(s));
         ++launches;
+        e->gen_base += kResidentBudget + 1;
+        if (e->h_ctl->run_id != e->run_id || e->h_ctl->done < 0) e->rsync_dirty = true;
         if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
         if (e->h_ctl->done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
         if (e->timing) {
@@ -790,8 +802,12 @@ static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     double dev_ticks = 0.0;
     float ms = 0.f;
     for (;;) {
-        HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(bt.n_sets), s));
-        ResidentArgs a{batch_buffers_of(e, 0), eps, max_sweeps, begin, kResidentBudget, e->run_id, 5000000ull, bt.d_sync,
+        if (bt.sync_dirty || bt.gen_base > (1u << 29)) {
+            HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(bt.cap_sets), s));
+            bt.sync_dirty = false;
+            bt.gen_base = 0;
+        }
+        ResidentArgs a{batch_buffers_of(e, 0), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
                        bt.h_ctl_dev, e->grid_resident, bt.n_sets, mask, p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)),
                        p.node_off[p.n], e->res_cap};
         if (e->timing) {
@@ -809,10 +825,12 @@ static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
             HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
             ms += t;
         }
+        bt.gen_base += kResidentBudget + 1;
         uint32_t next = 0;
         for (int32_t q = 0; q < bt.n_sets; ++q) {
             if (!((mask >> q) & 1u)) continue;
             const Ctl& c = bt.h_ctl[q];
+            if (c.run_id != e->run_id || c.done < 0) bt.sync_dirty = true;
             if (c.run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
             if (c.done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
             bt.sweeps[q] = c.n_sweeps;

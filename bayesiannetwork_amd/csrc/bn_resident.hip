@@ -90,7 +90,9 @@ __device__ __forceinline__ int verdict_of(const ResidentArgs& a, double r, int n
 // sweeps the granules of every tile block until all carry the generation, reduces the residual, decides
 // (converged / capped / go on), records the residual and publishes generation + verdict in one word per
 // group of tile blocks (blockIdx % 8: spreads the pollers), which the tile blocks poll when they next need
-// that set.  Round trips on the path from the last tile block's arrival to the verdict: granule store ->
+// that set.  Generations count on from launch to launch (gen_base), so nothing has to be zeroed between
+// launches: a stale granule or word always carries a smaller generation.
+// Round trips on the path from the last tile block's arrival to the verdict: granule store ->
 // sweep -> verdict store -> tile blocks' poll; none of them on a
 // tile block.  With several sets in flight the whole of it runs behind the other sets' sweeps.
 // (A two-level collection -- one service block per group, then a top block -- was measured ~0.3 us slower per
@@ -113,7 +115,7 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
             sy->res[it] = m;
             sh.verdict[set] = verdict_of(a, residual_of(m), s + 1);
         } else {
-            const unsigned gen = unsigned(it) + 1u;
+            const unsigned gen = a.gen_base + unsigned(it) + 1u;
             __hip_atomic_store(&sy->blk[blockIdx.x][0], granule(gen, unsigned(m >> 32)), RLX_AGENT);
             __hip_atomic_store(&sy->blk[blockIdx.x][1], granule(gen, unsigned(m)), RLX_AGENT);
         }
@@ -139,7 +141,7 @@ __device__ __forceinline__ bool poll_until(const ResidentArgs& a, Pred&& pred) {
 __device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& sh, int set, int it) {
     if (threadIdx.x == 0 && a.n_tile_blocks > 1) {
         ResidentSync* sy = a.sync + set;
-        const unsigned gen = unsigned(it) + 1u;
+        const unsigned gen = a.gen_base + unsigned(it) + 1u;
         const int groups = a.n_tile_blocks < 8 ? a.n_tile_blocks : 8;
         const int g = blockIdx.x % groups;
         unsigned word = 0;
@@ -162,7 +164,7 @@ __device__ __forceinline__ void resident_service(const ResidentArgs& a, int lane
     const int groups = nb < 8 ? nb : 8;
     unsigned active = a.set_mask;
     for (int it = 0; it < a.budget; ++it) {
-        const unsigned gen = unsigned(it) + 1u;
+        const unsigned gen = a.gen_base + unsigned(it) + 1u;
         for (int set = 0; set < a.n_sets; ++set) {
             if (((active >> set) & 1u) == 0) continue;
             ResidentSync* sy = a.sync + set;
