@@ -13,22 +13,22 @@
 // Between iterations stands ONE grid barrier (the Jacobi schedule needs nothing finer):
 //   producer  message stores are 16-byte WRITE-THROUGH (sc1) stores; every wave drains them
 //             (s_waitcnt vmcnt(0)), __syncthreads(), then lane 0 of the block arrives;
-//   barrier   hierarchical and atomic-free: a tile block publishes a pair of 8-byte {generation, residual half}
-//             granules and goes on; SERVICE blocks (extra blocks of the launch on CUs the tiles leave free)
-//             collect them per group (blockIdx % 8: sharding only) and then over the groups, decide, and
-//             publish generation + verdict in one word per group, which the tile blocks poll (relaxed
-//             agent-scope loads + s_sleep).  Loads of the records are sc1, so no acquire fence is needed.
-//             (cdna_hip_programming.md Guideline 16 R2 / MI355X_MICROARCH.md barrier-xcd, handoff-1to1.)
-//             Nothing depends on dispatch order or on which XCD a block runs.
-//   residual  max|new - old| (:105-131) travels in the granules; the top service block takes the stop
-//             decision (:147) and every block reads the same verdict.
+//   barrier   atomic-free: a tile block publishes a pair of 8-byte {generation, residual half} granules and
+//             goes on; ONE SERVICE block (an extra block of the launch on a CU the tiles leave free) sweeps the
+//             granules of all tile blocks, reduces the residual, decides, and publishes generation + verdict
+//             in one word per group of tile blocks (blockIdx % 8: spreads the pollers), which the tile blocks
+//             poll (relaxed agent-scope loads + s_sleep).  Loads of the records are sc1, so no acquire fence
+//             is needed.  (cdna_hip_programming.md Guideline 16 R2 / MI355X_MICROARCH.md barrier-xcd,
+//             handoff-1to1.)  Nothing depends on dispatch order or on which XCD a block runs.
+//   residual  max|new - old| (:105-131) travels in the granules; the service block takes the stop decision
+//             (:147) and every block reads the same verdict.
 // A one-block grid (<= 8 tiles: Pearl's network, small chains) needs no atomics at all: LDS slots and
 // __syncthreads().
 //
 // SEVERAL EVIDENCE SETS PER LAUNCH (bn_bp_run_batch).  The CPT image, the references and the layout are the
 // same for every query on a network; only messages, node vectors and evidence marks are per query.  The
 // kernel walks B sets round-robin -- sweep s of set A, arrive at A's barrier, sweep s of set B, arrive at B's,
-// wait for A's barrier, sweep s+1 of A, ... -- so the ~4.5 us a barrier takes to complete are spent computing
+// wait for A's barrier, sweep s+1 of A, ... -- so the ~3.5 us a barrier takes to complete are spent computing
 // the other sets instead of waiting, and one resident CPT serves all of them.  Every set has its own
 // record / node buffers, barrier words, residuals and verdict, and leaves the rotation on the sweep ITS
 // reference run would stop on; node vectors of a set go through memory between its turns (no registers left
@@ -69,7 +69,7 @@ struct BlockShared {
 };
 enum : int { kGoOn = 0, kConverged = 1, kCapped = 2, kAbort = 3 };
 
-// maximum_difference (:105) from the bit pattern accumulated by the atomic max
+// maximum_difference (:105) from its bit pattern (non-negative doubles order like unsigned integers)
 __device__ __forceinline__ double residual_of(unsigned long long bits) {
     const double r = __longlong_as_double((long long)bits);
     return r < DBL_MIN ? DBL_MIN : r;  // it starts at numeric_limits<double>::min()
@@ -84,7 +84,7 @@ __device__ __forceinline__ int verdict_of(const ResidentArgs& a, double r, int n
 // The tile blocks never wait inside an arrival and never execute a returning atomic.  A block that has
 // finished a sweep of a set publishes ONE pair of 8-byte granules {generation | half of its residual's bit
 // pattern} (cdna_hip_programming.md Guideline 16, form R2: the data is the flag, one aligned 8-byte sc1
-// store each, nothing to order).  The granules are collected by SERVICE blocks: extra blocks of the same
+// store each, nothing to order).
 // The granules are collected by a SERVICE block: one extra block of the same launch that carries no tile and
 // sits on a CU the tiles leave free (the host admits the path only when tile blocks + 1 fit the chip): it
 // sweeps the granules of every tile block until all carry the generation, reduces the residual, decides
