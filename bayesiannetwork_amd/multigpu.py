@@ -20,6 +20,8 @@ def init_control_plane(backend: str = "gloo"):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")        # a lone process (BN_FORCE_MULTI, tests) is a 1-rank world
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
     return dist
 
@@ -124,6 +126,23 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
                                    "avg_sweep_plus_exchange_us": kw * 1e3 / max(lw, 1),
                                    "sweeps_per_step": sw / max(a.steps // 2, 3)}
         engw.close()
+    # the other way to use N GPUs on a network that fits one: every GPU holds the whole network and answers
+    # its own queries (a different evidence set per rank); no exchange, no collective.  Reported beside the
+    # edge-cut figure, never as `value` (BASELINE.json configs[3] is the partitioned grid).
+    if not getattr(a, "no_replicas", False):
+        evr = synth.random_evidence(g, a.evidence, seed=7 + rank)
+        with Engine(g, device=local_rank) as er:
+            er.bp_set_evidence(evr)
+            dtr, sr, _, _ = _timed_runs(er, a.eps, a.steps, a.warmup, dist, torch)
+            rpath = er.last_path()
+        tot = torch.tensor([float(sr)], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            out["replicated_queries"] = {
+                "workload": f"{world} independent queries at a time: the whole {a.rows}x{a.cols} grid on every GPU, "
+                            f"a different evidence set per rank, no collective",
+                "value": g.messages_per_sweep() * float(tot[0]) / dtr, "unit": "edge-messages/s",
+                "ms_per_query": dtr / a.steps * 1e3, "path": "resident tiles, one launch per run" if rpath == 2 else "one launch per sweep"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.barrier()

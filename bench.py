@@ -341,6 +341,7 @@ def main():
     ap.add_argument("--no-extras", dest="no_extras", action="store_true",
                     help="headline only: skip the config2_dag / config5_lw / grid2048 / host-to-host extras")
     ap.add_argument("--no-weak", dest="no_weak", action="store_true", help="N>1: skip the weak-scaling extra")
+    ap.add_argument("--no-replicas", dest="no_replicas", action="store_true", help="N>1: skip the replicated-queries extra")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

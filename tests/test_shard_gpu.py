@@ -113,3 +113,25 @@ def test_rccl_single_rank_communicator(eng, monkeypatch):
         r = e.bp_run(None, 1e-6)
         assert e.last_path() == 0
         assert r["sweeps"] == want["sweeps"] and np.array_equal(r["beliefs"], want["beliefs"])
+
+
+def test_bench_multi_gpu_code_path_on_one_rank():
+    """bench.py's N > 1 branch (shard engine, RCCL communicator, control plane, weak-scaling and
+    replicated-queries extras) run end to end as a 1-rank world: the only way to execute that code
+    on a one-GPU box.  A child process: the bench initialises torch.distributed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BN_FORCE_MULTI="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--rows", "48", "--cols", "48"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "edge-messages/s"
+    assert line["weak_scaling"]["value"] > 0
+    assert line["replicated_queries"]["value"] > 0
+    for k in ("metric", "steps", "warmup", "ms_per_step", "scaling", "roofline", "config"):
+        assert k in line
