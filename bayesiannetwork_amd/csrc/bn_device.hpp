@@ -52,6 +52,22 @@ struct BpBuffers {
     double* beliefs;
 };
 
+// Several evidence sets in one launch of the per-sweep kernels (bn_bp_run_batch on networks the resident
+// kernel does not cover): blockIdx.y = evidence set; set q's records, node vectors, marks, beliefs,
+// residual history and control block follow set 0's at these strides (elements of the respective array).
+struct SetStrides {
+    int64_t rec, node, slot, belief;
+    int32_t res_hist;
+};
+__host__ __device__ inline void shift_to_set(BpBuffers& b, const SetStrides& st, int set) {
+    b.rec0 += set * st.rec; b.rec1 += set * st.rec;
+    b.node0 += set * st.node; b.node1 += set * st.node;
+    b.frozen += set * st.slot;
+    b.beliefs += set * st.belief;
+    b.res_hist += int64_t(set) * st.res_hist;
+    b.ctl += set;
+}
+
 struct SweepArgs {
     BpBuffers b;
     const double* rec_in;   // buffer (sweep & 1): the state this iteration reads
@@ -64,6 +80,7 @@ struct SweepArgs {
     int32_t tile_end;
     int32_t book;        // ... and, if set, the residual bookkeeping (done by the first wave past tile_end)
     uint32_t run_id;
+    SetStrides sets;     // batched launches only (gridDim.y = number of evidence sets)
 };
 
 struct FinishArgs {
@@ -73,6 +90,7 @@ struct FinishArgs {
     int32_t final_batch;  // 1: max_sweeps reached with this batch -> stop even if not converged
     uint32_t run_id;
     Ctl* host_ctl;        // pinned host copy of Ctl, written by the kernel itself (no D2H copy command)
+    SetStrides sets;      // gridDim.y > 1: one evidence set per y (host_ctl is an array then)
 };
 
 struct EvidenceArgs {
@@ -86,7 +104,8 @@ struct EvidenceArgs {
 // The whole run in one launch with every tile resident in registers (bn_resident.hip).
 constexpr int kResidentWaves = 8;       // 512 threads per block, one tile per wave, <= 256 VGPRs
 constexpr int kResidentLdsSlots = 18;   // double2 slots per lane of CPT kept in LDS (36 of the 64 entries of a k = 4, two-parent table)
-constexpr int kResidentMaxSets = 8;     // evidence sets one launch can walk round-robin (bn_bp_run_batch)
+constexpr int kResidentMaxSets = 4;     // evidence sets one launch walks round-robin (bn_bp_run_batch); measured on the 316x316 grid:
+                                        // 9.3 / 9.0 / 11.3 us per set-sweep with 2 / 4 / 8 sets per launch
 constexpr int kResidentBudget = 1024;   // iterations one launch may execute (size of ResidentSync::res)
 constexpr int kResidentMaxBlocks = 256;
 struct ResidentSync {                   // one per evidence set; zeroed at creation, after an aborted launch and when the
@@ -124,11 +143,12 @@ int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void*
 // launchers (bn_kernels.hip)
 int launch_bp_evidence(const EvidenceArgs& a, void* stream);  // bn_bp_set_evidence: marks + vectors
 int launch_bp_reset(const BpBuffers& b, void* stream);         // residual slots; after an abnormal end only
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, int variants, void* stream);
+// n_sets > 1: the batched instantiation, one evidence set per blockIdx.y (a.sets valid)
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, int n_sets, bool nontemporal, bool light, int variants, void* stream);
 // per-variant-set instantiations (bn_sweep_*.hip)
-int launch_bp_sweep_u(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream);
-int launch_bp_sweep_ug(const SweepArgs& a, int grid_blocks, bool nontemporal, void* stream);
-int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, void* stream);
-int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream);
+int launch_bp_sweep_u(const SweepArgs& a, int grid_blocks, int n_sets, bool nontemporal, void* stream);
+int launch_bp_sweep_ug(const SweepArgs& a, int grid_blocks, int n_sets, bool nontemporal, void* stream);
+int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, int n_sets, void* stream);
+int launch_bp_finish(const FinishArgs& a, int grid_blocks, int n_sets, void* stream);
 
 }  // namespace bnmi

@@ -146,9 +146,12 @@ struct bn_engine {
         uint8_t* d_frozen = nullptr;
         double* d_beliefs = nullptr;
         double* d_res_hist = nullptr;
-        ResidentSync* d_sync = nullptr;
+        ResidentSync* d_sync = nullptr;  // resident path: [min(cap_sets, kResidentMaxSets)]
         bool sync_dirty = true;
         uint32_t gen_base = 0;
+        Ctl* d_ctl = nullptr;       // per-sweep launches: one control block per set
+        bool rows_clean = true;     // ... and every set's residual slots are zero
+        int32_t predicted_sweeps = 0;
         Ctl* h_ctl = nullptr;       // pinned, [cap_sets]
         Ctl* h_ctl_dev = nullptr;
         char* d_ev = nullptr;       // staging of every set's evidence
@@ -190,7 +193,7 @@ static void free_engine(bn_engine* e) {
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
-                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev};
+                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -476,11 +479,11 @@ static int step_sweep(bn_engine* e, int32_t sweep, double eps, int part = 0) {
     const int32_t book = part == 1 ? 0 : 1;
     if (t1 - t0 + book <= 0) return BN_OK;
     SweepArgs sa{buffers_of(e), e->d_rec[cur], e->d_rec[cur ^ 1], e->d_node[cur], e->d_node[cur ^ 1], eps, sweep,
-                 t0, t1, book, e->run_id};
+                 t0, t1, book, e->run_id, SetStrides{}};
     // one wave per tile (+ one for the bookkeeping), blocks padded to a multiple of 8 for the XCD mapping
     const int grid = ((t1 - t0 + book + kWavesPerBlock - 1) / kWavesPerBlock + 7) & ~7;
     static const bool no_light = std::getenv("BN_NO_LIGHT") != nullptr;  // A/B switch
-    if (launch_bp_sweep(sa, grid, e->nontemporal, e->plan.light && !no_light, e->plan.variants, e->stream))
+    if (launch_bp_sweep(sa, grid, 1, e->nontemporal, e->plan.light && !no_light, e->plan.variants, e->stream))
         return fail(BN_ERR_HIP, "bp_sweep launch failed");
     return BN_OK;
 }
@@ -520,8 +523,8 @@ static int step_sweep_overlapped(bn_engine* e, int32_t sweep, double eps, bool g
 static int step_finish(bn_engine* e, int32_t launched, bool final_batch, double eps) {
     // wave 0 writes the outcome straight into the pinned host Ctl: visible after the stream
     // synchronises, no copy command in between
-    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->run_id, e->h_ctl_dev};
-    if (launch_bp_finish(fa, e->grid_tiles, e->stream)) return fail(BN_ERR_HIP, "bp_finish launch failed");
+    FinishArgs fa{buffers_of(e), eps, launched, final_batch ? 1 : 0, e->run_id, e->h_ctl_dev, SetStrides{}};
+    if (launch_bp_finish(fa, e->grid_tiles, 1, e->stream)) return fail(BN_ERR_HIP, "bp_finish launch failed");
     return BN_OK;
 }
 
@@ -692,7 +695,7 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     if (n_sets <= bt.cap_sets) return BN_OK;
     const Plan& p = e->plan;
     HIPCHK(hipStreamSynchronize(e->stream));
-    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync};
+    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl};
     for (void* q : old)
         if (q) (void)hipFree(q);
     if (bt.h_ctl) (void)hipHostFree(bt.h_ctl);
@@ -708,7 +711,9 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     if ((r = dalloc(&bt.d_frozen, B * size_t(std::max(p.n_slots, 1))))) return r;
     if ((r = dalloc(&bt.d_beliefs, B * size_t(p.node_off[p.n])))) return r;
     if ((r = dalloc(&bt.d_res_hist, B * size_t(e->res_cap)))) return r;
-    if ((r = dalloc(&bt.d_sync, B))) return r;
+    if ((r = dalloc(&bt.d_sync, std::min<size_t>(B, kResidentMaxSets)))) return r;
+    if ((r = dalloc(&bt.d_ctl, B))) return r;
+    HIPCHK(hipMemsetAsync(bt.d_ctl, 0, sizeof(Ctl) * B, e->stream));  // done_run = 0: no run is marked done
     HIPCHK(hipMemsetAsync(bt.d_frozen, 0, B * size_t(std::max(p.n_slots, 1)), e->stream));
     HIPCHK(hipMemsetAsync(bt.d_beliefs, 0, std::max<size_t>(B * p.node_off[p.n], 1) * 8, e->stream));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bt.h_ctl), sizeof(Ctl) * B, hipHostMallocMapped));
@@ -731,6 +736,7 @@ static BpBuffers batch_buffers_of(bn_engine* e, int32_t q) {
     b.frozen = bt.d_frozen + size_t(q) * std::max(p.n_slots, 1);
     b.beliefs = bt.d_beliefs + size_t(q) * p.node_off[p.n];
     b.res_hist = bt.d_res_hist + size_t(q) * e->res_cap;
+    b.ctl = bt.d_ctl + q;
     return b;
 }
 
@@ -738,7 +744,7 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
                                         const int32_t* ev_off, const double* ev_val) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
-    if (n_sets < 1 || n_sets > kResidentMaxSets) return fail(BN_ERR_ARG, "n_sets must be in 1.." + std::to_string(kResidentMaxSets));
+    if (n_sets < 1 || n_sets > BN_MAX_BATCH_SETS) return fail(BN_ERR_ARG, "n_sets must be in 1.." + std::to_string(BN_MAX_BATCH_SETS));
     if (e->plan.nranks > 1) return fail(BN_ERR_STATE, "batched evidence sets are not available on sharded engines");
     if (!ne) return fail(BN_ERR_ARG, "null ne");
     const Plan& p = e->plan;
@@ -790,26 +796,23 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     return BN_OK;
 }
 
-// every set through the resident kernel, round-robin in one launch
-static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
+// sets [first, first + count) through the resident kernel, round-robin in one launch (count <= kResidentMaxSets)
+static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps, int32_t first, int32_t count, int32_t& launches,
+                                    float& ms, double& dev_ticks) {
     bn_engine::Batch& bt = e->batch;
     const Plan& p = e->plan;
     hipStream_t s = e->stream;
-    ++e->run_id;
-    if (e->run_id == 0) e->run_id = 1;
-    int32_t begin = 0, launches = 0;
-    uint32_t mask = bt.n_sets >= 32 ? ~0u : ((1u << bt.n_sets) - 1u);
-    double dev_ticks = 0.0;
-    float ms = 0.f;
+    int32_t begin = 0;
+    uint32_t mask = (1u << count) - 1u;
     for (;;) {
         if (bt.sync_dirty || bt.gen_base > (1u << 29)) {
-            HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(bt.cap_sets), s));
+            HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(std::min(bt.cap_sets, kResidentMaxSets)), s));
             bt.sync_dirty = false;
             bt.gen_base = 0;
         }
-        ResidentArgs a{batch_buffers_of(e, 0), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
-                       bt.h_ctl_dev, e->grid_resident, bt.n_sets, mask, p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)),
-                       p.node_off[p.n], e->res_cap};
+        ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
+                       bt.h_ctl_dev + first, e->grid_resident, count, mask, p.rec_total_doubles, p.node_doubles,
+                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -827,26 +830,106 @@ static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
         }
         bt.gen_base += kResidentBudget + 1;
         uint32_t next = 0;
-        for (int32_t q = 0; q < bt.n_sets; ++q) {
+        for (int32_t q = 0; q < count; ++q) {
             if (!((mask >> q) & 1u)) continue;
-            const Ctl& c = bt.h_ctl[q];
+            const Ctl& c = bt.h_ctl[first + q];
             if (c.run_id != e->run_id || c.done < 0) bt.sync_dirty = true;
             if (c.run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
             if (c.done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
-            bt.sweeps[q] = c.n_sweeps;
-            bt.residual[q] = c.last_res;
+            bt.sweeps[first + q] = c.n_sweeps;
+            bt.residual[first + q] = c.last_res;
             if (c.done == 0) next |= 1u << q;
         }
-        dev_ticks += double(bt.h_ctl[0].t_last - bt.h_ctl[0].t_first);
+        dev_ticks += double(bt.h_ctl[first].t_last - bt.h_ctl[first].t_first);
         if (next == 0) break;
         mask = next;
         begin += kResidentBudget;
+    }
+    return BN_OK;
+}
+
+// every set through the resident kernel: up to kResidentMaxSets per launch, further sets in further launches
+static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
+    bn_engine::Batch& bt = e->batch;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    int32_t launches = 0;
+    double dev_ticks = 0.0;
+    float ms = 0.f;
+    const int32_t chunks = (bt.n_sets + kResidentMaxSets - 1) / kResidentMaxSets;
+    for (int32_t c = 0, first = 0; c < chunks; ++c) {
+        const int32_t count = (bt.n_sets - first + (chunks - c) - 1) / (chunks - c);  // balanced chunk sizes
+        int rc = run_batch_resident_chunk(e, eps, max_sweeps, first, count, launches, ms, dev_ticks);
+        if (rc) return rc;
+        first += count;
     }
     e->last_path = 2;
     e->stats.sweep_launches = launches;
     e->stats.sweep_kernel_ms = ms;
     e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
     e->stats.sweeps = *std::max_element(bt.sweeps.begin(), bt.sweeps.end());
+    return BN_OK;
+}
+
+// Every set in each per-sweep launch (blockIdx.y = evidence set): any tile variants.  The sets share the launch
+// and its latency -- what a small or latency-bound network pays for -- and the CPT lines in the caches; each keeps
+// its own records, node vectors, marks, residual slots and done mark, so it stops on the sweep its single run
+// stops on (a converged set's blocks return at once in the launches the others still need).
+static int run_batch_launches(bn_engine* e, double eps, int32_t max_sweeps) {
+    bn_engine::Batch& bt = e->batch;
+    const Plan& p = e->plan;
+    hipStream_t s = e->stream;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    const int32_t B = bt.n_sets;
+    if (!bt.rows_clean) {  // an earlier batched run did not end through its finish kernel
+        for (int32_t q = 0; q < bt.cap_sets; ++q)
+            if (int code = launch_bp_reset(batch_buffers_of(e, q), s))
+                return fail(BN_ERR_HIP, std::string("bp_reset launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
+    bt.rows_clean = false;
+    const SetStrides st{p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap};
+    const BpBuffers b0 = batch_buffers_of(e, 0);
+    const int32_t nt = int32_t(p.tiles.size());
+    const int grid = ((nt + 1 + kWavesPerBlock - 1) / kWavesPerBlock + 7) & ~7;
+    static const bool no_light = std::getenv("BN_NO_LIGHT") != nullptr;
+    int32_t launched = 0;
+    int32_t batch = bt.predicted_sweeps > 0 ? bt.predicted_sweeps : (e->predicted_sweeps > 0 ? e->predicted_sweeps : 8);
+    for (;;) {
+        if (max_sweeps > 0) batch = std::min(batch, max_sweeps - launched);
+        for (int32_t i = 0; i < batch; ++i) {
+            const int32_t sweep = launched + i;
+            const int cur = sweep & 1;
+            SweepArgs sa{b0, bt.d_rec[cur], bt.d_rec[cur ^ 1], bt.d_node[cur], bt.d_node[cur ^ 1], eps, sweep, 0, nt, 1, e->run_id, st};
+            // B == 1 runs the plain instantiation on set 0's buffers
+            if (launch_bp_sweep(sa, grid, B, false, p.light && !no_light, p.variants, s)) return fail(BN_ERR_HIP, "bp_sweep launch failed");
+        }
+        launched += batch;
+        FinishArgs fa{b0, eps, launched, (max_sweeps > 0 && launched >= max_sweeps) ? 1 : 0, e->run_id, bt.h_ctl_dev, st};
+        if (launch_bp_finish(fa, e->grid_tiles, B, s)) return fail(BN_ERR_HIP, "bp_finish launch failed");
+        HIPCHK(hipStreamSynchronize(s));
+        bool all_done = true;
+        for (int32_t q = 0; q < B; ++q) {
+            if (bt.h_ctl[q].run_id != e->run_id) return fail(BN_ERR_STATE, "finish kernel did not report (stale control block)");
+            if (bt.h_ctl[q].done == 0) all_done = false;
+        }
+        if (all_done) break;
+        batch = 8;
+    }
+    bt.rows_clean = true;  // every set's run ended in a finish kernel that saw it over
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int32_t q = 0; q < B; ++q) {
+        bt.sweeps[q] = bt.h_ctl[q].n_sweeps;
+        bt.residual[q] = bt.h_ctl[q].last_res;
+        t0 = std::min(t0, bt.h_ctl[q].t_first);
+        t1 = std::max(t1, bt.h_ctl[q].t_last);
+    }
+    bt.predicted_sweeps = *std::max_element(bt.sweeps.begin(), bt.sweeps.end());
+    e->last_path = 0;
+    e->stats.sweep_launches = launched;
+    e->stats.sweep_kernel_ms = 0.f;
+    e->stats.sweep_devclock_ms = t1 > t0 ? float(double(t1 - t0) * 1e-5) : 0.f;
+    e->stats.sweeps = bt.predicted_sweeps;
     return BN_OK;
 }
 
@@ -858,39 +941,38 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     if (bt.n_sets < 1) return fail(BN_ERR_STATE, "call bn_bp_set_evidence_batch first");
     const auto t_begin = std::chrono::steady_clock::now();
     ON_DEVICE(e);
-    const Plan& p = e->plan;
     bt.sweeps.assign(bt.n_sets, 0);
     bt.residual.assign(bt.n_sets, 0.0);
     int rc = BN_ERR_STATE;
-    if (e->resident_ok && e->multisweep != 0) {
+    bool aborted = false;
+    // Which way a batch goes (measured, scripts/time_batch.py, us per set-sweep at the best batch size of either path):
+    // per-sweep launches with one set per blockIdx.y share the launch latency among the sets, which is what networks
+    // up to ~900 tiles pay for (128x128 grid: 1.8 vs 7.7 resident, 200x200: 5.0 vs 8.0); on larger ones the CPT
+    // traffic the resident kernel saves weighs more (250x250: 9.1 vs 8.2, 316x316: 14.6 vs 8.6).
+    // "multisweep" = 2 forces the resident kernel wherever eligible, 0 the launches.
+    constexpr int64_t kResidentBatchMinTiles = 900;
+    const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
+    if (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays))) {
         rc = run_batch_resident(e, eps, max_sweeps);
         if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
         if (rc == BN_ERR_STATE) {
             if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] resident path disabled: %s\n", g_err.c_str());
             e->resident_ok = false;
-            // the aborted launch may have left marks / vectors half-written: apply the evidence again below
+            aborted = true;
         }
     }
     if (rc != BN_OK) {
-        // one set after another through the single-query path; results land in the batch arrays
-        const size_t nbel = size_t(p.node_off[p.n]);
-        int64_t node_at = 0, off_at = 0, val_at = 0;
-        for (int32_t q = 0; q < bt.n_sets; ++q) {
-            const int32_t neq = bt.ne[q];
-            rc = bn_bp_set_evidence(e, neq, bt.ev_node.data() + node_at, bt.ev_off.data() + off_at, bt.ev_val.data() + val_at);
+        if (aborted) {
+            // marks / vectors possibly half-written by the aborted launch: apply every set's evidence again
+            std::vector<int32_t> ne = bt.ne, ev_node = bt.ev_node, ev_off = bt.ev_off;
+            std::vector<double> ev_val = bt.ev_val;
+            rc = bn_bp_set_evidence_batch(e, int32_t(ne.size()), ne.data(), ev_node.data(), ev_off.data(), ev_val.data());
             if (rc) return rc;
-            rc = bn_bp_run_device(e, eps, max_sweeps, &bt.sweeps[q], &bt.residual[q]);
-            if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(bt.d_beliefs + size_t(q) * nbel, e->d_beliefs, nbel * 8, hipMemcpyDeviceToDevice, e->stream));
-            const int32_t cnt = std::min(bt.sweeps[q], e->res_cap);
-            if (cnt > 0)
-                HIPCHK(hipMemcpyAsync(bt.d_res_hist + size_t(q) * e->res_cap, e->d_res_hist, size_t(cnt) * 8,
-                                      hipMemcpyDeviceToDevice, e->stream));
-            val_at += neq > 0 ? bt.ev_off[off_at + neq] : 0;
-            node_at += neq;
-            off_at += neq + 1;
+            bt.sweeps.assign(bt.n_sets, 0);
+            bt.residual.assign(bt.n_sets, 0.0);
         }
-        HIPCHK(hipStreamSynchronize(e->stream));
+        rc = run_batch_launches(e, eps, max_sweeps);
+        if (rc) return rc;
     }
     bt.have_run = true;
     e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

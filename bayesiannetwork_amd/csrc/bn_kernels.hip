@@ -22,7 +22,9 @@ namespace bnmi {
 // The same iteration for networks WITHOUT register-resident tiles (any-arity and one-lane tiles
 // only): those tiles need a third of the registers and are latency-bound, so this instantiation
 // runs at twice the occupancy (4 waves per SIMD).
-__global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepArgs a) {
+template <bool BATCH>
+__global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepArgs a_in) {
+    const SweepArgs a = BATCH ? sweep_args_of_set(a_in) : a_in;
     __shared__ double flat_lds[kWavesPerBlock][kFlatLds];
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
@@ -80,25 +82,38 @@ __global__ __launch_bounds__(kBlockThreads) void bp_reset_kernel(BpBuffers b) {
 // (:151-158) for its tile's nodes from the buffer the last executed sweep wrote; when the host has to
 // go on (predicted sweep count too low) those beliefs are simply overwritten by the next finish.
 __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) {
-    const BpBuffers& b = a.b;
+    BpBuffers b = a.b;
+    Ctl* host_ctl = a.host_ctl;
+    if (gridDim.y > 1) {  // batched run: one evidence set per y
+        shift_to_set(b, a.sets, blockIdx.y);
+        host_ctl += blockIdx.y;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    // marked by a sweep launch = a previous kernel: every block sees the same value
-    const bool marked = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
+    // marked by a sweep launch = a previous kernel, or by wave 0 of this one (below, after it has written the
+    // fields read here: acquire pairs with its release)
+    const bool marked = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
     const int n_sweeps = marked ? b.ctl->n_sweeps : a.sweeps_launched;
     if (blockIdx.x == 0 && wave == 0) {
         int done = 1;
         double r = marked ? b.ctl->last_res : 0.0;
         unsigned long long t_last = marked ? b.ctl->t_last : wall_clock64();
+        if (marked && !(r < a.eps)) done = 2;  // marked by an earlier finish of this run that stopped it at max_sweeps
         if (!marked) {  // sweep (launched-1) wrote buffer (launched & 1)
             r = reduce_residual(b, (a.sweeps_launched & 1) ? b.rec1 : b.rec0, lane);
             if (lane == 0 && a.sweeps_launched - 1 < b.res_cap) b.res_hist[a.sweeps_launched - 1] = r;
             done = (r < a.eps) ? 1 : (a.final_batch ? 2 : 0);
         }
         if (lane == 0) {
-            a.host_ctl->last_res = r; a.host_ctl->n_sweeps = n_sweeps;
-            a.host_ctl->t_first = b.ctl->t_first; a.host_ctl->t_last = t_last;
-            a.host_ctl->run_id = a.run_id; a.host_ctl->done = done;
+            host_ctl->last_res = r; host_ctl->n_sweeps = n_sweeps;
+            host_ctl->t_first = b.ctl->t_first; host_ctl->t_last = t_last;
+            host_ctl->run_id = a.run_id; host_ctl->done = done;
+            if (!marked && done != 0) {
+                // the run ends here: mark it on the device too, so that launches a batched run still issues for
+                // its other evidence sets leave this one alone
+                b.ctl->n_sweeps = n_sweeps; b.ctl->last_res = r; b.ctl->t_last = t_last;
+                __hip_atomic_store(&b.ctl->done_run, a.run_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (done != 0) {
             unsigned long long* r0 = res_row(b, b.rec0, b.rank);
@@ -130,19 +145,22 @@ int launch_bp_reset(const BpBuffers& b, void* stream) {
     return hip_rc(hipGetLastError());
 }
 // variants: bit v set = the plan has tiles of variant v (bn_plan.hpp); light: any-arity / one-lane tiles only
-int launch_bp_sweep(const SweepArgs& a, int grid_blocks, bool nontemporal, bool light, int variants, void* stream) {
+int launch_bp_sweep(const SweepArgs& a, int grid_blocks, int n_sets, bool nontemporal, bool light, int variants, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
     if (light) {
-        hipLaunchKernelGGL(bp_sweep_light_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+        if (n_sets > 1)
+            hipLaunchKernelGGL(bp_sweep_light_kernel<true>, dim3(grid_blocks, n_sets), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(bp_sweep_light_kernel<false>, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
         return hip_rc(hipGetLastError());
     }
-    if (variants & ((1 << kVariantFlat) | (1 << kVariantGeneric))) return launch_bp_sweep_all(a, grid_blocks, stream);
-    if (variants & (1 << kVariantGroup)) return launch_bp_sweep_ug(a, grid_blocks, nontemporal, stream);
-    return launch_bp_sweep_u(a, grid_blocks, nontemporal, stream);
+    if (variants & ((1 << kVariantFlat) | (1 << kVariantGeneric))) return launch_bp_sweep_all(a, grid_blocks, n_sets, stream);
+    if (variants & (1 << kVariantGroup)) return launch_bp_sweep_ug(a, grid_blocks, n_sets, nontemporal, stream);
+    return launch_bp_sweep_u(a, grid_blocks, n_sets, nontemporal, stream);
 }
-int launch_bp_finish(const FinishArgs& a, int grid_blocks, void* stream) {
+int launch_bp_finish(const FinishArgs& a, int grid_blocks, int n_sets, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    hipLaunchKernelGGL(bp_finish_kernel, dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(bp_finish_kernel, dim3(grid_blocks, n_sets > 1 ? n_sets : 1), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     return hip_rc(hipGetLastError());
 }
 

@@ -46,9 +46,21 @@ __device__ __forceinline__ void sweep_bookkeeping(const SweepArgs& a, int lane) 
     for (int q = 0; q < kResSlots / kWave; ++q) row[q * kWave + lane] = 0ull;
 }
 
+// The launch's arguments moved to evidence set blockIdx.y (batched launches; everything stays wave-uniform).
+__device__ __forceinline__ SweepArgs sweep_args_of_set(const SweepArgs& in) {
+    SweepArgs a = in;
+    const int set = blockIdx.y;
+    shift_to_set(a.b, in.sets, set);
+    a.rec_in += set * in.sets.rec; a.rec_out += set * in.sets.rec;
+    a.node_in += set * in.sets.node; a.node_out += set * in.sets.node;
+    return a;
+}
+
 // VARIANTS: bit kVariantUniform / kVariantGroup / kVariantFlat set = the plan has such tiles
-template <bool NT, int VARIANTS>
-__global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a) {
+// BATCH: gridDim.y evidence sets per launch, each with its own buffers, residual slots and done mark
+template <bool NT, int VARIANTS, bool BATCH = false>
+__global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a_in) {
+    const SweepArgs a = BATCH ? sweep_args_of_set(a_in) : a_in;
     constexpr bool FLAT = (VARIANTS >> kVariantFlat) & 1;
     // any-arity tiles only: staged terms, children's messages
     __shared__ double flat_lds[FLAT ? kWavesPerBlock : 1][FLAT ? kFlatLds : 1];

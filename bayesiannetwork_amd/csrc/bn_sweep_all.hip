@@ -3,10 +3,13 @@
 
 namespace bnmi {
 
-int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, void* stream) {
+// (working sets beyond the Infinity Cache made of any-arity tiles are latency-bound either way: plain stores)
+int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, int n_sets, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    // working sets beyond the Infinity Cache made of any-arity tiles are latency-bound either way: plain stores
-    hipLaunchKernelGGL((bp_sweep_kernel<false, kVarAll>), dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    if (n_sets > 1)  // one evidence set per blockIdx.y; plain stores (a batch is sized for the Infinity Cache or latency-bound)
+        hipLaunchKernelGGL((bp_sweep_kernel<false, kVarAll, true>), dim3(grid_blocks, n_sets), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((bp_sweep_kernel<false, kVarAll>), dim3(grid_blocks), dim3(kBlockThreads), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }

@@ -718,6 +718,26 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
             lav[2 * h] = y.x; lav[2 * h + 1] = y.y;
         }
     }
+    // The node is finished by M + 1 lanes of its group (G >= M + 1 for every D): lane 0 normalises pi(v),
+    // lane 1 + jt the lambda-message to parent jt -- one normalisation (four divisions) per lane instead of
+    // 4 (M + 1) in a row on one lane -- and each requests the previous value of ITS message (for the
+    // residual, :105-131) now, with the other inputs, instead of in a round trip of its own at the end.
+    static_assert(G >= M + 1, "a group has a lane per finished vector");
+    Loc fin = in[0];
+#pragma unroll
+    for (int j = 1; j < M; ++j)
+        if (g == j + 1) fin = in[j];
+    const bool fin_msg = active && g >= 1 && g <= M;
+    double fold[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) fold[i] = 1.0;
+    if (fin_msg && !io.first) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const double2_t y = rec_in2[fin.lam + h * fin.stride];
+            fold[2 * h] = y.x; fold[2 * h + 1] = y.y;
+        }
+    }
     // ---- parent role (:202-238), spread over the group's lanes: lane g serves children g, g+G, ...
     // of node nl.  It needs only the OLD pi(v)/lambda(v) and the children's records, so its loads
     // ride behind the CPT stream and its arithmetic is cmax steps for the whole group instead of
@@ -872,41 +892,37 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
         for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
     }
 
-    // ---- the group's first lane finishes the node: normalise, residual, stores, parent role
-    if (active && g == 0) {
-        normalize_k<K>(pp);
-        {
-            double2_t y0, y1;
-            y0.x = frozen ? piv[0] : pp[0]; y0.y = frozen ? piv[1] : pp[1];
-            y1.x = frozen ? piv[2] : pp[2]; y1.y = frozen ? piv[3] : pp[3];
-            bn_store<NT>(&nout[0 * NPT], y0);
-            bn_store<NT>(&nout[1 * NPT], y1);
+    // ---- lanes 0..M of the group finish the node: normalise, residual, stores
+    {
+        double o[K];
+#pragma unroll
+        for (int ct = 0; ct < K; ++ct) {
+            o[ct] = pp[ct];
+#pragma unroll
+            for (int jt = 0; jt < M; ++jt)
+                if (g == jt + 1) o[ct] = jt < D ? of[jt < D ? jt : 0][ct] : ol[jt >= D ? jt - D : 0][ct];
         }
-#pragma unroll
-        for (int jt = 0; jt < M; ++jt) {
-            double o[K];
-#pragma unroll
-            for (int ct = 0; ct < K; ++ct) o[ct] = jt < D ? of[jt < D ? jt : 0][ct] : ol[jt >= D ? jt - D : 0][ct];
+        if (active && g <= M) {
             normalize_k<K>(o);
-            double old[K];
+            if (g == 0) {
+                double2_t y0, y1;
+                y0.x = frozen ? piv[0] : o[0]; y0.y = frozen ? piv[1] : o[1];
+                y1.x = frozen ? piv[2] : o[2]; y1.y = frozen ? piv[3] : o[3];
+                bn_store<NT>(&nout[0 * NPT], y0);
+                bn_store<NT>(&nout[1 * NPT], y1);
+            } else {
 #pragma unroll
-            for (int i = 0; i < K; ++i) old[i] = 1.0;
-            if (!io.first) {
+                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - fold[i]));
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const double2_t y = rec_in2[in[jt].lam + h * in[jt].stride];
-                    old[2 * h] = y.x; old[2 * h + 1] = y.y;
+                    double2_t y;
+                    y.x = o[2 * h]; y.y = o[2 * h + 1];
+                    bn_store<NT>(&rec_out2[fin.lam + h * fin.stride], y);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - old[i]));
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                double2_t y;
-                y.x = o[2 * h]; y.y = o[2 * h + 1];
-                bn_store<NT>(&rec_out2[in[jt].lam + h * in[jt].stride], y);
-            }
         }
+    }
+    if (active && g == 0) {
         if (io.first && !frozen) {  // initial state (:38-41); a group node always has parents
 #pragma unroll
             for (int i = 0; i < K; ++i) { piv[i] = 1.0; lav[i] = 1.0; }

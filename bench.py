@@ -223,12 +223,14 @@ def leg_dag(a, local_rank, torch):
         eng.bp_set_evidence(ev)
         t = time_bp(eng, g, a.eps, max(a.steps, 20), a.warmup, torch)
         h2h = time_host_to_host(eng, g, ev, a.eps, 10)
+        # B queries per call: every per-sweep launch carries all sets (blockIdx.y), so they share its latency
+        batch = time_batches(eng, g, a, torch, (4, 16))
     steps = max(a.steps, 20)
     out = {"workload": f"10 k-node random DAG, <=4 parents, k=4, {g.n_edges} edges (BASELINE.json configs[1]), "
                        f"{ev.ne} evidence nodes, eps={a.eps:g}",
            "value": t["msgs"] / t["dt"], "unit": "edge-messages/s", "ms_per_step": t["dt"] / steps * 1e3, "steps": steps,
            "sweeps_per_step": t["sweeps_total"] / steps, "messages_per_sweep": g.messages_per_sweep(),
-           "value_host_to_host": h2h["value"], "roofline": roofline_of(t, "dag10k")}
+           "value_host_to_host": h2h["value"], "roofline": roofline_of(t, "dag10k"), "batch": batch}
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps, budget_s=6.0)
     return out
@@ -274,33 +276,42 @@ def leg_lw(a, local_rank, torch):
     return out
 
 
+def time_batches(eng, g, a, torch, sizes):
+    """Throughput of bn_bp_run_batch_device over all sets of a call, for each batch size in `sizes`."""
+    from bayesiannetwork_amd import synth
+    out = {}
+    for B in sizes:
+        evs = [synth.random_evidence(g, a.evidence, seed=7 + q) for q in range(B)]
+        eng.bp_set_evidence_batch(evs)
+        for _ in range(3):
+            r = eng.bp_run_batch_device(a.eps)
+        torch.cuda.synchronize()
+        steps = max(10, a.steps // 2)
+        t0 = time.perf_counter()
+        sweeps = 0
+        for _ in range(steps):
+            r = eng.bp_run_batch_device(a.eps)
+            sweeps += int(r["sweeps"].sum())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = eng.bp_stats()
+        out[f"B{B}"] = {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_call": dt / steps * 1e3,
+                       "set_sweeps_per_call": sweeps / steps, "us_per_set_sweep": dt / sweeps * 1e6,
+                       "algorithmic_gbs": st["algorithmic_bytes_per_sweep"] * sweeps / dt / 1e9, "path": PATH_NAME.get(eng.last_path())}
+    return out
+
+
 def leg_batch(a, local_rank, torch):
-    """Several evidence sets per call on the headline grid (bn_bp_run_batch_device: all sets walked round-robin
-    by ONE resident launch, one CPT image in registers / LDS for all of them, each set's barrier hidden behind the
-    others' sweeps).  Throughput over all sets; every set's result is what a run of it alone gives (tests)."""
+    """Several evidence sets per call on the headline grid (bn_bp_run_batch_device: up to 4 sets walked round-robin
+    by one resident launch, one CPT image in registers / LDS for all of them, each set's barrier hidden behind the
+    others' sweeps; more sets = consecutive launches).  Throughput over all sets; every set's result is what a run
+    of it alone gives (tests)."""
     from bayesiannetwork_amd import synth
     from bayesiannetwork_amd.engine import Engine
     g = synth.grid(a.rows, a.cols, 4, seed=2)
     out = {"workload": f"{a.rows}x{a.cols} grid, B evidence sets per call ({a.evidence:g} evidence each, different nodes), eps={a.eps:g}"}
     with Engine(g, device=local_rank) as eng:
-        for B in (2, 4, 8):
-            evs = [synth.random_evidence(g, a.evidence, seed=7 + q) for q in range(B)]
-            eng.bp_set_evidence_batch(evs)
-            for _ in range(3):
-                r = eng.bp_run_batch_device(a.eps)
-            torch.cuda.synchronize()
-            steps = max(10, a.steps // 2)
-            t0 = time.perf_counter()
-            sweeps = 0
-            for _ in range(steps):
-                r = eng.bp_run_batch_device(a.eps)
-                sweeps += int(r["sweeps"].sum())
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            st = eng.bp_stats()
-            out[f"B{B}"] = {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_call": dt / steps * 1e3,
-                           "set_sweeps_per_call": sweeps / steps, "us_per_set_sweep": dt / sweeps * 1e6,
-                           "algorithmic_gbs": st["algorithmic_bytes_per_sweep"] * sweeps / dt / 1e9, "path": PATH_NAME.get(eng.last_path())}
+        out.update(time_batches(eng, g, a, torch, (2, 4, 16)))
     return out
 
 

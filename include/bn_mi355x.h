@@ -38,6 +38,7 @@ typedef enum bn_status {
 } bn_status;
 
 #define BN_MAX_PARENTS 16
+#define BN_MAX_BATCH_SETS 64 /* evidence sets per bn_bp_run_batch call */
 #define BN_DEVICE_HOST_ONLY (-2) /* build the layout plan only; no HIP call is made */
 #define BN_DEVICE_CURRENT (-1)
 
@@ -116,9 +117,11 @@ int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
  * Several evidence sets on ONE network in one call -- an extension beside the drop-in: the reference's
  * operator() (belief_propagation.hpp:31) takes one query at a time, and each set here gets exactly the
  * result that call would give it (same sweep count, same bits).  Networks the resident kernel covers
- * (bn_set_option "multisweep") run all sets in ONE launch that walks them round-robin: one resident CPT
- * image serves every set and each set's grid barrier completes while the others compute; other networks
- * run the sets one after another.  n_sets in 1..8.
+ * (bn_set_option "multisweep") run up to 8 sets per launch, walked round-robin: one resident CPT image
+ * serves every set and each set's grid barrier completes while the others compute (more sets: consecutive
+ * launches).  Every other network runs ALL sets in each per-sweep launch (one evidence set per blockIdx.y):
+ * B queries share the launch, its latency and the CPT lines in the caches; a set that has converged drops
+ * out of the following launches.  n_sets in 1..BN_MAX_BATCH_SETS.
  *   ne[n_sets]           : evidence nodes per set
  *   ev_node, ev_val      : the sets' arrays concatenated
  *   ev_off               : per set a block of ne[q] + 1 offsets STARTING AT 0, blocks concatenated

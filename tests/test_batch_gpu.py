@@ -1,8 +1,8 @@
 """Several evidence sets per call (bn_bp_run_batch): an extension beside the drop-in -- the reference runs
 one query per operator() call (belief_propagation.hpp:31) -- so the bar is that every set of a batch gets
 exactly what running it alone gives: same sweep count (sets stop on different sweeps), same residual
-history, same bits in the marginals; on the resident path (all sets walked round-robin in one launch) and
-on the sequential path of networks the resident kernel does not cover."""
+history, same bits in the marginals; on the resident path (sets walked round-robin in one launch, 8 at a
+time) and on the per-sweep launches with one evidence set per blockIdx.y that every other network takes."""
 import numpy as np
 import pytest
 
@@ -63,20 +63,45 @@ def test_batch_caps_and_reuse(Engine):
         assert np.array_equal(eng.bp_run(evs[0], 1e-6)["beliefs"], r["beliefs"])
 
 
-def test_batch_lane_group_dag_and_sequential_fallback(Engine):
+def test_batch_on_per_sweep_launches_every_tile_variant(Engine):
+    """Networks the resident kernel does not cover: every per-sweep launch carries all sets (blockIdx.y)."""
+    import os
     from bayesiannetwork_amd import _lib, synth
-    d = synth.random_dag(3000, 4, 64, 4, seed=5)                    # lane-group tiles: the sets run one after another
+    from bayesiannetwork_amd.dsc import load_dsc
+    d = synth.random_dag(3000, 4, 64, 4, seed=5)                    # register-resident + lane-group tiles
     evs = [synth.random_evidence(d, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
     with Engine(d) as eng:
-        _check_batch(eng, evs, 1e-6, want_path=0)
+        sweeps = _check_batch(eng, evs, 1e-6, want_path=0)
+        assert len(set(sweeps)) > 1
+        _check_batch(eng, evs, 1e-12, max_sweeps=4, want_path=0)    # every set capped together
+        _check_batch(eng, evs + evs[::-1] + evs + evs, 1e-4, want_path=0)   # 12 sets, larger batch on the same engine
+        _check_batch(eng, evs[:1], 1e-9, want_path=0)               # a batch of one, more sweeps than predicted
     t = synth.random_dag(2000, 2, 8, 4, seed=41)                    # <= 2 parents: one-lane tiles, resident if <= 8 children
     evs = [synth.random_evidence(t, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
     with Engine(t) as eng:
         _check_batch(eng, evs, 1e-6)
-    m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)            # any-arity tiles: the sets run one after another
+    m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)            # any-arity tiles (+ register-resident ones)
     evs = [synth.random_evidence(m, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.02])]
     with Engine(m) as eng:
-        _check_batch(eng, evs, 1e-6)
-        assert eng.last_path() == 0
+        _check_batch(eng, evs, 1e-6, want_path=0)
         with pytest.raises(_lib.BnError):
-            eng.bp_run_batch([None] * 9, 1e-3)                      # more than 8 sets
+            eng.bp_run_batch([None] * 65, 1e-3)                     # more than BN_MAX_BATCH_SETS
+    alarm, _ = load_dsc(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alarm_shaped.dsc"))
+    evs = [synth.random_evidence(alarm, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.2] * 4)]
+    with Engine(alarm) as eng:                                      # any-arity tiles only: the light kernel, 16 sets
+        _check_batch(eng, evs, 1e-9, want_path=0)
+        _check_batch(eng, evs[:5], 1e-3, max_sweeps=2, want_path=0)
+
+
+def test_batch_more_sets_than_one_resident_launch_walks(Engine):
+    from bayesiannetwork_amd import synth
+    g = synth.grid(40, 40, 4, seed=3)
+    evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(19)]   # 3 launches: 7 + 6 + 6 sets
+    with Engine(g) as eng:
+        _check_batch(eng, evs, 1e-6, want_path=2, reps=1)
+        eng.set_option("multisweep", 0)                              # the same batch through the per-sweep launches
+        out = eng.bp_run_batch(evs, 1e-6)
+        assert eng.last_path() == 0
+        for q, ev in enumerate(evs):
+            r = eng.bp_run(ev, 1e-6)
+            assert out["sweeps"][q] == r["sweeps"] and np.array_equal(out["beliefs"][q], r["beliefs"])

@@ -262,7 +262,7 @@ def test_hot_kernels_do_not_spill(bnlib):
     kr = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(kr)
     u = kr.kernel_resources(os.path.join(csrc, "bn_sweep_u.o"))
-    assert len(u) == 2
+    assert len(u) == 3  # plain stores, non-temporal stores, batched (one evidence set per blockIdx.y)
     for name, r in u.items():
         assert "bp_sweep_kernel" in name
         assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0 and r["vgpr"] <= 256, (name, r)
@@ -276,5 +276,8 @@ def test_hot_kernels_do_not_spill(bnlib):
             assert r["spill"] <= 64, (name, r)
         if ", 4>" in name or ", 0>" in name:  # 64-entry tables keep 36 entries per lane in LDS
             assert r["lds"] >= 144 * 1024, (name, r)
+    for obj in ("bn_sweep_ug.o", "bn_sweep_all.o"):  # lane-group / any-arity instantiations: no spills either
+        for name, r in kr.kernel_resources(os.path.join(csrc, obj)).items():
+            assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
     for name, r in kr.kernel_resources(os.path.join(csrc, "bn_lw_kernels.o")).items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
