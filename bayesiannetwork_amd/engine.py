@@ -395,6 +395,16 @@ class BeliefPropagation:
         self.last = self.engine.bp_run(precondition, epsilon)
         return _split(self.model, self.last["beliefs"])
 
+    def run_batch(self, preconditions, epsilon: float = 0.001):
+        """Not in the reference (one query per call): several evidence sets in one call; entry q is exactly what
+        ``self(preconditions[q], epsilon)`` returns.  Lists longer than BN_MAX_BATCH_SETS go in slices."""
+        evs = [Evidence.from_dict(self.model, p) if isinstance(p, dict) else p for p in preconditions]
+        out = []
+        for b in range(0, len(evs), _lib.BN_MAX_BATCH_SETS):
+            self.last = self.engine.bp_run_batch(evs[b:b + _lib.BN_MAX_BATCH_SETS], epsilon)
+            out += [_split(self.model, bel) for bel in self.last["beliefs"]]
+        return out
+
 
 class LikelihoodWeighting:
     """``bn::inference::likelihood_weighting``: ``lw = LikelihoodWeighting(model); marg = lw({node: state}, 10000)``."""

@@ -12,6 +12,7 @@
 #ifndef BNI_INFERENCE_BELIEF_PROPAGATION_HPP
 #define BNI_INFERENCE_BELIEF_PROPAGATION_HPP
 
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -93,6 +94,59 @@ public:
             result[model_.nodes[i]] = m;
         }
         return result;
+    }
+
+    // Not in the reference (one query per operator() call, :31): several evidence sets on this network in ONE
+    // call.  Entry q of the result is exactly what operator()(queries[q], epsilon) returns -- same iteration
+    // count, same bits -- but the queries share every kernel launch (bn_bp_run_batch, bn_mi355x.h).
+    // Up to BN_MAX_BATCH_SETS queries per call; longer lists are processed in slices of that size.
+    std::vector<return_type> run_batch(std::vector<std::unordered_map<vertex_type, matrix_type>> const& queries,
+                                       double const epsilon = 0.001)
+    {
+        std::vector<return_type> results;
+        results.reserve(queries.size());
+        std::size_t const nbel = static_cast<std::size_t>(model_.node_off.back());
+        for(std::size_t begin = 0; begin < queries.size(); begin += BN_MAX_BATCH_SETS)
+        {
+            std::size_t const count = std::min<std::size_t>(BN_MAX_BATCH_SETS, queries.size() - begin);
+            std::vector<std::int32_t> ne, ev_node, ev_off;
+            std::vector<double> ev_val;
+            for(std::size_t q = 0; q < count; ++q)
+            {
+                std::size_t const val_begin = ev_val.size();
+                ev_off.push_back(0);  // every set's offsets start at 0
+                for(auto const& p : queries[begin + q])
+                {
+                    auto const it = model_.index.find(p.first);
+                    if(it == model_.index.end()) throw std::runtime_error("belief_propagation: evidence on an unknown vertex");
+                    if(p.second.height() != 1) throw std::runtime_error("belief_propagation: evidence must be a 1 x k matrix");
+                    ev_node.push_back(it->second);
+                    ev_val.insert(ev_val.end(), p.second[0].begin(), p.second[0].end());
+                    ev_off.push_back(static_cast<std::int32_t>(ev_val.size() - val_begin));
+                }
+                ne.push_back(static_cast<std::int32_t>(queries[begin + q].size()));
+            }
+            std::vector<double> beliefs(nbel * count);
+            std::vector<std::int32_t> sweeps(count, 0);
+            std::vector<double> residual(count, 0.0);
+            mi355x::engine_handle::check(bn_bp_run_batch(
+                engine_.get(), static_cast<std::int32_t>(count), ne.data(), ev_node.data(), ev_off.data(), ev_val.data(),
+                epsilon, 0, beliefs.data(), sweeps.data(), residual.data()));
+            for(std::size_t q = 0; q < count; ++q)
+            {
+                return_type result;
+                for(std::size_t i = 0; i < model_.nodes.size(); ++i)
+                {
+                    matrix_type m(1, static_cast<std::size_t>(model_.k[i]));
+                    m.assign(beliefs.begin() + q * nbel + model_.node_off[i], beliefs.begin() + q * nbel + model_.node_off[i + 1]);
+                    result[model_.nodes[i]] = m;
+                }
+                results.push_back(std::move(result));
+            }
+            last_sweeps_ = sweeps.back();
+            last_residual_ = residual.back();
+        }
+        return results;
     }
 
     // Not in the reference (its operator() hides them): iterations and last maximum_difference.

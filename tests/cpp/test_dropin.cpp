@@ -197,6 +197,24 @@ int main(int argc, char** argv)
             for(std::size_t j = 0; j < c.teacher.size(); ++j) close_pct(res.at(v[c.query])[0][j], c.teacher[j], 3.0, "resume");
             print_marginals(("resume_" + std::to_string(idx++)).c_str(), chain, res);
         }
+        // the same five queries in ONE call (run_batch, an extension): bit-for-bit what the single calls return
+        std::vector<std::unordered_map<bn::vertex_type, bn::matrix_type>> queries;
+        for(auto const& c : cases)
+        {
+            std::unordered_map<bn::vertex_type, bn::matrix_type> pre;
+            for(auto const& e : c.ev) pre[v[e.first]] = one_hot(e.second);
+            queries.push_back(pre);
+        }
+        bn::inference::belief_propagation func(chain);
+        auto const batch = func.run_batch(queries);
+        if(batch.size() != queries.size()) { ++failures; std::printf("FAIL run_batch size\n"); }
+        for(std::size_t q = 0; q < batch.size(); ++q)
+        {
+            auto const single = func(queries[q]);
+            for(auto const& node : v)
+                for(std::size_t j = 0; j < single.at(node).width(); ++j)
+                    if(!(batch[q].at(node)[0][j] == single.at(node)[0][j])) { ++failures; std::printf("FAIL run_batch differs from operator()\n"); }
+        }
     }
     {   // likelihood weighting on Pearl, H = 0: within 2 % of the exact marginals at 4e5 samples
         auto const v = pearl.vertex_list();

@@ -105,3 +105,18 @@ def test_batch_more_sets_than_one_resident_launch_walks(Engine):
         for q, ev in enumerate(evs):
             r = eng.bp_run(ev, 1e-6)
             assert out["sweeps"][q] == r["sweeps"] and np.array_equal(out["beliefs"][q], r["beliefs"])
+
+
+def test_mirror_class_run_batch(bnlib):
+    """BeliefPropagation.run_batch (the Python spelling of the drop-in's run_batch extension): entry q == bp(queries[q])."""
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import BeliefPropagation
+    m = synth.resume_chain()
+    bp = BeliefPropagation(m)
+    queries = [{1: np.array([0.0, 0.0, 1.0]), 3: np.array([1.0, 0.0, 0.0])}, {2: np.array([0.0, 1.0])}, {}, {0: np.array([1.0, 0.0, 0.0])}]
+    got = bp.run_batch(queries, 1e-9)
+    assert len(got) == len(queries)
+    for q, pre in enumerate(queries):
+        want = bp(pre, 1e-9)
+        for v in want:
+            assert np.array_equal(got[q][v], want[v])
