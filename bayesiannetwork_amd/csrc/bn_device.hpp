@@ -29,6 +29,7 @@ struct Ctl {
 struct BpBuffers {
     const TileDesc* tiles;
     const ClassDesc* classes;
+    const FlatEntry* flat_tab;  // per-entry digits / summation places of the ordered any-arity classes
     int32_t n_tiles;
     const double* cpt;
     double* rec0;        // double-buffered message records (no arrays here: a dynamically indexed

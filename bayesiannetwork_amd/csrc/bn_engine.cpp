@@ -100,6 +100,7 @@ struct bn_engine {
     // device images
     TileDesc* d_tiles = nullptr;
     ClassDesc* d_classes = nullptr;
+    FlatEntry* d_flat_tab = nullptr;
     double* d_cpt = nullptr;
     double* d_rec[2] = {nullptr, nullptr};
     double* d_node[2] = {nullptr, nullptr};
@@ -189,7 +190,7 @@ static void free_engine(bn_engine* e) {
         if (e->ev_swept) (void)hipEventDestroy(e->ev_swept);
         if (e->ev_gathered) (void)hipEventDestroy(e->ev_gathered);
         if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
-        void* ptrs[] = {e->d_tiles, e->d_classes, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
+        void* ptrs[] = {e->d_tiles, e->d_classes, e->d_flat_tab, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
@@ -285,6 +286,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         int r;
         if ((r = upload(&e->d_tiles, p.tiles, e->stream))) return r;
         if ((r = upload(&e->d_classes, p.classes, e->stream))) return r;
+        if ((r = upload(&e->d_flat_tab, p.flat_tab, e->stream))) return r;
         if ((r = upload(&e->d_cpt, p.cpt_striped, e->stream))) return r;
         if ((r = upload(&e->d_out, p.out_refs, e->stream))) return r;
         if ((r = upload(&e->d_inrefs, p.in_refs, e->stream))) return r;
@@ -360,6 +362,7 @@ static BpBuffers buffers_of(bn_engine* e) {
     BpBuffers b;
     b.tiles = e->d_tiles;
     b.classes = e->d_classes;
+    b.flat_tab = e->d_flat_tab;
     b.n_tiles = int32_t(e->plan.tiles.size());
     b.cpt = e->d_cpt;
     b.rec0 = e->d_rec[0]; b.rec1 = e->d_rec[1];

@@ -197,6 +197,35 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
                 c.G = std::max(c.G, g_children);
             }
             c.npt = kWave / c.G;
+            c.flat_tab_off = -1;
+            c.magic_kv = (65536 + c.kv - 1) / c.kv;
+            c.magic_hv = ((1 << 20) + c.kvp / 2 - 1) / (c.kvp / 2);
+            for (int j = 0; j < c.m && j < BN_MAX_PARENTS; ++j) c.lam_run[j] = int32_t(int64_t(c.kv) * rows / c.kp[j]);
+            if (c.variant == kVariantFlat && int64_t(c.kv) * rows <= 2 * c.G && int64_t(c.kv) * rows <= 128) {
+                // ordered path: digits and summation places of every entry, computed once here
+                c.flat_tab_off = int32_t(p.flat_tab.size());
+                const int32_t S = int32_t(c.kv * rows);
+                for (int32_t e = 0; e < 2 * c.G; ++e) {
+                    FlatEntry fe;
+                    std::memset(&fe, 0, sizeof fe);
+                    if (e < S) {
+                        fe.valid = 1;
+                        const int32_t cond = e / c.kv, ei = e % c.kv;
+                        fe.ei = uint8_t(ei);
+                        fe.pos_pi = uint8_t(ei * rows + cond);
+                        int32_t dj[kFlatMaxParents] = {0};
+                        for (int j = 0; j < c.m; ++j) { dj[j] = (cond / c.cstride[j]) % c.kp[j]; fe.dj[j] = uint8_t(dj[j]); }
+                        for (int jt = 0; jt < c.m; ++jt) {
+                            const int32_t kj = c.kp[jt], per_state = int32_t(rows / kj);
+                            int32_t rest = 0;  // the assignment with digit jt removed, same radix order
+                            for (int j = 0; j < c.m; ++j)
+                                if (j != jt) rest += dj[j] * (j < jt ? c.cstride[j] / kj : c.cstride[j]);
+                            fe.pos_lam[jt] = uint8_t(dj[jt] * (c.kv * per_state) + ei * per_state + rest);
+                        }
+                    }
+                    p.flat_tab.push_back(fe);
+                }
+            }
             c.per_lane = int32_t((int64_t(c.kv) * rows + c.G - 1) / c.G);
             c.per_lane_pad = round_even(c.per_lane);
             int32_t off = 0;

@@ -74,8 +74,26 @@ struct ClassDesc {
     int32_t rec_doubles;             // per tile
     int32_t cstride[BN_MAX_PARENTS]; // mixed-radix stride of parent j in the assignment index
     int32_t n_nodes;
-    int32_t pad_;
+    // any-arity classes on the ordered path (at most two CPT entries per lane, kv * rows <= 128):
+    int32_t flat_tab_off;            // first FlatEntry of the class in Plan::flat_tab (2 G entries), -1: none
+    int32_t lam_run[BN_MAX_PARENTS]; // kv * rows / kp[j]: terms one bucket of the lambda-message to parent j sums
+    int32_t magic_kv;                // ceil(2^16 / kv): x / kv == (x * magic_kv) >> 16 for 0 <= x < 1024 (kv <= 64)
+    int32_t magic_hv;                // ceil(2^20 / (kvp / 2)): chunk stride of a MsgRef, (lam - pi) / (kvp / 2), for differences < 2^11
 };
+
+// Per CPT entry e of an ordered any-arity class, everything the tile code would otherwise derive with
+// runtime divisions: the digits of e in the mixed radix (own state fastest, last parent next) and the place
+// of e's term in each accumulator's summation run (the reference's order: own state outer, assignment inner,
+// belief_propagation.hpp:174-200, :240-266).  32 bytes, one pair of 16-byte loads.
+struct FlatEntry {
+    uint8_t dj[kFlatMaxParents];       // state of parent j in the assignment
+    uint8_t pos_lam[kFlatMaxParents];  // lambda-message to parent j: dj[j] * lam_run[j] + own state * (rows / kp[j]) + assignment without digit j
+    uint8_t ei;                        // own state
+    uint8_t pos_pi;                    // pi(v): ei * rows + assignment
+    uint8_t valid;                     // e < kv * rows
+    uint8_t pad_[13];
+};
+static_assert(sizeof(FlatEntry) == 32, "FlatEntry is loaded as two 16-byte words");
 
 // One wavefront of work.  POD, 64 bytes.
 struct TileDesc {
@@ -121,6 +139,7 @@ struct Plan {
     int64_t n_cut_edges = 0;         // cut edges incident to this rank
     // classes / tiles (owned nodes only)
     std::vector<ClassDesc> classes;
+    std::vector<FlatEntry> flat_tab;  // per ordered any-arity class, 2 G entries (ClassDesc::flat_tab_off)
     std::vector<TileDesc> tiles;
     std::vector<int32_t> node_class; // [n]   -1 for nodes of other ranks
     std::vector<int32_t> node_slot;  // [n]   tiles[t].slot_base + nl, or -1

@@ -75,10 +75,19 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a_
         return;
     }
     const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
+#ifdef BN_TILE_CLOCK
+    const unsigned long long t_entry = wall_clock64();
+#endif
     const TileDesc td = b.tiles[tile];
     if (done != 0) return;
     const double wres = run_tile<NT, VARIANTS>(b, io, td, lane, flat_lds[FLAT ? wave : 0]);
     publish_residual(b, a.rec_out, tile, wres, lane);
+#ifdef BN_TILE_CLOCK
+    if (lane == 0 && td.slot_base < kTileClockTiles) {
+        g_tile_clock[td.slot_base][9] = t_entry;
+        g_tile_clock[td.slot_base][11] = wall_clock64();
+    }
+#endif
 }
 
 

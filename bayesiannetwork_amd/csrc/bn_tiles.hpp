@@ -22,6 +22,20 @@
 
 namespace bnmi {
 
+// Diagnostic builds only (make EXTRA=-DBN_TILE_CLOCK, scripts/experiments/tile_clock.py): lane 0 of every tile
+// records the 100 MHz clock at a few points of the tile code; bn_debug_tile_clock() (bn_sweep_all.hip) reads them back.
+#ifdef BN_TILE_CLOCK
+constexpr int kTileClockStamps = 12, kTileClockTiles = 4096;
+static __device__ unsigned long long g_tile_clock[kTileClockTiles][kTileClockStamps];
+__device__ __forceinline__ void tile_stamp(int tile, int k, int lane) {
+    if (lane == 0 && tile < kTileClockTiles) g_tile_clock[tile][k] = wall_clock64();
+}
+#define TILE_STAMP(k) tile_stamp(int(td.slot_base), (k), wlane_for_stamp)
+#else
+#define TILE_STAMP(k) ((void)0)
+#endif
+
+
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // NT = non-temporal output stores.  Measured on MI355X: on a working set that fits the 256 MiB
@@ -961,6 +975,19 @@ __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOM
 
 // G lanes per node (NPT = 64 / G nodes per wave): G < 64 only for tables of at most 2 G entries
 // whose vectors fit G lanes (the ordered path); every "lane" below is then a lane of the node's group.
+// MsgRef -> Loc with the chunk stride by multiplication: magic = ceil(2^20 / h), exact because a tile-resident
+// record has lam - pi = h * npt <= 2^11 (bn_plan.cpp)
+__device__ __forceinline__ Loc decode_ref_magic(MsgRef r, unsigned magic) {
+    Loc l;
+    l.has = r.pi >= 0;
+    const bool cut = r.lam < 0;
+    const int lam = cut ? ~r.lam : r.lam;
+    l.pi = l.has ? r.pi : 0;
+    l.lam = l.has ? lam : 0;
+    l.stride = !l.has ? 0 : (cut ? 1 : int32_t((unsigned(lam - r.pi) * magic) >> 20));
+    return l;
+}
+
 template <int G, bool NT>
 __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, const TileDesc& td, const ClassDesc& cg,
                                             int wlane, double* lds) {
@@ -969,61 +996,53 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     const int nl = wlane / G, lane = wlane % G, gb = nl * G;  // node of the tile, lane inside its group, first lane
     const bool active = nl < td.n_nodes;
     const int nlc = active ? nl : 0;  // idle groups shadow node 0 (they take part in the shuffles, store nothing)
-    double* W = lds + (G == kWave ? 0 : nl * 2 * G);
+#ifdef BN_TILE_CLOCK
+    const int wlane_for_stamp = wlane;
+#endif
+    TILE_STAMP(0);
+    double* W = lds + nl * (kFlatW / NPT);  // the group's share: kFlatW / NPT = 16 G doubles
     double* LK = lds + kFlatW + nl * (kFlatLK / NPT);
-    // element x of a lane-spread vector of this node's group; x is the same for the whole group
-    auto bcast = [&](double x, int idx) {
-        if constexpr (G == kWave) return readlane_d(x, idx);
-        else return shfl_d(x, gb + idx);
-    };
     // the class fields used below, copied once into (scalar) registers: the wave-scope fences
     // between the LDS phases would otherwise make every later use a fresh load
     struct {
-        int kv, m, rows, kvp, per_lane;
-        int kp[MM], kpp[MM], rec_off[MM], cstride[MM];
+        int kv, m, rows, kvp, per_lane, tab;
+        unsigned magic_kv, magic_hv;
+        int kp[MM], kpp[MM], rec_off[MM], lam_run[MM];
     } c;
-    c.kv = cg.kv; c.m = cg.m; c.rows = cg.rows; c.kvp = cg.kvp; c.per_lane = cg.per_lane;
+    c.kv = cg.kv; c.m = cg.m; c.rows = cg.rows; c.kvp = cg.kvp; c.per_lane = cg.per_lane; c.tab = cg.flat_tab_off;
+    c.magic_kv = unsigned(cg.magic_kv); c.magic_hv = unsigned(cg.magic_hv);
 #pragma unroll
-    for (int j = 0; j < MM; ++j) { c.kp[j] = cg.kp[j]; c.kpp[j] = cg.kpp[j]; c.rec_off[j] = cg.rec_off[j]; c.cstride[j] = cg.cstride[j]; }
+    for (int j = 0; j < MM; ++j) { c.kp[j] = cg.kp[j]; c.kpp[j] = cg.kpp[j]; c.rec_off[j] = cg.rec_off[j]; c.lam_run[j] = cg.lam_run[j]; }
     const int kv = c.kv, m = c.m, rows = c.rows, kvp = c.kvp;
     const int S = kv * rows;
-    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
+    auto div_kv = [&](int x) { return int((unsigned(x) * c.magic_kv) >> 16); };  // x / kv for 0 <= x < 1024
+    const bool ordered = G < kWave || S <= kFlatOrdered;
+    TILE_STAMP(1);  // class descriptor in registers
     double wres = 0.0;
 
-    // ---- node vectors (old), lane i < kv
-    const double* nin = io.node_in + td.node_base;
-    double* nout = io.node_out + td.node_base;
-    // element i of pi(v) / lambda(v) in the tile's striped node block
-    auto nidx = [&](int half, int i) { return int64_t(half + (i >> 1)) * (NPT * 2) + nlc * 2 + (i & 1); };
-    double piv = 1.0, lav = 1.0;
-    if (lane < kv && (!io.first || frozen)) { piv = nin[nidx(0, lane)]; lav = nin[nidx(kvp / 2, lane)]; }
-    else if (lane < kv && m == 0) piv = b.cpt[td.cpt_base + (nlc * G + lane) * 2];  // a root starts from its CPT row (:58-64)
-
-    // ---- parent role, first pass: child (c, i) <-> lane c*kv + i.  Its reference, lambda-message
-    // element and previous pi-message element are requested now, so that these two dependent round
-    // trips overlap with the child role below instead of following it.
-    const int cmax = td.cmax;
-    const int ptotal = cmax * kv;
-    const int pchunk = (G / kv) * kv;  // whole children per pass
-    const bool pstaged = ptotal <= kFlatLK / NPT;
-    int pc0 = 0, pi0 = 0;
-    Loc pl0;
-    pl0.has = false; pl0.pi = 0; pl0.lam = 0; pl0.stride = 0;
-    double plk0 = 1.0, pold0 = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
-    if (pstaged && lane < pchunk && lane < ptotal) {
-        pc0 = lane / kv; pi0 = lane - pc0 * kv;
-        pl0 = decode_ref(b.out_refs[td.out_base + int64_t(pc0) * NPT + nlc], kvp / 2);
-        if (pl0.has && !io.first) {
-            plk0 = io.rec_in[(pl0.lam + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
-            pold0 = io.rec_in[(pl0.pi + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
+    // ---- every load whose address depends on the descriptors only goes out first: CPT values, the entry
+    // table, the in-edge records, marks and node vectors, the out-edge references
+    const double* cp = b.cpt + td.cpt_base + (nlc * G + lane) * 2;
+    double cval[2] = {0.0, 0.0};
+    uint4 fe_lo[2], fe_hi[2];
+    if (ordered) {
+        const uint4* tab = reinterpret_cast<const uint4*>(b.flat_tab + c.tab);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fe_lo[t] = tab[(lane + G * t) * 2];
+            fe_hi[t] = tab[(lane + G * t) * 2 + 1];
+            cval[t] = cp[t];  // slots beyond the table are zero-filled by the planner's image (valid decides)
         }
     }
-
-    // ---- in-edge records: lane x <-> (parent j, state d), x = offs[j] + d
+    // in-edge records: lane x <-> (parent j, state d), x = offs[j] + d
     int offs[MM + 1];
-    int myj = -1;
+    int myj = -1, mykj = 0, myoff = 0, myrun = 0;  // this lane's parent, its arity, first lane and bucket run length
     int64_t my_pi = 0, my_lam = 0;  // doubles from the start of a record buffer
     {
+        // the in-edge of this lane is picked with selects inside the loop (everything per j is wave-uniform);
+        // the 64-bit element address is formed once, after it
+        int64_t sel_pi = 0, sel_lam = 0;
+        int sel_stride = 0;
         int off = 0;
 #pragma unroll
         for (int j = 0; j < MM; ++j) {
@@ -1037,111 +1056,200 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
                     l.has = true; l.pi = (td.rec_base + c.rec_off[j]) / 2 + nlc; l.lam = l.pi + hj * NPT; l.stride = NPT;
                 }
                 if (lane >= off && lane < off + kj) {
-                    const int dd = lane - off;
-                    myj = j;
-                    my_pi = (l.pi + int64_t(dd >> 1) * l.stride) * 2 + (dd & 1);
-                    my_lam = (l.lam + int64_t(dd >> 1) * l.stride) * 2 + (dd & 1);
+                    myj = j; mykj = kj; myoff = off; myrun = c.lam_run[j];
+                    sel_pi = l.pi; sel_lam = l.lam; sel_stride = l.stride;
                 }
                 off += kj;
             }
         }
         offs[MM] = off;
+        const int dd = lane - myoff;
+        const int64_t step = int64_t((dd >> 1) * sel_stride);  // chunk offset: < 2^31 (stride <= 64 or 1, dd < 64)
+        my_pi = (sel_pi + step) * 2 + (dd & 1);
+        my_lam = (sel_lam + step) * 2 + (dd & 1);
     }
     const int sumk = offs[MM];
     double pim = 1.0, oldlam = 1.0;
     if (myj >= 0 && !io.first) { pim = io.rec_in[my_pi]; oldlam = io.rec_in[my_lam]; }
+    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
+    // node vectors (old), lane i < kv
+    const double* nin = io.node_in + td.node_base;
+    double* nout = io.node_out + td.node_base;
+    // element i of pi(v) / lambda(v) in the tile's striped node block
+    auto nidx = [&](int half, int i) { return int64_t(half + (i >> 1)) * (NPT * 2) + nlc * 2 + (i & 1); };
+    // requested whether or not they will be used (deciding first would put the mark's round trip in front of them);
+    // iteration 0 of a node without evidence starts from 1.0 / its CPT row instead (:33-73)
+    double piv = 1.0, lav = 1.0;
+    if (lane < kv) {
+        const double old_pi = nin[nidx(0, lane)], old_lam = nin[nidx(kvp / 2, lane)];
+        const double root = m == 0 ? b.cpt[td.cpt_base + (nlc * G + lane) * 2] : 1.0;  // a root starts from its CPT row (:58-64)
+        const bool kept = !io.first || frozen;
+        piv = kept ? old_pi : root;
+        lav = kept ? old_lam : 1.0;
+    }
 
-    // digits, factors and CPT value of entry e (all lanes take part in the shuffles)
-    auto entry = [&](int e, bool valid, double cval, double (&pj)[MM], int (&dj)[MM], int& ei, int& econd, double& li,
-                     double& cv) {
-        const int ee = valid ? e : 0;
-        int cond = ee / kv;
-        ei = ee - cond * kv;
-        econd = cond;
-#pragma unroll
-        for (int j = MM - 1; j >= 0; --j) {
-            dj[j] = 0; pj[j] = 1.0;
-            if (j < m) {
-                const int q = cond / c.kp[j];
-                dj[j] = cond - q * c.kp[j];
-                cond = q;
+    // ---- parent role, first pass: child (c, i) <-> lane c*kv + i.  Its reference heads a dependent chain
+    // (reference -> the child's lambda-message element and the previous pi-message element): the reference is
+    // requested now with everything else, the second trip once the child role's terms are staged, so that it
+    // is in flight while they are summed and normalised.
+    const int cmax = td.cmax;
+    const int ptotal = cmax * kv;
+    const int pchunk = div_kv(G) * kv;  // whole children per pass
+    const bool pstaged = ptotal <= kFlatLK / NPT;
+    const bool pfirst = pstaged && lane < pchunk && lane < ptotal;
+    int pi0 = 0;
+    MsgRef pr0{-1, 0};
+    if (pfirst) {
+        const int pc0 = div_kv(lane);
+        pi0 = lane - pc0 * kv;
+        pr0 = b.out_refs[td.out_base + int64_t(pc0) * NPT + nlc];
+    }
+    Loc pl0;
+    pl0.has = false; pl0.pi = 0; pl0.lam = 0; pl0.stride = 0;
+    double plk0 = 1.0, pold0 = 1.0;  // a missing child contributes 1.0 (x * 1.0 == x)
+    auto parent_second_trip = [&]() {
+        if (pfirst) {
+            pl0 = decode_ref_magic(pr0, c.magic_hv);
+            if (pl0.has && !io.first) {
+                plk0 = io.rec_in[(pl0.lam + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
+                pold0 = io.rec_in[(pl0.pi + int64_t(pi0 >> 1) * pl0.stride) * 2 + (pi0 & 1)];
             }
         }
-#pragma unroll
-        for (int j = 0; j < MM; ++j)
-            if (j < m) pj[j] = shfl_d(pim, gb + offs[j] + dj[j]);
-        li = shfl_d(lav, gb + ei);
-        cv = valid ? cval : 0.0;
     };
-    const double* cp = b.cpt + td.cpt_base + (nlc * G + lane) * 2;
+    TILE_STAMP(2);  // first-trip loads issued
+
     double outl = 0.0;  // lane x: un-normalised lambda-message element x (concatenated)
     double pin = 0.0;   // lane i: un-normalised pi(v)[i]
 
-    if (G < kWave || S <= kFlatOrdered) {
-        // ---- ordered path: at most two entries per lane.  Every term is written to LDS at the
-        // position it has in ITS accumulator's summation order, so each accumulator lane then adds
-        // one contiguous run front to back (reads pipelined, additions strictly in the reference's order).
+    if (ordered) {
+        // ---- ordered path: at most two entries per lane.  EVERY term -- of pi(v) and of the lambda-message to
+        // each parent -- is written to LDS at the position it has in ITS accumulator's summation order (FlatEntry,
+        // computed by the planner), region r of the group's share holding accumulator set r (0: pi(v), 1 + jt:
+        // parent jt); one fence; then each accumulator lane adds its contiguous run front to back (additions
+        // strictly in the reference's order :174-200, :240-266).
+        constexpr int kRegion = 2 * G;                 // doubles per region (S <= 2 G)
+        constexpr int kRegions = (kFlatW / NPT) / kRegion;  // 8
         double pj[2][MM], li[2], cv[2];
-        int dj[2][MM], ei[2], ec[2];
         bool ok[2];
+        unsigned ei[2], pos_pi[2], dj[2][MM], pos_lam[2][MM];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int e = lane + G * t;
-            ok[t] = e < S;
-            const double cval = ok[t] ? cp[t] : 0.0;
-            entry(e, ok[t], cval, pj[t], dj[t], ei[t], ec[t], li[t], cv[t]);
+            const unsigned w0[4] = {fe_lo[t].x, fe_lo[t].y, fe_lo[t].z, fe_lo[t].w};
+#pragma unroll
+            for (int j = 0; j < MM; ++j) {
+                dj[t][j] = (w0[j >> 2] >> (8 * (j & 3))) & 255u;
+                pos_lam[t][j] = (w0[2 + (j >> 2)] >> (8 * (j & 3))) & 255u;
+            }
+            ei[t] = fe_hi[t].x & 255u;
+            pos_pi[t] = (fe_hi[t].x >> 8) & 255u;
+            ok[t] = ((fe_hi[t].x >> 16) & 255u) != 0;
+#pragma unroll
+            for (int j = 0; j < MM; ++j) {
+                pj[t][j] = 1.0;
+                if (j < m) pj[t][j] = shfl_d(pim, gb + offs[j] + int(dj[t][j]));
+            }
+            li[t] = shfl_d(lav, gb + int(ei[t]));
+            cv[t] = ok[t] ? cval[t] : 0.0;
         }
-        // calculate_pi (:174-200): cpt * pi-messages (ascending parents), summed over assignments ascending
+        TILE_STAMP(3);  // in-edge messages and CPT values have arrived
+        // calculate_pi (:174-200): cpt * pi-messages (ascending parents)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             double v = cv[t];
 #pragma unroll
             for (int j = 0; j < MM; ++j)
                 if (j < m) v *= pj[t][j];
-            if (ok[t]) W[ei[t] * rows + ec[t]] = v;
+            if (ok[t]) W[pos_pi[t]] = v;
         }
+        // calculate_lambda_k (:240-266) per target parent: (lambda[i] * cpt) * the OTHER parents' pi-messages
+        auto lambda_terms = [&](int jt, int region) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                double w = li[t] * cv[t];
+#pragma unroll
+                for (int j = 0; j < MM; ++j)
+                    if (j < m && j != jt) w *= pj[t][j];
+                if (ok[t]) W[region * kRegion + int(pos_lam[t][jt])] = w;
+            }
+        };
+#pragma unroll
+        for (int jt = 0; jt < kRegions - 1; ++jt)
+            if (jt < m) lambda_terms(jt, 1 + jt);
         wave_lds_fence();
-        if (lane < kv) {
-            const double* run = W + lane * rows;
-            double acc = 0.0;
-#pragma unroll 8
-            for (int r = 0; r < rows; ++r) acc += run[r];
-            pin = acc;
+        TILE_STAMP(4);  // terms staged
+        parent_second_trip();
+        {
+            // both runs of a lane (pi(v)[lane] if lane < kv, its lambda-message element if it has one) are summed in one loop
+            const int Rpi = lane < kv ? rows : 0;
+            const int Rlam = (myj >= 0 && myj < kRegions - 1) ? myrun : 0;
+            const double* run_pi = W + (lane < kv ? lane : 0) * rows;
+            const double* run_lam = W + (1 + (myj < 0 ? 0 : myj)) * kRegion + (lane - myoff) * myrun;
+            int Rtop = rows;
+#pragma unroll
+            for (int j = 0; j < MM; ++j)
+                if (j < m) Rtop = c.lam_run[j] > Rtop ? c.lam_run[j] : Rtop;
+            int Rmin = rows;
+#pragma unroll
+            for (int j = 0; j < MM; ++j)
+                if (j < m) Rmin = c.lam_run[j] < Rmin ? c.lam_run[j] : Rmin;
+            // Eight consecutive terms of each run per step, read unconditionally (a read past a run's end stays
+            // inside this wave's LDS slice: the staging area is followed by the children's area): no remainder
+            // loop, no branches, reads with immediate offsets.  While every run of the tile has eight terms left
+            // the step is loads + additions only; after that a term past its run's end becomes +0.0, which leaves
+            // the sum as it is (a sum started from +0.0 is never -0.0), the selects off the chain of additions.
+            constexpr int kStep = 8;
+            double acc_pi = 0.0, acc_lam = 0.0;
+            int r0 = 0;
+            for (; r0 + kStep <= Rmin; r0 += kStep) {
+                double x_pi[kStep], x_lam[kStep];
+#pragma unroll
+                for (int q = 0; q < kStep; ++q) {
+                    x_pi[q] = run_pi[r0 + q];
+                    x_lam[q] = run_lam[r0 + q];
+                }
+#pragma unroll
+                for (int q = 0; q < kStep; ++q) {
+                    acc_pi += x_pi[q];
+                    acc_lam += x_lam[q];
+                }
+            }
+            for (; r0 < Rtop; r0 += kStep) {
+                double x_pi[kStep], x_lam[kStep];
+#pragma unroll
+                for (int q = 0; q < kStep; ++q) {
+                    x_pi[q] = run_pi[r0 + q];
+                    x_lam[q] = run_lam[r0 + q];
+                }
+#pragma unroll
+                for (int q = 0; q < kStep; ++q) {
+                    x_pi[q] = r0 + q < Rpi ? x_pi[q] : 0.0;
+                    x_lam[q] = r0 + q < Rlam ? x_lam[q] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < kStep; ++q) {
+                    acc_pi += x_pi[q];
+                    acc_lam += x_lam[q];
+                }
+            }
+            pin = acc_pi;
+            outl = acc_lam;
         }
-        wave_lds_fence();
-        // calculate_lambda_k (:240-266) per target parent: (lambda[i] * cpt) * the OTHER parents'
-        // pi-messages; bucket s of parent jt receives its terms own state outer, assignment inner
-#pragma unroll
-        for (int jt = 0; jt < MM; ++jt) {
-            if (jt < m) {
-                const int kj = c.kp[jt], per_state = rows / kj;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    double w = li[t] * cv[t];
-#pragma unroll
-                    for (int j = 0; j < MM; ++j)
-                        if (j < m && j != jt) w *= pj[t][j];
-                    // rank inside the bucket = i * (rows / kj) + (assignment with digit jt removed)
-                    int rest = 0;
-#pragma unroll
-                    for (int j = 0; j < MM; ++j)
-                        if (j < m && j != jt) rest += dj[t][j] * (j < jt ? c.cstride[j] / kj : c.cstride[j]);
-                    if (ok[t]) W[dj[t][jt] * (kv * per_state) + ei[t] * per_state + rest] = w;
-                }
-                wave_lds_fence();
-                if (lane >= offs[jt] && lane < offs[jt] + kj) {
-                    const int R = kv * per_state;
-                    const double* run = W + (lane - offs[jt]) * R;
-                    double acc = 0.0;
+        if (m > kRegions - 1) {  // an eighth parent: its terms reuse region 0 once pi(v) has been summed
+            wave_lds_fence();
+            lambda_terms(MM - 1, 0);
+            wave_lds_fence();
+            if (myj == MM - 1) {
+                const double* run = W + (lane - myoff) * myrun;
+                double acc = 0.0;
 #pragma unroll 8
-                    for (int r = 0; r < R; ++r) acc += run[r];
-                    outl = acc;
-                }
-                wave_lds_fence();
+                for (int r = 0; r < myrun; ++r) acc += run[r];
+                outl = acc;
             }
         }
+        wave_lds_fence();
     } else {
         // ---- large table: LDS atomics into [ lambda buckets (sumk) | pi (kv) ]
+        parent_second_trip();
         const int nacc = sumk + kv;  // <= 128
         for (int x = lane; x < nacc * kFlatCopies; x += kWave) W[x] = 0.0;
         wave_lds_fence();
@@ -1174,7 +1282,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
             }
             const int e = lane + kWave * t;
             const bool valid = e < S;
-            const double cval = (t & 3) == 0 ? cvals[0] : ((t & 3) == 1 ? cvals[1] : ((t & 3) == 2 ? cvals[2] : cvals[3]));
+            const double cvq = (t & 3) == 0 ? cvals[0] : ((t & 3) == 1 ? cvals[1] : ((t & 3) == 2 ? cvals[2] : cvals[3]));
             double pj[MM], li, cv;
             int dj[MM], ei;
             ei = valid ? cur_i : 0;
@@ -1185,7 +1293,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
                 if (j < m) pj[j] = shfl_d(pim, gb + offs[j] + dj[j]);
             }
             li = shfl_d(lav, gb + ei);
-            cv = valid ? cval : 0.0;
+            cv = valid ? cvq : 0.0;
             {   // e += 64 in mixed radix
                 int x = cur_i + inc_i;
                 int carry = x >= kv ? 1 : 0;
@@ -1230,27 +1338,49 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
         }
         wave_lds_fence();
     }
+    TILE_STAMP(5);  // pi(v) and the lambda-messages summed
 
-    // ---- normalise (:298-311: divide by the plain left-to-right sum), residual (:105-131), stores
+    // ---- normalise (:298-311: divide by the plain left-to-right sum), residual (:105-131), stores.
+    // The un-normalised elements go through LDS once; every lane then adds the elements of ITS vector front to
+    // back (the lanes of a vector compute the same sum), instead of one broadcast per element in turn.
     {
-        double sum = 0.0;
-        for (int i = 0; i < kv; ++i) sum += bcast(pin, i);
-        pin /= sum;
+        if (lane < sumk) W[lane] = outl;
+        if (lane < kv) W[G + lane] = pin;
+        wave_lds_fence();
+        const int n_pi = lane < kv ? kv : 0;
+        const int n_lam = mykj;  // 0 for a lane without an in-edge element
+        const double* v_pi = W + G;
+        const double* v_lam = W + myoff;
+        int top = kv;
+#pragma unroll
+        for (int j = 0; j < MM; ++j)
+            if (j < m) top = c.kp[j] > top ? c.kp[j] : top;
+        const int l_pi = n_pi > 0 ? n_pi - 1 : 0, l_lam = n_lam > 0 ? n_lam - 1 : 0;
+        double sum_pi = 0.0, sum_lam = 0.0;
+        for (int r0 = 0; r0 < top; r0 += 4) {
+            double x_pi[4], x_lam[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                x_pi[q] = v_pi[r0 + q < l_pi ? r0 + q : l_pi];
+                x_lam[q] = v_lam[r0 + q < l_lam ? r0 + q : l_lam];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // + 0.0 past the end (see above)
+                sum_pi += r0 + q < n_pi ? x_pi[q] : 0.0;
+                sum_lam += r0 + q < n_lam ? x_lam[q] : 0.0;
+            }
+        }
+        wave_lds_fence();
+        pin /= sum_pi;
+        if (myj >= 0) outl /= sum_lam;
         if (active && lane < kv) nout[nidx(0, lane)] = frozen ? piv : pin;
         if (active && lane == kv && kvp > kv) nout[nidx(0, lane)] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < MM; ++j) {
-        if (j < m) {
-            double sum = 0.0;
-            for (int dd = 0; dd < c.kp[j]; ++dd) sum += bcast(outl, offs[j] + dd);
-            if (myj == j) outl /= sum;
-        }
     }
     if (active && myj >= 0) {
         wres = res_acc(wres, fabs(outl - oldlam));
         io.rec_out[my_lam] = outl;
     }
+    TILE_STAMP(6);  // normalised, child-role stores issued
 
     // ---- parent role (:202-238): the children's lambda-messages staged in LDS, element (c, i) at c*kv + i
     if (pstaged) {
@@ -1259,37 +1389,55 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
         for (int base = chunk; base < total; base += chunk) {
             const int idx = base + lane;
             if (lane < chunk && idx < total) {
-                const int cc = idx / kv, ii = idx - cc * kv;
-                const Loc l = decode_ref(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], kvp / 2);
+                const int cc = div_kv(idx), ii = idx - cc * kv;
+                const Loc l = decode_ref_magic(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], c.magic_hv);
                 double val = 1.0;
                 if (l.has && !io.first) val = io.rec_in[(l.lam + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1)];
                 LK[idx] = val;
             }
         }
         wave_lds_fence();
-        {   // lambda(v): product of the children's lambda-messages from 1.0, ascending (:220-238)
-            double acc = 1.0;
-            if (lane < kv)
-                for (int x = 0; x < cmax; ++x) acc *= LK[x * kv + lane];
+        TILE_STAMP(7);  // children's messages staged
+        // product over the children x (ascending, :229-235 / :208-215) of element i of their lambda-messages,
+        // skipping child `skip`; four LDS reads in flight per step
+        auto children_product = [&](double init, int i, int skip) {
+            double acc = init;
+            for (int x0 = 0; x0 < cmax; x0 += 4) {
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = LK[(x0 + q < cmax ? x0 + q : cmax - 1) * kv + i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc *= (x0 + q < cmax && x0 + q != skip) ? v[q] : 1.0;  // x * 1.0 == x
+            }
+            return acc;
+        };
+        // left-to-right sum (:298-311) of the kv elements held by lanes first .. first + kv - 1 of the group
+        auto vector_sum = [&](double x, int first) {
             double sum = 0.0;
-            for (int i = 0; i < kv; ++i) sum += bcast(acc, i);
-            acc /= sum;
+            for (int i0 = 0; i0 < kv; i0 += 4) {
+                double v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = shfl_d(x, gb + first + (i0 + q < kv ? i0 + q : 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum += i0 + q < kv ? v[q] : 0.0;
+            }
+            return sum;
+        };
+        {   // lambda(v): product of the children's lambda-messages from 1.0, ascending (:220-238)
+            double acc = children_product(1.0, lane < kv ? lane : 0, -1);
+            acc /= vector_sum(acc, 0);
             if (active && lane < kv) nout[nidx(kvp / 2, lane)] = frozen ? lav : acc;
             if (active && lane == kv && kvp > kv) nout[nidx(kvp / 2, lane)] = 0.0;
         }
         for (int base = 0; base < total; base += chunk) {
             const int idx = base + lane;
             const bool mine = lane < chunk && idx < total;
-            const int cc = mine ? idx / kv : 0, ii = mine ? idx - cc * kv : 0;
+            const int cc = mine ? div_kv(idx) : 0, ii = mine ? idx - cc * kv : 0;
             // pi-message to child cc (:202-218): pi(v)[i] * the OTHER children's lambda-messages, ascending
-            double u = shfl_d(piv, gb + ii);
-            for (int x = 0; x < cmax; ++x)
-                if (x != cc) u *= LK[x * kv + ii];
-            double sum = 0.0;
-            for (int dd = 0; dd < kv; ++dd) sum += shfl_d(u, gb + lane - ii + dd);
-            u /= sum;
+            double u = children_product(shfl_d(piv, gb + ii), ii, cc);
+            u /= vector_sum(u, lane - ii);
             if (mine && active) {
-                const Loc l = base == 0 ? pl0 : decode_ref(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], kvp / 2);
+                const Loc l = base == 0 ? pl0 : decode_ref_magic(b.out_refs[td.out_base + int64_t(cc) * NPT + nlc], c.magic_hv);
                 if (l.has) {
                     const int64_t at = (l.pi + int64_t(ii >> 1) * l.stride) * 2 + (ii & 1);
                     const double old = io.first ? 1.0 : (base == 0 ? pold0 : io.rec_in[at]);
@@ -1298,6 +1446,13 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
                 }
             }
         }
+        TILE_STAMP(8);  // parent role done
+#ifdef BN_TILE_CLOCK
+        if (wlane == 0 && td.slot_base < kTileClockTiles) {
+            g_tile_clock[td.slot_base][10] = (unsigned long long)G | ((unsigned long long)m << 8) | ((unsigned long long)kv << 16) |
+                                             ((unsigned long long)cmax << 24) | ((unsigned long long)rows << 32);
+        }
+#endif
     } else if (lane == 0 && active) {
         wres = res_acc(wres, parent_role_generic(b, io, td, kv, kvp, nl, frozen, true));
     }

@@ -118,5 +118,5 @@ def test_mirror_class_run_batch(bnlib):
     assert len(got) == len(queries)
     for q, pre in enumerate(queries):
         want = bp(pre, 1e-9)
-        for v in want:
+        for v in range(m.n):
             assert np.array_equal(got[q][v], want[v])
