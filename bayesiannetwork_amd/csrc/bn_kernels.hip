@@ -36,10 +36,19 @@ __global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepA
         return;
     }
     const IO io{a.rec_in, a.rec_out, a.node_in, a.node_out, a.sweep == 0};
+#ifdef BN_TILE_CLOCK
+    const unsigned long long t_entry = wall_clock64();
+#endif
     const TileDesc td = b.tiles[tile];
     if (done != 0) return;
     const double wres = run_tile_light(b, io, td, lane, flat_lds[wave]);
     publish_residual(b, a.rec_out, tile, wres, lane);
+#ifdef BN_TILE_CLOCK
+    if (lane == 0 && td.slot_base < kTileClockTiles) {
+        g_tile_clock[td.slot_base][9] = t_entry;
+        g_tile_clock[td.slot_base][11] = wall_clock64();
+    }
+#endif
 }
 
 // bn_bp_set_evidence: apply the evidence (belief_propagation.hpp:68-73) to the nodes this rank owns:
@@ -165,3 +174,11 @@ int launch_bp_finish(const FinishArgs& a, int grid_blocks, int n_sets, void* str
 }
 
 }  // namespace bnmi
+
+#ifdef BN_TILE_CLOCK
+// diagnostic builds only: the stamps of the last launch of the light kernel
+extern "C" int bn_debug_tile_clock_light(unsigned long long* out, int n_tiles) {
+    if (n_tiles > bnmi::kTileClockTiles) n_tiles = bnmi::kTileClockTiles;
+    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_tile_clock), sizeof(unsigned long long) * bnmi::kTileClockStamps * n_tiles));
+}
+#endif

@@ -149,16 +149,17 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         sig.clear();
         sig.push_back(p.k[v]);
         for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) sig.push_back(p.k[p.in_idx[e]]);
-        // flat tiles stage the children's lambda-messages in the group's share of LDS (4 doubles per
-        // lane): a node with many children needs a wider group than its table does, so the width
-        // wanted by the out-degree is part of the class key (ignored by the other variants)
+        // flat tiles serve child (c, i) of the parent role on lane c * kv + i of the node's group, one pass per
+        // G / kv children (each pass costs a dependent round trip: reference -> the child's record): a node with
+        // many children gets a group wide enough for ONE pass, so the width wanted by the out-degree is part
+        // of the class key (ignored by the other variants)
         int32_t g_children = 0;
         bool templated, flat_ok;
         shape_of(v, templated, flat_ok);
         if (prefer_flat && flat_ok) templated = false;
         if (!templated && flat_ok) {
             g_children = 8;
-            while (g_children < kWave && int64_t(out_ptr[v + 1] - out_ptr[v]) * p.k[v] > 4 * g_children) g_children *= 2;
+            while (g_children < kWave && int64_t(out_ptr[v + 1] - out_ptr[v]) > g_children / p.k[v]) g_children *= 2;
         }
         sig.push_back(g_children);
         auto it = sig2cls.find(sig);

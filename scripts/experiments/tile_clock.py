@@ -31,6 +31,10 @@ with Engine(m) as e:
     rc = L.bn_debug_tile_clock(buf.ctypes.data_as(ctypes.c_void_p), n)
     assert rc == 0, rc
     rows = [(i, b) for i, b in enumerate(buf) if b[11] != 0]
+    if not rows:  # a network of any-arity tiles only runs the light kernel (another translation unit)
+        rc = L.bn_debug_tile_clock_light(buf.ctypes.data_as(ctypes.c_void_p), n)
+        assert rc == 0, rc
+        rows = [(i, b) for i, b in enumerate(buf) if b[11] != 0]
     t0 = min(int(b[9]) for _, b in rows)
     print(name, "sweeps", r["sweeps"], "tiles stamped", len(rows), "(x10 ns; columns: entry->s0 desc, s1 class, s2 loads issued, s3 inputs arrived,"
           " s4 pi summed, s5 lambda summed, s6 normalised+stored, s7 children staged, s8 parent role, end)")
