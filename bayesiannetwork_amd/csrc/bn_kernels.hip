@@ -175,10 +175,4 @@ int launch_bp_finish(const FinishArgs& a, int grid_blocks, int n_sets, void* str
 
 }  // namespace bnmi
 
-#ifdef BN_TILE_CLOCK
-// diagnostic builds only: the stamps of the last launch of the light kernel
-extern "C" int bn_debug_tile_clock_light(unsigned long long* out, int n_tiles) {
-    if (n_tiles > bnmi::kTileClockTiles) n_tiles = bnmi::kTileClockTiles;
-    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_tile_clock), sizeof(unsigned long long) * bnmi::kTileClockStamps * n_tiles));
-}
-#endif
+BN_TILE_CLOCK_GETTER(bn_debug_tile_clock_light)

@@ -92,3 +92,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void bp_sweep_kernel(SweepArgs a_
 
 
 }  // namespace bnmi
+
+// diagnostic builds only: every translation unit with sweep kernels has its own copy of the stamps and a getter for them
+#ifdef BN_TILE_CLOCK
+#define BN_TILE_CLOCK_GETTER(name)                                                                                          \
+    extern "C" int name(unsigned long long* out, int n_tiles) {                                                             \
+        if (n_tiles > bnmi::kTileClockTiles) n_tiles = bnmi::kTileClockTiles;                                               \
+        return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_tile_clock),                                                 \
+                                       sizeof(unsigned long long) * bnmi::kTileClockStamps * n_tiles));                     \
+    }
+#else
+#define BN_TILE_CLOCK_GETTER(name)
+#endif

@@ -16,10 +16,4 @@ int launch_bp_sweep_all(const SweepArgs& a, int grid_blocks, int n_sets, void* s
 
 }  // namespace bnmi
 
-#ifdef BN_TILE_CLOCK
-// diagnostic builds only: the stamps of the last launch of this translation unit's kernels
-extern "C" int bn_debug_tile_clock(unsigned long long* out, int n_tiles) {
-    if (n_tiles > bnmi::kTileClockTiles) n_tiles = bnmi::kTileClockTiles;
-    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_tile_clock), sizeof(unsigned long long) * bnmi::kTileClockStamps * n_tiles));
-}
-#endif
+BN_TILE_CLOCK_GETTER(bn_debug_tile_clock)

@@ -16,3 +16,5 @@ int launch_bp_sweep_u(const SweepArgs& a, int grid_blocks, int n_sets, bool nont
 }
 
 }  // namespace bnmi
+
+BN_TILE_CLOCK_GETTER(bn_debug_tile_clock_u)

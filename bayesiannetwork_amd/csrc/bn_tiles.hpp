@@ -424,6 +424,10 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
     constexpr int CB = (M > 0) ? C / K : 0;  // assignments per lambda bucket and own state
     double wres = 0.0;
     if (lane < td.n_nodes) {
+#ifdef BN_TILE_CLOCK
+        const int wlane_for_stamp = lane;
+#endif
+        TILE_STAMP(0);
         // ---- parent-role loads FIRST: the out-edge references head a dependent chain
         // (reference -> child record), so they are issued before the 32 CPT loads stream in
         const double2_t* rec_in2 = reinterpret_cast<const double2_t*>(io.rec_in);
@@ -508,6 +512,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             }
         }
 
+        TILE_STAMP(1);  // loads issued
         // ---- child role.  calculate_pi (:174-200): pi[i] = sum over assignments (ascending) of
         // cpt * pi-messages (ascending parent order).  calculate_lambda_k (:240-266): bucket
         // out[jt][ct] receives, own state outer and assignment inner, (lambda[i] * cpt) * the
@@ -556,6 +561,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
             }
         }
 
+        TILE_STAMP(2);  // contraction
         // ---- parent role: lambda(v) (:220-238), products in ascending child order from 1.0
         double lan[K];
 #pragma unroll
@@ -612,6 +618,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                 bn_store<NT>(&rec_out2[in_idx(jt, 1, h)], y);
             }
         }
+        TILE_STAMP(3);  // node vectors and lambda-messages normalised and stored
         // pi-message to child c (:202-218): pi(v) times the OTHER children's lambda-messages
 #pragma unroll
         for (int c = 0; c < RC; ++c) {
@@ -651,8 +658,15 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
                 }
             }
         }
+        TILE_STAMP(4);  // fused pi-messages
         if constexpr (RC == 0)  // more children than the fused path holds: separate parent role
             wres = res_acc(wres, parent_role_any<K, NT, 16>(b, io, td, lane, frozen, piv, lav));
+        TILE_STAMP(5);  // separate parent role
+#ifdef BN_TILE_CLOCK
+        if (lane == 0 && td.slot_base < kTileClockTiles)
+            g_tile_clock[td.slot_base][10] = (unsigned long long)RC | ((unsigned long long)M << 8) | ((unsigned long long)K << 16) |
+                                             ((unsigned long long)td.cmax << 24) | (0xfffeull << 32);
+#endif
     }
     return wres;
 }
@@ -680,6 +694,10 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
     const bool active = nl < td.n_nodes;
     double wres = 0.0;
 
+#ifdef BN_TILE_CLOCK
+    const int wlane_for_stamp = lane;
+#endif
+    TILE_STAMP(0);
     // ---- loads: this lane's 64 CPT entries (i-major: q = i*16 + c_{M-2}*4 + c_{M-1})
     const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
     double cpt[64];
@@ -752,6 +770,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
             fold[2 * h] = y.x; fold[2 * h + 1] = y.y;
         }
     }
+    TILE_STAMP(1);  // first-trip loads issued
     // ---- parent role (:202-238), spread over the group's lanes: lane g serves children g, g+G, ...
     // of node nl.  It needs only the OLD pi(v)/lambda(v) and the children's records, so its loads
     // ride behind the CPT stream and its arithmetic is cmax steps for the whole group instead of
@@ -783,6 +802,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
                 }
             }
         }
+        TILE_STAMP(2);  // children's records requested (the references have arrived)
         double lam_all[K], msg[CPL][K];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -830,6 +850,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
         }
     }
 
+    TILE_STAMP(3);  // parent role done (the children's records have arrived)
     // pi-message entries of the lane-fixed parents
     double pfix[D];
 #pragma unroll
@@ -880,6 +901,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
         pp[ib] = acc;
     }
 
+    TILE_STAMP(4);  // contraction over this lane's 64 entries
     // ---- combine inside the G-lane group
 #pragma unroll
     for (int mask = 1; mask < G; mask <<= 1) {
@@ -906,6 +928,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
         for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
     }
 
+    TILE_STAMP(5);  // combined inside the group
     // ---- lanes 0..M of the group finish the node: normalise, residual, stores
     {
         double o[K];
@@ -936,6 +959,11 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
             }
         }
     }
+    TILE_STAMP(6);  // normalised and stored
+#ifdef BN_TILE_CLOCK
+    if (lane == 0 && td.slot_base < kTileClockTiles)
+        g_tile_clock[td.slot_base][10] = (unsigned long long)G | ((unsigned long long)M << 8) | (4ull << 16) | ((unsigned long long)td.cmax << 24) | (0xffffull << 32);
+#endif
     if (active && g == 0) {
         if (io.first && !frozen) {  // initial state (:38-41); a group node always has parents
 #pragma unroll
