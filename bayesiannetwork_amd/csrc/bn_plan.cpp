@@ -124,6 +124,13 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         }
         templated = (same && S <= 64) || (same && kv == 4 && m >= 3 && m <= 5 && d.lanes_per_node != 1);
         flat_ok = d.lanes_per_node != 1 && m <= kFlatMaxParents && sum_kp <= kWave && kv <= kWave && S < (int64_t(1) << 22);
+        // A one-lane tile serves all children of a node on that node's lane: up to 4 fused with the child role,
+        // beyond that in fully unrolled code that costs ~1 us per child (measured with the tile stamps: mostly
+        // instruction fetch).  The any-arity tile gives every (child, state) a lane of its own, so a node with
+        // more than 4 children goes there (its <= 64-entry table takes the ordered path: same bits).
+        if (same && S <= 64 && flat_ok && d.lanes_per_node == 0 && out_ptr[v + 1] - out_ptr[v] > 4 &&
+            int64_t(out_ptr[v + 1] - out_ptr[v]) * kv <= kWave)
+            templated = false;
     };
     // A network made mostly of any-arity tiles runs them all that way: the launch without
     // register-resident tiles has twice the occupancy, which is what those latency-bound tiles need.
