@@ -2,6 +2,7 @@
 #include "bn_plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -14,9 +15,11 @@ static inline int32_t round_even(int32_t x) { return (x + 1) & ~1; }
 // Lanes per node.  k = 4 with 3, 4 or 5 parents: 4, 16 or 64 lanes cooperate on one node, each
 // owning the 64 CPT entries of one assignment of the leading parents -- the same per-lane footprint
 // as the register-resident path -- and the partial sums are combined with wave shuffles.
-static int pick_lanes(int kv, int m, bool all_k4, int forced) {
+// Lanes per node of the lane-group variant (k = 4, 3..5 parents): 4^(m-2), 64 table entries per lane; `wide`
+// (3 or 4 parents): 4^(m-1), 16 entries per lane -- four times the waves, a quarter of the serial work per wave.
+static int pick_lanes(int kv, int m, bool all_k4, int forced, bool wide) {
     if (forced == 1) return 1;
-    if (kv == 4 && all_k4 && m >= 3 && m <= 5) return 1 << (2 * (m - 2));
+    if (kv == 4 && all_k4 && m >= 3 && m <= 5) return 1 << (2 * (m - ((wide && m <= 4) ? 1 : 2)));
     return 1;
 }
 
@@ -146,6 +149,26 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         prefer_flat = n_flat_only >= 2 * n_templ && n_convertible == n_templ && n_flat_only > 0;
     }
 
+    // The lane-group split: a network whose lane-group tiles leave SIMDs idle is bound by the latency of ONE
+    // tile (tile stamps: 4.2 of a 4-parent tile's 8.9 us are the contraction over its 64 entries per lane on a
+    // SIMD that holds no other wave), so it takes the wide split while that still means at most one wave per
+    // SIMD (measured, us per sweep, 64 -> 16 entries per lane: 200-node DAG 9.8 -> 8.6, 1000 nodes 10.1 -> 9.2,
+    // 3000 nodes 10.3 -> 9.4; 10 k nodes = 2 699 tiles 11.9 -> 15.8: throughput-bound, keeps 64).  Decided on
+    // the whole model: every rank alike.
+    bool group_wide = false;
+    {
+        int64_t wide_tiles = 0;
+        for (int32_t v = 0; v < n; ++v) {
+            const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
+            bool same = kv == 4 && m >= 3 && m <= 5;
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1] && same; ++e) same = p.k[p.in_idx[e]] == 4;
+            if (same) wide_tiles += m == 3 ? 1 : 4;  // in quarters of a wave: 4 nodes per wave at m = 3, one at m = 4, 5
+        }
+        wide_tiles /= 4;
+        static const char* force = std::getenv("BN_GROUP_WIDE");  // A/B switch: 0 / 1
+        group_wide = force ? force[0] == '1' : wide_tiles <= 1024;
+    }
+
     // ---- shape classes over the owned nodes
     std::map<std::vector<int32_t>, int32_t> sig2cls;
     p.node_class.assign(n, -1);
@@ -188,7 +211,7 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             c.rows = int32_t(rows);
             const bool all_k4 = uniform && c.kv == 4;
             if (int64_t(c.kv) * rows > 64) uniform = false;  // register-resident CPT: <= 64 entries
-            c.G = pick_lanes(c.kv, c.m, all_k4, d.lanes_per_node);
+            c.G = pick_lanes(c.kv, c.m, all_k4, d.lanes_per_node, group_wide);
             c.variant = c.G > 1 ? kVariantGroup : (uniform ? kVariantUniform : kVariantGeneric);
             if (g_children > 0) { c.G = 1; c.variant = kVariantGeneric; }  // the any-arity variant was chosen above
             // every other shape: one wavefront per node (lanes_per_node == 1 keeps the

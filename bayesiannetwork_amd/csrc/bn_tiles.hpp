@@ -672,11 +672,12 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
 }
 
 // ---------------------------------------------------------------------------------------------
-// lane-group tile: k = 4, M = D + 2 parents, G = 4^D lanes per node (NPT = 64 / G nodes per
-// wave).  Lane (nl, g) owns the assignments whose D leading parents are in state digits(g) -- 64
-// CPT entries, the two trailing parents and the own state -- streams them through registers like
-// the register-resident path, and the partial sums are combined inside the G-lane group with
-// shuffles.  Products keep the reference's ascending-parent order (:190-193, :250-258); the SUM
+// lane-group tile: k = 4, M = D + T parents, G = 4^D lanes per node (NPT = 64 / G nodes per
+// wave).  Lane (nl, g) owns the assignments whose D leading parents are in state digits(g) -- the
+// T trailing parents and the own state: 64 CPT entries with T = 2, 16 with T = 1 (four times the
+// waves, a quarter of the serial work per wave: what a latency-bound network wants, bn_plan.cpp) --
+// streams them through registers like the register-resident path, and the partial sums are combined
+// inside the G-lane group with shuffles.  Products keep the reference's ascending-parent order (:190-193, :250-258); the SUM
 // over assignments is re-associated across lanes, so results agree with the reference to
 // rounding (not bit-for-bit; with >= 3 parents the reference's own products are unordered, :253).
 // ---------------------------------------------------------------------------------------------
@@ -686,10 +687,12 @@ __device__ __forceinline__ double pick4(const double (&v)[4], int d) {
     return d == 0 ? v[0] : (d == 1 ? v[1] : (d == 2 ? v[2] : v[3]));
 }
 
-template <int D, bool NT>
+template <int D, int T, bool NT>
 __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, const TileDesc& td, int lane) {
-    constexpr int K = 4, H = 2, M = D + 2;
+    constexpr int K = 4, H = 2, M = D + T;
     constexpr int G = 1 << (2 * D), NPT = kWave / G;
+    constexpr int CL = 1 << (2 * T), E = K * CL;  // assignments of the T trailing parents, CPT entries per lane
+    static_assert(T == 1 || T == 2, "one or two trailing parents per lane");
     const int nl = lane / G, g = lane % G;
     const bool active = nl < td.n_nodes;
     double wres = 0.0;
@@ -698,11 +701,11 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
     const int wlane_for_stamp = lane;
 #endif
     TILE_STAMP(0);
-    // ---- loads: this lane's 64 CPT entries (i-major: q = i*16 + c_{M-2}*4 + c_{M-1})
+    // ---- loads: this lane's E CPT entries (i-major: q = i*CL + the trailing parents' states, last parent fastest)
     const double2_t* cp = reinterpret_cast<const double2_t*>(b.cpt + td.cpt_base) + lane;
-    double cpt[64];
+    double cpt[E];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
+    for (int q = 0; q < E / 2; ++q) {
         const double2_t x = cpt_load<NT>(&cp[q * kWave]);
         cpt[2 * q] = x.x;
         cpt[2 * q + 1] = x.y;
@@ -858,10 +861,10 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 
     // ---- partial sums over this lane's 64 entries
     double pp[K];          // pi(v)[i]
-    double ol[2][K];       // lambda-messages to the two trailing parents, by target state
+    double ol[T][K];       // lambda-messages to the trailing parents, by target state
     double sf[D];          // lambda-messages to the leading parents: this lane's own bucket
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int ct = 0; ct < K; ++ct) ol[t][ct] = 0.0;
 #pragma unroll
@@ -870,45 +873,53 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
     for (int ib = 0; ib < K; ++ib) {
         double acc = 0.0;
 #pragma unroll
-        for (int cl = 0; cl < 16; ++cl) {
-            const int ca = cl >> 2, cb = cl & 3;  // states of parents M-2 and M-1
-            const double e = cpt[ib * 16 + cl];
+        for (int cl = 0; cl < CL; ++cl) {
+            int ct[T];  // states of the trailing parents D .. M-1 in this assignment
+#pragma unroll
+            for (int t = 0; t < T; ++t) ct[t] = (cl >> (2 * (T - 1 - t))) & 3;
+            const double e = cpt[ib * CL + cl];
             // calculate_pi: cpt * pi-messages, ascending parent order
             double v = e;
 #pragma unroll
             for (int j = 0; j < D; ++j) v *= pfix[j];
-            v *= pim[M - 2][ca];
-            v *= pim[M - 1][cb];
+#pragma unroll
+            for (int t = 0; t < T; ++t) v *= pim[D + t][ct[t]];
             acc += v;
             // calculate_lambda_k: (lambda[i] * cpt) * the OTHER parents' pi-messages, ascending
             const double tc = lav[ib] * e;
             double pre = tc;  // shared prefix over the leading parents
 #pragma unroll
             for (int j = 0; j < D; ++j) pre *= pfix[j];
-            ol[0][ca] += pre * pim[M - 1][cb];
-            ol[1][cb] += pre * pim[M - 2][ca];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                double w = pre;
+#pragma unroll
+                for (int t2 = 0; t2 < T; ++t2)
+                    if (t2 != t) w *= pim[D + t2][ct[t2]];
+                ol[t][ct[t]] += w;
+            }
 #pragma unroll
             for (int jt = 0; jt < D; ++jt) {
                 double w = tc;
 #pragma unroll
                 for (int j = 0; j < D; ++j)
                     if (j != jt) w *= pfix[j];
-                w *= pim[M - 2][ca];
-                w *= pim[M - 1][cb];
+#pragma unroll
+                for (int t = 0; t < T; ++t) w *= pim[D + t][ct[t]];
                 sf[jt] += w;
             }
         }
         pp[ib] = acc;
     }
 
-    TILE_STAMP(4);  // contraction over this lane's 64 entries
+    TILE_STAMP(4);  // contraction over this lane's entries
     // ---- combine inside the G-lane group
 #pragma unroll
     for (int mask = 1; mask < G; mask <<= 1) {
 #pragma unroll
         for (int i = 0; i < K; ++i) pp[i] += shfl_xor_d(pp[i], mask);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int ct = 0; ct < K; ++ct) ol[t][ct] += shfl_xor_d(ol[t][ct], mask);
     }
@@ -1529,9 +1540,10 @@ __device__ __forceinline__ double run_tile(const BpBuffers& b, const IO& io, con
         if (td.variant == kVariantGroup) {
             handled = true;
             switch (td.m) {
-                case 3: wres = tile_group<1, NT>(b, io, td, lane); break;
-                case 4: wres = tile_group<2, NT>(b, io, td, lane); break;
-                case 5: wres = tile_group<3, NT>(b, io, td, lane); break;
+                // npt tells the split: 4^(m-2) lanes per node (64 entries per lane) or 4^(m-1) (16 entries per lane)
+                case 3: wres = td.npt == 16 ? tile_group<1, 2, NT>(b, io, td, lane) : tile_group<2, 1, NT>(b, io, td, lane); break;
+                case 4: wres = td.npt == 4 ? tile_group<2, 2, NT>(b, io, td, lane) : tile_group<3, 1, NT>(b, io, td, lane); break;
+                case 5: wres = tile_group<3, 2, NT>(b, io, td, lane); break;
                 default: handled = false; break;
             }
         }
