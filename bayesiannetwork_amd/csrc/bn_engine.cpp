@@ -164,6 +164,9 @@ struct bn_engine {
         std::vector<double> residual;
         bool have_run = false;
     } batch;
+    bool batch_on_dense = false;    // the current batch lives in `dense`
+    bn_engine* dense = nullptr;     // a second engine with the dense layout: batches on a network whose own layout trades
+                                    // wavefront count for one query's latency (Plan::latency_rules_applied) run there
     int multisweep = 1;             // resident one-launch path: 0 never, 1 where it was measured faster (one block, or
                                     // >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
     int32_t last_path = 0;          // 0 per-sweep launches, 1 one launch for the whole run
@@ -182,6 +185,7 @@ struct bn_engine {
 
 static void free_engine(bn_engine* e) {
     if (!e) return;
+    if (e->dense) { free_engine(e->dense); e->dense = nullptr; }
     if (!e->host_only) {
         DeviceGuard guard;
         (void)guard.enter(e->device);
@@ -743,10 +747,52 @@ static BpBuffers batch_buffers_of(bn_engine* e, int32_t q) {
     return b;
 }
 
+// Batches want throughput; a layout built for the latency of one query (wide lane groups, any-arity tiles for
+// nodes with many children: bn_plan.cpp) has up to 4x the wavefronts.  Such an engine answers batches of two or more
+// sets through a second engine built from the same model with the dense layout (lanes_per_node = 2); the networks
+// this concerns are small, so the second copy is too.  Created at the first such call.
+static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) {
+    rc = BN_OK;
+    if (!e->plan.latency_rules_applied || e->plan.nranks > 1 || n_sets < 2) return nullptr;
+    if (!e->dense) {
+        const Plan& p = e->plan;
+        bn_model_desc d;
+        d.n_nodes = p.n;
+        d.k = p.k.data(); d.in_ptr = p.in_ptr.data(); d.in_idx = p.in_idx.data();
+        d.cpt_off = p.cpt_off.data(); d.cpt = p.cpt_flat.data();
+        d.device = e->device;
+        d.lanes_per_node = p.wide_requested ? 4 : 2;  // same lane-group split: same bits as this engine's single queries
+        rc = bn_create(&d, &e->dense);
+        if (rc) { e->dense = nullptr; return nullptr; }
+    }
+    e->dense->multisweep = e->multisweep;
+    e->dense->timing = e->timing;
+    return e->dense;
+}
+static void adopt_batch_outcome(bn_engine* e) {  // what bn_bp_stats / bn_bp_last_path report after a forwarded batch
+    e->last_path = e->dense->last_path;
+    const bn_bp_stats own = e->stats;
+    e->stats = e->dense->stats;
+    e->stats.algorithmic_bytes_per_sweep = own.algorithmic_bytes_per_sweep;
+    e->stats.layout_bytes_per_sweep = own.layout_bytes_per_sweep;
+    e->stats.messages_per_sweep = own.messages_per_sweep;
+}
+
 extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int32_t* ne, const int32_t* ev_node,
                                         const int32_t* ev_off, const double* ev_val) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    e->batch_on_dense = false;
+    if (n_sets >= 1 && n_sets <= BN_MAX_BATCH_SETS) {
+        int rc;
+        if (bn_engine* de = dense_engine_for_batch(e, n_sets, rc)) {
+            rc = bn_bp_set_evidence_batch(de, n_sets, ne, ev_node, ev_off, ev_val);
+            e->batch_on_dense = rc == BN_OK;
+            return rc;
+        } else if (rc) {
+            return rc;
+        }
+    }
     if (n_sets < 1 || n_sets > BN_MAX_BATCH_SETS) return fail(BN_ERR_ARG, "n_sets must be in 1.." + std::to_string(BN_MAX_BATCH_SETS));
     if (e->plan.nranks > 1) return fail(BN_ERR_STATE, "batched evidence sets are not available on sharded engines");
     if (!ne) return fail(BN_ERR_ARG, "null ne");
@@ -938,6 +984,12 @@ static int run_batch_launches(bn_engine* e, double eps, int32_t max_sweeps) {
 
 extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->batch_on_dense && e->dense) {
+        e->dense->multisweep = e->multisweep;
+        const int rc = bn_bp_run_batch_device(e->dense, eps, max_sweeps, sweeps_out, residual_out);
+        if (rc == BN_OK) adopt_batch_outcome(e);
+        return rc;
+    }
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
     bn_engine::Batch& bt = e->batch;
@@ -988,6 +1040,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
 
 extern "C" int bn_bp_copy_beliefs_batch(bn_engine* e, double* beliefs_out) {
     if (!e || !beliefs_out) return fail(BN_ERR_ARG, "null argument");
+    if (e->batch_on_dense && e->dense) return bn_bp_copy_beliefs_batch(e->dense, beliefs_out);
     if (e->host_only || !e->batch.have_run) return fail(BN_ERR_STATE, "no batched run to copy from");
     ON_DEVICE(e);
     HIPCHK(hipMemcpyAsync(beliefs_out, e->batch.d_beliefs, sizeof(double) * size_t(e->batch.n_sets) * e->plan.node_off[e->plan.n],
@@ -998,6 +1051,7 @@ extern "C" int bn_bp_copy_beliefs_batch(bn_engine* e, double* beliefs_out) {
 
 extern "C" int bn_bp_residual_history_batch(bn_engine* e, int32_t set, double* out, int32_t cap) {
     if (!e || !out || cap < 0) return fail(BN_ERR_ARG, "bad argument");
+    if (e->batch_on_dense && e->dense) return bn_bp_residual_history_batch(e->dense, set, out, cap);
     if (e->host_only || !e->batch.have_run) return fail(BN_ERR_STATE, "no batched run yet");
     if (set < 0 || set >= e->batch.n_sets) return fail(BN_ERR_ARG, "set index out of range");
     const int32_t cnt = std::min({cap, e->batch.sweeps[set], e->res_cap});

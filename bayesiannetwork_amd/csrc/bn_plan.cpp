@@ -39,7 +39,15 @@ void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>&
     }
 }
 
-std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) {
+std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& p) {
+    // lanes_per_node: 0 automatic, 2 dense (automatic without the any-arity rule for nodes with many children),
+    // 3 / 4 = 0 / 2 plus the wide lane-group split on small networks (bn_mi355x.h)
+    bn_model_desc d = d_in;
+    const bool latency_rules = d_in.lanes_per_node == 0 || d_in.lanes_per_node == 3;
+    const bool wide_requested = d_in.lanes_per_node == 3 || d_in.lanes_per_node == 4;
+    if (d.lanes_per_node >= 2 && d.lanes_per_node <= 4) d.lanes_per_node = 0;
+    p.latency_rules_applied = false;
+    p.wide_requested = wide_requested;
     const int32_t n = d.n_nodes;
     if (n < 0) return "n_nodes < 0";
     if (n > 0 && (!d.k || !d.in_ptr || !d.cpt_off)) return "null model array";
@@ -114,6 +122,32 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             }
     }
 
+    // The lane-group split (opt-in, lanes_per_node 3 / 4: it re-associates the sums over assignments, so its
+    // marginals differ from the 64-entries-per-lane split in the last bits -- both within rounding of the
+    // reference, whose own >= 3-parent products are unordered -- and it quadruples the wavefronts a batch pays
+    // for): a network whose lane-group tiles leave SIMDs idle is bound by the latency of ONE
+    // tile (tile stamps: 4.2 of a 4-parent tile's 8.9 us are the contraction over its 64 entries per lane on a
+    // SIMD that holds no other wave), so it takes the wide split while that still means at most one wave per
+    // SIMD (measured, us per sweep, 64 -> 16 entries per lane: 200-node DAG 9.8 -> 8.6, 1000 nodes 10.1 -> 9.2,
+    // 3000 nodes 10.3 -> 9.4; 10 k nodes = 2 699 tiles 11.9 -> 15.8: throughput-bound, keeps 64).  Decided on
+    // the whole model: every rank alike.
+    bool group_wide = false;
+    int64_t est_tiles = 0;  // wavefronts of the dense layout, estimated before the classes exist
+    {
+        int64_t wide_tiles = 0, dense64 = 0;
+        for (int32_t v = 0; v < n; ++v) {
+            const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
+            bool same = kv == 4 && m >= 3 && m <= 5;
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1] && same; ++e) same = p.k[p.in_idx[e]] == 4;
+            if (same) wide_tiles += m == 3 ? 1 : 4;  // in quarters of a wave: 4 nodes per wave at m = 3, one at m = 4, 5
+            dense64 += !same ? 1 : (m == 3 ? 4 : (m == 4 ? 16 : 64));  // in 64ths of a wave
+        }
+        wide_tiles /= 4;
+        est_tiles = dense64 / 64;
+        static const char* force = std::getenv("BN_GROUP_WIDE");  // A/B switch: 0 / 1
+        group_wide = force ? force[0] == '1' : (wide_requested && wide_tiles > 0 && wide_tiles <= 1024);
+    }
+
     // ---- which nodes have a templated variant, which can take the any-arity variant
     auto shape_of = [&](int32_t v, bool& templated, bool& flat_ok) {
         const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
@@ -130,10 +164,13 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
         // A one-lane tile serves all children of a node on that node's lane: up to 4 fused with the child role,
         // beyond that in fully unrolled code that costs ~1 us per child (measured with the tile stamps: mostly
         // instruction fetch).  The any-arity tile gives every (child, state) a lane of its own, so a node with
-        // more than 4 children goes there (its <= 64-entry table takes the ordered path: same bits).
-        if (same && S <= 64 && flat_ok && d.lanes_per_node == 0 && out_ptr[v + 1] - out_ptr[v] > 4 &&
-            int64_t(out_ptr[v + 1] - out_ptr[v]) * kv <= kWave)
+        // more than 4 children goes there (its <= 64-entry table takes the ordered path: same bits) -- while the
+        // network is small enough to be bound by the latency of one tile; it costs wavefronts.
+        if (same && S <= 64 && flat_ok && latency_rules && est_tiles <= 1024 && out_ptr[v + 1] - out_ptr[v] > 4 &&
+            int64_t(out_ptr[v + 1] - out_ptr[v]) * kv <= kWave) {
             templated = false;
+            p.latency_rules_applied = true;
+        }
     };
     // A network made mostly of any-arity tiles runs them all that way: the launch without
     // register-resident tiles has twice the occupancy, which is what those latency-bound tiles need.
@@ -147,26 +184,6 @@ std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& p) 
             else if (f) ++n_flat_only;
         }
         prefer_flat = n_flat_only >= 2 * n_templ && n_convertible == n_templ && n_flat_only > 0;
-    }
-
-    // The lane-group split: a network whose lane-group tiles leave SIMDs idle is bound by the latency of ONE
-    // tile (tile stamps: 4.2 of a 4-parent tile's 8.9 us are the contraction over its 64 entries per lane on a
-    // SIMD that holds no other wave), so it takes the wide split while that still means at most one wave per
-    // SIMD (measured, us per sweep, 64 -> 16 entries per lane: 200-node DAG 9.8 -> 8.6, 1000 nodes 10.1 -> 9.2,
-    // 3000 nodes 10.3 -> 9.4; 10 k nodes = 2 699 tiles 11.9 -> 15.8: throughput-bound, keeps 64).  Decided on
-    // the whole model: every rank alike.
-    bool group_wide = false;
-    {
-        int64_t wide_tiles = 0;
-        for (int32_t v = 0; v < n; ++v) {
-            const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
-            bool same = kv == 4 && m >= 3 && m <= 5;
-            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1] && same; ++e) same = p.k[p.in_idx[e]] == 4;
-            if (same) wide_tiles += m == 3 ? 1 : 4;  // in quarters of a wave: 4 nodes per wave at m = 3, one at m = 4, 5
-        }
-        wide_tiles /= 4;
-        static const char* force = std::getenv("BN_GROUP_WIDE");  // A/B switch: 0 / 1
-        group_wide = force ? force[0] == '1' : wide_tiles <= 1024;
     }
 
     // ---- shape classes over the owned nodes

@@ -140,6 +140,8 @@ struct Plan {
     // classes / tiles (owned nodes only)
     std::vector<ClassDesc> classes;
     std::vector<FlatEntry> flat_tab;  // per ordered any-arity class, 2 G entries (ClassDesc::flat_tab_off)
+    bool latency_rules_applied = false;  // the layout trades wavefront count for the latency of one query (bn_plan.cpp)
+    bool wide_requested = false;         // lanes_per_node 3 / 4
     std::vector<TileDesc> tiles;
     std::vector<int32_t> node_class; // [n]   -1 for nodes of other ranks
     std::vector<int32_t> node_slot;  // [n]   tiles[t].slot_base + nl, or -1

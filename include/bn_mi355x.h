@@ -56,8 +56,16 @@ typedef struct bn_model_desc {
     const int64_t *cpt_off; /* [n+1]  prefix sums of k[v] * prod k[parents]            */
     const double *cpt;      /* flat CPTs, reference row order                          */
     int32_t device;         /* HIP ordinal, BN_DEVICE_CURRENT or BN_DEVICE_HOST_ONLY   */
-    int32_t lanes_per_node; /* 0 = automatic; 1 = one lane per node everywhere (no lane  */
-                            /* groups, no wavefront-per-node variant: A/B tests)      */
+    int32_t lanes_per_node; /* 0 = automatic: small networks get a layout that shortens the   */
+                            /*     latency of ONE query (more, lighter wavefronts);          */
+                            /* 1 = one lane per node everywhere (no lane groups, no          */
+                            /*     wavefront-per-node variant: A/B tests);                   */
+                            /* 2 = dense: fewest wavefronts, for throughput (what the engine */
+                            /*     builds internally for bn_bp_run_batch on such networks);  */
+                            /* 3, 4 = 0, 2 plus the wide lane-group split (k = 4 with 3 or 4 */
+                            /*     parents: 16 table entries per lane instead of 64) on small*/
+                            /*     networks: ~10 % less latency per query, 4x the wavefronts;*/
+                            /*     marginals agree with 0 / 2 to rounding, not bit for bit   */
 } bn_model_desc;
 
 typedef struct bn_engine bn_engine;

@@ -179,3 +179,29 @@ def test_gpu_full_size_dag_config2(Engine, oracle_mod):
             r = eng.bp_run(ev, eps)
         assert r["sweeps"] == o["sweeps"]
         assert rel_err(r["beliefs"], o["beliefs"]) < 1e-9
+
+
+def test_layout_options_same_results(Engine, oracle_mod):
+    """bn_model_desc.lanes_per_node: 0 (automatic: nodes with more than 4 children on any-arity tiles) and 2 (dense)
+    give the same bits -- a batch on a dense second engine must equal single queries on the first; 3 / 4 (the
+    wide lane-group split, 16 table entries per lane) agree with the oracle like the default split does."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(900, 4, 64, 4, seed=21)          # lane-group tiles + nodes with 5..9 children
+    ev = synth.random_evidence(d, 0.02, seed=4)
+    o = oracle_mod.bp_run(d, ev, 1e-6, threads=4)
+    res, tiles = {}, {}
+    for lanes in (0, 2, 3, 4):
+        with Engine(d, lanes_per_node=lanes) as eng:
+            res[lanes] = eng.bp_run(ev, 1e-6)
+            tiles[lanes] = eng.layout()["n_tiles"]
+            assert res[lanes]["sweeps"] == o["sweeps"]
+            assert rel_err(res[lanes]["beliefs"], o["beliefs"]) < 1e-9
+    assert np.array_equal(res[0]["beliefs"], res[2]["beliefs"]) and np.array_equal(res[3]["beliefs"], res[4]["beliefs"])
+    assert tiles[2] < tiles[0] < tiles[3] and tiles[4] < tiles[3]
+    t = synth.random_dag(700, 2, 48, 3, seed=8)           # <= 2 parents: every layout is bit-identical to the reference
+    ev = synth.random_evidence(t, 0.02, seed=4)
+    o = oracle_mod.bp_run(t, ev, 1e-9, threads=4)
+    for lanes in (0, 1, 2, 3):
+        with Engine(t, lanes_per_node=lanes) as eng:
+            r = eng.bp_run(ev, 1e-9)
+            assert r["sweeps"] == o["sweeps"] and np.array_equal(r["beliefs"], o["beliefs"]), lanes
