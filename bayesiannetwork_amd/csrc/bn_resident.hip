@@ -43,6 +43,16 @@ namespace bnmi {
 
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+// Diagnostic builds (-DBN_TILE_CLOCK): lane 0 of every wave stamps the phases of ONE iteration (the sixth) of the run
+#ifdef BN_TILE_CLOCK
+#define RSTAMP(k, iter, lane_, wave_)                                                              \
+    do {                                                                                           \
+        if ((iter) == 5 && (lane_) == 0) g_tile_clock[blockIdx.x * kResidentWaves + (wave_)][k] = wall_clock64(); \
+    } while (0)
+#else
+#define RSTAMP(k, iter, lane_, wave_) ((void)0)
+#endif
+
 // Message records are exchanged between CUs / XCDs inside the launch: every record access is a
 // 16-byte sc1 access through a buffer descriptor (aux 16 = sc1) -- stores write through, loads
 // bypass the CU's L1 -- the form of Guideline 16 that needs neither a release nor an acquire fence
@@ -104,8 +114,11 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
                                        int wave) {
     const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
     if (lane == 0) sh.slot[set][wave] = bits;
+    RSTAMP(3, it, lane, wave);  // sweep issued
     drain_stores();  // this wave's write-through stores have reached memory
+    RSTAMP(4, it, lane, wave);  // stores drained
     __syncthreads();
+    RSTAMP(5, it, lane, wave);  // the block's waves have all arrived
     if (threadIdx.x == 0) {
         unsigned long long m = 0;
 #pragma unroll
@@ -212,10 +225,12 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
         for (int set = 0; set < n_sets; ++set) {
             if (((active >> set) & 1u) == 0) continue;
             int v = kGoOn;
+            RSTAMP(0, it, lane, wave);
             if (it > 0) {
                 v = wait_verdict(a, sh, set, it - 1);
                 if (v == kAbort) return false;
             }
+            RSTAMP(1, it, lane, wave);  // verdict of the previous iteration known
             if (v != kGoOn || it == a.budget) {
                 const int done = v != kGoOn ? v : 0;
                 finalize(set, s, done);
@@ -238,6 +253,7 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
             }
             const double wres = phase(set, s);
             arrive(a, sh, set, it, s, wres, lane, wave);
+            RSTAMP(6, it, lane, wave);  // granules published
         }
         if (active == 0) break;
     }
@@ -426,6 +442,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
             }
         }
 
+        RSTAMP(7, s - a.sweep_begin, lane, wave);  // parent role
         __builtin_amdgcn_sched_barrier(0);
         // ---- child role, calculate_pi (:174-200) and calculate_lambda_k (:240-266): each accumulator
         // sees its terms in the reference's order (see tile_uniform); lambda(v)[i] * cpt is formed at each
@@ -514,6 +531,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                 pin[ib] = acc;
             }
         }
+        RSTAMP(8, s - a.sweep_begin, lane, wave);  // contraction
         __builtin_amdgcn_sched_barrier(0);
         normalize_k<K>(pin);
 #pragma unroll
@@ -676,3 +694,10 @@ int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void*
 }
 
 }  // namespace bnmi
+
+#ifdef BN_TILE_CLOCK
+extern "C" int bn_debug_tile_clock_resident(unsigned long long* out, int n_tiles) {
+    if (n_tiles > bnmi::kTileClockTiles) n_tiles = bnmi::kTileClockTiles;
+    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_tile_clock), sizeof(unsigned long long) * bnmi::kTileClockStamps * n_tiles));
+}
+#endif
