@@ -197,7 +197,9 @@ def test_layout_options_same_results(Engine, oracle_mod):
             assert res[lanes]["sweeps"] == o["sweeps"]
             assert rel_err(res[lanes]["beliefs"], o["beliefs"]) < 1e-9
     assert np.array_equal(res[0]["beliefs"], res[2]["beliefs"]) and np.array_equal(res[3]["beliefs"], res[4]["beliefs"])
-    assert tiles[2] < tiles[0] < tiles[3] and tiles[4] < tiles[3]
+    import os
+    if "BN_GROUP_WIDE" not in os.environ:  # the A/B switch overrides the lane-group split of every engine
+        assert tiles[2] < tiles[0] < tiles[3] and tiles[4] < tiles[3]
     t = synth.random_dag(700, 2, 48, 3, seed=8)           # <= 2 parents: every layout is bit-identical to the reference
     ev = synth.random_evidence(t, 0.02, seed=4)
     o = oracle_mod.bp_run(t, ev, 1e-9, threads=4)
