@@ -15,6 +15,8 @@ if name == "alarm_shaped":
     m, _ = load_dsc(os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"))
 elif name == "mixed300":
     m = synth.random_dag(300, 3, 32, [2, 3, 4, 3, 2, 5], seed=4)
+elif name == "mixed2k":
+    m = synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)
 elif name == "dag200":
     m = synth.random_dag(200, 4, 64, 4, seed=200)
 else:
