@@ -103,11 +103,7 @@ def test_flat_tiles_in_shards(Engine):
         assert np.array_equal(bel, want["beliefs"], equal_nan=True)
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_random_shapes_match_oracle(Engine, oracle_mod, seed):
-    """Small random networks with arities 1..7 (arity 1 included), 0..6 parents, random hard and
-    soft evidence: same stopping sweep, marginals to rounding (bit-identical when no node has more
-    than two parents and no table exceeds the ordered path's 128 entries)."""
+def _random_network(seed):
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(5, 60))
     maxp = int(rng.integers(1, 7))
@@ -123,11 +119,27 @@ def test_random_shapes_match_oracle(Engine, oracle_mod, seed):
         t = 0.05 + rng.random((rows, ks[v]))
         cpts.append(t / t.sum(axis=1, keepdims=True))
     m = from_parent_lists(ks, parents, cpts)
-    evd = {}
-    for v in rng.choice(n, size=max(1, n // 8), replace=False):
-        v = int(v)
-        evd[v] = int(rng.integers(0, ks[v])) if rng.random() < 0.7 else (0.1 + rng.random(ks[v]))
-    ev = Evidence.from_dict(m, evd)
+
+    def evidence():
+        evd = {}
+        for v in rng.choice(n, size=max(1, n // 8), replace=False):
+            v = int(v)
+            evd[v] = int(rng.integers(0, ks[v])) if rng.random() < 0.7 else (0.1 + rng.random(ks[v]))
+        return Evidence.from_dict(m, evd)
+    return m, parents, cpts, evidence
+
+
+# BN_STRESS_SEEDS=400 python -m pytest tests/test_flat_gpu.py -m gpu   for a longer one-off run
+_SEEDS = int(__import__("os").environ.get("BN_STRESS_SEEDS", "12"))
+
+
+@pytest.mark.parametrize("seed", range(_SEEDS))
+def test_random_shapes_match_oracle(Engine, oracle_mod, seed):
+    """Small random networks with arities 1..7 (arity 1 included), 0..6 parents, random hard and
+    soft evidence: same stopping sweep, marginals to rounding (bit-identical when no node has more
+    than two parents and no table exceeds the ordered path's 128 entries)."""
+    m, parents, cpts, evidence = _random_network(seed)
+    ev = evidence()
     want = oracle_mod.bp_run(m, ev, eps=1e-6, max_sweeps=200)
     with Engine(m) as eng:
         got = eng.bp_run(ev, 1e-6, max_sweeps=200)
@@ -137,3 +149,17 @@ def test_random_shapes_match_oracle(Engine, oracle_mod, seed):
         assert np.array_equal(got["beliefs"], want["beliefs"], equal_nan=True)
     else:
         assert np.allclose(got["beliefs"], want["beliefs"], rtol=1e-10, atol=1e-13, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(max(_SEEDS // 2, 6)))
+def test_random_shapes_batch_equals_single(Engine, seed):
+    """The same random networks, three evidence sets per call: every set gets the bits of its single run
+    (per-sweep launches with one set per blockIdx.y, on the dense second engine where the layout has one)."""
+    m, _, _, evidence = _random_network(seed)
+    evs = [evidence(), None, evidence()]
+    with Engine(m) as eng:
+        want = [eng.bp_run(ev, 1e-6, max_sweeps=200) for ev in evs]
+        got = eng.bp_run_batch(evs, 1e-6, max_sweeps=200)
+    for q, w in enumerate(want):
+        assert got["sweeps"][q] == w["sweeps"]
+        assert np.array_equal(got["beliefs"][q], w["beliefs"], equal_nan=True)
