@@ -207,3 +207,20 @@ def test_layout_options_same_results(Engine, oracle_mod):
         with Engine(t, lanes_per_node=lanes) as eng:
             r = eng.bp_run(ev, 1e-9)
             assert r["sweeps"] == o["sweeps"] and np.array_equal(r["beliefs"], o["beliefs"]), lanes
+
+
+def test_gpu_beyond_the_infinity_cache_nontemporal_stores(Engine, oracle_mod):
+    """A working set above 192 MB (800x800 grid: ~570 MB per sweep) runs the per-sweep kernel's non-temporal-store
+    instantiation -- the one the 2048x2048 bench point uses.  Same bits as the oracle."""
+    from bayesiannetwork_amd import synth
+    g = synth.grid(800, 800, 4, seed=3)
+    ev = synth.random_evidence(g, 0.01, seed=7)
+    o = oracle_mod.bp_run(g, ev, 1e-3, threads=8)
+    with Engine(g) as eng:
+        lay = eng.layout()
+        assert 8 * (lay["cpt_doubles"] + 2 * lay["rec_doubles"] + 2 * lay["node_doubles"]) > (192 << 20)
+        r = eng.bp_run(ev, 1e-3)
+        assert eng.last_path() == 0
+    assert r["sweeps"] == o["sweeps"]
+    assert np.array_equal(r["beliefs"], o["beliefs"])
+    assert np.array_equal(np.asarray(r.get("residual")), np.asarray(o["residuals"][-1]))
