@@ -57,18 +57,24 @@ def test_resident_equals_launch_path_grids(Engine, rows, cols, k, frac, eps, rep
 
 
 def test_resident_trees_and_dags(Engine):
-    """<= 2 parents, up to 4 children per node (the shapes the resident kernel instantiates)."""
+    """<= 2 parents, up to 8 children per node: the all-shapes instantiation of the resident kernel (4- and
+    8-children parent roles).  The dense layout (lanes_per_node = 2) keeps nodes with more than 4 children on
+    one-lane tiles -- the automatic layout would move them to any-arity tiles, which are never resident."""
     from bayesiannetwork_amd import synth
+    resident, many_children = 0, 0
     for seed in range(6):
         d = synth.random_dag(700, 2, 8, [4, 3, 2][seed % 3], seed=40 + seed)
         ev = synth.random_evidence(d, 0.02, seed=seed)
-        with Engine(d) as eng:
+        with Engine(d, lanes_per_node=2) as eng:
             want = _launch_path(eng, ev, 1e-6)
             eng.set_option("multisweep", 2)
             eng.bp_run(ev, 1e-6)
-            if eng.last_path() == 0:  # some node has more than 4 children: not eligible, nothing to compare
+            if eng.last_path() == 0:  # some node has more than 8 children: not eligible, nothing to compare
                 continue
+            resident += 1
+            many_children += int(np.bincount(d.in_idx, minlength=d.n).max() > 4)
             _check_same(eng, ev, 1e-6, want, 5)
+    assert resident >= 3 and many_children >= 1
 
 
 def test_resident_max_sweeps_and_soft_evidence(Engine):
