@@ -224,3 +224,18 @@ def test_gpu_beyond_the_infinity_cache_nontemporal_stores(Engine, oracle_mod):
     assert r["sweeps"] == o["sweeps"]
     assert np.array_equal(r["beliefs"], o["beliefs"])
     assert np.array_equal(np.asarray(r.get("residual")), np.asarray(o["residuals"][-1]))
+
+
+def test_gpu_nontemporal_stores_with_lane_group_tiles(Engine, oracle_mod):
+    """A 100 k-node DAG with up to 4 parents: ~250 MB per sweep, so the non-temporal-store instantiation of the
+    kernel that carries the lane-group tiles runs; sweeps equal, marginals to rounding."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(100000, 4, 64, 4, seed=11)
+    ev = synth.random_evidence(d, 0.01, seed=7)
+    o = oracle_mod.bp_run(d, ev, 1e-3, threads=8)
+    with Engine(d) as eng:
+        lay = eng.layout()
+        assert 8 * (lay["cpt_doubles"] + 2 * lay["rec_doubles"] + 2 * lay["node_doubles"]) > (192 << 20)
+        r = eng.bp_run(ev, 1e-3)
+    assert r["sweeps"] == o["sweeps"]
+    assert rel_err(r["beliefs"], o["beliefs"]) < 1e-9
