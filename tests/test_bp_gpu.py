@@ -106,6 +106,7 @@ def test_gpu_vs_oracle_grids(Engine, oracle_mod, rows, cols, k, frac, eps):
 @pytest.mark.parametrize("n,maxp,k,frac,eps", [
     (3000, 2, 4, 0.01, 1e-6), (2000, 4, 4, 0.01, 1e-3), (1500, 4, 2, 0.02, 1e-6),
     (1200, 3, [2, 3, 4, 3], 0.02, 1e-6), (800, 4, 3, 0.0, 1e-3),
+    (400, 5, 4, 0.02, 1e-6),  # five parents, k = 4: the whole-wavefront lane group (4096-entry tables)
 ])
 def test_gpu_vs_oracle_dags(Engine, oracle_mod, n, maxp, k, frac, eps):
     from bayesiannetwork_amd import synth
