@@ -163,3 +163,26 @@ def test_random_shapes_batch_equals_single(Engine, seed):
     for q, w in enumerate(want):
         assert got["sweeps"][q] == w["sweeps"]
         assert np.array_equal(got["beliefs"][q], w["beliefs"], equal_nan=True)
+
+
+def test_eight_parents_on_the_ordered_path(Engine, oracle_mod):
+    """Eight parents with a table of <= 128 entries (some parents of arity 1): the ordered path stages the terms of
+    pi(v) and of seven lambda-messages in one pass and the eighth parent's in a second one (bn_tiles.hpp)."""
+    rng = np.random.default_rng(77)
+    ks = [1, 2, 1, 2, 1, 2, 1, 3, 3, 2, 3]            # nodes 0..7: roots, the parents of node 8; 9 and 10: its children
+    parents = [[] for _ in range(8)] + [list(range(8)), [8], [3, 8]]
+    cpts = []
+    for v, ps in enumerate(parents):
+        rows = int(np.prod([ks[p] for p in ps])) if ps else 1
+        t = 0.1 + rng.random((rows, ks[v]))
+        cpts.append(t / t.sum(axis=1, keepdims=True))
+    m = from_parent_lists(ks, parents, cpts)
+    assert ks[8] * int(np.prod(ks[:8])) <= 128
+    for evd in ({}, {9: 1, 1: 0}, {10: np.array([0.2, 0.5, 0.3]), 8: 2}):
+        ev = Evidence.from_dict(m, evd)
+        want = oracle_mod.bp_run(m, ev, eps=1e-9, max_sweeps=100)
+        with Engine(m) as eng:
+            assert 3 in variants(eng)
+            got = eng.bp_run(ev, 1e-9, max_sweeps=100)
+        assert got["sweeps"] == want["sweeps"]
+        assert np.allclose(got["beliefs"], want["beliefs"], rtol=1e-12, atol=1e-14)
