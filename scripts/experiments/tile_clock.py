@@ -18,6 +18,8 @@ if name == "alarm_shaped":
     m, _ = load_dsc(os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"))
 elif name == "mixed300":
     m = synth.random_dag(300, 3, 32, [2, 3, 4, 3, 2, 5], seed=4)
+elif name.startswith("grid"):
+    m = synth.grid(int(name[4:]), int(name[4:]), 4, seed=2)
 elif name == "dag10k":
     m = synth.random_dag(10000, 4, 64, 4, seed=1)
 elif name == "dag200":
