@@ -50,6 +50,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     p.wide_requested = wide_requested;
     const int32_t n = d.n_nodes;
     if (n < 0) return "n_nodes < 0";
+    if (d_in.lanes_per_node < 0 || d_in.lanes_per_node > 4) return "lanes_per_node outside 0..4 (bn_mi355x.h)";
     if (n > 0 && (!d.k || !d.in_ptr || !d.cpt_off)) return "null model array";
     if (shard.nranks < 1 || shard.rank < 0 || shard.rank >= shard.nranks) return "bad rank / nranks";
     p = Plan();

@@ -58,6 +58,8 @@ def test_model_validation_errors(bnlib):
     bad(cpt_off=np.array([0, 2, 4, 8, 15], np.int64))              # the reference's missing-row UB -> error
     with pytest.raises(_lib.BnError):
         engine.Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, rank=3, nranks=2)
+    with pytest.raises(_lib.BnError):
+        engine.Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, lanes_per_node=7)  # layout selector outside 0..4
 
 
 def test_layout_invariants(E):
