@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_gloo_sharded_exchange(bnlib, oracle_mod, case, world, order, tmp_path):
     """order "overlapped": the engine's overlapped schedule -- interior tiles of the next sweep computed
     while the all-gather is in flight, cut-touching tiles after it landed (see dist_worker.py)."""
-    port = 29600 + world * 7 + (0 if case == "grid" else 3) + (20 if order == "overlapped" else 0)
+    import socket
+    with socket.socket() as sk:  # a port nobody is listening on (a fixed one may still be in TIME_WAIT from another run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "dist_worker.py"), case, order]

@@ -123,8 +123,12 @@ def test_bench_multi_gpu_code_path_on_one_rank():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BN_FORCE_MULTI="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1",
+    with socket.socket() as sk:  # a port nobody is listening on
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BN_FORCE_MULTI="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                         "--rows", "48", "--cols", "48"], env=env, capture_output=True, text=True, timeout=600)
