@@ -32,7 +32,7 @@ class BpStats(ctypes.Structure):
     _fields_ = [("sweeps", ctypes.c_int32), ("sweep_launches", ctypes.c_int32), ("sweep_kernel_ms", ctypes.c_float),
                 ("total_ms", ctypes.c_float), ("algorithmic_bytes_per_sweep", ctypes.c_int64),
                 ("layout_bytes_per_sweep", ctypes.c_int64), ("messages_per_sweep", ctypes.c_int64),
-                ("sweep_devclock_ms", ctypes.c_float), ("pad_", ctypes.c_float)]
+                ("sweep_devclock_ms", ctypes.c_float), ("resident_aborts", ctypes.c_int32)]
 
 
 class LayoutInfo(ctypes.Structure):
@@ -58,6 +58,8 @@ SYMBOLS = [
     ("bn_version", ctypes.c_char_p, []),
     ("bn_bp_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p, ctypes.c_double, ctypes.c_int32,
                                  f64p, i32p, f64p]),
+    ("bn_bp_run_view", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p, ctypes.c_double, ctypes.c_int32,
+                                      ctypes.POINTER(f64p), i32p, f64p]),
     ("bn_bp_set_evidence", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, f64p]),
     ("bn_bp_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_int32, i32p, f64p]),
     ("bn_bp_beliefs_device", ctypes.c_void_p, [ctypes.c_void_p]),

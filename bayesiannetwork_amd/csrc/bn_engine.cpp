@@ -134,6 +134,16 @@ struct bn_engine {
     bool timing = false;            // HIP events around each batch of sweeps (bn_bp_stats.sweep_kernel_ms); opt-in:
                                     // an event record between two launches opens a ~6 us bubble in the queue
     bool resident_ok = false;       // every tile register-resident and co-resident: the whole run in one launch (bn_resident.hip)
+    // A launch of the resident kernel that gives up a bounded wait (its blocks were not all co-resident: another
+    // process or engine held CUs) sends this and the next `resident_cooldown` runs down the per-sweep launches;
+    // after that the resident path is tried again, and a repeated abort doubles the pause (<= 1024 runs).
+    int32_t resident_aborts = 0;    // launches that gave up, over the engine's life (bn_bp_stats.resident_aborts)
+    int32_t resident_cooldown = 0;  // runs left before the resident path is tried again
+    int32_t resident_backoff = 8;   // length of the next pause
+    double* h_beliefs = nullptr;    // pinned: bn_bp_run_view hands this out, bn_bp_run stages nothing through it
+    std::vector<uint32_t> ev_seen;  // check_evidence: epoch stamp per node (no per-call allocation)
+    uint32_t ev_epoch = 0;
+    bool ev_upload_pending = false; // an evidence H2D from h_ev may still be in flight (no sync since)
     int resident_lean = 0;          // ... and every node has this arity (2, 3 or 4) and <= 2 children; else 0
     int grid_resident = 0;
     ResidentSync* d_rsync = nullptr;
@@ -204,6 +214,7 @@ static void free_engine(bn_engine* e) {
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
         if (e->batch.h_ctl) (void)hipHostFree(e->batch.h_ctl);
         if (e->h_ev) (void)hipHostFree(e->h_ev);
+        if (e->h_beliefs) (void)hipHostFree(e->h_beliefs);
         for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
         if (e->stream) (void)hipStreamDestroy(e->stream);
     }
@@ -391,17 +402,20 @@ static BpBuffers buffers_of(bn_engine* e) {
     return b;
 }
 
-static int check_evidence(const Plan& p, int32_t ne, const int32_t* ev_node, const int32_t* ev_off) {
+// `seen` / `epoch`: one stamp per node, kept by the engine so that a query costs O(ne), not O(n)
+static int check_evidence(const Plan& p, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                          std::vector<uint32_t>& seen, uint32_t& epoch) {
     if (ne < 0) return fail(BN_ERR_ARG, "negative evidence count");
     if (ne == 0) return BN_OK;
     if (!ev_node || !ev_off) return fail(BN_ERR_ARG, "null evidence array");
     if (ev_off[0] != 0) return fail(BN_ERR_ARG, "ev_off[0] != 0");
-    std::vector<uint8_t> seen(p.n, 0);
+    if (seen.size() != size_t(p.n) || epoch == 0xffffffffu) { seen.assign(size_t(p.n), 0u); epoch = 0; }
+    ++epoch;
     for (int32_t j = 0; j < ne; ++j) {
         int32_t v = ev_node[j];
         if (v < 0 || v >= p.n) return fail(BN_ERR_ARG, "evidence node out of range");
-        if (seen[v]) return fail(BN_ERR_ARG, "evidence node listed twice");
-        seen[v] = 1;
+        if (seen[v] == epoch) return fail(BN_ERR_ARG, "evidence node listed twice");
+        seen[v] = epoch;
         if (ev_off[j + 1] - ev_off[j] != p.k[v])
             return fail(BN_ERR_ARG, "evidence vector of node " + std::to_string(v) + " must have selectable_num entries");
     }
@@ -420,18 +434,24 @@ static int ensure_events(bn_engine* e, size_t count) {
 // Evidence staging: one pinned host block [ev_node | ev_off | ev_val] -> one H2D copy, then the
 // evidence is APPLIED (marks cleared, new marks and vectors written): it stays in force for every
 // following run until the next call, so a run itself starts with its first sweep.
-extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
-                                  const double* ev_val) {
+// wait: block until the upload has left the pinned staging block (bn_bp_set_evidence); bn_bp_run passes false --
+// its own single synchronisation at the end of the call covers it
+static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                             const double* ev_val, bool wait) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     const Plan& p = e->plan;
-    int rc = check_evidence(p, ne, ev_node, ev_off);
+    int rc = check_evidence(p, ne, ev_node, ev_off, e->ev_seen, e->ev_epoch);
     if (rc) return rc;
     if (ne > 0 && !ev_val) return fail(BN_ERR_ARG, "null ev_val");
     ON_DEVICE(e);
     const int64_t nval = ne > 0 ? ev_off[ne] : 0;
     const size_t off_node = 0, off_off = size_t(ne) * 4, off_val = (off_off + size_t(ne + 1) * 4 + 7) & ~size_t(7);
     const size_t bytes = off_val + size_t(nval) * 8;
+    if (e->ev_upload_pending) {  // the staging block is about to be rewritten
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->ev_upload_pending = false;
+    }
     if (bytes > e->ev_bytes_cap) {
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->d_ev) (void)hipFree(e->d_ev);
@@ -459,9 +479,17 @@ extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_no
         e->ev_applied_dirty = true;
         return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
     }
-    // bn_bp_run's contract is "evidence uploaded when the call returns" (h_ev is reused by the next call)
-    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ev_upload_pending = ne > 0;
+    if (wait) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->ev_upload_pending = false;
+    }
     return BN_OK;
+}
+
+extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                                  const double* ev_val) {
+    return set_evidence_impl(e, ne, ev_node, ev_off, ev_val, true);
 }
 
 // ---- the steps of a run; bn_bp_run_device chains them, the bn_bp_step_* entry points expose
@@ -552,7 +580,9 @@ static int resident_service_blocks(int tile_blocks) { return tile_blocks > 1 ? 1
 // Networks of register-resident tiles that fit the chip: ONE launch runs the whole run with the CPTs,
 // references and node vectors resident in registers / LDS and a grid barrier per sweep (bn_resident.hip).
 // BN_ERR_STATE = a bounded wait inside the kernel gave up: the caller redoes the run with per-sweep launches.
-static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
+// copy_to: host memory the beliefs are copied into BEHIND the launch, before the run's one synchronisation
+// (bn_bp_run / bn_bp_run_view); nullptr leaves them in HBM (bn_bp_run_device)
+static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to) {
     hipStream_t s = e->stream;
     ++e->run_id;
     if (e->run_id == 0) e->run_id = 1;
@@ -578,7 +608,10 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
         if (int code = launch_bp_resident(a, e->grid_resident + resident_service_blocks(e->grid_resident), e->resident_lean, s))
             return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
+        if (copy_to)  // a launch that stops on its budget (1024 sweeps) copies an intermediate state; the last one counts
+            HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        e->ev_upload_pending = false;
         ++launches;
         e->gen_base += kResidentBudget + 1;
         if (e->h_ctl->run_id != e->run_id || e->h_ctl->done < 0) e->rsync_dirty = true;
@@ -603,8 +636,8 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     return BN_OK;
 }
 
-extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
-                                double* residual_out) {
+static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
+                           double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
@@ -617,9 +650,12 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
     constexpr int64_t kResidentMinTiles = 600;  // measured crossover: 160x160 grid (402 tiles) 8.2 vs 8.9 us per sweep, 200x200 (627) 9.5 vs 9.2
     const bool resident_pays = e->grid_resident == 1 || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
-    if (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays))) {
-        rc = run_resident(e, eps, max_sweeps);
+    const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
+    if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
+    else if (try_resident) {
+        rc = run_resident(e, eps, max_sweeps, copy_to);
         if (rc == BN_OK) {
+            e->resident_backoff = 8;
             e->stats.total_ms =
                 std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
             if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
@@ -627,9 +663,14 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
             return BN_OK;
         }
         if (rc != BN_ERR_STATE) return rc;
-        // a barrier wait gave up (e.g. not every block became resident): per-sweep launches from now on
-        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] resident path disabled: %s\n", g_err.c_str());
-        e->resident_ok = false;
+        // a bounded wait gave up (e.g. not every block became resident): this run and the next few go down the
+        // per-sweep launches, then the resident path is tried again
+        ++e->resident_aborts;
+        e->resident_cooldown = e->resident_backoff;
+        e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
+        if (std::getenv("BN_DEBUG"))
+            std::fprintf(stderr, "[bn_mi355x] resident launch aborted (%s); per-sweep launches for the next %d runs\n", g_err.c_str(),
+                         e->resident_cooldown);
     }
     e->last_path = 0;
     if ((rc = step_begin(e))) return rc;
@@ -656,7 +697,10 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
         if (e->timing) HIPCHK(hipEventRecord(e->events[2 * batches + 1], s));
         ++batches;
         if ((rc = step_finish(e, launched, max_sweeps > 0 && launched >= max_sweeps, eps))) return rc;
+        if (copy_to)  // behind the finish kernel; repeated if the predicted sweep count turns out too low
+            HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        e->ev_upload_pending = false;
         if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "finish kernel did not report (stale control block)");
         if (e->h_ctl->done != 0) break;
         batch = 8;
@@ -675,6 +719,11 @@ extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, in
     if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
     if (residual_out) *residual_out = e->last_ctl.last_res;
     return BN_OK;
+}
+
+extern "C" int bn_bp_run_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out,
+                                double* residual_out) {
+    return run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, nullptr);
 }
 
 // Engine options: "timing" = 1/0 (HIP events around the sweep launches; off: sweep_kernel_ms reads 0);
@@ -802,7 +851,7 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     for (int32_t q = 0; q < n_sets; ++q) {
         if (ne[q] < 0) return fail(BN_ERR_ARG, "negative evidence count");
         if (ne[q] > 0 && (!ev_node || !ev_off || !ev_val)) return fail(BN_ERR_ARG, "null evidence array");
-        int rc = check_evidence(p, ne[q], ev_node ? ev_node + node_at[q] : nullptr, ev_off ? ev_off + off_at[q] : nullptr);
+        int rc = check_evidence(p, ne[q], ev_node ? ev_node + node_at[q] : nullptr, ev_off ? ev_off + off_at[q] : nullptr, e->ev_seen, e->ev_epoch);
         if (rc) return rc;
         node_at[q + 1] = node_at[q] + ne[q];
         off_at[q + 1] = off_at[q] + ne[q] + 1;
@@ -1007,13 +1056,21 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     // "multisweep" = 2 forces the resident kernel wherever eligible, 0 the launches.
     constexpr int64_t kResidentBatchMinTiles = 900;
     const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
-    if (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays))) {
+    const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
+    if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
+    else if (try_resident) {
         rc = run_batch_resident(e, eps, max_sweeps);
         if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
         if (rc == BN_ERR_STATE) {
-            if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] resident path disabled: %s\n", g_err.c_str());
-            e->resident_ok = false;
+            ++e->resident_aborts;
+            e->resident_cooldown = e->resident_backoff;
+            e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
+            if (std::getenv("BN_DEBUG"))
+                std::fprintf(stderr, "[bn_mi355x] resident launch aborted (%s); per-sweep launches for the next %d runs\n", g_err.c_str(),
+                             e->resident_cooldown);
             aborted = true;
+        } else {
+            e->resident_backoff = 8;
         }
     }
     if (rc != BN_OK) {
@@ -1172,15 +1229,36 @@ extern "C" int bn_bp_copy_beliefs(bn_engine* e, double* beliefs_out) {
     return BN_OK;
 }
 
+// Evidence in, beliefs out, ONE stream synchronisation: the evidence upload, the evidence kernel, the run and
+// the copy of the beliefs are queued back to back on the engine's stream and waited for once.
 extern "C" int bn_bp_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
                          const double* ev_val, double eps, int32_t max_sweeps, double* beliefs_out,
                          int32_t* sweeps_out, double* residual_out) {
     if (!beliefs_out) return fail(BN_ERR_ARG, "null beliefs_out");
-    int rc = bn_bp_set_evidence(e, ne, ev_node, ev_off, ev_val);
+    int rc = set_evidence_impl(e, ne, ev_node, ev_off, ev_val, false);
     if (rc) return rc;
-    rc = bn_bp_run_device(e, eps, max_sweeps, sweeps_out, residual_out);
+    return run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, beliefs_out);
+}
+
+// The same with the beliefs left in a pinned host buffer the engine owns (valid until the next run on this
+// engine): the copy behind the run is one DMA into page-locked memory, and a caller that unpacks the flat
+// array anyway (the C++ functor builds its map of 1 x k matrices from it) never needs a second copy.
+extern "C" int bn_bp_run_view(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
+                              const double* ev_val, double eps, int32_t max_sweeps, const double** beliefs_view,
+                              int32_t* sweeps_out, double* residual_out) {
+    if (!beliefs_view) return fail(BN_ERR_ARG, "null beliefs_view");
+    *beliefs_view = nullptr;
+    int rc = set_evidence_impl(e, ne, ev_node, ev_off, ev_val, false);
     if (rc) return rc;
-    return bn_bp_copy_beliefs(e, beliefs_out);
+    if (!e->h_beliefs) {
+        ON_DEVICE(e);
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_beliefs), std::max<size_t>(e->plan.node_off[e->plan.n], 1) * sizeof(double),
+                             hipHostMallocDefault));
+    }
+    rc = run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, e->h_beliefs);
+    if (rc) return rc;
+    *beliefs_view = e->h_beliefs;
+    return BN_OK;
 }
 
 extern "C" int bn_bp_residual_history(bn_engine* e, double* out, int32_t cap) {
@@ -1206,6 +1284,7 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
 extern "C" int bn_bp_last_stats(bn_engine* e, bn_bp_stats* out) {
     if (!e || !out) return fail(BN_ERR_ARG, "null argument");
     *out = e->stats;
+    out->resident_aborts = e->resident_aborts;
     return BN_OK;
 }
 

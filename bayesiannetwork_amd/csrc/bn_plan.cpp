@@ -46,14 +46,13 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     const bool latency_rules = d_in.lanes_per_node == 0 || d_in.lanes_per_node == 3;
     const bool wide_requested = d_in.lanes_per_node == 3 || d_in.lanes_per_node == 4;
     if (d.lanes_per_node >= 2 && d.lanes_per_node <= 4) d.lanes_per_node = 0;
-    p.latency_rules_applied = false;
-    p.wide_requested = wide_requested;
     const int32_t n = d.n_nodes;
     if (n < 0) return "n_nodes < 0";
     if (d_in.lanes_per_node < 0 || d_in.lanes_per_node > 4) return "lanes_per_node outside 0..4 (bn_mi355x.h)";
     if (n > 0 && (!d.k || !d.in_ptr || !d.cpt_off)) return "null model array";
     if (shard.nranks < 1 || shard.rank < 0 || shard.rank >= shard.nranks) return "bad rank / nranks";
     p = Plan();
+    p.wide_requested = wide_requested;  // after the reset: dense_engine_for_batch (bn_engine.cpp) reads it
     p.n = n;
     p.rank = shard.rank;
     p.nranks = shard.nranks;

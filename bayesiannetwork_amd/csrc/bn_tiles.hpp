@@ -1,7 +1,7 @@
 // bn_tiles.hpp -- device code shared by the sweep kernels: one call = one tile (one wavefront of nodes
 // of one shape class, bn_plan.hpp) doing one iteration of the reference's while(true) loop
-// (bayesian/inference/belief_propagation.hpp:75-148) for its nodes.  Included by bn_kernels.hip (one
-// launch per sweep) and bn_multi.hip (all sweeps of a small network in one launch).
+// (bayesian/inference/belief_propagation.hpp:75-148) for its nodes.  Included by the per-sweep
+// kernels (bn_sweep.hpp, bn_kernels.hip) and by bn_resident.hip (the whole run in one launch).
 //
 // A lane (or lane group) owns everything that is computed from its node's CPT and node vectors:
 //   child role  : pi(v)      = calculate_pi       (:174-200)
@@ -1578,19 +1578,70 @@ __device__ __forceinline__ double run_tile_light(const BpBuffers& b, const IO& i
     return tile_generic(b, io, td, b.classes[td.cls], lane);
 }
 
-// belief = normalize(pi % lambda) (:151-158) of one tile's nodes from node buffer `node_buf`
+// belief = normalize(pi % lambda) (:151-158) of one tile's nodes from node buffer `node_buf`.
+// Lane nl serves node nl: its pi / lambda chunks are 16-byte loads, coalesced across the lanes (chunk h of
+// node nl sits at double2 index h * npt + nl); the k products stay in registers, one left-to-right sum,
+// one division each; the belief goes out in 16-byte stores where the node's offset allows (even sum of
+// the preceding arities), nothing is read back.  H = chunks per vector, 1..4 (k <= 8) unrolled.
+template <int H>
+__device__ __forceinline__ void tile_beliefs_regs(const BpBuffers& b, const TileDesc& td, const double* node_buf, int lane) {
+    const int npt = td.npt, kv = td.kv;
+    const double2_t* node = reinterpret_cast<const double2_t*>(node_buf + td.node_base) + lane;
+    double2_t p[H], l[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        p[h] = node[h * npt];
+        l[h] = node[(H + h) * npt];
+    }
+    const int64_t boff = b.slot_boff[td.slot_base + lane];
+    double x[2 * H];
+    double sum = 0;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        x[2 * h] = p[h].x * l[h].x;
+        x[2 * h + 1] = p[h].y * l[h].y;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * H; ++i)
+        if (i < kv) sum += x[i];
+#pragma unroll
+    for (int i = 0; i < 2 * H; ++i) x[i] = x[i] / sum;
+    double* out = b.beliefs + boff;
+    if ((boff & 1) == 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            if (2 * h + 1 < kv) {
+                double2_t y;
+                y.x = x[2 * h]; y.y = x[2 * h + 1];
+                reinterpret_cast<double2_t*>(out)[h] = y;
+            } else if (2 * h < kv) {
+                out[2 * h] = x[2 * h];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i)
+            if (i < kv) out[i] = x[i];
+    }
+}
+
 __device__ __forceinline__ void tile_beliefs(const BpBuffers& b, const TileDesc& td, const double* node_buf, int lane) {
     if (lane >= td.n_nodes) return;  // one lane per node writes the belief
+    const int half = ((td.kv + 1) & ~1) >> 1;
+    switch (half) {
+        case 1: return tile_beliefs_regs<1>(b, td, node_buf, lane);
+        case 2: return tile_beliefs_regs<2>(b, td, node_buf, lane);
+        case 3: return tile_beliefs_regs<3>(b, td, node_buf, lane);
+        case 4: return tile_beliefs_regs<4>(b, td, node_buf, lane);
+        default: break;
+    }
+    // arity above 8: two passes over the (cached) inputs, nothing read back from the output
     const double* node = node_buf + td.node_base;
     const int64_t boff = b.slot_boff[td.slot_base + lane];
-    const int half = ((td.kv + 1) & ~1) >> 1;
     double sum = 0;
-    for (int i = 0; i < td.kv; ++i) {
-        const double x = node[vidx(0, i, td.npt, lane)] * node[vidx(half, i, td.npt, lane)];
-        b.beliefs[boff + i] = x;
-        sum += x;
-    }
-    for (int i = 0; i < td.kv; ++i) b.beliefs[boff + i] = b.beliefs[boff + i] / sum;
+    for (int i = 0; i < td.kv; ++i) sum += node[vidx(0, i, td.npt, lane)] * node[vidx(half, i, td.npt, lane)];
+    for (int i = 0; i < td.kv; ++i)
+        b.beliefs[boff + i] = (node[vidx(0, i, td.npt, lane)] * node[vidx(half, i, td.npt, lane)]) / sum;
 }
 
 }  // namespace bnmi

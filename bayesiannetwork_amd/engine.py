@@ -85,6 +85,20 @@ class Engine:
                                         _p(bel, ctypes.c_double), ctypes.byref(sweeps), ctypes.byref(res)))
         return {"beliefs": bel, "sweeps": sweeps.value, "residual": res.value}
 
+    def bp_run_view(self, evidence: Evidence | None = None, eps: float = 0.001, max_sweeps: int = 0):
+        """bn_bp_run_view: like bp_run, but "beliefs" is a numpy VIEW of the engine's page-locked host buffer
+        (no second copy); it is overwritten by the next run on this engine and dies with it -- copy to keep."""
+        ev = evidence if evidence is not None else Evidence.none()
+        sweeps = ctypes.c_int32(0)
+        res = ctypes.c_double(0.0)
+        view = _lib.f64p()
+        _lib.check(_lib.lib().bn_bp_run_view(self._h, ev.ne, _p(ev.node, ctypes.c_int32), _p(ev.off, ctypes.c_int32),
+                                             _p(ev.val, ctypes.c_double), float(eps), int(max_sweeps),
+                                             ctypes.byref(view), ctypes.byref(sweeps), ctypes.byref(res)))
+        n = int(self.model.k.sum())
+        bel = np.ctypeslib.as_array(view, shape=(n,)) if n else np.zeros(0)
+        return {"beliefs": bel, "sweeps": sweeps.value, "residual": res.value}
+
     # ---- several evidence sets per call (bn_bp_*_batch) ------------------------------------
     @staticmethod
     def _pack_sets(evidences):
@@ -392,7 +406,8 @@ class BeliefPropagation:
             precondition, epsilon = None, float(precondition)  # the by-pass overload bp(epsilon), :24-28
         if isinstance(precondition, dict):
             precondition = Evidence.from_dict(self.model, precondition)
-        self.last = self.engine.bp_run(precondition, epsilon)
+        self.last = self.engine.bp_run_view(precondition, epsilon)
+        self.last["beliefs"] = self.last["beliefs"].copy()  # out of the engine's pinned buffer: the caller owns the result
         return _split(self.model, self.last["beliefs"])
 
     def run_batch(self, preconditions, epsilon: float = 0.001):

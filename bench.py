@@ -57,6 +57,32 @@ def profiled_traffic(label):
             "traffic_stale": None if fresh else best[0]}
 
 
+def profiled_valu(label, waves_per_simd):
+    """VALU-issue fraction of the dominant kernel from the committed SQ counter pass (profiles/*_summary.json,
+    `<label>_sq_counters_per_launch`): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of a resident wave's
+    cycles in which it issues a VALU instruction; times the waves that share a SIMD = how busy the vector ALU
+    of an occupied SIMD is.  Like `traffic` it comes from the last committed profile and is marked stale when
+    that profile was taken with another build of the library."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_summary.json"):
+            d = json.load(open(os.path.join(pdir, name)))
+            sq = d.get(f"{label}_sq_counters_per_launch")
+            if sq and sq.get("SQ_WAVE_CYCLES"):
+                best = (sq, f"profiles/{name}", d.get("lib_sha256"))
+    if not best:
+        return {"valu_frac": None}
+    sq, src, sha = best
+    per_wave = sq.get("SQ_ACTIVE_INST_VALU", 0.0) / sq["SQ_WAVE_CYCLES"]
+    out = {"valu_frac": min(per_wave * waves_per_simd, 1.0), "valu_active_per_wave_cycle": per_wave,
+           "valu_waves_per_simd": waves_per_simd, "valu_source": src,
+           "valu_counters": {k: sq[k] for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES") if k in sq}}
+    if not (sha is not None and sha == lib_sha256()):
+        out["valu_stale"] = True
+    return out
+
+
 def cpu_baseline(model, ev, eps, budget_s=12.0, threads=1, max_sweeps=0, max_runs=8):
     """The oracle (plain-C port of the reference algorithm) timed on this box's host cores on a
     bounded number of runs of the same workload: 1 thread like the reference, or OpenMP over the
@@ -167,7 +193,8 @@ def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
     return {"dt": dt, "sweeps_total": sweeps_total, "msgs": g.messages_per_sweep() * sweeps_total,
             "avg_sweep_s": avg_sweep_s, "avg_launch_s": avg_launch_s, "sweeps_per_launch": ev_sweeps / max(launches, 1),
             "avg_sweep_devclock_s": avg_dev_s, "achieved": achieved, "stats": st,
-            "path": path, "ms_per_step_with_events": dt_ev / max(ev_steps, 1) * 1e3, "event_steps": ev_steps}
+            "path": path, "ms_per_step_with_events": dt_ev / max(ev_steps, 1) * 1e3, "event_steps": ev_steps,
+            "n_tiles": eng.layout()["n_tiles"]}
 
 
 PATH_KERNEL = {0: "bp_sweep_kernel", 2: "bp_resident_kernel"}
@@ -192,6 +219,10 @@ def roofline_of(t, label):
     out.update(profiled_traffic(label))
     if out.get("traffic"):
         out["traffic_gbs"] = out["traffic"] / max(t["avg_launch_s"], 1e-12) / 1e9  # what the memory system actually moved
+    # resident tiles: 8 waves per 512-thread block on 4 SIMDs; per-sweep launches: 256-thread blocks, 2 blocks per CU
+    out.update(profiled_valu(label, 2 if t["path"] == 2 else min(2.0, max(1.0, t["n_tiles"] / 1024.0))))
+    if t["path"] == 2:
+        out["limiter"] = "valu+barrier"  # what actually bounds this kernel; `bound`/`frac` stay SURVEY 8(d)'s HBM figure
     if t["path"] == 2:
         out["note"] = ("achieved = SURVEY 8(d) algorithmic bytes (CPT read once per node and sweep) / time; the resident kernel "
                        "keeps the CPTs in registers / LDS for the whole run, so its real traffic (`traffic`, `traffic_gbs`) is "
@@ -200,17 +231,60 @@ def roofline_of(t, label):
     return out
 
 
-def time_host_to_host(eng, g, ev, eps, steps):
-    """wall time from evidence upload to beliefs on the host (bn_bp_run = evidence H2D,
-    run, 8 * sum(k) bytes of beliefs D2H), per run; PCIe inclusive, never the headline."""
-    eng.bp_run(ev, eps)
+def evidence_cycle(g, frac, n=8):
+    """n evidence sets of the same size on different nodes: a stream of different queries, so that the sweep
+    count of the next run is not the one the engine has just seen (its launch path enqueues the predicted
+    number of sweeps ahead)."""
+    from bayesiannetwork_amd import synth
+    return [synth.random_evidence(g, frac, seed=7 + q) for q in range(n)]
+
+
+def time_host_to_host(eng, g, evs, eps, steps):
+    """wall time from evidence upload to beliefs on the host, per query, over a cycle of different
+    evidence sets (bn_bp_run_view = evidence H2D, evidence kernel, run, 8 * sum(k) bytes of beliefs D2H into the
+    engine's page-locked buffer, ONE synchronisation); PCIe inclusive, never the headline."""
+    for ev in evs[:2]:
+        eng.bp_run_view(ev, eps)
     t0 = time.perf_counter()
     sweeps = 0
-    for _ in range(steps):
-        sweeps += eng.bp_run(ev, eps)["sweeps"]
+    for i in range(steps):
+        sweeps += eng.bp_run_view(evs[i % len(evs)], eps)["sweeps"]
     dt = time.perf_counter() - t0
+    out = {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_step": dt / steps * 1e3,
+           "steps": steps, "evidence_sets_cycled": len(evs), "sweeps_per_step": sweeps / steps,
+           "what": "bn_bp_run_view: evidence H2D + run to convergence + beliefs D2H (pinned), one sync, host wall clock"}
+    # the plain entry point with a caller-owned (pageable) array, for comparison
+    eng.bp_run(evs[0], eps)
+    t0 = time.perf_counter()
+    sw2 = 0
+    for i in range(steps):
+        sw2 += eng.bp_run(evs[i % len(evs)], eps)["sweeps"]
+    dt2 = time.perf_counter() - t0
+    out["pageable_out"] = {"value": g.messages_per_sweep() * sw2 / dt2, "ms_per_step": dt2 / steps * 1e3,
+                           "what": "bn_bp_run into a caller-owned pageable array"}
+    return out
+
+
+def time_cycled(eng, g, evs, eps, steps):
+    """Device-resident runs over a cycle of DIFFERENT evidence sets: each set is staged by bn_bp_set_evidence outside
+    the clock, the clock runs around bn_bp_run_device only (the call returns after its own synchronisation).  On
+    the launch path the engine enqueues the sweep count of the PREVIOUS run ahead, so a stream of different queries
+    pays for over- and under-shoots that a repeat of the same query never sees."""
+    for ev in evs[:2]:
+        eng.bp_set_evidence(ev)
+        eng.bp_run_device(eps)
+    dt, sweeps, launches = 0.0, 0, 0
+    for i in range(steps):
+        eng.bp_set_evidence(evs[i % len(evs)])
+        t0 = time.perf_counter()
+        r = eng.bp_run_device(eps)
+        dt += time.perf_counter() - t0
+        sweeps += r["sweeps"]
+        launches += eng.bp_stats()["sweep_launches"]
     return {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_step": dt / steps * 1e3,
-            "steps": steps, "what": "bn_bp_run: evidence H2D + run to convergence + beliefs D2H, host wall clock"}
+            "steps": steps, "evidence_sets_cycled": len(evs), "sweeps_per_step": sweeps / steps,
+            "sweep_launches_per_step": launches / steps,
+            "what": "bn_bp_run_device on a cycle of different staged evidence sets; clock around the run only"}
 
 
 def leg_dag(a, local_rank, torch):
@@ -222,15 +296,21 @@ def leg_dag(a, local_rank, torch):
     with Engine(g, device=local_rank) as eng:
         eng.bp_set_evidence(ev)
         t = time_bp(eng, g, a.eps, max(a.steps, 20), a.warmup, torch)
-        h2h = time_host_to_host(eng, g, ev, a.eps, 10)
+        evs = evidence_cycle(g, a.evidence)
+        cyc = time_cycled(eng, g, evs, a.eps, max(a.steps, 24))
+        h2h = time_host_to_host(eng, g, evs, a.eps, 16)
         # B queries per call: every per-sweep launch carries all sets (blockIdx.y), so they share its latency
         batch = time_batches(eng, g, a, torch, (4, 16))
     steps = max(a.steps, 20)
     out = {"workload": f"10 k-node random DAG, <=4 parents, k=4, {g.n_edges} edges (BASELINE.json configs[1]), "
                        f"{ev.ne} evidence nodes, eps={a.eps:g}",
-           "value": t["msgs"] / t["dt"], "unit": "edge-messages/s", "ms_per_step": t["dt"] / steps * 1e3, "steps": steps,
-           "sweeps_per_step": t["sweeps_total"] / steps, "messages_per_sweep": g.messages_per_sweep(),
-           "value_host_to_host": h2h["value"], "roofline": roofline_of(t, "dag10k"), "batch": batch}
+           "value": cyc["value"], "unit": "edge-messages/s", "ms_per_step": cyc["ms_per_step"], "steps": cyc["steps"],
+           "sweeps_per_step": cyc["sweeps_per_step"], "messages_per_sweep": g.messages_per_sweep(),
+           "cycled_evidence": cyc,
+           "same_evidence": {"value": t["msgs"] / t["dt"], "ms_per_step": t["dt"] / steps * 1e3, "steps": steps,
+                             "sweeps_per_step": t["sweeps_total"] / steps,
+                             "what": "the same staged evidence set run again and again (the sweep prediction is then exact)"},
+           "value_host_to_host": h2h["value"], "host_to_host": h2h, "roofline": roofline_of(t, "dag10k"), "batch": batch}
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps, budget_s=6.0)
     return out
@@ -261,6 +341,8 @@ def leg_lw(a, local_rank, torch):
             "algorithmic_bytes_per_sample": bytes_per_sample,
             "note": "informational: the sampler is VALU/latency-bound (DESIGN.md section 4), not HBM-bound"}
     roof.update(profiled_traffic("lw"))
+    roof.update(profiled_valu("lw", 8))  # 256-thread blocks, no LDS, <= 64 VGPRs: up to 8 waves per SIMD
+    roof["limiter"] = "valu+latency"
     out = {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
                        f"{a.samples} samples per step (BASELINE.json configs[4]; 10 M samples = {10000000 / rate:.3f} s at this rate)",
            "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
@@ -325,10 +407,14 @@ def leg_grid2048(a, local_rank, torch):
     with Engine(g, device=local_rank) as eng:
         eng.bp_set_evidence(ev)
         t = time_bp(eng, g, a.eps, steps, 1, torch, event_steps=2)
+        cyc = time_cycled(eng, g, evidence_cycle(g, a.evidence, 4), a.eps, 4)
     out = {"workload": f"2048x2048 2D-grid BN, k=4, {g.n} nodes, {g.n_edges} edges, {ev.ne} evidence nodes, eps={a.eps:g} "
                        "(working set beyond the 256 MiB Infinity Cache)",
-           "value": t["msgs"] / t["dt"], "unit": "edge-messages/s", "ms_per_step": t["dt"] / steps * 1e3, "steps": steps,
-           "sweeps_per_step": t["sweeps_total"] / steps, "messages_per_sweep": g.messages_per_sweep(),
+           "value": cyc["value"], "unit": "edge-messages/s", "ms_per_step": cyc["ms_per_step"], "steps": cyc["steps"],
+           "sweeps_per_step": cyc["sweeps_per_step"], "messages_per_sweep": g.messages_per_sweep(),
+           "cycled_evidence": cyc,
+           "same_evidence": {"value": t["msgs"] / t["dt"], "ms_per_step": t["dt"] / steps * 1e3, "steps": steps,
+                             "sweeps_per_step": t["sweeps_total"] / steps},
            "roofline": roofline_of(t, "grid2048")}
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps, budget_s=1.0, max_sweeps=3, max_runs=1)
@@ -414,7 +500,8 @@ def main():
         "sweep_only_msgs_per_s": g.messages_per_sweep() / t["avg_sweep_s"],
     }
     if not a.no_extras:
-        h2h = time_host_to_host(eng, g, ev, a.eps, min(a.steps, 20))
+        h2h = time_host_to_host(eng, g, evidence_cycle(g, a.evidence), a.eps, max(min(a.steps, 40), 16))
+        out["cycled_evidence"] = time_cycled(eng, g, evidence_cycle(g, a.evidence), a.eps, max(min(a.steps, 40), 16))
         out["value_host_to_host"] = h2h["value"]
         out["host_to_host"] = h2h
     if not a.no_cpu:

@@ -77,20 +77,23 @@ public:
             ev_val.insert(ev_val.end(), p.second[0].begin(), p.second[0].end());
             ev_off.push_back(static_cast<std::int32_t>(ev_val.size()));
         }
-        std::vector<double> beliefs(static_cast<std::size_t>(model_.node_off.back()));
+        // the marginals arrive in a page-locked buffer the engine owns (one DMA behind the run, one
+        // synchronisation for upload + run + download); the map is built straight from it
+        double const* beliefs = nullptr;
         std::int32_t sweeps = 0;
         double residual = 0;
-        mi355x::engine_handle::check(bn_bp_run(
+        mi355x::engine_handle::check(bn_bp_run_view(
             engine_.get(), static_cast<std::int32_t>(ev_node.size()), ev_node.data(), ev_off.data(), ev_val.data(),
-            epsilon, 0 /* unbounded, like the reference */, beliefs.data(), &sweeps, &residual));
+            epsilon, 0 /* unbounded, like the reference */, &beliefs, &sweeps, &residual));
         last_sweeps_ = sweeps;
         last_residual_ = residual;
 
         return_type result;
+        result.reserve(model_.nodes.size());
         for(std::size_t i = 0; i < model_.nodes.size(); ++i)
         {
             matrix_type m(1, static_cast<std::size_t>(model_.k[i]));
-            m.assign(beliefs.begin() + model_.node_off[i], beliefs.begin() + model_.node_off[i + 1]);
+            m.assign(beliefs + model_.node_off[i], beliefs + model_.node_off[i + 1]);
             result[model_.nodes[i]] = m;
         }
         return result;

@@ -119,6 +119,13 @@ int bn_bp_set_evidence(bn_engine *eng, int32_t ne, const int32_t *ev_node, const
 int bn_bp_run_device(bn_engine *eng, double eps, int32_t max_sweeps, int32_t *sweeps_out,
                      double *residual_out);
 const double *bn_bp_beliefs_device(bn_engine *eng);
+/* bn_bp_run with the marginals left in a page-locked host buffer owned by the engine (*beliefs_view, [sum k],
+ * valid until the next run on this engine): evidence upload, run and the copy of the beliefs are queued back
+ * to back and waited for ONCE, and a caller that unpacks the flat array anyway (the C++ functor building its
+ * map of 1 x k matrices, belief_propagation.hpp:151-158) reads it in place. */
+int bn_bp_run_view(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_off,
+                   const double *ev_val, double eps, int32_t max_sweeps, const double **beliefs_view,
+                   int32_t *sweeps_out, double *residual_out);
 int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
 
 /*
@@ -191,7 +198,8 @@ typedef struct bn_bp_stats {
     int64_t layout_bytes_per_sweep;      /* bytes the sweep kernel actually requests         */
     int64_t messages_per_sweep;          /* 2E                                              */
     float sweep_devclock_ms;   /* device clock: first sweep's start -> last executed sweep's end */
-    float pad_;
+    int32_t resident_aborts;   /* resident launches that gave up a bounded wait, over the engine's life: each sends
+                                  the following runs down the per-sweep launches for a while (8, 16, ... runs) */
 } bn_bp_stats;
 int bn_bp_last_stats(bn_engine *eng, bn_bp_stats *out);
 

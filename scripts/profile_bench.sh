@@ -6,7 +6,7 @@
 # Every pass puts the program itself after `--` (no env / shell hop); switches travel as exported
 # environment variables.  A pass that fails is recorded in failed_passes.txt and reported by the summary.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
@@ -40,10 +40,12 @@ export BN_MULTISWEEP=1
 trace trace_dag10k $B --workload dag --steps 20 --warmup 3
 pmc fetch_dag10k FETCH_SIZE $B --workload dag --steps 5 --warmup 2
 pmc write_dag10k WRITE_SIZE $B --workload dag --steps 5 --warmup 2
+pmc sq_dag10k "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload dag --steps 5 --warmup 2
 # config 5: likelihood weighting
 trace trace_lw $B --workload lw --steps 3
 pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
 pmc write_lw WRITE_SIZE $B --workload lw --steps 2
+pmc sq_lw "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload lw --steps 2
 # the HBM-resident point (4M nodes)
 trace trace_grid2048 $B --rows 2048 --cols 2048 --steps 3 --warmup 1
 pmc fetch_grid2048 FETCH_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1

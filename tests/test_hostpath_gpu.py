@@ -1,0 +1,87 @@
+"""The drop-in's host path (bn_bp_run / bn_bp_run_view): evidence upload, run and download queued back to back
+behind ONE synchronisation must give what the three-step path (set_evidence, run_device, copy_beliefs) gives,
+on both execution paths, for changing evidence sets, and when the predicted sweep count is wrong.
+Reference: belief_propagation.hpp:31 (one call = evidence in, marginals out), :151-158 (beliefs)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(bnlib):
+    from bayesiannetwork_amd.engine import Engine
+    return Engine
+
+
+def _three_steps(eng, ev, eps, max_sweeps=0):
+    eng.bp_set_evidence(ev)
+    r = eng.bp_run_device(eps, max_sweeps)
+    r["beliefs"] = eng.bp_beliefs()
+    return r
+
+
+@pytest.mark.parametrize("multisweep", [0, 2])
+def test_run_and_view_equal_three_step_path(Engine, oracle_mod, multisweep):
+    from bayesiannetwork_amd import synth
+    g = synth.grid(72, 65, 4, seed=21)
+    evs = [synth.random_evidence(g, f, seed=3 + q) for q, f in enumerate([0.0, 0.01, 0.2, 0.05, 0.0])]
+    with Engine(g) as eng:
+        eng.set_option("multisweep", multisweep)
+        for ev, eps in zip(evs, [1e-3, 1e-6, 1e-3, 1e-9, 1e-5]):  # sweep counts differ from call to call
+            want = oracle_mod.bp_run(g, ev, eps)
+            a = eng.bp_run(ev, eps)
+            assert eng.last_path() == multisweep
+            v = eng.bp_run_view(ev, eps)
+            view_copy = v["beliefs"].copy()
+            b = _three_steps(eng, ev, eps)
+            assert a["sweeps"] == v["sweeps"] == b["sweeps"] == want["sweeps"]
+            assert np.array_equal(a["beliefs"], want["beliefs"])
+            assert np.array_equal(view_copy, want["beliefs"])
+            assert np.array_equal(b["beliefs"], want["beliefs"])
+        capped = eng.bp_run_view(evs[1], 1e-12, max_sweeps=3)
+        assert capped["sweeps"] == 3
+        assert np.array_equal(capped["beliefs"], oracle_mod.bp_run(g, evs[1], 1e-12, max_sweeps=3)["beliefs"])
+
+
+def test_view_on_lane_group_and_any_arity_tiles(Engine, oracle_mod):
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(700, 4, 32, 4, seed=17)
+    mx = synth.random_dag(90, 3, 16, [2, 3, 5, 4], seed=8)
+    for net in (d, mx):
+        with Engine(net) as eng:
+            for q in range(3):
+                ev = synth.random_evidence(net, 0.03 * q, seed=q)
+                want = oracle_mod.bp_run(net, ev, 1e-6)
+                got = eng.bp_run_view(ev, 1e-6)
+                assert got["sweeps"] == want["sweeps"]
+                assert np.abs(got["beliefs"] - want["beliefs"]).max() < 1e-12
+
+
+def test_stats_report_resident_aborts(Engine):
+    from bayesiannetwork_amd import synth
+    g = synth.grid(40, 40, 4, seed=2)
+    with Engine(g) as eng:
+        eng.set_option("multisweep", 2)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() == 2
+        assert eng.bp_stats()["resident_aborts"] == 0
+
+
+def test_wide_split_batch_equals_single_queries(Engine):
+    """lanes_per_node = 3 (latency rules + 16 table entries per lane): a batch runs on the engine's dense twin, which
+    must use the SAME lane-group split so that every set keeps the bits of its single run (bn_plan.cpp)."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(260, 4, 24, 4, seed=23)
+    evs = [synth.random_evidence(g, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
+    with Engine(g, lanes_per_node=3) as eng:
+        cls = eng.layout_classes()
+        # the case must exercise both rules: wide lane groups (m = 3 -> 16 lanes, m = 4 -> 64) and any-arity tiles for
+        # one-lane shapes with more than four children
+        assert any(c["variant"] == 2 and c["lanes_per_node"] == 4 ** (c["m"] - 1) for c in cls), cls
+        assert any(c["variant"] == 3 and c["m"] <= 2 for c in cls), cls
+        singles = [eng.bp_run(ev, 1e-6) for ev in evs]
+        out = eng.bp_run_batch(evs, 1e-6)
+        for q, r in enumerate(singles):
+            assert out["sweeps"][q] == r["sweeps"]
+            assert np.array_equal(out["beliefs"][q], r["beliefs"]), f"set {q}: batch differs from the single run"
