@@ -120,6 +120,23 @@ struct ResidentSync {                   // one per evidence set; zeroed at creat
     unsigned long long blk[kResidentMaxBlocks][2];  // per tile block: the same, written by the block
     unsigned long long res[kResidentBudget];        // per-iteration maximum_difference, bit patterns (service block)
 };
+// Dataflow form (single evidence set, more than one tile block): no grid barrier.  Every TILE (wave) publishes, per
+// iteration, a pair of 8-byte granules {generation | half of its residual's bit pattern} into the slot of the
+// iteration's parity; a tile starts its next iteration once the tiles it exchanges messages with (Plan::nbr) carry
+// the generation of the previous one.  The stop decision lags by one iteration: a service block collects the
+// granules of iteration i while the tiles already compute i + 1, and publishes {generation, verdict}; a tile starts
+// iteration i + 2 only once the verdict of i is known, so records and node vectors of the state the run stops in
+// are still intact when it does (double buffers: the speculative iteration writes the OTHER buffer).
+constexpr int kFlowMaxTiles = kResidentWaves * kResidentMaxBlocks;
+enum : unsigned { kFlowGoOn = 0, kFlowConverged = 1, kFlowCapped = 2, kFlowAbort = 3, kFlowBudget = 4 };
+struct FlowSync {                      // zeroed at creation, after an aborted launch and before the generation would wrap
+    struct Line {
+        unsigned long long word;        // low 32 bits: generation of the last decided iteration; high 32: its verdict (kFlow*)
+        unsigned long long pad_[15];
+    } verdict[8];                       // copies on lines of their own: tile blocks poll copy blockIdx % 8
+    unsigned long long tile[2][kFlowMaxTiles][2];  // [iteration parity][tile]: {generation << 32 | residual half}
+    unsigned long long res[kResidentBudget];       // per-iteration maximum_difference, bit patterns
+};
 struct ResidentArgs {
     BpBuffers b;          // evidence set 0; set q's buffers follow at the strides below
     double eps;
@@ -138,8 +155,12 @@ struct ResidentArgs {
     int64_t slot_stride;              // bytes between their evidence marks
     int64_t belief_stride;            // doubles between their beliefs
     int32_t res_hist_stride;          // doubles between their residual histories
+    // dataflow form (flow != nullptr; n_sets == 1, n_tile_blocks > 1)
+    FlowSync* flow;
+    const int32_t* nbr;               // [n_tiles][kWave] neighbour tiles, -1 padded (Plan::nbr)
+    unsigned* host_abort;             // pinned: set by whoever gives up a bounded wait
 };
-int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // lean_k: uniform arity with <= 2 children per node, else 0
+int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // a.flow != nullptr: the dataflow form  // lean_k: uniform arity with <= 2 children per node, else 0
 
 // launchers (bn_kernels.hip)
 int launch_bp_evidence(const EvidenceArgs& a, void* stream);  // bn_bp_set_evidence: marks + vectors

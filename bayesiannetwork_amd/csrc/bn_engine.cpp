@@ -148,6 +148,15 @@ struct bn_engine {
     int grid_resident = 0;
     ResidentSync* d_rsync = nullptr;
     bool rsync_dirty = true;        // the sync block must be zeroed before the next launch
+    // dataflow form of the resident kernel (no grid barrier; single evidence set, more than one tile block)
+    bool flow_ok = false;           // every tile has <= 64 neighbour tiles
+    int flow = 1;                   // option "flow" / BN_RESIDENT_FLOW: 1 = use it where eligible, 0 = grid barrier per sweep
+    FlowSync* d_flow = nullptr;
+    bool flow_dirty = true;
+    uint32_t flow_gen_base = 0;
+    int32_t* d_nbr = nullptr;
+    unsigned* h_abort = nullptr;    // pinned + mapped: set by a kernel that gives up a bounded wait
+    unsigned* h_abort_dev = nullptr;
     uint32_t gen_base = 0;          // barrier generations used so far on d_rsync
     // several evidence sets per launch (bn_bp_*_batch): per-set records, node vectors, marks, beliefs, histories
     struct Batch {
@@ -206,12 +215,13 @@ static void free_engine(bn_engine* e) {
         if (e->comm_stream) (void)hipStreamDestroy(e->comm_stream);
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_flat_tab, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
-                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync,
+                        e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync, e->d_flow, e->d_nbr,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
+        if (e->h_abort) (void)hipHostFree(e->h_abort);
         if (e->batch.h_ctl) (void)hipHostFree(e->batch.h_ctl);
         if (e->h_ev) (void)hipHostFree(e->h_ev);
         if (e->h_beliefs) (void)hipHostFree(e->h_beliefs);
@@ -344,6 +354,16 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 if (td.cmax > 2 || int(td.kv) != e->resident_lean) e->resident_lean = 0;
             e->grid_resident = int(nb);
             if (ok) HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_rsync), sizeof(ResidentSync)));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_abort), 64, hipHostMallocMapped));
+            std::memset(e->h_abort, 0, 64);
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_abort_dev), e->h_abort, 0));
+            e->flow_ok = ok && nb > 1 && !p.nbr.empty() && p.nbr_max <= kWave && nt <= kFlowMaxTiles;
+            if (e->flow_ok) {
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_flow), sizeof(FlowSync)));
+                int r2;
+                if ((r2 = upload(&e->d_nbr, p.nbr, e->stream))) return r2;
+            }
+            if (const char* f = std::getenv("BN_RESIDENT_FLOW")) e->flow = std::atoi(f) != 0;
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -592,14 +612,22 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
     for (;;) {
         // polled words: generations count on from launch to launch, so they are zeroed only at creation, after an
         // aborted launch and before the 30-bit generation would wrap
-        if (e->rsync_dirty || e->gen_base > (1u << 29)) {
+        const bool flow = e->flow_ok && e->flow != 0;
+        if (flow) {
+            if (e->flow_dirty || e->flow_gen_base > (1u << 29)) {
+                HIPCHK(hipMemsetAsync(e->d_flow, 0, sizeof(FlowSync), s));
+                e->flow_dirty = false;
+                e->flow_gen_base = 0;
+            }
+        } else if (e->rsync_dirty || e->gen_base > (1u << 29)) {
             HIPCHK(hipMemsetAsync(e->d_rsync, 0, sizeof(ResidentSync), s));
             e->rsync_dirty = false;
             e->gen_base = 0;
         }
-        ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id, e->gen_base,
+        *e->h_abort = 0;
+        ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id, flow ? e->flow_gen_base : e->gen_base,
                        5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev,
-                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0};
+                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr, e->d_nbr, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -613,10 +641,11 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         HIPCHK(hipStreamSynchronize(s));
         e->ev_upload_pending = false;
         ++launches;
-        e->gen_base += kResidentBudget + 1;
-        if (e->h_ctl->run_id != e->run_id || e->h_ctl->done < 0) e->rsync_dirty = true;
+        (flow ? e->flow_gen_base : e->gen_base) += kResidentBudget + 1;
+        const bool gave_up = e->h_ctl->done < 0 || *e->h_abort != 0;  // any block may raise it, whatever block 0 / the service reported
+        if (e->h_ctl->run_id != e->run_id || gave_up) (flow ? e->flow_dirty : e->rsync_dirty) = true;
+        if (gave_up) return fail(BN_ERR_STATE, "resident kernel gave up a bounded wait");
         if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
-        if (e->h_ctl->done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
         if (e->timing) {
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
@@ -732,6 +761,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (!e || !name) return fail(BN_ERR_ARG, "null argument");
     if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
     if (std::strcmp(name, "overlap") == 0) { e->overlap = value != 0; return BN_OK; }
+    if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -908,9 +938,10 @@ static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps
             bt.sync_dirty = false;
             bt.gen_base = 0;
         }
+        *e->h_abort = 0;
         ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
                        bt.h_ctl_dev + first, e->grid_resident, count, mask, p.rec_total_doubles, p.node_doubles,
-                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap};
+                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -927,6 +958,10 @@ static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps
             ms += t;
         }
         bt.gen_base += kResidentBudget + 1;
+        if (*e->h_abort != 0) {
+            bt.sync_dirty = true;
+            return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
+        }
         uint32_t next = 0;
         for (int32_t q = 0; q < count; ++q) {
             if (!((mask >> q) & 1u)) continue;

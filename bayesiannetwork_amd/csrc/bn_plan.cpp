@@ -480,6 +480,29 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
                 p.in_refs[td.in_ref_base + int64_t(j) * c.npt + p.node_nl[v]] = p.edge_ref[p.in_ptr[v] + j];
     }
 
+    // ---- neighbour tiles (dataflow form of the resident kernel): the tiles of the parents and children of a tile's
+    // nodes on this rank, ascending, without the tile itself
+    {
+        std::vector<std::vector<int32_t>> nb(nt);
+        for (int64_t e = 0; e < p.E; ++e) {
+            const int32_t tu = p.node_tile[p.in_idx[e]], tv = p.node_tile[edge_child[e]];
+            if (tu < 0 || tv < 0 || tu == tv) continue;
+            nb[tu].push_back(tv);
+            nb[tv].push_back(tu);
+        }
+        p.nbr_max = 0;
+        for (int32_t t = 0; t < nt; ++t) {
+            std::sort(nb[t].begin(), nb[t].end());
+            nb[t].erase(std::unique(nb[t].begin(), nb[t].end()), nb[t].end());
+            p.nbr_max = std::max(p.nbr_max, int32_t(nb[t].size()));
+        }
+        p.nbr.clear();
+        if (p.nbr_max <= kWave) {
+            p.nbr.assign(size_t(std::max(nt, 1)) * kWave, -1);
+            for (int32_t t = 0; t < nt; ++t) std::copy(nb[t].begin(), nb[t].end(), p.nbr.begin() + size_t(t) * kWave);
+        }
+    }
+
     // ---- metrics, this rank's share: CPT of owned nodes once; every message it
     // produces and every owned node vector read once and written once
     int64_t vec = 0, cpt_owned = 0, msgs = 0;

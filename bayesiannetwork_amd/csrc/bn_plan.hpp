@@ -171,6 +171,12 @@ struct Plan {
     int64_t algorithmic_bytes = 0, layout_bytes = 0, messages_per_sweep = 0;
     int32_t g_max = 1;
     int32_t n_interior_tiles = 0;    // tiles [0, n_interior_tiles) touch no cut edge (all tiles when nranks == 1)
+    // Dataflow form of the resident kernel (bn_resident.hip): a tile waits for ITS neighbours only -- the tiles that
+    // hold a parent or a child of one of its nodes, i.e. every tile that writes a message it reads or reads one it
+    // writes -- instead of for a grid barrier.  Neighbour t-th of tile T at nbr[T * kWave + t] (lane t polls it),
+    // -1 beyond nbr_count; a tile with more than kWave neighbours makes the plan ineligible (nbr_max > kWave).
+    std::vector<int32_t> nbr;        // [n_tiles * kWave]
+    int32_t nbr_max = 0;             // most neighbours any tile has
     int32_t variants = 0;            // bit v set: some class is of Variant v (selects the kernel instantiation)
     bool light = false;              // no register-resident / k = 4 lane-group tile: the high-occupancy launch applies
 };

@@ -27,7 +27,7 @@
 //
 // SEVERAL EVIDENCE SETS PER LAUNCH (bn_bp_run_batch).  The CPT image, the references and the layout are the
 // same for every query on a network; only messages, node vectors and evidence marks are per query.  The
-// kernel walks B sets round-robin -- sweep s of set A, arrive at A's barrier, sweep s of set B, arrive at B's,
+// kernel walks B <= kResidentMaxSets = 4 sets round-robin -- sweep s of set A, arrive at A's barrier, sweep s of set B, arrive at B's,
 // wait for A's barrier, sweep s+1 of A, ... -- so the ~3.5 us a barrier takes to complete are spent computing
 // the other sets instead of waiting, and one resident CPT serves all of them.  Every set has its own
 // record / node buffers, barrier words, residuals and verdict, and leaves the rotation on the sweep ITS
@@ -143,6 +143,7 @@ __device__ __forceinline__ bool poll_until(const ResidentArgs& a, Pred&& pred) {
         if (pred()) return true;
         if (__hip_atomic_load(&a.sync->abort, RLX_AGENT) != 0) return false;  // set 0's word is the launch's abort flag
         if (wall_clock64() - t0 > a.timeout_ticks) {
+            if (pred()) return true;  // a wave that was descheduled across the deadline looks once more before giving up
             __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
             return false;
         }
@@ -233,7 +234,7 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
             RSTAMP(1, it, lane, wave);  // verdict of the previous iteration known
             if (v != kGoOn || it == a.budget) {
                 const int done = v != kGoOn ? v : 0;
-                finalize(set, s, done);
+                finalize(set, s, done, true);
                 if (blockIdx.x == 0 && wave == 0) {  // report: residual history (final since each barrier), outcome
                     const ResidentSync* sy = a.sync + set;
                     double* hist = a.b.res_hist + int64_t(set) * a.res_hist_stride;
@@ -263,16 +264,175 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
 // A wave without a tile: takes part in the barriers, contributes nothing.
 template <bool BATCH>
 __device__ __forceinline__ bool resident_idle(const ResidentArgs& a, BlockShared& sh, int lane, int wave) {
-    return resident_drive<BATCH>(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int) {});
+    return resident_drive<BATCH>(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int, bool) {});
+}
+
+// ---- the dataflow form: no grid barrier (single evidence set, more than one tile block) -----------------------
+// Jacobi iteration i + 1 of a tile reads what its NEIGHBOUR tiles wrote in iteration i and overwrites what they read in
+// iteration i (double buffers), nothing else (belief_propagation.hpp:78-101 read the old maps, :135-143 commit): a
+// wave may start i + 1 as soon as every neighbour tile has finished i.  Each wave publishes, per iteration, a granule
+// pair {generation | residual half} of its own; lane t of a waiting wave polls neighbour t's.  No __syncthreads, no
+// block-level arrival: a slow wave holds up its neighbours only, and that skew averages out over the iterations
+// instead of being paid at every barrier.
+// The stop decision (:147) needs the maximum over ALL tiles, so it lags: the service block (here all its 8 waves)
+// collects the granules of iteration i while the tiles compute i + 1 and publishes {generation, verdict}; a tile
+// starts i + 2 only once the verdict of i is known.  When the verdict says "stop after i" a tile has at most
+// executed i + 1 as well: that speculative iteration wrote the OTHER record / node buffer, so the state the run ends
+// in is intact -- messages in the record buffer, pi(v) / lambda(v) in the node buffer every iteration stores them to
+// (or still in registers when the tile had not started the speculative iteration).
+__device__ __forceinline__ void flow_raise_abort(const ResidentArgs& a) {
+    const unsigned long long w = (unsigned long long)(a.gen_base + 1u) | ((unsigned long long)kFlowAbort << 32);
+    for (int q = 0; q < 8; ++q) __hip_atomic_store(&a.flow->verdict[q].word, w, RLX_AGENT);
+    __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Waits until this tile may run iteration `it`; returns the verdict that ends the run for it (kFlowGoOn: run the
+// iteration) and, with a stop verdict, the number of iterations the run consists of in n_it.
+__device__ __forceinline__ unsigned flow_wait(const ResidentArgs& a, int tile, int it, int lane, int& n_it) {
+    n_it = 0;
+    if (it == 0) return kFlowGoOn;
+    FlowSync* f = a.flow;
+    const int nbr = a.nbr[int64_t(tile) * kWave + lane];
+    const unsigned long long* nb_granule = &f->tile[(it - 1) & 1][nbr < 0 ? 0 : nbr][0];
+    const unsigned long long* vword = &f->verdict[blockIdx.x & 7].word;
+    const unsigned want_nb = a.gen_base + unsigned(it);      // the neighbours have finished iteration it - 1
+    const unsigned want_v = a.gen_base + unsigned(it) - 1u;  // iteration it - 2 is decided
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        bool nb_ok = true;
+        if (nbr >= 0) nb_ok = unsigned(__hip_atomic_load(nb_granule, RLX_AGENT) >> 32) - want_nb < 0x40000000u;  // >= in wrap-around arithmetic
+        const unsigned long long w = __hip_atomic_load(vword, RLX_AGENT);
+        const unsigned gen = unsigned(w), kind = unsigned(w >> 32);
+        const bool ours = gen - (a.gen_base + 1u) < 0x40000000u;  // published by THIS launch (generations count on across launches)
+        if (ours && kind != kFlowGoOn) {
+            n_it = int(gen - a.gen_base);
+            return kind;
+        }
+        const bool v_ok = it < 2 || (ours && gen - want_v < 0x40000000u);
+        if (it < a.budget && v_ok && __all(nb_ok)) return kFlowGoOn;
+        if (wall_clock64() - t0 > a.timeout_ticks) {
+            if (lane == 0) flow_raise_abort(a);
+            return kFlowAbort;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <class Phase, class Finalize>
+__device__ __forceinline__ bool flow_drive(const ResidentArgs& a, int tile, int lane, int wave, Phase&& phase, Finalize&& finalize) {
+    for (int it = 0;; ++it) {
+        RSTAMP(0, it, lane, wave);
+        int n_it;
+        const unsigned v = flow_wait(a, tile, it, lane, n_it);
+        RSTAMP(1, it, lane, wave);  // neighbours ready, verdict of it - 2 known
+        if (v == kFlowAbort) return false;
+        if (v != kFlowGoOn) {  // the run consists of n_it iterations of this launch; this wave has executed `it` (n_it or n_it + 1)
+            finalize(0, a.sweep_begin + n_it, v == kFlowBudget ? 0 : int(v), n_it == it);
+            return true;
+        }
+        const double wres = phase(0, a.sweep_begin + it);
+        const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
+        RSTAMP(3, it, lane, wave);  // sweep issued
+        drain_stores();             // this wave's write-through stores have reached memory
+        RSTAMP(4, it, lane, wave);
+        if (lane == 0) {
+            const unsigned gen = a.gen_base + unsigned(it) + 1u;
+            unsigned long long* g = &a.flow->tile[it & 1][tile][0];
+            __hip_atomic_store(g, granule(gen, unsigned(bits >> 32)), RLX_AGENT);
+            __hip_atomic_store(g + 1, granule(gen, unsigned(bits)), RLX_AGENT);
+        }
+        RSTAMP(6, it, lane, wave);  // granules published
+    }
+}
+
+// The service block of the dataflow form, all kResidentWaves waves: thread x sweeps the granule pairs of tiles x, x + 512,
+// ... of the iteration in hand until they carry its generation; the block reduces, thread 0 decides and publishes.
+__device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared& sh, int lane, int wave) {
+    FlowSync* f = a.flow;
+    const int nt = a.b.n_tiles;
+    const unsigned long long t_first = wall_clock64();
+    if (threadIdx.x == 0) sh.verdict[1] = 0;
+    __syncthreads();
+    int n_it = 0;
+    unsigned v = kFlowGoOn;
+    for (int it = 0; it < a.budget; ++it) {
+        const unsigned gen = a.gen_base + unsigned(it) + 1u;
+        unsigned long long m = 0;
+        const unsigned long long t0 = wall_clock64();
+        bool ok = true;
+        for (;;) {
+            bool mine = true;
+            unsigned long long acc = 0;
+            for (int t = threadIdx.x; t < nt; t += kResidentWaves * kWave) {
+                const unsigned long long hi = __hip_atomic_load(&f->tile[it & 1][t][0], RLX_AGENT);
+                const unsigned long long lo = __hip_atomic_load(&f->tile[it & 1][t][1], RLX_AGENT);
+                mine = mine && unsigned(hi >> 32) == gen && unsigned(lo >> 32) == gen;
+                const unsigned long long x = (hi << 32) | (lo & 0xffffffffull);
+                acc = x > acc ? x : acc;
+            }
+            m = acc;
+            if (__all(mine)) break;
+            const unsigned long long w = __hip_atomic_load(&f->verdict[0].word, RLX_AGENT);
+            if (unsigned(w >> 32) == kFlowAbort && unsigned(w) - (a.gen_base + 1u) < 0x40000000u) { ok = false; break; }
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                if (lane == 0) flow_raise_abort(a);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        m = wave_umax(m);
+        if (lane == 0) {
+            sh.slot[0][wave] = m;
+            if (!ok) sh.verdict[1] = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned decision = kFlowAbort;
+            if (sh.verdict[1] == 0) {
+                unsigned long long mm = 0;
+#pragma unroll
+                for (int w = 0; w < kResidentWaves; ++w) mm = sh.slot[0][w] > mm ? sh.slot[0][w] : mm;
+                decision = unsigned(verdict_of(a, residual_of(mm), a.sweep_begin + it + 1));
+                if (decision == kFlowGoOn && it == a.budget - 1) decision = kFlowBudget;
+                __hip_atomic_store(&f->res[it], mm, RLX_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the residual is recorded before anyone learns the verdict
+                const unsigned long long word = (unsigned long long)gen | ((unsigned long long)decision << 32);
+                for (int q = 0; q < 8; ++q) __hip_atomic_store(&f->verdict[q].word, word, RLX_AGENT);
+            }
+            sh.verdict[0] = int(decision);
+        }
+        __syncthreads();
+        v = unsigned(sh.verdict[0]);
+        n_it = it + 1;
+        if (v != kFlowGoOn) break;
+    }
+    if (wave != 0) return;
+    // report: residual history, outcome, device clock
+    if (v != kFlowAbort) {
+        double* hist = a.b.res_hist;
+        for (int q = lane; q < n_it; q += kWave)
+            if (a.sweep_begin + q < a.b.res_cap) hist[a.sweep_begin + q] = residual_of(__hip_atomic_load(&f->res[q], RLX_AGENT));
+    }
+    if (lane == 0) {
+        Ctl* hc = a.host_ctl;
+        hc->last_res = (v != kFlowAbort && n_it > 0) ? residual_of(__hip_atomic_load(&f->res[n_it - 1], RLX_AGENT)) : 0.0;
+        hc->n_sweeps = a.sweep_begin + n_it;
+        hc->t_first = t_first;
+        hc->t_last = wall_clock64();
+        hc->run_id = a.run_id;
+        hc->done = v == kFlowAbort ? -1 : (v == kFlowBudget ? 0 : int(v));
+    }
 }
 
 // Tables of more than 32 entries (k = 4 with two parents: 64) keep the entries of the upper half of the
 // own states in LDS -- 16 bytes per lane and slot, lane-contiguous: conflict-free ds_read_b128 -- and the
 // lower half in registers; 128 VGPRs of CPT plus the working set do not fit 256 registers, and the
 // compiler's answer, scratch memory, would re-read two thirds of the table through the caches each sweep.
-template <int K, int M, int RC, bool BATCH>
-__device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+template <int K, int M, int RC, bool BATCH, bool FLOW>
+__device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int tile, int lane, int wave,
                                               double2_t* cpt_lds) {
+    static_assert(!(BATCH && FLOW), "the dataflow form runs one evidence set");
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
     constexpr int CB = (M > 0) ? C / K : 0;
@@ -570,13 +730,16 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
 #pragma unroll
             for (int i = 0; i < K; ++i) { piv[i] = pin[i]; lav[i] = lan[i]; }
         }
-        if constexpr (BATCH) store_nodes(set, s + 1);
+        // several sets: a set's vectors go through memory between its turns; dataflow form: the state the run stops in
+        // may be one iteration older than the registers (the stop decision lags)
+        if constexpr (BATCH || FLOW) store_nodes(set, s + 1);
         return wres;
     };
     // the set stopped after n sweeps (or the budget ran out, done == 0): node vectors to the buffer the next
     // reader expects (parity of n), beliefs = normalize(pi % lambda) (:151-158) when the run is over
-    auto finalize = [&](int set, int n, int done) {
+    auto finalize = [&](int set, int n, int done, bool regs_hold_n) {
         if constexpr (BATCH) load_nodes(set, n);
+        else if constexpr (FLOW) { if (!regs_hold_n) load_nodes(set, n); }  // every iteration stored its vectors
         else store_nodes(set, n);
         if (active && done != 0) {
             const int64_t boff = b.slot_boff[td.slot_base + lane];
@@ -592,42 +755,51 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
             for (int i = 0; i < K; ++i) beliefs[boff + i] = bel[i] / sum;
         }
     };
-    return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
+    if constexpr (FLOW) return flow_drive(a, tile, lane, wave, phase, finalize);
+    else return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
 }
 
-template <int K, int M, bool BATCH, int LEAN>
-__device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int lane, int wave,
+// MODE: 0 = one evidence set, grid barrier per sweep (one-block grids: LDS only); 1 = several evidence sets per launch
+// (node vectors through memory between a set's turns); 2 = one evidence set, dataflow form (no grid barrier)
+enum : int { kModeBarrier = 0, kModeBatch = 1, kModeFlow = 2 };
+
+template <int K, int M, int MODE, int LEAN>
+__device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int tile, int lane, int wave,
                                                   double2_t* cpt_lds) {
+    constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow;
 #ifdef BN_RES_ONLY_RC  // experiments: one instantiation only
-    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH>(a, sh, td, lane, wave, cpt_lds);
+    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
 #else
-    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
-    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH>(a, sh, td, lane, wave, cpt_lds);
-    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH>(a, sh, td, lane, wave, cpt_lds);
-    return resident_tile<K, M, 8, BATCH>(a, sh, td, lane, wave, cpt_lds);  // the host admits <= 8 children per node
+    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
+    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
+    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
+    return resident_tile<K, M, 8, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);  // the host admits <= 8 children per node
 #endif
 }
 
-// BATCH: several evidence sets per launch (node vectors through memory between a set's turns).
 // LEAN = k in {2, 3, 4}: every node has arity k and at most 2 children (grids, chains, polytrees of that
 // shape: the headline workload) -- an instantiation that carries no code or registers for the other shapes,
 // so its code-object figures (0 spills, tests/test_host_logic.py) are those of the path that actually runs.
 // LEAN = 0: every shape the resident path admits.
-template <bool BATCH, int LEAN>
+template <int MODE, int LEAN>
 __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(ResidentArgs a) {
+    constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow;
     __shared__ BlockShared sh;
     __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // the CPT entries not kept in registers, 18 KiB per wave
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // written now rather than kept in registers for the whole run
-        const unsigned long long t_first = wall_clock64();
-        for (int set = 0; set < a.n_sets; ++set) a.host_ctl[set].t_first = t_first;
+    if constexpr (!FLOW) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {  // written now rather than kept in registers for the whole run
+            const unsigned long long t_first = wall_clock64();
+            for (int set = 0; set < a.n_sets; ++set) a.host_ctl[set].t_first = t_first;
+        }
     }
-    // blocks past the tile blocks are the barrier's service blocks (one wave each)
+    // blocks past the tile blocks serve the barrier / collect the residuals
     const int nb = a.n_tile_blocks;
     if (int(blockIdx.x) >= nb) {
-        if (wave == 0) resident_service(a, lane);
+        if constexpr (FLOW) flow_service(a, sh, lane, wave);
+        else if (wave == 0) resident_service(a, lane);
         return;
     }
     // XCD-contiguous tile mapping (speed only), as in the per-sweep kernel
@@ -635,42 +807,47 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
     const int tile = lb * kResidentWaves + wave;
     bool ok;
     if (tile >= b.n_tiles) {
-        ok = resident_idle<BATCH>(a, sh, lane, wave);
+        if constexpr (FLOW) return;  // nobody waits for a wave without a tile
+        else ok = resident_idle<BATCH>(a, sh, lane, wave);
     } else {
         const TileDesc td = b.tiles[tile];
         double2_t* lds = cpt_lds_all[wave];
         {
 #ifdef BN_RES_ONLY_K
-            ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, BATCH, LEAN>(a, sh, td, lane, wave, lds);
+            ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, MODE, LEAN>(a, sh, td, tile, lane, wave, lds);
 #else
             if constexpr (LEAN != 0) {
                 switch (td.m) {
-                    case 0: ok = resident_dispatch<LEAN, 0, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                    case 1: ok = resident_dispatch<LEAN, 1, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
-                    default: ok = resident_dispatch<LEAN, 2, BATCH, LEAN>(a, sh, td, lane, wave, lds); break;
+                    case 0: ok = resident_dispatch<LEAN, 0, MODE, LEAN>(a, sh, td, tile, lane, wave, lds); break;
+                    case 1: ok = resident_dispatch<LEAN, 1, MODE, LEAN>(a, sh, td, tile, lane, wave, lds); break;
+                    default: ok = resident_dispatch<LEAN, 2, MODE, LEAN>(a, sh, td, tile, lane, wave, lds); break;
                 }
             } else {
                 switch (td.kv * 8 + td.m) {
-                    case 2 * 8 + 0: ok = resident_dispatch<2, 0, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 2 * 8 + 1: ok = resident_dispatch<2, 1, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 2 * 8 + 2: ok = resident_dispatch<2, 2, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 3 * 8 + 0: ok = resident_dispatch<3, 0, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 3 * 8 + 1: ok = resident_dispatch<3, 1, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 3 * 8 + 2: ok = resident_dispatch<3, 2, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 4 * 8 + 0: ok = resident_dispatch<4, 0, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    case 4 * 8 + 1: ok = resident_dispatch<4, 1, BATCH, 0>(a, sh, td, lane, wave, lds); break;
-                    default: ok = resident_dispatch<4, 2, BATCH, 0>(a, sh, td, lane, wave, lds); break;  // host admits only the shapes above
+                    case 2 * 8 + 0: ok = resident_dispatch<2, 0, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 2 * 8 + 1: ok = resident_dispatch<2, 1, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 2 * 8 + 2: ok = resident_dispatch<2, 2, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 3 * 8 + 0: ok = resident_dispatch<3, 0, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 3 * 8 + 1: ok = resident_dispatch<3, 1, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 3 * 8 + 2: ok = resident_dispatch<3, 2, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 4 * 8 + 0: ok = resident_dispatch<4, 0, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    case 4 * 8 + 1: ok = resident_dispatch<4, 1, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
+                    default: ok = resident_dispatch<4, 2, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;  // host admits only the shapes above
                 }
             }
 #endif
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // per-set outcomes were written as the sets stopped; the launch as a whole: timing, and the abort mark
-        const unsigned long long t_last = wall_clock64();
-        for (int set = 0; set < a.n_sets; ++set) {
-            a.host_ctl[set].t_last = t_last;
-            if (!ok) { a.host_ctl[set].run_id = a.run_id; a.host_ctl[set].done = -1; }
+    if constexpr (!FLOW) {
+        // a block that gave up a bounded wait says so itself: block 0 may long have reported its own outcome
+        if (!ok && threadIdx.x == 0 && a.host_abort) __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            // per-set outcomes were written as the sets stopped; the launch as a whole: timing, and the abort mark
+            const unsigned long long t_last = wall_clock64();
+            for (int set = 0; set < a.n_sets; ++set) {
+                a.host_ctl[set].t_last = t_last;
+                if (!ok) { a.host_ctl[set].run_id = a.run_id; a.host_ctl[set].done = -1; }
+            }
         }
     }
 }
@@ -680,13 +857,18 @@ int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void*
     (void)hipGetLastError();  // drop any stale error of this thread
     const dim3 g(grid_blocks), t(kResidentWaves * kWave);
     hipStream_t s = (hipStream_t)stream;
-    const bool batch = a.n_sets > 1;
-#define BN_RES_LAUNCH(B, L) hipLaunchKernelGGL((bp_resident_kernel<B, L>), g, t, 0, s, a)
+    const int mode = a.n_sets > 1 ? kModeBatch : (a.flow != nullptr ? kModeFlow : kModeBarrier);
+#define BN_RES_LAUNCH(L)                                                                          \
+    switch (mode) {                                                                               \
+        case kModeBatch: hipLaunchKernelGGL((bp_resident_kernel<kModeBatch, L>), g, t, 0, s, a); break;   \
+        case kModeFlow: hipLaunchKernelGGL((bp_resident_kernel<kModeFlow, L>), g, t, 0, s, a); break;     \
+        default: hipLaunchKernelGGL((bp_resident_kernel<kModeBarrier, L>), g, t, 0, s, a); break;         \
+    }
     switch (lean_k) {
-        case 2: if (batch) BN_RES_LAUNCH(true, 2); else BN_RES_LAUNCH(false, 2); break;
-        case 3: if (batch) BN_RES_LAUNCH(true, 3); else BN_RES_LAUNCH(false, 3); break;
-        case 4: if (batch) BN_RES_LAUNCH(true, 4); else BN_RES_LAUNCH(false, 4); break;
-        default: if (batch) BN_RES_LAUNCH(true, 0); else BN_RES_LAUNCH(false, 0); break;
+        case 2: BN_RES_LAUNCH(2); break;
+        case 3: BN_RES_LAUNCH(3); break;
+        case 4: BN_RES_LAUNCH(4); break;
+        default: BN_RES_LAUNCH(0); break;
     }
 #undef BN_RES_LAUNCH
     hipError_t e = hipGetLastError();

@@ -132,7 +132,7 @@ int bn_bp_copy_beliefs(bn_engine *eng, double *beliefs_out);
  * Several evidence sets on ONE network in one call -- an extension beside the drop-in: the reference's
  * operator() (belief_propagation.hpp:31) takes one query at a time, and each set here gets exactly the
  * result that call would give it (same sweep count, same bits).  Networks the resident kernel covers
- * (bn_set_option "multisweep") run up to 8 sets per launch, walked round-robin: one resident CPT image
+ * (bn_set_option "multisweep") run up to 4 sets per launch, walked round-robin: one resident CPT image
  * serves every set and each set's grid barrier completes while the others compute (more sets: consecutive
  * launches).  Every other network runs ALL sets in each per-sweep launch (one evidence set per blockIdx.y):
  * B queries share the launch, its latency and the CPT lines in the caches; a set that has converged drops
@@ -172,6 +172,9 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   and a grid barrier per sweep.  0 = always one launch per sweep; 1 = that path where it was measured
  *   faster (one-block networks, networks of >= 600 tiles); 2 = wherever eligible (tests, experiments).
  *   Results are bit-identical on either path.
+ * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 1):
+ *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
+ *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);

@@ -36,8 +36,10 @@ for name, mod in nets:
     with Engine(mod) as e:
         e.bp_set_evidence(Evidence.none())
         res = {}
-        for path in (1, 0):
-            e.set_option("multisweep", 2 * path)
+        # 0: one launch per sweep; 1: resident tiles, grid barrier per sweep; 2: resident tiles, dataflow form
+        for form in (2, 1, 0):
+            e.set_option("multisweep", 2 if form else 0)
+            e.set_option("flow", 1 if form == 2 else 0)
             for _ in range(3):
                 r = e.bp_run_device(1e-6)
             reps = 20
@@ -47,15 +49,17 @@ for name, mod in nets:
                 r = e.bp_run_device(1e-6)
                 dev += e.bp_stats()["sweep_devclock_ms"]
             wall = (time.perf_counter() - t0) / reps
-            res[path] = {"path": e.last_path(), "sweeps": r["sweeps"], "us_per_sweep_dev": dev / reps * 1e3 / r["sweeps"],
-                         "us_per_run_wall": wall * 1e6, "beliefs": e.bp_beliefs(), "res": e.bp_residuals()}
-        same = (np.array_equal(res[0]["beliefs"], res[1]["beliefs"], equal_nan=True) and np.array_equal(res[0]["res"], res[1]["res"])
-                and res[0]["sweeps"] == res[1]["sweeps"])
+            res[form] = {"path": e.last_path(), "sweeps": r["sweeps"], "us_per_sweep_dev": dev / reps * 1e3 / r["sweeps"],
+                         "us_per_run_wall": wall * 1e6, "beliefs": e.bp_beliefs(), "res": e.bp_residuals(),
+                         "aborts": e.bp_stats()["resident_aborts"]}
+        same = all(np.array_equal(res[0]["beliefs"], res[f]["beliefs"], equal_nan=True) and np.array_equal(res[0]["res"], res[f]["res"])
+                   and res[0]["sweeps"] == res[f]["sweeps"] for f in (1, 2))
         lay = e.layout()
         row = {"nodes": mod.n, "tiles": lay["n_tiles"], "sweeps": res[0]["sweeps"], "same_bits": bool(same),
-               "multi_path_taken": res[1]["path"],
+               "multi_path_taken": res[1]["path"], "aborts": res[2]["aborts"],
                "per_sweep_launch": {k: round(res[0][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")},
-               "one_launch": {k: round(res[1][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")}}
+               "one_launch": {k: round(res[1][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")},
+               "one_launch_flow": {k: round(res[2][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")}}
         out[name] = row
         print(name, json.dumps(row), flush=True)
 if len(sys.argv) <= 1:

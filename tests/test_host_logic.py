@@ -269,7 +269,7 @@ def test_hot_kernels_do_not_spill(bnlib):
         assert "bp_sweep_kernel" in name
         assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0 and r["vgpr"] <= 256, (name, r)
     res = kr.kernel_resources(os.path.join(csrc, "bn_resident.o"))
-    assert len(res) == 8
+    assert len(res) == 12  # {grid barrier, several sets, dataflow} x {LEAN k = 2, 3, 4; all shapes}
     for name, r in res.items():
         assert "bp_resident_kernel" in name and r["vgpr"] <= 256, (name, r)
         if ", 0>" not in name:  # LEAN = k: every node of arity k with <= 2 children -- what the headline grid runs (k = 4)

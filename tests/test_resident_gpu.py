@@ -23,19 +23,26 @@ def _launch_path(eng, ev, eps, max_sweeps=0):
 
 
 def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
+    """Both forms of the resident kernel: "flow" 1 = dataflow (a tile waits for its neighbour tiles, the stop decision
+    lags an iteration: the state the run ends in must be the one BEFORE the speculative iteration), 0 = grid barrier
+    per sweep.  One-block grids run the same LDS-only code under either setting."""
     r0, res0, (pi0, lam0) = want
     eng.set_option("multisweep", 2)
-    for i in range(reps):
-        r = eng.bp_run(ev, eps, max_sweeps)
-        assert eng.last_path() != 0
-        if want_path is not None:
-            assert eng.last_path() == want_path
-        assert r["sweeps"] == r0["sweeps"], f"run {i}"
-        assert np.array_equal(r["beliefs"], r0["beliefs"], equal_nan=True), f"run {i}"
-        assert r["residual"] == r0["residual"] or (np.isnan(r["residual"]) and np.isnan(r0["residual"]))
-    assert np.array_equal(eng.bp_residuals(), res0)
-    pi, lam = eng.bp_messages()
-    assert np.array_equal(pi, pi0, equal_nan=True) and np.array_equal(lam, lam0, equal_nan=True)
+    for flow in (1, 0):
+        eng.set_option("flow", flow)
+        for i in range(reps if flow else max(2, reps // 4)):
+            r = eng.bp_run(ev, eps, max_sweeps)
+            assert eng.last_path() != 0
+            if want_path is not None:
+                assert eng.last_path() == want_path
+            assert r["sweeps"] == r0["sweeps"], f"flow {flow} run {i}"
+            assert np.array_equal(r["beliefs"], r0["beliefs"], equal_nan=True), f"flow {flow} run {i}"
+            assert r["residual"] == r0["residual"] or (np.isnan(r["residual"]) and np.isnan(r0["residual"]))
+        assert np.array_equal(eng.bp_residuals(), res0), f"flow {flow}"
+        pi, lam = eng.bp_messages()
+        assert np.array_equal(pi, pi0, equal_nan=True) and np.array_equal(lam, lam0, equal_nan=True), f"flow {flow}"
+        assert eng.bp_stats()["resident_aborts"] == 0
+    eng.set_option("flow", 1)
 
 
 @pytest.mark.parametrize("rows,cols,k,frac,eps,reps", [
@@ -114,3 +121,27 @@ def test_paths_are_chosen_by_eligibility(Engine):
         eng.set_option("multisweep", 0)
         eng.bp_run(None, 1e-3)
         assert eng.last_path() == 0
+
+
+@pytest.mark.parametrize("flow", [1, 0])
+def test_resident_run_longer_than_one_launch(Engine, flow):
+    """A launch executes at most 1024 iterations; a longer run continues in another launch from the state the first
+    one left in memory (dataflow form: the node vectors every iteration stores, the record buffer of the right parity)."""
+    from bayesiannetwork_amd import synth
+    g = synth.grid(40, 33, 3, seed=77)   # 21 tiles in 3 blocks
+    ev = synth.random_evidence(g, 0.02, seed=5)
+    with Engine(g) as eng:
+        want = _launch_path(eng, ev, 0.0, max_sweeps=1100)   # eps = 0: never converges, stopped at max_sweeps
+        assert want[0]["sweeps"] == 1100
+        eng.set_option("multisweep", 2)
+        eng.set_option("flow", flow)
+        for _ in range(2):
+            r = eng.bp_run(ev, 0.0, 1100)
+            assert eng.last_path() == 2 and eng.bp_stats()["sweep_launches"] == 2
+            assert r["sweeps"] == 1100
+            assert np.array_equal(r["beliefs"], want[0]["beliefs"])
+            assert np.array_equal(eng.bp_residuals(), want[1])
+        pi, lam = eng.bp_messages()
+        assert np.array_equal(pi, want[2][0]) and np.array_equal(lam, want[2][1])
+        r = eng.bp_run(ev, 0.0, 1024)                        # exactly one launch's budget
+        assert r["sweeps"] == 1024 and np.array_equal(r["beliefs"], _launch_path(eng, ev, 0.0, max_sweeps=1024)[0]["beliefs"])
