@@ -74,6 +74,7 @@ SYMBOLS = [
     ("bn_bp_messages", ctypes.c_int, [ctypes.c_void_p, f64p, f64p]),
     ("bn_set_option", ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int32]),
     ("bn_bp_last_path", ctypes.c_int, [ctypes.c_void_p]),
+    ("bn_get_info", ctypes.c_int64, [ctypes.c_void_p, ctypes.c_char_p]),
     ("bn_bp_step_begin", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_bp_step_sweep", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double]),
     ("bn_bp_step_sweep_part", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32]),

@@ -157,7 +157,8 @@ struct ResidentArgs {
     int32_t res_hist_stride;          // doubles between their residual histories
     // dataflow form (flow != nullptr; n_sets == 1, n_tile_blocks > 1)
     FlowSync* flow;
-    const int32_t* nbr;               // [n_tiles][kWave] neighbour tiles, -1 padded (Plan::nbr)
+    const int32_t* nbr;               // [n_tiles][nbr_chunks][kWave] neighbour tiles, -1 padded (Plan::nbr)
+    int32_t nbr_chunks;
     unsigned* host_abort;             // pinned: set by whoever gives up a bounded wait
 };
 int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // a.flow != nullptr: the dataflow form  // lean_k: uniform arity with <= 2 children per node, else 0

@@ -188,7 +188,8 @@ struct bn_engine {
                                     // wavefront count for one query's latency (Plan::latency_rules_applied) run there
     int multisweep = 1;             // resident one-launch path: 0 never, 1 where it was measured faster (one block, or
                                     // >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
-    int32_t last_path = 0;          // 0 per-sweep launches, 1 one launch for the whole run
+    int32_t last_path = 0;          // 0 per-sweep launches, 2 one launch for the whole run (resident tiles)
+    int32_t last_flow = 0;          // ... in its dataflow form
     Ctl* h_ctl = nullptr;  // pinned
     Ctl* h_ctl_dev = nullptr;  // the same memory as the device sees it
     // run state
@@ -357,7 +358,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_abort), 64, hipHostMallocMapped));
             std::memset(e->h_abort, 0, 64);
             HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_abort_dev), e->h_abort, 0));
-            e->flow_ok = ok && nb > 1 && !p.nbr.empty() && p.nbr_max <= kWave && nt <= kFlowMaxTiles;
+            e->flow_ok = ok && nb > 1 && !p.nbr.empty() && nt <= kFlowMaxTiles;
             if (e->flow_ok) {
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_flow), sizeof(FlowSync)));
                 int r2;
@@ -627,7 +628,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         *e->h_abort = 0;
         ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id, flow ? e->flow_gen_base : e->gen_base,
                        5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev,
-                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr, e->d_nbr, e->h_abort_dev};
+                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr, e->d_nbr, e->plan.nbr_chunks, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -659,6 +660,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
     note_run_result(e);
     e->rows_clean = rows_were_clean;
     e->last_path = 2;
+    e->last_flow = (e->flow_ok && e->flow != 0) ? 1 : 0;
     e->stats.sweep_launches = launches;
     e->stats.sweep_kernel_ms = ms;
     e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
@@ -765,7 +767,18 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
-// 0 per-sweep launches, 2 resident tiles + grid barrier (bn_resident.hip)
+// Introspection for tests and tools: a named integer property of the engine / its last run.
+extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
+    if (!e || !name) return fail(BN_ERR_ARG, "null argument");
+    if (std::strcmp(name, "resident_eligible") == 0) return e->resident_ok ? 1 : 0;
+    if (std::strcmp(name, "flow_eligible") == 0) return e->flow_ok ? 1 : 0;
+    if (std::strcmp(name, "last_flow") == 0) return e->last_path == 2 ? e->last_flow : 0;
+    if (std::strcmp(name, "nbr_max") == 0) return e->plan.nbr_max;
+    if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
+    if (std::strcmp(name, "resident_aborts") == 0) return e->resident_aborts;
+    return fail(BN_ERR_ARG, std::string("unknown info ") + name);
+}
+// 0 per-sweep launches, 2 resident tiles (bn_resident.hip)
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;
@@ -941,7 +954,7 @@ static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps
         *e->h_abort = 0;
         ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
                        bt.h_ctl_dev + first, e->grid_resident, count, mask, p.rec_total_doubles, p.node_doubles,
-                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, e->h_abort_dev};
+                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, 1, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;

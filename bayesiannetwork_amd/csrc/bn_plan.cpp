@@ -497,9 +497,11 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
             p.nbr_max = std::max(p.nbr_max, int32_t(nb[t].size()));
         }
         p.nbr.clear();
-        if (p.nbr_max <= kWave) {
-            p.nbr.assign(size_t(std::max(nt, 1)) * kWave, -1);
-            for (int32_t t = 0; t < nt; ++t) std::copy(nb[t].begin(), nb[t].end(), p.nbr.begin() + size_t(t) * kWave);
+        p.nbr_chunks = std::max(1, (p.nbr_max + kWave - 1) / kWave);
+        if (p.nbr_chunks <= kMaxNbrChunks) {
+            const size_t per_tile = size_t(p.nbr_chunks) * kWave;
+            p.nbr.assign(size_t(std::max(nt, 1)) * per_tile, -1);
+            for (int32_t t = 0; t < nt; ++t) std::copy(nb[t].begin(), nb[t].end(), p.nbr.begin() + size_t(t) * per_tile);
         }
     }
 

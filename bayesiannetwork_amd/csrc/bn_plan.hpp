@@ -56,6 +56,7 @@ enum Variant : int32_t {
                            // CPT in lane e % G of the group; <= 8 parents, arities summing to <= 64
 };
 constexpr int kFlatMaxParents = 8;
+constexpr int kMaxNbrChunks = 4;   // dataflow form: a tile polls at most 4 x 64 neighbour tiles
 
 // Device-visible shape class.  POD.
 struct ClassDesc {
@@ -173,10 +174,12 @@ struct Plan {
     int32_t n_interior_tiles = 0;    // tiles [0, n_interior_tiles) touch no cut edge (all tiles when nranks == 1)
     // Dataflow form of the resident kernel (bn_resident.hip): a tile waits for ITS neighbours only -- the tiles that
     // hold a parent or a child of one of its nodes, i.e. every tile that writes a message it reads or reads one it
-    // writes -- instead of for a grid barrier.  Neighbour t-th of tile T at nbr[T * kWave + t] (lane t polls it),
-    // -1 beyond nbr_count; a tile with more than kWave neighbours makes the plan ineligible (nbr_max > kWave).
-    std::vector<int32_t> nbr;        // [n_tiles * kWave]
+    // writes -- instead of for a grid barrier.  Neighbour t of tile T at nbr[(T * nbr_chunks + t / kWave) * kWave +
+    // t % kWave] (lane t % kWave polls it in round t / kWave), -1 beyond the tile's count.  Empty when some tile has
+    // more than kMaxNbrChunks * kWave neighbours (the plan is then not eligible for the dataflow form).
+    std::vector<int32_t> nbr;        // [n_tiles * nbr_chunks * kWave]
     int32_t nbr_max = 0;             // most neighbours any tile has
+    int32_t nbr_chunks = 1;          // ceil(nbr_max / kWave)
     int32_t variants = 0;            // bit v set: some class is of Variant v (selects the kernel instantiation)
     bool light = false;              // no register-resident / k = 4 lane-group tile: the high-occupancy launch applies
 };

@@ -292,15 +292,24 @@ __device__ __forceinline__ unsigned flow_wait(const ResidentArgs& a, int tile, i
     n_it = 0;
     if (it == 0) return kFlowGoOn;
     FlowSync* f = a.flow;
-    const int nbr = a.nbr[int64_t(tile) * kWave + lane];
-    const unsigned long long* nb_granule = &f->tile[(it - 1) & 1][nbr < 0 ? 0 : nbr][0];
+    // lane t polls neighbour t (+ 64, + 128, ... for the few tiles with more than 64 neighbours: a grid's first column);
+    // a round whose neighbours were all seen ready is not polled again
+    const int32_t* nbr_list = a.nbr + int64_t(tile) * a.nbr_chunks * kWave + lane;
+    int round = 0;
+    int nbr = nbr_list[0];
+    const unsigned long long (*granules)[2] = f->tile[(it - 1) & 1];
     const unsigned long long* vword = &f->verdict[blockIdx.x & 7].word;
     const unsigned want_nb = a.gen_base + unsigned(it);      // the neighbours have finished iteration it - 1
     const unsigned want_v = a.gen_base + unsigned(it) - 1u;  // iteration it - 2 is decided
     const unsigned long long t0 = wall_clock64();
     for (;;) {
         bool nb_ok = true;
-        if (nbr >= 0) nb_ok = unsigned(__hip_atomic_load(nb_granule, RLX_AGENT) >> 32) - want_nb < 0x40000000u;  // >= in wrap-around arithmetic
+        if (nbr >= 0) nb_ok = unsigned(__hip_atomic_load(&granules[nbr][0], RLX_AGENT) >> 32) - want_nb < 0x40000000u;  // >= in wrap-around arithmetic
+        if (__all(nb_ok) && round + 1 < a.nbr_chunks) {  // wave-uniform: on to the next 64 neighbours
+            ++round;
+            nbr = nbr_list[round * kWave];
+            if (__any(nbr >= 0)) continue;
+        }
         const unsigned long long w = __hip_atomic_load(vword, RLX_AGENT);
         const unsigned gen = unsigned(w), kind = unsigned(w >> 32);
         const bool ours = gen - (a.gen_base + 1u) < 0x40000000u;  // published by THIS launch (generations count on across launches)

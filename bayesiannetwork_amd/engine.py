@@ -163,6 +163,10 @@ class Engine:
     def set_option(self, name: str, value: int) -> None:
         _lib.check(_lib.lib().bn_set_option(self._h, name.encode(), int(value)))
 
+    def info(self, name: str) -> int:
+        """bn_get_info: "flow_eligible", "last_flow", "nbr_max", "resident_eligible", "resident_blocks", "resident_aborts"."""
+        return _lib.check(_lib.lib().bn_get_info(self._h, name.encode()))
+
     def last_path(self) -> int:
         """2: the last run was one launch for the whole run (resident tiles); 0: one launch per sweep."""
         return _lib.check(_lib.lib().bn_bp_last_path(self._h))

@@ -178,6 +178,9 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
+/* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
+ * used the dataflow form), "nbr_max", "resident_blocks", "resident_aborts"; unknown name: BN_ERR_ARG. */
+int64_t bn_get_info(bn_engine *eng, const char *name);
 
 /* Single steps of a run (tests / diagnostics): begin, one sweep (without exchange), finish.
  * bn_debug_allgather emulates the exchange between n shard engines living on ONE device. */

@@ -35,6 +35,7 @@ def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
             assert eng.last_path() != 0
             if want_path is not None:
                 assert eng.last_path() == want_path
+            assert eng.info("last_flow") == (flow if eng.info("flow_eligible") else 0)
             assert r["sweeps"] == r0["sweeps"], f"flow {flow} run {i}"
             assert np.array_equal(r["beliefs"], r0["beliefs"], equal_nan=True), f"flow {flow} run {i}"
             assert r["residual"] == r0["residual"] or (np.isnan(r["residual"]) and np.isnan(r0["residual"]))
@@ -54,6 +55,9 @@ def test_resident_equals_launch_path_grids(Engine, rows, cols, k, frac, eps, rep
     g = synth.grid(rows, cols, k, seed=rows * 31 + cols)
     ev = synth.random_evidence(g, frac, seed=3)
     with Engine(g) as eng:
+        # every multi-block grid here must really take the dataflow form (a first-column tile of a wide grid has
+        # more than 64 neighbour tiles: polled in rounds of 64)
+        assert eng.info("flow_eligible") == (1 if eng.info("resident_blocks") > 1 else 0)
         want = _launch_path(eng, ev, eps)
         _check_same(eng, ev, eps, want, reps, want_path=2)
         # alternate the paths and the evidence: nothing of one run may leak into the next
