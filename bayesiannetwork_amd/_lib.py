@@ -51,6 +51,10 @@ SYMBOLS = [
     ("bn_create", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.POINTER(ctypes.c_void_p)]),
     ("bn_create_sharded", ctypes.c_int, [ctypes.POINTER(ModelDesc), ctypes.c_int32, ctypes.c_int32, i32p,
                                          ctypes.POINTER(ctypes.c_void_p)]),
+    ("bn_peer_blob_size", ctypes.c_int64, [ctypes.c_void_p]),
+    ("bn_peer_export", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    ("bn_peer_import", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), i64p, ctypes.c_int32]),
+    ("bn_layout_flow", ctypes.c_int, [ctypes.c_void_p, i32p, ctypes.POINTER(ctypes.c_uint32)]),
     ("bn_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_comm_init", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("bn_destroy", None, [ctypes.c_void_p]),

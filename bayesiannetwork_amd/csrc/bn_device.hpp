@@ -128,14 +128,33 @@ struct ResidentSync {                   // one per evidence set; zeroed at creat
 // iteration i + 2 only once the verdict of i is known, so records and node vectors of the state the run stops in
 // are still intact when it does (double buffers: the speculative iteration writes the OTHER buffer).
 constexpr int kFlowMaxTiles = kResidentWaves * kResidentMaxBlocks;
+static_assert(kFlowMaxTiles == kFlowSlotsPerRank, "one granule slot per possible tile of a rank");
+constexpr int kMaxRanks = 16;          // ranks of a sharded engine that can exchange inside the resident kernel
 enum : unsigned { kFlowGoOn = 0, kFlowConverged = 1, kFlowCapped = 2, kFlowAbort = 3, kFlowBudget = 4 };
-struct FlowSync {                      // zeroed at creation, after an aborted launch and before the generation would wrap
+// One allocation per engine: this header, then the granule table  [2 iteration parities][nranks * kFlowSlotsPerRank][2]
+// of {generation << 32 | residual half}: slot rank * kFlowSlotsPerRank + tile.  A rank writes its own tiles' slots --
+// in its own table and, for tiles that touch a cut edge, in the tables of the ranks across the cut (peer-mapped
+// memory: hipIpc handles between processes, plain pointers inside one) -- and polls only its own table.
+// Zeroed at creation, after an aborted launch and before the generation would wrap.
+struct FlowSync {
     struct Line {
         unsigned long long word;        // low 32 bits: generation of the last decided iteration; high 32: its verdict (kFlow*)
         unsigned long long pad_[15];
     } verdict[8];                       // copies on lines of their own: tile blocks poll copy blockIdx % 8
-    unsigned long long tile[2][kFlowMaxTiles][2];  // [iteration parity][tile]: {generation << 32 | residual half}
-    unsigned long long res[kResidentBudget];       // per-iteration maximum_difference, bit patterns
+    unsigned long long rank_granule[2][kMaxRanks][2];  // [parity][rank]: every rank's {generation | residual half} pair, written by that rank's service block
+    unsigned long long res[kResidentBudget];           // per-iteration maximum_difference, bit patterns
+};
+__host__ __device__ inline size_t flow_sync_bytes(int nranks) {
+    return sizeof(FlowSync) + sizeof(unsigned long long) * 2 * size_t(nranks) * kFlowSlotsPerRank * 2;
+}
+// What a rank needs of another to exchange inside the kernel (device array [nranks]; entry `rank` is the engine itself)
+struct PeerTable {
+    FlowSync* flow;   // the peer's sync block
+    double* rec0;     // the peer's record buffers: cut-edge halves are stored here as well as locally
+    double* rec1;
+    int64_t g_base;   // where the exchange region starts in THEIR record buffers (double2 units): the region's layout is
+                      // the same on every rank, its place behind the rank's own tile records is not
+    int64_t rec_bytes;  // size of one of their record buffers
 };
 struct ResidentArgs {
     BpBuffers b;          // evidence set 0; set q's buffers follow at the strides below
@@ -157,8 +176,13 @@ struct ResidentArgs {
     int32_t res_hist_stride;          // doubles between their residual histories
     // dataflow form (flow != nullptr; n_sets == 1, n_tile_blocks > 1)
     FlowSync* flow;
+    // ... of a sharded engine (peers != nullptr): halo exchange inside the kernel
+    const PeerTable* peers;           // [b.nranks]
+    const uint32_t* pub_mask;         // [n_tiles] bit q: the tile has a neighbour tile on rank q (gets its granules too)
+    int32_t n_interior;               // tiles [0, n_interior) touch no cut edge
     const int32_t* nbr;               // [n_tiles][nbr_chunks][kWave] neighbour tiles, -1 padded (Plan::nbr)
     int32_t nbr_chunks;
+    int32_t poll_sleep;               // pause between two polls of a waiting tile, in units of s_sleep(8) = 512 cycles
     unsigned* host_abort;             // pinned: set by whoever gives up a bounded wait
 };
 int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // a.flow != nullptr: the dataflow form  // lean_k: uniform arity with <= 2 children per node, else 0

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include <dlfcn.h>
@@ -150,11 +151,23 @@ struct bn_engine {
     bool rsync_dirty = true;        // the sync block must be zeroed before the next launch
     // dataflow form of the resident kernel (no grid barrier; single evidence set, more than one tile block)
     bool flow_ok = false;           // every tile has <= 64 neighbour tiles
-    int flow = 1;                   // option "flow" / BN_RESIDENT_FLOW: 1 = use it where eligible, 0 = grid barrier per sweep
+    int poll_sleep = 2;             // option "poll_sleep" / BN_POLL_SLEEP: pause between two polls of a waiting tile (x 512 cycles)
+    int flow = 0;                   // option "flow" / BN_RESIDENT_FLOW: 1 = dataflow form where eligible, 0 = grid barrier per sweep
+                                    // (the default on one GPU: measured equal per sweep, and the lagging stop decision costs one
+                                    // speculative iteration per run; sharded engines exchange through the dataflow form)
     FlowSync* d_flow = nullptr;
     bool flow_dirty = true;
     uint32_t flow_gen_base = 0;
     int32_t* d_nbr = nullptr;
+    // sharded engines: halo exchange inside the resident kernel (bn_peer_export / bn_peer_import)
+    bool shard_shapes_ok = false;   // this shard's tiles are what the resident kernel runs (uniform arity, <= 2 parents, <= 8 children)
+    bool shard_flow_ok = false;     // ... on every rank, and the peers' buffers are mapped: the dataflow form exchanges in-kernel
+    bool fine_grained = false;      // record buffers / sync block allocated fine-grained (peers store into them)
+    uint32_t shard_run_seq = 0;     // bn_bp_run_device calls on this sharded engine: every rank counts alike -> same generations
+    PeerTable* d_peers = nullptr;
+    uint32_t* d_pub_mask = nullptr;
+    std::vector<uint32_t> pub_mask; // host copy (introspection)
+    std::vector<void*> ipc_opened;  // hipIpcOpenMemHandle results to close
     unsigned* h_abort = nullptr;    // pinned + mapped: set by a kernel that gives up a bounded wait
     unsigned* h_abort_dev = nullptr;
     uint32_t gen_base = 0;          // barrier generations used so far on d_rsync
@@ -210,6 +223,9 @@ static void free_engine(bn_engine* e) {
         DeviceGuard guard;
         (void)guard.enter(e->device);
         lw_free(e->lw);
+        for (void* q : e->ipc_opened) (void)hipIpcCloseMemHandle(q);
+        if (e->d_peers) (void)hipFree(e->d_peers);
+        if (e->d_pub_mask) (void)hipFree(e->d_pub_mask);
         if (e->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(e->comm);
         if (e->ev_swept) (void)hipEventDestroy(e->ev_swept);
         if (e->ev_gathered) (void)hipEventDestroy(e->ev_gathered);
@@ -320,8 +336,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         if ((r = upload(&e->d_slot_boff, p.slot_boff, e->stream))) return r;
         if ((r = upload(&e->d_node_tile, p.node_tile, e->stream))) return r;
         if ((r = upload(&e->d_node_nl, p.node_nl, e->stream))) return r;
+        // shards: peers store cut-edge halves straight into these buffers from inside their kernels -> fine-grained
+        // (system-coherent) allocations; BN_SHARD_COARSE=1 keeps plain hipMalloc (A/B on one device)
+        e->fine_grained = p.nranks > 1 && !std::getenv("BN_SHARD_COARSE");
         for (int i = 0; i < 2; ++i) {
-            if ((r = dalloc(&e->d_rec[i], size_t(p.rec_total_doubles)))) return r;
+            if (e->fine_grained) {
+                HIPCHK(hipExtMallocWithFlags(reinterpret_cast<void**>(&e->d_rec[i]), std::max<size_t>(p.rec_total_doubles, 1) * 8,
+                                             hipDeviceMallocFinegrained));
+            } else if ((r = dalloc(&e->d_rec[i], size_t(p.rec_total_doubles)))) return r;
             if ((r = dalloc(&e->d_node[i], size_t(p.node_doubles)))) return r;
             HIPCHK(hipMemsetAsync(e->d_rec[i], 0, std::max<size_t>(p.rec_total_doubles, 1) * 8, e->stream));
             HIPCHK(hipMemsetAsync(e->d_node[i], 0, std::max<size_t>(p.node_doubles, 1) * 8, e->stream));
@@ -343,14 +365,16 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             HIPCHK(hipGetDeviceProperties(&prop, e->device));
             const int64_t nt = int64_t(p.tiles.size());
             int64_t nb = (nt + kResidentWaves - 1) / kResidentWaves;
-            if (nb > 1) nb = (nb + 7) & ~int64_t(7);
-            bool ok = p.nranks == 1 && nt > 0 && p.variants == (1 << kVariantUniform) &&
-                      nb + 1 <= int64_t(prop.multiProcessorCount) * 9 / 10 && nb <= kResidentMaxBlocks &&  // + the barrier's service block
-                      p.rec_total_doubles * 8 < (int64_t(1) << 31);  // 32-bit byte offsets into a record buffer
-            for (const TileDesc& td : p.tiles)
-                ok = ok && td.variant == kVariantUniform && td.cmax <= 8 && td.in_ref_base < 0 && td.m <= 2;
+            if (nb > 1 && p.nranks == 1) nb = (nb + 7) & ~int64_t(7);  // XCD-contiguous tile mapping wants a multiple of 8; shards keep the CUs for each other
+            bool shapes = (nt == 0 || p.variants == (1 << kVariantUniform)) &&
+                          nb + 1 <= int64_t(prop.multiProcessorCount) * 9 / 10 && nb <= kResidentMaxBlocks &&  // + the barrier's service block
+                          p.rec_total_doubles * 8 < (int64_t(1) << 31);  // 32-bit byte offsets into a record buffer
+            for (const TileDesc& td : p.tiles) shapes = shapes && td.variant == kVariantUniform && td.cmax <= 8 && td.m <= 2;
+            bool ok = shapes && p.nranks == 1 && nt > 0;
+            for (const TileDesc& td : p.tiles) ok = ok && td.in_ref_base < 0;
+            e->shard_shapes_ok = shapes && p.nranks > 1 && p.nranks <= kMaxRanks;
             e->resident_ok = ok;
-            e->resident_lean = ok && !p.tiles.empty() ? int(p.tiles[0].kv) : 0;
+            e->resident_lean = (ok || e->shard_shapes_ok) && !p.tiles.empty() ? int(p.tiles[0].kv) : 0;
             for (const TileDesc& td : p.tiles)
                 if (td.cmax > 2 || int(td.kv) != e->resident_lean) e->resident_lean = 0;
             e->grid_resident = int(nb);
@@ -360,11 +384,19 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_abort_dev), e->h_abort, 0));
             e->flow_ok = ok && nb > 1 && !p.nbr.empty() && nt <= kFlowMaxTiles;
             if (e->flow_ok) {
-                HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_flow), sizeof(FlowSync)));
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_flow), flow_sync_bytes(1)));
                 int r2;
                 if ((r2 = upload(&e->d_nbr, p.nbr, e->stream))) return r2;
             }
+            if (e->shard_shapes_ok) {  // zeroed HERE, once: peers write into it from their kernels whenever they run
+                if (e->fine_grained)
+                    HIPCHK(hipExtMallocWithFlags(reinterpret_cast<void**>(&e->d_flow), flow_sync_bytes(p.nranks), hipDeviceMallocFinegrained));
+                else
+                    HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_flow), flow_sync_bytes(p.nranks)));
+                HIPCHK(hipMemsetAsync(e->d_flow, 0, flow_sync_bytes(p.nranks), e->stream));
+            }
             if (const char* f = std::getenv("BN_RESIDENT_FLOW")) e->flow = std::atoi(f) != 0;
+            if (const char* z = std::getenv("BN_POLL_SLEEP")) e->poll_sleep = std::max(0, std::min(std::atoi(z), 64));
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -613,10 +645,17 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
     for (;;) {
         // polled words: generations count on from launch to launch, so they are zeroed only at creation, after an
         // aborted launch and before the 30-bit generation would wrap
-        const bool flow = e->flow_ok && e->flow != 0;
-        if (flow) {
+        const bool shard = e->plan.nranks > 1;  // (only called with shard_flow_ok then)
+        const bool flow = shard || (e->flow_ok && e->flow != 0);
+        if (shard) {
+            // Every rank derives the generations of a launch from the number of runs the engine has been asked for and
+            // the launch's place in the run: ranks agree without talking, nothing is ever zeroed while peers may be
+            // writing, and a granule left by an earlier (or an aborted) launch can never carry a wanted generation.
+            if (launches >= 4) return fail(BN_ERR_STATE, "sharded resident run needs more than 4 launches");
+            e->flow_gen_base = (((e->shard_run_seq & 0x3ffffu) << 2) + uint32_t(launches)) * uint32_t(kResidentBudget + 1);
+        } else if (flow) {
             if (e->flow_dirty || e->flow_gen_base > (1u << 29)) {
-                HIPCHK(hipMemsetAsync(e->d_flow, 0, sizeof(FlowSync), s));
+                HIPCHK(hipMemsetAsync(e->d_flow, 0, flow_sync_bytes(1), s));
                 e->flow_dirty = false;
                 e->flow_gen_base = 0;
             }
@@ -627,14 +666,17 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         }
         *e->h_abort = 0;
         ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id, flow ? e->flow_gen_base : e->gen_base,
-                       5000000ull /* 50 ms of the 100 MHz clock per wait */, e->d_rsync, e->h_ctl_dev,
-                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr, e->d_nbr, e->plan.nbr_chunks, e->h_abort_dev};
+                       // one wait: 50 ms of the 100 MHz clock; shards: 2 s (the ranks' launches start up to a host hiccup apart)
+                       shard ? 200000000ull : 5000000ull, e->d_rsync, e->h_ctl_dev,
+                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr,
+                       shard ? e->d_peers : nullptr, shard ? e->d_pub_mask : nullptr, shard ? e->plan.n_interior_tiles : 0,
+                       e->d_nbr, e->plan.nbr_chunks, e->poll_sleep, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
             HIPCHK(hipEventRecord(e->events[0], s));
         }
-        if (int code = launch_bp_resident(a, e->grid_resident + resident_service_blocks(e->grid_resident), e->resident_lean, s))
+        if (int code = launch_bp_resident(a, e->grid_resident + (shard ? 1 : resident_service_blocks(e->grid_resident)), e->resident_lean, s))
             return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
         if (copy_to)  // a launch that stops on its budget (1024 sweeps) copies an intermediate state; the last one counts
@@ -642,7 +684,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         HIPCHK(hipStreamSynchronize(s));
         e->ev_upload_pending = false;
         ++launches;
-        (flow ? e->flow_gen_base : e->gen_base) += kResidentBudget + 1;
+        if (!shard) (flow ? e->flow_gen_base : e->gen_base) += kResidentBudget + 1;
         const bool gave_up = e->h_ctl->done < 0 || *e->h_abort != 0;  // any block may raise it, whatever block 0 / the service reported
         if (e->h_ctl->run_id != e->run_id || gave_up) (flow ? e->flow_dirty : e->rsync_dirty) = true;
         if (gave_up) return fail(BN_ERR_STATE, "resident kernel gave up a bounded wait");
@@ -660,7 +702,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
     note_run_result(e);
     e->rows_clean = rows_were_clean;
     e->last_path = 2;
-    e->last_flow = (e->flow_ok && e->flow != 0) ? 1 : 0;
+    e->last_flow = (e->plan.nranks > 1 || (e->flow_ok && e->flow != 0)) ? 1 : 0;
     e->stats.sweep_launches = launches;
     e->stats.sweep_kernel_ms = ms;
     e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
@@ -672,7 +714,8 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
-    if (e->plan.nranks > 1 && !e->comm) return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init before running");
+    if (e->plan.nranks > 1 && !e->comm && !(e->shard_flow_ok && e->multisweep != 0))
+        return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init (RCCL exchange) or bn_peer_import (in-kernel exchange) before running");
     const auto t_begin = std::chrono::steady_clock::now();
     ON_DEVICE(e);
     hipStream_t s = e->stream;
@@ -681,7 +724,11 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
     constexpr int64_t kResidentMinTiles = 600;  // measured crossover: 160x160 grid (402 tiles) 8.2 vs 8.9 us per sweep, 200x200 (627) 9.5 vs 9.2
     const bool resident_pays = e->grid_resident == 1 || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
-    const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
+    if (e->plan.nranks > 1) ++e->shard_run_seq;
+    // shards: the in-kernel exchange wherever every rank's tiles qualify and the peers are mapped ("multisweep" 0 = the
+    // per-sweep launches with one RCCL all-gather per sweep)
+    const bool try_resident = e->plan.nranks > 1 ? (e->shard_flow_ok && e->multisweep != 0)
+                                                 : (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays)));
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
         rc = run_resident(e, eps, max_sweeps, copy_to);
@@ -704,6 +751,8 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
                          e->resident_cooldown);
     }
     e->last_path = 0;
+    if (e->plan.nranks > 1 && !e->comm)
+        return fail(BN_ERR_COMM, "the in-kernel exchange gave up and no RCCL communicator is set up to fall back on (bn_comm_init)");
     if ((rc = step_begin(e))) return rc;
     int32_t launched = 0, batches = 0;
     // every rank takes the same decisions: they all see the same sweep counts
@@ -764,6 +813,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
     if (std::strcmp(name, "overlap") == 0) { e->overlap = value != 0; return BN_OK; }
     if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
+    if (std::strcmp(name, "poll_sleep") == 0) { e->poll_sleep = std::max(0, std::min(value, 64)); return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -774,6 +824,9 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "flow_eligible") == 0) return e->flow_ok ? 1 : 0;
     if (std::strcmp(name, "last_flow") == 0) return e->last_path == 2 ? e->last_flow : 0;
     if (std::strcmp(name, "nbr_max") == 0) return e->plan.nbr_max;
+    if (std::strcmp(name, "nbr_chunks") == 0) return e->plan.nbr.empty() ? 0 : e->plan.nbr_chunks;
+    if (std::strcmp(name, "shard_flow") == 0) return e->shard_flow_ok ? 1 : 0;
+    if (std::strcmp(name, "n_boundary_nodes") == 0) return int64_t(e->plan.boundary_node.size());
     if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
     if (std::strcmp(name, "resident_aborts") == 0) return e->resident_aborts;
     return fail(BN_ERR_ARG, std::string("unknown info ") + name);
@@ -954,7 +1007,7 @@ static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps
         *e->h_abort = 0;
         ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
                        bt.h_ctl_dev + first, e->grid_resident, count, mask, p.rec_total_doubles, p.node_doubles,
-                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, 1, e->h_abort_dev};
+                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, nullptr, 0, nullptr, 1, 0, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -1261,6 +1314,146 @@ extern "C" int bn_comm_init(bn_engine* e, const void* id128) {
     if (r != ncclSuccess) {
         e->comm = nullptr;
         return fail(BN_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
+    return BN_OK;
+}
+
+// ---- in-kernel halo exchange of sharded engines: what a rank tells the others, and what it does with what they say ----
+namespace {
+struct PeerBlobHeader {
+    uint32_t magic;           // 'BNPB'
+    int32_t rank, nranks;
+    int32_t device;           // HIP ordinal in the exporting process, -1: host-only engine
+    int64_t pid;
+    int32_t n_boundary;       // (node, tile) pairs that follow
+    int32_t shapes_ok;        // this shard's tiles can run in the resident kernel
+    int64_t g_base, rec_bytes;  // start of the exchange region in its record buffers (double2 units), size of one buffer
+    uint64_t flow_ptr, rec0_ptr, rec1_ptr;  // raw device pointers (valid inside the exporting process)
+    hipIpcMemHandle_t h_flow, h_rec0, h_rec1;  // ... and their handles for other processes
+};
+constexpr uint32_t kPeerBlobMagic = 0x42504e42u;
+}  // namespace
+
+extern "C" int64_t bn_peer_blob_size(bn_engine* e) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    return int64_t(sizeof(PeerBlobHeader)) + int64_t(e->plan.boundary_node.size()) * 8;
+}
+
+extern "C" int bn_peer_export(bn_engine* e, void* blob, int64_t cap) {
+    if (!e || !blob) return fail(BN_ERR_ARG, "null argument");
+    if (e->plan.nranks < 2) return fail(BN_ERR_STATE, "not a sharded engine");
+    if (cap < bn_peer_blob_size(e)) return fail(BN_ERR_ARG, "blob buffer too small (bn_peer_blob_size)");
+    PeerBlobHeader h;
+    std::memset(&h, 0, sizeof h);
+    h.magic = kPeerBlobMagic;
+    h.rank = e->plan.rank;
+    h.nranks = e->plan.nranks;
+    h.device = e->host_only ? -1 : e->device;
+    h.pid = int64_t(getpid());
+    h.n_boundary = int32_t(e->plan.boundary_node.size());
+    h.shapes_ok = (e->host_only || e->shard_shapes_ok) ? 1 : 0;
+    h.g_base = e->plan.g_base;
+    h.rec_bytes = e->plan.rec_total_doubles * 8;
+    if (!e->host_only && e->shard_shapes_ok) {
+        ON_DEVICE(e);
+        h.flow_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_flow));
+        h.rec0_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_rec[0]));
+        h.rec1_ptr = uint64_t(reinterpret_cast<uintptr_t>(e->d_rec[1]));
+        HIPCHK(hipIpcGetMemHandle(&h.h_flow, e->d_flow));
+        HIPCHK(hipIpcGetMemHandle(&h.h_rec0, e->d_rec[0]));
+        HIPCHK(hipIpcGetMemHandle(&h.h_rec1, e->d_rec[1]));
+    }
+    char* out = static_cast<char*>(blob);
+    std::memcpy(out, &h, sizeof h);
+    int32_t* pairs = reinterpret_cast<int32_t*>(out + sizeof h);
+    for (int32_t i = 0; i < h.n_boundary; ++i) {
+        pairs[2 * i] = e->plan.boundary_node[i];
+        pairs[2 * i + 1] = e->plan.boundary_tile[i];
+    }
+    return BN_OK;
+}
+
+// blobs[r] = what rank r exported (this rank's own entry included), r = 0 .. nranks - 1
+extern "C" int bn_peer_import(bn_engine* e, const void* const* blobs, const int64_t* sizes, int32_t n) {
+    if (!e || !blobs || !sizes) return fail(BN_ERR_ARG, "null argument");
+    Plan& p = e->plan;
+    if (p.nranks < 2) return fail(BN_ERR_STATE, "not a sharded engine");
+    if (n != p.nranks) return fail(BN_ERR_ARG, "one blob per rank");
+    std::vector<PeerBlobHeader> hd(n);
+    std::vector<std::unordered_map<int32_t, int32_t>> tile_of(n);  // per rank: boundary node -> tile
+    bool all_ok = true;
+    for (int32_t r = 0; r < n; ++r) {
+        if (!blobs[r] || sizes[r] < int64_t(sizeof(PeerBlobHeader))) return fail(BN_ERR_ARG, "short peer blob");
+        std::memcpy(&hd[r], blobs[r], sizeof(PeerBlobHeader));
+        if (hd[r].magic != kPeerBlobMagic || hd[r].rank != r || hd[r].nranks != n) return fail(BN_ERR_ARG, "peer blob of the wrong rank / world");
+        if (sizes[r] < int64_t(sizeof(PeerBlobHeader)) + int64_t(hd[r].n_boundary) * 8) return fail(BN_ERR_ARG, "short peer blob");
+        const int32_t* pairs = reinterpret_cast<const int32_t*>(static_cast<const char*>(blobs[r]) + sizeof(PeerBlobHeader));
+        for (int32_t i = 0; i < hd[r].n_boundary; ++i) tile_of[r][pairs[2 * i]] = pairs[2 * i + 1];
+        all_ok = all_ok && hd[r].shapes_ok != 0;
+    }
+    // neighbour tiles across the cut and the ranks each tile reports to
+    const int32_t nt = int32_t(p.tiles.size());
+    std::vector<std::vector<int32_t>> remote(nt);
+    e->pub_mask.assign(std::max(nt, 1), 0u);
+    for (const Plan::CutLink& c : p.cut_links) {
+        auto it = tile_of[c.rank].find(c.node);
+        if (it == tile_of[c.rank].end()) return fail(BN_ERR_ARG, "a peer blob does not list the node across a cut edge (different model or partition?)");
+        if (it->second < 0 || it->second >= kFlowSlotsPerRank) { all_ok = false; continue; }
+        remote[c.tile].push_back(c.rank * kFlowSlotsPerRank + it->second);
+        e->pub_mask[c.tile] |= 1u << c.rank;
+    }
+    for (auto& v : remote) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    const std::string err = build_neighbour_table(p, remote);
+    if (!err.empty()) all_ok = false;
+    e->shard_flow_ok = false;
+    if (e->host_only) return BN_OK;  // tables only (tests)
+    if (!all_ok || !e->shard_shapes_ok) return BN_OK;  // stays on the per-sweep launches + RCCL
+    ON_DEVICE(e);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::vector<PeerTable> peers(n);
+    for (int32_t r = 0; r < n; ++r) {
+        if (r == p.rank) {
+            peers[r] = PeerTable{e->d_flow, e->d_rec[0], e->d_rec[1], p.g_base, p.rec_total_doubles * 8};
+        } else if (hd[r].pid == int64_t(getpid())) {  // another engine of this process: its pointers are ours
+            if (hd[r].device != e->device) {
+                hipError_t pe = hipDeviceEnablePeerAccess(hd[r].device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(BN_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+            peers[r] = PeerTable{reinterpret_cast<FlowSync*>(uintptr_t(hd[r].flow_ptr)), reinterpret_cast<double*>(uintptr_t(hd[r].rec0_ptr)),
+                                 reinterpret_cast<double*>(uintptr_t(hd[r].rec1_ptr)), hd[r].g_base, hd[r].rec_bytes};
+        } else {
+            void* q[3] = {nullptr, nullptr, nullptr};
+            const hipIpcMemHandle_t hs[3] = {hd[r].h_flow, hd[r].h_rec0, hd[r].h_rec1};
+            for (int k = 0; k < 3; ++k) {
+                HIPCHK(hipIpcOpenMemHandle(&q[k], hs[k], hipIpcMemLazyEnablePeerAccess));
+                e->ipc_opened.push_back(q[k]);
+            }
+            peers[r] = PeerTable{static_cast<FlowSync*>(q[0]), static_cast<double*>(q[1]), static_cast<double*>(q[2]), hd[r].g_base, hd[r].rec_bytes};
+        }
+    }
+    if (e->d_peers) { (void)hipFree(e->d_peers); e->d_peers = nullptr; }
+    if (e->d_pub_mask) { (void)hipFree(e->d_pub_mask); e->d_pub_mask = nullptr; }
+    if (e->d_nbr) { (void)hipFree(e->d_nbr); e->d_nbr = nullptr; }
+    int rc;
+    if ((rc = upload(&e->d_peers, peers, e->stream))) return rc;
+    if ((rc = upload(&e->d_pub_mask, e->pub_mask, e->stream))) return rc;
+    if ((rc = upload(&e->d_nbr, p.nbr, e->stream))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->shard_flow_ok = true;
+    return BN_OK;
+}
+
+// host copies of the dataflow tables (tests): nbr_out [n_tiles * nbr_chunks * 64] (bn_get_info "nbr_chunks"), pub_out [n_tiles]
+extern "C" int bn_layout_flow(bn_engine* e, int32_t* nbr_out, uint32_t* pub_out) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (nbr_out) std::copy(e->plan.nbr.begin(), e->plan.nbr.end(), nbr_out);
+    if (pub_out) {
+        for (size_t t = 0; t < e->plan.tiles.size(); ++t) pub_out[t] = t < e->pub_mask.size() ? e->pub_mask[t] : 0u;
     }
     return BN_OK;
 }

@@ -481,28 +481,40 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     }
 
     // ---- neighbour tiles (dataflow form of the resident kernel): the tiles of the parents and children of a tile's
-    // nodes on this rank, ascending, without the tile itself
+    // nodes on this rank, ascending, without the tile itself; across a cut edge the peer's node stands in for its
+    // tile until the peer's export blob names it (bn_engine.cpp: bn_peer_import)
     {
         std::vector<std::vector<int32_t>> nb(nt);
+        std::vector<uint8_t> is_boundary(n, 0);
+        p.cut_links.clear();
         for (int64_t e = 0; e < p.E; ++e) {
-            const int32_t tu = p.node_tile[p.in_idx[e]], tv = p.node_tile[edge_child[e]];
-            if (tu < 0 || tv < 0 || tu == tv) continue;
-            nb[tu].push_back(tv);
-            nb[tv].push_back(tu);
+            const int32_t u = p.in_idx[e], v = edge_child[e];
+            const int32_t tu = p.node_tile[u], tv = p.node_tile[v];
+            if (tu >= 0 && tv >= 0) {
+                if (tu != tv) { nb[tu].push_back(tv); nb[tv].push_back(tu); }
+            } else if (tu >= 0) {  // the child lives on another rank
+                is_boundary[u] = 1;
+                p.cut_links.push_back({tu, own(v), v});
+            } else if (tv >= 0) {  // the parent does
+                is_boundary[v] = 1;
+                p.cut_links.push_back({tv, own(u), u});
+            }
         }
-        p.nbr_max = 0;
+        p.boundary_node.clear();
+        p.boundary_tile.clear();
+        for (int32_t v = 0; v < n; ++v)
+            if (is_boundary[v]) { p.boundary_node.push_back(v); p.boundary_tile.push_back(p.node_tile[v]); }
+        p.nbl_ptr.assign(nt + 1, 0);
+        p.nbl_idx.clear();
         for (int32_t t = 0; t < nt; ++t) {
             std::sort(nb[t].begin(), nb[t].end());
             nb[t].erase(std::unique(nb[t].begin(), nb[t].end()), nb[t].end());
-            p.nbr_max = std::max(p.nbr_max, int32_t(nb[t].size()));
+            p.nbl_idx.insert(p.nbl_idx.end(), nb[t].begin(), nb[t].end());
+            p.nbl_ptr[t + 1] = int32_t(p.nbl_idx.size());
         }
-        p.nbr.clear();
-        p.nbr_chunks = std::max(1, (p.nbr_max + kWave - 1) / kWave);
-        if (p.nbr_chunks <= kMaxNbrChunks) {
-            const size_t per_tile = size_t(p.nbr_chunks) * kWave;
-            p.nbr.assign(size_t(std::max(nt, 1)) * per_tile, -1);
-            for (int32_t t = 0; t < nt; ++t) std::copy(nb[t].begin(), nb[t].end(), p.nbr.begin() + size_t(t) * per_tile);
-        }
+        std::vector<std::vector<int32_t>> none(nt);
+        std::string err = build_neighbour_table(p, none);
+        (void)err;  // too many neighbours: nbr stays empty, the plan is not eligible for the dataflow form
     }
 
     // ---- metrics, this rank's share: CPT of owned nodes once; every message it
@@ -521,6 +533,28 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     // written once, node vectors read + written, message references, tile descriptors, flags
     p.layout_bytes = 8 * cpt_cur + 8 * (2 * rec_cur + rec_cur) + 8 * 2 * node_cur + 8 * out_cur + 8 * inref_cur +
                      int64_t(sizeof(TileDesc)) * nt + slot_cur;
+    return "";
+}
+
+// Plan::nbr from the local neighbour lists plus, per tile, the slots of its neighbour tiles on other ranks.
+std::string build_neighbour_table(Plan& p, const std::vector<std::vector<int32_t>>& remote_slots) {
+    const int32_t nt = int32_t(p.tiles.size());
+    const int32_t base = p.rank * kFlowSlotsPerRank;  // local tile t has slot rank * kFlowSlotsPerRank + t
+    p.nbr.clear();
+    p.nbr_max = 0;
+    for (int32_t t = 0; t < nt; ++t)
+        p.nbr_max = std::max(p.nbr_max, p.nbl_ptr[t + 1] - p.nbl_ptr[t] + int32_t(remote_slots[t].size()));
+    p.nbr_chunks = std::max(1, (p.nbr_max + kWave - 1) / kWave);
+    if (p.nbr_chunks > kMaxNbrChunks) return "a tile has more than " + std::to_string(kMaxNbrChunks * kWave) + " neighbour tiles";
+    if (nt > kFlowSlotsPerRank) return "more tiles than granule slots per rank";
+    const size_t per_tile = size_t(p.nbr_chunks) * kWave;
+    p.nbr.assign(size_t(std::max(nt, 1)) * per_tile, -1);
+    for (int32_t t = 0; t < nt; ++t) {
+        int32_t* row = p.nbr.data() + size_t(t) * per_tile;
+        int32_t k = 0;
+        for (int32_t q = p.nbl_ptr[t]; q < p.nbl_ptr[t + 1]; ++q) row[k++] = base + p.nbl_idx[q];
+        for (int32_t slot : remote_slots[t]) row[k++] = slot;
+    }
     return "";
 }
 

@@ -56,6 +56,7 @@ enum Variant : int32_t {
                            // CPT in lane e % G of the group; <= 8 parents, arities summing to <= 64
 };
 constexpr int kFlatMaxParents = 8;
+constexpr int kFlowSlotsPerRank = 2048;  // granule slots per rank in a dataflow sync table (= 8 waves x 256 tile blocks)
 constexpr int kMaxNbrChunks = 4;   // dataflow form: a tile polls at most 4 x 64 neighbour tiles
 
 // Device-visible shape class.  POD.
@@ -180,6 +181,13 @@ struct Plan {
     std::vector<int32_t> nbr;        // [n_tiles * nbr_chunks * kWave]
     int32_t nbr_max = 0;             // most neighbours any tile has
     int32_t nbr_chunks = 1;          // ceil(nbr_max / kWave)
+    // Sharded plans: the neighbour tiles on THIS rank (CSR over tiles) and, per cut edge incident to this rank, the
+    // local tile, the peer rank and the peer's node; the peer's tile of that node arrives with its export blob
+    // (bn_peer_import), which turns the two into the table above with slots rank * kFlowSlotsPerRank + tile.
+    std::vector<int32_t> nbl_ptr, nbl_idx;
+    struct CutLink { int32_t tile, rank, node; };
+    std::vector<CutLink> cut_links;
+    std::vector<int32_t> boundary_node, boundary_tile;  // owned nodes with a cut edge (ascending) and their tiles
     int32_t variants = 0;            // bit v set: some class is of Variant v (selects the kernel instantiation)
     bool light = false;              // no register-resident / k = 4 lane-group tile: the high-occupancy launch applies
 };
@@ -195,6 +203,10 @@ void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>&
 
 // Builds the plan.  Returns empty string on success, else an error message (BN_ERR_ARG).
 std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& out);
+
+// (Re)builds Plan::nbr / nbr_max / nbr_chunks: local neighbour tiles (nbl_*) + the given slots of neighbour tiles on
+// other ranks, per tile.  Returns an error text when a tile has too many neighbours (nbr is then empty).
+std::string build_neighbour_table(Plan& p, const std::vector<std::vector<int32_t>>& remote_slots);
 
 // Host un-striping of a record buffer into CSR edge order (diagnostics, bn_bp_messages).
 // Edges without an owned endpoint are left untouched.

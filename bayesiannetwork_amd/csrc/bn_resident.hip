@@ -65,6 +65,14 @@ __device__ __forceinline__ double2_t ld_rec(__amdgpu_buffer_rsrc_t r, int64_t id
 __device__ __forceinline__ void st_rec(__amdgpu_buffer_rsrc_t r, int64_t idx2, double2_t v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, int(idx2) * 16, 0, 16);
 }
+// the same at system scope (aux 17 = sc0 sc1): cut-edge halves, read from this rank's exchange region where a peer
+// stored them, or stored into the peer's
+__device__ __forceinline__ double2_t ld_rec_sys(__amdgpu_buffer_rsrc_t r, int64_t idx2) {
+    return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, int(idx2) * 16, 0, 17));
+}
+__device__ __forceinline__ void st_rec_sys(__amdgpu_buffer_rsrc_t r, int64_t idx2, double2_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, int(idx2) * 16, 0, 17);
+}
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Pins a value at this point of the program: the empty asm is opaque to every compiler pass, so nothing
@@ -280,14 +288,43 @@ __device__ __forceinline__ bool resident_idle(const ResidentArgs& a, BlockShared
 // executed i + 1 as well: that speculative iteration wrote the OTHER record / node buffer, so the state the run ends
 // in is intact -- messages in the record buffer, pi(v) / lambda(v) in the node buffer every iteration stores them to
 // (or still in registers when the tile had not started the speculative iteration).
+// SHARD (a sharded engine, bn_create_sharded + bn_peer_import): the neighbour tiles across a cut edge live on other
+// ranks -- other GPUs, or other processes / engines on this one.  Nothing changes in the protocol: a tile that touches
+// a cut edge stores the message halves it produces for it into the peer's record buffer as well as its own (identical
+// exchange-region layout on every rank, bn_plan.hpp) and its granules into the peer's table as well as its own; every
+// rank's service block publishes the rank's residual to all ranks and takes the maximum.  Everything a rank READS is
+// in its own memory.  Cross-rank traffic is system-scope (sc0 sc1) on fine-grained allocations.
+#define RLX_SYS __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+template <bool SHARD>
+__device__ __forceinline__ unsigned long long flow_load(const unsigned long long* p) {
+    if constexpr (SHARD) return __hip_atomic_load(p, RLX_SYS);
+    else return __hip_atomic_load(p, RLX_AGENT);
+}
+template <bool SHARD>
+__device__ __forceinline__ void flow_store(unsigned long long* p, unsigned long long v) {
+    if constexpr (SHARD) __hip_atomic_store(p, v, RLX_SYS);
+    else __hip_atomic_store(p, v, RLX_AGENT);
+}
+// granule pair of slot `slot` (= rank * kFlowSlotsPerRank + tile) for iterations of parity `par` in the table behind `f`
+__device__ __forceinline__ unsigned long long* flow_slot(FlowSync* f, int nranks, int par, int slot) {
+    return reinterpret_cast<unsigned long long*>(f + 1) + (size_t(par) * nranks * kFlowSlotsPerRank + slot) * 2;
+}
+
+template <bool SHARD>
 __device__ __forceinline__ void flow_raise_abort(const ResidentArgs& a) {
     const unsigned long long w = (unsigned long long)(a.gen_base + 1u) | ((unsigned long long)kFlowAbort << 32);
-    for (int q = 0; q < 8; ++q) __hip_atomic_store(&a.flow->verdict[q].word, w, RLX_AGENT);
+    for (int q = 0; q < 8; ++q) flow_store<SHARD>(&a.flow->verdict[q].word, w);
+    if constexpr (SHARD) {  // the other ranks stop at their next poll instead of running into their own deadline
+        for (int r = 0; r < a.b.nranks; ++r)
+            if (r != a.b.rank)
+                for (int q = 0; q < 8; ++q) flow_store<true>(&a.peers[r].flow->verdict[q].word, w);
+    }
     __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Waits until this tile may run iteration `it`; returns the verdict that ends the run for it (kFlowGoOn: run the
 // iteration) and, with a stop verdict, the number of iterations the run consists of in n_it.
+template <bool SHARD>
 __device__ __forceinline__ unsigned flow_wait(const ResidentArgs& a, int tile, int it, int lane, int& n_it) {
     n_it = 0;
     if (it == 0) return kFlowGoOn;
@@ -297,42 +334,55 @@ __device__ __forceinline__ unsigned flow_wait(const ResidentArgs& a, int tile, i
     const int32_t* nbr_list = a.nbr + int64_t(tile) * a.nbr_chunks * kWave + lane;
     int round = 0;
     int nbr = nbr_list[0];
-    const unsigned long long (*granules)[2] = f->tile[(it - 1) & 1];
     const unsigned long long* vword = &f->verdict[blockIdx.x & 7].word;
-    const unsigned want_nb = a.gen_base + unsigned(it);      // the neighbours have finished iteration it - 1
+    // A neighbour's slot of this parity carries EXACTLY the generation of iteration it - 1 once it has finished it (it
+    // cannot finish it + 1 before this tile has finished `it`); ranks whose generation counters have drifted apart
+    // (one of them restarted after an aborted launch) never match and run into the deadline instead of reading on.
+    const unsigned want_nb = a.gen_base + unsigned(it);
     const unsigned want_v = a.gen_base + unsigned(it) - 1u;  // iteration it - 2 is decided
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
+    // the 100 MHz clock is a scalar MEMORY read (s_memrealtime, a round trip of its own): it bounds the wait, so it is
+    // looked at on every 32nd unsuccessful poll only
+    unsigned long long t0 = 0;
+    for (unsigned polls = 0;; ++polls) {
         bool nb_ok = true;
-        if (nbr >= 0) nb_ok = unsigned(__hip_atomic_load(&granules[nbr][0], RLX_AGENT) >> 32) - want_nb < 0x40000000u;  // >= in wrap-around arithmetic
+        if (nbr >= 0) nb_ok = unsigned(flow_load<SHARD>(flow_slot(f, a.b.nranks, (it - 1) & 1, nbr)) >> 32) == want_nb;
         if (__all(nb_ok) && round + 1 < a.nbr_chunks) {  // wave-uniform: on to the next 64 neighbours
             ++round;
             nbr = nbr_list[round * kWave];
             if (__any(nbr >= 0)) continue;
         }
-        const unsigned long long w = __hip_atomic_load(vword, RLX_AGENT);
+        const unsigned long long w = flow_load<SHARD>(vword);
         const unsigned gen = unsigned(w), kind = unsigned(w >> 32);
-        const bool ours = gen - (a.gen_base + 1u) < 0x40000000u;  // published by THIS launch (generations count on across launches)
+        const bool ours = gen - (a.gen_base + 1u) < unsigned(kResidentBudget);  // published by THIS launch (generations count on across launches)
         if (ours && kind != kFlowGoOn) {
             n_it = int(gen - a.gen_base);
             return kind;
         }
-        const bool v_ok = it < 2 || (ours && gen - want_v < 0x40000000u);
+        const bool v_ok = it < 2 || (ours && gen >= want_v);
         if (it < a.budget && v_ok && __all(nb_ok)) return kFlowGoOn;
-        if (wall_clock64() - t0 > a.timeout_ticks) {
-            if (lane == 0) flow_raise_abort(a);
-            return kFlowAbort;
+        if ((polls & 31u) == 31u) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > a.timeout_ticks) {
+                if (lane == 0) flow_raise_abort<SHARD>(a);
+                return kFlowAbort;
+            }
         }
-        __builtin_amdgcn_s_sleep(1);
+        // back off between polls: every poll is a handful of L2-missing line requests that queue with the message
+        // traffic of the waves still computing (measured: polling flat out slows their roles down by ~1 us)
+        for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(8);
     }
 }
 
-template <class Phase, class Finalize>
+template <bool SHARD, class Phase, class Finalize>
 __device__ __forceinline__ bool flow_drive(const ResidentArgs& a, int tile, int lane, int wave, Phase&& phase, Finalize&& finalize) {
+    const int my_slot = a.b.rank * kFlowSlotsPerRank + tile;
+    unsigned pub = 0;  // ranks that hold a neighbour of this tile
+    if constexpr (SHARD) pub = a.pub_mask[tile];
     for (int it = 0;; ++it) {
         RSTAMP(0, it, lane, wave);
         int n_it;
-        const unsigned v = flow_wait(a, tile, it, lane, n_it);
+        const unsigned v = flow_wait<SHARD>(a, tile, it, lane, n_it);
         RSTAMP(1, it, lane, wave);  // neighbours ready, verdict of it - 2 known
         if (v == kFlowAbort) return false;
         if (v != kFlowGoOn) {  // the run consists of n_it iterations of this launch; this wave has executed `it` (n_it or n_it + 1)
@@ -342,13 +392,20 @@ __device__ __forceinline__ bool flow_drive(const ResidentArgs& a, int tile, int 
         const double wres = phase(0, a.sweep_begin + it);
         const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
         RSTAMP(3, it, lane, wave);  // sweep issued
-        drain_stores();             // this wave's write-through stores have reached memory
+        drain_stores();             // this wave's write-through stores -- local and peer -- have reached memory
         RSTAMP(4, it, lane, wave);
+        const unsigned gen = a.gen_base + unsigned(it) + 1u;
         if (lane == 0) {
-            const unsigned gen = a.gen_base + unsigned(it) + 1u;
-            unsigned long long* g = &a.flow->tile[it & 1][tile][0];
-            __hip_atomic_store(g, granule(gen, unsigned(bits >> 32)), RLX_AGENT);
-            __hip_atomic_store(g + 1, granule(gen, unsigned(bits)), RLX_AGENT);
+            unsigned long long* g = flow_slot(a.flow, a.b.nranks, it & 1, my_slot);
+            flow_store<SHARD>(g, granule(gen, unsigned(bits >> 32)));
+            flow_store<SHARD>(g + 1, granule(gen, unsigned(bits)));
+        }
+        if constexpr (SHARD) {  // lane q + 1 tells rank q (only the generation matters there: the residual travels by rank)
+            const int q = lane - 1;
+            if (q >= 0 && q < a.b.nranks && ((pub >> q) & 1u) != 0) {
+                unsigned long long* g = flow_slot(a.peers[q].flow, a.b.nranks, it & 1, my_slot);
+                flow_store<true>(g, granule(gen, 0u));
+            }
         }
         RSTAMP(6, it, lane, wave);  // granules published
     }
@@ -356,9 +413,11 @@ __device__ __forceinline__ bool flow_drive(const ResidentArgs& a, int tile, int 
 
 // The service block of the dataflow form, all kResidentWaves waves: thread x sweeps the granule pairs of tiles x, x + 512,
 // ... of the iteration in hand until they carry its generation; the block reduces, thread 0 decides and publishes.
+// SHARD: thread 0 first publishes this rank's maximum to every rank and waits for theirs; all ranks decide alike.
+template <bool SHARD>
 __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared& sh, int lane, int wave) {
     FlowSync* f = a.flow;
-    const int nt = a.b.n_tiles;
+    const int nt = a.b.n_tiles, nranks = a.b.nranks, base = a.b.rank * kFlowSlotsPerRank;
     const unsigned long long t_first = wall_clock64();
     if (threadIdx.x == 0) sh.verdict[1] = 0;
     __syncthreads();
@@ -367,26 +426,31 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
     for (int it = 0; it < a.budget; ++it) {
         const unsigned gen = a.gen_base + unsigned(it) + 1u;
         unsigned long long m = 0;
-        const unsigned long long t0 = wall_clock64();
+        unsigned long long t0 = 0;
         bool ok = true;
-        for (;;) {
+        for (unsigned polls = 0;; ++polls) {
             bool mine = true;
             unsigned long long acc = 0;
             for (int t = threadIdx.x; t < nt; t += kResidentWaves * kWave) {
-                const unsigned long long hi = __hip_atomic_load(&f->tile[it & 1][t][0], RLX_AGENT);
-                const unsigned long long lo = __hip_atomic_load(&f->tile[it & 1][t][1], RLX_AGENT);
+                const unsigned long long* g = flow_slot(f, nranks, it & 1, base + t);
+                const unsigned long long hi = flow_load<SHARD>(g);
+                const unsigned long long lo = flow_load<SHARD>(g + 1);
                 mine = mine && unsigned(hi >> 32) == gen && unsigned(lo >> 32) == gen;
                 const unsigned long long x = (hi << 32) | (lo & 0xffffffffull);
                 acc = x > acc ? x : acc;
             }
             m = acc;
             if (__all(mine)) break;
-            const unsigned long long w = __hip_atomic_load(&f->verdict[0].word, RLX_AGENT);
-            if (unsigned(w >> 32) == kFlowAbort && unsigned(w) - (a.gen_base + 1u) < 0x40000000u) { ok = false; break; }
-            if (wall_clock64() - t0 > a.timeout_ticks) {
-                if (lane == 0) flow_raise_abort(a);
-                ok = false;
-                break;
+            const unsigned long long w = flow_load<SHARD>(&f->verdict[0].word);
+            if (unsigned(w >> 32) == kFlowAbort && unsigned(w) - (a.gen_base + 1u) < unsigned(kResidentBudget)) { ok = false; break; }
+            if ((polls & 31u) == 31u) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > a.timeout_ticks) {
+                    if (lane == 0) flow_raise_abort<SHARD>(a);
+                    ok = false;
+                    break;
+                }
             }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -398,16 +462,52 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned decision = kFlowAbort;
-            if (sh.verdict[1] == 0) {
-                unsigned long long mm = 0;
+            bool good = sh.verdict[1] == 0;
+            unsigned long long mm = 0;
+            if (good) {
 #pragma unroll
                 for (int w = 0; w < kResidentWaves; ++w) mm = sh.slot[0][w] > mm ? sh.slot[0][w] : mm;
+            }
+            if constexpr (SHARD) {
+                if (good) {  // this rank's maximum to every rank (its own table included), then the maximum over all of them
+                    for (int r = 0; r < nranks; ++r) {
+                        unsigned long long* g = &a.peers[r].flow->rank_granule[it & 1][a.b.rank][0];
+                        flow_store<true>(g, granule(gen, unsigned(mm >> 32)));
+                        flow_store<true>(g + 1, granule(gen, unsigned(mm)));
+                    }
+                    unsigned long long t1 = 0;
+                    for (unsigned polls = 0; good; ++polls) {
+                        bool all = true;
+                        unsigned long long acc = 0;
+                        for (int r = 0; r < nranks; ++r) {
+                            const unsigned long long hi = flow_load<true>(&f->rank_granule[it & 1][r][0]);
+                            const unsigned long long lo = flow_load<true>(&f->rank_granule[it & 1][r][1]);
+                            all = all && unsigned(hi >> 32) == gen && unsigned(lo >> 32) == gen;
+                            const unsigned long long x = (hi << 32) | (lo & 0xffffffffull);
+                            acc = x > acc ? x : acc;
+                        }
+                        if (all) { mm = acc; break; }
+                        const unsigned long long w = flow_load<true>(&f->verdict[0].word);
+                        if (unsigned(w >> 32) == kFlowAbort && unsigned(w) - (a.gen_base + 1u) < unsigned(kResidentBudget)) good = false;
+                        if ((polls & 31u) == 31u) {
+                            const unsigned long long now = wall_clock64();
+                            if (t1 == 0) t1 = now;
+                            if (now - t1 > a.timeout_ticks) {
+                                flow_raise_abort<true>(a);
+                                good = false;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+            }
+            if (good) {
                 decision = unsigned(verdict_of(a, residual_of(mm), a.sweep_begin + it + 1));
                 if (decision == kFlowGoOn && it == a.budget - 1) decision = kFlowBudget;
-                __hip_atomic_store(&f->res[it], mm, RLX_AGENT);
+                flow_store<SHARD>(&f->res[it], mm);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the residual is recorded before anyone learns the verdict
                 const unsigned long long word = (unsigned long long)gen | ((unsigned long long)decision << 32);
-                for (int q = 0; q < 8; ++q) __hip_atomic_store(&f->verdict[q].word, word, RLX_AGENT);
+                for (int q = 0; q < 8; ++q) flow_store<SHARD>(&f->verdict[q].word, word);
             }
             sh.verdict[0] = int(decision);
         }
@@ -421,11 +521,11 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
     if (v != kFlowAbort) {
         double* hist = a.b.res_hist;
         for (int q = lane; q < n_it; q += kWave)
-            if (a.sweep_begin + q < a.b.res_cap) hist[a.sweep_begin + q] = residual_of(__hip_atomic_load(&f->res[q], RLX_AGENT));
+            if (a.sweep_begin + q < a.b.res_cap) hist[a.sweep_begin + q] = residual_of(flow_load<SHARD>(&f->res[q]));
     }
     if (lane == 0) {
         Ctl* hc = a.host_ctl;
-        hc->last_res = (v != kFlowAbort && n_it > 0) ? residual_of(__hip_atomic_load(&f->res[n_it - 1], RLX_AGENT)) : 0.0;
+        hc->last_res = (v != kFlowAbort && n_it > 0) ? residual_of(flow_load<SHARD>(&f->res[n_it - 1])) : 0.0;
         hc->n_sweeps = a.sweep_begin + n_it;
         hc->t_first = t_first;
         hc->t_last = wall_clock64();
@@ -438,10 +538,11 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
 // own states in LDS -- 16 bytes per lane and slot, lane-contiguous: conflict-free ds_read_b128 -- and the
 // lower half in registers; 128 VGPRs of CPT plus the working set do not fit 256 registers, and the
 // compiler's answer, scratch memory, would re-read two thirds of the table through the caches each sweep.
-template <int K, int M, int RC, bool BATCH, bool FLOW>
+template <int K, int M, int RC, bool BATCH, bool FLOW, bool SHARD = false>
 __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int tile, int lane, int wave,
                                               double2_t* cpt_lds) {
     static_assert(!(BATCH && FLOW), "the dataflow form runs one evidence set");
+    static_assert(!SHARD || FLOW, "shards exchange through the dataflow form");
     constexpr int KP = (K + 1) & ~1, H = KP / 2;
     constexpr int C = ipow(K, M), S = K * C, SP = (S + 1) & ~1;
     constexpr int CB = (M > 0) ? C / K : 0;
@@ -469,6 +570,68 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     bool frozen = false;  // evidence mark of this lane's node for the set in hand
     const int64_t rbase = td.rec_base / 2 + lc;  // this lane's slot in the tile's record block (double2 units)
     const MsgRef* orf = b.out_refs + td.out_base + lc;
+    // SHARD: a tile behind the interior ones touches a cut edge (wave-uniform).  Its in-edges are reached through
+    // references (a parent on another rank: both halves in the exchange region, contiguous chunks), the others sit in
+    // the tile's own record block as everywhere else.
+    const bool btile = SHARD && tile >= a.n_interior;
+    MsgRef iref[M > 0 ? M : 1];
+#pragma unroll
+    for (int j = 0; j < M; ++j) iref[j] = MsgRef{0, 0};
+    if constexpr (SHARD) {
+        if (td.in_ref_base >= 0) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) iref[j] = b.in_refs[td.in_ref_base + j * kWave + lc];
+        }
+    }
+    const bool in_by_ref = SHARD && td.in_ref_base >= 0;
+    // chunk h of the pi-message (part 0) / lambda-message (part 1) of in-edge j, double2 units
+    auto in_idx = [&](int j, int part, int h) -> int64_t {
+        const int64_t own = rbase + ((j * 2 + part) * H + h) * kWave;
+        if constexpr (SHARD) {
+            if (in_by_ref) {
+                const bool cut = iref[j].lam < 0;
+                const int64_t lam = cut ? int64_t(~iref[j].lam) : int64_t(iref[j].lam);
+                const int64_t stride = cut ? 1 : (lam - iref[j].pi) / H;
+                return (part ? lam : int64_t(iref[j].pi)) + h * stride;
+            }
+        }
+        return own;
+    };
+    // record access of this tile: system scope where a peer may be the other end
+    auto LD = [&](__amdgpu_buffer_rsrc_t r, int64_t idx2) -> double2_t {
+        if constexpr (SHARD) {
+            if (btile) return ld_rec_sys(r, idx2);
+        }
+        return ld_rec(r, idx2);
+    };
+    auto ST = [&](__amdgpu_buffer_rsrc_t r, int64_t idx2, double2_t v) {
+        if constexpr (SHARD) {
+            if (btile) { st_rec_sys(r, idx2, v); return; }
+        }
+        st_rec(r, idx2, v);
+    };
+    // A message half this rank produced for a cut edge goes into the peer's exchange region too (same offset inside the
+    // region: its layout is identical on every rank).  `other` = where the edge's other half lives: the segment of the rank across the cut.
+    // One pass per rank that some lane of the wave has to reach (a stripe boundary: one).
+    auto push_remote = [&](bool cut_lane, int64_t other, bool into_rec1, const int64_t (&idx)[H], const double2_t (&val)[H]) {
+        if constexpr (SHARD) {
+            if (!btile) return;
+            for (int q = 0; q < b.nranks; ++q) {
+                if (q == b.rank) continue;
+                const int64_t lo = b.g_base + int64_t(q) * b.seg_d2;
+                const bool mine = cut_lane && other >= lo && other < lo + b.seg_d2;
+                if (__any(mine)) {
+                    double* base = into_rec1 ? a.peers[q].rec1 : a.peers[q].rec0;
+                    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(base, 0, int(a.peers[q].rec_bytes), 0x00020000);
+                    const int64_t shift = a.peers[q].g_base - b.g_base;  // same place in THEIR exchange region
+                    if (mine) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) st_rec_sys(pr, idx[h] + shift, val[h]);
+                    }
+                }
+            }
+        }
+    };
     // Out-edge references, packed (8 bytes per child) and decoded at each use: registers matter here.
     // Up to 4 children they stay resident; beyond (RC = 8) they are fetched again every sweep -- one
     // more dependent load at the head of those tiles' sweep, 16 registers less across the whole loop.
@@ -552,7 +715,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                         const Loc l = decode_ref(oref[c], H);  // a missing child reads record 0 and contributes 1.0
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
-                            const double2_t y = ld_rec(rin, l.lam + h * l.stride);
+                            const double2_t y = LD(rin, l.lam + h * l.stride);
                             lkc[c][2 * h] = l.has ? y.x : 1.0;
                             lkc[c][2 * h + 1] = l.has ? y.y : 1.0;
                         }
@@ -591,7 +754,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                         if (!first) {
 #pragma unroll
                             for (int h = 0; h < H; ++h) {  // previous pi-message of this edge, for the residual
-                                const double2_t x = ld_rec(rin, l.pi + h * l.stride);
+                                const double2_t x = LD(rin, l.pi + h * l.stride);
                                 old[2 * h] = x.x; old[2 * h + 1] = x.y;
                             }
                         }
@@ -600,12 +763,15 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                             o[i] = u[i];
                             wres = res_acc(wres, fabs(u[i] - old[i]));
                         }
+                        int64_t at[H];
+                        double2_t yv[H];
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
-                            double2_t y;
-                            y.x = o[2 * h]; y.y = o[2 * h + 1];
-                            st_rec(rout, l.pi + h * l.stride, y);
+                            yv[h].x = o[2 * h]; yv[h].y = o[2 * h + 1];
+                            at[h] = l.pi + h * l.stride;
+                            ST(rout, at[h], yv[h]);
                         }
+                        if constexpr (SHARD) push_remote(oref[c].lam < 0, l.lam, (s & 1) == 0, at, yv);  // the child's owner reads this half
                     }
                 }
             }
@@ -626,7 +792,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
             for (int j = 0; j < M; ++j)
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const double2_t x = ld_rec(rin, rbase + ((j * 2 + 0) * H + h) * kWave);
+                    const double2_t x = LD(rin, in_idx(j, 0, h));
                     pim[j][2 * h] = x.x; pim[j][2 * h + 1] = x.y;
                 }
         }
@@ -715,7 +881,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
             if (!first) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    const double2_t y = ld_rec(rin, rbase + ((jt * 2 + 1) * H + h) * kWave);
+                    const double2_t y = LD(rin, in_idx(jt, 1, h));
                     old[2 * h] = y.x; old[2 * h + 1] = y.y;
                 }
             }
@@ -725,12 +891,15 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                 wres = res_acc(wres, fabs(out[jt][i] - old[i]));
             }
             if (active) {
+                int64_t at[H];
+                double2_t yv[H];
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    double2_t y;
-                    y.x = o[2 * h]; y.y = o[2 * h + 1];
-                    st_rec(rout, rbase + ((jt * 2 + 1) * H + h) * kWave, y);
+                    yv[h].x = o[2 * h]; yv[h].y = o[2 * h + 1];
+                    at[h] = in_idx(jt, 1, h);
+                    ST(rout, at[h], yv[h]);
                 }
+                if constexpr (SHARD) push_remote(in_by_ref && iref[jt].lam < 0, iref[jt].pi, (s & 1) == 0, at, yv);  // the parent's owner reads this half
             }
         }
         if (!active) wres = 0.0;
@@ -764,25 +933,25 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
             for (int i = 0; i < K; ++i) beliefs[boff + i] = bel[i] / sum;
         }
     };
-    if constexpr (FLOW) return flow_drive(a, tile, lane, wave, phase, finalize);
+    if constexpr (FLOW) return flow_drive<SHARD>(a, tile, lane, wave, phase, finalize);
     else return resident_drive<BATCH>(a, sh, lane, wave, phase, finalize);
 }
 
 // MODE: 0 = one evidence set, grid barrier per sweep (one-block grids: LDS only); 1 = several evidence sets per launch
 // (node vectors through memory between a set's turns); 2 = one evidence set, dataflow form (no grid barrier)
-enum : int { kModeBarrier = 0, kModeBatch = 1, kModeFlow = 2 };
+enum : int { kModeBarrier = 0, kModeBatch = 1, kModeFlow = 2, kModeFlowShard = 3 };  // 3: dataflow form of a sharded engine (peer stores)
 
 template <int K, int M, int MODE, int LEAN>
 __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int tile, int lane, int wave,
                                                   double2_t* cpt_lds) {
-    constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow;
+    constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow || MODE == kModeFlowShard, SHARD = MODE == kModeFlowShard;
 #ifdef BN_RES_ONLY_RC  // experiments: one instantiation only
-    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
+    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
 #else
-    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
-    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
-    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);
-    return resident_tile<K, M, 8, BATCH, FLOW>(a, sh, td, tile, lane, wave, cpt_lds);  // the host admits <= 8 children per node
+    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
+    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
+    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
+    return resident_tile<K, M, 8, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);  // the host admits <= 8 children per node
 #endif
 }
 
@@ -792,7 +961,7 @@ __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockSh
 // LEAN = 0: every shape the resident path admits.
 template <int MODE, int LEAN>
 __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(ResidentArgs a) {
-    constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow;
+    constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow || MODE == kModeFlowShard, SHARD = MODE == kModeFlowShard;
     __shared__ BlockShared sh;
     __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // the CPT entries not kept in registers, 18 KiB per wave
     const BpBuffers& b = a.b;
@@ -807,7 +976,7 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
     // blocks past the tile blocks serve the barrier / collect the residuals
     const int nb = a.n_tile_blocks;
     if (int(blockIdx.x) >= nb) {
-        if constexpr (FLOW) flow_service(a, sh, lane, wave);
+        if constexpr (FLOW) flow_service<SHARD>(a, sh, lane, wave);
         else if (wave == 0) resident_service(a, lane);
         return;
     }
@@ -866,11 +1035,12 @@ int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void*
     (void)hipGetLastError();  // drop any stale error of this thread
     const dim3 g(grid_blocks), t(kResidentWaves * kWave);
     hipStream_t s = (hipStream_t)stream;
-    const int mode = a.n_sets > 1 ? kModeBatch : (a.flow != nullptr ? kModeFlow : kModeBarrier);
+    const int mode = a.n_sets > 1 ? kModeBatch : (a.flow != nullptr ? (a.peers != nullptr ? kModeFlowShard : kModeFlow) : kModeBarrier);
 #define BN_RES_LAUNCH(L)                                                                          \
     switch (mode) {                                                                               \
         case kModeBatch: hipLaunchKernelGGL((bp_resident_kernel<kModeBatch, L>), g, t, 0, s, a); break;   \
         case kModeFlow: hipLaunchKernelGGL((bp_resident_kernel<kModeFlow, L>), g, t, 0, s, a); break;     \
+        case kModeFlowShard: hipLaunchKernelGGL((bp_resident_kernel<kModeFlowShard, L>), g, t, 0, s, a); break; \
         default: hipLaunchKernelGGL((bp_resident_kernel<kModeBarrier, L>), g, t, 0, s, a); break;         \
     }
     switch (lean_k) {

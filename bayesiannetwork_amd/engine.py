@@ -182,6 +182,29 @@ class Engine:
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _lib.check(_lib.lib().bn_comm_init(self._h, buf))
 
+    def peer_export(self) -> bytes:
+        """bn_peer_export: this shard's blob for the in-kernel halo exchange (ship it to every rank)."""
+        n = _lib.check(_lib.lib().bn_peer_blob_size(self._h))
+        buf = ctypes.create_string_buffer(int(n))
+        _lib.check(_lib.lib().bn_peer_export(self._h, buf, n))
+        return buf.raw
+
+    def peer_import(self, blobs) -> bool:
+        """bn_peer_import: blobs[r] = rank r's export (own included).  True when the in-kernel exchange is set up."""
+        keep = [ctypes.create_string_buffer(bytes(b), len(b)) for b in blobs]
+        ptrs = (ctypes.c_void_p * len(keep))(*[ctypes.cast(k, ctypes.c_void_p) for k in keep])
+        sizes = np.asarray([len(b) for b in blobs], dtype=np.int64)
+        _lib.check(_lib.lib().bn_peer_import(self._h, ptrs, _p(sizes, ctypes.c_int64), len(keep)))
+        return bool(self.info("shard_flow"))
+
+    def flow_tables(self):
+        """(neighbour slots [n_tiles, chunks * 64], report masks [n_tiles]) of the dataflow form (bn_layout_flow)."""
+        nt, ch = self.layout()["n_tiles"], self.info("nbr_chunks")
+        nbr = np.full(max(nt * ch * 64, 1), -1, dtype=np.int32)
+        pub = np.zeros(max(nt, 1), dtype=np.uint32)
+        _lib.check(_lib.lib().bn_layout_flow(self._h, _p(nbr, ctypes.c_int32), pub.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        return nbr[:nt * ch * 64].reshape(nt, ch * 64) if ch else np.zeros((nt, 0), np.int32), pub[:nt]
+
     # single steps (tests): begin / sweep without exchange / finish
     def step_begin(self):
         _lib.check(_lib.lib().bn_bp_step_begin(self._h))

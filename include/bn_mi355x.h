@@ -87,6 +87,21 @@ void bn_destroy(bn_engine *eng);
  */
 int bn_create_sharded(const bn_model_desc *desc, int32_t rank, int32_t nranks, const int32_t *owner,
                       bn_engine **out);
+/*
+ * Halo exchange INSIDE the resident kernel (no collective per sweep): every rank exports a blob -- handles of its
+ * record buffers and sync block, and which of its tiles hold the nodes on cut edges -- the caller ships the blobs by
+ * any means (bench.py / tests: torch.distributed all_gather_object, a pipe), and every rank imports all of them
+ * (blobs[r] = rank r's, its own included).  After that a run of the sharded engine is ONE launch per rank: a tile
+ * stores the message halves it produces for a cut edge into the peer's exchange region as well as its own
+ * (peer-mapped memory: hipIpc handles between processes, plain pointers inside one; system-scope write-through
+ * stores over xGMI), tiles wait for their neighbour tiles' generation granules wherever those live, and each rank's
+ * service block hands its residual to every rank, so all ranks stop on the same sweep (belief_propagation.hpp:
+ * 105-147).  Networks whose tiles the resident kernel does not cover (any rank) stay on bn_comm_init + per-sweep
+ * launches; bn_get_info("shard_flow") tells.  Every rank must then run the same sequence of bn_bp_run* calls.
+ */
+int64_t bn_peer_blob_size(bn_engine *eng);
+int bn_peer_export(bn_engine *eng, void *blob, int64_t cap);
+int bn_peer_import(bn_engine *eng, const void *const *blobs, const int64_t *sizes, int32_t n);
 int bn_comm_unique_id(void *id_out128);
 int bn_comm_init(bn_engine *eng, const void *id128);
 const char *bn_last_error(void);
@@ -172,14 +187,16 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   and a grid barrier per sweep.  0 = always one launch per sweep; 1 = that path where it was measured
  *   faster (one-block networks, networks of >= 600 tiles); 2 = wherever eligible (tests, experiments).
  *   Results are bit-identical on either path.
- * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 1):
+ * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 0):
  *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
  *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.
+ * "poll_sleep" n -- dataflow form: pause between two polls of a waiting tile, n x 512 cycles (default 2).
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
- * used the dataflow form), "nbr_max", "resident_blocks", "resident_aborts"; unknown name: BN_ERR_ARG. */
+ * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
+ * exchange set up), "n_boundary_nodes"; unknown name: BN_ERR_ARG. */
 int64_t bn_get_info(bn_engine *eng, const char *name);
 
 /* Single steps of a run (tests / diagnostics): begin, one sweep (without exchange), finish.
@@ -275,6 +292,9 @@ int bn_layout_node_slots(bn_engine *eng, int32_t *slots_out);
 int bn_layout_node_tiles(bn_engine *eng, int32_t *tiles_out);
 /* per-class: kv, m, lanes_per_node, variant (0 = one-lane generic, 1 = register-resident template,
  * 2 = lane group (k = 4, 3-5 parents), 3 = any arities, a group of 8..64 lanes per node) */
+/* dataflow tables: nbr_out [n_tiles * bn_get_info("nbr_chunks") * 64] neighbour slots (rank * 2048 + tile, -1 padded),
+ * pub_out [n_tiles] bit q = the tile reports to rank q; either may be NULL */
+int bn_layout_flow(bn_engine *eng, int32_t *nbr_out, uint32_t *pub_out);
 int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,
                     int32_t *variant, int32_t *n_nodes);
 

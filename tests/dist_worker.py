@@ -95,7 +95,77 @@ def main():
         return max(float(G[(q + 1) * seg_d2 * 2 - 256]) for q in range(world))
 
     sweeps = 0
-    if not overlapped:
+    if len(sys.argv) > 2 and sys.argv[2] == "granules":
+        # The IN-KERNEL exchange of the sharded resident kernel (bn_resident.hip, SHARD) with gloo standing in for the
+        # peer-mapped memory: nobody gathers segments.  A rank PUSHES each half it produced for a cut edge to the one rank
+        # that reads it (the owner across the cut: the segment the edge's other half lives in), pushes the generation
+        # granule of every tile that touches a cut to the ranks in the tile's report mask, and its residual to every
+        # rank; before a sweep it checks -- like the kernel's poll -- that every neighbour slot of every one of its
+        # tiles (the table bn_peer_import built from the ranks' blobs) carries the previous sweep's generation, and it
+        # reads nothing but its own copy of the exchange region.
+        blobs = [None] * world
+        dist.all_gather_object(blobs, eng.peer_export())
+        eng.peer_import(blobs)                      # host-only engine: tables only
+        nbr, pub = eng.flow_tables()
+        tiles = eng.node_tiles()
+        region = np.zeros(world * seg_d2 * 2, dtype=np.float64)      # this rank's exchange region
+        table = {}                                                    # slot -> generation (this rank's granule table)
+        SLOTS = 2048
+        while True:
+            md = L.oracle_bp_sweep_owned(h, p(owner, ctypes.c_int32), rank)
+            npim, nlkm = arr(6, nm), arr(7, nm)
+            gen = sweeps + 1
+            outbox = [{"at": [], "val": [], "gran": [], "res": md} for _ in range(world)]
+            for e in cut:
+                u, v = model.in_idx[e], child[e]
+                a, b = owner[u], owner[v]
+                if a == rank:   # pi half: local copy + the child's owner
+                    o = (int(ref_pi[e]) - gbase) * 2
+                    region[o:o + kpar[e]] = npim[moff[e]:moff[e + 1]]
+                    outbox[b]["at"].append(o); outbox[b]["val"].append(npim[moff[e]:moff[e + 1]].copy())
+                if b == rank:   # lambda half: local copy + the parent's owner
+                    o = (int(~ref_lam[e]) - gbase) * 2
+                    region[o:o + kpar[e]] = nlkm[moff[e]:moff[e + 1]]
+                    outbox[a]["at"].append(o); outbox[a]["val"].append(nlkm[moff[e]:moff[e + 1]].copy())
+            for t in range(nbr.shape[0]):
+                table[rank * SLOTS + t] = gen
+                for q in range(world):
+                    if (int(pub[t]) >> q) & 1:
+                        outbox[q]["gran"].append(rank * SLOTS + t)
+            inbox = [None] * world
+            dist.all_gather_object(inbox, outbox)    # transport only: rank r takes inbox[q][r], what q addressed to it
+            res = 0.0
+            for q in range(world):
+                box = inbox[q][rank]
+                res = max(res, box["res"])           # every rank's residual reaches every rank
+                if q == rank:
+                    continue
+                for o, val in zip(box["at"], box["val"]):
+                    region[o:o + val.size] = val
+                for slot in box["gran"]:
+                    table[slot] = gen
+            # the poll of the next sweep: every neighbour tile, local or across a cut, has finished this one
+            for t in range(nbr.shape[0]):
+                for slot in nbr[t][nbr[t] >= 0]:
+                    assert table.get(int(slot)) == gen, f"rank {rank} tile {t}: neighbour slot {slot} never reported sweep {gen}"
+            unpack(region, npim, nlkm)               # reads this rank's own region only
+            L.oracle_bp_commit(h)
+            sweeps += 1
+            if res < eps:
+                break
+        # a tile reports to a rank exactly when it has a neighbour there, and the lists mirror each other across the cut
+        alltabs = [None] * world
+        dist.all_gather_object(alltabs, (nbr, pub))
+        for t in range(nbr.shape[0]):
+            want_mask = 0
+            for slot in nbr[t][nbr[t] >= 0]:
+                q, t2 = divmod(int(slot), SLOTS)
+                if q != rank:
+                    want_mask |= 1 << q
+                    assert rank * SLOTS + t in alltabs[q][0][t2] and (int(alltabs[q][1][t2]) >> rank) & 1
+            assert int(pub[t]) == want_mask
+        assert np.array_equal(np.unique(tiles[(owner == rank)]), np.arange(nbr.shape[0]))
+    elif not overlapped:
         while True:
             md = L.oracle_bp_sweep_owned(h, p(owner, ctypes.c_int32), rank)
             npim, nlkm = arr(6, nm), arr(7, nm)
@@ -141,7 +211,8 @@ def main():
         want = oracle.bp_run(model, ev, eps)
         assert sweeps == want["sweeps"], (sweeps, want["sweeps"])
         assert np.array_equal(tb.numpy(), want["beliefs"]), "sharded result differs from the unsharded oracle"
-        print(f"DIST_OK case={case} world={world} order={'overlapped' if overlapped else 'plain'} sweeps={sweeps} cut_edges={cut.size}")
+        order = sys.argv[2] if len(sys.argv) > 2 else "plain"
+        print(f"DIST_OK case={case} world={world} order={order} sweeps={sweeps} cut_edges={cut.size}")
     L.oracle_bp_close(h)
     dist.barrier()
 

@@ -9,10 +9,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("case,world,order", [("grid", 2, "plain"), ("dag", 2, "plain"), ("dag", 3, "plain"),
-                                              ("grid", 2, "overlapped"), ("dag", 3, "overlapped")])
+                                              ("grid", 2, "overlapped"), ("dag", 3, "overlapped"),
+                                              ("grid", 2, "granules"), ("dag", 3, "granules")])
 def test_gloo_sharded_exchange(bnlib, oracle_mod, case, world, order, tmp_path):
     """order "overlapped": the engine's overlapped schedule -- interior tiles of the next sweep computed
-    while the all-gather is in flight, cut-touching tiles after it landed (see dist_worker.py)."""
+    while the all-gather is in flight, cut-touching tiles after it landed; "granules": the in-kernel exchange of
+    the sharded resident kernel -- halves pushed to the one rank that reads them, per-tile generation granules
+    checked against the neighbour tables bn_peer_import builds, per-rank residuals (see dist_worker.py)."""
     import socket
     with socket.socket() as sk:  # a port nobody is listening on (a fixed one may still be in TIME_WAIT from another run)
         sk.bind(("127.0.0.1", 0))

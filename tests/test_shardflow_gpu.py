@@ -1,0 +1,90 @@
+"""Halo exchange INSIDE the resident kernel (bn_peer_export / bn_peer_import): the shards of a network run one
+launch each and talk through peer-mapped memory -- cut-edge message halves stored into the peer's exchange
+region, per-tile generation granules, per-rank residual granules -- instead of one RCCL all-gather per sweep.
+Exercised on ONE device: (a) n shard engines in one process, their kernels co-resident, one thread per shard;
+(b) n processes sharing device 0, the peers' buffers mapped through hipIpc handles.  Jacobi sweeps do not depend
+on who computes a message (belief_propagation.hpp:78-101, :135-143): beliefs, sweep count and residual history
+must be BIT-IDENTICAL to the unsharded engine's."""
+import os
+import subprocess
+import sys
+import tempfile
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng(bnlib):
+    from bayesiannetwork_amd import engine
+    return engine
+
+
+def _single(eng, model, ev, eps, max_sweeps=0):
+    with eng.Engine(model) as one:
+        want = one.bp_run(ev, eps, max_sweeps)
+        return want, one.bp_residuals(), one.bp_messages()
+
+
+@pytest.mark.parametrize("cases", [("grid96x80_r2", "grid96x80_r4", "grid48x40_r3", "grid40x33_k3_r2", "grid50x50_k2_r3"),
+                                   ("grid200_r8", "grid316_r2"),
+                                   ("worst_cut", "caps_and_empty_rank", "tree", "mixed_k", "long_run_two_launches")])
+def test_shards_in_one_process(cases):
+    """2-8 shard engines in ONE process, kernels co-resident on one device (tests/shardflow_inproc.py; a process of its
+    own because the number of hardware queues per process is fixed when HIP starts)."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shardflow_inproc.py"), *cases], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    for c in cases:
+        assert f"INPROC_OK {c}" in p.stdout
+
+
+def test_networks_outside_the_resident_kernel_stay_on_rccl(eng):
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(600, 4, 32, 4, seed=7)   # 3-4 parents: lane-group tiles
+    shards = [eng.Engine(d, rank=r, nranks=2) for r in range(2)]
+    try:
+        blobs = [s.peer_export() for s in shards]
+        assert not any(s.peer_import(blobs) for s in shards)
+    finally:
+        for s in shards:
+            s.close()
+
+
+@pytest.mark.parametrize("rows,cols,nranks,eps,max_sweeps", [(316, 316, 2, 1e-3, 0), (120, 100, 4, 1e-6, 0), (64, 64, 2, 0.0, 1100)])
+def test_shards_in_separate_processes_over_ipc(eng, rows, cols, nranks, eps, max_sweeps):
+    """world_size n on ONE GPU: n processes, each owning a shard on device 0, peers mapped with hipIpcOpenMemHandle --
+    the arrangement of a real node (one process per GPU) minus the xGMI links.  (64x64, eps 0, 1100 sweeps: a run that
+    takes two launches per rank.)"""
+    from bayesiannetwork_amd import synth
+    g = synth.grid(rows, cols, 4, seed=rows * 31 + cols)
+    ev = synth.random_evidence(g, 0.02, seed=3)
+    want, want_res, _ = _single(eng, g, ev, eps, max_sweeps)
+    reps = 3
+    with tempfile.TemporaryDirectory() as work:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shardflow_worker.py"), str(r), str(nranks), work,
+                                   str(rows), str(cols), repr(eps), str(max_sweeps), str(reps), "0"],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(nranks)]
+        logs = []
+        for p in procs:
+            try:
+                logs.append(p.communicate(timeout=600)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()   # exactly the processes started here
+                raise
+        assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+        outs = [np.load(os.path.join(work, f"out{r}.npz")) for r in range(nranks)]
+    for o in outs:
+        assert bool(o["shard_flow"]) and int(o["aborts"]) == 0
+    for i in range(reps):
+        for o in outs:
+            assert int(o[f"path{i}"]) == 2 and int(o[f"flow{i}"]) == 1
+            assert int(o[f"sweeps{i}"]) == want["sweeps"]
+            assert float(o[f"residual{i}"]) == want["residual"]
+            assert np.array_equal(o[f"history{i}"], want_res)
+        bel = sum(o[f"beliefs{i}"] for o in outs)
+        assert np.array_equal(bel, want["beliefs"], equal_nan=True), f"rep {i}"
