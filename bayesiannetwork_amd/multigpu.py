@@ -26,14 +26,55 @@ def init_control_plane(backend: str = "gloo"):
     return dist
 
 
-def make_shard(model, rank: int, world: int, device: int, owner=None) -> Engine:
-    """Create shard `rank` and join the library's communicator (collective: every rank calls it)."""
+def make_shard(model, rank: int, world: int, device: int, owner=None, in_kernel: bool = True) -> Engine:
+    """Create shard `rank`, join the library's RCCL communicator (the per-sweep all-gather path, also the fallback) and --
+    in_kernel -- set up the halo exchange inside the resident kernel: every rank's blob (bn_peer_export: hipIpc handles of
+    its record buffers and sync block, tiles of its nodes on cut edges) goes to every rank (bn_peer_import).
+    Collective: every rank calls it."""
     dist = init_control_plane()
     eng = Engine(model, device=device, rank=rank, nranks=world, owner=owner)
-    box = [Engine.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    eng.comm_init(box[0])
+    if not os.environ.get("BN_NO_RCCL"):  # (several ranks on ONE device, a test arrangement, cannot form an RCCL communicator)
+        box = [Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(box[0])
+    if in_kernel and world > 1:
+        blobs = [None] * world
+        dist.all_gather_object(blobs, eng.peer_export())
+        eng.peer_import(blobs)
     return eng
+
+
+def verify_in_kernel_exchange(eng: Engine, model, ev, eps: float, device: int) -> bool:
+    """The in-kernel exchange relies on system-scope stores into peer-mapped fine-grained memory being visible to the
+    peer's polls in order; before anything is timed, one run of it is compared, on this node's links, with the UNSHARDED
+    run of the same query on this rank's own GPU: same sweep count, same residual history, same bits in the beliefs of
+    the nodes this rank owns.  On any difference -- on ANY rank -- every rank switches to per-sweep launches + RCCL.
+    Collective."""
+    import torch
+    dist = init_control_plane()
+    if not eng.info("shard_flow"):
+        return False
+    ok = 1
+    with Engine(model, device=device) as one:
+        want = one.bp_run(ev, eps)
+        want_hist = one.bp_residuals()
+    dist.barrier()  # the ranks' kernels wait for each other (bounded: 2 s): enter the run together
+    try:
+        got = eng.bp_run_device(eps)
+        bel = eng.bp_beliefs()
+        owned = np.repeat(eng.node_slots() >= 0, model.k)
+        if (eng.last_path() != 2 or got["sweeps"] != want["sweeps"] or not np.array_equal(eng.bp_residuals(), want_hist)
+                or not np.array_equal(bel[owned], want["beliefs"][owned], equal_nan=True)):
+            ok = 0
+    except Exception as ex:  # noqa: BLE001 - e.g. a bounded wait gave up
+        print(f"[multigpu] rank {eng.rank}: in-kernel exchange failed verification: {ex}", flush=True)
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t[0]) == 0:
+        eng.set_option("multisweep", 0)
+        return False
+    return True
 
 
 def gather_beliefs(eng: Engine) -> np.ndarray:
@@ -82,14 +123,27 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
     dog.daemon = True
     dog.start()
     dist = init_control_plane()
-    torch.cuda.set_device(local_rank)
+    # BN_BENCH_SAME_DEVICE (with BN_NO_RCCL): every rank on device 0 -- the N-process arrangement on a one-GPU box (tests)
+    device = 0 if os.environ.get("BN_BENCH_SAME_DEVICE") else local_rank
+    torch.cuda.set_device(device)
+    have_rccl = not os.environ.get("BN_NO_RCCL")
     out = None
     g = synth.grid(a.rows, a.cols, 4, seed=2)
     ev = synth.random_evidence(g, a.evidence, seed=7)
-    eng = make_shard(g, rank, world, local_rank)
+    eng = make_shard(g, rank, world, device, in_kernel=not os.environ.get("BN_NO_PEER_EXCHANGE"))
     eng.bp_set_evidence(ev)
+    in_kernel = verify_in_kernel_exchange(eng, g, ev, a.eps, device)
+    if not in_kernel and not have_rccl:
+        raise SystemExit("in-kernel exchange not available and BN_NO_RCCL set: nothing to run the shards with")
     dt, sweeps, kern_ms, launches = _timed_runs(eng, a.eps, a.steps, a.warmup, dist, torch)
     path = eng.last_path()
+    rccl = None
+    if in_kernel and have_rccl:  # the same shards through per-sweep launches + one RCCL all-gather per sweep, for comparison
+        eng.set_option("multisweep", 0)
+        dtr, sr, _, _ = _timed_runs(eng, a.eps, max(a.steps // 2, 3), 2, dist, torch)
+        eng.set_option("multisweep", 1)
+        rccl = {"value": g.messages_per_sweep() * sr / dtr, "ms_per_step": dtr / max(a.steps // 2, 3) * 1e3,
+                "what": "per-sweep launches + one in-place RCCL all-gather per sweep, overlapped with the interior tiles"}
     li = eng.layout()
     seg = li["segment_bytes"]
     if rank == 0:
@@ -103,27 +157,37 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
             "config": {"workload": f"{a.rows}x{a.cols} 2D-grid BN, k=4, {g.n} nodes, {g.n_edges} edges, cut into "
                                    f"{world} row stripes (BASELINE.json configs[3]), {ev.ne} evidence nodes, eps={a.eps:g}",
                        "sweeps_per_step": sweeps / a.steps, "messages_per_sweep": g.messages_per_sweep(),
-                       "parallelism": f"edge-cut x{world}, 1 in-place RCCL all-gather per sweep "
-                                      f"({seg} B per rank incl. residual slots)"},
+                       "parallelism": (f"edge-cut x{world}, halo exchange inside the resident kernel: cut-edge halves stored into the "
+                                       f"peer's exchange region over xGMI, per-tile generation granules, per-rank residual granules "
+                                       f"(one launch per rank and run, no collective)") if in_kernel else
+                                      (f"edge-cut x{world}, 1 in-place RCCL all-gather per sweep ({seg} B per rank incl. residual slots)"),
+                       "exchange": "in-kernel (peer-mapped memory)" if in_kernel else "rccl all-gather per sweep"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": achieved / (8000.0 * world), "traffic": None,
                          "kernel": "bp_sweep_kernel (interior | cut-touching tiles) + all-gather on a second stream"
-                                   if path == 0 else "bp_resident_kernel (one rank: no exchange)",
+                                   if path == 0 else "bp_resident_kernel, dataflow form with peer stores",
                          "avg_launch_us": per_launch_s * 1e6,
                          "avg_launch_us_source": "device clock, sweep start to next sweep start (exchange included)"},
         }
+        if rccl:
+            out["rccl_exchange"] = rccl
     eng.close()
     # weak scaling: 316 rows per GPU
     if not getattr(a, "no_weak", False):
         gw = synth.grid(a.rows * world, a.cols, 4, seed=2)
         evw = synth.random_evidence(gw, a.evidence, seed=7)
-        engw = make_shard(gw, rank, world, local_rank)
+        engw = make_shard(gw, rank, world, device, in_kernel=not os.environ.get("BN_NO_PEER_EXCHANGE"))
         engw.bp_set_evidence(evw)
-        dtw, sw, kw, lw = _timed_runs(engw, a.eps, max(a.steps // 2, 3), 2, dist, torch)
-        if rank == 0:
+        in_kernel_w = verify_in_kernel_exchange(engw, gw, evw, a.eps, device)
+        if in_kernel_w or have_rccl:
+            dtw, sw, kw, lw = _timed_runs(engw, a.eps, max(a.steps // 2, 3), 2, dist, torch)
+        elif rank == 0:  # several ranks sharing ONE device (test arrangement): their kernels do not fit the chip together
+            out["weak_scaling"] = {"error": "in-kernel exchange not available at this size and no RCCL communicator"}
+        if rank == 0 and (in_kernel_w or have_rccl):
             out["weak_scaling"] = {"workload": f"{a.rows * world}x{a.cols} grid, {a.rows} rows per GPU",
                                    "value": gw.messages_per_sweep() * sw / dtw, "unit": "edge-messages/s",
                                    "avg_sweep_plus_exchange_us": kw * 1e3 / max(lw, 1),
+                                   "exchange": "in-kernel (peer-mapped memory)" if in_kernel_w else "rccl all-gather per sweep",
                                    "sweeps_per_step": sw / max(a.steps // 2, 3)}
         engw.close()
     # the other way to use N GPUs on a network that fits one: every GPU holds the whole network and answers
@@ -131,7 +195,7 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
     # edge-cut figure, never as `value` (BASELINE.json configs[3] is the partitioned grid).
     if not getattr(a, "no_replicas", False):
         evr = synth.random_evidence(g, a.evidence, seed=7 + rank)
-        with Engine(g, device=local_rank) as er:
+        with Engine(g, device=device) as er:
             er.bp_set_evidence(evr)
             dtr, sr, _, _ = _timed_runs(er, a.eps, a.steps, a.warmup, dist, torch)
             rpath = er.last_path()
@@ -163,7 +227,7 @@ def bench_lw_main(a, rank: int, world: int, local_rank: int) -> None:
     torch.cuda.set_device(local_rank)
     d = synth.random_dag(10000, 4, 64, 4, seed=1)
     ev = synth.random_evidence(d, a.evidence, seed=7).hard_states(d)
-    eng = make_shard(d, rank, world, local_rank)
+    eng = make_shard(d, rank, world, local_rank, in_kernel=False)
     total = a.samples * world
     for w in range(max(a.warmup, 1)):
         eng.lw_run_allreduce(ev, total, seed=1, sample_begin=w * total)

@@ -269,10 +269,12 @@ def test_hot_kernels_do_not_spill(bnlib):
         assert "bp_sweep_kernel" in name
         assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0 and r["vgpr"] <= 256, (name, r)
     res = kr.kernel_resources(os.path.join(csrc, "bn_resident.o"))
-    assert len(res) == 12  # {grid barrier, several sets, dataflow} x {LEAN k = 2, 3, 4; all shapes}
+    assert len(res) == 16  # {grid barrier, several sets, dataflow, dataflow of a shard} x {LEAN k = 2, 3, 4; all shapes}
     for name, r in res.items():
         assert "bp_resident_kernel" in name and r["vgpr"] <= 256, (name, r)
-        if ", 0>" not in name:  # LEAN = k: every node of arity k with <= 2 children -- what the headline grid runs (k = 4)
+        if "<3, 4>" in name:    # a shard's k = 4 tiles also carry the references of their cut edges: a handful of dwords
+            assert r["spill"] <= 8, (name, r)
+        elif ", 0>" not in name:  # LEAN = k: every node of arity k with <= 2 children -- what the headline grid runs (k = 4)
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
         else:                   # every shape inlined into one kernel: the 4- / 8-children parent roles spill a little
             assert r["spill"] <= 64, (name, r)

@@ -88,3 +88,25 @@ def test_shards_in_separate_processes_over_ipc(eng, rows, cols, nranks, eps, max
             assert np.array_equal(o[f"history{i}"], want_res)
         bel = sum(o[f"beliefs{i}"] for o in outs)
         assert np.array_equal(bel, want["beliefs"], equal_nan=True), f"rep {i}"
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py --gpus 2 as two torchrun processes that share device 0 (BN_BENCH_SAME_DEVICE; no RCCL communicator can
+    span two ranks on one GPU, so BN_NO_RCCL): the N > 1 branch with the in-kernel exchange end to end -- blobs through
+    torch.distributed, verification against the unsharded run, timed runs, weak-scaling and replicated-queries legs."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, BN_BENCH_SAME_DEVICE="1", BN_NO_RCCL="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--rows", "96", "--cols", "80"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["config"]["exchange"].startswith("in-kernel"), line["config"]
+    assert line["weak_scaling"]["exchange"].startswith("in-kernel") and line["weak_scaling"]["value"] > 0
+    assert line["replicated_queries"]["value"] > 0
