@@ -168,6 +168,7 @@ struct ResidentArgs {
     ResidentSync* sync;   // [n_sets]
     Ctl* host_ctl;        // [n_sets], pinned
     int32_t n_tile_blocks;  // blocks [0, n_tile_blocks) carry tiles; the launch's further blocks serve the barrier
+    int32_t waves;          // tiles (= waves) per block: kResidentWaves, or half of it on networks small enough (one wave per SIMD)
     int32_t n_sets;       // 1: node vectors stay in registers; > 1: they go through memory between a set's turns
     uint32_t set_mask;    // sets still running (a continued launch skips the others)
     int64_t rec_stride, node_stride;  // doubles between consecutive sets' record / node buffers

@@ -147,6 +147,7 @@ struct bn_engine {
     bool ev_upload_pending = false; // an evidence H2D from h_ev may still be in flight (no sync since)
     int resident_lean = 0;          // ... and every node has this arity (2, 3 or 4) and <= 2 children; else 0
     int grid_resident = 0;
+    int resident_waves = kResidentWaves;  // tiles per block of the resident kernel (8, or 4 on networks small enough)
     ResidentSync* d_rsync = nullptr;
     bool rsync_dirty = true;        // the sync block must be zeroed before the next launch
     // dataflow form of the resident kernel (no grid barrier; single evidence set, more than one tile block)
@@ -364,7 +365,19 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, e->device));
             const int64_t nt = int64_t(p.tiles.size());
-            int64_t nb = (nt + kResidentWaves - 1) / kResidentWaves;
+            // One 8-wave block per CU is two waves per SIMD sharing its issue slots.  A network whose tiles fit the chip at
+            // FOUR waves per block (the CPT slots in LDS keep it at one block per CU) gives every wave a SIMD of its own.
+            // BN_RESIDENT_WAVES=8 / 4 forces either (A/B).
+            e->resident_waves = kResidentWaves;
+            {
+                const int64_t cap4 = (int64_t(prop.multiProcessorCount) * 9 / 10 - 1) * (kResidentWaves / 2);
+                if (nt > kResidentWaves && nt <= cap4) e->resident_waves = kResidentWaves / 2;
+                if (const char* w = std::getenv("BN_RESIDENT_WAVES")) {
+                    const int v = std::atoi(w);
+                    if (v == kResidentWaves || (v == kResidentWaves / 2 && nt <= cap4) || (v == 2 && nt <= cap4 / 2 && nt > 2)) e->resident_waves = v;
+                }
+            }
+            int64_t nb = (nt + e->resident_waves - 1) / e->resident_waves;
             if (nb > 1 && p.nranks == 1) nb = (nb + 7) & ~int64_t(7);  // XCD-contiguous tile mapping wants a multiple of 8; shards keep the CUs for each other
             bool shapes = (nt == 0 || p.variants == (1 << kVariantUniform)) &&
                           nb + 1 <= int64_t(prop.multiProcessorCount) * 9 / 10 && nb <= kResidentMaxBlocks &&  // + the barrier's service block
@@ -668,7 +681,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         ResidentArgs a{buffers_of(e), eps, max_sweeps, begin, kResidentBudget, e->run_id, flow ? e->flow_gen_base : e->gen_base,
                        // one wait: 50 ms of the 100 MHz clock; shards: 2 s (the ranks' launches start up to a host hiccup apart)
                        shard ? 200000000ull : 5000000ull, e->d_rsync, e->h_ctl_dev,
-                       e->grid_resident, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr,
+                       e->grid_resident, e->resident_waves, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr,
                        shard ? e->d_peers : nullptr, shard ? e->d_pub_mask : nullptr, shard ? e->plan.n_interior_tiles : 0,
                        e->d_nbr, e->plan.nbr_chunks, e->poll_sleep, e->h_abort_dev};
         if (e->timing) {
@@ -723,7 +736,9 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     // resident tiles pay on one block (no grid barrier at all) and on large networks (the CPT traffic saved
     // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
     constexpr int64_t kResidentMinTiles = 600;  // measured crossover: 160x160 grid (402 tiles) 8.2 vs 8.9 us per sweep, 200x200 (627) 9.5 vs 9.2
-    const bool resident_pays = e->grid_resident == 1 || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
+    // ... with 8 waves per block; at 4 (networks up to ~900 tiles: every wave has a SIMD of its own) it is faster than the
+    // launches from the smallest multi-block network on (32x32 grid 7.2 vs 7.4-7.8 us per sweep, 128x128 7.7 vs 8.0, 200x200 8.7 vs 9.5)
+    const bool resident_pays = e->grid_resident == 1 || e->resident_waves < kResidentWaves || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
     if (e->plan.nranks > 1) ++e->shard_run_seq;
     // shards: the in-kernel exchange wherever every rank's tiles qualify and the peers are mapped ("multisweep" 0 = the
     // per-sweep launches with one RCCL all-gather per sweep)
@@ -828,6 +843,7 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "shard_flow") == 0) return e->shard_flow_ok ? 1 : 0;
     if (std::strcmp(name, "n_boundary_nodes") == 0) return int64_t(e->plan.boundary_node.size());
     if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
+    if (std::strcmp(name, "resident_waves") == 0) return e->resident_waves;
     if (std::strcmp(name, "resident_aborts") == 0) return e->resident_aborts;
     return fail(BN_ERR_ARG, std::string("unknown info ") + name);
 }
@@ -1006,7 +1022,7 @@ static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps
         }
         *e->h_abort = 0;
         ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
-                       bt.h_ctl_dev + first, e->grid_resident, count, mask, p.rec_total_doubles, p.node_doubles,
+                       bt.h_ctl_dev + first, e->grid_resident, e->resident_waves, count, mask, p.rec_total_doubles, p.node_doubles,
                        int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, nullptr, 0, nullptr, 1, 0, e->h_abort_dev};
         if (e->timing) {
             int rc = ensure_events(e, 2);

@@ -129,8 +129,7 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
     RSTAMP(5, it, lane, wave);  // the block's waves have all arrived
     if (threadIdx.x == 0) {
         unsigned long long m = 0;
-#pragma unroll
-        for (int w = 0; w < kResidentWaves; ++w) m = sh.slot[set][w] > m ? sh.slot[set][w] : m;
+        for (int w = 0; w < a.waves; ++w) m = sh.slot[set][w] > m ? sh.slot[set][w] : m;
         ResidentSync* sy = a.sync + set;
         if (a.n_tile_blocks == 1) {
             sy->res[it] = m;
@@ -431,7 +430,7 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
         for (unsigned polls = 0;; ++polls) {
             bool mine = true;
             unsigned long long acc = 0;
-            for (int t = threadIdx.x; t < nt; t += kResidentWaves * kWave) {
+            for (int t = threadIdx.x; t < nt; t += a.waves * kWave) {
                 const unsigned long long* g = flow_slot(f, nranks, it & 1, base + t);
                 const unsigned long long hi = flow_load<SHARD>(g);
                 const unsigned long long lo = flow_load<SHARD>(g + 1);
@@ -465,8 +464,7 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
             bool good = sh.verdict[1] == 0;
             unsigned long long mm = 0;
             if (good) {
-#pragma unroll
-                for (int w = 0; w < kResidentWaves; ++w) mm = sh.slot[0][w] > mm ? sh.slot[0][w] : mm;
+                for (int w = 0; w < a.waves; ++w) mm = sh.slot[0][w] > mm ? sh.slot[0][w] : mm;
             }
             if constexpr (SHARD) {
                 if (good) {  // this rank's maximum to every rank (its own table included), then the maximum over all of them
@@ -574,28 +572,21 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     // references (a parent on another rank: both halves in the exchange region, contiguous chunks), the others sit in
     // the tile's own record block as everywhere else.
     const bool btile = SHARD && tile >= a.n_interior;
-    MsgRef iref[M > 0 ? M : 1];
-#pragma unroll
-    for (int j = 0; j < M; ++j) iref[j] = MsgRef{0, 0};
-    if constexpr (SHARD) {
-        if (td.in_ref_base >= 0) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) iref[j] = b.in_refs[td.in_ref_base + j * kWave + lc];
-        }
-    }
     const bool in_by_ref = SHARD && td.in_ref_base >= 0;
+    // (fetched at each use -- three times a sweep, boundary tiles only -- rather than kept: registers matter here)
+    auto IREF = [&](int j) -> MsgRef { return b.in_refs[td.in_ref_base + j * kWave + lc]; };
     // chunk h of the pi-message (part 0) / lambda-message (part 1) of in-edge j, double2 units
     auto in_idx = [&](int j, int part, int h) -> int64_t {
-        const int64_t own = rbase + ((j * 2 + part) * H + h) * kWave;
         if constexpr (SHARD) {
             if (in_by_ref) {
-                const bool cut = iref[j].lam < 0;
-                const int64_t lam = cut ? int64_t(~iref[j].lam) : int64_t(iref[j].lam);
-                const int64_t stride = cut ? 1 : (lam - iref[j].pi) / H;
-                return (part ? lam : int64_t(iref[j].pi)) + h * stride;
+                const MsgRef r = IREF(j);
+                const bool cut = r.lam < 0;
+                const int lam = cut ? ~r.lam : r.lam;
+                const int stride = cut ? 1 : (lam - r.pi) / H;
+                return int64_t((part ? lam : r.pi) + h * stride);
             }
         }
-        return own;
+        return rbase + ((j * 2 + part) * H + h) * kWave;
     };
     // record access of this tile: system scope where a peer may be the other end
     auto LD = [&](__amdgpu_buffer_rsrc_t r, int64_t idx2) -> double2_t {
@@ -899,7 +890,12 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                     at[h] = in_idx(jt, 1, h);
                     ST(rout, at[h], yv[h]);
                 }
-                if constexpr (SHARD) push_remote(in_by_ref && iref[jt].lam < 0, iref[jt].pi, (s & 1) == 0, at, yv);  // the parent's owner reads this half
+                if constexpr (SHARD) {
+                    if (in_by_ref) {  // the parent's owner reads this half
+                        const MsgRef r = IREF(jt);
+                        push_remote(r.lam < 0, r.pi, (s & 1) == 0, at, yv);
+                    }
+                }
             }
         }
         if (!active) wres = 0.0;
@@ -982,7 +978,7 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
     }
     // XCD-contiguous tile mapping (speed only), as in the per-sweep kernel
     const int lb = (nb % 8 == 0) ? (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-    const int tile = lb * kResidentWaves + wave;
+    const int tile = lb * a.waves + wave;  // a.waves = 8, or 4 when that still gives every tile a wave: one wave per SIMD then
     bool ok;
     if (tile >= b.n_tiles) {
         if constexpr (FLOW) return;  // nobody waits for a wave without a tile
@@ -1033,7 +1029,7 @@ __global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(
 // lean_k: 2, 3 or 4 when every node has that arity and at most 2 children, else 0
 int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-    const dim3 g(grid_blocks), t(kResidentWaves * kWave);
+    const dim3 g(grid_blocks), t(a.waves * kWave);
     hipStream_t s = (hipStream_t)stream;
     const int mode = a.n_sets > 1 ? kModeBatch : (a.flow != nullptr ? (a.peers != nullptr ? kModeFlowShard : kModeFlow) : kModeBarrier);
 #define BN_RES_LAUNCH(L)                                                                          \

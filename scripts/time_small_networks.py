@@ -56,7 +56,7 @@ for name, mod in nets:
                    and res[0]["sweeps"] == res[f]["sweeps"] for f in (1, 2))
         lay = e.layout()
         row = {"nodes": mod.n, "tiles": lay["n_tiles"], "sweeps": res[0]["sweeps"], "same_bits": bool(same),
-               "multi_path_taken": res[1]["path"], "aborts": res[2]["aborts"],
+               "multi_path_taken": res[1]["path"], "aborts": res[2]["aborts"], "waves_per_block": e.info("resident_waves"),
                "per_sweep_launch": {k: round(res[0][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")},
                "one_launch": {k: round(res[1][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")},
                "one_launch_flow": {k: round(res[2][k], 2) for k in ("us_per_sweep_dev", "us_per_run_wall")}}

@@ -272,8 +272,10 @@ def test_hot_kernels_do_not_spill(bnlib):
     assert len(res) == 16  # {grid barrier, several sets, dataflow, dataflow of a shard} x {LEAN k = 2, 3, 4; all shapes}
     for name, r in res.items():
         assert "bp_resident_kernel" in name and r["vgpr"] <= 256, (name, r)
-        if "<3, 4>" in name:    # a shard's k = 4 tiles also carry the references of their cut edges: a handful of dwords
+        if "<3, 4>" in name:    # a shard's k = 4 tiles also carry the code for their cut edges: a handful of dwords
             assert r["spill"] <= 8, (name, r)
+        elif "<3, 0>" in name:  # ... and with every shape inlined
+            assert r["spill"] <= 96, (name, r)
         elif ", 0>" not in name:  # LEAN = k: every node of arity k with <= 2 children -- what the headline grid runs (k = 4)
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
         else:                   # every shape inlined into one kernel: the 4- / 8-children parent roles spill a little

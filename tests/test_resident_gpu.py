@@ -115,9 +115,11 @@ def test_paths_are_chosen_by_eligibility(Engine):
         eng.set_option("multisweep", 2)
         eng.bp_run(None, 1e-3)
         assert eng.last_path() == 0
-    with Engine(synth.grid(64, 64, 4, seed=1)) as eng:  # 66 tiles in 16 blocks: eligible, but the default policy keeps
-        eng.bp_run(None, 1e-3)                           # per-sweep launches in the range where the barrier costs more
-        assert eng.last_path() == 0
+    with Engine(synth.grid(64, 64, 4, seed=1)) as eng:  # 66 tiles: four waves per block (one per SIMD), where the resident
+        eng.bp_run(None, 1e-3)                           # kernel beats the launches from the smallest networks on
+        assert eng.last_path() == 2 and eng.info("resident_waves") == 4
+    with Engine(synth.grid(250, 250, 4, seed=1)) as eng:  # 978 tiles: too many for four waves per block
+        assert eng.info("resident_waves") == 8
     with Engine(synth.grid(20, 20, 4, seed=1)) as eng:
         eng.set_option("multisweep", 2)
         eng.bp_run(None, 1e-3)
