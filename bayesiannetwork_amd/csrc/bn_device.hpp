@@ -38,7 +38,8 @@ struct BpBuffers {
     double* node1;
     const MsgRef* out_refs;
     const MsgRef* in_refs;
-    uint8_t* frozen;     // per lane-slot evidence marker (preconditional_node_, :69)
+    uint8_t* frozen;     // per lane-slot evidence marker (preconditional_node_, :69): marked when == frozen_mark
+    uint8_t frozen_mark; // the value that marks the evidence set in force (a new set takes the next value: nothing to clear)
     const int32_t* slot_node;
     const int64_t* slot_boff;
     const int32_t* node_tile;

@@ -113,6 +113,8 @@ struct bn_engine {
     hipEvent_t ev_gathered = nullptr;    // comm stream: the current sweep's all-gather
     bool overlap = true;                 // BN_OVERLAP=0 / bn_set_option("overlap", 0): kernel and collective back to back
     uint8_t* d_frozen = nullptr;
+    uint8_t frozen_mark = 1;        // mark value of the evidence set in force (1..255; wrapping clears the array)
+    char* h_ev_dev = nullptr;       // h_ev as the device sees it (mapped page-locked memory: the evidence kernel reads it in place)
     int32_t* d_slot_node = nullptr;
     int64_t* d_slot_boff = nullptr;
     int32_t* d_node_tile = nullptr;
@@ -142,6 +144,11 @@ struct bn_engine {
     int32_t resident_cooldown = 0;  // runs left before the resident path is tried again
     int32_t resident_backoff = 8;   // length of the next pause
     double* h_beliefs = nullptr;    // pinned: bn_bp_run_view hands this out, bn_bp_run stages nothing through it
+    double* h_beliefs_dev = nullptr;  // ... as the device sees it
+    double* beliefs_override = nullptr;  // where the kernels write the beliefs of the run in hand instead of d_beliefs
+    int beliefs_direct = 1;         // option "beliefs_direct": bn_bp_run_view lets the kernels write the marginals straight into
+                                    // the mapped host buffer (no copy command behind the run; 316x316 grid: 253 -> 235 us per query);
+                                    // outputs above 16 MB go through the copy engine (larger PCIe payloads)
     std::vector<uint32_t> ev_seen;  // check_evidence: epoch stamp per node (no per-call allocation)
     uint32_t ev_epoch = 0;
     bool ev_upload_pending = false; // an evidence H2D from h_ev may still be in flight (no sync since)
@@ -450,6 +457,7 @@ static BpBuffers buffers_of(bn_engine* e) {
     b.node0 = e->d_node[0]; b.node1 = e->d_node[1];
     b.out_refs = e->d_out;
     b.frozen = e->d_frozen;
+    b.frozen_mark = e->frozen_mark;
     b.slot_node = e->d_slot_node;
     b.slot_boff = e->d_slot_boff;
     b.node_tile = e->d_node_tile;
@@ -464,7 +472,7 @@ static BpBuffers buffers_of(bn_engine* e) {
     b.res_hist = e->d_res_hist;
     b.res_cap = e->res_cap;
     b.ctl = e->d_ctl;
-    b.beliefs = e->d_beliefs;
+    b.beliefs = e->beliefs_override ? e->beliefs_override : e->d_beliefs;
     return b;
 }
 
@@ -524,20 +532,24 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
         if (e->h_ev) (void)hipHostFree(e->h_ev);
         e->d_ev = nullptr; e->h_ev = nullptr;
         e->ev_bytes_cap = std::max<size_t>(bytes * 2, 4096);
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_ev), e->ev_bytes_cap));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ev), e->ev_bytes_cap, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ev), e->ev_bytes_cap, hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ev_dev), e->h_ev, 0));
     }
+    // ONE kernel applies a set: it reads the arrays in place from the page-locked staging block (no copy command in the
+    // queue in front of the run) and marks the nodes with this set's mark value (no memset of the previous set's marks)
     if (ne > 0) {
         std::memcpy(e->h_ev + off_node, ev_node, size_t(ne) * 4);
         std::memcpy(e->h_ev + off_off, ev_off, size_t(ne + 1) * 4);
         std::memcpy(e->h_ev + off_val, ev_val, size_t(nval) * 8);
-        HIPCHK(hipMemcpyAsync(e->d_ev, e->h_ev, bytes, hipMemcpyHostToDevice, e->stream));
     }
-    e->d_ev_node = reinterpret_cast<int32_t*>(e->d_ev + off_node);
-    e->d_ev_off = reinterpret_cast<int32_t*>(e->d_ev + off_off);
-    e->d_ev_val = reinterpret_cast<double*>(e->d_ev + off_val);
-    if (e->ev_ne > 0 || e->ev_applied_dirty)  // drop the previous set's marks
+    e->d_ev_node = reinterpret_cast<int32_t*>(e->h_ev_dev + off_node);
+    e->d_ev_off = reinterpret_cast<int32_t*>(e->h_ev_dev + off_off);
+    e->d_ev_val = reinterpret_cast<double*>(e->h_ev_dev + off_val);
+    if (e->frozen_mark == 255 || e->ev_applied_dirty) {  // the mark values are used up (or a launch failed half-way): start over
         HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), e->stream));
+        e->frozen_mark = 0;
+    }
+    ++e->frozen_mark;
     e->ev_ne = ne;
     e->ev_applied_dirty = false;
     EvidenceArgs ea{buffers_of(e), ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
@@ -827,6 +839,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (!e || !name) return fail(BN_ERR_ARG, "null argument");
     if (std::strcmp(name, "timing") == 0) { e->timing = value != 0; return BN_OK; }
     if (std::strcmp(name, "overlap") == 0) { e->overlap = value != 0; return BN_OK; }
+    if (std::strcmp(name, "beliefs_direct") == 0) { e->beliefs_direct = value != 0; return BN_OK; }
     if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
     if (std::strcmp(name, "poll_sleep") == 0) { e->poll_sleep = std::max(0, std::min(value, 64)); return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
@@ -902,6 +915,7 @@ static BpBuffers batch_buffers_of(bn_engine* e, int32_t q) {
     b.node0 = bt.d_node[0] + size_t(q) * p.node_doubles;
     b.node1 = bt.d_node[1] + size_t(q) * p.node_doubles;
     b.frozen = bt.d_frozen + size_t(q) * std::max(p.n_slots, 1);
+    b.frozen_mark = 1;  // batches clear their marks with a memset per call
     b.beliefs = bt.d_beliefs + size_t(q) * p.node_off[p.n];
     b.res_hist = bt.d_res_hist + size_t(q) * e->res_cap;
     b.ctl = bt.d_ctl + q;
@@ -1510,9 +1524,16 @@ extern "C" int bn_bp_run_view(bn_engine* e, int32_t ne, const int32_t* ev_node, 
     if (!e->h_beliefs) {
         ON_DEVICE(e);
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_beliefs), std::max<size_t>(e->plan.node_off[e->plan.n], 1) * sizeof(double),
-                             hipHostMallocDefault));
+                             hipHostMallocMapped));
+        HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_beliefs_dev), e->h_beliefs, 0));
     }
-    rc = run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, e->h_beliefs);
+    if (e->beliefs_direct && e->plan.nranks == 1 && e->plan.node_off[e->plan.n] * 8 <= (int64_t(16) << 20)) {
+        e->beliefs_override = e->h_beliefs_dev;
+        rc = run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, nullptr);
+        e->beliefs_override = nullptr;
+    } else {
+        rc = run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, e->h_beliefs);
+    }
     if (rc) return rc;
     *beliefs_view = e->h_beliefs;
     return BN_OK;

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void bp_sweep_light_kernel(SweepA
 
 // bn_bp_set_evidence: apply the evidence (belief_propagation.hpp:68-73) to the nodes this rank owns:
 // pi(v) = lambda(v) = the given vector in the buffer iteration 0 reads, node marked
-// (preconditional_node_).  `frozen` was cleared by the host just before.  The marks and vectors stay
+// (preconditional_node_: the slot takes the mark value of this evidence set, so the previous set's marks need no
+// clearing).  The arrays are read straight from the caller-side staging block in page-locked host memory.  The marks and vectors stay
 // until the next bn_bp_set_evidence: a marked node's vectors are copied forward by every sweep, so
 // both buffers keep holding them and any number of runs can follow without touching them again.
 __global__ __launch_bounds__(kBlockThreads) void bp_evidence_kernel(EvidenceArgs a) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kBlockThreads) void bp_evidence_kernel(EvidenceArgs
         b.node1[td.node_base + vidx(0, i, td.npt, nl)] = x;
         b.node1[td.node_base + vidx(half, i, td.npt, nl)] = x;
     }
-    b.frozen[td.slot_base + nl] = 1;
+    b.frozen[td.slot_base + nl] = b.frozen_mark;
 }
 
 // This rank's residual slots in both buffers.  A finished run leaves them zero itself

@@ -638,7 +638,7 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     // at the end (buffer parity as on the launch path), the registers are only the turn's working copy.
     double piv[KP], lav[KP];
     auto load_nodes = [&](int set, int s) {
-        frozen = b.frozen[(BATCH ? int64_t(set) * a.slot_stride : 0) + td.slot_base + lc] != 0;
+        frozen = b.frozen[(BATCH ? int64_t(set) * a.slot_stride : 0) + td.slot_base + lc] == b.frozen_mark;
 #pragma unroll
         for (int i = 0; i < KP; ++i) {  // initial state (:38-64): roots start from their CPT row
             piv[i] = (M == 0 && i < K) ? cpt[i] : 1.0;

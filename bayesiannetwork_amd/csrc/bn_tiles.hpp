@@ -345,7 +345,7 @@ __device__ __forceinline__ double tile_generic(const BpBuffers& b, const IO& io,
     const double* cpt = b.cpt + td.cpt_base + lane * 2;
     const double* node_in = io.node_in + td.node_base + lane * 2;
     double* node_out = io.node_out + td.node_base + lane * 2;
-    const bool frozen = b.frozen[td.slot_base + lane] != 0;
+    const bool frozen = b.frozen[td.slot_base + lane] == b.frozen_mark;
     const bool synth = io.first && !frozen;
     const int kv = c.kv, m = c.m, rows = c.rows, hv = c.kvp >> 1;
     // in-edge j: inside the tile's record block, or wherever the reference says (boundary tile)
@@ -482,7 +482,7 @@ __device__ __forceinline__ double tile_uniform(const BpBuffers& b, const IO& io,
         };
         const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + lane;
         double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + lane;
-        const bool frozen = b.frozen[td.slot_base + lane] != 0;
+        const bool frozen = b.frozen[td.slot_base + lane] == b.frozen_mark;
         double pim[M > 0 ? M : 1][KP];
 #pragma unroll
         for (int j = 0; j < M; ++j)
@@ -727,7 +727,7 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
     }
     const double2_t* nin = reinterpret_cast<const double2_t*>(io.node_in + td.node_base) + nlc;
     double2_t* nout = reinterpret_cast<double2_t*>(io.node_out + td.node_base) + nlc;
-    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
+    const bool frozen = b.frozen[td.slot_base + nlc] == b.frozen_mark;
     double pim[M][K];
 #pragma unroll
     for (int j = 0; j < M; ++j)
@@ -859,10 +859,20 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 #pragma unroll
     for (int j = 0; j < D; ++j) pfix[j] = pick4(pim[j], (g >> (2 * (D - 1 - j))) & 3);
 
-    // ---- partial sums over this lane's 64 entries
+    // ---- partial sums over this lane's E entries.  The four own states of one trailing-parent assignment are
+    // handled TOGETHER: their product chains (cpt * pi-messages, ascending parent order as in the reference,
+    // :190-193, :250-258) are independent of each other, so four of them are in flight where one chain alone would
+    // leave a SIMD that holds no other wave waiting for its own results half the time (tile stamps, round 2: 4.2 us
+    // for the 1 280 fp64 instructions of a 4-parent tile = ~50 % of one wave's issue rate).  pi(v)[i] adds its terms
+    // in assignment order as before; a lambda bucket receives the sum over the own states of one assignment
+    // ((t0 + t1) + (t2 + t3)) per step -- the sum over a lane's entries is re-associated, like the sum across the
+    // group's lanes already is (results agree with the reference to rounding; its own >= 3-parent products are
+    // unordered, :253).
     double pp[K];          // pi(v)[i]
     double ol[T][K];       // lambda-messages to the trailing parents, by target state
     double sf[D];          // lambda-messages to the leading parents: this lane's own bucket
+#pragma unroll
+    for (int i = 0; i < K; ++i) pp[i] = 0.0;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -870,46 +880,63 @@ __device__ __forceinline__ double tile_group(const BpBuffers& b, const IO& io, c
 #pragma unroll
     for (int j = 0; j < D; ++j) sf[j] = 0.0;
 #pragma unroll
-    for (int ib = 0; ib < K; ++ib) {
-        double acc = 0.0;
+    for (int cl = 0; cl < CL; ++cl) {
+        int ct[T];  // states of the trailing parents D .. M-1 in this assignment
 #pragma unroll
-        for (int cl = 0; cl < CL; ++cl) {
-            int ct[T];  // states of the trailing parents D .. M-1 in this assignment
+        for (int t = 0; t < T; ++t) ct[t] = (cl >> (2 * (T - 1 - t))) & 3;
+        double e[K], v[K], tc[K], pre[K], w[K];
 #pragma unroll
-            for (int t = 0; t < T; ++t) ct[t] = (cl >> (2 * (T - 1 - t))) & 3;
-            const double e = cpt[ib * CL + cl];
-            // calculate_pi: cpt * pi-messages, ascending parent order
-            double v = e;
+        for (int ib = 0; ib < K; ++ib) e[ib] = cpt[ib * CL + cl];
+        // calculate_pi: cpt * pi-messages, ascending parent order
 #pragma unroll
-            for (int j = 0; j < D; ++j) v *= pfix[j];
+        for (int ib = 0; ib < K; ++ib) v[ib] = e[ib];
 #pragma unroll
-            for (int t = 0; t < T; ++t) v *= pim[D + t][ct[t]];
-            acc += v;
-            // calculate_lambda_k: (lambda[i] * cpt) * the OTHER parents' pi-messages, ascending
-            const double tc = lav[ib] * e;
-            double pre = tc;  // shared prefix over the leading parents
+        for (int j = 0; j < D; ++j)
 #pragma unroll
-            for (int j = 0; j < D; ++j) pre *= pfix[j];
+            for (int ib = 0; ib < K; ++ib) v[ib] *= pfix[j];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                double w = pre;
+        for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int t2 = 0; t2 < T; ++t2)
-                    if (t2 != t) w *= pim[D + t2][ct[t2]];
-                ol[t][ct[t]] += w;
-            }
+            for (int ib = 0; ib < K; ++ib) v[ib] *= pim[D + t][ct[t]];
 #pragma unroll
-            for (int jt = 0; jt < D; ++jt) {
-                double w = tc;
+        for (int ib = 0; ib < K; ++ib) pp[ib] += v[ib];
+        // calculate_lambda_k: (lambda[i] * cpt) * the OTHER parents' pi-messages, ascending
 #pragma unroll
-                for (int j = 0; j < D; ++j)
-                    if (j != jt) w *= pfix[j];
+        for (int ib = 0; ib < K; ++ib) tc[ib] = lav[ib] * e[ib];
 #pragma unroll
-                for (int t = 0; t < T; ++t) w *= pim[D + t][ct[t]];
-                sf[jt] += w;
-            }
+        for (int ib = 0; ib < K; ++ib) pre[ib] = tc[ib];  // shared prefix over the leading parents
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int ib = 0; ib < K; ++ib) pre[ib] *= pfix[j];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int ib = 0; ib < K; ++ib) w[ib] = pre[ib];
+#pragma unroll
+            for (int t2 = 0; t2 < T; ++t2)
+                if (t2 != t) {
+#pragma unroll
+                    for (int ib = 0; ib < K; ++ib) w[ib] *= pim[D + t2][ct[t2]];
+                }
+            ol[t][ct[t]] += (w[0] + w[1]) + (w[2] + w[3]);
         }
-        pp[ib] = acc;
+#pragma unroll
+        for (int jt = 0; jt < D; ++jt) {
+#pragma unroll
+            for (int ib = 0; ib < K; ++ib) w[ib] = tc[ib];
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                if (j != jt) {
+#pragma unroll
+                    for (int ib = 0; ib < K; ++ib) w[ib] *= pfix[j];
+                }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int ib = 0; ib < K; ++ib) w[ib] *= pim[D + t][ct[t]];
+            sf[jt] += (w[0] + w[1]) + (w[2] + w[3]);
+        }
     }
 
     TILE_STAMP(4);  // contraction over this lane's entries
@@ -1110,7 +1137,7 @@ __device__ __forceinline__ double tile_flat(const BpBuffers& b, const IO& io, co
     const int sumk = offs[MM];
     double pim = 1.0, oldlam = 1.0;
     if (myj >= 0 && !io.first) { pim = io.rec_in[my_pi]; oldlam = io.rec_in[my_lam]; }
-    const bool frozen = b.frozen[td.slot_base + nlc] != 0;
+    const bool frozen = b.frozen[td.slot_base + nlc] == b.frozen_mark;
     // node vectors (old), lane i < kv
     const double* nin = io.node_in + td.node_base;
     double* nout = io.node_out + td.node_base;

@@ -191,6 +191,8 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
  *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.
  * "poll_sleep" n -- dataflow form: pause between two polls of a waiting tile, n x 512 cycles (default 2).
+ * "beliefs_direct" 1/0 -- bn_bp_run_view: the kernels write the marginals straight into the engine's mapped host
+ *   buffer (default 1, outputs up to 16 MB) instead of a copy command queued behind the run.
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);

@@ -36,6 +36,12 @@ with Engine(g) as e:
         o["copy_beliefs_pageable_us"] = avg(lambda i: e.bp_beliefs())
         o["bp_run_pageable_us"] = avg(lambda i: e.bp_run(evs[i % 8], 1e-3))
         o["bp_run_view_us"] = avg(lambda i: e.bp_run_view(evs[i % 8], 1e-3))
+        e.set_option("beliefs_direct", 1)
+        o["bp_run_view_direct_us"] = avg(lambda i: e.bp_run_view(evs[i % 8], 1e-3))
+        want = e.bp_run(evs[3], 1e-3)["beliefs"]
+        import numpy as np
+        assert np.array_equal(e.bp_run_view(evs[3], 1e-3)["beliefs"], want)
+        e.set_option("beliefs_direct", 0)
         o["sweeps"] = e.bp_run_device(1e-3)["sweeps"]
         o["devclock_us_per_sweep"] = e.bp_stats()["sweep_devclock_ms"] * 1e3 / o["sweeps"]
         out[f"flow{flow}"] = o
