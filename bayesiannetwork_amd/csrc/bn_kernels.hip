@@ -100,14 +100,17 @@ __global__ __launch_bounds__(kBlockThreads) void bp_finish_kernel(FinishArgs a) 
     }
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
-    // marked by a sweep launch = a previous kernel, or by wave 0 of this one (below, after it has written the
-    // fields read here: acquire pairs with its release)
-    const bool marked = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
-    const int n_sweeps = marked ? b.ctl->n_sweeps : a.sweeps_launched;
+    // Marked by a sweep launch = a previous kernel, or by wave 0 of this one (below, which releases the fields it wrote
+    // before the mark).  The mark and then, behind it, the sweep count are read with L1-bypassing loads: what the
+    // release made visible in L2 is what they see.  (An ACQUIRE load here invalidated the CU's L1 once per wave --
+    // 65 536 times on the 2048x2048 grid -- and held this kernel at ~0.8 TB/s: 595 us there, 17 us on the 316x316 grid.)
+    const bool marked = __hip_atomic_load(&b.ctl->done_run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.run_id;
+    int n_sweeps = a.sweeps_launched;
+    if (marked) n_sweeps = __hip_atomic_load(&b.ctl->n_sweeps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x == 0 && wave == 0) {
         int done = 1;
-        double r = marked ? b.ctl->last_res : 0.0;
-        unsigned long long t_last = marked ? b.ctl->t_last : wall_clock64();
+        double r = marked ? __hip_atomic_load(&b.ctl->last_res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        unsigned long long t_last = marked ? __hip_atomic_load(&b.ctl->t_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : wall_clock64();
         if (marked && !(r < a.eps)) done = 2;  // marked by an earlier finish of this run that stopped it at max_sweeps
         if (!marked) {  // sweep (launched-1) wrote buffer (launched & 1)
             r = reduce_residual(b, (a.sweeps_launched & 1) ? b.rec1 : b.rec0, lane);
