@@ -936,7 +936,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
         d.k = p.k.data(); d.in_ptr = p.in_ptr.data(); d.in_idx = p.in_idx.data();
         d.cpt_off = p.cpt_off.data(); d.cpt = p.cpt_flat.data();
         d.device = e->device;
-        d.lanes_per_node = p.wide_requested ? 4 : 2;  // same lane-group split: same bits as this engine's single queries
+        d.lanes_per_node = p.group_wide ? 4 : 2;  // same lane-group split: same bits as this engine's single queries
         rc = bn_create(&d, &e->dense);
         if (rc) { e->dense = nullptr; return nullptr; }
     }

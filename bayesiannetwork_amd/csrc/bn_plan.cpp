@@ -122,9 +122,9 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
             }
     }
 
-    // The lane-group split (opt-in, lanes_per_node 3 / 4: it re-associates the sums over assignments, so its
-    // marginals differ from the 64-entries-per-lane split in the last bits -- both within rounding of the
-    // reference, whose own >= 3-parent products are unordered -- and it quadruples the wavefronts a batch pays
+    // The lane-group split (automatic layout and lanes_per_node 3 / 4; not with 2 = dense: it re-associates the sums over
+    // assignments, so its marginals differ from the 64-entries-per-lane split in the last bits -- both within rounding
+    // of the reference, whose own >= 3-parent products are unordered -- and it quadruples the wavefronts a batch pays
     // for): a network whose lane-group tiles leave SIMDs idle is bound by the latency of ONE
     // tile (tile stamps: 4.2 of a 4-parent tile's 8.9 us are the contraction over its 64 entries per lane on a
     // SIMD that holds no other wave), so it takes the wide split while that still means at most one wave per
@@ -145,7 +145,10 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
         wide_tiles /= 4;
         est_tiles = dense64 / 64;
         static const char* force = std::getenv("BN_GROUP_WIDE");  // A/B switch: 0 / 1
-        group_wide = force ? force[0] == '1' : (wide_requested && wide_tiles > 0 && wide_tiles <= 1024);
+        // automatic layout (lanes_per_node 0): applied by itself, like the other latency rule -- with three or more
+        // parents the reference's own products are unordered (:253), so neither split is "the" reference order
+        group_wide = force ? force[0] == '1' : ((wide_requested || d_in.lanes_per_node == 0) && wide_tiles > 0 && wide_tiles <= 1024);
+        p.group_wide = group_wide;
     }
 
     // ---- which nodes have a templated variant, which can take the any-arity variant

@@ -144,6 +144,7 @@ struct Plan {
     std::vector<FlatEntry> flat_tab;  // per ordered any-arity class, 2 G entries (ClassDesc::flat_tab_off)
     bool latency_rules_applied = false;  // the layout trades wavefront count for the latency of one query (bn_plan.cpp)
     bool wide_requested = false;         // lanes_per_node 3 / 4
+    bool group_wide = false;             // the wide lane-group split (16 table entries per lane) is in force
     std::vector<TileDesc> tiles;
     std::vector<int32_t> node_class; // [n]   -1 for nodes of other ranks
     std::vector<int32_t> node_slot;  // [n]   tiles[t].slot_base + nl, or -1

@@ -57,7 +57,9 @@ typedef struct bn_model_desc {
     const double *cpt;      /* flat CPTs, reference row order                          */
     int32_t device;         /* HIP ordinal, BN_DEVICE_CURRENT or BN_DEVICE_HOST_ONLY   */
     int32_t lanes_per_node; /* 0 = automatic: small networks get a layout that shortens the   */
-                            /*     latency of ONE query (more, lighter wavefronts);          */
+                            /*     latency of ONE query (more, lighter wavefronts: any-arity */
+                            /*     tiles for nodes with many children, the wide lane-group   */
+                            /*     split of 3 / 4 below);                                    */
                             /* 1 = one lane per node everywhere (no lane groups, no          */
                             /*     wavefront-per-node variant: A/B tests);                   */
                             /* 2 = dense: fewest wavefronts, for throughput (what the engine */

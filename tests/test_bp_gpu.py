@@ -183,9 +183,10 @@ def test_gpu_full_size_dag_config2(Engine, oracle_mod):
 
 
 def test_layout_options_same_results(Engine, oracle_mod):
-    """bn_model_desc.lanes_per_node: 0 (automatic: nodes with more than 4 children on any-arity tiles) and 2 (dense)
-    give the same bits -- a batch on a dense second engine must equal single queries on the first; 3 / 4 (the
-    wide lane-group split, 16 table entries per lane) agree with the oracle like the default split does."""
+    """bn_model_desc.lanes_per_node: 0 (automatic: nodes with more than 4 children on any-arity tiles, and on a network
+    this small the wide lane-group split, 16 table entries per lane) gives the bits of 3 (the same two rules, asked for);
+    2 (dense) those of 4 minus the wide split, i.e. the 64-entries-per-lane sums: with three or more parents the splits
+    agree to rounding (the reference's own products are unordered there, :253), and each agrees with the oracle."""
     from bayesiannetwork_amd import synth
     d = synth.random_dag(900, 4, 64, 4, seed=21)          # lane-group tiles + nodes with 5..9 children
     ev = synth.random_evidence(d, 0.02, seed=4)
@@ -197,10 +198,11 @@ def test_layout_options_same_results(Engine, oracle_mod):
             tiles[lanes] = eng.layout()["n_tiles"]
             assert res[lanes]["sweeps"] == o["sweeps"]
             assert rel_err(res[lanes]["beliefs"], o["beliefs"]) < 1e-9
-    assert np.array_equal(res[0]["beliefs"], res[2]["beliefs"]) and np.array_equal(res[3]["beliefs"], res[4]["beliefs"])
+    assert np.array_equal(res[0]["beliefs"], res[3]["beliefs"]) and np.array_equal(res[3]["beliefs"], res[4]["beliefs"])
+    assert np.abs(res[0]["beliefs"] - res[2]["beliefs"]).max() < 1e-12
     import os
     if "BN_GROUP_WIDE" not in os.environ:  # the A/B switch overrides the lane-group split of every engine
-        assert tiles[2] < tiles[0] < tiles[3] and tiles[4] < tiles[3]
+        assert tiles[2] < tiles[4] < tiles[3] and tiles[0] == tiles[3]
     t = synth.random_dag(700, 2, 48, 3, seed=8)           # <= 2 parents: every layout is bit-identical to the reference
     ev = synth.random_evidence(t, 0.02, seed=4)
     o = oracle_mod.bp_run(t, ev, 1e-9, threads=4)

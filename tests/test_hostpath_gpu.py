@@ -74,6 +74,14 @@ def test_wide_split_batch_equals_single_queries(Engine):
     from bayesiannetwork_amd import synth
     g = synth.random_dag(260, 4, 24, 4, seed=23)
     evs = [synth.random_evidence(g, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
+    with Engine(g) as auto, Engine(g, lanes_per_node=2) as dense:   # the automatic layout applies the split by itself ...
+        assert any(c["variant"] == 2 and c["lanes_per_node"] == 4 ** (c["m"] - 1) for c in auto.layout_classes())
+        assert all(c["lanes_per_node"] == 4 ** (c["m"] - 2) for c in dense.layout_classes() if c["variant"] == 2)   # ... the dense one never
+        a, d = auto.bp_run(evs[1], 1e-6), dense.bp_run(evs[1], 1e-6)
+        assert a["sweeps"] == d["sweeps"] and np.abs(a["beliefs"] - d["beliefs"]).max() < 1e-12      # same to rounding
+        out = auto.bp_run_batch(evs, 1e-6)
+        for q, ev in enumerate(evs):                                                                   # and batches keep the bits
+            assert np.array_equal(out["beliefs"][q], auto.bp_run(ev, 1e-6)["beliefs"])
     with Engine(g, lanes_per_node=3) as eng:
         cls = eng.layout_classes()
         # the case must exercise both rules: wide lane groups (m = 3 -> 16 lanes, m = 4 -> 64) and any-arity tiles for
