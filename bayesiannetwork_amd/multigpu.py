@@ -38,9 +38,19 @@ def make_shard(model, rank: int, world: int, device: int, owner=None, in_kernel:
         dist.broadcast_object_list(box, src=0)
         eng.comm_init(box[0])
     if in_kernel and world > 1:
+        import torch
         blobs = [None] * world
         dist.all_gather_object(blobs, eng.peer_export())
-        eng.peer_import(blobs)
+        ok = 1
+        try:
+            eng.peer_import(blobs)
+        except Exception as ex:  # noqa: BLE001 - e.g. a peer's buffers cannot be mapped on this node
+            print(f"[multigpu] rank {rank}: bn_peer_import failed ({ex}); staying on per-sweep launches + RCCL", flush=True)
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)  # every rank or none
+        if int(t[0]) == 0:
+            eng.set_option("multisweep", 0)
     return eng
 
 
@@ -52,7 +62,10 @@ def verify_in_kernel_exchange(eng: Engine, model, ev, eps: float, device: int) -
     Collective."""
     import torch
     dist = init_control_plane()
-    if not eng.info("shard_flow"):
+    have = torch.tensor([1 if eng.info("shard_flow") else 0], dtype=torch.int32)
+    dist.all_reduce(have, op=dist.ReduceOp.MIN)  # the same answer, and the same collectives below, on every rank
+    if int(have[0]) == 0:
+        eng.set_option("multisweep", 0)
         return False
     ok = 1
     with Engine(model, device=device) as one:
