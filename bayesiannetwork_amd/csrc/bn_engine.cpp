@@ -704,9 +704,16 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         if (int code = launch_bp_resident(a, e->grid_resident + (shard ? 1 : resident_service_blocks(e->grid_resident)), e->resident_lean, s))
             return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
-        if (copy_to)  // a launch that stops on its budget (1024 sweeps) copies an intermediate state; the last one counts
+        // (shards: the copy goes out only once the kernel has ended -- a copy into pageable memory blocks inside the runtime,
+        // and where several shard engines live in one process, the thread of a rank whose kernel is still waiting for a
+        // peer's would keep that peer's thread from launching)
+        if (copy_to && !shard)  // a launch that stops on its budget (1024 sweeps) copies an intermediate state; the last one counts
             HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (copy_to && shard) {
+            HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
         e->ev_upload_pending = false;
         ++launches;
         if (!shard) (flow ? e->flow_gen_base : e->gen_base) += kResidentBudget + 1;

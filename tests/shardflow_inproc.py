@@ -98,6 +98,40 @@ def mixed_k():
         check(d, synth.random_evidence(d, 0.02, seed=2), 1e-6, 2, lanes_per_node=2)
 
 
+def evidence_changes():
+    """A stream of different queries through bn_bp_run (evidence in, marginals out, one call) on every shard: nothing of
+    one query may leak into the next (marks take a new value per set, generations count on with the engine's runs)."""
+    g = synth.grid(72, 60, 4, seed=13)
+    evs = [synth.random_evidence(g, f, seed=5 + q) for q, f in enumerate([0.02, 0.0, 0.1, 0.02, 0.3])]
+    with Engine(g) as one:
+        wants = [one.bp_run(ev, 1e-6) for ev in evs]
+    shards = [Engine(g, rank=r, nranks=3) for r in range(3)]
+    try:
+        blobs = [s.peer_export() for s in shards]
+        assert all(s.peer_import(blobs) for s in shards)
+        for ev, want in zip(evs, wants):
+            out, err = [None] * 3, []
+
+            def work(i):
+                try:
+                    out[i] = shards[i].bp_run(ev, 1e-6)
+                except Exception as ex:  # noqa: BLE001
+                    err.append(str(ex))
+
+            th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert not err, err
+            assert all(o["sweeps"] == want["sweeps"] for o in out)
+            assert np.array_equal(sum(o["beliefs"] for o in out), want["beliefs"])
+            assert all(s.last_path() == 2 and s.bp_stats()["resident_aborts"] == 0 for s in shards)
+    finally:
+        for s in shards:
+            s.close()
+
+
 CASES = {
     "grid96x80_r2": lambda: grid_case(96, 80, 2, 1e-6),
     "grid96x80_r4": lambda: grid_case(96, 80, 4, 1e-3),
@@ -108,6 +142,7 @@ CASES = {
     "grid316_r2": lambda: grid_case(316, 316, 2, 1e-3),
     "long_run_two_launches": lambda: grid_case(40, 33, 2, 0.0, k=3, max_sweeps=1100, launches=2),
     "worst_cut": worst_cut,
+    "evidence_changes": evidence_changes,
     "caps_and_empty_rank": caps_and_empty_rank,
     "tree": tree,
     "mixed_k": mixed_k,

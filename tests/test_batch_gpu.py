@@ -1,7 +1,7 @@
 """Several evidence sets per call (bn_bp_run_batch): an extension beside the drop-in -- the reference runs
 one query per operator() call (belief_propagation.hpp:31) -- so the bar is that every set of a batch gets
 exactly what running it alone gives: same sweep count (sets stop on different sweeps), same residual
-history, same bits in the marginals; on the resident path (sets walked round-robin in one launch, 8 at a
+history, same bits in the marginals; on the resident path (sets walked round-robin in one launch, 4 at a
 time) and on the per-sweep launches with one evidence set per blockIdx.y that every other network takes."""
 import numpy as np
 import pytest
@@ -96,7 +96,7 @@ def test_batch_on_per_sweep_launches_every_tile_variant(Engine):
 def test_batch_more_sets_than_one_resident_launch_walks(Engine):
     from bayesiannetwork_amd import synth
     g = synth.grid(40, 40, 4, seed=3)
-    evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(19)]   # 3 launches: 7 + 6 + 6 sets
+    evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(19)]   # 5 launches: 4 + 4 + 4 + 4 + 3 sets (kResidentMaxSets = 4, balanced chunks)
     with Engine(g) as eng:
         _check_batch(eng, evs, 1e-6, want_path=2, reps=1)
         eng.set_option("multisweep", 0)                              # the same batch through the per-sweep launches

@@ -30,7 +30,7 @@ def _single(eng, model, ev, eps, max_sweeps=0):
 
 @pytest.mark.parametrize("cases", [("grid96x80_r2", "grid96x80_r4", "grid48x40_r3", "grid40x33_k3_r2", "grid50x50_k2_r3"),
                                    ("grid200_r8", "grid316_r2"),
-                                   ("worst_cut", "caps_and_empty_rank", "tree", "mixed_k", "long_run_two_launches")])
+                                   ("worst_cut", "caps_and_empty_rank", "tree", "mixed_k", "long_run_two_launches", "evidence_changes")])
 def test_shards_in_one_process(cases):
     """2-8 shard engines in ONE process, kernels co-resident on one device (tests/shardflow_inproc.py; a process of its
     own because the number of hardware queues per process is fixed when HIP starts)."""
