@@ -14,6 +14,7 @@ for rows in (316, 200, 128):
     ev = synth.random_evidence(g, 0.01, seed=7)
     with Engine(g) as e:
         e.set_option("multisweep", 2)
+        e.set_option("flow", 1)
         e.bp_set_evidence(ev)
         row = {}
         for z in (0, 1, 2, 4, 6, 8, 12, 16, 24):
@@ -26,6 +27,7 @@ for rows in (316, 200, 128):
                 r = e.bp_run_device(1e-3)
                 dev += e.bp_stats()["sweep_devclock_ms"]
             wall = (time.perf_counter() - t0) / reps * 1e6
+            assert e.info("last_flow") == 1
             row[z] = (round(dev / reps * 1e3 / r["sweeps"], 2), round(wall, 1))
         e.set_option("flow", 0)
         for _ in range(3):
