@@ -955,11 +955,14 @@ __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockSh
 // shape: the headline workload) -- an instantiation that carries no code or registers for the other shapes,
 // so its code-object figures (0 spills, tests/test_host_logic.py) are those of the path that actually runs.
 // LEAN = 0: every shape the resident path admits.
-template <int MODE, int LEAN>
-__global__ __launch_bounds__(kResidentWaves * kWave, 2) void bp_resident_kernel(ResidentArgs a) {
+// WMAX: most waves a block of this instantiation is launched with.  8 (two waves per SIMD: 256 registers each) everywhere
+// but in the all-shapes instantiations for networks that run four waves per block: one wave per SIMD may use the whole
+// register file (512), which is what the 4- and 8-children parent roles inlined side by side need to stay out of scratch.
+template <int MODE, int LEAN, int WMAX = kResidentWaves>
+__global__ __launch_bounds__(WMAX * kWave, WMAX == kResidentWaves ? 2 : 1) void bp_resident_kernel(ResidentArgs a) {
     constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow || MODE == kModeFlowShard, SHARD = MODE == kModeFlowShard;
     __shared__ BlockShared sh;
-    __shared__ double2_t cpt_lds_all[kResidentWaves][kResidentLdsSlots * kWave];  // the CPT entries not kept in registers, 18 KiB per wave
+    __shared__ double2_t cpt_lds_all[WMAX][kResidentLdsSlots * kWave];  // the CPT entries not kept in registers, 18 KiB per wave
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1039,12 +1042,23 @@ int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void*
         case kModeFlowShard: hipLaunchKernelGGL((bp_resident_kernel<kModeFlowShard, L>), g, t, 0, s, a); break; \
         default: hipLaunchKernelGGL((bp_resident_kernel<kModeBarrier, L>), g, t, 0, s, a); break;         \
     }
+#define BN_RES_LAUNCH_W4(L)                                                                       \
+    switch (mode) {                                                                               \
+        case kModeBatch: hipLaunchKernelGGL((bp_resident_kernel<kModeBatch, L, 4>), g, t, 0, s, a); break;   \
+        case kModeFlow: hipLaunchKernelGGL((bp_resident_kernel<kModeFlow, L, 4>), g, t, 0, s, a); break;     \
+        case kModeFlowShard: hipLaunchKernelGGL((bp_resident_kernel<kModeFlowShard, L, 4>), g, t, 0, s, a); break; \
+        default: hipLaunchKernelGGL((bp_resident_kernel<kModeBarrier, L, 4>), g, t, 0, s, a); break;         \
+    }
     switch (lean_k) {
         case 2: BN_RES_LAUNCH(2); break;
         case 3: BN_RES_LAUNCH(3); break;
         case 4: BN_RES_LAUNCH(4); break;
-        default: BN_RES_LAUNCH(0); break;
+        default:
+            if (a.waves <= 4) { BN_RES_LAUNCH_W4(0); }
+            else { BN_RES_LAUNCH(0); }
+            break;
     }
+#undef BN_RES_LAUNCH_W4
 #undef BN_RES_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);

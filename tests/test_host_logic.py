@@ -269,18 +269,24 @@ def test_hot_kernels_do_not_spill(bnlib):
         assert "bp_sweep_kernel" in name
         assert r["spill"] == 0 and r["scratch"] == 0 and r["lds"] == 0 and r["vgpr"] <= 256, (name, r)
     res = kr.kernel_resources(os.path.join(csrc, "bn_resident.o"))
-    assert len(res) == 16  # {grid barrier, several sets, dataflow, dataflow of a shard} x {LEAN k = 2, 3, 4; all shapes}
+    # {grid barrier, several sets, dataflow, dataflow of a shard} x {LEAN k = 2, 3, 4; all shapes at 8 and at 4 waves per block}
+    assert len(res) == 20
+    import re
     for name, r in res.items():
-        assert "bp_resident_kernel" in name and r["vgpr"] <= 256, (name, r)
-        if "<3, 4>" in name:    # a shard's k = 4 tiles also carry the code for their cut edges: a handful of dwords
+        m = re.search(r"bp_resident_kernel<(\d+), (\d+), (\d+)>", name)
+        assert m, name
+        mode, lean, wmax = (int(x) for x in m.groups())
+        if wmax == 4:           # all shapes, one wave per SIMD: the whole register file, nothing in scratch
+            assert lean == 0 and r["spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 512, (name, r)
+            continue
+        assert r["vgpr"] <= 256, (name, r)
+        if mode == 3 and lean == 4:   # a shard's k = 4 tiles also carry the code for their cut edges: a handful of dwords
             assert r["spill"] <= 8, (name, r)
-        elif "<3, 0>" in name:  # ... and with every shape inlined
-            assert r["spill"] <= 96, (name, r)
-        elif ", 0>" not in name:  # LEAN = k: every node of arity k with <= 2 children -- what the headline grid runs (k = 4)
+        elif lean != 0:         # LEAN = k: every node of arity k with <= 2 children -- what the headline grid runs (k = 4)
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
-        else:                   # every shape inlined into one kernel: the 4- / 8-children parent roles spill a little
-            assert r["spill"] <= 64, (name, r)
-        if ", 4>" in name or ", 0>" in name:  # 64-entry tables keep 36 entries per lane in LDS
+        else:                   # every shape inlined into one kernel at two waves per SIMD (networks above ~900 tiles only)
+            assert r["spill"] <= (96 if mode == 3 else 64), (name, r)
+        if lean in (0, 4):      # 64-entry tables keep 36 entries per lane in LDS
             assert r["lds"] >= 144 * 1024, (name, r)
     for obj in ("bn_sweep_ug.o", "bn_sweep_all.o"):  # lane-group / any-arity instantiations: no spills either
         for name, r in kr.kernel_resources(os.path.join(csrc, obj)).items():
