@@ -408,6 +408,16 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 int r2;
                 if ((r2 = upload(&e->d_nbr, p.nbr, e->stream))) return r2;
             }
+            if (p.nranks > 1) {
+                // shards allocate their page-locked staging now: no allocation call may fall between two ranks' launches of a run
+                // (several shard engines in one process: such calls can wait for the whole device)
+                const size_t evb = ((size_t(p.n) * 4 + size_t(p.n + 1) * 4 + 7) & ~size_t(7)) + size_t(p.node_off[p.n]) * 8 + 64;
+                e->ev_bytes_cap = evb;
+                HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ev), evb, hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ev_dev), e->h_ev, 0));
+                HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_beliefs), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double), hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_beliefs_dev), e->h_beliefs, 0));
+            }
             if (e->shard_shapes_ok) {  // zeroed HERE, once: peers write into it from their kernels whenever they run
                 if (e->fine_grained)
                     HIPCHK(hipExtMallocWithFlags(reinterpret_cast<void**>(&e->d_flow), flow_sync_bytes(p.nranks), hipDeviceMallocFinegrained));
@@ -526,15 +536,15 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
         HIPCHK(hipStreamSynchronize(e->stream));
         e->ev_upload_pending = false;
     }
-    if (bytes > e->ev_bytes_cap) {
-        HIPCHK(hipStreamSynchronize(e->stream));
-        if (e->d_ev) (void)hipFree(e->d_ev);
-        if (e->h_ev) (void)hipHostFree(e->h_ev);
-        e->d_ev = nullptr; e->h_ev = nullptr;
-        e->ev_bytes_cap = std::max<size_t>(bytes * 2, 4096);
+    if (!e->h_ev) {
+        // the staging block is sized ONCE, for the largest evidence set the model admits (every node observed): growing it
+        // later would mean hipHostFree, which waits for the whole device -- and where several shard engines share a process,
+        // a rank whose kernel is already waiting for this rank's would never let that return
+        e->ev_bytes_cap = ((size_t(p.n) * 4 + size_t(p.n + 1) * 4 + 7) & ~size_t(7)) + size_t(p.node_off[p.n]) * 8 + 64;
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ev), e->ev_bytes_cap, hipHostMallocMapped));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ev_dev), e->h_ev, 0));
     }
+    if (bytes > e->ev_bytes_cap) return fail(BN_ERR_ARG, "evidence larger than the model");
     // ONE kernel applies a set: it reads the arrays in place from the page-locked staging block (no copy command in the
     // queue in front of the run) and marks the nodes with this set's mark value (no memset of the previous set's marks)
     if (ne > 0) {
@@ -710,16 +720,27 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
         if (copy_to && !shard)  // a launch that stops on its budget (1024 sweeps) copies an intermediate state; the last one counts
             HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (copy_to && shard) {
-            HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
+        if (copy_to && shard) {  // through the engine's page-locked buffer: a plain DMA, nothing that blocks inside the runtime
+            const size_t bytes = sizeof(double) * e->plan.node_off[e->plan.n];
+            if (copy_to != e->h_beliefs && !e->h_beliefs) {
+                HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_beliefs), std::max<size_t>(bytes, 8), hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_beliefs_dev), e->h_beliefs, 0));
+            }
+            HIPCHK(hipMemcpyAsync(e->h_beliefs, e->d_beliefs, bytes, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (copy_to != e->h_beliefs) std::memcpy(copy_to, e->h_beliefs, bytes);
         }
         e->ev_upload_pending = false;
         ++launches;
         if (!shard) (flow ? e->flow_gen_base : e->gen_base) += kResidentBudget + 1;
         const bool gave_up = e->h_ctl->done < 0 || *e->h_abort != 0;  // any block may raise it, whatever block 0 / the service reported
         if (e->h_ctl->run_id != e->run_id || gave_up) (flow ? e->flow_dirty : e->rsync_dirty) = true;
-        if (gave_up) return fail(BN_ERR_STATE, "resident kernel gave up a bounded wait");
+        if (gave_up) {
+            char where[96];
+            std::snprintf(where, sizeof where, " (code 0x%x: wait kind %u, iteration %u, tile %u; run seq %u)", *e->h_abort, *e->h_abort & 0xffu,
+                          (*e->h_abort >> 8) & 0xfffu, (*e->h_abort >> 20) & 0x7ffu, e->shard_run_seq);
+            return fail(BN_ERR_STATE, std::string("resident kernel gave up a bounded wait") + where);
+        }
         if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
         if (e->timing) {
             float t = 0.f;

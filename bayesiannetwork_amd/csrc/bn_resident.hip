@@ -309,8 +309,10 @@ __device__ __forceinline__ unsigned long long* flow_slot(FlowSync* f, int nranks
     return reinterpret_cast<unsigned long long*>(f + 1) + (size_t(par) * nranks * kFlowSlotsPerRank + slot) * 2;
 }
 
+// `where`: which wait gave up (diagnostics: the host prints it under BN_DEBUG) -- 1 a tile's neighbours / verdict, 2 the
+// service block's own tiles, 3 the other ranks' residuals; bits 8.. the iteration
 template <bool SHARD>
-__device__ __forceinline__ void flow_raise_abort(const ResidentArgs& a) {
+__device__ __forceinline__ void flow_raise_abort(const ResidentArgs& a, unsigned where = 0) {
     const unsigned long long w = (unsigned long long)(a.gen_base + 1u) | ((unsigned long long)kFlowAbort << 32);
     for (int q = 0; q < 8; ++q) flow_store<SHARD>(&a.flow->verdict[q].word, w);
     if constexpr (SHARD) {  // the other ranks stop at their next poll instead of running into their own deadline
@@ -318,7 +320,7 @@ __device__ __forceinline__ void flow_raise_abort(const ResidentArgs& a) {
             if (r != a.b.rank)
                 for (int q = 0; q < 8; ++q) flow_store<true>(&a.peers[r].flow->verdict[q].word, w);
     }
-    __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.host_abort, 0x80000000u | where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Waits until this tile may run iteration `it`; returns the verdict that ends the run for it (kFlowGoOn: run the
@@ -363,7 +365,7 @@ __device__ __forceinline__ unsigned flow_wait(const ResidentArgs& a, int tile, i
             const unsigned long long now = wall_clock64();
             if (t0 == 0) t0 = now;
             if (now - t0 > a.timeout_ticks) {
-                if (lane == 0) flow_raise_abort<SHARD>(a);
+                if (lane == 0) flow_raise_abort<SHARD>(a, 1u | (unsigned(it) << 8) | (unsigned(tile) << 20));
                 return kFlowAbort;
             }
         }
@@ -446,7 +448,7 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
                 const unsigned long long now = wall_clock64();
                 if (t0 == 0) t0 = now;
                 if (now - t0 > a.timeout_ticks) {
-                    if (lane == 0) flow_raise_abort<SHARD>(a);
+                    if (lane == 0) flow_raise_abort<SHARD>(a, 2u | (unsigned(it) << 8));
                     ok = false;
                     break;
                 }
@@ -491,7 +493,7 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
                             const unsigned long long now = wall_clock64();
                             if (t1 == 0) t1 = now;
                             if (now - t1 > a.timeout_ticks) {
-                                flow_raise_abort<true>(a);
+                                flow_raise_abort<true>(a, 3u | (unsigned(it) << 8));
                                 good = false;
                             }
                         }
@@ -536,7 +538,10 @@ __device__ __forceinline__ void flow_service(const ResidentArgs& a, BlockShared&
 // own states in LDS -- 16 bytes per lane and slot, lane-contiguous: conflict-free ds_read_b128 -- and the
 // lower half in registers; 128 VGPRs of CPT plus the working set do not fit 256 registers, and the
 // compiler's answer, scratch memory, would re-read two thirds of the table through the caches each sweep.
-template <int K, int M, int RC, bool BATCH, bool FLOW, bool SHARD = false>
+// BIG: the block runs at most four waves, one per SIMD, and its kernel may use the whole register file: the CPT stays in
+// registers entirely (no LDS slots) and the contraction is left to the scheduler (no pins) -- a wave alone on its SIMD
+// has nobody to fill its dependency stalls, so instruction-level parallelism is what it runs on.
+template <int K, int M, int RC, bool BATCH, bool FLOW, bool SHARD = false, bool BIG = false>
 __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int tile, int lane, int wave,
                                               double2_t* cpt_lds) {
     static_assert(!(BATCH && FLOW), "the dataflow form runs one evidence set");
@@ -546,8 +551,9 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
     constexpr int CB = (M > 0) ? C / K : 0;
     // entries [0, SR) of the i-major image stay in registers, the rest in LDS: 28 of 64 (k = 4, two parents) leaves the
     // working set just enough registers; everything for smaller tables
-    constexpr int SR = (S > 32) ? 28 : SP;
+    constexpr int SR = (S > 32 && !BIG) ? 28 : SP;
     static_assert(SR % 2 == 0 && (SR == SP || (S - SR) / 2 <= kResidentLdsSlots), "CPT split");
+    auto PIN = [](double& x) { if constexpr (!BIG) pin_here(x); };
     const BpBuffers& b = a.b;
     const bool active = lane < td.n_nodes;
     const int lc = active ? lane : 0;  // idle lanes shadow lane 0 and store nothing
@@ -723,9 +729,9 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
 #pragma unroll
             for (int c = 0; c < RC; ++c) {
                 if (c < td.cmax) {  // wave-uniform
-                    pin_here(wres);  // one child at a time (see pin_here)
+                    PIN(wres);  // one child at a time (see pin_here)
 #pragma unroll
-                    for (int i = 0; i < K; ++i) pin_here(piv[i]);
+                    for (int i = 0; i < K; ++i) PIN(piv[i]);
 
                     double u[K];
 #pragma unroll
@@ -799,15 +805,15 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
                 pin[ib] = 0.0 + cpt[ib];
             } else {
                 // one own state at a time: everything this step consumes is pinned here
-                pin_here(lav[ib]);
+                PIN(lav[ib]);
 #pragma unroll
                 for (int j = 0; j < M; ++j)
 #pragma unroll
-                    for (int i = 0; i < K; ++i) pin_here(pim[j][i]);
+                    for (int i = 0; i < K; ++i) PIN(pim[j][i]);
 #pragma unroll
                 for (int jt = 0; jt < M; ++jt)
 #pragma unroll
-                    for (int ct = 0; ct < K; ++ct) pin_here(out[jt][ct]);
+                    for (int ct = 0; ct < K; ++ct) PIN(out[jt][ct]);
                 // entry `cond` of own state ib: a register, or this wave's LDS slots (read where it is used:
                 // a copy of the whole row would cost 2 C registers for the length of the step)
                 const double* lds_lane = reinterpret_cast<const double*>(cpt_lds + lane);
@@ -820,17 +826,17 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
 #pragma unroll
                 for (int rr = 0; rr < CB; ++rr) {
                     if (rr > 0) {  // K + M K independent chains per step are plenty; pin the step's boundary
-                        asm volatile("" ::: "memory");
-                        pin_here(acc);
-                        pin_here(lav[ib]);
+                        if constexpr (!BIG) asm volatile("" ::: "memory");
+                        PIN(acc);
+                        PIN(lav[ib]);
 #pragma unroll
                         for (int j = 0; j < M; ++j)
 #pragma unroll
-                            for (int i = 0; i < K; ++i) pin_here(pim[j][i]);
+                            for (int i = 0; i < K; ++i) PIN(pim[j][i]);
 #pragma unroll
                         for (int jt = 0; jt < M; ++jt)
 #pragma unroll
-                            for (int ct = 0; ct < K; ++ct) pin_here(out[jt][ct]);
+                            for (int ct = 0; ct < K; ++ct) PIN(out[jt][ct]);
                     }
 #pragma unroll
                     for (int x = 0; x < K; ++x) {
@@ -937,17 +943,17 @@ __device__ __forceinline__ bool resident_tile(const ResidentArgs& a, BlockShared
 // (node vectors through memory between a set's turns); 2 = one evidence set, dataflow form (no grid barrier)
 enum : int { kModeBarrier = 0, kModeBatch = 1, kModeFlow = 2, kModeFlowShard = 3 };  // 3: dataflow form of a sharded engine (peer stores)
 
-template <int K, int M, int MODE, int LEAN>
+template <int K, int M, int MODE, int LEAN, bool BIG>
 __device__ __forceinline__ bool resident_dispatch(const ResidentArgs& a, BlockShared& sh, const TileDesc& td, int tile, int lane, int wave,
                                                   double2_t* cpt_lds) {
     constexpr bool BATCH = MODE == kModeBatch, FLOW = MODE == kModeFlow || MODE == kModeFlowShard, SHARD = MODE == kModeFlowShard;
 #ifdef BN_RES_ONLY_RC  // experiments: one instantiation only
-    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
+    return resident_tile<K, M, BN_RES_ONLY_RC, BATCH, FLOW, SHARD, BIG>(a, sh, td, tile, lane, wave, cpt_lds);
 #else
-    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
-    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
-    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);
-    return resident_tile<K, M, 8, BATCH, FLOW, SHARD>(a, sh, td, tile, lane, wave, cpt_lds);  // the host admits <= 8 children per node
+    if constexpr (LEAN != 0) return resident_tile<K, M, 2, BATCH, FLOW, SHARD, BIG>(a, sh, td, tile, lane, wave, cpt_lds);
+    if (td.cmax <= 2) return resident_tile<K, M, 2, BATCH, FLOW, SHARD, BIG>(a, sh, td, tile, lane, wave, cpt_lds);
+    if (td.cmax <= 4) return resident_tile<K, M, 4, BATCH, FLOW, SHARD, BIG>(a, sh, td, tile, lane, wave, cpt_lds);
+    return resident_tile<K, M, 8, BATCH, FLOW, SHARD, BIG>(a, sh, td, tile, lane, wave, cpt_lds);  // the host admits <= 8 children per node
 #endif
 }
 
@@ -991,25 +997,25 @@ __global__ __launch_bounds__(WMAX * kWave, WMAX == kResidentWaves ? 2 : 1) void 
         double2_t* lds = cpt_lds_all[wave];
         {
 #ifdef BN_RES_ONLY_K
-            ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, MODE, LEAN>(a, sh, td, tile, lane, wave, lds);
+            ok = resident_dispatch<BN_RES_ONLY_K, BN_RES_ONLY_M, MODE, LEAN, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds);
 #else
             if constexpr (LEAN != 0) {
                 switch (td.m) {
-                    case 0: ok = resident_dispatch<LEAN, 0, MODE, LEAN>(a, sh, td, tile, lane, wave, lds); break;
-                    case 1: ok = resident_dispatch<LEAN, 1, MODE, LEAN>(a, sh, td, tile, lane, wave, lds); break;
-                    default: ok = resident_dispatch<LEAN, 2, MODE, LEAN>(a, sh, td, tile, lane, wave, lds); break;
+                    case 0: ok = resident_dispatch<LEAN, 0, MODE, LEAN, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 1: ok = resident_dispatch<LEAN, 1, MODE, LEAN, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    default: ok = resident_dispatch<LEAN, 2, MODE, LEAN, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
                 }
             } else {
                 switch (td.kv * 8 + td.m) {
-                    case 2 * 8 + 0: ok = resident_dispatch<2, 0, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 2 * 8 + 1: ok = resident_dispatch<2, 1, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 2 * 8 + 2: ok = resident_dispatch<2, 2, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 3 * 8 + 0: ok = resident_dispatch<3, 0, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 3 * 8 + 1: ok = resident_dispatch<3, 1, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 3 * 8 + 2: ok = resident_dispatch<3, 2, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 4 * 8 + 0: ok = resident_dispatch<4, 0, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    case 4 * 8 + 1: ok = resident_dispatch<4, 1, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;
-                    default: ok = resident_dispatch<4, 2, MODE, 0>(a, sh, td, tile, lane, wave, lds); break;  // host admits only the shapes above
+                    case 2 * 8 + 0: ok = resident_dispatch<2, 0, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 2 * 8 + 1: ok = resident_dispatch<2, 1, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 2 * 8 + 2: ok = resident_dispatch<2, 2, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 3 * 8 + 0: ok = resident_dispatch<3, 0, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 3 * 8 + 1: ok = resident_dispatch<3, 1, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 3 * 8 + 2: ok = resident_dispatch<3, 2, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 4 * 8 + 0: ok = resident_dispatch<4, 0, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    case 4 * 8 + 1: ok = resident_dispatch<4, 1, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;
+                    default: ok = resident_dispatch<4, 2, MODE, 0, (WMAX < kResidentWaves)>(a, sh, td, tile, lane, wave, lds); break;  // host admits only the shapes above
                 }
             }
 #endif
@@ -1049,14 +1055,12 @@ int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void*
         case kModeFlowShard: hipLaunchKernelGGL((bp_resident_kernel<kModeFlowShard, L, 4>), g, t, 0, s, a); break; \
         default: hipLaunchKernelGGL((bp_resident_kernel<kModeBarrier, L, 4>), g, t, 0, s, a); break;         \
     }
+    const bool w4 = a.waves <= 4 && grid_blocks > 1;
     switch (lean_k) {
-        case 2: BN_RES_LAUNCH(2); break;
+        case 2: BN_RES_LAUNCH(2); break;  // (k = 2, 3: the tables are in registers anyway and nothing is pinned hard)
         case 3: BN_RES_LAUNCH(3); break;
-        case 4: BN_RES_LAUNCH(4); break;
-        default:
-            if (a.waves <= 4) { BN_RES_LAUNCH_W4(0); }
-            else { BN_RES_LAUNCH(0); }
-            break;
+        case 4: if (w4) { BN_RES_LAUNCH_W4(4); } else { BN_RES_LAUNCH(4); } break;
+        default: if (w4) { BN_RES_LAUNCH_W4(0); } else { BN_RES_LAUNCH(0); } break;
     }
 #undef BN_RES_LAUNCH_W4
 #undef BN_RES_LAUNCH
