@@ -341,7 +341,7 @@ def leg_lw(a, local_rank, torch):
             "algorithmic_bytes_per_sample": bytes_per_sample,
             "note": "informational: the sampler is VALU/latency-bound (DESIGN.md section 4), not HBM-bound"}
     roof.update(profiled_traffic("lw"))
-    roof.update(profiled_valu("lw", 8))  # 256-thread blocks, no LDS, <= 64 VGPRs: up to 8 waves per SIMD
+    roof.update(profiled_valu("lw", 5))  # lw_sample_kernel: 91-93 VGPRs -> 5 waves per SIMD (7 816 waves per step on 1 024 SIMDs)
     roof["limiter"] = "valu+latency"
     out = {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
                        f"{a.samples} samples per step (BASELINE.json configs[4]; 10 M samples = {10000000 / rate:.3f} s at this rate)",
