@@ -294,3 +294,54 @@ def test_hot_kernels_do_not_spill(bnlib):
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
     for name, r in kr.kernel_resources(os.path.join(csrc, "bn_lw_kernels.o")).items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+
+
+def test_peer_blobs_and_flow_tables_host_only(bnlib):
+    """bn_peer_export / bn_peer_import on host-only shard engines (no GPU): blob size and contents are consistent, the
+    neighbour tables of all ranks mirror each other across the cut, a tile reports to exactly the ranks that hold one
+    of its neighbours, and malformed input is an argument error, never a crash."""
+    import ctypes
+    from bayesiannetwork_amd import _lib, engine, synth
+    g = synth.grid(30, 25, 4, seed=4)
+    n = 4
+    sh = [engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY, rank=r, nranks=n) for r in range(n)]
+    blobs = [s.peer_export() for s in sh]
+    for s, b in zip(sh, blobs):
+        assert len(b) == _lib.lib().bn_peer_blob_size(s._h) and s.info("n_boundary_nodes") * 8 < len(b)
+        assert s.peer_import(blobs) is False          # host-only: tables only, no exchange set up
+        assert s.info("nbr_chunks") >= 1 and s.info("shard_flow") == 0
+    tabs = [s.flow_tables() for s in sh]
+    tiles = [s.node_tiles() for s in sh]
+    child = np.repeat(np.arange(g.n), np.diff(g.in_ptr))
+    owner = np.full(g.n, -1)
+    for r in range(n):
+        owner[tiles[r] >= 0] = r
+    assert (owner >= 0).all()
+    for e_ in range(g.n_edges):                        # every cut edge: each side lists the other's tile and reports to its rank
+        u, v = int(g.in_idx[e_]), int(child[e_])
+        a, b = owner[u], owner[v]
+        if a == b:
+            continue
+        tu, tv = int(tiles[a][u]), int(tiles[b][v])
+        assert b * 2048 + tv in tabs[a][0][tu] and a * 2048 + tu in tabs[b][0][tv]
+        assert (int(tabs[a][1][tu]) >> b) & 1 and (int(tabs[b][1][tv]) >> a) & 1
+    for r in range(n):                                 # and nobody else
+        nbr, pub = tabs[r]
+        for t in range(nbr.shape[0]):
+            ranks = {int(x) // 2048 for x in nbr[t][nbr[t] >= 0]} - {r}
+            assert int(pub[t]) == sum(1 << q for q in ranks)
+    with pytest.raises(_lib.BnError):                  # a blob of the wrong rank in slot 0
+        sh[0].peer_import([blobs[1]] + blobs[1:])
+    with pytest.raises(_lib.BnError):                  # too few blobs
+        sh[0].peer_import(blobs[:2])
+    with pytest.raises(_lib.BnError):                  # truncated blob
+        sh[0].peer_import([blobs[0][:40]] + blobs[1:])
+    other = synth.grid(30, 25, 4, seed=4)
+    with engine.Engine(other, device=_lib.BN_DEVICE_HOST_ONLY) as one:   # not a sharded engine
+        with pytest.raises(_lib.BnError):
+            one.peer_export()
+        assert one.info("flow_eligible") == 0 and one.info("resident_waves") in (4, 8)
+        with pytest.raises(_lib.BnError):
+            one.info("no_such_property")
+    for s in sh:
+        s.close()
