@@ -28,14 +28,21 @@ def _single(eng, model, ev, eps, max_sweeps=0):
         return want, one.bp_residuals(), one.bp_messages()
 
 
-@pytest.mark.parametrize("cases", [("grid96x80_r2", "grid96x80_r4", "grid48x40_r3", "grid40x33_k3_r2", "grid50x50_k2_r3"),
-                                   ("grid200_r8", "grid316_r2"),
-                                   ("worst_cut", "caps_and_empty_rank", "tree", "mixed_k", "long_run_two_launches", "evidence_changes")])
-def test_shards_in_one_process(cases):
+@pytest.mark.parametrize("cases,waves", [
+    (("grid96x80_r2", "grid96x80_r4", "grid48x40_r3", "grid40x33_k3_r2", "grid50x50_k2_r3"), None),
+    (("grid200_r8",), None),
+    (("grid316_r2",), "8"),
+    (("worst_cut", "caps_and_empty_rank", "tree", "mixed_k", "long_run_two_launches", "evidence_changes"), None),
+    (("grid96x80_r2", "tree", "evidence_changes"), "8")])
+def test_shards_in_one_process(cases, waves):
     """2-8 shard engines in ONE process, kernels co-resident on one device (tests/shardflow_inproc.py; a process of its
-    own because the number of hardware queues per process is fixed when HIP starts)."""
-    # (8 waves per block: on a GPU of its own a shard this small spreads out at 4, one wave per SIMD; here the shards share one chip)
-    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", BN_RESIDENT_WAVES="8")
+    own because the number of hardware queues per process is fixed when HIP starts).  waves None: what the engine picks --
+    four waves per block, one per SIMD, with the whole register file, on shards this small (the instantiations a shard of
+    the 316x316 grid runs on a GPU of its own); "8": eight waves per block, which the two halves of the 316x316 grid need
+    to be co-resident on ONE chip."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    if waves:
+        env["BN_RESIDENT_WAVES"] = waves
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shardflow_inproc.py"), *cases], env=env, capture_output=True,
                        text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
@@ -66,7 +73,9 @@ def test_shards_in_separate_processes_over_ipc(eng, rows, cols, nranks, eps, max
     want, want_res, _ = _single(eng, g, ev, eps, max_sweeps)
     reps = 3
     with tempfile.TemporaryDirectory() as work:
-        env = dict(os.environ, BN_RESIDENT_WAVES="8")  # the ranks share ONE chip here: keep their blocks few enough to be co-resident
+        env = dict(os.environ)
+        if rows * cols > 40000:
+            env["BN_RESIDENT_WAVES"] = "8"  # the ranks share ONE chip here: keep their blocks few enough to be co-resident
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shardflow_worker.py"), str(r), str(nranks), work,
                                    str(rows), str(cols), repr(eps), str(max_sweeps), str(reps), "0"], env=env,
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(nranks)]
@@ -101,7 +110,7 @@ def test_bench_two_ranks_on_one_device():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, BN_BENCH_SAME_DEVICE="1", BN_NO_RCCL="1", OMP_NUM_THREADS="1", BN_RESIDENT_WAVES="8")
+    env = dict(os.environ, BN_BENCH_SAME_DEVICE="1", BN_NO_RCCL="1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
            "--rows", "96", "--cols", "80"]
