@@ -146,6 +146,7 @@ struct bn_engine {
     double* h_beliefs = nullptr;    // pinned: bn_bp_run_view hands this out, bn_bp_run stages nothing through it
     double* h_beliefs_dev = nullptr;  // ... as the device sees it
     double* beliefs_override = nullptr;  // where the kernels write the beliefs of the run in hand instead of d_beliefs
+    bool beliefs_on_host_only = false;   // the last run wrote its marginals into h_beliefs, not d_beliefs (synced back on demand)
     int beliefs_direct = 1;         // option "beliefs_direct": bn_bp_run_view lets the kernels write the marginals straight into
                                     // the mapped host buffer (no copy command behind the run; 316x316 grid: 253 -> 235 us per query);
                                     // outputs above 16 MB go through the copy engine (larger PCIe payloads)
@@ -765,6 +766,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
 static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
                            double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
+    e->beliefs_on_host_only = false;  // (bn_bp_run_view sets it again when its kernels wrote to the host buffer)
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
     if (e->plan.nranks > 1 && !e->comm && !(e->shard_flow_ok && e->multisweep != 0))
@@ -1516,11 +1518,28 @@ extern "C" int bn_layout_flow(bn_engine* e, int32_t* nbr_out, uint32_t* pub_out)
     return BN_OK;
 }
 
-extern "C" const double* bn_bp_beliefs_device(bn_engine* e) { return (e && !e->host_only) ? e->d_beliefs : nullptr; }
+// the marginals of the last run in device memory (a bn_bp_run_view that wrote them straight to the host buffer: uploaded first)
+static int beliefs_to_device(bn_engine* e) {
+    if (!e->beliefs_on_host_only) return BN_OK;
+    ON_DEVICE(e);
+    HIPCHK(hipMemcpyAsync(e->d_beliefs, e->h_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->beliefs_on_host_only = false;
+    return BN_OK;
+}
+extern "C" const double* bn_bp_beliefs_device(bn_engine* e) {
+    if (!e || e->host_only) return nullptr;
+    if (beliefs_to_device(e) != BN_OK) return nullptr;
+    return e->d_beliefs;
+}
 
 extern "C" int bn_bp_copy_beliefs(bn_engine* e, double* beliefs_out) {
     if (!e || !beliefs_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run to copy from");
+    if (e->beliefs_on_host_only) {  // the last run's marginals are in the engine's page-locked buffer
+        if (beliefs_out != e->h_beliefs) std::memcpy(beliefs_out, e->h_beliefs, sizeof(double) * e->plan.node_off[e->plan.n]);
+        return BN_OK;
+    }
     ON_DEVICE(e);
     HIPCHK(hipMemcpyAsync(beliefs_out, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n],
                           hipMemcpyDeviceToHost, e->stream));
@@ -1559,6 +1578,7 @@ extern "C" int bn_bp_run_view(bn_engine* e, int32_t ne, const int32_t* ev_node, 
         e->beliefs_override = e->h_beliefs_dev;
         rc = run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, nullptr);
         e->beliefs_override = nullptr;
+        e->beliefs_on_host_only = rc == BN_OK;
     } else {
         rc = run_device_impl(e, eps, max_sweeps, sweeps_out, residual_out, e->h_beliefs);
     }
