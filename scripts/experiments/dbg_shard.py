@@ -1,5 +1,9 @@
-import sys, threading
-sys.path.insert(0, '/root/repo')
+# n shard engines of a grid in ONE process (threads), in-kernel exchange, compared with the unsharded engine message by message:
+#   GPU_MAX_HW_QUEUES=16 python scripts/experiments/dbg_shard.py ROWS COLS [NRANKS]
+import os
+import sys
+import threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from bayesiannetwork_amd import synth
 from bayesiannetwork_amd.engine import Engine
