@@ -22,6 +22,7 @@
 #include "bn_device.hpp"
 #include "bn_fit.hpp"
 #include "bn_lw.hpp"
+#include "bn_small.hpp"
 
 using namespace bnmi;
 
@@ -208,9 +209,22 @@ struct bn_engine {
     bool batch_on_dense = false;    // the current batch lives in `dense`
     bn_engine* dense = nullptr;     // a second engine with the dense layout: batches on a network whose own layout trades
                                     // wavefront count for one query's latency (Plan::latency_rules_applied) run there
+    // small networks: the whole run in ONE workgroup with the state in LDS (bn_small.hip)
+    SmallPlan small;
+    bool small_ok = false;
+    SmallEntry* d_s_ent = nullptr;
+    double* d_s_cpt = nullptr;
+    uint32_t* d_s_term = nullptr;
+    uint16_t* d_s_clist = nullptr;
+    SmallSlot* d_s_bslot = nullptr;
+    SmallSlot* d_s_cslot = nullptr;
+    int32_t* d_s_nvidx = nullptr;
+    int32_t* d_s_nvslot = nullptr;
+    double* d_s_init = nullptr;
+    double* d_s_state = nullptr;    // [2 M + 2 N] the state the last launch stopped in
     int multisweep = 1;             // resident one-launch path: 0 never, 1 where it was measured faster (one block, or
                                     // >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
-    int32_t last_path = 0;          // 0 per-sweep launches, 2 one launch for the whole run (resident tiles)
+    int32_t last_path = 0;          // 0 per-sweep launches, 2 one launch for the whole run (resident tiles), 3 one workgroup, state in LDS (bn_small.hip)
     int32_t last_flow = 0;          // ... in its dataflow form
     Ctl* h_ctl = nullptr;  // pinned
     Ctl* h_ctl_dev = nullptr;  // the same memory as the device sees it
@@ -242,6 +256,7 @@ static void free_engine(bn_engine* e) {
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_flat_tab, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync, e->d_flow, e->d_nbr,
+                        e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl};
         for (void* p : ptrs)
@@ -428,6 +443,26 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             }
             if (const char* f = std::getenv("BN_RESIDENT_FLOW")) e->flow = std::atoi(f) != 0;
             if (const char* z = std::getenv("BN_POLL_SLEEP")) e->poll_sleep = std::max(0, std::min(std::atoi(z), 64));
+        }
+        if (p.nranks == 1 && !std::getenv("BN_NO_SMALL")) {  // one-workgroup path for small networks (bn_small.hpp)
+            build_small_plan(p, e->small);
+            if (e->small.ok) {
+                const SmallPlan& sp = e->small;
+                int r2;
+                if ((r2 = upload(&e->d_s_ent, sp.ent, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_cpt, sp.ent_cpt, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_term, sp.term, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_clist, sp.clist, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_bslot, sp.bslot, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_cslot, sp.cslot, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_nvidx, sp.nv_idx, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_nvslot, sp.nv_slot, e->stream))) return r2;
+                if ((r2 = upload(&e->d_s_init, sp.npi_init, e->stream))) return r2;
+                if ((r2 = dalloc(&e->d_s_state, size_t(2 * sp.M + 2 * sp.N)))) return r2;
+                if (int code = prepare_bp_small())
+                    return fail(BN_ERR_HIP, std::string("bp_small attribute: ") + hipGetErrorString(hipError_t(code)));
+                e->small_ok = true;
+            }
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -763,6 +798,62 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
     return BN_OK;
 }
 
+static SmallArgs small_args_of(bn_engine* e, const BpBuffers& b, double eps, int32_t max_sweeps, int32_t begin, Ctl* host_ctl) {
+    const SmallPlan& sp = e->small;
+    SmallArgs a{};
+    a.b = b; a.eps = eps; a.max_sweeps = max_sweeps; a.sweep_begin = begin; a.budget = kSmallBudget; a.run_id = e->run_id;
+    a.host_ctl = host_ctl;
+    a.n = sp.n; a.N = sp.N; a.M = sp.M; a.S = sp.S; a.T = sp.T; a.TT = sp.TT; a.CL = sp.CL;
+    a.re = sp.re; a.rb = sp.rb; a.rc = sp.rc; a.mmax = sp.mmax;
+    a.ent = e->d_s_ent; a.ent_cpt = e->d_s_cpt; a.term = e->d_s_term; a.clist = e->d_s_clist;
+    a.bslot = e->d_s_bslot; a.cslot = e->d_s_cslot; a.nv_idx = e->d_s_nvidx; a.nv_slot = e->d_s_nvslot; a.npi_init = e->d_s_init;
+    a.state = e->d_s_state; a.sets = SetStrides{}; a.state_stride = 0;
+    return a;
+}
+
+// Small networks: ONE workgroup runs every iteration with the state in LDS and writes the beliefs (bn_small.hip).
+static int run_small(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to) {
+    hipStream_t s = e->stream;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    int32_t begin = 0, launches = 0;
+    float ms = 0.f;
+    double dev_ticks = 0.0;
+    for (;;) {
+        const SmallArgs a = small_args_of(e, buffers_of(e), eps, max_sweeps, begin, e->h_ctl_dev);
+        if (e->timing) {
+            int rc = ensure_events(e, 2);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->events[0], s));
+        }
+        if (int code = launch_bp_small(a, e->small.waves, e->small.lds_bytes, 1, s))
+            return fail(BN_ERR_HIP, std::string("bp_small launch failed: ") + hipGetErrorString(hipError_t(code)));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
+        if (copy_to)  // a launch that stops on its budget copies an intermediate state; the last one counts
+            HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        e->ev_upload_pending = false;
+        ++launches;
+        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_HIP, "bp_small kernel did not report (stale control block)");
+        if (e->timing) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
+            ms += t;
+        }
+        dev_ticks += double(e->h_ctl->t_last - e->h_ctl->t_first);
+        if (e->h_ctl->done != 0) break;
+        begin = e->h_ctl->n_sweeps;
+    }
+    const bool rows_were_clean = e->rows_clean;  // this path never touches the residual slots
+    note_run_result(e);
+    e->rows_clean = rows_were_clean;
+    e->last_path = 3;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = ms;
+    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
+    return BN_OK;
+}
+
 static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
                            double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -786,6 +877,13 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     // per-sweep launches with one RCCL all-gather per sweep)
     const bool try_resident = e->plan.nranks > 1 ? (e->shard_flow_ok && e->multisweep != 0)
                                                  : (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays)));
+    if (e->small_ok && e->multisweep != 0) {
+        if ((rc = run_small(e, eps, max_sweeps, copy_to))) return rc;
+        e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+        if (residual_out) *residual_out = e->last_ctl.last_res;
+        return BN_OK;
+    }
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
         rc = run_resident(e, eps, max_sweeps, copy_to);
@@ -888,9 +986,12 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
     if (std::strcmp(name, "resident_waves") == 0) return e->resident_waves;
     if (std::strcmp(name, "resident_aborts") == 0) return e->resident_aborts;
+    if (std::strcmp(name, "small_eligible") == 0) return e->small_ok ? 1 : 0;
+    if (std::strcmp(name, "small_waves") == 0) return e->small_ok ? e->small.waves : 0;
+    if (std::strcmp(name, "small_lds_bytes") == 0) return e->small_ok ? int64_t(e->small.lds_bytes) : 0;
     return fail(BN_ERR_ARG, std::string("unknown info ") + name);
 }
-// 0 per-sweep launches, 2 resident tiles (bn_resident.hip)
+// 0 per-sweep launches, 2 resident tiles (bn_resident.hip), 3 one workgroup with the state in LDS (bn_small.hip)
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;
@@ -1600,6 +1701,12 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
     if (!e || !pi_msg_out || !lambda_msg_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
     ON_DEVICE(e);
+    if (e->last_path == 3) {  // bn_small.hip leaves the messages in CSR edge order
+        const size_t bytes = sizeof(double) * size_t(e->small.M);
+        HIPCHK(hipMemcpy(pi_msg_out, e->d_s_state, bytes, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lambda_msg_out, e->d_s_state + e->small.M, bytes, hipMemcpyDeviceToHost));
+        return BN_OK;
+    }
     std::vector<double> rec(std::max<int64_t>(e->plan.rec_total_doubles, 1));
     HIPCHK(hipMemcpy(rec.data(), e->d_rec[e->last_ctl.n_sweeps & 1], sizeof(double) * e->plan.rec_total_doubles,
                      hipMemcpyDeviceToHost));

@@ -1,0 +1,86 @@
+// bn_small.hpp -- SMALL networks (ALARM-sized: what the reference's users actually load): the whole run in ONE
+// workgroup with the complete state -- messages, node vectors, CPT, staged terms -- in the CU's LDS (bn_small.hip).
+//
+// The tile layout (bn_plan.hpp) gives a wavefront to a handful of nodes; on a network of 37 nodes that is 21
+// wavefronts of ~2 000 instructions each, one launch per iteration: ~10 us per sweep whatever the size.  Here the
+// work items are the things the reference's loops enumerate (belief_propagation.hpp):
+//   entry item        one CPT entry (node v, parent assignment a, own state i): its term of pi(v)[i] (:174-200) and
+//                     of the lambda-message to every parent (:240-266), written to the PLACE the term has in its
+//                     accumulator's summation order;
+//   accumulator item  one element of pi(v) or of a lambda-message: adds its run of staged terms front to back (the
+//                     reference's order: own state outer, assignment inner), normalises (:298-311), residual;
+//   product item      one element of lambda(v) (:220-238) or of a pi-message (:202-218): product over the children
+//                     in ascending order, normalise, residual.
+// The elements of one vector sit in adjacent lanes of one wavefront (normalisation never crosses a wave); two
+// workgroup barriers per iteration; the stop decision (:147) is taken by every wave from the same LDS words.
+// Sums and products keep the reference's order for ANY table size: results equal the CPU restatement bit for bit
+// (the reference itself is order-nondeterministic only in the product over >= 3 parents, :253 -- ascending here).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bn_device.hpp"
+
+namespace bnmi {
+
+constexpr int kSmallMaxWaves = 16;       // one workgroup of up to 1024 threads
+constexpr int kSmallMaxRounds = 4;       // items of one kind a thread handles at most
+constexpr int kSmallMaxParents = 8;
+constexpr int kSmallLdsBytes = 150 * 1024;
+constexpr int kSmallBudget = 1 << 16;    // iterations per launch
+
+struct SmallSlot { uint32_t x, y, z, w; };  // one accumulator / product item (bn_small_plan.cpp: encodings)
+struct SmallEntry { uint32_t x, y; };       // one entry item
+
+// Host plan + its device image.
+struct SmallPlan {
+    bool ok = false;
+    std::string why;                 // not eligible because ...
+    int32_t n = 0, N = 0, M = 0;     // nodes, sum of arities, sum over edges of the parent's arity
+    int32_t S = 0, T = 0, TT = 0;    // CPT entries, staged terms (doubles), per-entry parent terms (u32)
+    int32_t CL = 0;                  // child-list entries
+    int32_t waves = 0, re = 0, rb = 0, rc = 0;  // workgroup size, rounds per item kind
+    int32_t mmax = 0;
+    size_t lds_bytes = 0;
+    std::vector<SmallEntry> ent;     // [re][threads]
+    std::vector<double> ent_cpt;     // [re][threads]
+    std::vector<uint32_t> term;      // [TT]   gather index (pi-message element) | staging place of the lambda term << 16
+    std::vector<uint16_t> clist;     // [CL]   first element of the child's lambda-message
+    std::vector<SmallSlot> bslot;    // [rb][threads] accumulator items
+    std::vector<SmallSlot> cslot;    // [rc][threads] product items
+    std::vector<int32_t> nv_idx;     // [N]    where the evidence kernel puts element x of a node vector (doubles into node0)
+    std::vector<int32_t> nv_slot;    // [N]    the node's evidence-mark slot
+    std::vector<double> npi_init;    // [N]    initial pi(v): the CPT row of a root, else 1.0 (:38-64)
+};
+
+// Builds the plan from the model held in `p` (single rank).  sp.ok false + sp.why when the network does not fit.
+void build_small_plan(const Plan& p, SmallPlan& sp);
+
+struct SmallArgs {
+    BpBuffers b;              // evidence marks, node0 (evidence vectors), beliefs, res_hist
+    double eps;
+    int32_t max_sweeps, sweep_begin, budget;
+    uint32_t run_id;
+    Ctl* host_ctl;
+    int32_t n, N, M, S, T, TT, CL, re, rb, rc, mmax;
+    const SmallEntry* ent;
+    const double* ent_cpt;
+    const uint32_t* term;
+    const uint16_t* clist;
+    const SmallSlot* bslot;
+    const SmallSlot* cslot;
+    const int32_t* nv_idx;
+    const int32_t* nv_slot;
+    const double* npi_init;
+    double* state;            // [2M + 2N] pi-messages, lambda-messages (CSR edge order), pi(v), lambda(v): the state the
+                              // launch stopped in (bn_bp_messages; a run longer than one launch's budget continues from it)
+    // several evidence sets, one workgroup each (blockIdx.x): strides of the per-set arrays
+    SetStrides sets;
+    int64_t state_stride;
+};
+int prepare_bp_small();  // once per device, before the first launch
+int launch_bp_small(const SmallArgs& a, int waves, size_t lds_bytes, int n_sets, void* stream);
+
+}  // namespace bnmi
