@@ -55,6 +55,9 @@ SYMBOLS = [
     ("bn_peer_export", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     ("bn_peer_import", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), i64p, ctypes.c_int32]),
     ("bn_layout_flow", ctypes.c_int, [ctypes.c_void_p, i32p, ctypes.POINTER(ctypes.c_uint32)]),
+    ("bn_small_plan_get", ctypes.c_int, [ctypes.c_void_p, i32p, ctypes.POINTER(ctypes.c_uint32), f64p, ctypes.POINTER(ctypes.c_uint32),
+                                         ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                         f64p]),
     ("bn_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_comm_init", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("bn_destroy", None, [ctypes.c_void_p]),

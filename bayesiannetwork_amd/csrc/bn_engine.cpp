@@ -192,6 +192,7 @@ struct bn_engine {
         ResidentSync* d_sync = nullptr;  // resident path: [min(cap_sets, kResidentMaxSets)]
         bool sync_dirty = true;
         uint32_t gen_base = 0;
+        double* d_s_state = nullptr;  // one-workgroup path (bn_small.hip): [cap_sets][2 M + 2 N]
         Ctl* d_ctl = nullptr;       // per-sweep launches: one control block per set
         bool rows_clean = true;     // ... and every set's residual slots are zero
         int32_t predicted_sweeps = 0;
@@ -212,6 +213,7 @@ struct bn_engine {
     // small networks: the whole run in ONE workgroup with the state in LDS (bn_small.hip)
     SmallPlan small;
     bool small_ok = false;
+    int small_mode = 1;             // option "small": 0 never, 1 where it was measured faster than the other paths, 2 wherever eligible
     SmallEntry* d_s_ent = nullptr;
     double* d_s_cpt = nullptr;
     uint32_t* d_s_term = nullptr;
@@ -258,7 +260,7 @@ static void free_engine(bn_engine* e) {
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync, e->d_flow, e->d_nbr,
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
-                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl};
+                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -323,6 +325,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     e->stats.algorithmic_bytes_per_sweep = p.algorithmic_bytes;
     e->stats.layout_bytes_per_sweep = p.layout_bytes;
     e->stats.messages_per_sweep = p.messages_per_sweep;
+    if (p.nranks == 1 && !std::getenv("BN_NO_SMALL")) {  // one-workgroup path for small networks (bn_small.hpp)
+        try {
+            build_small_plan(p, e->small);
+        } catch (const std::bad_alloc&) {
+            delete e;
+            return fail(BN_ERR_ALLOC, "out of host memory while building the small-network plan");
+        }
+    }
     if (desc->device == BN_DEVICE_HOST_ONLY) {
         *out = e;
         return BN_OK;
@@ -444,8 +454,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             if (const char* f = std::getenv("BN_RESIDENT_FLOW")) e->flow = std::atoi(f) != 0;
             if (const char* z = std::getenv("BN_POLL_SLEEP")) e->poll_sleep = std::max(0, std::min(std::atoi(z), 64));
         }
-        if (p.nranks == 1 && !std::getenv("BN_NO_SMALL")) {  // one-workgroup path for small networks (bn_small.hpp)
-            build_small_plan(p, e->small);
+        {
             if (e->small.ok) {
                 const SmallPlan& sp = e->small;
                 int r2;
@@ -877,7 +886,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     // per-sweep launches with one RCCL all-gather per sweep)
     const bool try_resident = e->plan.nranks > 1 ? (e->shard_flow_ok && e->multisweep != 0)
                                                  : (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays)));
-    if (e->small_ok && e->multisweep != 0) {
+    if (e->small_ok && e->multisweep != 0 && e->small_mode != 0) {
         if ((rc = run_small(e, eps, max_sweeps, copy_to))) return rc;
         e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
@@ -969,6 +978,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "overlap") == 0) { e->overlap = value != 0; return BN_OK; }
     if (std::strcmp(name, "beliefs_direct") == 0) { e->beliefs_direct = value != 0; return BN_OK; }
     if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
+    if (std::strcmp(name, "small") == 0) { e->small_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "poll_sleep") == 0) { e->poll_sleep = std::max(0, std::min(value, 64)); return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     return fail(BN_ERR_ARG, std::string("unknown option ") + name);
@@ -986,9 +996,9 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
     if (std::strcmp(name, "resident_waves") == 0) return e->resident_waves;
     if (std::strcmp(name, "resident_aborts") == 0) return e->resident_aborts;
-    if (std::strcmp(name, "small_eligible") == 0) return e->small_ok ? 1 : 0;
-    if (std::strcmp(name, "small_waves") == 0) return e->small_ok ? e->small.waves : 0;
-    if (std::strcmp(name, "small_lds_bytes") == 0) return e->small_ok ? int64_t(e->small.lds_bytes) : 0;
+    if (std::strcmp(name, "small_eligible") == 0) return e->small.ok ? 1 : 0;
+    if (std::strcmp(name, "small_waves") == 0) return e->small.ok ? e->small.waves : 0;
+    if (std::strcmp(name, "small_lds_bytes") == 0) return e->small.ok ? int64_t(e->small.lds_bytes) : 0;
     return fail(BN_ERR_ARG, std::string("unknown info ") + name);
 }
 // 0 per-sweep launches, 2 resident tiles (bn_resident.hip), 3 one workgroup with the state in LDS (bn_small.hip)
@@ -1007,7 +1017,7 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     if (n_sets <= bt.cap_sets) return BN_OK;
     const Plan& p = e->plan;
     HIPCHK(hipStreamSynchronize(e->stream));
-    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl};
+    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl, bt.d_s_state};
     for (void* q : old)
         if (q) (void)hipFree(q);
     if (bt.h_ctl) (void)hipHostFree(bt.h_ctl);
@@ -1025,6 +1035,7 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     if ((r = dalloc(&bt.d_res_hist, B * size_t(e->res_cap)))) return r;
     if ((r = dalloc(&bt.d_sync, std::min<size_t>(B, kResidentMaxSets)))) return r;
     if ((r = dalloc(&bt.d_ctl, B))) return r;
+    if (e->small_ok && (r = dalloc(&bt.d_s_state, B * size_t(2 * e->small.M + 2 * e->small.N)))) return r;
     HIPCHK(hipMemsetAsync(bt.d_ctl, 0, sizeof(Ctl) * B, e->stream));  // done_run = 0: no run is marked done
     HIPCHK(hipMemsetAsync(bt.d_frozen, 0, B * size_t(std::max(p.n_slots, 1)), e->stream));
     HIPCHK(hipMemsetAsync(bt.d_beliefs, 0, std::max<size_t>(B * p.node_off[p.n], 1) * 8, e->stream));
@@ -1060,6 +1071,7 @@ static BpBuffers batch_buffers_of(bn_engine* e, int32_t q) {
 static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) {
     rc = BN_OK;
     if (!e->plan.latency_rules_applied || e->plan.nranks > 1 || n_sets < 2) return nullptr;
+    if (e->small_ok && e->small_mode != 0 && e->multisweep != 0) return nullptr;  // one workgroup per set (bn_small.hip): the layout plays no part
     if (!e->dense) {
         const Plan& p = e->plan;
         bn_model_desc d;
@@ -1293,6 +1305,49 @@ static int run_batch_launches(bn_engine* e, double eps, int32_t max_sweeps) {
     return BN_OK;
 }
 
+// Small networks: one workgroup per evidence set, all sets in ONE launch, each set stopping by itself (bn_small.hip).
+static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
+    bn_engine::Batch& bt = e->batch;
+    const Plan& p = e->plan;
+    hipStream_t s = e->stream;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    const int32_t B = bt.n_sets;
+    const SetStrides st{p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap};
+    const int64_t state_stride = 2 * int64_t(e->small.M) + 2 * int64_t(e->small.N);
+    SmallArgs a = small_args_of(e, batch_buffers_of(e, 0), eps, max_sweeps, 0, bt.h_ctl_dev);
+    a.state = bt.d_s_state; a.sets = st; a.state_stride = state_stride;
+    if (int code = launch_bp_small(a, e->small.waves, e->small.lds_bytes, B, s))
+        return fail(BN_ERR_HIP, std::string("bp_small launch failed: ") + hipGetErrorString(hipError_t(code)));
+    HIPCHK(hipStreamSynchronize(s));
+    int32_t launches = 1;
+    for (int32_t q = 0; q < B; ++q) {
+        if (bt.h_ctl[q].run_id != e->run_id) return fail(BN_ERR_HIP, "bp_small kernel did not report (stale control block)");
+        while (bt.h_ctl[q].done == 0) {  // a set that used up the launch's budget of iterations goes on by itself
+            SmallArgs c = small_args_of(e, batch_buffers_of(e, q), eps, max_sweeps, bt.h_ctl[q].n_sweeps, bt.h_ctl_dev + q);
+            c.state = bt.d_s_state + size_t(q) * state_stride;
+            if (int code = launch_bp_small(c, e->small.waves, e->small.lds_bytes, 1, s))
+                return fail(BN_ERR_HIP, std::string("bp_small launch failed: ") + hipGetErrorString(hipError_t(code)));
+            HIPCHK(hipStreamSynchronize(s));
+            ++launches;
+        }
+    }
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int32_t q = 0; q < B; ++q) {
+        bt.sweeps[q] = bt.h_ctl[q].n_sweeps;
+        bt.residual[q] = bt.h_ctl[q].last_res;
+        t0 = std::min(t0, bt.h_ctl[q].t_first);
+        t1 = std::max(t1, bt.h_ctl[q].t_last);
+    }
+    bt.predicted_sweeps = *std::max_element(bt.sweeps.begin(), bt.sweeps.end());
+    e->last_path = 3;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = 0.f;
+    e->stats.sweep_devclock_ms = t1 > t0 ? float(double(t1 - t0) * 1e-5) : 0.f;
+    e->stats.sweeps = bt.predicted_sweeps;
+    return BN_OK;
+}
+
 extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->batch_on_dense && e->dense) {
@@ -1319,7 +1374,9 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     constexpr int64_t kResidentBatchMinTiles = 900;
     const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
     const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
-    if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
+    if (e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state) {
+        if ((rc = run_batch_small(e, eps, max_sweeps))) return rc;
+    } else if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
         rc = run_batch_resident(e, eps, max_sweeps);
         if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
@@ -1722,6 +1779,28 @@ extern "C" int bn_bp_last_stats(bn_engine* e, bn_bp_stats* out) {
 }
 
 // ---- layout introspection ---------------------------------------------------------------------
+// The plan of the one-workgroup path (bn_small.hpp; tests emulate the kernel on it).  dims_out[12] = n, N, M, S, T, TT, CL,
+// waves, re, rb, rc, mmax; the arrays (any may be null) are sized from those: ent [re * 64 waves][2], ent_cpt [re * 64 waves],
+// term [TT], clist [CL], bslot / cslot [rb | rc * 64 waves][4], npi_init [N].  BN_ERR_STATE when the network is not eligible.
+extern "C" int bn_small_plan_get(bn_engine* e, int32_t* dims_out, uint32_t* ent, double* ent_cpt, uint32_t* term, uint16_t* clist,
+                                 uint32_t* bslot, uint32_t* cslot, double* npi_init) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    const SmallPlan& sp = e->small;
+    if (!sp.ok) return fail(BN_ERR_STATE, "not eligible for the one-workgroup path: " + (sp.why.empty() ? std::string("disabled") : sp.why));
+    if (dims_out) {
+        const int32_t d[12] = {sp.n, sp.N, sp.M, sp.S, sp.T, sp.TT, sp.CL, sp.waves, sp.re, sp.rb, sp.rc, sp.mmax};
+        std::copy(d, d + 12, dims_out);
+    }
+    if (ent) std::memcpy(ent, sp.ent.data(), sp.ent.size() * sizeof(SmallEntry));
+    if (ent_cpt) std::copy(sp.ent_cpt.begin(), sp.ent_cpt.end(), ent_cpt);
+    if (term) std::copy(sp.term.begin(), sp.term.begin() + sp.TT, term);
+    if (clist) std::copy(sp.clist.begin(), sp.clist.begin() + sp.CL, clist);
+    if (bslot) std::memcpy(bslot, sp.bslot.data(), sp.bslot.size() * sizeof(SmallSlot));
+    if (cslot) std::memcpy(cslot, sp.cslot.data(), sp.cslot.size() * sizeof(SmallSlot));
+    if (npi_init) std::copy(sp.npi_init.begin(), sp.npi_init.end(), npi_init);
+    return BN_OK;
+}
+
 extern "C" int bn_layout_get(bn_engine* e, bn_layout_info* o) {
     if (!e || !o) return fail(BN_ERR_ARG, "null argument");
     const Plan& p = e->plan;

@@ -3,9 +3,9 @@
 //
 // One iteration of the reference's while(true) loop (:75-148) =
 //   phase 1   entry items: the terms of pi(v) (:174-200) and of the lambda-messages (:240-266) -> staging;
-//             product items: lambda(v) (:220-238) and the pi-messages (:202-218) from the OLD state, normalised, stored;
 //   barrier
 //   phase 2   accumulator items: each adds its run of staged terms front to back, normalises (:298-311), stores;
+//             product items: lambda(v) (:220-238) and the pi-messages (:202-218) from the OLD state, normalised, stored;
 //             maximum_difference (:105-131) of the wave -> LDS;
 //   barrier   every wave reads the same words and takes the same stop decision (:147, strict <).
 // Old and new state are the two halves of double buffers (the reference's new_* maps, :135-143).
@@ -95,15 +95,19 @@ __device__ __forceinline__ int wave_imax(int x) {
 // One CPT entry: cpt * pi-messages in ascending parent order (:174-200) and, per target parent, (lambda(v)[i] * cpt)
 // * the OTHER parents' pi-messages in ascending order (:240-266).  MM = the wave's largest parent count: the loops are
 // unrolled to it, a lane with fewer parents multiplies by 1.0 (x * 1.0 == x).
-template <int MM>
-__device__ __forceinline__ void small_entry(const SmallLds& L, const double* pi_cur, const double* nlam_cur, SmallEntry h, double c) {
+template <int MM, bool REG>
+__device__ __forceinline__ void small_entry(const SmallLds& L, const double* pi_cur, const double* nlam_cur, SmallEntry h, double c,
+                                            const uint32_t (&treg)[4]) {
     if (((h.y >> 24) & 1u) == 0) return;
     const int m = int((h.y >> 16) & 0xffu), tbase = int(h.y & 0xffffu);
     const double li = nlam_cur[h.x & 0xffffu];
     uint32_t tw[MM > 0 ? MM : 1];
     double pj[MM > 0 ? MM : 1];
 #pragma unroll
-    for (int j = 0; j < MM; ++j) tw[j] = j < m ? L.term[tbase + j] : 0u;
+    for (int j = 0; j < MM; ++j) {
+        if (REG && MM <= 4) tw[j] = treg[j < 4 ? j : 0];  // (an entry's parent terms never change: kept in registers when they fit)
+        else tw[j] = j < m ? L.term[tbase + j] : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < MM; ++j) {
         const double x = pi_cur[tw[j] & 0xffffu];
@@ -124,15 +128,17 @@ __device__ __forceinline__ void small_entry(const SmallLds& L, const double* pi_
     }
 }
 
-__device__ __forceinline__ void small_entry_any(int mm, const SmallLds& L, const double* pi_cur, const double* nlam_cur, SmallEntry h, double c) {
+template <bool REG>
+__device__ __forceinline__ void small_entry_any(int mm, const SmallLds& L, const double* pi_cur, const double* nlam_cur, SmallEntry h, double c,
+                                                const uint32_t (&treg)[4]) {
     switch (mm) {
-        case 0: return small_entry<0>(L, pi_cur, nlam_cur, h, c);
-        case 1: return small_entry<1>(L, pi_cur, nlam_cur, h, c);
-        case 2: return small_entry<2>(L, pi_cur, nlam_cur, h, c);
-        case 3: return small_entry<3>(L, pi_cur, nlam_cur, h, c);
-        case 4: return small_entry<4>(L, pi_cur, nlam_cur, h, c);
-        case 5: case 6: return small_entry<6>(L, pi_cur, nlam_cur, h, c);
-        default: return small_entry<8>(L, pi_cur, nlam_cur, h, c);
+        case 0: return small_entry<0, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 1: return small_entry<1, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 2: return small_entry<2, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 3: return small_entry<3, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 4: return small_entry<4, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 5: case 6: return small_entry<6, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        default: return small_entry<8, REG>(L, pi_cur, nlam_cur, h, c, treg);
     }
 }
 
@@ -174,7 +180,9 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
     SmallEntry ent[ROUNDS];
     double ecpt[ROUNDS];
     SmallSlot bs[ROUNDS], cs[ROUNDS];
-    int e_mm[ROUNDS], b_rmax[ROUNDS], b_rmin[ROUNDS], b_kmax[ROUNDS], c_dmax[ROUNDS], c_kmax[ROUNDS];
+    constexpr bool kTermsInRegs = ROUNDS == 1;
+    uint32_t treg[ROUNDS][4];
+    int e_mm[ROUNDS], b_rmax[ROUNDS], b_kmax[ROUNDS], c_dmax[ROUNDS], c_kmax[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         ent[r] = SmallEntry{0u, 0u}; ecpt[r] = 0.0;
@@ -182,10 +190,13 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
         if (r < a.re) { ent[r] = a.ent[r * nt + tid]; ecpt[r] = a.ent_cpt[r * nt + tid]; }
         if (r < a.rb) bs[r] = a.bslot[r * nt + tid];
         if (r < a.rc) cs[r] = a.cslot[r * nt + tid];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            treg[r][j] = 0u;
+            if (kTermsInRegs && ((ent[r].y >> 24) & 1u) && j < int((ent[r].y >> 16) & 0xffu)) treg[r][j] = a.term[(ent[r].y & 0xffffu) + j];
+        }
         e_mm[r] = wave_imax(((ent[r].y >> 24) & 1u) ? int((ent[r].y >> 16) & 0xffu) : 0);
         b_rmax[r] = wave_imax(int(bs[r].x >> 16));
-        b_rmin[r] = -wave_imax(bs[r].z != 0 ? -int(bs[r].x >> 16) : -(1 << 20));  // shortest run among the wave's items
-        if (b_rmin[r] > b_rmax[r]) b_rmin[r] = b_rmax[r];                          // (a wave without items)
         b_kmax[r] = wave_imax(bs[r].z != 0 ? int((bs[r].y >> 16) & 0xffu) : 0);
         c_dmax[r] = wave_imax(int(cs[r].x >> 16));
         c_kmax[r] = wave_imax((cs[r].z & 0xffu) != 0 ? int((cs[r].y >> 16) & 0xffu) : 0);
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
     // ---- tables and initial state (:33-73) into LDS
     for (int t = tid; t < a.TT; t += nt) L.term[t] = a.term[t];
     for (int t = tid; t < a.CL; t += nt) L.clist[t] = a.clist[t];
+    for (int t = tid; t < a.T; t += nt) L.stg[t] = 0.0;  // the padding of the runs stays zero for the whole run
     int s = a.sweep_begin;
     {
         const int c0 = s & 1;
@@ -230,12 +242,50 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
         double* nlam_new = L.nlam + (cur ^ 1) * a.N;
         double wres = 0.0;
         SMALL_STAMP(0);
-        // ---- phase 1a: entry items
+        // ---- phase 1: entry items
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r)
-            if (r < a.re) small_entry_any(e_mm[r], L, pi_cur, nlam_cur, ent[r], ecpt[r]);
+            if (r < a.re) small_entry_any<kTermsInRegs>(e_mm[r], L, pi_cur, nlam_cur, ent[r], ecpt[r], treg[r]);
         SMALL_STAMP(1);
-        // ---- phase 1b: product items (old state only)
+        __syncthreads();
+        SMALL_STAMP(2);
+        // ---- phase 2a: accumulator items
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r >= a.rb) break;
+            const SmallSlot q = bs[r];
+            const int kind = int(q.z & 0xffu);
+            const bool on = kind != 0;
+            const int base = int(q.x & 0xffffu);
+            const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
+            // what the stores behind the sum need of the old state is requested before it
+            const double old = kind == 1 ? npi_cur[out_idx] : lam_cur[out_idx];
+            const bool frozen = L.frz[out_idx] != 0;
+            // The run is added strictly front to back (the reference's order): the chain of dependent additions IS the
+            // phase's critical path.  Runs are padded with zeros to the wave's common length (bn_small_plan.cpp), so a step
+            // is four loads at immediate offsets -- issued one step ahead -- and four additions, nothing else.
+            const double* ptr = L.stg + base;
+            const int n8 = b_rmax[r];
+            double acc = 0.0;
+            double x0 = ptr[0], x1 = ptr[1], x2 = ptr[2], x3 = ptr[3];
+            for (int r0 = 0; r0 < n8; r0 += 8) {
+                const double y0 = ptr[r0 + 4], y1 = ptr[r0 + 5], y2 = ptr[r0 + 6], y3 = ptr[r0 + 7];
+                acc += x0; acc += x1; acc += x2; acc += x3;
+                x0 = ptr[r0 + 8]; x1 = ptr[r0 + 9]; x2 = ptr[r0 + 10]; x3 = ptr[r0 + 11];
+                acc += y0; acc += y1; acc += y2; acc += y3;
+            }
+            if (r == 0) SMALL_STAMP(6);
+            double* buf = kind == 1 ? npi_new : lam_new;
+            const double val = small_normalize(buf, on, out_idx, k, at, acc, b_kmax[r]);
+            if (kind == 1) npi_new[out_idx] = frozen ? old : val;  // evidence nodes are never updated (:177)
+            if (kind == 2) {
+                lam_new[out_idx] = val;
+                wres = res_acc(wres, fabs(val - old));
+            }
+        }
+        SMALL_STAMP(7);
+        // ---- phase 2b: product items.  They read the old state only, so they could run on either side of the barrier: here,
+        // because the plan gives the waves with the longest runs the cheapest products (bn_small_plan.cpp).
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             if (r >= a.rc) break;
@@ -244,6 +294,8 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
             const bool on = kind != 0;
             const int cl = int(q.x & 0xffffu), deg = int(q.x >> 16);
             const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
+            const double old = kind == 4 ? pi_cur[out_idx] : nlam_cur[out_idx];
+            const bool frozen = L.frz[out_idx] != 0;
             // lambda(v): from 1.0 (:220-238); pi-message: from pi(v)[i] (:202-218); children in ascending order
             double val = kind == 4 ? npi_cur[q.w & 0xffffu] : 1.0;
             for (int x0 = 0; x0 < c_dmax[r]; x0 += 4) {
@@ -259,65 +311,13 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
             }
             double* buf = kind == 4 ? pi_new : nlam_new;
             val = small_normalize(buf, on, out_idx, k, at, val, c_kmax[r]);
-            if (kind == 3) nlam_new[out_idx] = L.frz[out_idx] ? nlam_cur[out_idx] : val;  // evidence nodes are never updated (:177)
+            if (kind == 3) nlam_new[out_idx] = frozen ? old : val;  // evidence nodes are never updated (:177)
             if (kind == 4) {
                 pi_new[out_idx] = val;
-                wres = res_acc(wres, fabs(val - pi_cur[out_idx]));
+                wres = res_acc(wres, fabs(val - old));
             }
         }
-        SMALL_STAMP(2);
-        __syncthreads();
         SMALL_STAMP(3);
-        // ---- phase 2: accumulator items
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            if (r >= a.rb) break;
-            const SmallSlot q = bs[r];
-            const int kind = int(q.z & 0xffu);
-            const bool on = kind != 0;
-            const int base = int(q.x & 0xffffu), len = int(q.x >> 16);
-            const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
-            // The run is added strictly front to back (the reference's order), so the chain of dependent additions IS the
-            // phase's critical path: the loads run one step of eight ahead of it, and while every lane of the wave still
-            // has eight terms left a step is loads + additions only.
-            const double* run = L.stg + base;  // term r of this element at run[r * k]
-            double acc = 0.0;
-            const int rmin = b_rmin[r];
-            int r0 = 0;
-            if (rmin >= 8) {
-                double x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = run[u * k];
-                for (; r0 + 16 <= rmin; r0 += 8) {
-                    double y[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) y[u] = run[(r0 + 8 + u) * k];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += x[u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = y[u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += x[u];
-                r0 += 8;
-            }
-            for (; r0 < b_rmax[r]; r0 += 8) {
-                double x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = run[r0 + u < len ? (r0 + u) * k : 0];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += r0 + u < len ? x[u] : 0.0;  // + 0.0 past the end: a sum started from +0.0 is never -0.0
-            }
-            if (r == 0) SMALL_STAMP(6);
-            double* buf = kind == 1 ? npi_new : lam_new;
-            const double val = small_normalize(buf, on, out_idx, k, at, acc, b_kmax[r]);
-            if (r == 0) SMALL_STAMP(7);
-            if (kind == 1) npi_new[out_idx] = L.frz[out_idx] ? npi_cur[out_idx] : val;
-            if (kind == 2) {
-                lam_new[out_idx] = val;
-                wres = res_acc(wres, fabs(val - lam_cur[out_idx]));
-            }
-        }
         // maximum_difference (:105-131): the wave's maximum (bit patterns of non-negative doubles order like the values)
         // -> the wave's LDS word; after the barrier every wave reduces the same 16 words
         const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));

@@ -5,16 +5,25 @@
 //   SmallEntry.y  = first parent term in `term` | number of parents << 16 | valid << 24
 //   term[t]       = element of parent j's pi-message the entry's assignment selects | place of the term of the
 //                   lambda-message to parent j << 16
-//   accumulator slot: x = first staged term of the run (term r at + r * arity) | run length << 16
+//   accumulator slot: x = first staged term of the element's run | padded run length << 16 (a multiple of 8, the same for
+//                         every lane of the wave)
 //                     y = output element | arity of the vector << 16 | lane of the vector's first element << 24
 //                     z = kind (0 none, 1 pi(v), 2 lambda-message)
 //   product slot:     x = first child-list entry | number of children << 16
 //                     y = as above
 //                     z = kind (3 lambda(v), 4 pi-message) | ordinal of the child the message goes to << 8 (0xffff: none)
 //                     w = element of pi(u) the message starts from
+//
+// Staging layout.  Every accumulator element owns a contiguous run: its terms in the reference's summation order, padded
+// with zeros (written once, never touched again: x + 0.0 == x for the partial sums that occur) to the longest run of
+// its wave's row rounded up to 8 -- so every lane of a wave adds the same number of terms with the same instructions,
+// reads with immediate offsets, no selects.  The runs of a vector's elements start an ODD number of words apart: the
+// lanes of a wave then hit different LDS banks (runs a power of two apart cost 16- to 32-way conflicts on every read
+// of the dependent chain).
 #include "bn_small.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace bnmi {
 
@@ -25,35 +34,32 @@ struct Vec {           // one output vector = k adjacent lanes of one wavefront
     int k;
     SmallSlot first;   // slot of element 0; element i adds `step` to x / y / w
     uint32_t step_x, step_y, step_w;
+    int node, which;   // accumulators: the node and -1 (pi(v)) or the in-edge slot j (lambda-message)
+    int row, lane0;    // where the packing put it
 };
 
-// Vectors, most expensive first, into rows of 64 lanes (no vector straddles a row); row r -> wave r % waves, round r / waves.
-int pack_rows(std::vector<Vec>& vecs, std::vector<std::vector<SmallSlot>>& rows) {
+// Vectors, most expensive first, into rows of 64 lanes (no vector straddles a row).  `alike`: a row also ends where the
+// cost falls below 3/4 of its first vector's -- the lanes of a wave run in lockstep to the longest run among them --
+// unless that needs more than `max_rows` rows.  Returns the number of rows.
+int pack_rows(std::vector<Vec>& vecs, bool alike, int max_rows) {
     std::stable_sort(vecs.begin(), vecs.end(), [](const Vec& a, const Vec& b) { return a.cost > b.cost; });
-    rows.clear();
-    int used = kWave;
-    for (const Vec& v : vecs) {
-        if (used + v.k > kWave) { rows.emplace_back(kWave, SmallSlot{0, 0, 0, 0}); used = 0; }
-        for (int i = 0; i < v.k; ++i) {
-            SmallSlot s = v.first;
-            s.x += v.step_x * uint32_t(i);
-            s.y += v.step_y * uint32_t(i);
-            s.w += v.step_w * uint32_t(i);
-            s.y |= uint32_t(used) << 24;  // lane of element 0
-            rows.back()[used + i] = s;
+    int nrows = 0;
+    for (int pass = alike ? 0 : 1; pass < 2; ++pass) {
+        nrows = 0;
+        int used = kWave, first_cost = 0;
+        for (Vec& v : vecs) {
+            if (used + v.k > kWave || (pass == 0 && 4 * v.cost < 3 * first_cost)) {
+                ++nrows;
+                used = 0;
+                first_cost = v.cost;
+            }
+            v.row = nrows - 1;
+            v.lane0 = used;
+            used += v.k;
         }
-        used += v.k;
+        if (nrows <= max_rows) break;
     }
-    return int(rows.size());
-}
-
-void rows_to_slots(const std::vector<std::vector<SmallSlot>>& rows, int waves, int rounds, std::vector<SmallSlot>& out) {
-    const int nt = waves * kWave;
-    out.assign(size_t(rounds) * nt, SmallSlot{0, 0, 0, 0});
-    for (size_t r = 0; r < rows.size(); ++r) {
-        const int wave = int(r % waves), round = int(r / waves);
-        for (int l = 0; l < kWave; ++l) out[size_t(round) * nt + wave * kWave + l] = rows[r][l];
-    }
+    return nrows;
 }
 
 }  // namespace
@@ -67,9 +73,7 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     if (n <= 0) return no("empty");
     const int64_t N = p.node_off[n], M = p.msg_off[E], S = p.cpt_off[n];
     if (n > 60000 || N > 60000 || M > 60000 || S > int64_t(kSmallMaxRounds) * kSmallMaxWaves * kWave) return no("too large");
-    // per node: parents, rows, staging base
     std::vector<int> m(n), rows(n);
-    std::vector<int64_t> stg_base(n + 1, 0);
     int mmax = 0;
     int64_t TT = 0;
     for (int v = 0; v < n; ++v) {
@@ -80,13 +84,11 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
         int64_t r = 1;
         for (int j = 0; j < m[v]; ++j) r *= p.k[p.in_idx[p.in_ptr[v] + j]];
         if (r * p.k[v] != p.cpt_off[v + 1] - p.cpt_off[v]) return no("CPT size mismatch");
-        if (r > 60000) return no("too large");
+        if (r * p.k[v] > 30000) return no("too large");
         rows[v] = int(r);
-        stg_base[v + 1] = stg_base[v] + (p.cpt_off[v + 1] - p.cpt_off[v]) * (m[v] + 1);
         TT += (p.cpt_off[v + 1] - p.cpt_off[v]) * m[v];
     }
-    const int64_t T = stg_base[n];
-    if (T > 65535 || TT > 65535) return no("too many staged terms");
+    if (TT > 65535) return no("too many staged terms");
     // children ascending (the order graph_t::out_edges produces): CSR over parents
     std::vector<int> cptr(n + 1, 0);
     for (int64_t e = 0; e < E; ++e) cptr[p.in_idx[e] + 1]++;
@@ -103,43 +105,104 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     std::vector<Vec> bv, cv;
     for (int v = 0; v < n; ++v) {
         const int kv = p.k[v], Sv = kv * rows[v];
-        const uint32_t base = uint32_t(stg_base[v]);
-        // pi(v): element i sums the `rows` terms at base + r * kv + i, r = 0 .. rows - 1 (term r of the k elements of a
-        // vector side by side: adjacent lanes read adjacent words -- runs laid end to end put the lanes of a wave a run
-        // length apart, 16- to 32-way LDS bank conflicts on every read of the dependent chain)
-        bv.push_back(Vec{rows[v], kv, SmallSlot{base | uint32_t(rows[v]) << 16, uint32_t(p.node_off[v]) | uint32_t(kv) << 16, 1u, 0u},
-                         1u, 1u, 0u});
+        // pi(v): element i sums `rows` terms (the run's place is filled in once the rows are known)
+        bv.push_back(Vec{rows[v], kv, SmallSlot{0u, uint32_t(p.node_off[v]) | uint32_t(kv) << 16, 1u, 0u}, 0u, 1u, 0u, v, -1, 0, 0});
         for (int j = 0; j < m[v]; ++j) {
             const int e = p.in_ptr[v] + j, kp = p.k[p.in_idx[e]];
-            const int run = Sv / kp;  // kv * rows / kp terms per element of the lambda-message to parent j
-            bv.push_back(Vec{run, kp, SmallSlot{(base + uint32_t(Sv) * uint32_t(1 + j)) | uint32_t(run) << 16,
-                                                uint32_t(p.msg_off[e]) | uint32_t(kp) << 16, 2u, 0u},
-                             1u, 1u, 0u});
+            // kv * rows / kp terms per element of the lambda-message to parent j
+            bv.push_back(Vec{Sv / kp, kp, SmallSlot{0u, uint32_t(p.msg_off[e]) | uint32_t(kp) << 16, 2u, 0u}, 0u, 1u, 0u, v, j, 0, 0});
         }
         const int deg = cptr[v + 1] - cptr[v];
         // lambda(v): product over all children
         cv.push_back(Vec{deg, kv, SmallSlot{uint32_t(cptr[v]) | uint32_t(deg) << 16, uint32_t(p.node_off[v]) | uint32_t(kv) << 16,
                                             3u | 0xffffu << 8, 0u},
-                         0u, 1u, 0u});
+                         0u, 1u, 0u, v, -1, 0, 0});
         for (int x = 0; x < deg; ++x) {  // pi-message to child x: pi(v) times the OTHER children's lambda-messages
             const int e = cedge[cptr[v] + x];
             cv.push_back(Vec{deg, kv, SmallSlot{uint32_t(cptr[v]) | uint32_t(deg) << 16, uint32_t(p.msg_off[e]) | uint32_t(kv) << 16,
                                                 4u | uint32_t(x) << 8, uint32_t(p.node_off[v])},
-                             0u, 1u, 1u});
+                             0u, 1u, 1u, v, x, 0, 0});
         }
     }
-    std::vector<std::vector<SmallSlot>> brows, crows;
-    const int nb = pack_rows(bv, brows), nc = pack_rows(cv, crows);
+    const int nb = pack_rows(bv, true, kSmallMaxWaves), nc = pack_rows(cv, false, 0);
     const int ne_rows = int((S + kWave - 1) / kWave);
     // as many waves as the largest kind needs for one round, at most 16
     int waves = std::max(1, std::min(kSmallMaxWaves, std::max(ne_rows, std::max(nb, nc))));
+    if (const char* w = std::getenv("BN_SMALL_WAVES")) waves = std::max(1, std::min(kSmallMaxWaves, std::atoi(w)));  // experiments
     sp.re = (ne_rows + waves - 1) / waves;
     sp.rb = (nb + waves - 1) / waves;
     sp.rc = (nc + waves - 1) / waves;
     if (sp.re > kSmallMaxRounds || sp.rb > kSmallMaxRounds || sp.rc > kSmallMaxRounds) return no("too many work items");
     const int nt = waves * kWave;
-    rows_to_slots(brows, waves, sp.rb, sp.bslot);
-    rows_to_slots(crows, waves, sp.rc, sp.cslot);
+
+    // ---- staging: per row the padded run length, per vector its base and the (odd) distance between its elements' runs
+    std::vector<int> row_len(nb, 0), row_pad(nb, 0);
+    for (const Vec& v : bv) row_len[v.row] = std::max(row_len[v.row], v.cost);
+    for (int r = 0; r < nb; ++r) row_pad[r] = (row_len[r] + 7) & ~7;
+    std::vector<std::vector<uint32_t>> vec_base(n), vec_stride(n);  // [node][1 + j]
+    for (int v = 0; v < n; ++v) { vec_base[v].assign(m[v] + 1, 0u); vec_stride[v].assign(m[v] + 1, 0u); }
+    int64_t T = 0;
+    for (Vec& v : bv) {
+        const uint32_t stride = uint32_t(row_pad[v.row]) | 1u;
+        if (T + int64_t(v.k) * stride > 65000) return no("too many staged terms");
+        vec_base[v.node][v.which + 1] = uint32_t(T);
+        vec_stride[v.node][v.which + 1] = stride;
+        v.first.x = uint32_t(T) | uint32_t(row_pad[v.row]) << 16;
+        v.step_x = stride;
+        T += int64_t(v.k) * stride;
+    }
+    T += 16;  // the loads run one step ahead of the additions: up to 12 words past the last run's end
+    if (T < N) T = N;  // (the final beliefs are normalised in this array)
+
+    // ---- rows -> waves.  Accumulator rows and product rows run between the same two barriers, and wave w issues on
+    // SIMD w % 4: each row, most expensive first, goes to the wave whose SIMD has the least work so far (then the wave
+    // with the least), so that the wave with the longest chain of dependent additions shares its SIMD with little else.
+    struct RowJob { double cost; int kind, row; };
+    std::vector<RowJob> jobs;
+    for (int r = 0; r < nb; ++r) jobs.push_back(RowJob{12.0 + 1.0 * row_pad[r], 0, r});
+    {
+        std::vector<int> dmax(nc, 0);
+        for (const Vec& v : cv) dmax[v.row] = std::max(dmax[v.row], v.cost);
+        for (int r = 0; r < nc; ++r) jobs.push_back(RowJob{14.0 + 4.0 * ((dmax[r] + 3) & ~3), 1, r});
+    }
+    std::stable_sort(jobs.begin(), jobs.end(), [](const RowJob& a, const RowJob& b) { return a.cost > b.cost; });
+    std::vector<double> simd_load(4, 0.0), wave_load(waves, 0.0);
+    std::vector<int> used_b(waves, 0), used_c(waves, 0);
+    std::vector<int> b_wave(nb, 0), b_round(nb, 0), c_wave(nc, 0), c_round(nc, 0);
+    for (const RowJob& j : jobs) {
+        int best = -1;
+        for (int w = 0; w < waves; ++w) {
+            if ((j.kind == 0 ? used_b[w] : used_c[w]) >= (j.kind == 0 ? sp.rb : sp.rc)) continue;
+            if (best < 0 || simd_load[w & 3] < simd_load[best & 3] ||
+                (simd_load[w & 3] == simd_load[best & 3] && wave_load[w] < wave_load[best]))
+                best = w;
+        }
+        if (j.kind == 0) { b_wave[j.row] = best; b_round[j.row] = used_b[best]++; }
+        else { c_wave[j.row] = best; c_round[j.row] = used_c[best]++; }
+        simd_load[best & 3] += j.cost;
+        wave_load[best] += j.cost;
+    }
+    auto place = [&](const std::vector<Vec>& vecs, const std::vector<int>& wave_of, const std::vector<int>& round_of, int rounds,
+                     std::vector<SmallSlot>& out) {
+        out.assign(size_t(rounds) * nt, SmallSlot{0, 0, 0, 0});
+        for (const Vec& v : vecs)
+            for (int i = 0; i < v.k; ++i) {
+                SmallSlot s = v.first;
+                s.x += v.step_x * uint32_t(i);
+                s.y += v.step_y * uint32_t(i);
+                s.w += v.step_w * uint32_t(i);
+                s.y |= uint32_t(v.lane0) << 24;  // lane of element 0
+                out[size_t(round_of[v.row]) * nt + wave_of[v.row] * kWave + v.lane0 + i] = s;
+            }
+    };
+    place(bv, b_wave, b_round, sp.rb, sp.bslot);
+    place(cv, c_wave, c_round, sp.rc, sp.cslot);
+    // every lane of a wave adds the same number of terms: the lanes without an item carry the row's length too
+    for (int r = 0; r < nb; ++r)
+        for (int l = 0; l < kWave; ++l) {
+            SmallSlot& s = sp.bslot[size_t(b_round[r]) * nt + b_wave[r] * kWave + l];
+            if (s.z == 0) s.x = uint32_t(row_pad[r]) << 16;
+        }
 
     // ---- entry items: nodes ordered by parent count (a wave's entries then need the same unrolled code), entries
     // of a node in table order
@@ -151,23 +214,24 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     sp.term.assign(std::max<int64_t>(TT, 1), 0);
     int64_t slot = 0, tnext = 0;
     for (int v : order) {
-        const int kv = p.k[v], Sv = kv * rows[v], e0 = p.in_ptr[v];
-        const uint32_t base = uint32_t(stg_base[v]);
+        const int kv = p.k[v], e0 = p.in_ptr[v];
         int kp[kSmallMaxParents], digit[kSmallMaxParents];
         for (int j = 0; j < m[v]; ++j) { kp[j] = p.k[p.in_idx[e0 + j]]; digit[j] = 0; }
         for (int a = 0; a < rows[v]; ++a) {  // odometer over the parents, last parent fastest (belief_propagation.hpp:269-295)
             for (int i = 0; i < kv; ++i) {
-                const size_t at = size_t(slot / nt) * nt + size_t(slot % nt);  // round-major: slot s -> round s / nt, thread s % nt
-                sp.ent[at] = SmallEntry{uint32_t(p.node_off[v] + i) | (base + uint32_t(a * kv + i)) << 16,
-                                        uint32_t(tnext) | uint32_t(m[v]) << 16 | 1u << 24};
-                sp.ent_cpt[at] = p.cpt_flat[p.cpt_off[v] + int64_t(a) * kv + i];
+                // pi(v)[i] adds its terms in assignment order (:174-200): term a of element i
+                const uint32_t place_pi = vec_base[v][0] + uint32_t(i) * vec_stride[v][0] + uint32_t(a);
+                sp.ent[slot] = SmallEntry{uint32_t(p.node_off[v] + i) | place_pi << 16, uint32_t(tnext) | uint32_t(m[v]) << 16 | 1u << 24};
+                sp.ent_cpt[slot] = p.cpt_flat[p.cpt_off[v] + int64_t(a) * kv + i];
                 for (int jt = 0; jt < m[v]; ++jt) {
-                    // the assignment without digit jt, same radix order: its rank among the assignments that share digit jt
+                    // element digit[jt] of the lambda-message to parent jt adds own state outer, assignment inner (:240-266):
+                    // this entry is term i * (rows / kp) + (rank of the assignment among those that share digit jt)
                     int rest = 0;
                     for (int j = 0; j < m[v]; ++j)
                         if (j != jt) rest = rest * kp[j] + digit[j];
-                    const uint32_t place = base + uint32_t(Sv) * uint32_t(1 + jt) + uint32_t((i * (rows[v] / kp[jt]) + rest) * kp[jt] + digit[jt]);
-                    sp.term[tnext++] = uint32_t(p.msg_off[e0 + jt] + digit[jt]) | place << 16;
+                    const uint32_t place_lam = vec_base[v][1 + jt] + uint32_t(digit[jt]) * vec_stride[v][1 + jt] +
+                                               uint32_t(i * (rows[v] / kp[jt]) + rest);
+                    sp.term[tnext++] = uint32_t(p.msg_off[e0 + jt] + digit[jt]) | place_lam << 16;
                 }
                 ++slot;
             }

@@ -164,7 +164,8 @@ class Engine:
         _lib.check(_lib.lib().bn_set_option(self._h, name.encode(), int(value)))
 
     def info(self, name: str) -> int:
-        """bn_get_info: "flow_eligible", "last_flow", "nbr_max", "resident_eligible", "resident_blocks", "resident_aborts"."""
+        """bn_get_info: "flow_eligible", "last_flow", "nbr_max", "resident_eligible", "resident_blocks", "resident_aborts",
+        "small_eligible", "small_waves", "small_lds_bytes" ..."""
         return _lib.check(_lib.lib().bn_get_info(self._h, name.encode()))
 
     def last_path(self) -> int:
@@ -204,6 +205,32 @@ class Engine:
         pub = np.zeros(max(nt, 1), dtype=np.uint32)
         _lib.check(_lib.lib().bn_layout_flow(self._h, _p(nbr, ctypes.c_int32), pub.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
         return nbr[:nt * ch * 64].reshape(nt, ch * 64) if ch else np.zeros((nt, 0), np.int32), pub[:nt]
+
+    def small_plan(self):
+        """The plan of the one-workgroup path for small networks (bn_small_plan_get), or None when the network is not
+        eligible: dict(n, N, M, S, T, TT, CL, waves, re, rb, rc, mmax, ent [re*nt, 2], ent_cpt, term, clist,
+        bslot [rb*nt, 4], cslot [rc*nt, 4], npi_init)."""
+        L = _lib.lib()
+        if not self.info("small_eligible"):
+            return None
+        dims = np.zeros(12, dtype=np.int32)
+        _lib.check(L.bn_small_plan_get(self._h, _p(dims, ctypes.c_int32), None, None, None, None, None, None, None))
+        names = ["n", "N", "M", "S", "T", "TT", "CL", "waves", "re", "rb", "rc", "mmax"]
+        d = {k: int(v) for k, v in zip(names, dims)}
+        nt = 64 * d["waves"]
+        u32 = ctypes.POINTER(ctypes.c_uint32)
+        ent = np.zeros((d["re"] * nt, 2), dtype=np.uint32)
+        ent_cpt = np.zeros(d["re"] * nt, dtype=np.float64)
+        term = np.zeros(max(d["TT"], 1), dtype=np.uint32)
+        clist = np.zeros(max(d["CL"], 1), dtype=np.uint16)
+        bslot = np.zeros((d["rb"] * nt, 4), dtype=np.uint32)
+        cslot = np.zeros((d["rc"] * nt, 4), dtype=np.uint32)
+        init = np.zeros(d["N"], dtype=np.float64)
+        _lib.check(L.bn_small_plan_get(self._h, None, ent.ctypes.data_as(u32), _p(ent_cpt, ctypes.c_double), term.ctypes.data_as(u32),
+                                       clist.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), bslot.ctypes.data_as(u32),
+                                       cslot.ctypes.data_as(u32), _p(init, ctypes.c_double)))
+        d.update(ent=ent, ent_cpt=ent_cpt, term=term[:d["TT"]], clist=clist[:d["CL"]], bslot=bslot, cslot=cslot, npi_init=init)
+        return d
 
     # single steps (tests): begin / sweep without exchange / finish
     def step_begin(self):

@@ -189,18 +189,25 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   and a grid barrier per sweep.  0 = always one launch per sweep; 1 = that path where it was measured
  *   faster (one-block networks, networks of >= 600 tiles); 2 = wherever eligible (tests, experiments).
  *   Results are bit-identical on either path.
+ * "small" 0/1/2 -- SMALL networks (the state fits one CU's LDS: up to a few thousand CPT entries, <= 8 parents per
+ *   node -- ALARM-sized): the whole run in ONE workgroup with messages, node vectors and staged terms in LDS, one
+ *   work item per CPT entry / per message element instead of one wavefront per handful of nodes; sums and
+ *   products in the reference's order for any table size, i.e. bit-identical to the CPU restatement.  0 = never,
+ *   1 = where eligible (default; "multisweep" 0 also turns it off), 2 = the same.  bn_bp_run_batch on such a network
+ *   runs one workgroup per evidence set, all sets in one launch.  bn_get_info "small_eligible".
  * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 0):
  *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
  *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.
  * "poll_sleep" n -- dataflow form: pause between two polls of a waiting tile, n x 512 cycles (default 2).
  * "beliefs_direct" 1/0 -- bn_bp_run_view: the kernels write the marginals straight into the engine's mapped host
  *   buffer (default 1, outputs up to 16 MB) instead of a copy command queued behind the run.
- * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run). */
+ * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run), 3 = one workgroup, state in LDS
+ *   (small networks, one launch per run). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
  * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
- * exchange set up), "n_boundary_nodes"; unknown name: BN_ERR_ARG. */
+ * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes"; unknown name: BN_ERR_ARG. */
 int64_t bn_get_info(bn_engine *eng, const char *name);
 
 /* Single steps of a run (tests / diagnostics): begin, one sweep (without exchange), finish.
@@ -301,6 +308,13 @@ int bn_layout_node_tiles(bn_engine *eng, int32_t *tiles_out);
 int bn_layout_flow(bn_engine *eng, int32_t *nbr_out, uint32_t *pub_out);
 int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_t *lanes_per_node,
                     int32_t *variant, int32_t *n_nodes);
+/* The plan of the one-workgroup path for small networks (csrc/bn_small.hpp; tests emulate the kernel on it):
+ * dims_out[12] = n, N (sum of arities), M (sum over edges of the parent's arity), S (CPT entries), T (staged terms),
+ * TT (parent terms), CL (child-list entries), waves, re, rb, rc (rounds per item kind), mmax; the arrays (any may be
+ * NULL) are sized from those: ent [re * 64 * waves][2], ent_cpt [re * 64 * waves], term [TT], clist [CL],
+ * bslot [rb * 64 * waves][4], cslot [rc * 64 * waves][4], npi_init [N].  BN_ERR_STATE: the network is not eligible. */
+int bn_small_plan_get(bn_engine *eng, int32_t *dims_out, uint32_t *ent, double *ent_cpt, uint32_t *term, uint16_t *clist,
+                      uint32_t *bslot, uint32_t *cslot, double *npi_init);
 
 #ifdef __cplusplus
 }

@@ -29,11 +29,12 @@ with Engine(g) as e:
     buf = np.zeros((16, 8), dtype=np.uint64)
     assert L.bn_debug_small_clock(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     st = buf[: e.info("small_waves")].astype(np.int64)
-    names = ["entry items", "product items", "barrier 1", "accumulator items + residual", "barrier 2 + decision"]
-    d = np.stack([st[:, i + 1] - st[:, i] for i in range(5)], axis=1) * 10
+    names = ["entry items", "barrier 1", "run sums (round 0)", "normalise, stores", "product items", "residual", "barrier 2 + decision"]
+    order = [0, 1, 2, 6, 7, 3, 4, 5]
+    d = np.stack([st[:, order[i + 1]] - st[:, order[i]] for i in range(7)], axis=1) * 10
     print(f"{name}: {g.n} nodes, {e.info('small_waves')} waves, {r['sweeps']} sweeps, {e.bp_stats()['sweep_devclock_ms'] * 1e3 / r['sweeps']:.2f} us per sweep; iteration 3, ns: median / max over waves")
     for i, nm in enumerate(names):
         print(f"  {nm:30s} {np.median(d[:, i]):7.0f} {d[:, i].max():7.0f}")
     print("  per wave (ns):")
     for w in range(st.shape[0]):
-        print("   ", w, d[w].tolist(), " phase 2 split: run sums", (st[w, 6] - st[w, 3]) * 10, "normalise", (st[w, 7] - st[w, 6]) * 10, "stores + residual", (st[w, 4] - st[w, 7]) * 10)
+        print("   ", w, d[w].tolist())

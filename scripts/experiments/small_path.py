@@ -27,8 +27,9 @@ for name, mod in nets:
         ev = synth.random_evidence(mod, 0.05, seed=3)
         e.bp_set_evidence(ev)
         res = {}
-        for form in (0, 1):
-            e.set_option("multisweep", form)
+        for form in (0, 1, 2):  # 0: one launch per sweep; 1: one workgroup, state in LDS (bn_small.hip); 2: what else multisweep = 2 gives
+            e.set_option("multisweep", 0 if form == 0 else 2)
+            e.set_option("small", 2 if form == 1 else 0)
             for _ in range(3):
                 r = e.bp_run_device(1e-6)
             reps = 50

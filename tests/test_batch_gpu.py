@@ -44,6 +44,7 @@ def test_batch_equals_single_runs_grids(Engine, rows, cols, k, n_sets, eps):
     # different amounts of evidence -> the sets converge on different sweeps
     evs = [synth.random_evidence(g, f, seed=11 + q) for q, f in enumerate([0.0, 0.01, 0.05, 0.2, 0.002, 0.1, 0.0, 0.03][:n_sets])]
     with Engine(g) as eng:
+        eng.set_option("small", 0)   # (the 7 x 5 grid would otherwise take the one-workgroup path: tests/test_small_gpu.py)
         sweeps = _check_batch(eng, evs, eps, want_path=2)
         if rows >= 40:
             assert len(set(sweeps)) > 1, "the case should exercise sets leaving the rotation at different sweeps"
@@ -89,8 +90,11 @@ def test_batch_on_per_sweep_launches_every_tile_variant(Engine):
     alarm, _ = load_dsc(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alarm_shaped.dsc"))
     evs = [synth.random_evidence(alarm, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.2] * 4)]
     with Engine(alarm) as eng:                                      # any-arity tiles only: the light kernel, 16 sets
+        eng.set_option("small", 0)
         _check_batch(eng, evs, 1e-9, want_path=0)
         _check_batch(eng, evs[:5], 1e-3, max_sweeps=2, want_path=0)
+        eng.set_option("small", 1)                                   # by default: one workgroup per set (bn_small.hip), same bits
+        _check_batch(eng, evs, 1e-9, want_path=3)
 
 
 def test_batch_more_sets_than_one_resident_launch_walks(Engine):

@@ -257,7 +257,7 @@ def test_hot_kernels_do_not_spill(bnlib):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "bayesiannetwork_amd", "csrc")
-    need = ["bn_sweep_u.o", "bn_resident.o", "bn_lw_kernels.o"]
+    need = ["bn_sweep_u.o", "bn_resident.o", "bn_lw_kernels.o", "bn_small.o"]
     if not all(os.path.exists(os.path.join(csrc, f)) for f in need) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("object files / llvm tools not on this box")
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
@@ -294,6 +294,79 @@ def test_hot_kernels_do_not_spill(bnlib):
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
     for name, r in kr.kernel_resources(os.path.join(csrc, "bn_lw_kernels.o")).items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+    small = kr.kernel_resources(os.path.join(csrc, "bn_small.o"))   # one workgroup per run, state in LDS (small networks)
+    assert len(small) == 3
+    for name, r in small.items():
+        rounds = int(re.search(r"bp_small_kernel<(\d+)>", name).group(1))
+        assert r["vgpr"] <= 128, (name, r)           # 16 waves per workgroup
+        if rounds <= 2:                               # what ALARM-sized networks run
+            assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+        else:
+            assert r["spill"] <= 16, (name, r)
+
+
+def test_small_plan_emulated_equals_oracle(bnlib, oracle_mod):
+    """The plan of the one-workgroup path (bn_small_plan.cpp), executed item by item on the CPU (tests/small_emulator.py),
+    reproduces the oracle bit for bit -- beliefs, sweep count, residual history, final messages -- on networks with up to
+    four parents per node, mixed arities, hard and soft evidence.  (On the GPU: tests/test_small_gpu.py.)"""
+    import os
+    import small_emulator
+    from bayesiannetwork_amd import Evidence, _lib, engine, synth
+    from bayesiannetwork_amd.dsc import load_dsc
+    alarm, _ = load_dsc(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alarm_shaped.dsc"))
+    mixed = synth.random_dag(24, 4, 12, [2, 3, 4, 3, 2, 5], seed=12)
+    soft = Evidence.from_dict(mixed, {3: np.full(int(mixed.k[3]), 1.0 / mixed.k[3]), 7: np.eye(int(mixed.k[7]))[0]})
+    cases = [(synth.pearl(), Evidence.none(), 1e-9, 0), (alarm, synth.random_evidence(alarm, 0.1, seed=2), 1e-6, 0),
+             (mixed, soft, 1e-6, 0), (mixed, synth.random_evidence(mixed, 0.1, seed=1), 1e-12, 7)]
+    for g, ev, eps, cap in cases:
+        with engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+            plan = e.small_plan()
+        assert plan is not None
+        got = small_emulator.emulate(plan, g, ev, eps, cap)
+        want = oracle_mod.bp_run(g, ev, eps, cap, dump_msgs=True)
+        assert got["sweeps"] == want["sweeps"]
+        assert np.array_equal(got["beliefs"], want["beliefs"]) and np.array_equal(got["residuals"], want["residuals"])
+        assert np.array_equal(got["pi_msg"], want["pi_msg"]) and np.array_equal(got["lambda_msg"], want["lambda_msg"])
+
+
+def test_small_plan_invariants(bnlib):
+    """Every output element has exactly one work item; a vector's elements sit in adjacent lanes of one wave; no two
+    staged terms share a place and none lands in the zero padding of another run; the lanes of a wave add equally
+    many terms; networks that do not fit say why."""
+    from bayesiannetwork_amd import _lib, engine, synth
+    g = synth.random_dag(40, 3, 16, [2, 3, 4, 3, 2, 4], seed=21)
+    with engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        p = e.small_plan()
+        assert p is not None and e.info("small_lds_bytes") <= 150 * 1024 and 1 <= p["waves"] <= 16
+    nt = 64 * p["waves"]
+    N, M = int(g.k.sum()), int(g.k[g.in_idx].sum())
+    assert (p["N"], p["M"], p["S"]) == (N, M, len(g.cpt))
+    for slots, kinds, sizes in ((p["bslot"], (1, 2), (N, M)), (p["cslot"], (3, 4), (N, M))):
+        for kind, size in zip(kinds, sizes):
+            sel = slots[(slots[:, 2] & 0xff) == kind]
+            assert sorted((sel[:, 1] & 0xffff).tolist()) == list(range(size))   # each element exactly once
+        on = np.nonzero(slots[:, 2] & 0xff)[0]
+        lane, first, k = on % 64, slots[on, 1] >> 24, (slots[on, 1] >> 16) & 0xff
+        assert (lane >= first).all() and (first + k <= 64).all()                # a vector never leaves its wave
+        at = lane - first
+        assert ((slots[on - at, 1] & 0xffff) + at == (slots[on, 1] & 0xffff)).all()  # ... and its elements are adjacent
+    b = p["bslot"].reshape(-1, 64, 4)
+    assert all(len(set((row[:, 0] >> 16).tolist())) == 1 and (row[0, 0] >> 16) % 8 == 0 for row in b)
+    # staged terms: one place each, inside the run of the accumulator that adds them
+    valid = ((p["ent"][:, 1] >> 24) & 1) == 1
+    assert valid.sum() == p["S"]
+    places = (p["ent"][valid, 0] >> 16).tolist() + (p["term"] >> 16).tolist()
+    assert len(set(places)) == len(places) and max(places) < p["T"]
+    covered = set()
+    for s_ in p["bslot"][(p["bslot"][:, 2] & 0xff) != 0]:
+        base, n8 = int(s_[0]) & 0xffff, int(s_[0]) >> 16
+        covered.update(range(base, base + n8))
+    assert set(places) <= covered
+    # not eligible: too large, more than 8 parents
+    with engine.Engine(synth.grid(64, 64, 4, seed=1), device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("small_eligible") == 0 and e.small_plan() is None
+    with engine.Engine(synth.random_dag(30, 9, 30, 2, seed=3), device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("small_eligible") == 0
 
 
 def test_peer_blobs_and_flow_tables_host_only(bnlib):

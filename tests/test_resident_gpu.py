@@ -27,6 +27,7 @@ def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
     lags an iteration: the state the run ends in must be the one BEFORE the speculative iteration), 0 = grid barrier
     per sweep.  One-block grids run the same LDS-only code under either setting."""
     r0, res0, (pi0, lam0) = want
+    eng.set_option("small", 0)   # (the smallest networks here would otherwise take the one-workgroup path: tests/test_small_gpu.py)
     eng.set_option("multisweep", 2)
     for flow in (1, 0):
         eng.set_option("flow", flow)
