@@ -886,7 +886,15 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     // per-sweep launches with one RCCL all-gather per sweep)
     const bool try_resident = e->plan.nranks > 1 ? (e->shard_flow_ok && e->multisweep != 0)
                                                  : (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays)));
-    if (e->small_ok && e->multisweep != 0 && e->small_mode != 0) {
+    // The one-workgroup path is taken wherever the network fits, except where the resident-tile kernel runs the network in ONE
+    // block and was measured faster (scripts/experiments/small_vs_resident.py, us per sweep small / resident): chains and trees
+    // (one parent per node) beyond ~128 nodes or one round of entry items (200-node chain, k = 4: 5.2 / 2.8; 100 nodes: 2.9 /
+    // 2.6), and networks that need two rounds of accumulator or product items (16 x 16 grid, k = 2: 4.3 / 3.5).  With two
+    // parents per node the tile kernel's 64-entry contraction costs more than the items (8 x 8 grid, k = 4: 4.2 / 5.1;
+    // 40-node DAG: 2.6 / 6.4).  "small" 2 = wherever eligible.
+    const bool small_pays = !(e->resident_ok && e->grid_resident == 1) ||
+                            (e->small.rb == 1 && e->small.rc == 1 && (e->small.mmax >= 2 || (e->small.re == 1 && e->small.n <= 128)));
+    if (e->small_ok && e->multisweep != 0 && (e->small_mode == 2 || (e->small_mode == 1 && small_pays))) {
         if ((rc = run_small(e, eps, max_sweeps, copy_to))) return rc;
         e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
@@ -1084,6 +1092,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
         if (rc) { e->dense = nullptr; return nullptr; }
     }
     e->dense->multisweep = e->multisweep;
+    e->dense->small_mode = e->small_mode;
     e->dense->timing = e->timing;
     return e->dense;
 }
@@ -1352,6 +1361,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->batch_on_dense && e->dense) {
         e->dense->multisweep = e->multisweep;
+        e->dense->small_mode = e->small_mode;
         const int rc = bn_bp_run_batch_device(e->dense, eps, max_sweeps, sweeps_out, residual_out);
         if (rc == BN_OK) adopt_batch_outcome(e);
         return rc;

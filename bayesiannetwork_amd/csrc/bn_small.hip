@@ -265,15 +265,17 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
             // phase's critical path.  Runs are padded with zeros to the wave's common length (bn_small_plan.cpp), so a step
             // is four loads at immediate offsets -- issued one step ahead -- and four additions, nothing else.
             const double* ptr = L.stg + base;
-            const int n8 = b_rmax[r];
+            const int n4 = b_rmax[r];  // a multiple of 4
             double acc = 0.0;
             double x0 = ptr[0], x1 = ptr[1], x2 = ptr[2], x3 = ptr[3];
-            for (int r0 = 0; r0 < n8; r0 += 8) {
+            int r0 = 0;
+            for (; r0 + 8 <= n4; r0 += 8) {
                 const double y0 = ptr[r0 + 4], y1 = ptr[r0 + 5], y2 = ptr[r0 + 6], y3 = ptr[r0 + 7];
                 acc += x0; acc += x1; acc += x2; acc += x3;
                 x0 = ptr[r0 + 8]; x1 = ptr[r0 + 9]; x2 = ptr[r0 + 10]; x3 = ptr[r0 + 11];
                 acc += y0; acc += y1; acc += y2; acc += y3;
             }
+            if (r0 < n4) { acc += x0; acc += x1; acc += x2; acc += x3; }  // an odd number of steps: the last four are loaded already
             if (r == 0) SMALL_STAMP(6);
             double* buf = kind == 1 ? npi_new : lam_new;
             const double val = small_normalize(buf, on, out_idx, k, at, acc, b_kmax[r]);

@@ -5,7 +5,7 @@
 //   SmallEntry.y  = first parent term in `term` | number of parents << 16 | valid << 24
 //   term[t]       = element of parent j's pi-message the entry's assignment selects | place of the term of the
 //                   lambda-message to parent j << 16
-//   accumulator slot: x = first staged term of the element's run | padded run length << 16 (a multiple of 8, the same for
+//   accumulator slot: x = first staged term of the element's run | padded run length << 16 (a multiple of 4, the same for
 //                         every lane of the wave)
 //                     y = output element | arity of the vector << 16 | lane of the vector's first element << 24
 //                     z = kind (0 none, 1 pi(v), 2 lambda-message)
@@ -16,7 +16,7 @@
 //
 // Staging layout.  Every accumulator element owns a contiguous run: its terms in the reference's summation order, padded
 // with zeros (written once, never touched again: x + 0.0 == x for the partial sums that occur) to the longest run of
-// its wave's row rounded up to 8 -- so every lane of a wave adds the same number of terms with the same instructions,
+// its wave's row rounded up to 4 -- so every lane of a wave adds the same number of terms with the same instructions,
 // reads with immediate offsets, no selects.  The runs of a vector's elements start an ODD number of words apart: the
 // lanes of a wave then hit different LDS banks (runs a power of two apart cost 16- to 32-way conflicts on every read
 // of the dependent chain).
@@ -138,7 +138,7 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     // ---- staging: per row the padded run length, per vector its base and the (odd) distance between its elements' runs
     std::vector<int> row_len(nb, 0), row_pad(nb, 0);
     for (const Vec& v : bv) row_len[v.row] = std::max(row_len[v.row], v.cost);
-    for (int r = 0; r < nb; ++r) row_pad[r] = (row_len[r] + 7) & ~7;
+    for (int r = 0; r < nb; ++r) row_pad[r] = (row_len[r] + 3) & ~3;
     std::vector<std::vector<uint32_t>> vec_base(n), vec_stride(n);  // [node][1 + j]
     for (int v = 0; v < n; ++v) { vec_base[v].assign(m[v] + 1, 0u); vec_stride[v].assign(m[v] + 1, 0u); }
     int64_t T = 0;

@@ -193,8 +193,10 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   node -- ALARM-sized): the whole run in ONE workgroup with messages, node vectors and staged terms in LDS, one
  *   work item per CPT entry / per message element instead of one wavefront per handful of nodes; sums and
  *   products in the reference's order for any table size, i.e. bit-identical to the CPU restatement.  0 = never,
- *   1 = where eligible (default; "multisweep" 0 also turns it off), 2 = the same.  bn_bp_run_batch on such a network
- *   runs one workgroup per evidence set, all sets in one launch.  bn_get_info "small_eligible".
+ *   1 = where eligible and not measured slower than the resident tiles (default: everything eligible except long chains /
+ *   trees and two-round networks the resident kernel runs in one block; "multisweep" 0 also turns it off), 2 = wherever
+ *   eligible.  bn_bp_run_batch on such a network runs one workgroup per evidence set, all sets in one launch.
+ *   bn_get_info "small_eligible".
  * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 0):
  *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
  *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.

@@ -351,7 +351,7 @@ def test_small_plan_invariants(bnlib):
         at = lane - first
         assert ((slots[on - at, 1] & 0xffff) + at == (slots[on, 1] & 0xffff)).all()  # ... and its elements are adjacent
     b = p["bslot"].reshape(-1, 64, 4)
-    assert all(len(set((row[:, 0] >> 16).tolist())) == 1 and (row[0, 0] >> 16) % 8 == 0 for row in b)
+    assert all(len(set((row[:, 0] >> 16).tolist())) == 1 and (row[0, 0] >> 16) % 4 == 0 for row in b)
     # staged terms: one place each, inside the run of the accumulator that adds them
     valid = ((p["ent"][:, 1] >> 24) & 1) == 1
     assert valid.sum() == p["S"]
