@@ -8,6 +8,7 @@ One JSON line on stdout (rank 0).  See DESIGN.md "Measurement" for the definitio
 
 The default single-GPU line also carries, as extra keys measured after the timed region,
   value_host_to_host : SURVEY 8(d)'s definition -- evidence upload to beliefs on the host (PCIe inclusive)
+  config1_alarm      : BASELINE configs[0]'s network on the GPU: the ALARM-shaped 37-node net (queries per second)
   config2_dag        : BASELINE configs[1], the 10 k-node random DAG
   config5_lw         : BASELINE configs[4], likelihood weighting on that DAG
   grid2048           : the HBM-resident point (4.2 M nodes, 3.76 GB per sweep)
@@ -198,7 +199,8 @@ def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
 
 
 PATH_KERNEL = {0: "bp_sweep_kernel", 2: "bp_resident_kernel"}
-PATH_NAME = {0: "one launch per sweep", 2: "resident tiles, one launch for the whole run (grid barrier per sweep)"}
+PATH_NAME = {0: "one launch per sweep", 2: "resident tiles, one launch for the whole run (grid barrier per sweep)",
+             3: "one workgroup, state in LDS, one launch for the whole run (small networks)"}
 
 
 def roofline_of(t, label):
@@ -316,6 +318,74 @@ def leg_dag(a, local_rank, torch):
     return out
 
 
+def leg_alarm(a, local_rank, torch):
+    """BASELINE configs[0]'s network (ALARM-shaped: 37 nodes, mixed arities, up to 4 parents -- tests/golden/alarm_shaped.dsc)
+    through the drop-in's host path: what a user of the reference pays per query.  The whole run is one workgroup with
+    the state in LDS (csrc/bn_small.hip); a batch runs one workgroup per evidence set."""
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.dsc import load_dsc
+    from bayesiannetwork_amd.engine import Engine
+    g, _ = load_dsc(os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"))
+    eps = 1e-6
+    evs = [synth.random_evidence(g, 0.1, seed=7 + q) for q in range(8)]
+    out = {"workload": f"ALARM-shaped network: {g.n} nodes, {g.n_edges} edges, {len(g.cpt)} CPT entries, 10 % evidence on different nodes "
+                       f"per query, eps={eps:g}"}
+    with Engine(g, device=local_rank) as eng:
+        steps = 400
+        h2h = time_host_to_host(eng, g, evs, eps, steps)
+        out["path"] = PATH_NAME.get(eng.last_path())
+        dev = 0.0
+        sweeps = 0
+        for i in range(64):
+            r = eng.bp_run_view(evs[i % len(evs)], eps)
+            dev += eng.bp_stats()["sweep_devclock_ms"]
+            sweeps += r["sweeps"]
+        out.update({"value": 1e3 / h2h["ms_per_step"], "unit": "queries/s (evidence in, marginals on the host, one query per call)",
+                    "us_per_query": h2h["ms_per_step"] * 1e3, "sweeps_per_query": h2h["sweeps_per_step"],
+                    "edge_messages_per_s": h2h["value"], "kernel_us_per_sweep": dev / sweeps * 1e3, "host_to_host": h2h})
+        eng.set_option("small", 0)   # the tile kernels on the same network: one launch per sweep
+        eng.set_option("multisweep", 0)
+        tiles = time_host_to_host(eng, g, evs, eps, 100)
+        out["tile_kernels"] = {"us_per_query": tiles["ms_per_step"] * 1e3, "path": PATH_NAME.get(eng.last_path())}
+        eng.set_option("small", 1)
+        eng.set_option("multisweep", 1)
+        batch = {}
+        for B in (16, 64):
+            sets = [synth.random_evidence(g, 0.1, seed=100 + q) for q in range(B)]
+            eng.bp_set_evidence_batch(sets)
+            for _ in range(3):
+                eng.bp_run_batch_device(eps)
+            reps = 50
+            t0 = time.perf_counter()
+            sw = 0
+            for _ in range(reps):
+                sw += int(eng.bp_run_batch_device(eps)["sweeps"].sum())
+            dt = time.perf_counter() - t0
+            batch[f"B{B}"] = {"queries_per_s": B * reps / dt, "us_per_call": dt / reps * 1e6, "us_per_set_sweep": dt / sw * 1e6,
+                              "path": PATH_NAME.get(eng.last_path()), "what": "bn_bp_run_batch_device: evidence staged, marginals left in HBM"}
+        out["batch"] = batch
+    if not a.no_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.0:
+            oracle.bp_run(g, evs[n % len(evs)], eps)
+            n += 1
+        out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} queries of the same cycle through oracle/bp_oracle.c, 1 thread"}
+        ref = None
+        try:
+            if oracle.ref_available():
+                r = oracle.ref_bp(g, evs[0], eps, timeout=60)
+                ref = {"value": 1.0 / r["sweep_s"] if r["sweep_s"] > 0 else None, "unit": "queries/s", "cores": 1, "kind": "reference",
+                       "sample": f"one query, {r['sweeps']} sweeps, bn::inference::belief_propagation unmodified (time of the while(true) loop only)"}
+        except Exception as ex:  # noqa: BLE001 - informational
+            ref = {"error": str(ex)[:200]}
+        if ref:
+            out["cpu_reference"] = ref
+    return out
+
+
 def leg_lw(a, local_rank, torch):
     """BASELINE configs[4] on one GPU: weighted samples/s on the 10 k-node DAG with 1 % evidence."""
     from bayesiannetwork_amd import synth
@@ -426,7 +496,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["grid", "dag", "lw"], default="grid",
+    ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm"], default="grid",
                     help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG; "
                          "lw = configs[4], likelihood weighting on the 10 k-node DAG")
     ap.add_argument("--samples", type=int, default=2000000, help="lw: weighted samples per step")
@@ -472,6 +542,19 @@ def main():
             out["cpu_baseline"] = leg["cpu_baseline"]
         print(json.dumps(out))
         return
+    if a.workload == "alarm":
+        leg = leg_alarm(a, local_rank, torch)
+        out = {"metric": "queries/sec, evidence in -> marginals on the host (ALARM-shaped 37-node network)", "value": leg["value"],
+               "unit": "queries/s", "n_gpus": 1, "steps": leg["host_to_host"]["steps"], "warmup": 2,
+               "ms_per_step": leg["host_to_host"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic", "config": {"workload": leg["workload"], "run_path": leg["path"]},
+               "roofline": {"bound": "latency", "note": "one workgroup on one CU: LDS round trips and chains of dependent fp64 additions in the "
+                                                        "reference's order; neither HBM nor MFMA apply", "kernel_us_per_sweep": leg["kernel_us_per_sweep"]}}
+        for k in ("tile_kernels", "batch", "cpu_baseline", "cpu_reference"):
+            if k in leg:
+                out[k] = leg[k]
+        print(json.dumps(out))
+        return
     if a.workload == "dag":
         g = synth.random_dag(10000, 4, 64, 4, seed=1)
         wname = (f"10 k-node random DAG, <=4 parents, k=4, {g.n_edges} edges (BASELINE.json configs[1])")
@@ -514,7 +597,7 @@ def main():
             out["cpu_reference_small"] = ref
     eng.close()
     if default_run and not a.no_extras:
-        for key, fn in (("batch", leg_batch), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
+        for key, fn in (("batch", leg_batch), ("config1_alarm", leg_alarm), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
             try:
                 out[key] = fn(a, local_rank, torch)
             except Exception as ex:  # noqa: BLE001 - an extra must never lose the headline

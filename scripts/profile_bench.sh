@@ -41,6 +41,9 @@ trace trace_dag10k $B --workload dag --steps 20 --warmup 3
 pmc fetch_dag10k FETCH_SIZE $B --workload dag --steps 5 --warmup 2
 pmc write_dag10k WRITE_SIZE $B --workload dag --steps 5 --warmup 2
 pmc sq_dag10k "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload dag --steps 5 --warmup 2
+# config 0's network on the GPU: the ALARM-shaped net, one workgroup per run (bn_small.hip)
+trace trace_alarm --no-cpu --workload alarm
+pmc sq_alarm "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" --no-cpu --workload alarm
 # config 5: likelihood weighting
 trace trace_lw $B --workload lw --steps 3
 pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
