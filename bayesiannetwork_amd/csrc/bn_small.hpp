@@ -26,6 +26,7 @@
 namespace bnmi {
 
 constexpr int kSmallMaxWaves = 16;       // one workgroup of up to 1024 threads
+constexpr int kSmallPreferredWaves = 12; // ... of which three per SIMD run faster than four (bn_small_plan.cpp)
 constexpr int kSmallMaxRounds = 4;       // items of one kind a thread handles at most
 constexpr int kSmallMaxParents = 8;
 constexpr int kSmallLdsBytes = 150 * 1024;

@@ -124,10 +124,22 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
                              0u, 1u, 1u, v, x, 0, 0});
         }
     }
-    const int nb = pack_rows(bv, true, kSmallMaxWaves), nc = pack_rows(cv, false, 0);
+    int nb = pack_rows(bv, true, kSmallPreferredWaves);
+    const int nc = pack_rows(cv, false, 0);
     const int ne_rows = int((S + kWave - 1) / kWave);
-    // as many waves as the largest kind needs for one round, at most 16
-    int waves = std::max(1, std::min(kSmallMaxWaves, std::max(ne_rows, std::max(nb, nc))));
+    // As many waves as the largest kind needs for one round, but 12 rather than 16: three waves per SIMD instead of four
+    // measured faster even where the entry items then take a second round (27-node network: 58.7 vs 61.5 us per query; ALARM-
+    // shaped: 49 vs 51) -- unless the entry items already take three or more rounds at 16 waves and 12 would add another
+    // (48-node network: 73 vs 65; 8 x 8 grid, k = 4: not eligible at 12).
+    int waves = std::max(1, std::min(kSmallPreferredWaves, std::max(ne_rows, std::max(nb, nc))));
+    {
+        const int re12 = (ne_rows + kSmallPreferredWaves - 1) / kSmallPreferredWaves, re16 = (ne_rows + kSmallMaxWaves - 1) / kSmallMaxWaves;
+        const int rb12 = (nb + kSmallPreferredWaves - 1) / kSmallPreferredWaves, rc12 = (nc + kSmallPreferredWaves - 1) / kSmallPreferredWaves;
+        if ((re12 > re16 && re16 >= 3) || re12 > kSmallMaxRounds || rb12 > kSmallMaxRounds || rc12 > kSmallMaxRounds) {
+            waves = kSmallMaxWaves;
+            nb = pack_rows(bv, true, kSmallMaxWaves);  // (more rows of like runs fit one round now)
+        }
+    }
     if (const char* w = std::getenv("BN_SMALL_WAVES")) waves = std::max(1, std::min(kSmallMaxWaves, std::atoi(w)));  // experiments
     sp.re = (ne_rows + waves - 1) / waves;
     sp.rb = (nb + waves - 1) / waves;
