@@ -245,8 +245,13 @@ def time_host_to_host(eng, g, evs, eps, steps):
     """wall time from evidence upload to beliefs on the host, per query, over a cycle of different
     evidence sets (bn_bp_run_view = evidence H2D, evidence kernel, run, 8 * sum(k) bytes of beliefs D2H into the
     engine's page-locked buffer, ONE synchronisation); PCIe inclusive, never the headline."""
-    for ev in evs[:2]:
-        eng.bp_run_view(ev, eps)
+    # warm-up by TIME: for some tens of milliseconds after `import torch` a process answers short queries 2-3x slower (measured:
+    # ALARM-sized network 157 vs 58 us per query in the first 400 queries, scripts/experiments/alarm_torch.py)
+    t0 = time.perf_counter()
+    i = 0
+    while i < 2 or (time.perf_counter() - t0 < 0.15 and i < 4096):
+        eng.bp_run_view(evs[i % len(evs)], eps)
+        i += 1
     t0 = time.perf_counter()
     sweeps = 0
     for i in range(steps):
