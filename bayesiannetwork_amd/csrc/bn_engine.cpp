@@ -193,6 +193,10 @@ struct bn_engine {
         bool sync_dirty = true;
         uint32_t gen_base = 0;
         double* d_s_state = nullptr;  // one-workgroup path (bn_small.hip): [cap_sets][2 M + 2 N]
+        bool ev_deferred = false;     // the sets' evidence sits in d_ev only (read there by that kernel); d_ev_meta: per set {count, first node / offset / value}
+        int32_t* d_ev_meta = nullptr;
+        size_t ev_b_node = 0, ev_b_off = 0, ev_b_val = 0;  // where the three arrays start inside d_ev
+        std::vector<int64_t> ev_node_at, ev_off_at, ev_val_at;
         Ctl* d_ctl = nullptr;       // per-sweep launches: one control block per set
         bool rows_clean = true;     // ... and every set's residual slots are zero
         int32_t predicted_sweeps = 0;
@@ -224,6 +228,10 @@ struct bn_engine {
     int32_t* d_s_nvslot = nullptr;
     double* d_s_init = nullptr;
     double* d_s_state = nullptr;    // [2 M + 2 N] the state the last launch stopped in
+    int32_t* d_s_nodeoff = nullptr;
+    bool ev_deferred = false;       // the evidence in force sits in the staging block only: the one-workgroup kernel reads it there
+                                    // itself (no evidence launch in front of the run); the tile buffers get it -- marks, vectors --
+                                    // when another path needs them (flush_evidence)
     int multisweep = 1;             // resident one-launch path: 0 never, 1 where it was measured faster (one block, or
                                     // >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
     int32_t last_path = 0;          // 0 per-sweep launches, 2 one launch for the whole run (resident tiles), 3 one workgroup, state in LDS (bn_small.hip)
@@ -258,9 +266,9 @@ static void free_engine(bn_engine* e) {
         void* ptrs[] = {e->d_tiles, e->d_classes, e->d_flat_tab, e->d_cpt, e->d_rec[0], e->d_rec[1], e->d_node[0], e->d_node[1],
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync, e->d_flow, e->d_nbr,
-                        e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state,
+                        e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
-                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state};
+                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state, e->batch.d_ev_meta};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -468,6 +476,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 if ((r2 = upload(&e->d_s_nvslot, sp.nv_slot, e->stream))) return r2;
                 if ((r2 = upload(&e->d_s_init, sp.npi_init, e->stream))) return r2;
                 if ((r2 = dalloc(&e->d_s_state, size_t(2 * sp.M + 2 * sp.N)))) return r2;
+                if ((r2 = upload(&e->d_s_nodeoff, sp.node_off, e->stream))) return r2;
                 if (int code = prepare_bp_small())
                     return fail(BN_ERR_HIP, std::string("bp_small attribute: ") + hipGetErrorString(hipError_t(code)));
                 e->small_ok = true;
@@ -565,6 +574,27 @@ static int ensure_events(bn_engine* e, size_t count) {
 // following run until the next call, so a run itself starts with its first sweep.
 // wait: block until the upload has left the pinned staging block (bn_bp_set_evidence); bn_bp_run passes false --
 // its own single synchronisation at the end of the call covers it
+// The evidence in force (staging block) -> the tile buffers: ONE kernel marks the nodes with this set's mark value and writes
+// their vectors (bp_evidence_kernel).  No-op when they hold it already.
+static int flush_evidence(bn_engine* e) {
+    if (!e->ev_deferred) return BN_OK;
+    const Plan& p = e->plan;
+    if (e->frozen_mark == 255 || e->ev_applied_dirty) {  // the mark values are used up (or a launch failed half-way): start over
+        HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), e->stream));
+        e->frozen_mark = 0;
+    }
+    ++e->frozen_mark;
+    e->ev_applied_dirty = false;
+    e->ev_deferred = false;
+    EvidenceArgs ea{buffers_of(e), e->ev_ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
+    if (int code = launch_bp_evidence(ea, e->stream)) {
+        e->ev_applied_dirty = true;
+        return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
+    e->ev_upload_pending = e->ev_ne > 0;
+    return BN_OK;
+}
+
 static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
                              const double* ev_val, bool wait) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -600,19 +630,14 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
     e->d_ev_node = reinterpret_cast<int32_t*>(e->h_ev_dev + off_node);
     e->d_ev_off = reinterpret_cast<int32_t*>(e->h_ev_dev + off_off);
     e->d_ev_val = reinterpret_cast<double*>(e->h_ev_dev + off_val);
-    if (e->frozen_mark == 255 || e->ev_applied_dirty) {  // the mark values are used up (or a launch failed half-way): start over
-        HIPCHK(hipMemsetAsync(e->d_frozen, 0, std::max<size_t>(p.n_slots, 1), e->stream));
-        e->frozen_mark = 0;
-    }
-    ++e->frozen_mark;
     e->ev_ne = ne;
-    e->ev_applied_dirty = false;
-    EvidenceArgs ea{buffers_of(e), ne, e->d_ev_node, e->d_ev_off, e->d_ev_val};
-    if (int code = launch_bp_evidence(ea, e->stream)) {
-        e->ev_applied_dirty = true;
-        return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    if (e->small_ok) {  // the one-workgroup kernel reads the arrays where they are; flush_evidence() serves every other path
+        e->ev_deferred = true;
+        e->ev_upload_pending = ne > 0;
+        return BN_OK;
     }
-    e->ev_upload_pending = ne > 0;
+    e->ev_deferred = true;
+    if ((rc = flush_evidence(e))) return rc;
     if (wait) {
         HIPCHK(hipStreamSynchronize(e->stream));
         e->ev_upload_pending = false;
@@ -628,6 +653,7 @@ extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_no
 // ---- the steps of a run; bn_bp_run_device chains them, the bn_bp_step_* entry points expose
 // them one by one (tests drive several shards on one GPU with an emulated all-gather).
 static int step_begin(bn_engine* e) {
+    if (int rc = flush_evidence(e)) return rc;
     ++e->run_id;
     if (e->run_id == 0) e->run_id = 1;
     if (!e->rows_clean) {  // the previous run did not end through a finish kernel that saw it over
@@ -817,6 +843,8 @@ static SmallArgs small_args_of(bn_engine* e, const BpBuffers& b, double eps, int
     a.ent = e->d_s_ent; a.ent_cpt = e->d_s_cpt; a.term = e->d_s_term; a.clist = e->d_s_clist;
     a.bslot = e->d_s_bslot; a.cslot = e->d_s_cslot; a.nv_idx = e->d_s_nvidx; a.nv_slot = e->d_s_nvslot; a.npi_init = e->d_s_init;
     a.state = e->d_s_state; a.sets = SetStrides{}; a.state_stride = 0;
+    a.ev_mode = 0; a.ev_ne = 0; a.ev_node = nullptr; a.ev_off = nullptr; a.ev_val = nullptr; a.ev_meta = nullptr;
+    a.node_off = e->d_s_nodeoff;
     return a;
 }
 
@@ -829,7 +857,10 @@ static int run_small(bn_engine* e, double eps, int32_t max_sweeps, double* copy_
     float ms = 0.f;
     double dev_ticks = 0.0;
     for (;;) {
-        const SmallArgs a = small_args_of(e, buffers_of(e), eps, max_sweeps, begin, e->h_ctl_dev);
+        SmallArgs a = small_args_of(e, buffers_of(e), eps, max_sweeps, begin, e->h_ctl_dev);
+        if (e->ev_deferred) {  // the evidence in force was never written to the tile buffers: the kernel reads the staging block
+            a.ev_mode = 1; a.ev_ne = e->ev_ne; a.ev_node = e->d_ev_node; a.ev_off = e->d_ev_off; a.ev_val = e->d_ev_val;
+        }
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -901,6 +932,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         if (residual_out) *residual_out = e->last_ctl.last_res;
         return BN_OK;
     }
+    if ((rc = flush_evidence(e))) return rc;  // the tile kernels read the evidence from their own buffers
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
         rc = run_resident(e, eps, max_sweeps, copy_to);
@@ -1025,7 +1057,8 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     if (n_sets <= bt.cap_sets) return BN_OK;
     const Plan& p = e->plan;
     HIPCHK(hipStreamSynchronize(e->stream));
-    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl, bt.d_s_state};
+    void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl, bt.d_s_state,
+                   bt.d_ev, bt.d_ev_meta};
     for (void* q : old)
         if (q) (void)hipFree(q);
     if (bt.h_ctl) (void)hipHostFree(bt.h_ctl);
@@ -1105,6 +1138,23 @@ static void adopt_batch_outcome(bn_engine* e) {  // what bn_bp_stats / bn_bp_las
     e->stats.messages_per_sweep = own.messages_per_sweep;
 }
 
+// The batch's evidence (bt.d_ev) -> the sets' tile buffers: marks cleared, one bp_evidence_kernel per set.  No-op when done already.
+static int flush_batch_evidence(bn_engine* e) {
+    bn_engine::Batch& bt = e->batch;
+    if (!bt.ev_deferred) return BN_OK;
+    const Plan& p = e->plan;
+    HIPCHK(hipMemsetAsync(bt.d_frozen, 0, size_t(bt.n_sets) * size_t(std::max(p.n_slots, 1)), e->stream));
+    for (int32_t q = 0; q < bt.n_sets; ++q) {
+        EvidenceArgs ea{batch_buffers_of(e, q), bt.ne[q], reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_node) + bt.ev_node_at[q],
+                        reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_off) + bt.ev_off_at[q],
+                        reinterpret_cast<double*>(bt.d_ev + bt.ev_b_val) + bt.ev_val_at[q]};
+        if (int code = launch_bp_evidence(ea, e->stream))
+            return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
+    bt.ev_deferred = false;
+    return BN_OK;
+}
+
 extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int32_t* ne, const int32_t* ev_node,
                                         const int32_t* ev_off, const double* ev_val) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -1161,14 +1211,22 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     }
     if (ev_off) std::memcpy(host.data() + b_off, ev_off, size_t(off_at[n_sets]) * 4);
     if (bytes) HIPCHK(hipMemcpyAsync(bt.d_ev, host.data(), bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemsetAsync(bt.d_frozen, 0, size_t(n_sets) * size_t(std::max(p.n_slots, 1)), e->stream));
-    for (int32_t q = 0; q < n_sets; ++q) {
-        EvidenceArgs ea{batch_buffers_of(e, q), ne[q], reinterpret_cast<int32_t*>(bt.d_ev + b_node) + node_at[q],
-                        reinterpret_cast<int32_t*>(bt.d_ev + b_off) + off_at[q], reinterpret_cast<double*>(bt.d_ev + b_val) + val_at[q]};
-        if (int code = launch_bp_evidence(ea, e->stream))
-            return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    bt.ev_b_node = b_node; bt.ev_b_off = b_off; bt.ev_b_val = b_val;
+    bt.ev_node_at = node_at; bt.ev_off_at = off_at; bt.ev_val_at = val_at;
+    bt.ev_deferred = true;
+    std::vector<int32_t> meta(size_t(n_sets) * 4);
+    if (e->small_ok) {
+        // the one-workgroup kernel (one workgroup per set) reads each set's arrays where they are -- no evidence launch per
+        // set in front of the run; the tile buffers get the marks and vectors only if another path runs the batch
+        for (int32_t q = 0; q < n_sets; ++q) {
+            meta[4 * q] = ne[q]; meta[4 * q + 1] = int32_t(node_at[q]); meta[4 * q + 2] = int32_t(off_at[q]); meta[4 * q + 3] = int32_t(val_at[q]);
+        }
+        if (!bt.d_ev_meta) HIPCHK(hipMalloc(reinterpret_cast<void**>(&bt.d_ev_meta), sizeof(int32_t) * 4 * BN_MAX_BATCH_SETS));
+        HIPCHK(hipMemcpyAsync(bt.d_ev_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, e->stream));
+    } else if ((rc = flush_batch_evidence(e))) {
+        return rc;
     }
-    HIPCHK(hipStreamSynchronize(e->stream));  // `host` is a local
+    HIPCHK(hipStreamSynchronize(e->stream));  // `host` and `meta` are locals
     return BN_OK;
 }
 
@@ -1326,6 +1384,15 @@ static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
     const int64_t state_stride = 2 * int64_t(e->small.M) + 2 * int64_t(e->small.N);
     SmallArgs a = small_args_of(e, batch_buffers_of(e, 0), eps, max_sweeps, 0, bt.h_ctl_dev);
     a.state = bt.d_s_state; a.sets = st; a.state_stride = state_stride;
+    auto evidence_of = [&](SmallArgs& x, bool per_set_meta, int32_t q) {
+        if (!bt.ev_deferred) return;  // the tile buffers hold it
+        x.ev_mode = 1;
+        x.ev_node = reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_node);
+        x.ev_off = reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_off);
+        x.ev_val = reinterpret_cast<double*>(bt.d_ev + bt.ev_b_val);
+        x.ev_meta = per_set_meta ? bt.d_ev_meta : bt.d_ev_meta + 4 * q;  // (a single-set launch reads entry `blockIdx.x` = 0)
+    };
+    evidence_of(a, true, 0);
     if (int code = launch_bp_small(a, e->small.waves, e->small.lds_bytes, B, s))
         return fail(BN_ERR_HIP, std::string("bp_small launch failed: ") + hipGetErrorString(hipError_t(code)));
     HIPCHK(hipStreamSynchronize(s));
@@ -1335,6 +1402,7 @@ static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
         while (bt.h_ctl[q].done == 0) {  // a set that used up the launch's budget of iterations goes on by itself
             SmallArgs c = small_args_of(e, batch_buffers_of(e, q), eps, max_sweeps, bt.h_ctl[q].n_sweeps, bt.h_ctl_dev + q);
             c.state = bt.d_s_state + size_t(q) * state_stride;
+            evidence_of(c, false, q);
             if (int code = launch_bp_small(c, e->small.waves, e->small.lds_bytes, 1, s))
                 return fail(BN_ERR_HIP, std::string("bp_small launch failed: ") + hipGetErrorString(hipError_t(code)));
             HIPCHK(hipStreamSynchronize(s));
@@ -1384,7 +1452,10 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     constexpr int64_t kResidentBatchMinTiles = 900;
     const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
     const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
-    if (e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state) {
+    const bool batch_small = e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state != nullptr;
+    if (!batch_small && (rc = flush_batch_evidence(e))) return rc;
+    rc = BN_ERR_STATE;
+    if (batch_small) {
         if ((rc = run_batch_small(e, eps, max_sweeps))) return rc;
     } else if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
@@ -1412,6 +1483,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
             bt.sweeps.assign(bt.n_sets, 0);
             bt.residual.assign(bt.n_sets, 0.0);
         }
+        if ((rc = flush_batch_evidence(e))) return rc;
         rc = run_batch_launches(e, eps, max_sweeps);
         if (rc) return rc;
     }

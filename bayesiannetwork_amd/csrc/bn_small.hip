@@ -208,16 +208,46 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
     int s = a.sweep_begin;
     {
         const int c0 = s & 1;
-        for (int y = tid; y < a.N; y += nt) {
-            const bool frozen = b.frozen[a.nv_slot[y]] == b.frozen_mark;  // preconditional_node_ (:69)
-            L.frz[y] = frozen ? 1 : 0;
-            if (s == 0) {
-                const double ev = b.node0[a.nv_idx[y]];  // where bp_evidence_kernel left the evidence vector
-                L.npi[c0 * a.N + y] = frozen ? ev : a.npi_init[y];
-                L.nlam[c0 * a.N + y] = frozen ? ev : 1.0;
-            } else {
-                L.npi[c0 * a.N + y] = state[2 * a.M + y];
-                L.nlam[c0 * a.N + y] = state[2 * a.M + a.N + y];
+        if (a.ev_mode == 0) {
+            for (int y = tid; y < a.N; y += nt) {
+                const bool frozen = b.frozen[a.nv_slot[y]] == b.frozen_mark;  // preconditional_node_ (:69)
+                L.frz[y] = frozen ? 1 : 0;
+                if (s == 0) {
+                    const double ev = b.node0[a.nv_idx[y]];  // where bp_evidence_kernel left the evidence vector
+                    L.npi[c0 * a.N + y] = frozen ? ev : a.npi_init[y];
+                    L.nlam[c0 * a.N + y] = frozen ? ev : 1.0;
+                } else {
+                    L.npi[c0 * a.N + y] = state[2 * a.M + y];
+                    L.nlam[c0 * a.N + y] = state[2 * a.M + a.N + y];
+                }
+            }
+        } else {
+            // the evidence arrays themselves (mapped host memory or the batch's staging block): requested first, the
+            // initial state is written while they travel
+            const int32_t* meta = a.ev_meta ? a.ev_meta + 4 * set : nullptr;
+            const int ne = meta ? meta[0] : a.ev_ne;
+            const int32_t* ev_node = a.ev_node + (meta ? meta[1] : 0);
+            const int32_t* ev_off = a.ev_off + (meta ? meta[2] : 0);
+            const double* ev_val = a.ev_val + (meta ? meta[3] : 0);
+            int v0 = 0, o0 = 0;
+            if (tid < ne) { v0 = ev_node[tid]; o0 = ev_off[tid]; }
+            for (int y = tid; y < a.N; y += nt) {
+                L.frz[y] = 0;
+                L.npi[c0 * a.N + y] = s == 0 ? a.npi_init[y] : state[2 * a.M + y];
+                L.nlam[c0 * a.N + y] = s == 0 ? 1.0 : state[2 * a.M + a.N + y];
+            }
+            __syncthreads();
+            for (int j = tid; j < ne; j += nt) {  // both pi(v) and lambda(v) take the evidence vector (:68-73)
+                const int v = j == tid ? v0 : ev_node[j], o = j == tid ? o0 : ev_off[j];
+                const int lo = a.node_off[v], hi = a.node_off[v + 1];
+                for (int i = 0; i < hi - lo; ++i) {
+                    L.frz[lo + i] = 1;
+                    if (s == 0) {
+                        const double x = ev_val[o + i];
+                        L.npi[c0 * a.N + lo + i] = x;
+                        L.nlam[c0 * a.N + lo + i] = x;
+                    }
+                }
             }
         }
         for (int x = tid; x < a.M; x += nt) {

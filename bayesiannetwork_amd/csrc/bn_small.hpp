@@ -54,6 +54,7 @@ struct SmallPlan {
     std::vector<int32_t> nv_idx;     // [N]    where the evidence kernel puts element x of a node vector (doubles into node0)
     std::vector<int32_t> nv_slot;    // [N]    the node's evidence-mark slot
     std::vector<double> npi_init;    // [N]    initial pi(v): the CPT row of a root, else 1.0 (:38-64)
+    std::vector<int32_t> node_off;   // [n + 1] first element of node v's vectors
 };
 
 // Builds the plan from the model held in `p` (single rank).  sp.ok false + sp.why when the network does not fit.
@@ -75,6 +76,15 @@ struct SmallArgs {
     const int32_t* nv_idx;
     const int32_t* nv_slot;
     const double* npi_init;
+    // Evidence (:68-73).  ev_mode 0: the marks and vectors bp_evidence_kernel left in the tile buffers (b.frozen, b.node0);
+    // 1: the caller's arrays, read in place -- no evidence launch in front of the run: set q has ev_meta[4 q .. 4 q + 3] =
+    // {count, first node entry, first offset entry, first value} (ev_meta null: one set, ev_ne entries from the start)
+    int32_t ev_mode, ev_ne;
+    const int32_t* ev_node;
+    const int32_t* ev_off;
+    const double* ev_val;
+    const int32_t* ev_meta;
+    const int32_t* node_off;
     double* state;            // [2M + 2N] pi-messages, lambda-messages (CSR edge order), pi(v), lambda(v): the state the
                               // launch stopped in (bn_bp_messages; a run longer than one launch's budget continues from it)
     // several evidence sets, one workgroup each (blockIdx.x): strides of the per-set arrays

@@ -267,6 +267,7 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
             if (m[v] == 0) sp.npi_init[p.node_off[v] + i] = p.cpt_flat[p.cpt_off[v] + i];  // a root starts from its CPT row (:58-64)
         }
     }
+    sp.node_off.assign(p.node_off.begin(), p.node_off.begin() + n + 1);
     sp.n = n; sp.N = int32_t(N); sp.M = int32_t(M); sp.S = int32_t(S); sp.T = int32_t(T); sp.TT = int32_t(TT);
     sp.CL = int32_t(E); sp.waves = waves; sp.mmax = mmax;
     // LDS: 4 M + 4 N + T doubles, TT words, CL halfwords, N marks, the residual words

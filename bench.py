@@ -368,6 +368,28 @@ def leg_alarm(a, local_rank, torch):
             dt = time.perf_counter() - t0
             batch[f"B{B}"] = {"queries_per_s": B * reps / dt, "us_per_call": dt / reps * 1e6, "us_per_set_sweep": dt / sw * 1e6,
                               "path": PATH_NAME.get(eng.last_path()), "what": "bn_bp_run_batch_device: evidence staged, marginals left in HBM"}
+            # the whole call: the caller's evidence arrays in, every set's marginals in the caller's array out
+            import ctypes
+            import numpy as np
+            from bayesiannetwork_amd import _lib
+            from bayesiannetwork_amd.engine import _p
+            ne, node, off, val = eng._pack_sets(sets)
+            bel = np.empty((B, int(g.k.sum())))
+            sweeps_out, res_out = np.zeros(B, dtype=np.int32), np.zeros(B)
+            L = _lib.lib()
+
+            def call():
+                _lib.check(L.bn_bp_run_batch(eng._h, B, _p(ne, ctypes.c_int32), _p(node, ctypes.c_int32), _p(off, ctypes.c_int32),
+                                             _p(val, ctypes.c_double), eps, 0, _p(bel, ctypes.c_double), _p(sweeps_out, ctypes.c_int32),
+                                             _p(res_out, ctypes.c_double)))
+            for _ in range(5):
+                call()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            dt = time.perf_counter() - t0
+            batch[f"B{B}"]["end_to_end"] = {"queries_per_s": B * reps / dt, "us_per_call": dt / reps * 1e6,
+                                            "what": "bn_bp_run_batch: evidence arrays in, marginals in the caller's array out"}
         out["batch"] = batch
     if not a.no_cpu:
         import oracle

@@ -145,3 +145,39 @@ def test_small_through_the_view_and_evidence_changes(Engine, oracle_mod):
         got = np.concatenate([np.asarray(m).ravel() for m in bp(ev, 1e-6)])   # a list of 1 x k arrays, one per node
         assert np.array_equal(got, want[q % 7]), q
     assert bp.engine.last_path() == 3
+
+
+def test_small_evidence_is_read_in_place_and_survives_path_changes(Engine, oracle_mod):
+    """On this path the kernel reads the evidence arrays where the caller's call left them (no evidence launch in front of the
+    run); the tile buffers get marks and vectors only when another path runs.  Staged once, the evidence stays in force
+    whichever path the following runs take."""
+    from bayesiannetwork_amd import synth
+    g = _alarm()
+    ev, ev2 = synth.random_evidence(g, 0.15, seed=31), synth.random_evidence(g, 0.1, seed=32)
+    o, o2 = oracle_mod.bp_run(g, ev, 1e-6), oracle_mod.bp_run(g, ev2, 1e-6)
+    with Engine(g) as eng:
+        eng.bp_set_evidence(ev)
+        for small, path in ((1, 3), (0, 0), (1, 3), (0, 0)):
+            eng.set_option("small", small)
+            r = eng.bp_run_device(1e-6)
+            assert eng.last_path() == path and r["sweeps"] == o["sweeps"]
+            assert np.array_equal(eng.bp_beliefs(), o["beliefs"])   # (ALARM's tables take the ordered path of the tile kernels: same bits)
+        eng.set_option("small", 0)
+        eng.bp_set_evidence(ev2)            # staged while the tile path is selected, run on this one
+        eng.set_option("small", 1)
+        r = eng.bp_run_device(1e-6)
+        assert eng.last_path() == 3 and np.array_equal(eng.bp_beliefs(), o2["beliefs"])
+        # batches: staged for one path, run on the other
+        sets = [ev, ev2, None, ev]
+        want = [o, o2, oracle_mod.bp_run(g, None, 1e-6), o]
+        for small_at_set, small_at_run in ((1, 0), (0, 1), (1, 1)):
+            eng.set_option("small", small_at_set)
+            eng.bp_set_evidence_batch(sets)
+            eng.set_option("small", small_at_run)
+            out = eng.bp_run_batch_device(1e-6)
+            assert eng.last_path() == (3 if small_at_run else 0)
+            bel = eng.bp_beliefs_batch()
+            for q, w in enumerate(want):
+                assert out["sweeps"][q] == w["sweeps"] and np.array_equal(bel[q], w["beliefs"]), (small_at_set, small_at_run, q)
+        eng.set_option("small", 1)
+        assert np.array_equal(eng.bp_run(ev2, 1e-6)["beliefs"], o2["beliefs"])
