@@ -194,7 +194,15 @@ struct bn_engine {
         uint32_t gen_base = 0;
         double* d_s_state = nullptr;  // one-workgroup path (bn_small.hip): [cap_sets][2 M + 2 N]
         bool ev_deferred = false;     // the sets' evidence sits in d_ev only (read there by that kernel); d_ev_meta: per set {count, first node / offset / value}
-        int32_t* d_ev_meta = nullptr;
+        int32_t* d_ev_meta = nullptr;   // (inside the staging block)
+        char* h_ev = nullptr;           // small networks: the staging block is page-locked host memory the kernels read in place
+        char* ev_base = nullptr;        // the staging block as the device sees it: d_ev, or h_ev mapped
+        size_t h_ev_cap = 0;
+        double* h_beliefs = nullptr;    // small networks, bn_bp_run_batch: the kernel writes every set's marginals here (mapped) ...
+        double* h_beliefs_dev = nullptr;
+        size_t h_beliefs_cap = 0;
+        bool direct_out = false;        // ... when this is set for the run at hand
+        bool beliefs_on_host = false;   // the last run's marginals are in h_beliefs, not d_beliefs
         size_t ev_b_node = 0, ev_b_off = 0, ev_b_val = 0;  // where the three arrays start inside d_ev
         std::vector<int64_t> ev_node_at, ev_off_at, ev_val_at;
         Ctl* d_ctl = nullptr;       // per-sweep launches: one control block per set
@@ -268,12 +276,14 @@ static void free_engine(bn_engine* e) {
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync, e->d_flow, e->d_nbr,
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
-                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state, e->batch.d_ev_meta};
+                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
         if (e->h_abort) (void)hipHostFree(e->h_abort);
         if (e->batch.h_ctl) (void)hipHostFree(e->batch.h_ctl);
+        if (e->batch.h_ev) (void)hipHostFree(e->batch.h_ev);
+        if (e->batch.h_beliefs) (void)hipHostFree(e->batch.h_beliefs);
         if (e->h_ev) (void)hipHostFree(e->h_ev);
         if (e->h_beliefs) (void)hipHostFree(e->h_beliefs);
         for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
@@ -1058,7 +1068,9 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     const Plan& p = e->plan;
     HIPCHK(hipStreamSynchronize(e->stream));
     void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl, bt.d_s_state,
-                   bt.d_ev, bt.d_ev_meta};
+                   bt.d_ev};
+    if (bt.h_ev) (void)hipHostFree(bt.h_ev);
+    if (bt.h_beliefs) (void)hipHostFree(bt.h_beliefs);
     for (void* q : old)
         if (q) (void)hipFree(q);
     if (bt.h_ctl) (void)hipHostFree(bt.h_ctl);
@@ -1145,9 +1157,9 @@ static int flush_batch_evidence(bn_engine* e) {
     const Plan& p = e->plan;
     HIPCHK(hipMemsetAsync(bt.d_frozen, 0, size_t(bt.n_sets) * size_t(std::max(p.n_slots, 1)), e->stream));
     for (int32_t q = 0; q < bt.n_sets; ++q) {
-        EvidenceArgs ea{batch_buffers_of(e, q), bt.ne[q], reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_node) + bt.ev_node_at[q],
-                        reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_off) + bt.ev_off_at[q],
-                        reinterpret_cast<double*>(bt.d_ev + bt.ev_b_val) + bt.ev_val_at[q]};
+        EvidenceArgs ea{batch_buffers_of(e, q), bt.ne[q], reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[q],
+                        reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[q],
+                        reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[q]};
         if (int code = launch_bp_evidence(ea, e->stream))
             return fail(BN_ERR_HIP, std::string("bp_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
     }
@@ -1195,38 +1207,55 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     bt.ev_node.assign(ev_node, ev_node + node_at[n_sets]);
     bt.ev_off.assign(ev_off, ev_off + (node_at[n_sets] > 0 || ev_off ? off_at[n_sets] : 0));
     bt.ev_val.assign(ev_val, ev_val + val_at[n_sets]);
-    // one staging block [nodes | offs | vals], one H2D copy, then one evidence kernel per set
+    // one staging block [nodes | offs | vals | per-set meta]
     const size_t b_node = 0, b_off = size_t(node_at[n_sets]) * 4, b_val = (b_off + size_t(off_at[n_sets]) * 4 + 7) & ~size_t(7);
-    const size_t bytes = b_val + size_t(val_at[n_sets]) * 8;
+    const size_t b_meta = b_val + size_t(val_at[n_sets]) * 8;
+    const size_t bytes = b_meta + size_t(n_sets) * 16;
+    auto fill = [&](char* dst) {
+        if (node_at[n_sets] > 0) {
+            std::memcpy(dst + b_node, ev_node, size_t(node_at[n_sets]) * 4);
+            std::memcpy(dst + b_val, ev_val, size_t(val_at[n_sets]) * 8);
+        }
+        if (ev_off) std::memcpy(dst + b_off, ev_off, size_t(off_at[n_sets]) * 4);
+        int32_t* meta = reinterpret_cast<int32_t*>(dst + b_meta);  // per set {count, first node entry, first offset entry, first value}
+        for (int32_t q = 0; q < n_sets; ++q) {
+            meta[4 * q] = ne[q]; meta[4 * q + 1] = int32_t(node_at[q]); meta[4 * q + 2] = int32_t(off_at[q]); meta[4 * q + 3] = int32_t(val_at[q]);
+        }
+    };
+    bt.ev_b_node = b_node; bt.ev_b_off = b_off; bt.ev_b_val = b_val;
+    bt.ev_node_at = node_at; bt.ev_off_at = off_at; bt.ev_val_at = val_at;
+    bt.ev_deferred = true;
+    bt.beliefs_on_host = false;
+    if (e->small_ok) {
+        // Small networks: the block is page-locked host memory that the kernels read in place -- the one-workgroup kernel (one
+        // workgroup per set) each set's arrays, no copy command, no evidence launch per set, no synchronisation here; the tile
+        // buffers get the marks and vectors only if another path runs the batch (flush_batch_evidence).  (No kernel is in
+        // flight when the block is rewritten: every run entry point synchronises before it returns.)
+        if (bytes > bt.h_ev_cap) {
+            if (bt.h_ev) (void)hipHostFree(bt.h_ev);
+            bt.h_ev = nullptr;
+            bt.h_ev_cap = std::max<size_t>(bytes * 2, 4096);
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bt.h_ev), bt.h_ev_cap, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&bt.ev_base), bt.h_ev, 0));
+        }
+        fill(bt.h_ev);
+        bt.d_ev_meta = reinterpret_cast<int32_t*>(bt.ev_base + b_meta);
+        return BN_OK;
+    }
+    // every other network: one H2D copy, then one evidence kernel per set
     if (bytes > bt.ev_cap) {
         if (bt.d_ev) (void)hipFree(bt.d_ev);
         bt.d_ev = nullptr;
         bt.ev_cap = std::max<size_t>(bytes * 2, 4096);
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&bt.d_ev), bt.ev_cap));
     }
+    bt.ev_base = bt.d_ev;
     std::vector<char> host(std::max<size_t>(bytes, 1));
-    if (node_at[n_sets] > 0) {
-        std::memcpy(host.data() + b_node, ev_node, size_t(node_at[n_sets]) * 4);
-        std::memcpy(host.data() + b_val, ev_val, size_t(val_at[n_sets]) * 8);
-    }
-    if (ev_off) std::memcpy(host.data() + b_off, ev_off, size_t(off_at[n_sets]) * 4);
-    if (bytes) HIPCHK(hipMemcpyAsync(bt.d_ev, host.data(), bytes, hipMemcpyHostToDevice, e->stream));
-    bt.ev_b_node = b_node; bt.ev_b_off = b_off; bt.ev_b_val = b_val;
-    bt.ev_node_at = node_at; bt.ev_off_at = off_at; bt.ev_val_at = val_at;
-    bt.ev_deferred = true;
-    std::vector<int32_t> meta(size_t(n_sets) * 4);
-    if (e->small_ok) {
-        // the one-workgroup kernel (one workgroup per set) reads each set's arrays where they are -- no evidence launch per
-        // set in front of the run; the tile buffers get the marks and vectors only if another path runs the batch
-        for (int32_t q = 0; q < n_sets; ++q) {
-            meta[4 * q] = ne[q]; meta[4 * q + 1] = int32_t(node_at[q]); meta[4 * q + 2] = int32_t(off_at[q]); meta[4 * q + 3] = int32_t(val_at[q]);
-        }
-        if (!bt.d_ev_meta) HIPCHK(hipMalloc(reinterpret_cast<void**>(&bt.d_ev_meta), sizeof(int32_t) * 4 * BN_MAX_BATCH_SETS));
-        HIPCHK(hipMemcpyAsync(bt.d_ev_meta, meta.data(), sizeof(int32_t) * meta.size(), hipMemcpyHostToDevice, e->stream));
-    } else if ((rc = flush_batch_evidence(e))) {
-        return rc;
-    }
-    HIPCHK(hipStreamSynchronize(e->stream));  // `host` and `meta` are locals
+    fill(host.data());
+    HIPCHK(hipMemcpyAsync(bt.d_ev, host.data(), bytes, hipMemcpyHostToDevice, e->stream));
+    bt.d_ev_meta = reinterpret_cast<int32_t*>(bt.ev_base + b_meta);
+    if ((rc = flush_batch_evidence(e))) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));  // `host` is a local
     return BN_OK;
 }
 
@@ -1384,12 +1413,24 @@ static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
     const int64_t state_stride = 2 * int64_t(e->small.M) + 2 * int64_t(e->small.N);
     SmallArgs a = small_args_of(e, batch_buffers_of(e, 0), eps, max_sweeps, 0, bt.h_ctl_dev);
     a.state = bt.d_s_state; a.sets = st; a.state_stride = state_stride;
+    const size_t per_set = size_t(p.node_off[p.n]);
+    if (bt.direct_out) {  // bn_bp_run_batch: the marginals go straight into page-locked host memory (no copy command, no second sync)
+        if (size_t(B) * per_set > bt.h_beliefs_cap) {
+            if (bt.h_beliefs) (void)hipHostFree(bt.h_beliefs);
+            bt.h_beliefs = nullptr;
+            bt.h_beliefs_cap = size_t(bt.cap_sets) * per_set;
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&bt.h_beliefs), std::max<size_t>(bt.h_beliefs_cap, 1) * sizeof(double), hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&bt.h_beliefs_dev), bt.h_beliefs, 0));
+        }
+        a.b.beliefs = bt.h_beliefs_dev;
+    }
+    bt.beliefs_on_host = bt.direct_out;
     auto evidence_of = [&](SmallArgs& x, bool per_set_meta, int32_t q) {
         if (!bt.ev_deferred) return;  // the tile buffers hold it
         x.ev_mode = 1;
-        x.ev_node = reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_node);
-        x.ev_off = reinterpret_cast<int32_t*>(bt.d_ev + bt.ev_b_off);
-        x.ev_val = reinterpret_cast<double*>(bt.d_ev + bt.ev_b_val);
+        x.ev_node = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node);
+        x.ev_off = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off);
+        x.ev_val = reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val);
         x.ev_meta = per_set_meta ? bt.d_ev_meta : bt.d_ev_meta + 4 * q;  // (a single-set launch reads entry `blockIdx.x` = 0)
     };
     evidence_of(a, true, 0);
@@ -1402,6 +1443,7 @@ static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
         while (bt.h_ctl[q].done == 0) {  // a set that used up the launch's budget of iterations goes on by itself
             SmallArgs c = small_args_of(e, batch_buffers_of(e, q), eps, max_sweeps, bt.h_ctl[q].n_sweeps, bt.h_ctl_dev + q);
             c.state = bt.d_s_state + size_t(q) * state_stride;
+            if (bt.direct_out) c.b.beliefs = bt.h_beliefs_dev + size_t(q) * per_set;
             evidence_of(c, false, q);
             if (int code = launch_bp_small(c, e->small.waves, e->small.lds_bytes, 1, s))
                 return fail(BN_ERR_HIP, std::string("bp_small launch failed: ") + hipGetErrorString(hipError_t(code)));
@@ -1442,6 +1484,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     ON_DEVICE(e);
     bt.sweeps.assign(bt.n_sets, 0);
     bt.residual.assign(bt.n_sets, 0.0);
+    bt.beliefs_on_host = false;
     int rc = BN_ERR_STATE;
     bool aborted = false;
     // Which way a batch goes (measured, scripts/time_batch.py, us per set-sweep at the best batch size of either path):
@@ -1500,6 +1543,10 @@ extern "C" int bn_bp_copy_beliefs_batch(bn_engine* e, double* beliefs_out) {
     if (!e || !beliefs_out) return fail(BN_ERR_ARG, "null argument");
     if (e->batch_on_dense && e->dense) return bn_bp_copy_beliefs_batch(e->dense, beliefs_out);
     if (e->host_only || !e->batch.have_run) return fail(BN_ERR_STATE, "no batched run to copy from");
+    if (e->batch.beliefs_on_host) {  // the last run wrote them into page-locked host memory
+        std::memcpy(beliefs_out, e->batch.h_beliefs, sizeof(double) * size_t(e->batch.n_sets) * e->plan.node_off[e->plan.n]);
+        return BN_OK;
+    }
     ON_DEVICE(e);
     HIPCHK(hipMemcpyAsync(beliefs_out, e->batch.d_beliefs, sizeof(double) * size_t(e->batch.n_sets) * e->plan.node_off[e->plan.n],
                           hipMemcpyDeviceToHost, e->stream));
@@ -1525,7 +1572,10 @@ extern "C" int bn_bp_run_batch(bn_engine* e, int32_t n_sets, const int32_t* ne, 
     if (!beliefs_out) return fail(BN_ERR_ARG, "null beliefs_out");
     int rc = bn_bp_set_evidence_batch(e, n_sets, ne, ev_node, ev_off, ev_val);
     if (rc) return rc;
+    bn_engine* on = (e->batch_on_dense && e->dense) ? e->dense : e;
+    on->batch.direct_out = true;   // (the one-workgroup path writes the marginals into page-locked host memory; other paths ignore it)
     rc = bn_bp_run_batch_device(e, eps, max_sweeps, sweeps_out, residual_out);
+    on->batch.direct_out = false;
     if (rc) return rc;
     return bn_bp_copy_beliefs_batch(e, beliefs_out);
 }
