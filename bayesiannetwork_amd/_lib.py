@@ -15,7 +15,7 @@ _LIB = None
 
 BN_OK, BN_ERR_ARG, BN_ERR_HIP, BN_ERR_NO_DEVICE, BN_ERR_ALLOC, BN_ERR_COMM, BN_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 BN_DEVICE_HOST_ONLY, BN_DEVICE_CURRENT = -2, -1
-BN_MAX_BATCH_SETS = 64  # include/bn_mi355x.h
+BN_MAX_BATCH_SETS = 256  # include/bn_mi355x.h
 
 i32p = ctypes.POINTER(ctypes.c_int32)
 i64p = ctypes.POINTER(ctypes.c_int64)

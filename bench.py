@@ -355,7 +355,7 @@ def leg_alarm(a, local_rank, torch):
         eng.set_option("small", 1)
         eng.set_option("multisweep", 1)
         batch = {}
-        for B in (16, 64):
+        for B in (16, 64, 256):
             sets = [synth.random_evidence(g, 0.1, seed=100 + q) for q in range(B)]
             eng.bp_set_evidence_batch(sets)
             for _ in range(3):

@@ -38,7 +38,7 @@ typedef enum bn_status {
 } bn_status;
 
 #define BN_MAX_PARENTS 16
-#define BN_MAX_BATCH_SETS 64 /* evidence sets per bn_bp_run_batch call */
+#define BN_MAX_BATCH_SETS 256 /* evidence sets per bn_bp_run_batch call */
 #define BN_DEVICE_HOST_ONLY (-2) /* build the layout plan only; no HIP call is made */
 #define BN_DEVICE_CURRENT (-1)
 

@@ -86,7 +86,7 @@ def test_batch_on_per_sweep_launches_every_tile_variant(Engine):
     with Engine(m) as eng:
         _check_batch(eng, evs, 1e-6, want_path=0)
         with pytest.raises(_lib.BnError):
-            eng.bp_run_batch([None] * 65, 1e-3)                     # more than BN_MAX_BATCH_SETS
+            eng.bp_run_batch([None] * (_lib.BN_MAX_BATCH_SETS + 1), 1e-3)   # more than BN_MAX_BATCH_SETS
     alarm, _ = load_dsc(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "alarm_shaped.dsc"))
     evs = [synth.random_evidence(alarm, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.2] * 4)]
     with Engine(alarm) as eng:                                      # any-arity tiles only: the light kernel, 16 sets

@@ -115,7 +115,7 @@ def test_small_batch_one_workgroup_per_set(Engine, oracle_mod):
     evs = [synth.random_evidence(g, f, seed=20 + q) for q, f in enumerate([0.0, 0.05, 0.1, 0.3, 0.02, 0.5, 0.2])]
     evs.append(Evidence.from_dict(g, {4: np.full(int(g.k[4]), 0.5)}))
     with Engine(g) as eng:
-        for sets, eps, cap in ((evs, 1e-6, 0), (evs[:3], 1e-12, 4), (evs[:1], 1e-6, 0), (evs * 8, 1e-9, 0)):
+        for sets, eps, cap in ((evs, 1e-6, 0), (evs[:3], 1e-12, 4), (evs[:1], 1e-6, 0), (evs * 8, 1e-9, 0), (evs * 32, 1e-6, 0)):   # up to 256 sets: one workgroup per CU
             out = eng.bp_run_batch(sets, eps, cap)
             assert eng.last_path() == 3 and eng.bp_stats()["sweep_launches"] == 1
             for q, ev in enumerate(sets):
