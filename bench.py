@@ -277,21 +277,29 @@ def time_cycled(eng, g, evs, eps, steps):
     the clock, the clock runs around bn_bp_run_device only (the call returns after its own synchronisation).  On
     the launch path the engine enqueues the sweep count of the PREVIOUS run ahead, so a stream of different queries
     pays for over- and under-shoots that a repeat of the same query never sees."""
-    for ev in evs[:2]:
-        eng.bp_set_evidence(ev)
-        eng.bp_run_device(eps)
-    dt, sweeps, launches = 0.0, 0, 0
-    for i in range(steps):
+    t0 = time.perf_counter()
+    i = 0
+    while i < 2 or (time.perf_counter() - t0 < 0.1 and i < 4096):   # warm-up by time (see time_host_to_host)
         eng.bp_set_evidence(evs[i % len(evs)])
-        t0 = time.perf_counter()
-        r = eng.bp_run_device(eps)
-        dt += time.perf_counter() - t0
-        sweeps += r["sweeps"]
-        launches += eng.bp_stats()["sweep_launches"]
+        eng.bp_run_device(eps)
+        i += 1
+    blocks = []
+    for _ in range(3):   # three blocks of `steps` runs, the median block is reported (a leg that follows seconds of CPU-only work
+        dt, sweeps, launches = 0.0, 0, 0   # -- another leg's CPU baseline -- has been seen 70 % slow for a whole block)
+        for i in range(steps):
+            eng.bp_set_evidence(evs[i % len(evs)])
+            t0 = time.perf_counter()
+            r = eng.bp_run_device(eps)
+            dt += time.perf_counter() - t0
+            sweeps += r["sweeps"]
+            launches += eng.bp_stats()["sweep_launches"]
+        blocks.append((dt, sweeps, launches))
+    blocks.sort()
+    dt, sweeps, launches = blocks[1]
     return {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_step": dt / steps * 1e3,
             "steps": steps, "evidence_sets_cycled": len(evs), "sweeps_per_step": sweeps / steps,
-            "sweep_launches_per_step": launches / steps,
-            "what": "bn_bp_run_device on a cycle of different staged evidence sets; clock around the run only"}
+            "sweep_launches_per_step": launches / steps, "ms_per_step_blocks": [round(b[0] / steps * 1e3, 4) for b in blocks],
+            "what": "bn_bp_run_device on a cycle of different staged evidence sets; clock around the run only; median of three blocks"}
 
 
 def leg_dag(a, local_rank, torch):
