@@ -128,6 +128,7 @@ struct bn_engine {
     char* h_ev = nullptr;
     size_t ev_bytes_cap = 0;
     int32_t ev_ne = 0;
+    int32_t ev_nval = 0;            // values of the evidence in force (sum of the observed nodes' arities)
     int32_t* d_ev_node = nullptr;
     int32_t* d_ev_off = nullptr;
     double* d_ev_val = nullptr;
@@ -641,6 +642,7 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
     e->d_ev_off = reinterpret_cast<int32_t*>(e->h_ev_dev + off_off);
     e->d_ev_val = reinterpret_cast<double*>(e->h_ev_dev + off_val);
     e->ev_ne = ne;
+    e->ev_nval = int32_t(nval);
     if (e->small_ok) {  // the one-workgroup kernel reads the arrays where they are; flush_evidence() serves every other path
         e->ev_deferred = true;
         e->ev_upload_pending = ne > 0;
@@ -853,7 +855,7 @@ static SmallArgs small_args_of(bn_engine* e, const BpBuffers& b, double eps, int
     a.ent = e->d_s_ent; a.ent_cpt = e->d_s_cpt; a.term = e->d_s_term; a.clist = e->d_s_clist;
     a.bslot = e->d_s_bslot; a.cslot = e->d_s_cslot; a.nv_idx = e->d_s_nvidx; a.nv_slot = e->d_s_nvslot; a.npi_init = e->d_s_init;
     a.state = e->d_s_state; a.sets = SetStrides{}; a.state_stride = 0;
-    a.ev_mode = 0; a.ev_ne = 0; a.ev_node = nullptr; a.ev_off = nullptr; a.ev_val = nullptr; a.ev_meta = nullptr;
+    a.ev_mode = 0; a.ev_ne = 0; a.ev_nval = 0; a.ev_node = nullptr; a.ev_off = nullptr; a.ev_val = nullptr; a.ev_meta = nullptr;
     a.node_off = e->d_s_nodeoff;
     return a;
 }
@@ -869,7 +871,7 @@ static int run_small(bn_engine* e, double eps, int32_t max_sweeps, double* copy_
     for (;;) {
         SmallArgs a = small_args_of(e, buffers_of(e), eps, max_sweeps, begin, e->h_ctl_dev);
         if (e->ev_deferred) {  // the evidence in force was never written to the tile buffers: the kernel reads the staging block
-            a.ev_mode = 1; a.ev_ne = e->ev_ne; a.ev_node = e->d_ev_node; a.ev_off = e->d_ev_off; a.ev_val = e->d_ev_val;
+            a.ev_mode = 1; a.ev_ne = e->ev_ne; a.ev_nval = e->ev_nval; a.ev_node = e->d_ev_node; a.ev_off = e->d_ev_off; a.ev_val = e->d_ev_val;
         }
         if (e->timing) {
             int rc = ensure_events(e, 2);
@@ -1210,16 +1212,17 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     // one staging block [nodes | offs | vals | per-set meta]
     const size_t b_node = 0, b_off = size_t(node_at[n_sets]) * 4, b_val = (b_off + size_t(off_at[n_sets]) * 4 + 7) & ~size_t(7);
     const size_t b_meta = b_val + size_t(val_at[n_sets]) * 8;
-    const size_t bytes = b_meta + size_t(n_sets) * 16;
+    const size_t bytes = b_meta + size_t(n_sets) * 32;
     auto fill = [&](char* dst) {
         if (node_at[n_sets] > 0) {
             std::memcpy(dst + b_node, ev_node, size_t(node_at[n_sets]) * 4);
             std::memcpy(dst + b_val, ev_val, size_t(val_at[n_sets]) * 8);
         }
         if (ev_off) std::memcpy(dst + b_off, ev_off, size_t(off_at[n_sets]) * 4);
-        int32_t* meta = reinterpret_cast<int32_t*>(dst + b_meta);  // per set {count, first node entry, first offset entry, first value}
+        int32_t* meta = reinterpret_cast<int32_t*>(dst + b_meta);  // per set {count, first node entry, first offset entry, first value, values}
         for (int32_t q = 0; q < n_sets; ++q) {
-            meta[4 * q] = ne[q]; meta[4 * q + 1] = int32_t(node_at[q]); meta[4 * q + 2] = int32_t(off_at[q]); meta[4 * q + 3] = int32_t(val_at[q]);
+            meta[8 * q] = ne[q]; meta[8 * q + 1] = int32_t(node_at[q]); meta[8 * q + 2] = int32_t(off_at[q]); meta[8 * q + 3] = int32_t(val_at[q]);
+            meta[8 * q + 4] = int32_t(val_at[q + 1] - val_at[q]); meta[8 * q + 5] = meta[8 * q + 6] = meta[8 * q + 7] = 0;
         }
     };
     bt.ev_b_node = b_node; bt.ev_b_off = b_off; bt.ev_b_val = b_val;
@@ -1431,7 +1434,7 @@ static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
         x.ev_node = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node);
         x.ev_off = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off);
         x.ev_val = reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val);
-        x.ev_meta = per_set_meta ? bt.d_ev_meta : bt.d_ev_meta + 4 * q;  // (a single-set launch reads entry `blockIdx.x` = 0)
+        x.ev_meta = per_set_meta ? bt.d_ev_meta : bt.d_ev_meta + 8 * q;  // (a single-set launch reads entry `blockIdx.x` = 0)
     };
     evidence_of(a, true, 0);
     if (int code = launch_bp_small(a, e->small.waves, e->small.lds_bytes, B, s))

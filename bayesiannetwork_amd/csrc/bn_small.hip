@@ -222,20 +222,27 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
                 }
             }
         } else {
-            // the evidence arrays themselves (mapped host memory or the batch's staging block): requested first, the
-            // initial state is written while they travel
-            const int32_t* meta = a.ev_meta ? a.ev_meta + 4 * set : nullptr;
-            const int ne = meta ? meta[0] : a.ev_ne;
+            // the evidence arrays themselves (mapped host memory): nodes, offsets AND values are requested together -- the
+            // values' range is known from the set's header, so they travel while the initial state is written and wait in
+            // the staging array until the offsets say where they belong (one trip over PCIe instead of two dependent ones)
+            const int32_t* meta = a.ev_meta ? a.ev_meta + 8 * set : nullptr;
+            const int ne = meta ? meta[0] : a.ev_ne, nval = meta ? meta[4] : a.ev_nval;
             const int32_t* ev_node = a.ev_node + (meta ? meta[1] : 0);
             const int32_t* ev_off = a.ev_off + (meta ? meta[2] : 0);
             const double* ev_val = a.ev_val + (meta ? meta[3] : 0);
             int v0 = 0, o0 = 0;
+            double x0 = 0.0;
             if (tid < ne) { v0 = ev_node[tid]; o0 = ev_off[tid]; }
+            if (tid < nval && s == 0) x0 = ev_val[tid];
             for (int y = tid; y < a.N; y += nt) {
                 L.frz[y] = 0;
                 L.npi[c0 * a.N + y] = s == 0 ? a.npi_init[y] : state[2 * a.M + y];
                 L.nlam[c0 * a.N + y] = s == 0 ? 1.0 : state[2 * a.M + a.N + y];
             }
+            __syncthreads();   // (the staging array has been zeroed by every thread's loop above)
+            const bool vals_in_lds = nval <= a.T;
+            if (s == 0 && vals_in_lds)
+                for (int t = tid; t < nval; t += nt) L.stg[t] = t == tid ? x0 : ev_val[t];
             __syncthreads();
             for (int j = tid; j < ne; j += nt) {  // both pi(v) and lambda(v) take the evidence vector (:68-73)
                 const int v = j == tid ? v0 : ev_node[j], o = j == tid ? o0 : ev_off[j];
@@ -243,12 +250,15 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_small_kernel(SmallA
                 for (int i = 0; i < hi - lo; ++i) {
                     L.frz[lo + i] = 1;
                     if (s == 0) {
-                        const double x = ev_val[o + i];
+                        const double x = vals_in_lds ? L.stg[o + i] : ev_val[o + i];
                         L.npi[c0 * a.N + lo + i] = x;
                         L.nlam[c0 * a.N + lo + i] = x;
                     }
                 }
             }
+            __syncthreads();
+            if (s == 0 && vals_in_lds)
+                for (int t = tid; t < nval; t += nt) L.stg[t] = 0.0;  // the padding of the runs is zero again
         }
         for (int x = tid; x < a.M; x += nt) {
             L.pi[c0 * a.M + x] = s == 0 ? 1.0 : state[x];

@@ -77,9 +77,10 @@ struct SmallArgs {
     const int32_t* nv_slot;
     const double* npi_init;
     // Evidence (:68-73).  ev_mode 0: the marks and vectors bp_evidence_kernel left in the tile buffers (b.frozen, b.node0);
-    // 1: the caller's arrays, read in place -- no evidence launch in front of the run: set q has ev_meta[4 q .. 4 q + 3] =
-    // {count, first node entry, first offset entry, first value} (ev_meta null: one set, ev_ne entries from the start)
-    int32_t ev_mode, ev_ne;
+    // 1: the caller's arrays, read in place -- no evidence launch in front of the run: set q has ev_meta[8 q .. 8 q + 4] =
+    // {count, first node entry, first offset entry, first value, number of values} (ev_meta null: one set, ev_ne entries and
+    // ev_nval values from the start)
+    int32_t ev_mode, ev_ne, ev_nval;
     const int32_t* ev_node;
     const int32_t* ev_off;
     const double* ev_val;
