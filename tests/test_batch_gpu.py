@@ -124,3 +124,17 @@ def test_mirror_class_run_batch(bnlib):
         want = bp(pre, 1e-9)
         for v in range(m.n):
             assert np.array_equal(got[q][v], want[v])
+
+
+def test_batch_beyond_64_sets_on_every_path(Engine):
+    """BN_MAX_BATCH_SETS = 256: more than 64 sets per call on the per-sweep launches (blockIdx.y = set), on the resident tiles
+    (4 sets per launch, launch after launch) and -- tests/test_small_gpu.py -- one workgroup per set."""
+    from bayesiannetwork_amd import synth
+    m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)
+    evs = [synth.random_evidence(m, 0.01 * (q % 7), seed=q) for q in range(130)]
+    with Engine(m) as eng:
+        _check_batch(eng, evs, 1e-6, want_path=0, reps=1)
+    g = synth.grid(40, 40, 4, seed=3)
+    evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(70)]
+    with Engine(g) as eng:
+        _check_batch(eng, evs, 1e-4, want_path=2, reps=1)
