@@ -55,6 +55,8 @@ SYMBOLS = [
     ("bn_peer_export", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     ("bn_peer_import", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), i64p, ctypes.c_int32]),
     ("bn_layout_flow", ctypes.c_int, [ctypes.c_void_p, i32p, ctypes.POINTER(ctypes.c_uint32)]),
+    ("bn_mid_plan_get", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, ctypes.POINTER(ctypes.c_uint32), f64p, ctypes.POINTER(ctypes.c_uint32),
+                                       ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), f64p]),
     ("bn_small_plan_get", ctypes.c_int, [ctypes.c_void_p, i32p, ctypes.POINTER(ctypes.c_uint32), f64p, ctypes.POINTER(ctypes.c_uint32),
                                          ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                          f64p]),

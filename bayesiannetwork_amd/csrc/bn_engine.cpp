@@ -238,6 +238,28 @@ struct bn_engine {
     double* d_s_init = nullptr;
     double* d_s_state = nullptr;    // [2 M + 2 N] the state the last launch stopped in
     int32_t* d_s_nodeoff = nullptr;
+    // networks beyond one workgroup's LDS, spread over up to 32 (bn_mid.hip): the same items, state in device memory
+    MidPlan mid;
+    bool mid_ok = false;
+    int mid_mode = 1;               // option "mid": 0 never, 1 where eligible and the resident tiles do not cover the network, 2 wherever eligible
+    int32_t mid_cooldown = 0, mid_aborts = 0;   // runs left on the tile kernels after a grid wait gave up; how often that happened
+    MidPart* d_m_parts = nullptr;
+    SmallEntry* d_m_ent = nullptr;
+    double* d_m_cpt = nullptr;
+    uint32_t* d_m_term = nullptr;
+    uint16_t* d_m_clist = nullptr;
+    SmallSlot* d_m_bslot = nullptr;
+    SmallSlot* d_m_cslot = nullptr;
+    int32_t* d_m_nvidx = nullptr;
+    int32_t* d_m_nvslot = nullptr;
+    double* d_m_init = nullptr;
+    int32_t* d_m_nodeoff = nullptr;
+    int32_t* d_m_msgfirst = nullptr;
+    double* d_m_state = nullptr;    // [4 M + 4 N]: pi[2][M], lam[2][M], npi[2][N], nlam[2][N]
+    uint8_t* d_m_frz = nullptr;
+    char* d_m_sync = nullptr;       // per state slot 64 bytes: the barrier counter, then (8 bytes on) the three residual words
+    int32_t mid_slots = 0;          // state slots allocated (1 for single queries; batches run several sets per launch)
+    int32_t n_cus = 0;
     bool ev_deferred = false;       // the evidence in force sits in the staging block only: the one-workgroup kernel reads it there
                                     // itself (no evidence launch in front of the run); the tile buffers get it -- marks, vectors --
                                     // when another path needs them (flush_evidence)
@@ -276,6 +298,8 @@ static void free_engine(bn_engine* e) {
                         e->d_out, e->d_frozen, e->d_slot_node, e->d_slot_boff, e->d_node_tile, e->d_node_nl,
                         e->d_inrefs, e->d_res_hist, e->d_ctl, e->d_beliefs, e->d_ev, e->d_rsync, e->d_flow, e->d_nbr,
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
+                        e->d_m_parts, e->d_m_ent, e->d_m_cpt, e->d_m_term, e->d_m_clist, e->d_m_bslot, e->d_m_cslot, e->d_m_nvidx, e->d_m_nvslot,
+                        e->d_m_init, e->d_m_nodeoff, e->d_m_msgfirst, e->d_m_state, e->d_m_frz, e->d_m_sync,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state};
         for (void* p : ptrs)
@@ -320,6 +344,23 @@ static void debug_segv_handler(int sig) {
     raise(sig);
 }
 
+// state slots of the mid-size kernel (bn_mid.hip): per slot the four double-buffered state arrays, the marks, the barrier words
+static int mid_reserve_slots(bn_engine* e, int32_t slots) {
+    if (slots <= e->mid_slots) return BN_OK;
+    const SmallPlan& g0 = e->mid.parts[0];
+    if (e->stream) HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->d_m_state) (void)hipFree(e->d_m_state);
+    if (e->d_m_frz) (void)hipFree(e->d_m_frz);
+    if (e->d_m_sync) (void)hipFree(e->d_m_sync);
+    e->d_m_state = nullptr; e->d_m_frz = nullptr; e->d_m_sync = nullptr; e->mid_slots = 0;
+    int r;
+    if ((r = dalloc(&e->d_m_state, size_t(slots) * size_t(4 * g0.M + 4 * g0.N)))) return r;
+    if ((r = dalloc(&e->d_m_frz, size_t(slots) * size_t(g0.N)))) return r;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_m_sync), size_t(slots) * 64));
+    e->mid_slots = slots;
+    return BN_OK;
+}
+
 static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_engine** out) {
     if (!desc || !out) return fail(BN_ERR_ARG, "null argument");
     if (std::getenv("BN_DEBUG")) signal(SIGSEGV, debug_segv_handler);
@@ -350,6 +391,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         } catch (const std::bad_alloc&) {
             delete e;
             return fail(BN_ERR_ALLOC, "out of host memory while building the small-network plan");
+        }
+    }
+    if (p.nranks == 1 && !e->small.ok && !std::getenv("BN_NO_MID")) {  // ... spread over several workgroups (bn_mid.hip)
+        try {
+            build_mid_plan(p, e->mid);
+        } catch (const std::bad_alloc&) {
+            delete e;
+            return fail(BN_ERR_ALLOC, "out of host memory while building the mid-size plan");
         }
     }
     if (desc->device == BN_DEVICE_HOST_ONLY) {
@@ -416,6 +465,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         {   // resident path (bn_resident.hip): one-lane tiles (<= 2 parents, <= 8 children per node), one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, e->device));
+            e->n_cus = prop.multiProcessorCount;
             const int64_t nt = int64_t(p.tiles.size());
             // One 8-wave block per CU is two waves per SIMD sharing its issue slots.  A network whose tiles fit the chip at
             // FOUR waves per block (the CPT slots in LDS keep it at one block per CU) gives every wave a SIMD of its own.
@@ -492,6 +542,47 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                     return fail(BN_ERR_HIP, std::string("bp_small attribute: ") + hipGetErrorString(hipError_t(code)));
                 e->small_ok = true;
             }
+        }
+        if (e->mid.ok) {
+            const MidPlan& mp = e->mid;
+            std::vector<MidPart> parts;
+            std::vector<SmallEntry> ent;
+            std::vector<double> cpt;
+            std::vector<uint32_t> term;
+            std::vector<uint16_t> clist;
+            std::vector<SmallSlot> bslot, cslot;
+            for (const SmallPlan& sp : mp.parts) {
+                MidPart pt{sp.v0, sp.v1, int32_t(ent.size()), int32_t(term.size()), int32_t(clist.size()), int32_t(bslot.size()), int32_t(cslot.size()),
+                           sp.re, sp.rb, sp.rc, sp.T, sp.TT, sp.CL, sp.waves * kWave};
+                parts.push_back(pt);
+                ent.insert(ent.end(), sp.ent.begin(), sp.ent.end());
+                cpt.insert(cpt.end(), sp.ent_cpt.begin(), sp.ent_cpt.end());
+                term.insert(term.end(), sp.term.begin(), sp.term.end());
+                clist.insert(clist.end(), sp.clist.begin(), sp.clist.end());
+                bslot.insert(bslot.end(), sp.bslot.begin(), sp.bslot.end());
+                cslot.insert(cslot.end(), sp.cslot.begin(), sp.cslot.end());
+            }
+            const SmallPlan& g0 = mp.parts[0];  // (carries the tables over all nodes)
+            std::vector<int32_t> msg_first(p.n + 1);
+            for (int v = 0; v <= p.n; ++v) msg_first[v] = int32_t(p.msg_off[v < p.n ? p.in_ptr[v] : p.in_ptr[p.n]]);
+            int r2;
+            if ((r2 = upload(&e->d_m_parts, parts, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_ent, ent, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_cpt, cpt, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_term, term, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_clist, clist, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_bslot, bslot, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_cslot, cslot, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_nvidx, g0.nv_idx, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_nvslot, g0.nv_slot, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_init, g0.npi_init, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_nodeoff, g0.node_off, e->stream))) return r2;
+            if ((r2 = upload(&e->d_m_msgfirst, msg_first, e->stream))) return r2;
+            if ((r2 = mid_reserve_slots(e, 1))) return r2;
+            if (int code = prepare_bp_mid())
+                return fail(BN_ERR_HIP, std::string("bp_mid attribute: ") + hipGetErrorString(hipError_t(code)));
+            if (const char* mm = std::getenv("BN_MID")) e->mid_mode = std::atoi(mm) != 0;
+            e->mid_ok = true;
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -643,7 +734,7 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
     e->d_ev_val = reinterpret_cast<double*>(e->h_ev_dev + off_val);
     e->ev_ne = ne;
     e->ev_nval = int32_t(nval);
-    if (e->small_ok) {  // the one-workgroup kernel reads the arrays where they are; flush_evidence() serves every other path
+    if (e->small_ok || e->mid_ok) {  // the item kernels read the arrays where they are; flush_evidence() serves every other path
         e->ev_deferred = true;
         e->ev_upload_pending = ne > 0;
         return BN_OK;
@@ -906,6 +997,80 @@ static int run_small(bn_engine* e, double eps, int32_t max_sweeps, double* copy_
     return BN_OK;
 }
 
+// the mid-size kernel is the path of choice for this engine (measured: grids, chains and trees run faster on the resident tiles)
+static bool mid_applies(const bn_engine* e) {
+    return e->mid_ok && e->multisweep != 0 && (e->mid_mode == 2 || (e->mid_mode == 1 && !e->resident_ok));
+}
+
+// Networks spread over several workgroups (bn_mid.hip).  The arguments of a launch over the sets [set_base, set_base + n)
+// of a batch (single query: set 0 of one) working in state slots [0, n).
+static MidArgs mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides& st, Ctl* h_ctl_dev, double eps, int32_t max_sweeps,
+                           int32_t begin, int32_t set_base, int32_t slot_base) {
+    const SmallPlan& g0 = e->mid.parts[0];
+    MidArgs a{};
+    a.b = b0; a.eps = eps; a.max_sweeps = max_sweeps; a.sweep_begin = begin; a.budget = kSmallBudget; a.run_id = e->run_id;
+    a.host_ctl = h_ctl_dev;
+    a.n = g0.n; a.N = g0.N; a.M = g0.M; a.nparts = int32_t(e->mid.parts.size());
+    a.parts = e->d_m_parts; a.ent = e->d_m_ent; a.ent_cpt = e->d_m_cpt; a.term = e->d_m_term; a.clist = e->d_m_clist;
+    a.bslot = e->d_m_bslot; a.cslot = e->d_m_cslot; a.nv_idx = e->d_m_nvidx; a.nv_slot = e->d_m_nvslot; a.npi_init = e->d_m_init;
+    a.node_off = e->d_m_nodeoff; a.msg_first = e->d_m_msgfirst;
+    a.ev_mode = 0; a.ev_ne = 0; a.ev_node = nullptr; a.ev_off = nullptr; a.ev_val = nullptr; a.ev_meta = nullptr;
+    a.state_stride = 4 * int64_t(g0.M) + 4 * int64_t(g0.N);
+    a.pi = e->d_m_state; a.lam = a.pi + 2 * size_t(g0.M); a.npi = a.lam + 2 * size_t(g0.M); a.nlam = a.npi + 2 * size_t(g0.N);
+    a.frz = e->d_m_frz;
+    a.bar = reinterpret_cast<unsigned*>(e->d_m_sync);
+    a.res = reinterpret_cast<unsigned long long*>(e->d_m_sync + 8);
+    a.abort = e->h_abort_dev;
+    a.timeout_ticks = 5000000ull;  // one wait: 50 ms of the 100 MHz clock
+    a.sets = st; a.set_base = set_base; a.slot_base = slot_base;
+    return a;
+}
+// launch + wait; BN_ERR_STATE: a grid wait gave up (the caller redoes the work on the tile kernels)
+static int mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to) {
+    hipStream_t s = e->stream;
+    *e->h_abort = 0;
+    HIPCHK(hipMemsetAsync(e->d_m_sync + size_t(a.slot_base) * 64, 0, size_t(n_sets) * 64, s));
+    if (int code = launch_bp_mid(a, e->mid.waves, e->mid.rounds, e->mid.lds_bytes, n_sets, s))
+        return fail(BN_ERR_HIP, std::string("bp_mid launch failed: ") + hipGetErrorString(hipError_t(code)));
+    if (copy_to) HIPCHK(hipMemcpyAsync(copy_to, copy_from, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    e->ev_upload_pending = false;
+    if (*e->h_abort != 0) {
+        *e->h_abort = 0;
+        return fail(BN_ERR_STATE, "a workgroup of the mid-size kernel gave up its grid wait");
+    }
+    return BN_OK;
+}
+// one query: one launch for the whole run (more only beyond 65 536 iterations)
+static int run_mid(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to) {
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    int32_t begin = 0, launches = 0;
+    double dev_ticks = 0.0;
+    const BpBuffers b = buffers_of(e);
+    for (;;) {
+        MidArgs a = mid_args_of(e, b, SetStrides{}, e->h_ctl_dev, eps, max_sweeps, begin, 0, 0);
+        if (e->ev_deferred) {  // the evidence in force was never written to the tile buffers: the kernel reads the staging block
+            a.ev_mode = 1; a.ev_ne = e->ev_ne; a.ev_node = e->d_ev_node; a.ev_off = e->d_ev_off; a.ev_val = e->d_ev_val;
+        }
+        if (int rc = mid_launch(e, a, 1, b.beliefs, copy_to)) return rc;
+        ++launches;
+        if (e->h_ctl->done < 0) return fail(BN_ERR_STATE, "a workgroup of the mid-size kernel gave up its grid wait");
+        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_HIP, "bp_mid kernel did not report (stale control block)");
+        dev_ticks += double(e->h_ctl->t_last - e->h_ctl->t_first);
+        if (e->h_ctl->done != 0) break;
+        begin = e->h_ctl->n_sweeps;
+    }
+    const bool rows_were_clean = e->rows_clean;  // this path never touches the residual slots
+    note_run_result(e);
+    e->rows_clean = rows_were_clean;
+    e->last_path = 4;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = 0.f;
+    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
+    return BN_OK;
+}
+
 static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
                            double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -943,6 +1108,22 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
         if (residual_out) *residual_out = e->last_ctl.last_res;
         return BN_OK;
+    }
+    // networks beyond one workgroup's LDS that the resident tiles do not cover: the same items over several workgroups (bn_mid.hip)
+    const bool try_mid = mid_applies(e);
+    if (try_mid && e->mid_cooldown > 0) --e->mid_cooldown;
+    else if (try_mid) {
+        rc = run_mid(e, eps, max_sweeps, copy_to);
+        if (rc == BN_OK) {
+            e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+            if (residual_out) *residual_out = e->last_ctl.last_res;
+            return BN_OK;
+        }
+        if (rc != BN_ERR_STATE) return rc;
+        ++e->mid_aborts;
+        e->mid_cooldown = 64;   // something else holds CUs: the tile kernels for a while
+        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] mid-size kernel aborted (%s); tile kernels for the next 64 runs\n", g_err.c_str());
     }
     if ((rc = flush_evidence(e))) return rc;  // the tile kernels read the evidence from their own buffers
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
@@ -1030,6 +1211,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "overlap") == 0) { e->overlap = value != 0; return BN_OK; }
     if (std::strcmp(name, "beliefs_direct") == 0) { e->beliefs_direct = value != 0; return BN_OK; }
     if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
+    if (std::strcmp(name, "mid") == 0) { e->mid_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "small") == 0) { e->small_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "poll_sleep") == 0) { e->poll_sleep = std::max(0, std::min(value, 64)); return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
@@ -1048,12 +1230,15 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
     if (std::strcmp(name, "resident_waves") == 0) return e->resident_waves;
     if (std::strcmp(name, "resident_aborts") == 0) return e->resident_aborts;
+    if (std::strcmp(name, "mid_eligible") == 0) return e->mid.ok ? 1 : 0;
+    if (std::strcmp(name, "mid_parts") == 0) return e->mid.ok ? int64_t(e->mid.parts.size()) : 0;
+    if (std::strcmp(name, "mid_aborts") == 0) return e->mid_aborts;
     if (std::strcmp(name, "small_eligible") == 0) return e->small.ok ? 1 : 0;
     if (std::strcmp(name, "small_waves") == 0) return e->small.ok ? e->small.waves : 0;
     if (std::strcmp(name, "small_lds_bytes") == 0) return e->small.ok ? int64_t(e->small.lds_bytes) : 0;
     return fail(BN_ERR_ARG, std::string("unknown info ") + name);
 }
-// 0 per-sweep launches, 2 resident tiles (bn_resident.hip), 3 one workgroup with the state in LDS (bn_small.hip)
+// 0 per-sweep launches, 2 resident tiles (bn_resident.hip), 3 one workgroup with the state in LDS (bn_small.hip), 4 the same items over several workgroups (bn_mid.hip)
 extern "C" int bn_bp_last_path(bn_engine* e) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     return e->last_path;
@@ -1127,6 +1312,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
     rc = BN_OK;
     if (!e->plan.latency_rules_applied || e->plan.nranks > 1 || n_sets < 2) return nullptr;
     if (e->small_ok && e->small_mode != 0 && e->multisweep != 0) return nullptr;  // one workgroup per set (bn_small.hip): the layout plays no part
+    if (mid_applies(e)) return nullptr;                                           // ... or a few per set (bn_mid.hip)
     if (!e->dense) {
         const Plan& p = e->plan;
         bn_model_desc d;
@@ -1140,6 +1326,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
     }
     e->dense->multisweep = e->multisweep;
     e->dense->small_mode = e->small_mode;
+    e->dense->mid_mode = e->mid_mode;
     e->dense->timing = e->timing;
     return e->dense;
 }
@@ -1229,7 +1416,7 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     bt.ev_node_at = node_at; bt.ev_off_at = off_at; bt.ev_val_at = val_at;
     bt.ev_deferred = true;
     bt.beliefs_on_host = false;
-    if (e->small_ok) {
+    if (e->small_ok || e->mid_ok) {
         // Small networks: the block is page-locked host memory that the kernels read in place -- the one-workgroup kernel (one
         // workgroup per set) each set's arrays, no copy command, no evidence launch per set, no synchronisation here; the tile
         // buffers get the marks and vectors only if another path runs the batch (flush_batch_evidence).  (No kernel is in
@@ -1470,11 +1657,68 @@ static int run_batch_small(bn_engine* e, double eps, int32_t max_sweeps) {
     return BN_OK;
 }
 
+// Mid-size networks: every set runs exactly like a single query (same kernel, same bits), as many sets per launch as fit the
+// chip with a workgroup per CU (the grid barrier needs every workgroup of a set resident).  BN_ERR_STATE: a grid wait gave up.
+static int run_batch_mid(bn_engine* e, double eps, int32_t max_sweeps) {
+    bn_engine::Batch& bt = e->batch;
+    const Plan& p = e->plan;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    const int32_t B = bt.n_sets, nparts = int32_t(e->mid.parts.size());
+    const int32_t per_launch = std::max(1, std::min(B, (e->n_cus * 9 / 10) / nparts));
+    int rc;
+    if ((rc = mid_reserve_slots(e, per_launch))) return rc;
+    const SetStrides st{p.rec_total_doubles, p.node_doubles, int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap};
+    const BpBuffers b0 = batch_buffers_of(e, 0);
+    auto evidence_of = [&](MidArgs& x) {
+        if (!bt.ev_deferred) return;  // the tile buffers hold it
+        x.ev_mode = 1;
+        x.ev_node = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node);
+        x.ev_off = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off);
+        x.ev_val = reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val);
+        x.ev_meta = bt.d_ev_meta;
+    };
+    int32_t launches = 0;
+    for (int32_t first = 0; first < B; first += per_launch) {
+        const int32_t count = std::min(per_launch, B - first);
+        MidArgs a = mid_args_of(e, b0, st, bt.h_ctl_dev, eps, max_sweeps, 0, first, 0);
+        evidence_of(a);
+        if ((rc = mid_launch(e, a, count, nullptr, nullptr))) return rc;
+        ++launches;
+        for (int32_t q = first; q < first + count; ++q) {
+            if (bt.h_ctl[q].done < 0) return fail(BN_ERR_STATE, "a workgroup of the mid-size kernel gave up its grid wait");
+            if (bt.h_ctl[q].run_id != e->run_id) return fail(BN_ERR_HIP, "bp_mid kernel did not report (stale control block)");
+            while (bt.h_ctl[q].done == 0) {  // a set that used up the launch's budget of iterations goes on by itself, in its slot
+                MidArgs c = mid_args_of(e, b0, st, bt.h_ctl_dev, eps, max_sweeps, bt.h_ctl[q].n_sweeps, q, q - first);
+                evidence_of(c);
+                if ((rc = mid_launch(e, c, 1, nullptr, nullptr))) return rc;
+                ++launches;
+                if (bt.h_ctl[q].done < 0) return fail(BN_ERR_STATE, "a workgroup of the mid-size kernel gave up its grid wait");
+            }
+        }
+    }
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int32_t q = 0; q < B; ++q) {
+        bt.sweeps[q] = bt.h_ctl[q].n_sweeps;
+        bt.residual[q] = bt.h_ctl[q].last_res;
+        t0 = std::min(t0, bt.h_ctl[q].t_first);
+        t1 = std::max(t1, bt.h_ctl[q].t_last);
+    }
+    bt.predicted_sweeps = *std::max_element(bt.sweeps.begin(), bt.sweeps.end());
+    e->last_path = 4;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = 0.f;
+    e->stats.sweep_devclock_ms = t1 > t0 ? float(double(t1 - t0) * 1e-5) : 0.f;
+    e->stats.sweeps = bt.predicted_sweeps;
+    return BN_OK;
+}
+
 extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->batch_on_dense && e->dense) {
         e->dense->multisweep = e->multisweep;
         e->dense->small_mode = e->small_mode;
+        e->dense->mid_mode = e->mid_mode;
         const int rc = bn_bp_run_batch_device(e->dense, eps, max_sweeps, sweeps_out, residual_out);
         if (rc == BN_OK) adopt_batch_outcome(e);
         return rc;
@@ -1499,10 +1743,25 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
     const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
     const bool batch_small = e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state != nullptr;
-    if (!batch_small && (rc = flush_batch_evidence(e))) return rc;
-    rc = BN_ERR_STATE;
+    bool batch_mid = !batch_small && mid_applies(e) && bt.ev_base != nullptr;
+    if (batch_mid && e->mid_cooldown > 0) { --e->mid_cooldown; batch_mid = false; }
+    if (batch_mid) {
+        rc = run_batch_mid(e, eps, max_sweeps);
+        if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
+        if (rc == BN_ERR_STATE) {   // a grid wait gave up: the whole batch again on the tile kernels
+            ++e->mid_aborts;
+            e->mid_cooldown = 64;
+            batch_mid = false;
+            bt.sweeps.assign(bt.n_sets, 0);
+            bt.residual.assign(bt.n_sets, 0.0);
+        }
+    }
+    if (!batch_small && !batch_mid && (rc = flush_batch_evidence(e))) return rc;
+    if (!batch_mid) rc = BN_ERR_STATE;
     if (batch_small) {
         if ((rc = run_batch_small(e, eps, max_sweeps))) return rc;
+    } else if (batch_mid) {
+        // done above
     } else if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
         rc = run_batch_resident(e, eps, max_sweeps);
@@ -1893,6 +2152,12 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
     if (!e || !pi_msg_out || !lambda_msg_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
     ON_DEVICE(e);
+    if (e->last_path == 4) {  // bn_mid.hip keeps them in CSR edge order, two buffers: the run stopped in buffer n_sweeps & 1
+        const size_t M = size_t(e->mid.parts[0].M), par = size_t(e->last_ctl.n_sweeps & 1);
+        HIPCHK(hipMemcpy(pi_msg_out, e->d_m_state + par * M, sizeof(double) * M, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lambda_msg_out, e->d_m_state + 2 * M + par * M, sizeof(double) * M, hipMemcpyDeviceToHost));
+        return BN_OK;
+    }
     if (e->last_path == 3) {  // bn_small.hip leaves the messages in CSR edge order
         const size_t bytes = sizeof(double) * size_t(e->small.M);
         HIPCHK(hipMemcpy(pi_msg_out, e->d_s_state, bytes, hipMemcpyDeviceToHost));
@@ -1917,11 +2182,28 @@ extern "C" int bn_bp_last_stats(bn_engine* e, bn_bp_stats* out) {
 // The plan of the one-workgroup path (bn_small.hpp; tests emulate the kernel on it).  dims_out[12] = n, N, M, S, T, TT, CL,
 // waves, re, rb, rc, mmax; the arrays (any may be null) are sized from those: ent [re * 64 waves][2], ent_cpt [re * 64 waves],
 // term [TT], clist [CL], bslot / cslot [rb | rc * 64 waves][4], npi_init [N].  BN_ERR_STATE when the network is not eligible.
+static int small_plan_copy(const SmallPlan& sp, const SmallPlan& tables, int32_t* dims_out, uint32_t* ent, double* ent_cpt, uint32_t* term,
+                           uint16_t* clist, uint32_t* bslot, uint32_t* cslot, double* npi_init);
 extern "C" int bn_small_plan_get(bn_engine* e, int32_t* dims_out, uint32_t* ent, double* ent_cpt, uint32_t* term, uint16_t* clist,
                                  uint32_t* bslot, uint32_t* cslot, double* npi_init) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     const SmallPlan& sp = e->small;
     if (!sp.ok) return fail(BN_ERR_STATE, "not eligible for the one-workgroup path: " + (sp.why.empty() ? std::string("disabled") : sp.why));
+    return small_plan_copy(sp, sp, dims_out, ent, ent_cpt, term, clist, bslot, cslot, npi_init);
+}
+// ... of part `part` of the plan that spreads a mid-size network over several workgroups (bn_get_info "mid_parts"); the same
+// layout (message / node-vector indices global, staging places the part's own); dims_out[12..13] = the part's node range
+extern "C" int bn_mid_plan_get(bn_engine* e, int32_t part, int32_t* dims_out, uint32_t* ent, double* ent_cpt, uint32_t* term, uint16_t* clist,
+                               uint32_t* bslot, uint32_t* cslot, double* npi_init) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (!e->mid.ok) return fail(BN_ERR_STATE, "not eligible for the mid-size path: " + (e->mid.why.empty() ? std::string("not needed or disabled") : e->mid.why));
+    if (part < 0 || part >= int32_t(e->mid.parts.size())) return fail(BN_ERR_ARG, "part index out of range");
+    const SmallPlan& sp = e->mid.parts[part];
+    if (dims_out) { dims_out[12] = sp.v0; dims_out[13] = sp.v1; }
+    return small_plan_copy(sp, e->mid.parts[0], dims_out, ent, ent_cpt, term, clist, bslot, cslot, npi_init);
+}
+static int small_plan_copy(const SmallPlan& sp, const SmallPlan& tables, int32_t* dims_out, uint32_t* ent, double* ent_cpt, uint32_t* term,
+                           uint16_t* clist, uint32_t* bslot, uint32_t* cslot, double* npi_init) {
     if (dims_out) {
         const int32_t d[12] = {sp.n, sp.N, sp.M, sp.S, sp.T, sp.TT, sp.CL, sp.waves, sp.re, sp.rb, sp.rc, sp.mmax};
         std::copy(d, d + 12, dims_out);
@@ -1932,7 +2214,7 @@ extern "C" int bn_small_plan_get(bn_engine* e, int32_t* dims_out, uint32_t* ent,
     if (clist) std::copy(sp.clist.begin(), sp.clist.begin() + sp.CL, clist);
     if (bslot) std::memcpy(bslot, sp.bslot.data(), sp.bslot.size() * sizeof(SmallSlot));
     if (cslot) std::memcpy(cslot, sp.cslot.data(), sp.cslot.size() * sizeof(SmallSlot));
-    if (npi_init) std::copy(sp.npi_init.begin(), sp.npi_init.end(), npi_init);
+    if (npi_init) std::copy(tables.npi_init.begin(), tables.npi_init.end(), npi_init);
     return BN_OK;
 }
 

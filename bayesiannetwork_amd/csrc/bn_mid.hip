@@ -1,0 +1,385 @@
+// bn_mid.hip -- networks too large for ONE workgroup's LDS but small enough for a few dozen: the items of bn_small.hip
+// (CPT entries, accumulator elements, product elements -- bn_small.hpp) spread over up to 32 workgroups by contiguous
+// node ranges, one launch for the whole run.  Reference: belief_propagation.hpp:33-158.
+//
+// What differs from bn_small.hip: the STATE (pi / lambda-messages, node vectors, evidence marks) lives in device memory
+// and is read and written with agent-scope accesses (sc1: through to L2 / memory, coherent across the XCDs); only the
+// staged terms, the parent terms and the child lists of a workgroup's own nodes are in its LDS.  An iteration is
+//   entries (gathers from memory) -> staging (LDS) -> s_barrier -> accumulators + products -> stores to memory,
+//   the workgroup's maximum_difference -> one atomic max -> GRID barrier (one atomic add per workgroup on a counter
+//   that only grows, one polling thread per workgroup) -> every workgroup reads the same word: same stop decision.
+// Sums and products keep the reference's order: bit-identical to the oracle, like bn_small.hip.
+// Every wait is bounded: a workgroup that gives up raises *abort (page-locked host word) and leaves; the host redoes the
+// run with one launch per sweep.
+#include "bn_small.hpp"
+#include "bn_tiles.hpp"
+#include "bn_small_dev.hpp"
+
+namespace bnmi {
+
+__device__ __forceinline__ double ld_state(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_state(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct MidLds {
+    double* stg;        // [T] this workgroup's staged terms
+    uint32_t* term;     // [TT]
+    uint16_t* clist;    // [CL]
+    double* scratch;    // [waves][64] normalisation: a line per wave
+    unsigned long long* red;  // [2][16]
+    unsigned* flag;     // [1] set by the polling thread: the grid wait gave up
+};
+
+__device__ __forceinline__ MidLds mid_carve(char* base, const MidPart& pt) {
+    MidLds L;
+    double* d = reinterpret_cast<double*>(base);
+    L.stg = d; d += pt.T;
+    L.scratch = d; d += kSmallMaxWaves * kWave;
+    L.red = reinterpret_cast<unsigned long long*>(d); d += 2 * 16;
+    L.term = reinterpret_cast<uint32_t*>(d);
+    char* c = reinterpret_cast<char*>(L.term + (((pt.TT > 0 ? pt.TT : 1) + 1) & ~1));
+    L.clist = reinterpret_cast<uint16_t*>(c);
+    c += (size_t(pt.CL > 0 ? pt.CL : 1) * 2 + 7) & ~size_t(7);
+    L.flag = reinterpret_cast<unsigned*>(c);
+    return L;
+}
+
+// One CPT entry (bn_small.hip small_entry, state read from memory)
+template <int MM, bool REG>
+__device__ __forceinline__ void mid_entry(const MidLds& L, const double* pi_cur, const double* nlam_cur, SmallEntry h, double c,
+                                          const uint32_t (&treg)[4]) {
+    if (((h.y >> 24) & 1u) == 0) return;
+    const int m = int((h.y >> 16) & 0xffu), tbase = int(h.y & 0xffffu);
+    const double li = ld_state(nlam_cur + (h.x & 0xffffu));
+    uint32_t tw[MM > 0 ? MM : 1];
+    double pj[MM > 0 ? MM : 1];
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        if (REG && MM <= 4) tw[j] = treg[j < 4 ? j : 0];
+        else tw[j] = j < m ? L.term[tbase + j] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < MM; ++j) {
+        const double x = ld_state(pi_cur + (tw[j] & 0xffffu));
+        pj[j] = j < m ? x : 1.0;
+    }
+    double v = c;
+#pragma unroll
+    for (int j = 0; j < MM; ++j) v *= pj[j];
+    L.stg[h.x >> 16] = v;
+    const double lc = li * c;
+#pragma unroll
+    for (int jt = 0; jt < MM; ++jt) {
+        double w = lc;
+#pragma unroll
+        for (int j = 0; j < MM; ++j)
+            if (j != jt) w *= pj[j];
+        if (jt < m) L.stg[tw[jt] >> 16] = w;
+    }
+}
+template <bool REG>
+__device__ __forceinline__ void mid_entry_any(int mm, const MidLds& L, const double* pi_cur, const double* nlam_cur, SmallEntry h, double c,
+                                              const uint32_t (&treg)[4]) {
+    switch (mm) {
+        case 0: return mid_entry<0, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 1: return mid_entry<1, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 2: return mid_entry<2, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 3: return mid_entry<3, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 4: return mid_entry<4, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        case 5: case 6: return mid_entry<6, REG>(L, pi_cur, nlam_cur, h, c, treg);
+        default: return mid_entry<8, REG>(L, pi_cur, nlam_cur, h, c, treg);
+    }
+}
+
+// normalisation of the vector whose elements sit in adjacent lanes of this wave, through the wave's scratch line (:298-311)
+__device__ __forceinline__ double mid_normalize(double* line, int lane, int k, int at, double val, int kmax) {
+    line[lane] = val;
+    lds_fence();
+    const int first = lane - at;
+    double sum = 0.0;
+    for (int r0 = 0; r0 < kmax; r0 += 4) {
+        double x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = line[first + (r0 + q < k ? r0 + q : 0)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sum += r0 + q < k ? x[q] : 0.0;  // + 0.0 past the end: a sum started from +0.0 is never -0.0
+    }
+    lds_fence();
+    return val / sum;
+}
+
+// Grid barrier number `gen` (1, 2, ...): every workgroup's stores are out, one thread counts the workgroup off and polls.
+// Returns false when the wait gave up (or another workgroup has).
+__device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds& L, unsigned gen, int tid) {
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
+    __syncthreads();
+    if (tid == 0) {
+        unsigned give_up = 0;
+        __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = gen * unsigned(a.nparts);
+        const unsigned long long t0 = wall_clock64();
+        unsigned polls = 0;
+        while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++polls & 255u) == 0) {
+                if (wall_clock64() - t0 > a.timeout_ticks || __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+                    __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    give_up = 1;
+                    break;
+                }
+            }
+        }
+        *L.flag = give_up;
+    }
+    __syncthreads();
+    return *L.flag == 0;
+}
+
+template <int ROUNDS>
+__global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs a_in) {
+    extern __shared__ __attribute__((aligned(16))) char mid_lds[];
+    MidArgs a = a_in;
+    BpBuffers b = a.b;
+    {   // this launch's set blockIdx.y: its slice of the batch's buffers, its state slot
+        const int set = a.set_base + int(blockIdx.y), slot = a.slot_base + int(blockIdx.y);
+        shift_to_set(b, a.sets, set);
+        a.host_ctl += set;
+        if (a.ev_meta) a.ev_meta += 8 * set;
+        a.pi += slot * a.state_stride; a.lam += slot * a.state_stride; a.npi += slot * a.state_stride; a.nlam += slot * a.state_stride;
+        a.frz += int64_t(slot) * a.N;
+        a.bar += slot * 16;
+        a.res += slot * 8;
+    }
+    const MidPart pt = a.parts[blockIdx.x];
+    const MidLds L = mid_carve(mid_lds, pt);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* line = L.scratch + wave * kWave;
+    const unsigned long long t_first = wall_clock64();
+    const bool mine = tid < pt.nt;   // (the launch is as wide as the widest part)
+
+    // ---- this thread's items, kept in registers for the whole run
+    SmallEntry ent[ROUNDS];
+    double ecpt[ROUNDS];
+    SmallSlot bs[ROUNDS], cs[ROUNDS];
+    constexpr bool kTermsInRegs = ROUNDS == 1;
+    uint32_t treg[ROUNDS][4];
+    int e_mm[ROUNDS], b_rmax[ROUNDS], b_kmax[ROUNDS], c_dmax[ROUNDS], c_kmax[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        ent[r] = SmallEntry{0u, 0u}; ecpt[r] = 0.0;
+        bs[r] = SmallSlot{0u, 0u, 0u, 0u}; cs[r] = SmallSlot{0u, 0u, 0u, 0u};
+        if (mine && r < pt.re) { ent[r] = a.ent[pt.ent_off + r * pt.nt + tid]; ecpt[r] = a.ent_cpt[pt.ent_off + r * pt.nt + tid]; }
+        if (mine && r < pt.rb) bs[r] = a.bslot[pt.bslot_off + r * pt.nt + tid];
+        if (mine && r < pt.rc) cs[r] = a.cslot[pt.cslot_off + r * pt.nt + tid];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            treg[r][j] = 0u;
+            if (kTermsInRegs && ((ent[r].y >> 24) & 1u) && j < int((ent[r].y >> 16) & 0xffu)) treg[r][j] = a.term[pt.term_off + (ent[r].y & 0xffffu) + j];
+        }
+        e_mm[r] = wave_imax(((ent[r].y >> 24) & 1u) ? int((ent[r].y >> 16) & 0xffu) : 0);
+        b_rmax[r] = wave_imax(int(bs[r].x >> 16));
+        b_kmax[r] = wave_imax(bs[r].z != 0 ? int((bs[r].y >> 16) & 0xffu) : 0);
+        c_dmax[r] = wave_imax(int(cs[r].x >> 16));
+        c_kmax[r] = wave_imax((cs[r].z & 0xffu) != 0 ? int((cs[r].y >> 16) & 0xffu) : 0);
+    }
+    for (int t = tid; t < pt.TT; t += nt) L.term[t] = a.term[pt.term_off + t];
+    for (int t = tid; t < pt.CL; t += nt) L.clist[t] = a.clist[pt.clist_off + t];
+    for (int t = tid; t < pt.T; t += nt) L.stg[t] = 0.0;  // the padding of the runs stays zero for the whole run
+    if (tid < 32) L.red[tid] = 0ull;
+    if (tid == 0) *L.flag = 0u;
+
+    // ---- initial state (:33-73) of this workgroup's nodes [v0, v1): their vectors, the messages on their in-edges
+    int s = a.sweep_begin;
+    const int y0 = a.node_off[pt.v0], y1 = a.node_off[pt.v1];
+    const int x0 = a.msg_first[pt.v0], x1 = a.msg_first[pt.v1];
+    if (s == 0) {
+        for (int y = y0 + tid; y < y1; y += nt) {
+            bool frozen = false;
+            double ev = 0.0;
+            if (a.ev_mode == 0) {   // marks and vectors bp_evidence_kernel left in the tile buffers
+                frozen = b.frozen[a.nv_slot[y]] == b.frozen_mark;
+                ev = b.node0[a.nv_idx[y]];
+            }
+            a.frz[y] = frozen ? 1 : 0;
+            st_state(a.npi + y, frozen ? ev : a.npi_init[y]);
+            st_state(a.nlam + y, frozen ? ev : 1.0);
+        }
+        for (int x = x0 + tid; x < x1; x += nt) { st_state(a.pi + x, 1.0); st_state(a.lam + x, 1.0); }
+        if (a.ev_mode != 0) {   // the evidence arrays themselves: every workgroup walks the list and takes its own nodes
+            const int32_t* meta = a.ev_meta;
+            const int ne = meta ? meta[0] : a.ev_ne;
+            const int32_t* ev_node = a.ev_node + (meta ? meta[1] : 0);
+            const int32_t* ev_off = a.ev_off + (meta ? meta[2] : 0);
+            const double* ev_val = a.ev_val + (meta ? meta[3] : 0);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            for (int j = tid; j < ne; j += nt) {
+                const int v = ev_node[j];
+                if (v < pt.v0 || v >= pt.v1) continue;
+                const int o = ev_off[j], lo = a.node_off[v], hi = a.node_off[v + 1];
+                for (int i = 0; i < hi - lo; ++i) {   // both pi(v) and lambda(v) take the evidence vector (:68-73)
+                    const double x = ev_val[o + i];
+                    a.frz[lo + i] = 1;
+                    st_state(a.npi + lo + i, x);
+                    st_state(a.nlam + lo + i, x);
+                }
+            }
+        }
+    }
+    unsigned gen = 1;
+    bool alive = mid_grid_barrier(a, L, gen, tid);
+
+    int done = 0;
+    double r_last = 0.0;
+    while (alive) {
+        const int cur = s & 1;
+        const double* pi_cur = a.pi + cur * a.M;
+        const double* lam_cur = a.lam + cur * a.M;
+        const double* npi_cur = a.npi + cur * a.N;
+        const double* nlam_cur = a.nlam + cur * a.N;
+        double* pi_new = a.pi + (cur ^ 1) * a.M;
+        double* lam_new = a.lam + (cur ^ 1) * a.M;
+        double* npi_new = a.npi + (cur ^ 1) * a.N;
+        double* nlam_new = a.nlam + (cur ^ 1) * a.N;
+        double wres = 0.0;
+        // the residual word of the iteration after this one: its readers (iteration s - 2) are all behind the last barrier
+        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.res + (s + 1) % 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- phase 1: entry items
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (r < pt.re) mid_entry_any<kTermsInRegs>(e_mm[r], L, pi_cur, nlam_cur, ent[r], ecpt[r], treg[r]);
+        __syncthreads();
+        // ---- phase 2a: accumulator items
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r >= pt.rb) break;
+            const SmallSlot q = bs[r];
+            const int kind = int(q.z & 0xffu);
+            const int base = int(q.x & 0xffffu);
+            const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
+            double old = 0.0;
+            bool frozen = false;
+            if (kind == 1) { old = ld_state(npi_cur + out_idx); frozen = a.frz[out_idx] != 0; }
+            if (kind == 2) old = ld_state(lam_cur + out_idx);
+            const double* ptr = L.stg + base;
+            const int n4 = b_rmax[r];  // a multiple of 4
+            double acc = 0.0;
+            double x0_ = ptr[0], x1_ = ptr[1], x2_ = ptr[2], x3_ = ptr[3];
+            int r0 = 0;
+            for (; r0 + 8 <= n4; r0 += 8) {
+                const double y0_ = ptr[r0 + 4], y1_ = ptr[r0 + 5], y2_ = ptr[r0 + 6], y3_ = ptr[r0 + 7];
+                acc += x0_; acc += x1_; acc += x2_; acc += x3_;
+                x0_ = ptr[r0 + 8]; x1_ = ptr[r0 + 9]; x2_ = ptr[r0 + 10]; x3_ = ptr[r0 + 11];
+                acc += y0_; acc += y1_; acc += y2_; acc += y3_;
+            }
+            if (r0 < n4) { acc += x0_; acc += x1_; acc += x2_; acc += x3_; }
+            const double val = mid_normalize(line, lane, kind != 0 ? k : 0, kind != 0 ? at : 0, acc, b_kmax[r]);
+            if (kind == 1) st_state(npi_new + out_idx, frozen ? old : val);  // evidence nodes are never updated (:177)
+            if (kind == 2) {
+                st_state(lam_new + out_idx, val);
+                wres = res_acc(wres, fabs(val - old));
+            }
+        }
+        // ---- phase 2b: product items (old state only)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r >= pt.rc) break;
+            const SmallSlot q = cs[r];
+            const int kind = int(q.z & 0xffu), skip = int((q.z >> 8) & 0xffffu);
+            const int cl = int(q.x & 0xffffu), deg = int(q.x >> 16);
+            const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
+            double old = 0.0;
+            bool frozen = false;
+            if (kind == 4) old = ld_state(pi_cur + out_idx);
+            if (kind == 3) { old = ld_state(nlam_cur + out_idx); frozen = a.frz[out_idx] != 0; }
+            // lambda(v): from 1.0 (:220-238); pi-message: from pi(v)[i] (:202-218); children in ascending order
+            double val = kind == 4 ? ld_state(npi_cur + (q.w & 0xffffu)) : 1.0;
+            for (int c0 = 0; c0 < c_dmax[r]; c0 += 4) {
+                double f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool has = c0 + u < deg;
+                    const int cb = L.clist[has ? cl + c0 + u : 0];
+                    f[u] = has ? ld_state(lam_cur + cb + at) : 1.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) val *= (c0 + u < deg && c0 + u != skip) ? f[u] : 1.0;  // x * 1.0 == x
+            }
+            val = mid_normalize(line, lane, kind != 0 ? k : 0, kind != 0 ? at : 0, val, c_kmax[r]);
+            if (kind == 3) st_state(nlam_new + out_idx, frozen ? old : val);
+            if (kind == 4) {
+                st_state(pi_new + out_idx, val);
+                wres = res_acc(wres, fabs(val - old));
+            }
+        }
+        // maximum_difference (:105-131): wave -> workgroup (LDS) -> one atomic max per workgroup -> grid barrier -> the same word
+        const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
+        if (lane == 0) L.red[cur * 16 + wave] = bits;
+        __syncthreads();
+        if (wave == 0) {
+            const unsigned long long bm = wave_umax64_dpp<true>(L.red[cur * 16 + (lane & 15)]);
+            if (lane == 0 && bm != 0ull) __hip_atomic_fetch_max(a.res + s % 3, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++gen;
+        alive = mid_grid_barrier(a, L, gen, tid);
+        if (!alive) break;
+        const unsigned long long mx = __hip_atomic_load(a.res + s % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double rr = __longlong_as_double((long long)mx);
+        rr = rr < DBL_MIN ? DBL_MIN : rr;
+        r_last = rr;
+        if (blockIdx.x == 0 && tid == 0 && s < b.res_cap) b.res_hist[s] = rr;
+        ++s;
+        if (rr < a.eps) { done = 1; break; }                                 // strict < (:147)
+        if (a.max_sweeps > 0 && s >= a.max_sweeps) { done = 2; break; }
+        if (s - a.sweep_begin >= a.budget) break;                            // the host continues in another launch
+    }
+    if (!alive) done = -1;
+
+    // ---- belief = normalize(pi % lambda) (:151-158) of this workgroup's nodes, from the state the run stopped in
+    const int fin = s & 1;
+    if (alive) {
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (r >= pt.rc) break;
+            const SmallSlot q = cs[r];
+            const bool on = (q.z & 0xffu) == 3;  // the lambda(v) items: one per node-vector element
+            const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
+            const double val = on ? ld_state(a.npi + fin * a.N + out_idx) * ld_state(a.nlam + fin * a.N + out_idx) : 0.0;
+            const double bel = mid_normalize(line, lane, on ? k : 0, on ? at : 0, val, c_kmax[r]);
+            if (on) b.beliefs[out_idx] = bel;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        Ctl* h = a.host_ctl;
+        h->last_res = r_last; h->n_sweeps = s; h->t_first = t_first; h->t_last = wall_clock64();
+        h->run_id = a.run_id; h->done = done;
+    }
+}
+
+int prepare_bp_mid() {
+    (void)hipGetLastError();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bp_mid_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLdsBytes);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bp_mid_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLdsBytes);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(bp_mid_kernel<kSmallMaxRounds>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLdsBytes);
+    return e == hipSuccess ? 0 : int(e);
+}
+
+int launch_bp_mid(const MidArgs& a, int waves, int rounds, size_t lds_bytes, int n_sets, void* stream) {
+    (void)hipGetLastError();  // drop any stale error of this thread
+    const dim3 grid(a.nparts, n_sets > 1 ? n_sets : 1), block(waves * kWave);
+    if (rounds <= 1) hipLaunchKernelGGL(bp_mid_kernel<1>, grid, block, lds_bytes, (hipStream_t)stream, a);
+    else if (rounds <= 2) hipLaunchKernelGGL(bp_mid_kernel<2>, grid, block, lds_bytes, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(bp_mid_kernel<kSmallMaxRounds>, grid, block, lds_bytes, (hipStream_t)stream, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+
+}  // namespace bnmi

@@ -55,7 +55,20 @@ struct SmallPlan {
     std::vector<int32_t> nv_slot;    // [N]    the node's evidence-mark slot
     std::vector<double> npi_init;    // [N]    initial pi(v): the CPT row of a root, else 1.0 (:38-64)
     std::vector<int32_t> node_off;   // [n + 1] first element of node v's vectors
+    int32_t v0 = 0, v1 = 0;          // the nodes whose items these are (the whole network unless a part of a MidPlan)
 };
+
+// A network spread over several workgroups (bn_mid.hip): one SmallPlan per contiguous node range, message / node-vector indices
+// global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
+constexpr int kMidMaxParts = 32;
+struct MidPlan {
+    bool ok = false;
+    std::string why;
+    std::vector<SmallPlan> parts;
+    int32_t waves = 0, rounds = 0;   // the largest of the parts': one launch configuration for all workgroups
+    size_t lds_bytes = 0;
+};
+void build_mid_plan(const Plan& p, MidPlan& mp);
 
 // Builds the plan from the model held in `p` (single rank).  sp.ok false + sp.why when the network does not fit.
 void build_small_plan(const Plan& p, SmallPlan& sp);
@@ -92,6 +105,56 @@ struct SmallArgs {
     SetStrides sets;
     int64_t state_stride;
 };
+// ---- bn_mid.hip: several workgroups, state in memory
+struct MidPart {          // one workgroup's share (device array [nparts])
+    int32_t v0, v1;       // its nodes
+    int32_t ent_off, term_off, clist_off, bslot_off, cslot_off;  // where its tables start in the concatenated arrays
+    int32_t re, rb, rc, T, TT, CL, nt;                           // rounds per item kind, staged terms, parent terms, child-list entries, threads
+};
+struct MidArgs {
+    BpBuffers b;              // evidence marks, node0 (evidence vectors), beliefs, res_hist
+    double eps;
+    int32_t max_sweeps, sweep_begin, budget;
+    uint32_t run_id;
+    Ctl* host_ctl;
+    int32_t n, N, M, nparts;
+    const MidPart* parts;
+    const SmallEntry* ent;
+    const double* ent_cpt;
+    const uint32_t* term;
+    const uint16_t* clist;
+    const SmallSlot* bslot;
+    const SmallSlot* cslot;
+    const int32_t* nv_idx;
+    const int32_t* nv_slot;
+    const double* npi_init;
+    const int32_t* node_off;  // [n + 1]
+    const int32_t* msg_first; // [n + 1] first message element of node v's in-edges
+    int32_t ev_mode, ev_ne;   // as SmallArgs (ev_meta: this set's header or null)
+    const int32_t* ev_node;
+    const int32_t* ev_off;
+    const double* ev_val;
+    const int32_t* ev_meta;
+    // the state, in device memory: [2][M] pi-messages, [2][M] lambda-messages (CSR edge order), [2][N] pi(v), [2][N] lambda(v), marks
+    double* pi;
+    double* lam;
+    double* npi;
+    double* nlam;
+    uint8_t* frz;
+    unsigned* bar;               // grid barrier counter, zeroed by the host before a launch
+    unsigned long long* res;     // [3] maximum_difference of iteration s in word s % 3, zeroed by the host before a launch
+    unsigned* abort;             // page-locked host word
+    unsigned long long timeout_ticks;
+    // several evidence sets in one launch (gridDim.y): set blockIdx.y of the launch is set `set_base + blockIdx.y` of the batch
+    // (its beliefs, residual history, control block, evidence header) and works in state slot `slot_base + blockIdx.y`
+    // (state, marks and barrier words, `state_stride` doubles / N bytes / 64 bytes apart)
+    SetStrides sets;
+    int32_t set_base, slot_base;
+    int64_t state_stride;
+};
+int prepare_bp_mid();
+int launch_bp_mid(const MidArgs& a, int waves, int rounds, size_t lds_bytes, int n_sets, void* stream);
+
 int prepare_bp_small();  // once per device, before the first launch
 int launch_bp_small(const SmallArgs& a, int waves, size_t lds_bytes, int n_sets, void* stream);
 

@@ -64,19 +64,22 @@ int pack_rows(std::vector<Vec>& vecs, bool alike, int max_rows) {
 
 }  // namespace
 
-void build_small_plan(const Plan& p, SmallPlan& sp) {
+// The plan of the items of nodes [v0, v1).  part = false: the whole network in one workgroup, state in LDS (bn_small.hip).
+// part = true: one workgroup's share of a network that is spread over several (bn_mid.hip): message and node-vector indices stay
+// GLOBAL (the state lives in memory), staging places, parent terms and child lists are the workgroup's own.
+static void build_plan_of_range(const Plan& p, int v0, int v1, bool part, SmallPlan& sp) {
     sp = SmallPlan();
     auto no = [&](const char* why) { sp.ok = false; sp.why = why; };
     if (p.nranks != 1) return no("sharded");
     const int n = p.n;
     const int64_t E = p.E;
-    if (n <= 0) return no("empty");
-    const int64_t N = p.node_off[n], M = p.msg_off[E], S = p.cpt_off[n];
+    if (n <= 0 || v1 <= v0) return no("empty");
+    const int64_t N = p.node_off[n], M = p.msg_off[E], S = p.cpt_off[v1] - p.cpt_off[v0];
     if (n > 60000 || N > 60000 || M > 60000 || S > int64_t(kSmallMaxRounds) * kSmallMaxWaves * kWave) return no("too large");
     std::vector<int> m(n), rows(n);
     int mmax = 0;
     int64_t TT = 0;
-    for (int v = 0; v < n; ++v) {
+    for (int v = v0; v < v1; ++v) {
         m[v] = p.in_ptr[v + 1] - p.in_ptr[v];
         if (m[v] > kSmallMaxParents) return no("a node has more than 8 parents");
         if (p.k[v] > kWave) return no("arity above 64");
@@ -96,14 +99,17 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     std::vector<int> cedge(std::max<int64_t>(E, 1)), fill(n, 0);
     for (int v = 0; v < n; ++v)
         for (int e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) cedge[cptr[p.in_idx[e]] + fill[p.in_idx[e]]++] = e;
-    sp.clist.resize(std::max<int64_t>(E, 1), 0);
-    for (int64_t q = 0; q < E; ++q) sp.clist[q] = uint16_t(p.msg_off[cedge[q]]);
-    for (int v = 0; v < n; ++v)
+    // the child lists of the range's nodes, one after another (cl0 = where the first one starts in the global order)
+    const int cl0 = cptr[v0], ncl = cptr[v1] - cptr[v0];
+    sp.clist.resize(std::max(ncl, 1), 0);
+    for (int q = 0; q < ncl; ++q) sp.clist[q] = uint16_t(p.msg_off[cedge[cl0 + q]]);
+    for (int v = v0; v < v1; ++v)
         if (cptr[v + 1] - cptr[v] > 60000) return no("too many children");
+    if (ncl > 65000) return no("too large");
 
     // ---- accumulator and product vectors
     std::vector<Vec> bv, cv;
-    for (int v = 0; v < n; ++v) {
+    for (int v = v0; v < v1; ++v) {
         const int kv = p.k[v], Sv = kv * rows[v];
         // pi(v): element i sums `rows` terms (the run's place is filled in once the rows are known)
         bv.push_back(Vec{rows[v], kv, SmallSlot{0u, uint32_t(p.node_off[v]) | uint32_t(kv) << 16, 1u, 0u}, 0u, 1u, 0u, v, -1, 0, 0});
@@ -114,12 +120,12 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
         }
         const int deg = cptr[v + 1] - cptr[v];
         // lambda(v): product over all children
-        cv.push_back(Vec{deg, kv, SmallSlot{uint32_t(cptr[v]) | uint32_t(deg) << 16, uint32_t(p.node_off[v]) | uint32_t(kv) << 16,
+        cv.push_back(Vec{deg, kv, SmallSlot{uint32_t(cptr[v] - cl0) | uint32_t(deg) << 16, uint32_t(p.node_off[v]) | uint32_t(kv) << 16,
                                             3u | 0xffffu << 8, 0u},
                          0u, 1u, 0u, v, -1, 0, 0});
         for (int x = 0; x < deg; ++x) {  // pi-message to child x: pi(v) times the OTHER children's lambda-messages
             const int e = cedge[cptr[v] + x];
-            cv.push_back(Vec{deg, kv, SmallSlot{uint32_t(cptr[v]) | uint32_t(deg) << 16, uint32_t(p.msg_off[e]) | uint32_t(kv) << 16,
+            cv.push_back(Vec{deg, kv, SmallSlot{uint32_t(cptr[v] - cl0) | uint32_t(deg) << 16, uint32_t(p.msg_off[e]) | uint32_t(kv) << 16,
                                                 4u | uint32_t(x) << 8, uint32_t(p.node_off[v])},
                              0u, 1u, 1u, v, x, 0, 0});
         }
@@ -152,7 +158,7 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     for (const Vec& v : bv) row_len[v.row] = std::max(row_len[v.row], v.cost);
     for (int r = 0; r < nb; ++r) row_pad[r] = (row_len[r] + 3) & ~3;
     std::vector<std::vector<uint32_t>> vec_base(n), vec_stride(n);  // [node][1 + j]
-    for (int v = 0; v < n; ++v) { vec_base[v].assign(m[v] + 1, 0u); vec_stride[v].assign(m[v] + 1, 0u); }
+    for (int v = v0; v < v1; ++v) { vec_base[v].assign(m[v] + 1, 0u); vec_stride[v].assign(m[v] + 1, 0u); }
     int64_t T = 0;
     for (Vec& v : bv) {
         const uint32_t stride = uint32_t(row_pad[v.row]) | 1u;
@@ -164,7 +170,7 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
         T += int64_t(v.k) * stride;
     }
     T += 16;  // the loads run one step ahead of the additions: up to 12 words past the last run's end
-    if (T < N) T = N;  // (the final beliefs are normalised in this array)
+    if (!part && T < N) T = N;  // (the final beliefs are normalised in this array)
 
     // ---- rows -> waves.  Accumulator rows and product rows run between the same two barriers, and wave w issues on
     // SIMD w % 4: each row, most expensive first, goes to the wave whose SIMD has the least work so far (then the wave
@@ -218,8 +224,8 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
 
     // ---- entry items: nodes ordered by parent count (a wave's entries then need the same unrolled code), entries
     // of a node in table order
-    std::vector<int> order(n);
-    for (int v = 0; v < n; ++v) order[v] = v;
+    std::vector<int> order(v1 - v0);
+    for (int v = v0; v < v1; ++v) order[v - v0] = v;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return m[a] > m[b]; });
     sp.ent.assign(size_t(sp.re) * nt, SmallEntry{0, 0});
     sp.ent_cpt.assign(size_t(sp.re) * nt, 0.0);
@@ -257,27 +263,83 @@ void build_small_plan(const Plan& p, SmallPlan& sp) {
     sp.nv_idx.assign(N, 0);
     sp.nv_slot.assign(N, 0);
     sp.npi_init.assign(N, 1.0);
-    for (int v = 0; v < n; ++v) {
+    for (int v = 0; v < n && (!part || v0 == 0); ++v) {  // (global tables: built with the first part only)
+        const int mv = p.in_ptr[v + 1] - p.in_ptr[v];
         const TileDesc& td = p.tiles[p.node_tile[v]];
         const int nl = p.node_nl[v];
         for (int i = 0; i < p.k[v]; ++i) {
             // element i of pi(v) in the tile's striped node block (bn_tiles.hpp vidx(0, i, npt, nl))
             sp.nv_idx[p.node_off[v] + i] = int32_t(td.node_base + int64_t(i >> 1) * (int64_t(td.npt) * 2) + nl * 2 + (i & 1));
             sp.nv_slot[p.node_off[v] + i] = p.node_slot[v];
-            if (m[v] == 0) sp.npi_init[p.node_off[v] + i] = p.cpt_flat[p.cpt_off[v] + i];  // a root starts from its CPT row (:58-64)
+            if (mv == 0) sp.npi_init[p.node_off[v] + i] = p.cpt_flat[p.cpt_off[v] + i];  // a root starts from its CPT row (:58-64)
         }
     }
     sp.node_off.assign(p.node_off.begin(), p.node_off.begin() + n + 1);
     sp.n = n; sp.N = int32_t(N); sp.M = int32_t(M); sp.S = int32_t(S); sp.T = int32_t(T); sp.TT = int32_t(TT);
-    sp.CL = int32_t(E); sp.waves = waves; sp.mmax = mmax;
+    sp.CL = int32_t(ncl); sp.waves = waves; sp.mmax = mmax;
+    sp.v0 = v0; sp.v1 = v1;
     // LDS: 4 M + 4 N + T doubles, TT words, CL halfwords, N marks, the residual words
-    size_t bytes = size_t(4 * M + 4 * N + T) * 8 + ((size_t(std::max<int64_t>(TT, 1)) + 1) & ~size_t(1)) * 4;
-    bytes += (size_t(std::max<int64_t>(E, 1)) * 2 + 7) & ~size_t(7);
-    bytes += (size_t(N) + 7) & ~size_t(7);
+    size_t bytes = size_t(part ? T : 4 * M + 4 * N + T) * 8 + ((size_t(std::max<int64_t>(TT, 1)) + 1) & ~size_t(1)) * 4;
+    bytes += (size_t(std::max(ncl, 1)) * 2 + 7) & ~size_t(7);
+    bytes += part ? size_t(kSmallMaxWaves) * kWave * 8 : (size_t(N) + 7) & ~size_t(7);  // (parts: a normalisation scratch line per wave)
     bytes += 2 * 16 * 8;  // the residual words: [iteration parity][wave]
+    if (part) bytes += 64;  // (the grid barrier's flag word)
     sp.lds_bytes = bytes;
     if (bytes > size_t(kSmallLdsBytes)) return no("state does not fit the LDS");
     sp.ok = true;
+}
+
+void build_small_plan(const Plan& p, SmallPlan& sp) { build_plan_of_range(p, 0, p.n, false, sp); }
+
+// A network too large for one workgroup, spread over up to kMidMaxParts of them (bn_mid.hip): contiguous node ranges, each
+// within the per-workgroup limits of the items (LDS, rounds).  The ranges are cut where the estimated staging of a range
+// reaches a target; the target shrinks until every part fits.
+void build_mid_plan(const Plan& p, MidPlan& mp) {
+    mp = MidPlan();
+    auto no = [&](const std::string& why) { mp.ok = false; mp.why = why; mp.parts.clear(); };
+    if (p.nranks != 1 || p.n <= 1) return no("sharded or empty");
+    const int n = p.n;
+    if (p.node_off[n] > 60000 || p.msg_off[p.E] > 60000) return no("too large");
+    std::vector<int64_t> est(n);  // staged terms of node v, padding included (estimate)
+    int64_t total = 0;
+    for (int v = 0; v < n; ++v) {
+        const int m = p.in_ptr[v + 1] - p.in_ptr[v];
+        if (m > kSmallMaxParents) return no("a node has more than 8 parents");
+        if (p.k[v] > kWave) return no("arity above 64");
+        est[v] = (p.cpt_off[v + 1] - p.cpt_off[v]) * (m + 1) * 5 / 4 + 8 * p.k[v] * (m + 1);
+        total += est[v];
+    }
+    for (int64_t target = 11000; target >= 1500; target = target * 3 / 4) {
+        // balanced: as many parts as the target asks for, each about total / parts
+        const int64_t nparts_want = std::max<int64_t>(2, (total + target - 1) / target);
+        if (nparts_want > kMidMaxParts) continue;
+        const int64_t per = (total + nparts_want - 1) / nparts_want;
+        std::vector<int> cut{0};
+        int64_t acc = 0;
+        for (int v = 0; v < n; ++v) {
+            if (acc > 0 && acc + est[v] > per && int(cut.size()) < kMidMaxParts) { cut.push_back(v); acc = 0; }
+            acc += est[v];
+        }
+        cut.push_back(n);
+        std::vector<SmallPlan> parts(cut.size() - 1);
+        bool all = true;
+        for (size_t q = 0; q + 1 < cut.size() && all; ++q) {
+            build_plan_of_range(p, cut[q], cut[q + 1], true, parts[q]);
+            all = parts[q].ok;
+            if (!all) mp.why = parts[q].why;
+        }
+        if (!all) continue;
+        mp.parts.swap(parts);
+        mp.ok = true;
+        mp.waves = 0; mp.rounds = 0; mp.lds_bytes = 0;
+        for (const SmallPlan& sp : mp.parts) {
+            mp.waves = std::max(mp.waves, sp.waves);
+            mp.rounds = std::max(mp.rounds, std::max(sp.re, std::max(sp.rb, sp.rc)));
+            mp.lds_bytes = std::max(mp.lds_bytes, sp.lds_bytes);
+        }
+        return;
+    }
+    no(mp.why.empty() ? std::string("does not fit ") + std::to_string(kMidMaxParts) + " workgroups" : mp.why);
 }
 
 }  // namespace bnmi

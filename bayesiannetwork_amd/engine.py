@@ -206,6 +206,34 @@ class Engine:
         _lib.check(_lib.lib().bn_layout_flow(self._h, _p(nbr, ctypes.c_int32), pub.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
         return nbr[:nt * ch * 64].reshape(nt, ch * 64) if ch else np.zeros((nt, 0), np.int32), pub[:nt]
 
+    def mid_plan(self):
+        """The plan that spreads a mid-size network over several workgroups (bn_mid_plan_get): a list with one dict per part, laid
+        out like small_plan()'s plus v0, v1 (the part's node range); None when the network is not eligible."""
+        if not self.info("mid_eligible"):
+            return None
+        L = _lib.lib()
+        u32 = ctypes.POINTER(ctypes.c_uint32)
+        parts = []
+        for q in range(self.info("mid_parts")):
+            dims = np.zeros(14, dtype=np.int32)
+            _lib.check(L.bn_mid_plan_get(self._h, q, _p(dims, ctypes.c_int32), None, None, None, None, None, None, None))
+            names = ["n", "N", "M", "S", "T", "TT", "CL", "waves", "re", "rb", "rc", "mmax", "v0", "v1"]
+            d = {k: int(v) for k, v in zip(names, dims)}
+            nt = 64 * d["waves"]
+            ent = np.zeros((d["re"] * nt, 2), dtype=np.uint32)
+            ent_cpt = np.zeros(d["re"] * nt, dtype=np.float64)
+            term = np.zeros(max(d["TT"], 1), dtype=np.uint32)
+            clist = np.zeros(max(d["CL"], 1), dtype=np.uint16)
+            bslot = np.zeros((d["rb"] * nt, 4), dtype=np.uint32)
+            cslot = np.zeros((d["rc"] * nt, 4), dtype=np.uint32)
+            init = np.zeros(d["N"], dtype=np.float64)
+            _lib.check(L.bn_mid_plan_get(self._h, q, None, ent.ctypes.data_as(u32), _p(ent_cpt, ctypes.c_double), term.ctypes.data_as(u32),
+                                         clist.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), bslot.ctypes.data_as(u32),
+                                         cslot.ctypes.data_as(u32), _p(init, ctypes.c_double)))
+            d.update(ent=ent, ent_cpt=ent_cpt, term=term[:d["TT"]], clist=clist[:d["CL"]], bslot=bslot, cslot=cslot, npi_init=init)
+            parts.append(d)
+        return parts
+
     def small_plan(self):
         """The plan of the one-workgroup path for small networks (bn_small_plan_get), or None when the network is not
         eligible: dict(n, N, M, S, T, TT, CL, waves, re, rb, rc, mmax, ent [re*nt, 2], ent_cpt, term, clist,

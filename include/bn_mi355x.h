@@ -197,6 +197,11 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   trees and two-round networks the resident kernel runs in one block; "multisweep" 0 also turns it off), 2 = wherever
  *   eligible.  bn_bp_run_batch on such a network runs one workgroup per evidence set, all sets in one launch.
  *   bn_get_info "small_eligible".
+ * "mid" 0/1/2 -- MID-SIZE networks (beyond one workgroup's LDS, up to 32 workgroups' worth: a few hundred to a thousand nodes
+ *   of mixed arity with <= 8 parents): the same items as "small", spread over several workgroups by node ranges, state in
+ *   device memory, a grid barrier per iteration, one launch per run; bit-identical to the CPU restatement as well.  0 = never,
+ *   1 = where eligible and the resident tiles do not cover the network (default), 2 = wherever eligible.  bn_bp_last_path = 4.
+ *   Batches run as many sets per launch as fit the chip.  bn_get_info "mid_eligible", "mid_parts", "mid_aborts".
  * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 0):
  *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
  *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.
@@ -204,12 +209,12 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * "beliefs_direct" 1/0 -- bn_bp_run_view: the kernels write the marginals straight into the engine's mapped host
  *   buffer (default 1, outputs up to 16 MB) instead of a copy command queued behind the run.
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run), 3 = one workgroup, state in LDS
- *   (small networks, one launch per run). */
+ *   (small networks, one launch per run), 4 = the same items over several workgroups (mid-size networks). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
  * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
- * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes"; unknown name: BN_ERR_ARG. */
+ * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts"; unknown name: BN_ERR_ARG. */
 int64_t bn_get_info(bn_engine *eng, const char *name);
 
 /* Single steps of a run (tests / diagnostics): begin, one sweep (without exchange), finish.
@@ -317,6 +322,11 @@ int bn_layout_class(bn_engine *eng, int32_t cls, int32_t *kv, int32_t *m, int32_
  * bslot [rb * 64 * waves][4], cslot [rc * 64 * waves][4], npi_init [N].  BN_ERR_STATE: the network is not eligible. */
 int bn_small_plan_get(bn_engine *eng, int32_t *dims_out, uint32_t *ent, double *ent_cpt, uint32_t *term, uint16_t *clist,
                       uint32_t *bslot, uint32_t *cslot, double *npi_init);
+/* ... of part `part` (0 .. bn_get_info "mid_parts" - 1) of the plan that spreads a mid-size network over several workgroups
+ * (csrc/bn_mid.hip): same arrays; message and node-vector indices are global, staging places the part's own;
+ * dims_out[14]: the twelve values above, then the part's node range [v0, v1). */
+int bn_mid_plan_get(bn_engine *eng, int32_t part, int32_t *dims_out, uint32_t *ent, double *ent_cpt, uint32_t *term, uint16_t *clist,
+                    uint32_t *bslot, uint32_t *cslot, double *npi_init);
 
 #ifdef __cplusplus
 }

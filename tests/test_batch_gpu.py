@@ -84,6 +84,7 @@ def test_batch_on_per_sweep_launches_every_tile_variant(Engine):
     m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)            # any-arity tiles (+ register-resident ones)
     evs = [synth.random_evidence(m, f, seed=q) for q, f in enumerate([0.0, 0.05, 0.1, 0.02])]
     with Engine(m) as eng:
+        eng.set_option("mid", 0)   # (by default this network takes the item kernel over several workgroups: tests/test_mid_gpu.py)
         _check_batch(eng, evs, 1e-6, want_path=0)
         with pytest.raises(_lib.BnError):
             eng.bp_run_batch([None] * (_lib.BN_MAX_BATCH_SETS + 1), 1e-3)   # more than BN_MAX_BATCH_SETS
@@ -133,6 +134,7 @@ def test_batch_beyond_64_sets_on_every_path(Engine):
     m = synth.random_dag(400, 3, 24, [2, 3, 4], seed=9)
     evs = [synth.random_evidence(m, 0.01 * (q % 7), seed=q) for q in range(130)]
     with Engine(m) as eng:
+        eng.set_option("mid", 0)
         _check_batch(eng, evs, 1e-6, want_path=0, reps=1)
     g = synth.grid(40, 40, 4, seed=3)
     evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(70)]

@@ -84,10 +84,16 @@ def _vs_oracle(Engine, oracle_mod, model, ev, eps, exact):
         path = eng.last_path()
         eng.set_option("multisweep", 0 if path != 0 else 2)
         g3 = eng.bp_run(ev, eps)
-        assert g3["sweeps"] == g["sweeps"] and np.array_equal(g3["beliefs"], g["beliefs"], equal_nan=True)
-        assert np.array_equal(eng.bp_residuals(), res)
-        pi3, lam3 = eng.bp_messages()
-        assert np.array_equal(pi3, pi, equal_nan=True) and np.array_equal(lam3, lam, equal_nan=True)
+        if path in (3, 4) and not exact:
+            # the item kernels (bn_small.hip / bn_mid.hip) keep the reference's order for any table size; the tile kernels
+            # re-associate the sums of nodes with three and more parents: equal to rounding, not to the bit
+            assert g3["sweeps"] == g["sweeps"] and np.allclose(g3["beliefs"], g["beliefs"], rtol=0, atol=1e-12, equal_nan=True)
+            assert np.array_equal(g["beliefs"], o["beliefs"], equal_nan=True) and np.array_equal(res, o["residuals"])
+        else:
+            assert g3["sweeps"] == g["sweeps"] and np.array_equal(g3["beliefs"], g["beliefs"], equal_nan=True)
+            assert np.array_equal(eng.bp_residuals(), res)
+            pi3, lam3 = eng.bp_messages()
+            assert np.array_equal(pi3, pi, equal_nan=True) and np.array_equal(lam3, lam, equal_nan=True)
         if path != 0:
             assert eng.last_path() == 0
     return o

@@ -257,7 +257,7 @@ def test_hot_kernels_do_not_spill(bnlib):
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "bayesiannetwork_amd", "csrc")
-    need = ["bn_sweep_u.o", "bn_resident.o", "bn_lw_kernels.o", "bn_small.o"]
+    need = ["bn_sweep_u.o", "bn_resident.o", "bn_lw_kernels.o", "bn_small.o", "bn_mid.o"]
     if not all(os.path.exists(os.path.join(csrc, f)) for f in need) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("object files / llvm tools not on this box")
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(root, "scripts", "kernel_resources.py"))
@@ -294,6 +294,9 @@ def test_hot_kernels_do_not_spill(bnlib):
             assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
     for name, r in kr.kernel_resources(os.path.join(csrc, "bn_lw_kernels.o")).items():
         assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
+    for name, r in kr.kernel_resources(os.path.join(csrc, "bn_mid.o")).items():   # the same items over several workgroups
+        rounds = int(re.search(r"bp_mid_kernel<(\d+)>", name).group(1))
+        assert r["vgpr"] <= 128 and (r["spill"] == 0 if rounds <= 2 else r["spill"] <= 32), (name, r)
     small = kr.kernel_resources(os.path.join(csrc, "bn_small.o"))   # one workgroup per run, state in LDS (small networks)
     assert len(small) == 3
     for name, r in small.items():
@@ -327,6 +330,32 @@ def test_small_plan_emulated_equals_oracle(bnlib, oracle_mod):
         assert got["sweeps"] == want["sweeps"]
         assert np.array_equal(got["beliefs"], want["beliefs"]) and np.array_equal(got["residuals"], want["residuals"])
         assert np.array_equal(got["pi_msg"], want["pi_msg"]) and np.array_equal(got["lambda_msg"], want["lambda_msg"])
+
+
+def test_mid_plan_emulated_equals_oracle(bnlib, oracle_mod):
+    """Networks beyond one workgroup's LDS: the plan that spreads the same items over several workgroups (bn_mid.hip), executed
+    part by part on the CPU, reproduces the oracle bit for bit; the parts partition the nodes; the spill bounds of the kernel."""
+    import small_emulator
+    from bayesiannetwork_amd import _lib, engine, synth
+    g = synth.random_dag(90, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=17)
+    ev = synth.random_evidence(g, 0.08, seed=2)
+    with engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("small_eligible") == 0 and e.info("mid_eligible") == 1 and 2 <= e.info("mid_parts") <= 32
+        parts = e.mid_plan()
+    assert parts[0]["v0"] == 0 and parts[-1]["v1"] == g.n and all(a["v1"] == b["v0"] for a, b in zip(parts, parts[1:]))
+    N, M = int(g.k.sum()), int(g.k[g.in_idx].sum())
+    for kind, size in ((1, N), (2, M), (3, N), (4, M)):   # every output element has exactly one item, in exactly one part
+        got = []
+        for p in parts:
+            slots = p["bslot"] if kind <= 2 else p["cslot"]
+            got += (slots[(slots[:, 2] & 0xff) == kind][:, 1] & 0xffff).tolist()
+        assert sorted(got) == list(range(size))
+    got = small_emulator.emulate(parts, g, ev, 1e-6)
+    want = oracle_mod.bp_run(g, ev, 1e-6, dump_msgs=True)
+    assert got["sweeps"] == want["sweeps"] and np.array_equal(got["beliefs"], want["beliefs"]) and np.array_equal(got["residuals"], want["residuals"])
+    assert np.array_equal(got["pi_msg"], want["pi_msg"]) and np.array_equal(got["lambda_msg"], want["lambda_msg"])
+    with engine.Engine(synth.grid(64, 64, 4, seed=1), device=_lib.BN_DEVICE_HOST_ONLY) as e:   # too large for 32 workgroups
+        assert e.info("mid_eligible") == 0 and e.mid_plan() is None
 
 
 def test_small_plan_invariants(bnlib):

@@ -108,8 +108,11 @@ def test_resident_max_sweeps_and_soft_evidence(Engine):
 
 def test_paths_are_chosen_by_eligibility(Engine):
     from bayesiannetwork_amd import synth
-    with Engine(synth.random_dag(300, 3, 32, [2, 3, 4], seed=1)) as eng:  # any-arity tiles: never resident
+    with Engine(synth.random_dag(300, 3, 32, [2, 3, 4], seed=1)) as eng:  # any-arity tiles: never resident ...
         eng.set_option("multisweep", 2)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() == 4                                         # ... the item kernel over several workgroups instead
+        eng.set_option("mid", 0)
         eng.bp_run(None, 1e-3)
         assert eng.last_path() == 0
     with Engine(synth.random_dag(3000, 4, 64, 4, seed=5)) as eng:  # lane-group tiles (3-4 parents): never resident

@@ -33,6 +33,8 @@ def _run_sharded(eng, model, ev, eps, nranks, owner=None, max_sweeps=0, overlapp
 
 def _check(eng, model, ev, eps, nranks, owner=None):
     with eng.Engine(model) as single:
+        single.set_option("small", 0)   # the shards run the tile kernels: the reference run too (same bits)
+        single.set_option("mid", 0)
         want = single.bp_run(ev, eps)
         want_res = single.bp_residuals()
         want_pi, want_lam = single.bp_messages()
