@@ -26,6 +26,15 @@ __device__ __forceinline__ void st_state(double* p, double v) {
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// diagnostic builds (make EXTRA=-DBN_TILE_CLOCK): thread 0 of every workgroup records the 100 MHz clock at the phase
+// boundaries of iteration 3 (scripts/experiments/mid_clock.py prints them)
+#ifdef BN_TILE_CLOCK
+__device__ unsigned long long g_mid_clock[kMidMaxParts][8];
+#define MID_STAMP(k) do { if (tid == 0 && blockIdx.y == 0 && s == a.sweep_begin + 3) g_mid_clock[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define MID_STAMP(k) do { } while (0)
+#endif
+
 struct MidLds {
     double* stg;        // [T] this workgroup's staged terms
     uint32_t* term;     // [TT]
@@ -251,11 +260,41 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
         double wres = 0.0;
         // the residual word of the iteration after this one: its readers (iteration s - 2) are all behind the last barrier
         if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.res + (s + 1) % 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- everything phase 2 needs of the OLD state is requested now (its previous values for the residual, the pi(v)
+        // element a pi-message starts from, the first four children's lambda-messages): a trip to L2 costs about as much as a
+        // whole phase here, and these travel while the entry items run
+        MID_STAMP(0);
+        constexpr bool kPreload = ROUNDS <= 2;
+        double pre_b[ROUNDS], pre_c[ROUNDS], pre_v[ROUNDS], pre_f[ROUNDS][4];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            pre_b[r] = pre_c[r] = 0.0; pre_v[r] = 1.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pre_f[r][u] = 1.0;
+            if (!kPreload) continue;
+            if (r < pt.rb) {
+                const int kind = int(bs[r].z & 0xffu), out_idx = int(bs[r].y & 0xffffu);
+                if (kind == 1) pre_b[r] = ld_state(npi_cur + out_idx);
+                if (kind == 2) pre_b[r] = ld_state(lam_cur + out_idx);
+            }
+            if (r < pt.rc) {
+                const SmallSlot q = cs[r];
+                const int kind = int(q.z & 0xffu), out_idx = int(q.y & 0xffffu), at = lane - int(q.y >> 24);
+                const int cl = int(q.x & 0xffffu), deg = int(q.x >> 16);
+                if (kind == 4) { pre_c[r] = ld_state(pi_cur + out_idx); pre_v[r] = ld_state(npi_cur + (q.w & 0xffffu)); }
+                if (kind == 3) pre_c[r] = ld_state(nlam_cur + out_idx);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (kind != 0 && u < deg) pre_f[r][u] = ld_state(lam_cur + L.clist[cl + u] + at);
+            }
+        }
         // ---- phase 1: entry items
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r)
             if (r < pt.re) mid_entry_any<kTermsInRegs>(e_mm[r], L, pi_cur, nlam_cur, ent[r], ecpt[r], treg[r]);
+        MID_STAMP(1);
         __syncthreads();
+        MID_STAMP(2);
         // ---- phase 2a: accumulator items
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -264,10 +303,10 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
             const int kind = int(q.z & 0xffu);
             const int base = int(q.x & 0xffffu);
             const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
-            double old = 0.0;
+            double old = pre_b[r];
             bool frozen = false;
-            if (kind == 1) { old = ld_state(npi_cur + out_idx); frozen = a.frz[out_idx] != 0; }
-            if (kind == 2) old = ld_state(lam_cur + out_idx);
+            if (kind == 1) { if (!kPreload) old = ld_state(npi_cur + out_idx); frozen = a.frz[out_idx] != 0; }
+            if (kind == 2 && !kPreload) old = ld_state(lam_cur + out_idx);
             const double* ptr = L.stg + base;
             const int n4 = b_rmax[r];  // a multiple of 4
             double acc = 0.0;
@@ -287,6 +326,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
                 wres = res_acc(wres, fabs(val - old));
             }
         }
+        MID_STAMP(3);
         // ---- phase 2b: product items (old state only)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -295,16 +335,17 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
             const int kind = int(q.z & 0xffu), skip = int((q.z >> 8) & 0xffffu);
             const int cl = int(q.x & 0xffffu), deg = int(q.x >> 16);
             const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
-            double old = 0.0;
+            double old = pre_c[r];
             bool frozen = false;
-            if (kind == 4) old = ld_state(pi_cur + out_idx);
-            if (kind == 3) { old = ld_state(nlam_cur + out_idx); frozen = a.frz[out_idx] != 0; }
+            if (kind == 4 && !kPreload) old = ld_state(pi_cur + out_idx);
+            if (kind == 3) { if (!kPreload) old = ld_state(nlam_cur + out_idx); frozen = a.frz[out_idx] != 0; }
             // lambda(v): from 1.0 (:220-238); pi-message: from pi(v)[i] (:202-218); children in ascending order
-            double val = kind == 4 ? ld_state(npi_cur + (q.w & 0xffffu)) : 1.0;
+            double val = kind == 4 ? (kPreload ? pre_v[r] : ld_state(npi_cur + (q.w & 0xffffu))) : 1.0;
             for (int c0 = 0; c0 < c_dmax[r]; c0 += 4) {
                 double f[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    if (kPreload && c0 == 0) { f[u] = pre_f[r][u]; continue; }
                     const bool has = c0 + u < deg;
                     const int cb = L.clist[has ? cl + c0 + u : 0];
                     f[u] = has ? ld_state(lam_cur + cb + at) : 1.0;
@@ -319,6 +360,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
                 wres = res_acc(wres, fabs(val - old));
             }
         }
+        MID_STAMP(4);
         // maximum_difference (:105-131): wave -> workgroup (LDS) -> one atomic max per workgroup -> grid barrier -> the same word
         const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
         if (lane == 0) L.red[cur * 16 + wave] = bits;
@@ -327,8 +369,10 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
             const unsigned long long bm = wave_umax64_dpp<true>(L.red[cur * 16 + (lane & 15)]);
             if (lane == 0 && bm != 0ull) __hip_atomic_fetch_max(a.res + s % 3, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        MID_STAMP(5);
         ++gen;
         alive = mid_grid_barrier(a, L, gen, tid);
+        MID_STAMP(6);
         if (!alive) break;
         const unsigned long long mx = __hip_atomic_load(a.res + s % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double rr = __longlong_as_double((long long)mx);
@@ -383,3 +427,9 @@ int launch_bp_mid(const MidArgs& a, int waves, int rounds, size_t lds_bytes, int
 }
 
 }  // namespace bnmi
+
+#ifdef BN_TILE_CLOCK
+extern "C" int bn_debug_mid_clock(unsigned long long* out) {
+    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_mid_clock), sizeof(unsigned long long) * bnmi::kMidMaxParts * 8));
+}
+#endif

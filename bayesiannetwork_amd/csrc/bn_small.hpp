@@ -61,6 +61,7 @@ struct SmallPlan {
 // A network spread over several workgroups (bn_mid.hip): one SmallPlan per contiguous node range, message / node-vector indices
 // global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
 constexpr int kMidMaxParts = 32;
+constexpr int kMidPreferredParts = 16;
 struct MidPlan {
     bool ok = false;
     std::string why;

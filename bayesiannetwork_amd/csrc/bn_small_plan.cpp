@@ -293,7 +293,7 @@ void build_small_plan(const Plan& p, SmallPlan& sp) { build_plan_of_range(p, 0, 
 
 // A network too large for one workgroup, spread over up to kMidMaxParts of them (bn_mid.hip): contiguous node ranges, each
 // within the per-workgroup limits of the items (LDS, rounds).  The ranges are cut where the estimated staging of a range
-// reaches a target; the target shrinks until every part fits.
+// reaches a target; the target grows until 32 parts hold the network.
 void build_mid_plan(const Plan& p, MidPlan& mp) {
     mp = MidPlan();
     auto no = [&](const std::string& why) { mp.ok = false; mp.why = why; mp.parts.clear(); };
@@ -309,7 +309,10 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
         est[v] = (p.cpt_off[v + 1] - p.cpt_off[v]) * (m + 1) * 5 / 4 + 8 * p.k[v] * (m + 1);
         total += est[v];
     }
-    for (int64_t target = 11000; target >= 1500; target = target * 3 / 4) {
+    // About 16 workgroups where the network allows it: fewer, larger parts mean more rounds of items per thread (stamps: 1.7 us of
+    // entry items + 1.7 us of accumulator items per iteration at four rounds), more parts a slower grid barrier (32 workgroups:
+    // 300-node network 7.5 -> 7.8 us per sweep, 60-node / 12 k entries 7.2 -> 8.2); larger parts only where 32 do not hold the network
+    for (int64_t target = std::max<int64_t>(2000, std::min<int64_t>((total + kMidPreferredParts - 1) / kMidPreferredParts, 9000)); target <= 12000; target = target * 4 / 3 + 1) {
         // balanced: as many parts as the target asks for, each about total / parts
         const int64_t nparts_want = std::max<int64_t>(2, (total + target - 1) / target);
         if (nparts_want > kMidMaxParts) continue;
