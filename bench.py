@@ -9,6 +9,7 @@ One JSON line on stdout (rank 0).  See DESIGN.md "Measurement" for the definitio
 The default single-GPU line also carries, as extra keys measured after the timed region,
   value_host_to_host : SURVEY 8(d)'s definition -- evidence upload to beliefs on the host (PCIe inclusive)
   config1_alarm      : BASELINE configs[0]'s network on the GPU: the ALARM-shaped 37-node net (queries per second)
+  mid_mixed300       : a 300-node network of mixed arities (2-5), <= 3 parents: beyond one workgroup's LDS (bn_mid.hip)
   config2_dag        : BASELINE configs[1], the 10 k-node random DAG
   config5_lw         : BASELINE configs[4], likelihood weighting on that DAG
   grid2048           : the HBM-resident point (4.2 M nodes, 3.76 GB per sweep)
@@ -200,7 +201,8 @@ def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
 
 PATH_KERNEL = {0: "bp_sweep_kernel", 2: "bp_resident_kernel"}
 PATH_NAME = {0: "one launch per sweep", 2: "resident tiles, one launch for the whole run (grid barrier per sweep)",
-             3: "one workgroup, state in LDS, one launch for the whole run (small networks)"}
+             3: "one workgroup, state in LDS, one launch for the whole run (small networks)",
+             4: "the same items over several workgroups, state in memory, grid barrier per iteration, one launch for the whole run (mid-size networks)"}
 
 
 def roofline_of(t, label):
@@ -421,6 +423,54 @@ def leg_alarm(a, local_rank, torch):
     return out
 
 
+def leg_mid(a, local_rank, torch):
+    """A mid-size network of mixed arities (not a BASELINE config; the kind between configs[0] and configs[1]): 300 nodes, arities
+    2-5, up to 3 parents, 10.6 k CPT entries -- the item kernel over ~18 workgroups (csrc/bn_mid.hip) beside the tile kernels."""
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+    g = synth.random_dag(300, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=12)
+    eps = 1e-6
+    evs = [synth.random_evidence(g, 0.05, seed=7 + q) for q in range(8)]
+    out = {"workload": f"{g.n}-node random DAG, arities 2-5, <= 3 parents, {g.n_edges} edges, {len(g.cpt)} CPT entries, 5 % evidence on different "
+                       f"nodes per query, eps={eps:g}"}
+    with Engine(g, device=local_rank) as eng:
+        h2h = time_host_to_host(eng, g, evs, eps, 200)
+        out["path"] = PATH_NAME.get(eng.last_path())
+        out["workgroups"] = eng.info("mid_parts")
+        dev, sweeps = 0.0, 0
+        for i in range(32):
+            r = eng.bp_run_view(evs[i % len(evs)], eps)
+            dev += eng.bp_stats()["sweep_devclock_ms"]
+            sweeps += r["sweeps"]
+        out.update({"value": h2h["value"], "unit": "edge-messages/s (evidence in, marginals on the host, one query per call)",
+                    "us_per_query": h2h["ms_per_step"] * 1e3, "sweeps_per_query": h2h["sweeps_per_step"], "kernel_us_per_sweep": dev / sweeps * 1e3})
+        eng.set_option("mid", 0)
+        tiles = time_host_to_host(eng, g, evs, eps, 100)
+        out["tile_kernels"] = {"us_per_query": tiles["ms_per_step"] * 1e3, "path": PATH_NAME.get(eng.last_path())}
+        eng.set_option("mid", 1)
+        sets = [synth.random_evidence(g, 0.05, seed=100 + q) for q in range(64)]
+        eng.bp_set_evidence_batch(sets)
+        for _ in range(3):
+            eng.bp_run_batch_device(eps)
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.bp_run_batch_device(eps)
+        dt = time.perf_counter() - t0
+        out["batch_B64"] = {"queries_per_s": 64 * reps / dt, "us_per_call": dt / reps * 1e6, "path": PATH_NAME.get(eng.last_path())}
+    if not a.no_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 2.0:
+            oracle.bp_run(g, evs[n % len(evs)], eps)
+            n += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} queries of the same cycle through oracle/bp_oracle.c, 1 thread"}
+    return out
+
+
 def leg_lw(a, local_rank, torch):
     """BASELINE configs[4] on one GPU: weighted samples/s on the 10 k-node DAG with 1 % evidence."""
     from bayesiannetwork_amd import synth
@@ -632,7 +682,7 @@ def main():
             out["cpu_reference_small"] = ref
     eng.close()
     if default_run and not a.no_extras:
-        for key, fn in (("batch", leg_batch), ("config1_alarm", leg_alarm), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
+        for key, fn in (("batch", leg_batch), ("config1_alarm", leg_alarm), ("mid_mixed300", leg_mid), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
             try:
                 out[key] = fn(a, local_rank, torch)
             except Exception as ex:  # noqa: BLE001 - an extra must never lose the headline
