@@ -244,6 +244,14 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
     }
     unsigned gen = 1;
     bool alive = mid_grid_barrier(a, L, gen, tid);
+    // the evidence marks of this thread's pi(v) / lambda(v) items do not change during a run: read once (a byte from memory in
+    // front of every store was a round trip on each phase's critical path)
+    bool frz_b[ROUNDS], frz_c[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        frz_b[r] = (bs[r].z & 0xffu) == 1 && a.frz[bs[r].y & 0xffffu] != 0;
+        frz_c[r] = (cs[r].z & 0xffu) == 3 && a.frz[cs[r].y & 0xffffu] != 0;
+    }
 
     int done = 0;
     double r_last = 0.0;
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
             const int out_idx = int(q.y & 0xffffu), k = int((q.y >> 16) & 0xffu), at = lane - int(q.y >> 24);
             double old = pre_b[r];
             bool frozen = false;
-            if (kind == 1) { if (!kPreload) old = ld_state(npi_cur + out_idx); frozen = a.frz[out_idx] != 0; }
+            if (kind == 1) { if (!kPreload) old = ld_state(npi_cur + out_idx); frozen = frz_b[r]; }
             if (kind == 2 && !kPreload) old = ld_state(lam_cur + out_idx);
             const double* ptr = L.stg + base;
             const int n4 = b_rmax[r];  // a multiple of 4
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
             double old = pre_c[r];
             bool frozen = false;
             if (kind == 4 && !kPreload) old = ld_state(pi_cur + out_idx);
-            if (kind == 3) { if (!kPreload) old = ld_state(nlam_cur + out_idx); frozen = a.frz[out_idx] != 0; }
+            if (kind == 3) { if (!kPreload) old = ld_state(nlam_cur + out_idx); frozen = frz_c[r]; }
             // lambda(v): from 1.0 (:220-238); pi-message: from pi(v)[i] (:202-218); children in ascending order
             double val = kind == 4 ? (kPreload ? pre_v[r] : ld_state(npi_cur + (q.w & 0xffffu))) : 1.0;
             for (int c0 = 0; c0 < c_dmax[r]; c0 += 4) {
