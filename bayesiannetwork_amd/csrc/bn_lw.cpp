@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstring>
 #include <queue>
 #include <vector>
 
@@ -23,6 +24,8 @@ void lw_free(LwState& s) {
     void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s.h_ev) (void)hipHostFree(s.h_ev);
+    if (s.h_hist) (void)hipHostFree(s.h_hist);
     s = LwState();
 }
 
@@ -118,6 +121,8 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_topo), (size_t(p.n) + 1) * sizeof(int32_t)));
         LWCHK(hipMemsetAsync(s.d_ev_topo, 0xff, (size_t(p.n) + 1) * sizeof(int32_t), st));
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double)));
+        LWCHK(hipHostMalloc(reinterpret_cast<void**>(&s.h_ev), (size_t(p.n) + 1) * sizeof(int32_t), hipHostMallocDefault));
+        LWCHK(hipHostMalloc(reinterpret_cast<void**>(&s.h_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double), hipHostMallocDefault));
         s.ready = true;
     }
     // batch: enough blocks to fill the chip, bounded so the [node][sample] state matrix stays
@@ -157,10 +162,10 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     int r = lw_prepare(s, p, st, n_samples, err);
     if (r) return r;
     const size_t hist_n = size_t(p.node_off[p.n]);
-    std::vector<int32_t> evt(std::max(p.n, 1));
-    for (int32_t t = 0; t < p.n; ++t) evt[t] = evs[s.topo[t]];
-    LWCHK(hipMemcpyAsync(s.d_ev_topo, evt.data(), sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
-    LWCHK(hipStreamSynchronize(st));  // evt is a local
+    // one synchronisation per call: the evidence goes up from page-locked staging (no kernel of an earlier call is in flight: every
+    // entry point of the sampler family returns synchronised), the histogram comes down into page-locked memory
+    for (int32_t t = 0; t < p.n; ++t) s.h_ev[t] = evs[s.topo[t]];
+    LWCHK(hipMemcpyAsync(s.d_ev_topo, s.h_ev, sizeof(int32_t) * p.n, hipMemcpyHostToDevice, st));
     LWCHK(hipMemsetAsync(s.d_hist, 0, std::max<size_t>(hist_n, 1) * sizeof(double), st));
     uint64_t done = 0;
     while (done < n_samples) {
@@ -172,10 +177,9 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
         s.last_batch_samples = cnt;
         done += cnt;
     }
-    if (hist_out) {
-        LWCHK(hipMemcpyAsync(hist_out, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
-        LWCHK(hipStreamSynchronize(st));
-    }
+    if (hist_out) LWCHK(hipMemcpyAsync(s.h_hist, s.d_hist, hist_n * sizeof(double), hipMemcpyDeviceToHost, st));
+    LWCHK(hipStreamSynchronize(st));
+    if (hist_out) std::memcpy(hist_out, s.h_hist, hist_n * sizeof(double));
     return 0;
 }
 

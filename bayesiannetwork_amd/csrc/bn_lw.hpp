@@ -45,6 +45,8 @@ struct LwState {
     uint8_t* d_states = nullptr;   // [n][batch] sampled states of the current batch
     double* d_weights = nullptr;   // [batch]
     double* d_hist = nullptr;      // [sum k]
+    int32_t* h_ev = nullptr;       // page-locked staging of d_ev_topo: the upload needs no synchronisation of its own
+    double* h_hist = nullptr;      // page-locked landing place of the histogram
     uint64_t batch = 0;            // samples per launch (multiple of kLwBlockSamples)
     uint64_t last_batch_samples = 0;
     std::vector<int32_t> topo;
