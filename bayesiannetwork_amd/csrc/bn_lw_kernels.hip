@@ -24,6 +24,8 @@
 // (sample range, node, state) at the end.  Nodes with more than 8 states use lw_hist_wide_kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "bn_lw.hpp"
 
 namespace bnmi {
@@ -375,11 +377,14 @@ int launch_lw_hist(const LwArgs& a, int blocks, void* stream) {
         hipLaunchKernelGGL(lw_hist_wide_kernel, dim3(blocks), dim3(kLwThreads), 0, st, a.states, a.weights, a.k,
                            a.node_off, a.hist, a.n, a.batch, a.n_valid);
     } else if (a.n_valid > 0) {
-        // enough (node block, sample range) pairs to fill the chip; ranges are multiples of 1024
+        // enough (node block, sample range) pairs to fill the chip; ranges are multiples of 256 (a block walks its range 64 samples
+        // at a time: with multiples of 1024 the reference's default of 10 000 samples on a 37-node network was 10 blocks of 16
+        // trips each, 70 us -- more than the sampling itself)
         const unsigned xb = unsigned((a.n + kLwThreads - 1) / kLwThreads);
         uint64_t ranges = (4096 + xb - 1) / xb;
         uint64_t range = (a.n_valid + ranges - 1) / ranges;
-        range = (range + 1023) / 1024 * 1024;
+        range = std::max<uint64_t>(range, (a.n_valid + 1023) / 1024);  // ... and at most ~1 000 ranges: every range ends in atomics on the same bins
+        range = (range + 255) / 256 * 256;
         const unsigned yb = unsigned((a.n_valid + range - 1) / range);
         const dim3 grid(xb, yb);
         if (a.kmax <= 2)
