@@ -257,7 +257,7 @@ struct bn_engine {
     int32_t* d_m_msgfirst = nullptr;
     double* d_m_state = nullptr;    // [4 M + 4 N]: pi[2][M], lam[2][M], npi[2][N], nlam[2][N]
     uint8_t* d_m_frz = nullptr;
-    char* d_m_sync = nullptr;       // per state slot 64 bytes: the barrier counter, then (8 bytes on) the three residual words
+    char* d_m_sync = nullptr;       // per state slot kMidSyncBytes: the barrier counter, the three residual words, the group counters
     int32_t mid_slots = 0;          // state slots allocated (1 for single queries; batches run several sets per launch)
     int32_t n_cus = 0;
     bool ev_deferred = false;       // the evidence in force sits in the staging block only: the one-workgroup kernel reads it there
@@ -356,7 +356,7 @@ static int mid_reserve_slots(bn_engine* e, int32_t slots) {
     int r;
     if ((r = dalloc(&e->d_m_state, size_t(slots) * size_t(4 * g0.M + 4 * g0.N)))) return r;
     if ((r = dalloc(&e->d_m_frz, size_t(slots) * size_t(g0.N)))) return r;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_m_sync), size_t(slots) * 64));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_m_sync), size_t(slots) * kMidSyncBytes));
     e->mid_slots = slots;
     return BN_OK;
 }
@@ -999,7 +999,14 @@ static int run_small(bn_engine* e, double eps, int32_t max_sweeps, double* copy_
 
 // the mid-size kernel is the path of choice for this engine (measured: grids, chains and trees run faster on the resident tiles)
 static bool mid_applies(const bn_engine* e) {
-    return e->mid_ok && e->multisweep != 0 && (e->mid_mode == 2 || (e->mid_mode == 1 && !e->resident_ok));
+    if (!e->mid_ok || e->multisweep == 0 || e->mid_mode == 0) return false;
+    if (e->mid_mode == 2) return true;
+    if (e->resident_ok) return false;
+    // beyond 32 workgroups the grid barrier takes two levels and most of the gain: still ahead of the any-arity tiles (2 000-node
+    // mixed network, 61 workgroups: 14.9 -> 10.8 us per sweep), behind the k = 4 lane-group tiles (200 nodes with 1 024-entry
+    // tables, 42 workgroups: 8.8 -> 10.5)
+    const bool lane_groups = (e->plan.variants >> kVariantGroup) & 1;
+    return e->mid.parts.size() <= 32 || !lane_groups;
 }
 
 // Networks spread over several workgroups (bn_mid.hip).  The arguments of a launch over the sets [set_base, set_base + n)
@@ -1029,7 +1036,7 @@ static MidArgs mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides& 
 static int mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to) {
     hipStream_t s = e->stream;
     *e->h_abort = 0;
-    HIPCHK(hipMemsetAsync(e->d_m_sync + size_t(a.slot_base) * 64, 0, size_t(n_sets) * 64, s));
+    HIPCHK(hipMemsetAsync(e->d_m_sync + size_t(a.slot_base) * kMidSyncBytes, 0, size_t(n_sets) * kMidSyncBytes, s));
     if (int code = launch_bp_mid(a, e->mid.waves, e->mid.rounds, e->mid.lds_bytes, n_sets, s))
         return fail(BN_ERR_HIP, std::string("bp_mid launch failed: ") + hipGetErrorString(hipError_t(code)));
     if (copy_to) HIPCHK(hipMemcpyAsync(copy_to, copy_from, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));

@@ -60,7 +60,8 @@ struct SmallPlan {
 
 // A network spread over several workgroups (bn_mid.hip): one SmallPlan per contiguous node range, message / node-vector indices
 // global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
-constexpr int kMidMaxParts = 32;
+constexpr int kMidMaxParts = 96;
+constexpr int kMidSyncBytes = 512;   // per state slot: the barrier counter, the three residual words (8 bytes on), the group counters (64 bytes on)
 constexpr int kMidPreferredParts = 16;
 struct MidPlan {
     bool ok = false;
@@ -142,7 +143,7 @@ struct MidArgs {
     double* npi;
     double* nlam;
     uint8_t* frz;
-    unsigned* bar;               // grid barrier counter, zeroed by the host before a launch
+    unsigned* bar;               // grid barrier counter (bar[16 + g]: the counter of workgroup group g), zeroed by the host before a launch
     unsigned long long* res;     // [3] maximum_difference of iteration s in word s % 3, zeroed by the host before a launch
     unsigned* abort;             // page-locked host word
     unsigned long long timeout_ticks;

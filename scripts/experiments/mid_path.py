@@ -15,7 +15,8 @@ import oracle  # noqa: E402
 nets = [(f"mixed{n}", synth.random_dag(n, mp, 16, [2, 3, 4, 3, 2, 4, 5], seed=seed)) for n, mp, seed in ((80, 3, 10), (150, 3, 11), (300, 3, 12), (600, 3, 13), (1000, 3, 14))]
 nets += [("dag60k4", synth.random_dag(60, 4, 16, 4, seed=5)), ("grid12k3", synth.grid(12, 12, 3, seed=1)), ("grid16k4", synth.grid(16, 16, 4, seed=1)),
          ("grid32k4", synth.grid(32, 32, 4, seed=1)), ("dag200k4p2", synth.random_dag(200, 2, 16, 4, seed=5)), ("dag1000k2p3", synth.random_dag(1000, 3, 16, 2, seed=5)),
-         ("chain400k4", synth.grid(400, 1, 4, seed=1))]
+         ("chain400k4", synth.grid(400, 1, 4, seed=1)), ("dag200k4", synth.random_dag(200, 4, 64, 4, seed=200)),
+         ("mixed3000", synth.random_dag(3000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=15)), ("mixed2000", synth.random_dag(2000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=16))]
 if len(sys.argv) > 1:
     nets = [x for x in nets if x[0] in sys.argv[1:]]
 for name, mod in nets:
