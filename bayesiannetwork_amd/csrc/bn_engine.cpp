@@ -1000,13 +1000,14 @@ static int run_small(bn_engine* e, double eps, int32_t max_sweeps, double* copy_
 // the mid-size kernel is the path of choice for this engine (measured: grids, chains and trees run faster on the resident tiles)
 static bool mid_applies(const bn_engine* e) {
     if (!e->mid_ok || e->multisweep == 0 || e->mid_mode == 0) return false;
-    if (e->mid_mode == 2) return true;
-    if (e->resident_ok) return false;
-    // beyond 32 workgroups the grid barrier takes two levels and most of the gain: still ahead of the any-arity tiles (2 000-node
-    // mixed network, 61 workgroups: 14.9 -> 10.8 us per sweep), behind the k = 4 lane-group tiles (200 nodes with 1 024-entry
-    // tables, 42 workgroups: 8.8 -> 10.5)
-    const bool lane_groups = (e->plan.variants >> kVariantGroup) & 1;
-    return e->mid.parts.size() <= 32 || !lane_groups;
+    if (e->mid_mode == 2 || !e->resident_ok) return true;
+    // Networks the resident tiles cover as well (scripts/experiments/mid_path.py, us per sweep resident / this path): with two
+    // parents per node and four states the tile's 64-entry contraction costs more than the items (16 x 16 grid 5.9 / 4.3,
+    // 32 x 32 7.0 / 6.4, 200-node DAG 6.7 / 4.3); chains, trees and smaller tables stay on the tiles (400-node chain 3.2 / 4.3,
+    // 12 x 12 grid of k = 3: 3.7 / 4.3).
+    int kmax = 0;
+    for (int32_t k : e->plan.k) kmax = std::max(kmax, int(k));
+    return e->mid.parts[0].mmax >= 2 && kmax >= 4;
 }
 
 // Networks spread over several workgroups (bn_mid.hip).  The arguments of a launch over the sets [set_base, set_base + n)

@@ -1,13 +1,13 @@
 // bn_mid.hip -- networks too large for ONE workgroup's LDS but small enough for a few dozen: the items of bn_small.hip
-// (CPT entries, accumulator elements, product elements -- bn_small.hpp) spread over up to 32 workgroups by contiguous
+// (CPT entries, accumulator elements, product elements -- bn_small.hpp) spread over up to 128 workgroups by contiguous
 // node ranges, one launch for the whole run.  Reference: belief_propagation.hpp:33-158.
 //
 // What differs from bn_small.hip: the STATE (pi / lambda-messages, node vectors, evidence marks) lives in device memory
 // and is read and written with agent-scope accesses (sc1: through to L2 / memory, coherent across the XCDs); only the
 // staged terms, the parent terms and the child lists of a workgroup's own nodes are in its LDS.  An iteration is
 //   entries (gathers from memory) -> staging (LDS) -> s_barrier -> accumulators + products -> stores to memory,
-//   the workgroup's maximum_difference -> one atomic max -> GRID barrier (one atomic add per workgroup on a counter
-//   that only grows, one polling thread per workgroup) -> every workgroup reads the same word: same stop decision.
+//   the workgroup's maximum_difference -> one atomic max -> GRID barrier (a flag word per workgroup: it stores the
+//   generation there, its first wave reads all flags) -> every workgroup reads the same word: same stop decision.
 // Sums and products keep the reference's order: bit-identical to the oracle, like bn_small.hip.
 // Every wait is bounded: a workgroup that gives up raises *abort (page-locked host word) and leaves; the host redoes the
 // run with one launch per sweep.
@@ -122,39 +122,34 @@ __device__ __forceinline__ double mid_normalize(double* line, int lane, int k, i
     return val / sum;
 }
 
-// Grid barrier number `gen` (1, 2, ...): every workgroup's stores are out, one thread counts the workgroup off and polls.
-// Up to 32 workgroups count on ONE word (30 workgroups: 7.7 us per sweep flat, 8.1 in two levels); beyond that in two levels (groups of eight count on a word of their own, the last
-// arrival of a group counts the group off on the common word): arrivals on one address are serialised in L2, ~30 ns each.
-// Returns false when the wait gave up (or another workgroup has).
+// Grid barrier number `gen` (1, 2, ...).  Every workgroup has a flag word on a line of its own: once the workgroup's stores are
+// out, it STORES the generation there (no atomic: arrivals on one counter are serialised in L2, ~30 ns each -- 2.5 us at 30
+// workgroups, ~5 us at 60-85 even in two levels), and its first wave reads all flags, a lane per workgroup, until none is behind.
+// Bounded: returns false when the wait gave up (or another workgroup has).
 __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds& L, unsigned gen, int tid) {
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
     __syncthreads();
-    if (tid == 0) {
-        unsigned give_up = 0;
-        unsigned target;
-        if (a.nparts <= 32) {
-            __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            target = gen * unsigned(a.nparts);
-        } else {
-            const unsigned g = blockIdx.x >> 3, ngroups = (unsigned(a.nparts) + 7u) >> 3;
-            const unsigned gs = g + 1 < ngroups ? 8u : unsigned(a.nparts) - 8u * g;
-            const unsigned old = __hip_atomic_fetch_add(a.bar + 16 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old + 1 == gen * gs) __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            target = gen * ngroups;
-        }
+    if (tid < kWave) {
+        unsigned* flags = a.bar + 32;
+        if (tid == 0) __hip_atomic_store(flags + 32 * blockIdx.x, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool has0 = tid < a.nparts, has1 = tid + kWave < a.nparts;
         const unsigned long long t0 = wall_clock64();
-        unsigned polls = 0;
-        while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        unsigned polls = 0, give_up = 0;
+        for (;;) {
+            const unsigned v0 = has0 ? __hip_atomic_load(flags + 32 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
+            const unsigned v1 = has1 ? __hip_atomic_load(flags + 32 * (tid + kWave), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
+            if (__ballot(v0 < gen || v1 < gen) == 0ull) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++polls & 255u) == 0) {
-                if (wall_clock64() - t0 > a.timeout_ticks || __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-                    __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned ab = __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (wall_clock64() - t0 > a.timeout_ticks || ab != 0) {
+                    if (tid == 0) __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     give_up = 1;
                     break;
                 }
             }
         }
-        *L.flag = give_up;
+        if (tid == 0) *L.flag = give_up;
     }
     __syncthreads();
     return *L.flag == 0;

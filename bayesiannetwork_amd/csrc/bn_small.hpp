@@ -60,9 +60,9 @@ struct SmallPlan {
 
 // A network spread over several workgroups (bn_mid.hip): one SmallPlan per contiguous node range, message / node-vector indices
 // global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
-constexpr int kMidMaxParts = 96;
-constexpr int kMidSyncBytes = 512;   // per state slot: the barrier counter, the three residual words (8 bytes on), the group counters (64 bytes on)
-constexpr int kMidPreferredParts = 16;
+constexpr int kMidMaxParts = 128;
+constexpr int kMidSyncBytes = 128 + 128 * kMidMaxParts;   // per state slot: the three residual words (8 bytes on), then one 128-byte line per workgroup: its barrier flag
+constexpr int kMidPreferredParts = 32;
 struct MidPlan {
     bool ok = false;
     std::string why;
@@ -143,7 +143,7 @@ struct MidArgs {
     double* npi;
     double* nlam;
     uint8_t* frz;
-    unsigned* bar;               // grid barrier counter (bar[16 + g]: the counter of workgroup group g), zeroed by the host before a launch
+    unsigned* bar;               // the slot's barrier words: workgroup p's flag at bar[32 + 32 p] (a line of its own), zeroed by the host before a launch
     unsigned long long* res;     // [3] maximum_difference of iteration s in word s % 3, zeroed by the host before a launch
     unsigned* abort;             // page-locked host word
     unsigned long long timeout_ticks;

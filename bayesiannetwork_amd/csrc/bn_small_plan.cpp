@@ -312,7 +312,9 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
     // About 16 workgroups where the network allows it: fewer, larger parts mean more rounds of items per thread (stamps: 1.7 us of
     // entry items + 1.7 us of accumulator items per iteration at four rounds), more parts a slower grid barrier (32 workgroups:
     // 300-node network 7.5 -> 7.8 us per sweep, 60-node / 12 k entries 7.2 -> 8.2); larger parts only where 32 do not hold the network
-    for (int64_t target = std::max<int64_t>(2000, std::min<int64_t>((total + kMidPreferredParts - 1) / kMidPreferredParts, 9000)); target <= 12000; target = target * 4 / 3 + 1) {
+    int64_t preferred = kMidPreferredParts;
+    if (const char* pp = std::getenv("BN_MID_PARTS")) preferred = std::max(2, std::min(kMidMaxParts, std::atoi(pp)));  // experiments
+    for (int64_t target = std::max<int64_t>(2000, std::min<int64_t>((total + preferred - 1) / preferred, 9000)); target <= 12000; target = target * 4 / 3 + 1) {
         // balanced: as many parts as the target asks for, each about total / parts
         const int64_t nparts_want = std::max<int64_t>(2, (total + target - 1) / target);
         if (nparts_want > kMidMaxParts) continue;

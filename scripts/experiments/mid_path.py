@@ -25,7 +25,7 @@ for name, mod in nets:
         e.bp_set_evidence(ev)
         res = {}
         for form in ("tiles", "mid"):
-            e.set_option("mid", 1 if form == "mid" else 0)
+            e.set_option("mid", 2 if form == "mid" else 0)   # 2: also where the policy would keep the tiles
             for _ in range(3):
                 r = e.bp_run_device(1e-6)
             reps = 30

@@ -55,6 +55,7 @@ def test_batch_caps_and_reuse(Engine):
     g = synth.grid(48, 48, 4, seed=5)
     evs = [synth.random_evidence(g, 0.03, seed=2), None, Evidence.from_dict(g, {5: np.array([0.2, 0.5, 0.2, 0.1]), 900: 2})]
     with Engine(g) as eng:
+        eng.set_option("mid", 0)   # the resident kernel's batch form (by default: tests/test_mid_gpu.py)
         _check_batch(eng, evs, 1e-12, max_sweeps=3, want_path=2)   # every set capped together
         _check_batch(eng, evs, 1e-3, want_path=2)
         _check_batch(eng, evs[:1], 1e-6, want_path=2)              # a batch of one
@@ -103,6 +104,7 @@ def test_batch_more_sets_than_one_resident_launch_walks(Engine):
     g = synth.grid(40, 40, 4, seed=3)
     evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(19)]   # 5 launches: 4 + 4 + 4 + 4 + 3 sets (kResidentMaxSets = 4, balanced chunks)
     with Engine(g) as eng:
+        eng.set_option("mid", 0)
         _check_batch(eng, evs, 1e-6, want_path=2, reps=1)
         eng.set_option("multisweep", 0)                              # the same batch through the per-sweep launches
         out = eng.bp_run_batch(evs, 1e-6)
@@ -139,4 +141,5 @@ def test_batch_beyond_64_sets_on_every_path(Engine):
     g = synth.grid(40, 40, 4, seed=3)
     evs = [synth.random_evidence(g, 0.01 * (q % 5), seed=q) for q in range(70)]
     with Engine(g) as eng:
+        eng.set_option("mid", 0)
         _check_batch(eng, evs, 1e-4, want_path=2, reps=1)

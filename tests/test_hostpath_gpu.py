@@ -64,6 +64,7 @@ def test_stats_report_resident_aborts(Engine):
     g = synth.grid(40, 40, 4, seed=2)
     with Engine(g) as eng:
         eng.set_option("multisweep", 2)
+        eng.set_option("mid", 0)   # (by default this grid takes the several-workgroup item kernel)
         eng.bp_run(None, 1e-3)
         assert eng.last_path() == 2
         assert eng.bp_stats()["resident_aborts"] == 0

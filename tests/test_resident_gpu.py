@@ -27,7 +27,8 @@ def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
     lags an iteration: the state the run ends in must be the one BEFORE the speculative iteration), 0 = grid barrier
     per sweep.  One-block grids run the same LDS-only code under either setting."""
     r0, res0, (pi0, lam0) = want
-    eng.set_option("small", 0)   # (the smallest networks here would otherwise take the one-workgroup path: tests/test_small_gpu.py)
+    eng.set_option("small", 0)   # (the smallest networks here would otherwise take the one-workgroup path: tests/test_small_gpu.py,
+    eng.set_option("mid", 0)     #  mid-size ones of k = 4 with two parents the several-workgroup path: tests/test_mid_gpu.py)
     eng.set_option("multisweep", 2)
     for flow in (1, 0):
         eng.set_option("flow", flow)
@@ -78,6 +79,7 @@ def test_resident_trees_and_dags(Engine):
         d = synth.random_dag(700, 2, 8, [4, 3, 2][seed % 3], seed=40 + seed)
         ev = synth.random_evidence(d, 0.02, seed=seed)
         with Engine(d, lanes_per_node=2) as eng:
+            eng.set_option("mid", 0)   # this test is about the resident kernel
             want = _launch_path(eng, ev, 1e-6)
             eng.set_option("multisweep", 2)
             eng.bp_run(ev, 1e-6)
@@ -126,6 +128,9 @@ def test_paths_are_chosen_by_eligibility(Engine):
         assert eng.info("resident_waves") == 8
     with Engine(synth.grid(20, 20, 4, seed=1)) as eng:
         eng.set_option("multisweep", 2)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() == 4   # k = 4, two parents, 400 nodes: the item kernel over several workgroups is faster than the tiles
+        eng.set_option("mid", 0)
         eng.bp_run(None, 1e-3)
         assert eng.last_path() == 2
         eng.set_option("multisweep", 0)
