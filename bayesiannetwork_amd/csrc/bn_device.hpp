@@ -120,6 +120,7 @@ struct ResidentSync {                   // one per evidence set; zeroed at creat
     } grp[8];
     unsigned long long blk[kResidentMaxBlocks][2];  // per tile block: the same, written by the block
     unsigned long long res[kResidentBudget];        // per-iteration maximum_difference, bit patterns (service block)
+    unsigned long long blk_odd[kResidentMaxBlocks][2];  // direct form: the granules of odd iterations (even ones in blk)
 };
 // Dataflow form (single evidence set, more than one tile block): no grid barrier.  Every TILE (wave) publishes, per
 // iteration, a pair of 8-byte granules {generation | half of its residual's bit pattern} into the slot of the
@@ -186,6 +187,7 @@ struct ResidentArgs {
     int32_t nbr_chunks;
     int32_t poll_sleep;               // pause between two polls of a waiting tile, in units of s_sleep(8) = 512 cycles
     unsigned* host_abort;             // pinned: set by whoever gives up a bounded wait
+    int32_t direct;                   // grid-barrier form, one evidence set: every tile block reads all blocks' granules itself (no service block)
 };
 int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // a.flow != nullptr: the dataflow form  // lean_k: uniform arity with <= 2 children per node, else 0
 

@@ -115,6 +115,10 @@ __device__ __forceinline__ int verdict_of(const ResidentArgs& a, double r, int n
 // tile block.  With several sets in flight the whole of it runs behind the other sets' sweeps.
 // (A two-level collection -- one service block per group, then a top block -- was measured ~0.3 us slower per
 // barrier than this single sweep over all tile blocks' granules.)
+// Direct form (ResidentArgs::direct, one evidence set -- the default there since round 3): no service block; the first wave of
+// EVERY tile block sweeps all blocks' granules itself and takes the decision (wait_verdict): one hand-off per barrier instead
+// of two, 0.3-0.5 us per sweep (32 x 32 grid 6.98 -> 6.46 us, 316 x 316 11.46 -> 11.04).  Granules of consecutive iterations
+// alternate between two tables, so a block already past a barrier cannot overwrite what a slower block still has to read.
 __device__ __forceinline__ unsigned long long granule(unsigned gen, unsigned half) { return ((unsigned long long)gen << 32) | half; }
 
 // First half of the barrier of iteration `it` (sweep s) of evidence set `set`: publish the block's residual.
@@ -136,8 +140,11 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
             sh.verdict[set] = verdict_of(a, residual_of(m), s + 1);
         } else {
             const unsigned gen = a.gen_base + unsigned(it) + 1u;
-            __hip_atomic_store(&sy->blk[blockIdx.x][0], granule(gen, unsigned(m >> 32)), RLX_AGENT);
-            __hip_atomic_store(&sy->blk[blockIdx.x][1], granule(gen, unsigned(m)), RLX_AGENT);
+            // direct form: the granules of consecutive iterations alternate between two tables -- a block that is already past
+            // this barrier must not overwrite what a slower block still has to read
+            unsigned long long* g = (a.direct != 0 && (it & 1)) ? sy->blk_odd[blockIdx.x] : sy->blk[blockIdx.x];
+            __hip_atomic_store(g, granule(gen, unsigned(m >> 32)), RLX_AGENT);
+            __hip_atomic_store(g + 1, granule(gen, unsigned(m)), RLX_AGENT);
         }
     }
 }
@@ -160,6 +167,44 @@ __device__ __forceinline__ bool poll_until(const ResidentArgs& a, Pred&& pred) {
 
 // Second half: the verdict of iteration `it` of `set` once every block has arrived.
 __device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& sh, int set, int it) {
+    if (a.direct != 0 && a.n_tile_blocks > 1) {
+        // Direct form (one evidence set): the first wave of EVERY tile block sweeps all blocks' granules itself -- lane l those of
+        // blocks l, l + 64, ... -- reduces the residual and takes the (same) decision: one hand-off (granule store -> the other
+        // blocks' poll) instead of two (granule -> service block -> verdict word -> poll).
+        if (threadIdx.x < kWave) {
+            int lane = int(threadIdx.x);
+            // opaque to the optimiser: otherwise the per-lane granule addresses are hoisted out of the sweep loop as loop invariants
+            // and, with the tile's CPT and vectors live in this wave (256 VGPRs), spilled to scratch and reloaded every sweep
+            asm volatile("" : "+v"(lane));
+            ResidentSync* sy = a.sync + set;
+            const unsigned gen = a.gen_base + unsigned(it) + 1u;
+            const int nb = a.n_tile_blocks;
+            // generation and value come with the same load: a second pass over the granules once all have arrived would put another
+            // memory round trip (~1 us) on every sweep (measured: 0.153 instead of 0.143 ms per headline query)
+            unsigned long long (*g)[2] = (it & 1) ? sy->blk_odd : sy->blk;
+            unsigned long long m = 0;
+            const bool ok = poll_until(a, [&] {
+                bool mine = true;
+                unsigned long long acc = 0;
+                for (int blk = lane; blk < nb; blk += kWave) {
+                    const unsigned long long hi = __hip_atomic_load(&g[blk][0], RLX_AGENT);
+                    const unsigned long long lo = __hip_atomic_load(&g[blk][1], RLX_AGENT);
+                    mine = mine && unsigned(hi >> 32) == gen && unsigned(lo >> 32) == gen;
+                    const unsigned long long v = (hi << 32) | (lo & 0xffffffffull);
+                    acc = v > acc ? v : acc;
+                }
+                m = acc;
+                return __all(mine) != 0;
+            });
+            m = wave_umax(m);
+            if (lane == 0) {
+                if (blockIdx.x == 0 && ok) __hip_atomic_store(&sy->res[it], m, RLX_AGENT);   // the residual history (read back by this block)
+                sh.verdict[set] = ok ? verdict_of(a, residual_of(m), a.sweep_begin + it + 1) : kAbort;
+            }
+        }
+        __syncthreads();
+        return sh.verdict[set];
+    }
     if (threadIdx.x == 0 && a.n_tile_blocks > 1) {
         ResidentSync* sy = a.sync + set;
         const unsigned gen = a.gen_base + unsigned(it) + 1u;
@@ -181,6 +226,7 @@ __device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& 
 // reduces the residual, lane 0 decides and publishes.  It follows the same (iteration, set) order as the tile
 // blocks and knows from its own verdicts which sets are still running.
 __device__ __forceinline__ void resident_service(const ResidentArgs& a, int lane) {
+    if (a.direct != 0) return;  // every tile block collects the granules itself
     const int nb = a.n_tile_blocks;
     const int groups = nb < 8 ? nb : 8;
     unsigned active = a.set_mask;
@@ -245,7 +291,9 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
                 if (blockIdx.x == 0 && wave == 0) {  // report: residual history (final since each barrier), outcome
                     const ResidentSync* sy = a.sync + set;
                     double* hist = a.b.res_hist + int64_t(set) * a.res_hist_stride;
-                    for (int q = lane; q < it; q += kWave)
+                    int q0 = lane;
+                    asm volatile("" : "+v"(q0));  // once per run: its addresses must not be carried (spilled) through the sweep loop
+                    for (int q = q0; q < it; q += kWave)
                         if (a.sweep_begin + q < a.b.res_cap)
                             hist[a.sweep_begin + q] = residual_of(__hip_atomic_load(&sy->res[q], RLX_AGENT));
                     if (lane == 0) {

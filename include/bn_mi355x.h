@@ -206,6 +206,9 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * "flow" 1/0 -- resident path, one evidence set, more than one tile block (BN_RESIDENT_FLOW sets the default, 0):
  *   1 = dataflow form: a tile waits for the tiles it exchanges messages with instead of for a grid barrier, and
  *   the stop decision lags one iteration behind; 0 = grid barrier per sweep.  Same bits either way.
+ * "direct" 1/0 -- resident path, grid-barrier form, one evidence set (BN_RESIDENT_DIRECT sets the default, 1): 1 = every tile block
+ *   reads all blocks' arrival words itself and takes the stop decision (one hand-off per barrier); 0 = a service block collects
+ *   them and publishes the decision (two).  Same bits.
  * "poll_sleep" n -- dataflow form: pause between two polls of a waiting tile, n x 512 cycles (default 2).
  * "beliefs_direct" 1/0 -- bn_bp_run_view: the kernels write the marginals straight into the engine's mapped host
  *   buffer (default 1, outputs up to 16 MB) instead of a copy command queued behind the run.
