@@ -30,22 +30,25 @@ def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
     eng.set_option("small", 0)   # (the smallest networks here would otherwise take the one-workgroup path: tests/test_small_gpu.py,
     eng.set_option("mid", 0)     #  mid-size ones of k = 4 with two parents the several-workgroup path: tests/test_mid_gpu.py)
     eng.set_option("multisweep", 2)
-    for flow in (1, 0):
+    # (flow, direct): the barrier form with its two collectors -- every tile block reads all granules itself (default) / the service block
+    for flow, direct in ((1, 1), (0, 1), (0, 0)):
         eng.set_option("flow", flow)
-        for i in range(reps if flow else max(2, reps // 4)):
+        eng.set_option("direct", direct)
+        for i in range(reps if flow or direct else max(2, reps // 4)):
             r = eng.bp_run(ev, eps, max_sweeps)
             assert eng.last_path() != 0
             if want_path is not None:
                 assert eng.last_path() == want_path
             assert eng.info("last_flow") == (flow if eng.info("flow_eligible") else 0)
-            assert r["sweeps"] == r0["sweeps"], f"flow {flow} run {i}"
-            assert np.array_equal(r["beliefs"], r0["beliefs"], equal_nan=True), f"flow {flow} run {i}"
+            assert r["sweeps"] == r0["sweeps"], f"flow {flow} direct {direct} run {i}"
+            assert np.array_equal(r["beliefs"], r0["beliefs"], equal_nan=True), f"flow {flow} direct {direct} run {i}"
             assert r["residual"] == r0["residual"] or (np.isnan(r["residual"]) and np.isnan(r0["residual"]))
-        assert np.array_equal(eng.bp_residuals(), res0), f"flow {flow}"
+        assert np.array_equal(eng.bp_residuals(), res0), f"flow {flow} direct {direct}"
         pi, lam = eng.bp_messages()
-        assert np.array_equal(pi, pi0, equal_nan=True) and np.array_equal(lam, lam0, equal_nan=True), f"flow {flow}"
+        assert np.array_equal(pi, pi0, equal_nan=True) and np.array_equal(lam, lam0, equal_nan=True), f"flow {flow} direct {direct}"
         assert eng.bp_stats()["resident_aborts"] == 0
     eng.set_option("flow", 1)
+    eng.set_option("direct", 1)
 
 
 @pytest.mark.parametrize("rows,cols,k,frac,eps,reps", [
