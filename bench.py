@@ -231,7 +231,7 @@ def roofline_of(t, label):
         out["note"] = ("achieved = SURVEY 8(d) algorithmic bytes (CPT read once per node and sweep) / time; the resident kernel "
                        "keeps the CPTs in registers / LDS for the whole run, so its real traffic (`traffic`, `traffic_gbs`) is "
                        "about a third of the algorithmic bytes: frac measures time against the per-sweep formulation's floor, "
-                       "not HBM utilisation")
+                       "not HBM utilisation (it can exceed 1: the kernel does not move the CPT bytes the floor prices)")
     return out
 
 
