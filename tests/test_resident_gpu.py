@@ -54,6 +54,7 @@ def _check_same(eng, ev, eps, want, reps, max_sweeps=0, want_path=None):
 @pytest.mark.parametrize("rows,cols,k,frac,eps,reps", [
     (316, 316, 4, 0.01, 1e-3, 40), (316, 316, 4, 0.0, 1e-6, 10), (64, 64, 4, 0.05, 1e-9, 10), (40, 33, 3, 0.02, 1e-6, 10),
     (50, 50, 2, 0.02, 1e-6, 10), (1, 300, 4, 0.0, 1e-6, 10), (7, 5, 4, 0.1, 1e-3, 10), (128, 128, 4, 0.01, 1e-6, 10),
+    (338, 338, 4, 0.01, 1e-3, 4),   # 1 786 tiles = 224 blocks: the most the path admits (the granule sweep's fourth round is partly filled)
 ])
 def test_resident_equals_launch_path_grids(Engine, rows, cols, k, frac, eps, reps):
     from bayesiannetwork_amd import synth
@@ -63,6 +64,8 @@ def test_resident_equals_launch_path_grids(Engine, rows, cols, k, frac, eps, rep
         # every multi-block grid here must really take the dataflow form (a first-column tile of a wide grid has
         # more than 64 neighbour tiles: polled in rounds of 64)
         assert eng.info("flow_eligible") == (1 if eng.info("resident_blocks") > 1 else 0)
+        if rows == 338:
+            assert eng.info("resident_blocks") == 224
         want = _launch_path(eng, ev, eps)
         _check_same(eng, ev, eps, want, reps, want_path=2)
         # alternate the paths and the evidence: nothing of one run may leak into the next
