@@ -13,15 +13,16 @@
 // Between iterations stands ONE grid barrier (the Jacobi schedule needs nothing finer):
 //   producer  message stores are 16-byte WRITE-THROUGH (sc1) stores; every wave drains them
 //             (s_waitcnt vmcnt(0)), __syncthreads(), then lane 0 of the block arrives;
-//   barrier   atomic-free: a tile block publishes a pair of 8-byte {generation, residual half} granules and
-//             goes on; ONE SERVICE block (an extra block of the launch on a CU the tiles leave free) sweeps the
-//             granules of all tile blocks, reduces the residual, decides, and publishes generation + verdict
-//             in one word per group of tile blocks (blockIdx % 8: spreads the pollers), which the tile blocks
-//             poll (relaxed agent-scope loads + s_sleep).  Loads of the records are sc1, so no acquire fence
-//             is needed.  (cdna_hip_programming.md Guideline 16 R2 / MI355X_MICROARCH.md barrier-xcd,
-//             handoff-1to1.)  Nothing depends on dispatch order or on which XCD a block runs.
-//   residual  max|new - old| (:105-131) travels in the granules; the service block takes the stop decision
-//             (:147) and every block reads the same verdict.
+//   barrier   atomic-free: a tile block publishes a pair of 8-byte {generation, residual half} granules.  One evidence set
+//             (ResidentArgs::direct, the default): the first wave of EVERY tile block sweeps all blocks' granules itself --
+//             one memory round trip per sweep (sweep_granules) -- reduces the residual and takes the same decision.
+//             Several sets per launch, or "direct" 0: ONE SERVICE block (an extra block of the launch on a CU the tiles
+//             leave free) does the sweep and publishes generation + verdict in one word per group of tile blocks
+//             (blockIdx % 8: spreads the pollers), which the tile blocks poll (relaxed agent-scope loads + s_sleep).
+//             Loads of the records are sc1, so no acquire fence is needed.  (cdna_hip_programming.md Guideline 16 R2 /
+//             MI355X_MICROARCH.md barrier-xcd, handoff-1to1.)  Nothing depends on dispatch order or on which XCD a block runs.
+//   residual  max|new - old| (:105-131) travels in the granules; whoever collects them takes the stop decision
+//             (:147): every block arrives at the same verdict.
 // A one-block grid (<= 8 tiles: Pearl's network, small chains) needs no atomics at all: LDS slots and
 // __syncthreads().
 //
