@@ -314,10 +314,13 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
     // 300-node network 7.5 -> 7.8 us per sweep, 60-node / 12 k entries 7.2 -> 8.2); larger parts only where 32 do not hold the network
     int64_t preferred = kMidPreferredParts;
     if (const char* pp = std::getenv("BN_MID_PARTS")) preferred = std::max(2, std::min(kMidMaxParts, std::atoi(pp)));  // experiments
-    for (int64_t target = std::max<int64_t>(2000, std::min<int64_t>((total + preferred - 1) / preferred, 9000)); target <= 12000; target = target * 4 / 3 + 1) {
+    constexpr int64_t kTargetMax = 12000;  // staged terms a part may hold (LDS)
+    for (int64_t target = std::max<int64_t>(2000, std::min<int64_t>((total + preferred - 1) / preferred, 9000));;
+         target = std::min(kTargetMax, target * 4 / 3 + 1)) {
+        const bool last = target == kTargetMax;  // (the growth used to step over the largest target: 9 000 -> 12 001)
         // balanced: as many parts as the target asks for, each about total / parts
         const int64_t nparts_want = std::max<int64_t>(2, (total + target - 1) / target);
-        if (nparts_want > kMidMaxParts) continue;
+        if (nparts_want > kMidMaxParts) { if (last) break; continue; }
         const int64_t per = (total + nparts_want - 1) / nparts_want;
         std::vector<int> cut{0};
         int64_t acc = 0;
@@ -333,7 +336,7 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
             all = parts[q].ok;
             if (!all) mp.why = parts[q].why;
         }
-        if (!all) continue;
+        if (!all) { if (last) break; continue; }
         mp.parts.swap(parts);
         mp.ok = true;
         mp.waves = 0; mp.rounds = 0; mp.lds_bytes = 0;
