@@ -16,7 +16,11 @@ nets = [(f"mixed{n}", synth.random_dag(n, mp, 16, [2, 3, 4, 3, 2, 4, 5], seed=se
 nets += [("dag60k4", synth.random_dag(60, 4, 16, 4, seed=5)), ("grid12k3", synth.grid(12, 12, 3, seed=1)), ("grid16k4", synth.grid(16, 16, 4, seed=1)),
          ("grid32k4", synth.grid(32, 32, 4, seed=1)), ("dag200k4p2", synth.random_dag(200, 2, 16, 4, seed=5)), ("dag1000k2p3", synth.random_dag(1000, 3, 16, 2, seed=5)),
          ("chain400k4", synth.grid(400, 1, 4, seed=1)), ("dag200k4", synth.random_dag(200, 4, 64, 4, seed=200)),
-         ("mixed3000", synth.random_dag(3000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=15)), ("mixed2000", synth.random_dag(2000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=16))]
+         ("mixed3000", synth.random_dag(3000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=15)), ("mixed2000", synth.random_dag(2000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=16)),
+         # 96-128 parts at the largest part size
+         ("mixed2k4p", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)), ("dag800k4", synth.random_dag(800, 4, 48, 4, seed=77)),
+         ("dag600k4", synth.random_dag(600, 4, 48, 4, seed=78)), ("mixed5000", synth.random_dag(5000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=17)),
+         ("k5p3_1200", synth.random_dag(1200, 3, 32, 5, seed=18))]
 if len(sys.argv) > 1:
     nets = [x for x in nets if x[0] in sys.argv[1:]]
 for name, mod in nets:
