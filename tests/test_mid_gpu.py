@@ -102,3 +102,18 @@ def test_mid_batches_and_the_view(Engine, oracle_mod):
         got = np.concatenate([np.asarray(m).ravel() for m in bp(evs[q % 7], 1e-6)])
         assert np.array_equal(got, oracle_mod.bp_run(g, evs[q % 7], 1e-6)["beliefs"]), q
     assert bp.engine.last_path() == 4
+
+
+def test_mid_batch_on_a_network_of_more_than_100_workgroups(Engine, oracle_mod):
+    """108 workgroups per set: two sets per launch fit the chip; five sets = three launches, every set the oracle bit for bit."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)
+    evs = [synth.random_evidence(g, f, seed=40 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1])]
+    with Engine(g) as eng:
+        assert eng.info("mid_eligible") == 1 and eng.info("mid_parts") > 100
+        out = eng.bp_run_batch(evs, 1e-6)
+        assert eng.last_path() == 4 and eng.info("mid_aborts") == 0
+        for q, ev in enumerate(evs):
+            o = oracle_mod.bp_run(g, ev, 1e-6)
+            assert out["sweeps"][q] == o["sweeps"] and np.array_equal(out["beliefs"][q], o["beliefs"], equal_nan=True), q
+            assert np.array_equal(eng.bp_residuals_batch(q), o["residuals"]), q
