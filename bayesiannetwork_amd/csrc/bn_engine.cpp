@@ -546,6 +546,10 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 e->small_ok = true;
             }
         }
+        if (e->mid.ok && e->n_cus > 0 && int64_t(e->mid.parts.size()) > int64_t(e->n_cus) * 9 / 10) {
+            e->mid.ok = false;  // the workgroups of a run wait for each other: one per CU, with room to spare
+            e->mid.why = "more workgroups than 0.9 x the device's CUs";
+        }
         if (e->mid.ok) {
             const MidPlan& mp = e->mid;
             std::vector<MidPart> parts;

@@ -132,13 +132,18 @@ __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds&
     if (tid < kWave) {
         unsigned* flags = a.bar + 32;
         if (tid == 0) __hip_atomic_store(flags + 32 * blockIdx.x, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool has0 = tid < a.nparts, has1 = tid + kWave < a.nparts;
+        static_assert(kMidMaxParts <= 4 * kWave, "a poll reads every workgroup's flag: lane l those of workgroups l, l + 64, l + 128, l + 192");
+        const int rounds = (a.nparts + kWave - 1) / kWave;   // uniform: the loads of a poll are issued back to back, one round trip
+        const int last = a.nparts - 1;
         const unsigned long long t0 = wall_clock64();
         unsigned polls = 0, give_up = 0;
         for (;;) {
-            const unsigned v0 = has0 ? __hip_atomic_load(flags + 32 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
-            const unsigned v1 = has1 ? __hip_atomic_load(flags + 32 * (tid + kWave), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gen;
-            if (__ballot(v0 < gen || v1 < gen) == 0ull) break;
+            // (a lane past the last workgroup looks at the last one's flag again)
+            unsigned v0 = __hip_atomic_load(flags + 32 * (tid < last ? tid : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = gen, v2 = gen, v3 = gen;
+            if (rounds > 1) v1 = __hip_atomic_load(flags + 32 * (tid + kWave < last ? tid + kWave : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rounds > 2) v2 = __hip_atomic_load(flags + 32 * (tid + 2 * kWave < last ? tid + 2 * kWave : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rounds > 3) v3 = __hip_atomic_load(flags + 32 * (tid + 3 * kWave < last ? tid + 3 * kWave : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(v0 < gen || v1 < gen || v2 < gen || v3 < gen) == 0ull) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++polls & 255u) == 0) {
                 const unsigned ab = __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

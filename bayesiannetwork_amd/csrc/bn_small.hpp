@@ -60,7 +60,7 @@ struct SmallPlan {
 
 // A network spread over several workgroups (bn_mid.hip): one SmallPlan per contiguous node range, message / node-vector indices
 // global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
-constexpr int kMidMaxParts = 128;
+constexpr int kMidMaxParts = 224;   // workgroups of one run: all co-resident, one per CU (the engine admits a plan only below 0.9 x CUs); <= 4 x 64 flags per barrier poll
 constexpr int kMidSyncBytes = 128 + 128 * kMidMaxParts;   // per state slot: the three residual words (8 bytes on), then one 128-byte line per workgroup: its barrier flag
 constexpr int kMidPreferredParts = 32;
 struct MidPlan {
