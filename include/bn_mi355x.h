@@ -197,7 +197,7 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   trees and two-round networks the resident kernel runs in one block; "multisweep" 0 also turns it off), 2 = wherever
  *   eligible.  bn_bp_run_batch on such a network runs one workgroup per evidence set, all sets in one launch.
  *   bn_get_info "small_eligible".
- * "mid" 0/1/2 -- MID-SIZE networks (beyond one workgroup's LDS, up to 128 workgroups' worth: a few hundred to a few thousand nodes
+ * "mid" 0/1/2 -- MID-SIZE networks (beyond one workgroup's LDS, up to 224 workgroups' worth: a few hundred to ten thousand nodes
  *   of mixed arity with <= 8 parents): the same items as "small", spread over several workgroups by node ranges, state in
  *   device memory, a grid barrier per iteration, one launch per run; bit-identical to the CPU restatement as well.  0 = never,
  *   1 = where eligible and not measured slower than the resident tiles (default: everything the resident tiles do not cover,
