@@ -21,7 +21,8 @@ def _nets():
             ("dag60k4_4parents", synth.random_dag(60, 4, 16, 4, seed=5)),                       # 1 024-entry tables: 256-term runs
             ("binary1000_3parents", synth.random_dag(1000, 3, 16, 2, seed=5)),
             ("k7", synth.random_dag(120, 2, 8, [7, 5, 6, 2], seed=8)),
-            ("mixed2k_4parents", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9))]       # 176 k entries: 108 workgroups at the largest part size
+            ("mixed2k_4parents", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)),       # 176 k entries: ~150 workgroups
+            ("mixed8000", synth.random_dag(8000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=19))]             # 318 k entries: 224 workgroups, the most a run may have
 
 
 @pytest.mark.parametrize("name", [n for n, _ in _nets()])
