@@ -10,6 +10,7 @@ The default single-GPU line also carries, as extra keys measured after the timed
   value_host_to_host : SURVEY 8(d)'s definition -- evidence upload to beliefs on the host (PCIe inclusive)
   config1_alarm      : BASELINE configs[0]'s network on the GPU: the ALARM-shaped 37-node net (queries per second)
   mid_mixed300       : a 300-node network of mixed arities (2-5), <= 3 parents: beyond one workgroup's LDS (bn_mid.hip)
+                       (+ `mixed10k`: the same path on 10 000 nodes / ~400 k CPT entries, more than 200 workgroups)
   config2_dag        : BASELINE configs[1], the 10 k-node random DAG
   config5_lw         : BASELINE configs[4], likelihood weighting on that DAG
   grid2048           : the HBM-resident point (4.2 M nodes, 3.76 GB per sweep)
@@ -468,6 +469,25 @@ def leg_mid(a, local_rank, torch):
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
                                "sample": f"{n} queries of the same cycle through oracle/bp_oracle.c, 1 thread"}
+    # the same path at the scale of configs[1]: 10 000 nodes of mixed arities, ~400 k CPT entries, more than 200 workgroups
+    big = synth.random_dag(10000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=20)
+    evs = [synth.random_evidence(big, 0.01, seed=7 + q) for q in range(8)]
+    with Engine(big, device=local_rank) as eng:
+        h2h = time_host_to_host(eng, big, evs, eps, 50)
+        o10 = {"workload": f"{big.n}-node random DAG, arities 2-5, <= 3 parents, {big.n_edges} edges, {len(big.cpt)} CPT entries, 1 % evidence, eps={eps:g}",
+               "path": PATH_NAME.get(eng.last_path()), "workgroups": eng.info("mid_parts"), "value": h2h["value"],
+               "unit": "edge-messages/s (evidence in, marginals on the host, one query per call)", "us_per_query": h2h["ms_per_step"] * 1e3,
+               "sweeps_per_query": h2h["sweeps_per_step"]}
+        dev, sweeps = 0.0, 0
+        for i in range(16):
+            r = eng.bp_run_view(evs[i % len(evs)], eps)
+            dev += eng.bp_stats()["sweep_devclock_ms"]
+            sweeps += r["sweeps"]
+        o10["kernel_us_per_sweep"] = dev / sweeps * 1e3
+        eng.set_option("mid", 0)
+        tiles = time_host_to_host(eng, big, evs, eps, 30)
+        o10["tile_kernels"] = {"us_per_query": tiles["ms_per_step"] * 1e3, "path": PATH_NAME.get(eng.last_path())}
+    out["mixed10k"] = o10
     return out
 
 
