@@ -315,12 +315,21 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
     int64_t preferred = kMidPreferredParts;
     if (const char* pp = std::getenv("BN_MID_PARTS")) preferred = std::max(2, std::min(kMidMaxParts, std::atoi(pp)));  // experiments
     constexpr int64_t kTargetMax = 12000;  // staged terms a part may hold (LDS)
-    for (int64_t target = std::max<int64_t>(2000, std::min<int64_t>((total + preferred - 1) / preferred, 9000));;
-         target = std::min(kTargetMax, target * 4 / 3 + 1)) {
-        const bool last = target == kTargetMax;  // (the growth used to step over the largest target: 9 000 -> 12 001)
+    // Targets tried in turn: from total / preferred (at least 2 000, at most 9 000) UP to the largest part size -- fewer, larger parts
+    // when the network needs more than kMidMaxParts of the first size -- and then DOWN from the first: the estimate is low for
+    // tables whose accumulator runs are padded most (1 024-entry tables), and a part that turns out too large for a workgroup
+    // asks for more, smaller parts, not fewer.
+    const int64_t start = std::max<int64_t>(2000, std::min<int64_t>((total + preferred - 1) / preferred, 9000));
+    std::vector<int64_t> targets;
+    for (int64_t t = start;; t = std::min(kTargetMax, t * 4 / 3 + 1)) {  // (the growth used to step over the largest target: 9 000 -> 12 001)
+        targets.push_back(t);
+        if (t == kTargetMax) break;
+    }
+    for (int64_t t = start * 3 / 4; t >= 1500; t = t * 3 / 4) targets.push_back(t);
+    for (const int64_t target : targets) {
         // balanced: as many parts as the target asks for, each about total / parts
         const int64_t nparts_want = std::max<int64_t>(2, (total + target - 1) / target);
-        if (nparts_want > kMidMaxParts) { if (last) break; continue; }
+        if (nparts_want > kMidMaxParts) continue;
         const int64_t per = (total + nparts_want - 1) / nparts_want;
         std::vector<int> cut{0};
         int64_t acc = 0;
@@ -336,9 +345,10 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
             all = parts[q].ok;
             if (!all) mp.why = parts[q].why;
         }
-        if (!all) { if (last) break; continue; }
+        if (!all) continue;
         mp.parts.swap(parts);
         mp.ok = true;
+        mp.why.clear();
         mp.waves = 0; mp.rounds = 0; mp.lds_bytes = 0;
         for (const SmallPlan& sp : mp.parts) {
             mp.waves = std::max(mp.waves, sp.waves);

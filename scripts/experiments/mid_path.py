@@ -23,7 +23,7 @@ nets += [("dag60k4", synth.random_dag(60, 4, 16, 4, seed=5)), ("grid12k3", synth
          ("k5p3_1200", synth.random_dag(1200, 3, 32, 5, seed=18)),
          # 200+ parts
          ("mixed8000", synth.random_dag(8000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=19)), ("mixed10000", synth.random_dag(10000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=20)),
-         ("dag1000k4", synth.random_dag(1000, 4, 48, 4, seed=77)), ("mixed4k4p", synth.random_dag(4000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=21))]
+         ("dag1000k4", synth.random_dag(1000, 4, 48, 4, seed=77)), ("dag800k4b", synth.random_dag(800, 4, 48, 4, seed=77)), ("dag400k4", synth.random_dag(400, 4, 48, 4, seed=79)), ("mixed4k4p", synth.random_dag(4000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=21))]
 if len(sys.argv) > 1:
     nets = [x for x in nets if x[0] in sys.argv[1:]]
 for name, mod in nets:
