@@ -426,7 +426,7 @@ def leg_alarm(a, local_rank, torch):
 
 def leg_mid(a, local_rank, torch):
     """A mid-size network of mixed arities (not a BASELINE config; the kind between configs[0] and configs[1]): 300 nodes, arities
-    2-5, up to 3 parents, 10.6 k CPT entries -- the item kernel over ~18 workgroups (csrc/bn_mid.hip) beside the tile kernels."""
+    2-5, up to 3 parents, 10.6 k CPT entries -- the item kernel over 37 workgroups (csrc/bn_mid.hip) beside the tile kernels."""
     from bayesiannetwork_amd import synth
     from bayesiannetwork_amd.engine import Engine
     g = synth.random_dag(300, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=12)
