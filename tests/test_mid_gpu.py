@@ -22,6 +22,7 @@ def _nets():
             ("binary1000_3parents", synth.random_dag(1000, 3, 16, 2, seed=5)),
             ("k7", synth.random_dag(120, 2, 8, [7, 5, 6, 2], seed=8)),
             ("mixed2k_4parents", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)),       # 176 k entries: ~150 workgroups
+            ("dag600k4_4parents", synth.random_dag(600, 4, 48, 4, seed=78)),                          # parts of the first size do not fit a workgroup: the planner falls back to smaller ones
             ("mixed8000", synth.random_dag(8000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=19))]             # 318 k entries: 224 workgroups, the most a run may have
 
 
