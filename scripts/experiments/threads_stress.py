@@ -14,20 +14,22 @@ import oracle  # noqa: E402
 
 alarm, _ = load_dsc(os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"))
 nets = [("small", alarm), ("mid", synth.random_dag(300, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=12)), ("resident", synth.grid(64, 64, 4, seed=1)),
-        ("mid_batch", synth.random_dag(150, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=11))]
+        ("mid_batch", synth.random_dag(150, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=11)),
+        ("mid_wide", synth.random_dag(2000, 4, 64, [2, 3, 4, 3, 2, 4, 4], seed=9)), ("resident_direct", synth.grid(316, 316, 4, seed=2))]   # ~150 / 196 co-resident workgroups each
 bad = []
 
 
 def work(name, g):
     evs = [synth.random_evidence(g, 0.05, seed=q) for q in range(4)]
-    want = [oracle.bp_run(g, ev, 1e-6) for ev in evs]
+    eps = 1e-3 if name == "resident_direct" else 1e-6
+    want = [oracle.bp_run(g, ev, eps) for ev in evs]
     with Engine(g) as e:
         for i in range(150):
             if name == "mid_batch":
-                out = e.bp_run_batch(evs * 8, 1e-6)
+                out = e.bp_run_batch(evs * 8, eps)
                 ok = all(np.array_equal(out["beliefs"][q], want[q % 4]["beliefs"]) for q in range(32))
             else:
-                r = e.bp_run_view(evs[i % 4], 1e-6)
+                r = e.bp_run_view(evs[i % 4], eps)
                 ok = r["sweeps"] == want[i % 4]["sweeps"] and np.array_equal(r["beliefs"], want[i % 4]["beliefs"])
             if not ok:
                 bad.append((name, i))
