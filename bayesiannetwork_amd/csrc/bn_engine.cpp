@@ -1014,8 +1014,10 @@ static bool mid_applies(const bn_engine* e) {
     // 12 x 12 grid of k = 3: 3.7 / 4.3).
     int kmax = 0;
     for (int32_t k : e->plan.k) kmax = std::max(kmax, int(k));
-    // ... up to the 40 x 40 grid (60 workgroups: 6.6 against 6.6-6.9); larger ones need more, larger parts and stay on the tiles (64 x 64: 6.4)
-    return e->mid.parts[0].mmax >= 2 && kmax >= 4 && e->mid.parts.size() <= 64;
+    // ... up to the size of the 40 x 40 grid (6.6 against 6.6-6.9); larger ones stay on the tiles (64 x 64: 6.4)
+    int mmax = 0;  // (over all parts: the first one may hold a grid's first row only)
+    for (const SmallPlan& sp : e->mid.parts) mmax = std::max(mmax, int(sp.mmax));
+    return mmax >= 2 && kmax >= 4 && e->mid.est_total <= 580000;
 }
 
 // Networks spread over several workgroups (bn_mid.hip).  The arguments of a launch over the sets [set_base, set_base + n)

@@ -62,13 +62,14 @@ struct SmallPlan {
 // global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
 constexpr int kMidMaxParts = 224;   // workgroups of one run: all co-resident, one per CU (the engine admits a plan only below 0.9 x CUs); <= 4 x 64 flags per barrier poll
 constexpr int kMidSyncBytes = 128 + 128 * kMidMaxParts;   // per state slot: the three residual words (8 bytes on), then one 128-byte line per workgroup: its barrier flag
-constexpr int kMidPreferredParts = 32;
+constexpr int kMidPreferredParts = 96;   // parts of at least 2 000 staged terms, about this many where the network is large enough (measured, bn_small_plan.cpp)
 struct MidPlan {
     bool ok = false;
     std::string why;
     std::vector<SmallPlan> parts;
     int32_t waves = 0, rounds = 0;   // the largest of the parts': one launch configuration for all workgroups
     size_t lds_bytes = 0;
+    int64_t est_total = 0;           // estimated staged terms of the whole network (the planner's measure of size)
 };
 void build_mid_plan(const Plan& p, MidPlan& mp);
 

@@ -309,17 +309,22 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
         est[v] = (p.cpt_off[v + 1] - p.cpt_off[v]) * (m + 1) * 5 / 4 + 8 * p.k[v] * (m + 1);
         total += est[v];
     }
-    // About 16 workgroups where the network allows it: fewer, larger parts mean more rounds of items per thread (stamps: 1.7 us of
-    // entry items + 1.7 us of accumulator items per iteration at four rounds), more parts a slower grid barrier (32 workgroups:
-    // 300-node network 7.5 -> 7.8 us per sweep, 60-node / 12 k entries 7.2 -> 8.2); larger parts only where 32 do not hold the network
+    // Parts of >= 2 000 staged terms, about kMidPreferredParts of them where the network is large enough: fewer, larger parts mean
+    // more rounds of items per thread (stamps: 1.7 us of entry items + 1.7 us of accumulator items per iteration at four rounds),
+    // and with the flag barrier more parts cost little -- us per sweep at 32 / 96 preferred: 600-node network 5.7 / 5.2, 1 000 nodes
+    // 6.5 / 5.5, 3 000 nodes 7.5 / 6.8, 200 nodes of 1 024-entry tables 7.6 / 6.9, smaller networks unchanged (the 2 000-term floor
+    // decides there; at 1 000 terms a 16 x 16 grid goes 4.3 -> 4.9).  Larger parts only where kMidMaxParts do not hold the network.
     int64_t preferred = kMidPreferredParts;
     if (const char* pp = std::getenv("BN_MID_PARTS")) preferred = std::max(2, std::min(kMidMaxParts, std::atoi(pp)));  // experiments
+    mp.est_total = total;
     constexpr int64_t kTargetMax = 12000;  // staged terms a part may hold (LDS)
     // Targets tried in turn: from total / preferred (at least 2 000, at most 9 000) UP to the largest part size -- fewer, larger parts
     // when the network needs more than kMidMaxParts of the first size -- and then DOWN from the first: the estimate is low for
     // tables whose accumulator runs are padded most (1 024-entry tables), and a part that turns out too large for a workgroup
     // asks for more, smaller parts, not fewer.
-    const int64_t start = std::max<int64_t>(2000, std::min<int64_t>((total + preferred - 1) / preferred, 9000));
+    int64_t floor_terms = 2000;
+    if (const char* ff = std::getenv("BN_MID_FLOOR")) floor_terms = std::max(500, std::atoi(ff));  // experiments
+    const int64_t start = std::max<int64_t>(floor_terms, std::min<int64_t>((total + preferred - 1) / preferred, 9000));
     std::vector<int64_t> targets;
     for (int64_t t = start;; t = std::min(kTargetMax, t * 4 / 3 + 1)) {  // (the growth used to step over the largest target: 9 000 -> 12 001)
         targets.push_back(t);
