@@ -601,7 +601,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm"], default="grid",
+    ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm", "mid"], default="grid",
                     help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG; "
                          "lw = configs[4], likelihood weighting on the 10 k-node DAG")
     ap.add_argument("--samples", type=int, default=2000000, help="lw: weighted samples per step")
@@ -656,6 +656,18 @@ def main():
                "roofline": {"bound": "latency", "note": "one workgroup on one CU: LDS round trips and chains of dependent fp64 additions in the "
                                                         "reference's order; neither HBM nor MFMA apply", "kernel_us_per_sweep": leg["kernel_us_per_sweep"]}}
         for k in ("tile_kernels", "batch", "cpu_baseline", "cpu_reference"):
+            if k in leg:
+                out[k] = leg[k]
+        print(json.dumps(out))
+        return
+    if a.workload == "mid":
+        leg = leg_mid(a, local_rank, torch)
+        out = {"metric": "queries/sec, evidence in -> marginals on the host (300-node mixed-arity network)", "value": 1e6 / leg["us_per_query"],
+               "unit": "queries/s", "n_gpus": 1, "steps": 200, "warmup": 2, "ms_per_step": leg["us_per_query"] / 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": leg["workload"], "run_path": leg["path"]},
+               "roofline": {"bound": "latency", "note": "a few tens of workgroups, a flag-per-workgroup grid barrier per phase; neither HBM nor MFMA apply",
+                            "kernel_us_per_sweep": leg["kernel_us_per_sweep"]}}
+        for k in ("workgroups", "tile_kernels", "batch_B64", "cpu_baseline", "mixed10k"):
             if k in leg:
                 out[k] = leg[k]
         print(json.dumps(out))

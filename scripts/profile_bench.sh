@@ -44,6 +44,9 @@ pmc sq_dag10k "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
 # config 0's network on the GPU: the ALARM-shaped net, one workgroup per run (bn_small.hip)
 trace trace_alarm --no-cpu --workload alarm
 pmc sq_alarm "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" --no-cpu --workload alarm
+# a mid-size network (300 nodes, 38 workgroups) and a 10 000-node one (213 workgroups): several workgroups per run (bn_mid.hip)
+trace trace_mid --no-cpu --workload mid
+pmc sq_mid "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" --no-cpu --workload mid
 # config 5: likelihood weighting
 trace trace_lw $B --workload lw --steps 3
 pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
