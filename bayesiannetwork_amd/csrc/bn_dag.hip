@@ -1,0 +1,650 @@
+// bn_dag.hip -- k = 4 networks with up to 5 parents per node: the whole belief-propagation run in ONE launch, every CPT
+// entry resident in a register, a node's two roles on different waves (bn_dag.hpp).  Reference:
+// bayesian/inference/belief_propagation.hpp:33-158.
+//
+// One iteration of the reference's while(true) loop (:75-148) for a wave = ONE round trip for its inputs (every load of
+// the iteration is requested before the first is used), the arithmetic, 16-byte write-through stores, drain, arrival.
+// Everything reads the OLD buffers and writes the NEW ones (the reference's new_* maps); the grid barrier between two
+// iterations is bn_resident.hip's direct form: a block publishes a pair of 8-byte granules {generation | residual half},
+// the first wave of every block collects all blocks' pairs in one round trip per poll and takes the stop decision (:147).
+// Every wait is bounded; a wait that gives up raises `abort`, every block leaves and the host redoes the run with one
+// launch per sweep.
+#include "bn_dag.hpp"
+#include "bn_tiles.hpp"
+#include "bn_small_dev.hpp"
+
+#include <type_traits>
+
+namespace bnmi {
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+#ifdef BN_TILE_CLOCK
+__device__ unsigned long long g_dag_clock[kDagMaxBlocks * kDagWaves][8];
+#define DSTAMP(k, it) do { if ((it) == 5 && lane == 0) g_dag_clock[blockIdx.x * kDagWaves + wave][k] = wall_clock64(); } while (0)
+#else
+#define DSTAMP(k, it) ((void)0)
+#endif
+
+typedef unsigned dag_u32x4 __attribute__((ext_vector_type(4)));
+// state records: 16-byte sc1 accesses through a buffer descriptor (aux 16): stores write through, loads bypass the CU's
+// L1 -- no release / acquire fences around the barrier (cdna_hip_programming.md Guideline 16)
+__device__ __forceinline__ double2_t dag_ld(__amdgpu_buffer_rsrc_t r, int64_t idx2) {
+    return __builtin_bit_cast(double2_t, __builtin_amdgcn_raw_buffer_load_b128(r, int(idx2) * 16, 0, 16));
+}
+__device__ __forceinline__ void dag_st(__amdgpu_buffer_rsrc_t r, int64_t idx2, double2_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dag_u32x4, v), r, int(idx2) * 16, 0, 16);
+}
+__device__ __forceinline__ void dag_ld4(__amdgpu_buffer_rsrc_t r, int64_t idx2, double (&v)[4]) {
+    const double2_t a = dag_ld(r, idx2), b = dag_ld(r, idx2 + 1);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ __forceinline__ void dag_st4(__amdgpu_buffer_rsrc_t r, int64_t idx2, const double (&v)[4]) {
+    double2_t a, b;
+    a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+    dag_st(r, idx2, a);
+    dag_st(r, idx2 + 1, b);
+}
+
+struct DagShared {
+    unsigned long long slot[kDagWaves];  // per-wave residual bit patterns
+    int verdict;
+};
+enum : int { kDagGoOn = 0, kDagConverged = 1, kDagCapped = 2, kDagAbort = 3 };
+
+__device__ __forceinline__ double dag_residual_of(unsigned long long bits) {
+    const double r = __longlong_as_double((long long)bits);
+    return r < DBL_MIN ? DBL_MIN : r;  // maximum_difference starts at numeric_limits<double>::min() (:105)
+}
+__device__ __forceinline__ int dag_verdict_of(const DagArgs& a, double r, int n_done) {
+    if (r < a.eps) return kDagConverged;                              // strict '<' (:147)
+    if (a.max_sweeps > 0 && n_done >= a.max_sweeps) return kDagCapped;
+    return kDagGoOn;
+}
+
+// ---- grid barrier (bn_resident.hip's direct form) ------------------------------------------------------------------
+__device__ __forceinline__ void dag_arrive(const DagArgs& a, DagShared& sh, int it, int s, double wres, int lane, int wave) {
+    const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
+    if (lane == 0) sh.slot[wave] = bits;
+    DSTAMP(3, it);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have reached memory
+    DSTAMP(4, it);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = 0;
+        for (int w = 0; w < kDagWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
+        if (a.n_blocks == 1) {
+            a.sync->res[it] = m;
+            sh.verdict = dag_verdict_of(a, dag_residual_of(m), s + 1);
+        } else {
+            // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
+            // overwrite what a slower block still has to read
+            const unsigned gen = a.gen_base + unsigned(it) + 1u;
+            unsigned long long* g = (it & 1) ? a.sync->blk_odd[blockIdx.x] : a.sync->blk[blockIdx.x];
+            __hip_atomic_store(g, ((unsigned long long)gen << 32) | unsigned(m >> 32), RLX_AGENT);
+            __hip_atomic_store(g + 1, ((unsigned long long)gen << 32) | unsigned(m), RLX_AGENT);
+        }
+    }
+}
+
+// lane l requests the pairs of blocks l, l + 64, l + 128, l + 192 back to back (one round trip) -- bn_resident.hip sweep_granules
+__device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc) {
+    static_assert(kDagMaxBlocks == 4 * kWave, "four pairs per lane cover the table");
+    const unsigned voff = unsigned(lane) * 16u;
+    dag_u32x4 r0, r1, r2, r3;
+    if (nb <= kWave)
+        asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(voff), "s"(tbl) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %4, %5 sc1\n\t"
+                     "global_load_dwordx4 %1, %4, %5 offset:1024 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:2048 sc1\n\t"
+                     "global_load_dwordx4 %3, %4, %5 offset:3072 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
+    bool mine = true;
+    acc = 0;
+    auto take = [&](const dag_u32x4& r, int blk) {  // words: {residual high half, generation, residual low half, generation}
+        if (blk < nb) {
+            mine = mine && r.y == gen && r.w == gen;
+            const unsigned long long v = (unsigned long long)r.x << 32 | r.z;
+            acc = v > acc ? v : acc;
+        }
+    };
+    take(r0, lane);
+    if (nb > kWave) { take(r1, lane + kWave); take(r2, lane + 2 * kWave); take(r3, lane + 3 * kWave); }
+    return mine;
+}
+
+__device__ __forceinline__ int dag_wait(const DagArgs& a, DagShared& sh, int it) {
+    if (a.n_blocks > 1 && threadIdx.x < kWave) {
+        int lane = int(threadIdx.x);
+        asm volatile("" : "+v"(lane));  // (keeps the per-lane granule addresses out of the iteration loop's live registers)
+        const unsigned gen = a.gen_base + unsigned(it) + 1u;
+        const int nb = a.n_blocks;
+        const unsigned long long* tbl = (it & 1) ? &a.sync->blk_odd[0][0] : &a.sync->blk[0][0];
+        unsigned long long m = 0;
+        bool ok = true;
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned n = 1;; ++n) {
+            if (__all(dag_sweep_granules(tbl, lane, nb, gen, m)) != 0) break;
+            if ((n & 7u) == 0) {   // the abort word and the clock are round trips of their own: every 8th poll
+                if (__hip_atomic_load(&a.sync->abort, RLX_AGENT) != 0) { ok = false; break; }
+                if (wall_clock64() - t0 > a.timeout_ticks) {
+                    if (__all(dag_sweep_granules(tbl, lane, nb, gen, m)) != 0) break;
+                    __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        m = wave_umax64_dpp(m);
+        if (lane == 0) {
+            if (blockIdx.x == 0 && ok) __hip_atomic_store(&a.sync->res[it], m, RLX_AGENT);
+            sh.verdict = ok ? dag_verdict_of(a, dag_residual_of(m), a.sweep_begin + it + 1) : kDagAbort;
+        }
+    }
+    __syncthreads();
+    return sh.verdict;
+}
+
+// The launch's loop over iterations.  phase(s): one sweep of this wave's tile(s), returns the wave's share of
+// maximum_difference; finalize(n, done): the run stopped after n sweeps (done = kDagConverged / kDagCapped) or the launch's
+// budget ran out (done = 0).  false: a bounded wait gave up.
+template <class Phase, class Finalize>
+__device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int lane, int wave, Phase&& phase, Finalize&& finalize) {
+    for (int it = 0; it <= a.budget; ++it) {  // the pass it == budget only collects the verdict
+        const int s = a.sweep_begin + it;
+        int v = kDagGoOn;
+        DSTAMP(0, it);
+        if (it > 0) {
+            v = dag_wait(a, sh, it - 1);
+            if (v == kDagAbort) return false;
+        }
+        DSTAMP(1, it);
+        if (v != kDagGoOn || it == a.budget) {
+            const int done = v != kDagGoOn ? v : 0;
+            finalize(s, done);
+            if (blockIdx.x == 0 && wave == 0) {  // report: residual history, outcome
+                int q0 = lane;
+                asm volatile("" : "+v"(q0));
+                for (int q = q0; q < it; q += kWave)
+                    if (a.sweep_begin + q < a.b.res_cap)
+                        a.b.res_hist[a.sweep_begin + q] = dag_residual_of(__hip_atomic_load(&a.sync->res[q], RLX_AGENT));
+                if (lane == 0) {
+                    Ctl* hc = a.host_ctl;
+                    hc->last_res = it > 0 ? dag_residual_of(__hip_atomic_load(&a.sync->res[it - 1], RLX_AGENT)) : 0.0;
+                    hc->n_sweeps = s;
+                    hc->run_id = a.run_id;
+                    hc->done = done;
+                }
+            }
+            return true;
+        }
+        const double wres = phase(s);
+        dag_arrive(a, sh, it, s, wres, lane, wave);
+        DSTAMP(6, it);
+    }
+    return true;
+}
+
+// belief = normalize(pi % lambda) (:151-158) of `node` from the state after n sweeps
+__device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int node, int n) {
+    double pv[4], lv[4], bel[4];
+    dag_ld4(rs, dag_off_npi(a.E, a.n, n & 1, node), pv);
+    dag_ld4(rs, dag_off_nlam(a.E, a.n, n & 1, node), lv);
+    double sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bel[i] = pv[i] * lv[i]; sum += bel[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.b.beliefs[int64_t(node) * 4 + i] = bel[i] / sum;
+}
+
+// ---- child tile, at most two parents: one lane per node, the reference's operation order (bn_tiles.hpp tile_uniform) ----
+template <int M>
+struct DagChildU {
+    static constexpr int K = 4, C = ipow(K, M), S = K * C, CB = (M > 0) ? C / K : 0;
+    int node, ebase;
+    bool active, frozen;
+    double cpt[S];  // entry cond * 4 + i
+    __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
+        const DagChildLane cl = a.cnode[t.lane_base + lane];
+        active = cl.node >= 0;
+        node = active ? cl.node : 0;  // idle lanes shadow node 0 and store nothing
+        ebase = active ? cl.ebase : 0;
+        frozen = active && a.frz[node] == a.frz_mark;
+        const double2_t* cp = reinterpret_cast<const double2_t*>(a.cpt_img) + t.cpt_base + lane;
+#pragma unroll
+        for (int q = 0; q < S / 2; ++q) {
+            const double2_t x = cp[q * kWave];
+            cpt[2 * q] = x.x; cpt[2 * q + 1] = x.y;
+        }
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
+        const bool first = s == 0;
+        const int cur = s & 1, nxt = cur ^ 1;
+        double pim[M > 0 ? M : 1][K], lold[M > 0 ? M : 1][K], lav[K], pold[K];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int i = 0; i < K; ++i) { pim[j][i] = 1.0; lold[j][i] = 1.0; }
+#pragma unroll
+        for (int i = 0; i < K; ++i) { lav[i] = 1.0; pold[i] = 1.0; }
+        if (!first) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                dag_ld4(rs, dag_off_pim(a.E, a.n, cur, ebase + j), pim[j]);
+                dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + j), lold[j]);
+            }
+        }
+        if (!first || frozen) {  // evidence nodes hold their vector as pi and lambda in both buffers (:68-73)
+            dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), lav);
+            dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), pold);
+        }
+        // calculate_pi (:174-200): assignments ascending, cpt * pi-messages in ascending parent order;
+        // calculate_lambda_k (:240-266): bucket out[jt][ct] receives, own state outer and assignment inner,
+        // (lambda[i] * cpt) * the OTHER parents' pi-messages
+        double pin[K];
+        double out[M > 0 ? M : 1][K];
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt)
+#pragma unroll
+            for (int ct = 0; ct < K; ++ct) out[jt][ct] = 0.0;
+#pragma unroll
+        for (int ib = 0; ib < K; ++ib) {
+            if constexpr (M == 0) {
+                pin[ib] = 0.0 + cpt[ib];
+            } else {
+                double acc = 0.0;
+#pragma unroll
+                for (int rr = 0; rr < CB; ++rr) {
+#pragma unroll
+                    for (int x = 0; x < K; ++x) {
+                        const int cond = rr * K + x;
+                        double value = cpt[cond * K + ib];
+#pragma unroll
+                        for (int j = 0; j < M; ++j) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                        acc += value;
+                    }
+#pragma unroll
+                    for (int jt = 0; jt < M; ++jt) {
+                        const int stride = ipow(K, M - 1 - jt);
+#pragma unroll
+                        for (int ct = 0; ct < K; ++ct) {  // rr-th assignment whose digit jt equals ct
+                            const int cond = (rr / stride) * stride * K + ct * stride + (rr % stride);
+                            double value = lav[ib] * cpt[cond * K + ib];
+#pragma unroll
+                            for (int j = 0; j < M; ++j)
+                                if (j != jt) value *= pim[j][(cond / ipow(K, M - 1 - j)) % K];
+                            out[jt][ct] += value;
+                        }
+                    }
+                }
+                pin[ib] = acc;
+            }
+        }
+        normalize_k<K>(pin);
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt) normalize_k<K>(out[jt]);
+        double wres = 0.0;
+#pragma unroll
+        for (int jt = 0; jt < M; ++jt)
+#pragma unroll
+            for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(out[jt][i] - lold[jt][i]));
+        if (active) {
+            if (frozen) dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), pold);   // evidence nodes keep pi (:177)
+            else dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), pin);
+#pragma unroll
+            for (int jt = 0; jt < M; ++jt) dag_st4(rs, dag_off_lam(a.E, a.n, nxt, ebase + jt), out[jt]);
+        }
+        return active ? wres : 0.0;
+    }
+    __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n) {
+        if (active) dag_belief(a, rs, node, n);
+    }
+};
+
+// ---- child tile, M = D + 2 parents: G = 4^D lanes per node, lane g holds the 64 entries of one assignment of the D leading
+// parents.  The sums over the two trailing parents (states c, d) are formed ONCE per lane and shared by the five outputs:
+//   Q[c][d] = sum_i lambda(v)[i] P[c][d][i]       R[c][i] = sum_d P[c][d][i] piD[d]       S[i] = sum_c piC[c] R[c][i]
+//   LC[c]   = sum_d Q[c][d] piD[d]                LD[d]   = sum_c piC[c] Q[c][d]          L    = sum_c piC[c] LC[c]
+//   pi(v)[i] += w S[i],  lambda->C[c] += w LC[c],  lambda->D[d] += w LD[d]   (w = product of the lane's leading pi-message entries)
+//   lambda->leading parent jt, bucket = the lane's digit jt:  += L * product of the OTHER leading entries
+// 350 fp64 operations per lane where the reference's term-by-term products (bn_tiles.hpp tile_group) take 1 280; the results
+// agree with the reference to rounding (its own >= 3-parent products are unordered, :253).  The group's partial sums are
+// combined with shuffles exactly as in tile_group; lanes 0 .. M of a group finish one vector each.
+template <int D>
+struct DagChildG {
+    static constexpr int K = 4, M = D + 2, G = 1 << (2 * D), NPT = kWave / G;
+    static_assert(G >= M + 1, "a group has a lane per finished vector");
+    int node, ebase, nl, g;
+    bool active, frozen;
+    double cpt[64];  // entry (c * 4 + d) * 4 + i
+    __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
+        const DagChildLane cl = a.cnode[t.lane_base + lane];
+        nl = lane / G; g = lane % G;
+        active = cl.node >= 0;
+        node = active ? cl.node : 0;
+        ebase = active ? cl.ebase : 0;
+        frozen = active && a.frz[node] == a.frz_mark;
+        const double2_t* cp = reinterpret_cast<const double2_t*>(a.cpt_img) + t.cpt_base + lane;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const double2_t x = cp[q * kWave];
+            cpt[2 * q] = x.x; cpt[2 * q + 1] = x.y;
+        }
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
+        const bool first = s == 0;
+        const int cur = s & 1, nxt = cur ^ 1;
+        double pim[M][K], lav[K], fold[K];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int i = 0; i < K; ++i) pim[j][i] = 1.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { lav[i] = 1.0; fold[i] = 1.0; }
+        if (!first) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) dag_ld4(rs, dag_off_pim(a.E, a.n, cur, ebase + j), pim[j]);
+        }
+        if (!first || frozen) dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), lav);
+        // lane 0 of the group finishes pi(v), lane 1 + jt the lambda-message to parent jt: each requests the previous value
+        // of ITS vector now (residual :105-131; an evidence node's pi is carried over, :177)
+        const bool fin_msg = g >= 1 && g <= M;
+        if (fin_msg && !first) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + g - 1), fold);
+        if (g == 0 && frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), fold);
+
+        double pfix[D > 0 ? D : 1];
+#pragma unroll
+        for (int j = 0; j < D; ++j) pfix[j] = pick4(pim[j], (g >> (2 * (D - 1 - j))) & 3);
+        const double (&pC)[K] = pim[D];
+        const double (&pD)[K] = pim[D + 1];
+        double S[K], LC[K], LD[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { S[i] = 0.0; LD[i] = 0.0; }
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            double R[K], lc = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) R[i] = 0.0;
+#pragma unroll
+            for (int d = 0; d < K; ++d) {
+                const double* e = &cpt[(c * K + d) * K];
+                const double q = (lav[0] * e[0] + lav[1] * e[1]) + (lav[2] * e[2] + lav[3] * e[3]);
+#pragma unroll
+                for (int i = 0; i < K; ++i) R[i] += e[i] * pD[d];
+                lc += q * pD[d];
+                LD[d] += pC[c] * q;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) S[i] += pC[c] * R[i];
+            LC[c] = lc;
+        }
+        double L = 0.0;
+#pragma unroll
+        for (int c = 0; c < K; ++c) L += pC[c] * LC[c];
+        double w = 1.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) w *= pfix[j];
+        double pp[K], ol[2][K], sf[D > 0 ? D : 1];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { pp[i] = w * S[i]; ol[0][i] = w * LC[i]; ol[1][i] = w * LD[i]; }
+#pragma unroll
+        for (int jt = 0; jt < D; ++jt) {
+            double x = L;
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                if (j != jt) x *= pfix[j];
+            sf[jt] = x;
+        }
+        // ---- combine inside the G-lane group
+#pragma unroll
+        for (int mask = 1; mask < G; mask <<= 1) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) pp[i] += shfl_xor_d(pp[i], mask);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ct = 0; ct < K; ++ct) ol[t][ct] += shfl_xor_d(ol[t][ct], mask);
+        }
+        // leading parent jt: sum over the lanes that share digit jt, then collect the four buckets from the lanes whose
+        // other digits are zero
+        double of[D > 0 ? D : 1][K];
+#pragma unroll
+        for (int jt = 0; jt < D; ++jt) {
+            double x = sf[jt];
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                if (j != jt) {
+                    x += shfl_xor_d(x, 1 << (2 * (D - 1 - j)));
+                    x += shfl_xor_d(x, 2 << (2 * (D - 1 - j)));
+                }
+#pragma unroll
+            for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
+        }
+        // ---- lanes 0 .. M of the group finish the node: normalise (:298-311), residual, stores
+        double o[K];
+#pragma unroll
+        for (int ct = 0; ct < K; ++ct) {
+            o[ct] = pp[ct];
+#pragma unroll
+            for (int jt = 0; jt < M; ++jt)
+                if (g == jt + 1) o[ct] = jt < D ? of[jt < D ? jt : 0][ct] : ol[jt >= D ? jt - D : 0][ct];
+        }
+        double wres = 0.0;
+        if (active && g <= M) {
+            normalize_k<K>(o);
+            if (g == 0) {
+                if (frozen) dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), fold);
+                else dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), o);
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - fold[i]));
+                dag_st4(rs, dag_off_lam(a.E, a.n, nxt, ebase + g - 1), o);
+            }
+        }
+        return wres;
+    }
+    __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n) {
+        if (active && g == 0) dag_belief(a, rs, node, n);
+    }
+};
+
+// ---- parent items: a lane per pi-message (:202-218) and per lambda(v) (:220-238); the product runs over the node's children
+// in ascending order, the target left out -- the reference's multiplication sequence
+struct DagParent {
+    static constexpr int K = 4, RC = kDagRegChildren;
+    int node, tedge, obeg, deg, tpos, dmax;
+    bool active, frozen;
+    int oe[RC];  // the first out-edges' CSR ids
+    __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
+        const DagParentLane it = a.pitem[t.lane_base + lane];
+        active = it.node >= 0;
+        node = active ? it.node : 0;
+        tedge = it.tedge;
+        obeg = it.obeg;
+        deg = active ? (it.deg_tpos & 0xffff) : 0;
+        tpos = it.deg_tpos >> 16;  // (0xffff for the lambda(v) item: no child is left out)
+        dmax = t.dmax;
+        frozen = active && a.frz[node] == a.frz_mark;
+#pragma unroll
+        for (int x = 0; x < RC; ++x) oe[x] = (x < deg) ? a.oedge[obeg + x] : 0;
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
+        const bool first = s == 0;
+        const int cur = s & 1, nxt = cur ^ 1;
+        const bool is_msg = tedge >= 0;
+        double acc[K], old[K], lk[RC][K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { acc[i] = 1.0; old[i] = 1.0; }
+#pragma unroll
+        for (int x = 0; x < RC; ++x)
+#pragma unroll
+            for (int i = 0; i < K; ++i) lk[x][i] = 1.0;
+        // a pi-message starts from pi(v) (:207): the previous sweep's, or in sweep 0 the initial one (1.0, a root's CPT row, the evidence)
+        if (is_msg) {
+            if (!first || frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), acc);
+            else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) acc[i] = a.npi_init[int64_t(node) * 4 + i];
+            }
+            if (!first) dag_ld4(rs, dag_off_pim(a.E, a.n, cur, tedge), old);
+        } else if (frozen) {
+            dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), old);  // an evidence node's lambda is carried over (:223)
+        }
+        if (!first) {
+#pragma unroll
+            for (int x = 0; x < RC; ++x)
+                if (x < dmax) {  // wave-uniform
+                    if (x < deg) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, oe[x]), lk[x]);
+                }
+        }
+#pragma unroll
+        for (int x = 0; x < RC; ++x)
+            if (x < dmax) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) acc[i] *= (x != tpos) ? lk[x][i] : 1.0;  // x * 1.0 == x
+            }
+        for (int x0 = RC; x0 < dmax; x0 += RC) {  // nodes with more children than the registers hold: further round trips
+            int ids[RC];
+#pragma unroll
+            for (int x = 0; x < RC; ++x) ids[x] = (x0 + x < deg) ? a.oedge[obeg + x0 + x] : 0;
+#pragma unroll
+            for (int x = 0; x < RC; ++x) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) lk[x][i] = 1.0;
+                if (!first && x0 + x < deg) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ids[x]), lk[x]);
+            }
+#pragma unroll
+            for (int x = 0; x < RC; ++x)
+#pragma unroll
+                for (int i = 0; i < K; ++i) acc[i] *= (x0 + x != tpos) ? lk[x][i] : 1.0;
+        }
+        normalize_k<K>(acc);
+        double wres = 0.0;
+        if (active) {
+            if (is_msg) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(acc[i] - old[i]));
+                dag_st4(rs, dag_off_pim(a.E, a.n, nxt, tedge), acc);
+            } else if (frozen) {
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), old);
+            } else {
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), acc);
+            }
+        }
+        return wres;
+    }
+};
+
+// one tile, whatever its kind: state set up, f(state) called
+template <class F>
+__device__ __forceinline__ void dag_with_tile(const DagArgs& a, const DagTile& t, int lane, F&& f) {
+    switch (t.kind) {
+        case 0: { DagChildU<0> st; st.init(a, t, lane); f(st); break; }
+        case 1: { DagChildU<1> st; st.init(a, t, lane); f(st); break; }
+        case 2: { DagChildU<2> st; st.init(a, t, lane); f(st); break; }
+        case 3: { DagChildG<1> st; st.init(a, t, lane); f(st); break; }
+        case 4: { DagChildG<2> st; st.init(a, t, lane); f(st); break; }
+        case 5: { DagChildG<3> st; st.init(a, t, lane); f(st); break; }
+        default: { DagParent st; st.init(a, t, lane); f(st); break; }
+    }
+}
+template <class T> struct dag_has_belief { static constexpr bool value = true; };
+template <> struct dag_has_belief<DagParent> { static constexpr bool value = false; };
+
+// STREAM = false: at most one tile per wave, its static state (CPT, ids, marks) in registers for the whole run.
+// STREAM = true: a wave walks its tiles [slot_ptr[slot], slot_ptr[slot + 1]) every iteration, setting each up again.
+template <bool STREAM>
+__global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
+    __shared__ DagShared sh;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.host_ctl->t_first = wall_clock64();
+    const int slot = blockIdx.x * kDagWaves + wave;
+    const int t0 = a.slot_ptr[slot], t1 = a.slot_ptr[slot + 1];
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.state, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
+    bool ok = true;
+    if (t1 <= t0) {
+        ok = dag_drive(a, sh, lane, wave, [](int) { return 0.0; }, [](int, int) {});
+    } else if constexpr (STREAM) {
+        ok = dag_drive(a, sh, lane, wave,
+                       [&](int s) {
+                           double w = 0.0;
+                           for (int t = t0; t < t1; ++t) {
+                               const DagTile td = a.tiles[t];
+                               dag_with_tile(a, td, lane, [&](auto& st) { w = res_acc(w, st.sweep(a, rs, s)); });
+                           }
+                           return w;
+                       },
+                       [&](int n, int done) {
+                           if (done == 0) return;
+                           for (int t = t0; t < t1; ++t) {
+                               const DagTile td = a.tiles[t];
+                               if (td.kind == kDagParent) continue;
+                               dag_with_tile(a, td, lane, [&](auto& st) {
+                                   if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) st.belief(a, rs, n);
+                               });
+                           }
+                       });
+    } else {
+        const DagTile td = a.tiles[t0];
+        dag_with_tile(a, td, lane, [&](auto& st) {
+            ok = dag_drive(a, sh, lane, wave, [&](int s) { return st.sweep(a, rs, s); },
+                           [&](int n, int done) {
+                               if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) {
+                                   if (done != 0) st.belief(a, rs, n);
+                               }
+                           });
+        });
+    }
+    // a block that gave up a bounded wait says so itself: block 0 may long have reported its own outcome
+    if (!ok && threadIdx.x == 0 && a.host_abort) __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.host_ctl->t_last = wall_clock64();
+        if (!ok) { a.host_ctl->run_id = a.run_id; a.host_ctl->done = -1; }
+    }
+}
+
+// bn_bp_set_evidence for this path (:68-73): pi(v) = lambda(v) = the given vector in BOTH buffers (an observed node's vectors
+// are carried over by every sweep), node marked with this set's mark value (the previous set's marks need no clearing)
+__global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.ne) return;
+    const int v = a.ev_node[j];
+    for (int i = 0; i < 4; ++i) {
+        const double x = a.ev_val[a.ev_off[j] + i];
+        for (int par = 0; par < 2; ++par) {
+            a.state[dag_off_npi(a.E, a.n, par, v) * 2 + i] = x;
+            a.state[dag_off_nlam(a.E, a.n, par, v) * 2 + i] = x;
+        }
+    }
+    a.frz[v] = a.frz_mark;
+}
+
+int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle) {
+    (void)hipGetLastError();
+    const dim3 g(a.n_blocks), t(kDagWaves * kWave);
+    if (stream) hipLaunchKernelGGL(bp_dag_kernel<true>, g, t, 0, (hipStream_t)stream_handle, a);
+    else hipLaunchKernelGGL(bp_dag_kernel<false>, g, t, 0, (hipStream_t)stream_handle, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+int launch_dag_evidence(const DagEvidenceArgs& a, void* stream_handle) {
+    (void)hipGetLastError();
+    if (a.ne <= 0) return 0;
+    hipLaunchKernelGGL(dag_evidence_kernel, dim3((a.ne + 255) / 256), dim3(256), 0, (hipStream_t)stream_handle, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+
+}  // namespace bnmi
+
+#ifdef BN_TILE_CLOCK
+extern "C" int bn_debug_dag_clock(unsigned long long* out, int n_waves) {
+    if (n_waves > bnmi::kDagMaxBlocks * bnmi::kDagWaves) n_waves = bnmi::kDagMaxBlocks * bnmi::kDagWaves;
+    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_dag_clock), sizeof(unsigned long long) * 8 * n_waves));
+}
+#endif

@@ -1,0 +1,114 @@
+// bn_dag.hpp -- k = 4 networks with up to 5 parents per node (BASELINE.json configs[1]: the 10 k-node random DAG, 2.7 M
+// CPT entries): the whole run in ONE launch with every CPT entry resident in a register (bn_dag.hip).
+//
+// The tile layout (bn_plan.hpp) runs such a network at 12.4 us per sweep: 2.9 us of launch gap, then ONE lane-group tile's
+// latency -- descriptor -> CPT stream -> references -> records -> 1 280 dependent fp64 instructions -> parent role, in a
+// row on one wave.  The item kernels (bn_small.hpp) stage 5 terms per entry in LDS: 100 MB here, the chip has 40.
+// This path splits a node's two roles (belief_propagation.hpp) over DIFFERENT waves and keeps everything static on chip:
+//   child tile   one wavefront of nodes with m parents (64 nodes, or 64 / 4^(m-2) lane groups for m >= 3): pi(v) =
+//                calculate_pi (:174-200) and the lambda-message to every parent = calculate_lambda_k (:240-266).  Its 64
+//                CPT entries per lane live in VGPRs for the whole run (2.7 M entries = 17 % of the chip's register files).
+//                m <= 2: the reference's operation order, bit for bit.  m >= 3: the contraction is FACTORED -- the sums over
+//                the two trailing parents are formed once and shared by all five outputs (350 instead of 1 280 fp64
+//                operations per lane) and combined across the group's lanes by shuffles; results agree with the reference
+//                to rounding (its own >= 3-parent products are unordered: it iterates an unordered_map, :253).
+//   parent item  one lane per pi-message (calculate_pi_i, :202-218) and one per lambda(v) (calculate_lambda, :220-238):
+//                the product over the node's children in ascending order, skipping the target -- the reference's order.
+// State (pi-/lambda-messages in CSR edge order, pi(v), lambda(v); double-buffered) lives in device memory and is exchanged
+// with 16-byte sc1 accesses; one grid barrier per iteration in the atomic-free granule form of bn_resident.hip (every block
+// publishes {generation | residual half} pairs, the first wave of every block collects them: one hand-off per iteration).
+// Networks beyond what the chip holds at one tile per wave run the same tile code in STREAM form: a wave walks several
+// tiles per iteration and re-reads their CPT image from L2 / memory.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bn_device.hpp"
+
+namespace bnmi {
+
+constexpr int kDagWaves = 8;            // per block: two per SIMD, 256 VGPRs each
+constexpr int kDagMaxBlocks = kResidentMaxBlocks;  // one granule pair per block, four pairs per polling lane
+constexpr int kDagBudget = kResidentBudget;        // iterations per launch (ResidentSync::res)
+constexpr int kDagMaxParents = 5;
+constexpr int kDagRegChildren = 8;      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
+
+enum : int32_t { kDagChild0 = 0, /* 1..5: child tile of nodes with that many parents */ kDagParent = 8 };
+
+// One wavefront of work.  32 bytes.
+struct DagTile {
+    int32_t kind;       // 0..5: child tile, nodes with `kind` parents; kDagParent: 64 parent items
+    int32_t n_active;   // nodes (child tile) / items (parent tile) in use
+    int32_t lane_base;  // first entry of the tile in the per-lane tables (cnode / pitem): 64 per tile
+    int32_t cpt_base;   // child tile: first double2 of its CPT image; entry pair q of lane l at cpt_base + q * 64 + l
+    int32_t dmax;       // parent tile: largest child count among its items
+    int32_t pad_[3];
+};
+static_assert(sizeof(DagTile) == 32, "DagTile is loaded as two 16-byte words");
+
+struct DagChildLane { int32_t node, ebase; };                 // node id (-1: idle lane), CSR id of its first in-edge
+struct DagParentLane { int32_t node, tedge, obeg, deg_tpos; }; // node (-1: idle), CSR id of the target out-edge (-1: the lambda(v)
+                                                              // item), first entry in oedge, child count | target's rank << 16
+
+struct DagPlan {
+    bool ok = false;
+    std::string why;
+    int32_t n = 0, E = 0;
+    std::vector<DagTile> tiles;            // in slot order: the tiles of wave slot s are [slot_ptr[s], slot_ptr[s + 1])
+    std::vector<int32_t> slot_ptr;         // [blocks * kDagWaves + 1]; slot = block * kDagWaves + wave
+    int32_t blocks = 0;
+    bool stream = false;                   // some wave walks more than one tile per iteration
+    std::vector<DagChildLane> cnode;       // [n_tiles * 64] (child tiles' entries)
+    std::vector<DagParentLane> pitem;      // [n_tiles * 64] (parent tiles' entries)
+    std::vector<int32_t> oedge;            // out-edges (CSR edge ids) of every node, children ascending
+    std::vector<double> cpt_img;           // child tiles' images, double2 units x 2
+    std::vector<double> npi_init;          // [n][4] initial pi(v): the CPT row of a root (:58-64, not normalised), else 1.0
+    int32_t n_child_tiles = 0, n_parent_tiles = 0;
+};
+
+// cap_blocks: most blocks a launch may have (0.9 x CUs, rounded down to a multiple of 8; host-only engines: 224)
+void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp);
+
+struct DagArgs {
+    BpBuffers b;              // beliefs, res_hist / res_cap
+    double eps;
+    int32_t max_sweeps, sweep_begin, budget;
+    uint32_t run_id, gen_base;
+    unsigned long long timeout_ticks;
+    ResidentSync* sync;       // abort word, granule tables, per-iteration residuals
+    Ctl* host_ctl;
+    unsigned* host_abort;
+    int32_t n, E, n_blocks;
+    const DagTile* tiles;
+    const int32_t* slot_ptr;
+    const DagChildLane* cnode;
+    const DagParentLane* pitem;
+    const int32_t* oedge;
+    const double* cpt_img;
+    const double* npi_init;
+    double* state;            // pi-messages [2][E][4], lambda-messages [2][E][4], pi(v) [2][n][4], lambda(v) [2][n][4]
+    const uint8_t* frz;       // [n] evidence marks: observed when == frz_mark
+    uint8_t frz_mark;
+};
+struct DagEvidenceArgs {
+    int32_t ne, n, E;
+    const int32_t* ev_node;
+    const int32_t* ev_off;
+    const double* ev_val;
+    double* state;
+    uint8_t* frz;
+    uint8_t frz_mark;
+};
+int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle);
+int launch_dag_evidence(const DagEvidenceArgs& a, void* stream_handle);
+
+// where things live in DagArgs::state, in double2 units (a record = 4 doubles = two of them)
+__host__ __device__ inline int64_t dag_off_pim(int64_t E, int64_t, int par, int64_t e) { return (int64_t(par) * E + e) * 2; }
+__host__ __device__ inline int64_t dag_off_lam(int64_t E, int64_t, int par, int64_t e) { return 4 * E + (int64_t(par) * E + e) * 2; }
+__host__ __device__ inline int64_t dag_off_npi(int64_t E, int64_t n, int par, int64_t v) { return 8 * E + (int64_t(par) * n + v) * 2; }
+__host__ __device__ inline int64_t dag_off_nlam(int64_t E, int64_t n, int par, int64_t v) { return 8 * E + 4 * n + (int64_t(par) * n + v) * 2; }
+__host__ __device__ inline int64_t dag_state_doubles(int64_t E, int64_t n) { return 16 * E + 16 * n; }
+
+}  // namespace bnmi

@@ -1,0 +1,169 @@
+// bn_dag_plan.cpp -- host plan of the register-resident path for k = 4 networks with up to 5 parents per node (bn_dag.hpp).
+#include "bn_dag.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace bnmi {
+
+namespace {
+inline int lanes_of(int m) { return m <= 2 ? 1 : 1 << (2 * (m - 2)); }          // lanes that share a node
+inline int entries_of(int m) { return m == 0 ? 4 : (m == 1 ? 16 : 64); }        // CPT entries per lane
+// what a tile costs its SIMD per iteration, relative to a 4-parent child tile (instruction counts of bn_dag.hip)
+inline double cost_of(const DagTile& t) {
+    switch (t.kind) {
+        case 0: return 0.10;
+        case 1: return 0.30;
+        case 2: return 0.85;   // 64 entries in the reference's order
+        case 3: return 0.90;
+        case 4: return 1.00;
+        case 5: return 1.10;
+        default: return 0.20 + 0.04 * t.dmax;
+    }
+}
+}  // namespace
+
+void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
+    dp = DagPlan();
+    const int32_t n = p.n;
+    if (p.nranks != 1) { dp.why = "sharded engine"; return; }
+    if (n < 1) { dp.why = "empty network"; return; }
+    if (p.E + int64_t(n) >= (int64_t(1) << 23)) { dp.why = "state beyond 32-bit byte offsets"; return; }
+    for (int32_t v = 0; v < n; ++v) {
+        if (p.k[v] != 4) { dp.why = "a node's arity is not 4"; return; }
+        if (p.in_ptr[v + 1] - p.in_ptr[v] > kDagMaxParents) { dp.why = "a node has more than 5 parents"; return; }
+    }
+    cap_blocks = std::min<int32_t>(cap_blocks & ~7, kDagMaxBlocks);
+    if (cap_blocks < 8) { dp.why = "device too small"; return; }
+    dp.n = n;
+    dp.E = int32_t(p.E);
+
+    // children (ascending) with the CSR edge id of each out-edge
+    std::vector<int32_t> out_ptr(n + 1, 0);
+    for (int64_t e = 0; e < p.E; ++e) out_ptr[p.in_idx[e] + 1]++;
+    for (int32_t v = 0; v < n; ++v) out_ptr[v + 1] += out_ptr[v];
+    dp.oedge.assign(std::max<int64_t>(p.E, 1), 0);
+    {
+        std::vector<int32_t> fill(n, 0);
+        for (int32_t v = 0; v < n; ++v)   // children visited in ascending order: every list comes out ascending
+            for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) {
+                const int32_t u = p.in_idx[e];
+                dp.oedge[out_ptr[u] + fill[u]++] = e;
+            }
+    }
+    dp.npi_init.assign(size_t(n) * 4, 1.0);
+    for (int32_t v = 0; v < n; ++v)
+        if (p.in_ptr[v + 1] == p.in_ptr[v])
+            for (int i = 0; i < 4; ++i) dp.npi_init[size_t(v) * 4 + i] = p.cpt_flat[p.cpt_off[v] + i];
+
+    // ---- tiles in natural order: child tiles by parent count, then parent items by child count
+    std::vector<DagTile> tiles;
+    std::vector<DagChildLane> cnode;
+    std::vector<DagParentLane> pitem;
+    std::vector<double> img;
+    auto new_tile = [&](int32_t kind) -> DagTile& {
+        DagTile t{};
+        t.kind = kind;
+        t.lane_base = int32_t(tiles.size()) * kWave;
+        tiles.push_back(t);
+        cnode.resize(tiles.size() * kWave, DagChildLane{-1, 0});
+        pitem.resize(tiles.size() * kWave, DagParentLane{-1, -1, 0, 0});
+        return tiles.back();
+    };
+    for (int m = 0; m <= kDagMaxParents; ++m) {
+        const int G = lanes_of(m), npt = kWave / G, epl = entries_of(m), D = m > 2 ? m - 2 : 0;
+        std::vector<int32_t> nodes;
+        for (int32_t v = 0; v < n; ++v)
+            if (p.in_ptr[v + 1] - p.in_ptr[v] == m) nodes.push_back(v);
+        for (size_t at = 0; at < nodes.size(); at += size_t(npt)) {
+            DagTile& t = new_tile(m);
+            t.n_active = int32_t(std::min<size_t>(npt, nodes.size() - at));
+            t.cpt_base = int32_t(img.size() / 2);
+            img.resize(img.size() + size_t(epl) * kWave, 0.0);
+            double* im = img.data() + size_t(t.cpt_base) * 2;
+            for (int nl = 0; nl < t.n_active; ++nl) {
+                const int32_t v = nodes[at + nl];
+                const double* cpt = p.cpt_flat.data() + p.cpt_off[v];
+                for (int g = 0; g < G; ++g) {
+                    const int lane = nl * G + g;
+                    cnode[size_t(t.lane_base) + lane] = DagChildLane{v, p.in_ptr[v]};
+                    // the lane's leading-parent digits (first parent most significant) are the digits of g; its entries run
+                    // over the trailing parents (the last one fastest) and the own state: entry cl * 4 + i
+                    const int trailing = m < 2 ? m : 2, ncl = 1 << (2 * trailing);
+                    for (int cl = 0; cl < ncl; ++cl)
+                        for (int i = 0; i < 4; ++i) {
+                            const int64_t row = (int64_t(g) << (2 * trailing)) | cl;   // assignment index, first parent most significant
+                            const int q = cl * 4 + i;
+                            im[size_t(q >> 1) * (2 * kWave) + size_t(lane) * 2 + (q & 1)] = cpt[row * 4 + i];
+                        }
+                    (void)D;
+                }
+            }
+        }
+    }
+    dp.n_child_tiles = int32_t(tiles.size());
+    {
+        std::vector<int32_t> order(n);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            return out_ptr[a + 1] - out_ptr[a] < out_ptr[b + 1] - out_ptr[b];
+        });
+        int fill = kWave;
+        DagTile* cur = nullptr;
+        auto push = [&](const DagParentLane& it) {
+            if (fill == kWave) { cur = &new_tile(kDagParent); fill = 0; }
+            pitem[size_t(cur->lane_base) + fill++] = it;
+            cur->n_active = fill;
+            cur->dmax = std::max(cur->dmax, it.deg_tpos & 0xffff);
+        };
+        for (int32_t u : order) {
+            const int32_t deg = out_ptr[u + 1] - out_ptr[u];
+            push(DagParentLane{u, -1, out_ptr[u], int32_t(uint32_t(deg) | 0xffff0000u)});   // lambda(v): no child is skipped
+            for (int32_t r = 0; r < deg; ++r) push(DagParentLane{u, dp.oedge[out_ptr[u] + r], out_ptr[u], deg | (r << 16)});
+        }
+    }
+    dp.n_parent_tiles = int32_t(tiles.size()) - dp.n_child_tiles;
+
+    // ---- wave slots.  One block per CU, kDagWaves waves: waves w and w + 4 share a SIMD.  Tiles in order of decreasing
+    // cost go to the slots wave-major (every block's wave 0, then every block's wave 1, ...), alternate passes reversed:
+    // every SIMD gets one of the heaviest tiles before any gets a second, and the light ones fill up beside them.
+    const int64_t total = int64_t(tiles.size());
+    int64_t heavy = 0;
+    for (const DagTile& t : tiles) heavy += t.kind >= 2 && t.kind <= kDagMaxParents;
+    int64_t want = std::max((total + kDagWaves - 1) / kDagWaves, (heavy + 3) / 4);
+    want = (std::max<int64_t>(want, 1) + 7) & ~int64_t(7);
+    if (total <= kDagWaves) want = 1;   // one block: no grid barrier at all
+    const int32_t nb = int32_t(std::min<int64_t>(want, cap_blocks));
+    const int32_t slots = nb * kDagWaves;
+    dp.blocks = nb;
+    dp.stream = total > slots;
+    std::vector<int32_t> by_cost(tiles.size());
+    std::iota(by_cost.begin(), by_cost.end(), 0);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int32_t a, int32_t b) { return cost_of(tiles[a]) > cost_of(tiles[b]); });
+    std::vector<std::vector<int32_t>> of_slot(slots);
+    for (size_t i = 0; i < by_cost.size(); ++i) {
+        const int64_t pass = int64_t(i) / slots, at = int64_t(i) % slots;
+        const int64_t pos = (pass & 1) ? slots - 1 - at : at;           // wave-major position
+        const int32_t w = int32_t(pos / nb), bq = int32_t(pos % nb);
+        const int32_t blk = (w & 1) ? nb - 1 - bq : bq;
+        of_slot[size_t(blk) * kDagWaves + w].push_back(by_cost[i]);
+    }
+    dp.slot_ptr.assign(size_t(slots) + 1, 0);
+    dp.tiles.reserve(tiles.size());
+    dp.cnode.resize(tiles.size() * kWave);
+    dp.pitem.resize(tiles.size() * kWave);
+    for (int32_t s = 0; s < slots; ++s) {
+        for (int32_t t : of_slot[s]) {
+            DagTile nt = tiles[t];
+            nt.lane_base = int32_t(dp.tiles.size()) * kWave;
+            std::copy(cnode.begin() + size_t(tiles[t].lane_base), cnode.begin() + size_t(tiles[t].lane_base) + kWave, dp.cnode.begin() + nt.lane_base);
+            std::copy(pitem.begin() + size_t(tiles[t].lane_base), pitem.begin() + size_t(tiles[t].lane_base) + kWave, dp.pitem.begin() + nt.lane_base);
+            dp.tiles.push_back(nt);
+        }
+        dp.slot_ptr[s + 1] = int32_t(dp.tiles.size());
+    }
+    dp.cpt_img.swap(img);
+    dp.ok = true;
+}
+
+}  // namespace bnmi

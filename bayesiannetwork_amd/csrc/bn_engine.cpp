@@ -23,6 +23,7 @@
 #include "bn_fit.hpp"
 #include "bn_lw.hpp"
 #include "bn_small.hpp"
+#include "bn_dag.hpp"
 
 using namespace bnmi;
 
@@ -262,6 +263,26 @@ struct bn_engine {
     char* d_m_sync = nullptr;       // per state slot kMidSyncBytes: the barrier counter, the three residual words, the group counters
     int32_t mid_slots = 0;          // state slots allocated (1 for single queries; batches run several sets per launch)
     int32_t n_cus = 0;
+    // k = 4 networks with up to 5 parents per node (BASELINE configs[1]): child tiles with the CPT in registers + parent items on
+    // waves of their own, state in device memory, one launch per run (bn_dag.hip)
+    DagPlan dag;
+    bool dag_ok = false;
+    int dag_mode = 1;               // option "dag": 0 never, 1 where eligible and no other one-launch path takes the network, 2 wherever eligible
+    int32_t dag_cooldown = 0, dag_aborts = 0;   // runs left on the tile kernels after a grid wait gave up; how often that happened
+    DagTile* d_g_tiles = nullptr;
+    int32_t* d_g_slotptr = nullptr;
+    DagChildLane* d_g_cnode = nullptr;
+    DagParentLane* d_g_pitem = nullptr;
+    int32_t* d_g_oedge = nullptr;
+    double* d_g_cpt = nullptr;
+    double* d_g_init = nullptr;
+    double* d_g_state = nullptr;    // pi-/lambda-messages (CSR edge order), pi(v), lambda(v): two buffers each (bn_dag.hpp dag_off_*)
+    uint8_t* d_g_frz = nullptr;
+    uint8_t dag_mark = 0;           // mark value of the evidence set applied to d_g_state / d_g_frz
+    bool dag_ev_applied = false;    // ... and whether that is the set in force
+    ResidentSync* d_g_sync = nullptr;
+    bool dag_sync_dirty = true;
+    uint32_t dag_gen_base = 0;
     bool ev_deferred = false;       // the evidence in force sits in the staging block only: the one-workgroup kernel reads it there
                                     // itself (no evidence launch in front of the run); the tile buffers get it -- marks, vectors --
                                     // when another path needs them (flush_evidence)
@@ -302,6 +323,7 @@ static void free_engine(bn_engine* e) {
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
                         e->d_m_parts, e->d_m_ent, e->d_m_cpt, e->d_m_term, e->d_m_clist, e->d_m_bslot, e->d_m_cslot, e->d_m_nvidx, e->d_m_nvslot,
                         e->d_m_init, e->d_m_nodeoff, e->d_m_msgfirst, e->d_m_state, e->d_m_frz, e->d_m_sync,
+                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state};
         for (void* p : ptrs)
@@ -403,6 +425,15 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             return fail(BN_ERR_ALLOC, "out of host memory while building the mid-size plan");
         }
     }
+    constexpr int32_t kDagDefaultCap = 224;  // 0.9 x 256 CUs, a multiple of 8 (rebuilt below when the device has another count)
+    if (p.nranks == 1 && !std::getenv("BN_NO_DAG")) {  // k = 4, <= 5 parents: register-resident child tiles + parent items (bn_dag.hpp)
+        try {
+            build_dag_plan(p, kDagDefaultCap, e->dag);
+        } catch (const std::bad_alloc&) {
+            delete e;
+            return fail(BN_ERR_ALLOC, "out of host memory while building the plan of the register-resident DAG path");
+        }
+    }
     if (desc->device == BN_DEVICE_HOST_ONLY) {
         *out = e;
         return BN_OK;
@@ -474,11 +505,19 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             // BN_RESIDENT_WAVES=8 / 4 forces either (A/B).
             e->resident_waves = kResidentWaves;
             {
-                const int64_t cap4 = (int64_t(prop.multiProcessorCount) * 9 / 10 - 1) * (kResidentWaves / 2);
-                if (nt > kResidentWaves && nt <= cap4) e->resident_waves = kResidentWaves / 2;
+                // blocks a launch of `w` waves per block needs (single engines round up to a multiple of 8 for the XCD-contiguous
+                // mapping, below) + the barrier's service block must fit 0.9 x CUs: decided on the ROUNDED count (a 239 x 240 grid
+                // has 898 tiles = 225 blocks of four, 232 after rounding: too many -- it keeps 8 waves per block)
+                const int64_t cu_cap = int64_t(prop.multiProcessorCount) * 9 / 10;
+                auto fits = [&](int w) {
+                    int64_t b = (nt + w - 1) / w;
+                    if (b > 1 && p.nranks == 1) b = (b + 7) & ~int64_t(7);
+                    return b + 1 <= cu_cap && b <= kResidentMaxBlocks;
+                };
+                if (nt > kResidentWaves && fits(kResidentWaves / 2)) e->resident_waves = kResidentWaves / 2;
                 if (const char* w = std::getenv("BN_RESIDENT_WAVES")) {
                     const int v = std::atoi(w);
-                    if (v == kResidentWaves || (v == kResidentWaves / 2 && nt <= cap4) || (v == 2 && nt <= cap4 / 2 && nt > 2)) e->resident_waves = v;
+                    if (v == kResidentWaves || (v == kResidentWaves / 2 && fits(v)) || (v == 2 && nt > 2 && fits(v))) e->resident_waves = v;
                 }
             }
             int64_t nb = (nt + e->resident_waves - 1) / e->resident_waves;
@@ -590,6 +629,29 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 return fail(BN_ERR_HIP, std::string("bp_mid attribute: ") + hipGetErrorString(hipError_t(code)));
             if (const char* mm = std::getenv("BN_MID")) e->mid_mode = std::atoi(mm) != 0;
             e->mid_ok = true;
+        }
+        if (e->dag.ok) {
+            const int32_t cap = int32_t((int64_t(e->n_cus) * 9 / 10) & ~int64_t(7));
+            if (cap != kDagDefaultCap) build_dag_plan(p, cap, e->dag);
+        }
+        if (e->dag.ok) {
+            const DagPlan& dp = e->dag;
+            int r2;
+            if ((r2 = upload(&e->d_g_tiles, dp.tiles, e->stream))) return r2;
+            if ((r2 = upload(&e->d_g_slotptr, dp.slot_ptr, e->stream))) return r2;
+            if ((r2 = upload(&e->d_g_cnode, dp.cnode, e->stream))) return r2;
+            if ((r2 = upload(&e->d_g_pitem, dp.pitem, e->stream))) return r2;
+            if ((r2 = upload(&e->d_g_oedge, dp.oedge, e->stream))) return r2;
+            if ((r2 = upload(&e->d_g_cpt, dp.cpt_img, e->stream))) return r2;
+            if ((r2 = upload(&e->d_g_init, dp.npi_init, e->stream))) return r2;
+            const size_t sd = size_t(dag_state_doubles(dp.E, dp.n));
+            if ((r2 = dalloc(&e->d_g_state, sd))) return r2;
+            HIPCHK(hipMemsetAsync(e->d_g_state, 0, std::max<size_t>(sd, 1) * 8, e->stream));
+            if ((r2 = dalloc(&e->d_g_frz, size_t(dp.n)))) return r2;
+            HIPCHK(hipMemsetAsync(e->d_g_frz, 0, size_t(dp.n), e->stream));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_g_sync), sizeof(ResidentSync)));
+            if (const char* dm = std::getenv("BN_DAG")) e->dag_mode = std::max(0, std::min(2, std::atoi(dm)));
+            e->dag_ok = true;
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -704,6 +766,7 @@ static int flush_evidence(bn_engine* e) {
     return BN_OK;
 }
 
+static bool dag_applies(const bn_engine* e);
 static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, const int32_t* ev_off,
                              const double* ev_val, bool wait) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -741,7 +804,8 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
     e->d_ev_val = reinterpret_cast<double*>(e->h_ev_dev + off_val);
     e->ev_ne = ne;
     e->ev_nval = int32_t(nval);
-    if (e->small_ok || e->mid_ok) {  // the item kernels read the arrays where they are; flush_evidence() serves every other path
+    e->dag_ev_applied = false;
+    if (e->small_ok || e->mid_ok || dag_applies(e)) {  // the item kernels read the arrays where they are; flush_evidence() serves every other path
         e->ev_deferred = true;
         e->ev_upload_pending = ne > 0;
         return BN_OK;
@@ -763,6 +827,10 @@ extern "C" int bn_bp_set_evidence(bn_engine* e, int32_t ne, const int32_t* ev_no
 // ---- the steps of a run; bn_bp_run_device chains them, the bn_bp_step_* entry points expose
 // them one by one (tests drive several shards on one GPU with an emulated all-gather).
 static int step_begin(bn_engine* e) {
+    // a run on the tile kernels starts here (also the single-step API): what it leaves behind -- beliefs in d_beliefs, messages
+    // in the record buffers -- is what the diagnostics must read, whatever path and output buffer the previous run used
+    e->beliefs_on_host_only = false;
+    e->last_path = 0;
     if (int rc = flush_evidence(e)) return rc;
     ++e->run_id;
     if (e->run_id == 0) e->run_id = 1;
@@ -1089,6 +1157,97 @@ static int run_mid(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
     return BN_OK;
 }
 
+// k = 4 networks with up to 5 parents per node whose size puts them beyond the item kernels (BASELINE configs[1]): the
+// register-resident DAG path (bn_dag.hip) where no other one-launch path takes the network; "dag" 2 = wherever eligible
+static bool dag_applies(const bn_engine* e) {
+    if (!e->dag_ok || e->multisweep == 0 || e->dag_mode == 0) return false;
+    if (e->dag_mode == 2) return true;
+    return !e->small_ok && !e->resident_ok && !mid_applies(e);
+}
+
+// The evidence in force (staging block) -> the state arrays of the DAG path: marks of this set's own value, vectors in both buffers.
+static int flush_dag_evidence(bn_engine* e) {
+    if (e->dag_ev_applied) return BN_OK;
+    if (e->dag_mark == 255) {  // the mark values are used up: start over
+        HIPCHK(hipMemsetAsync(e->d_g_frz, 0, size_t(e->dag.n), e->stream));
+        e->dag_mark = 0;
+    }
+    ++e->dag_mark;
+    DagEvidenceArgs ea{e->ev_ne, e->dag.n, e->dag.E, e->d_ev_node, e->d_ev_off, e->d_ev_val, e->d_g_state, e->d_g_frz, e->dag_mark};
+    if (int code = launch_dag_evidence(ea, e->stream))
+        return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    e->dag_ev_applied = true;
+    e->ev_upload_pending = e->ev_ne > 0;
+    return BN_OK;
+}
+
+// One launch runs the whole query (more only beyond kDagBudget iterations).  BN_ERR_STATE: a grid wait gave up.
+static int run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to) {
+    hipStream_t s = e->stream;
+    const DagPlan& dp = e->dag;
+    if (int rc = flush_dag_evidence(e)) return rc;
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    int32_t begin = 0, launches = 0;
+    float ms = 0.f;
+    double dev_ticks = 0.0;
+    const BpBuffers b = buffers_of(e);
+    for (;;) {
+        // polled words: generations count on from launch to launch; zeroed at creation, after an abort and before they would wrap
+        if (e->dag_sync_dirty || e->dag_gen_base > (1u << 29)) {
+            HIPCHK(hipMemsetAsync(e->d_g_sync, 0, sizeof(ResidentSync), s));
+            e->dag_sync_dirty = false;
+            e->dag_gen_base = 0;
+        }
+        *e->h_abort = 0;
+        DagArgs a{};
+        a.b = b; a.eps = eps; a.max_sweeps = max_sweeps; a.sweep_begin = begin; a.budget = kDagBudget; a.run_id = e->run_id;
+        a.gen_base = e->dag_gen_base;
+        a.timeout_ticks = 5000000ull;  // one wait: 50 ms of the 100 MHz clock
+        a.sync = e->d_g_sync; a.host_ctl = e->h_ctl_dev; a.host_abort = e->h_abort_dev;
+        a.n = dp.n; a.E = dp.E; a.n_blocks = dp.blocks;
+        a.tiles = e->d_g_tiles; a.slot_ptr = e->d_g_slotptr; a.cnode = e->d_g_cnode; a.pitem = e->d_g_pitem; a.oedge = e->d_g_oedge;
+        a.cpt_img = e->d_g_cpt; a.npi_init = e->d_g_init; a.state = e->d_g_state; a.frz = e->d_g_frz; a.frz_mark = e->dag_mark;
+        if (e->timing) {
+            int rc = ensure_events(e, 2);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->events[0], s));
+        }
+        if (int code = launch_bp_dag(a, dp.stream, s))
+            return fail(BN_ERR_HIP, std::string("bp_dag launch failed: ") + hipGetErrorString(hipError_t(code)));
+        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
+        if (copy_to)  // a launch that stops on its budget copies an intermediate state; the last one counts
+            HIPCHK(hipMemcpyAsync(copy_to, e->d_beliefs, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        e->ev_upload_pending = false;
+        ++launches;
+        e->dag_gen_base += kDagBudget + 1;
+        const bool gave_up = e->h_ctl->done < 0 || *e->h_abort != 0;
+        if (e->h_ctl->run_id != e->run_id || gave_up) e->dag_sync_dirty = true;
+        if (gave_up) {
+            *e->h_abort = 0;
+            return fail(BN_ERR_STATE, "a block of the register-resident DAG kernel gave up its grid wait");
+        }
+        if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_HIP, "bp_dag kernel did not report (stale control block)");
+        if (e->timing) {
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
+            ms += t;
+        }
+        dev_ticks += double(e->h_ctl->t_last - e->h_ctl->t_first);
+        if (e->h_ctl->done != 0) break;
+        begin = e->h_ctl->n_sweeps;
+    }
+    const bool rows_were_clean = e->rows_clean;  // this path never touches the residual slots
+    note_run_result(e);
+    e->rows_clean = rows_were_clean;
+    e->last_path = 5;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = ms;
+    e->stats.sweep_devclock_ms = float(dev_ticks * 1e-5);
+    return BN_OK;
+}
+
 static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
                            double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -1118,6 +1277,26 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     // 2.6), and networks that need two rounds of accumulator or product items (16 x 16 grid, k = 2: 4.3 / 3.5).  With two
     // parents per node the tile kernel's 64-entry contraction costs more than the items (8 x 8 grid, k = 4: 4.2 / 5.1;
     // 40-node DAG: 2.6 / 6.4).  "small" 2 = wherever eligible.
+    // the register-resident DAG path (bn_dag.hip): after the item kernels by default, ahead of them when forced ("dag" 2)
+    bool dag_tried = false;
+    auto attempt_dag = [&]() -> int {   // BN_OK: the run is done; BN_ERR_STATE: not taken / aborted, go on with the next path
+        if (dag_tried || !dag_applies(e)) return BN_ERR_STATE;
+        dag_tried = true;
+        if (e->dag_cooldown > 0) { --e->dag_cooldown; return BN_ERR_STATE; }
+        const int r = run_dag(e, eps, max_sweeps, copy_to);
+        if (r == BN_OK) {
+            e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
+            if (residual_out) *residual_out = e->last_ctl.last_res;
+            return BN_OK;
+        }
+        if (r != BN_ERR_STATE) return r;
+        ++e->dag_aborts;
+        e->dag_cooldown = 64;   // something else holds CUs: the other paths for a while
+        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] register-resident DAG kernel aborted (%s); other paths for the next 64 runs\n", g_err.c_str());
+        return BN_ERR_STATE;
+    };
+    if (e->dag_mode == 2 && (rc = attempt_dag()) != BN_ERR_STATE) return rc;
     const bool small_pays = !(e->resident_ok && e->grid_resident == 1) ||
                             (e->small.rb == 1 && e->small.rc == 1 && (e->small.mmax >= 2 || (e->small.re == 1 && e->small.n <= 128)));
     if (e->small_ok && e->multisweep != 0 && (e->small_mode == 2 || (e->small_mode == 1 && small_pays))) {
@@ -1143,6 +1322,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         e->mid_cooldown = 64;   // something else holds CUs: the tile kernels for a while
         if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] mid-size kernel aborted (%s); tile kernels for the next 64 runs\n", g_err.c_str());
     }
+    if ((rc = attempt_dag()) != BN_ERR_STATE) return rc;
     if ((rc = flush_evidence(e))) return rc;  // the tile kernels read the evidence from their own buffers
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
@@ -1231,6 +1411,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
     if (std::strcmp(name, "direct") == 0) { e->resident_direct = value != 0; return BN_OK; }
     if (std::strcmp(name, "mid") == 0) { e->mid_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
+    if (std::strcmp(name, "dag") == 0) { e->dag_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "small") == 0) { e->small_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "poll_sleep") == 0) { e->poll_sleep = std::max(0, std::min(value, 64)); return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
@@ -1252,6 +1433,11 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "mid_eligible") == 0) return e->mid.ok ? 1 : 0;
     if (std::strcmp(name, "mid_parts") == 0) return e->mid.ok ? int64_t(e->mid.parts.size()) : 0;
     if (std::strcmp(name, "mid_aborts") == 0) return e->mid_aborts;
+    if (std::strcmp(name, "dag_eligible") == 0) return e->dag.ok ? 1 : 0;
+    if (std::strcmp(name, "dag_blocks") == 0) return e->dag.ok ? e->dag.blocks : 0;
+    if (std::strcmp(name, "dag_tiles") == 0) return e->dag.ok ? int64_t(e->dag.tiles.size()) : 0;
+    if (std::strcmp(name, "dag_stream") == 0) return e->dag.ok && e->dag.stream ? 1 : 0;
+    if (std::strcmp(name, "dag_aborts") == 0) return e->dag_aborts;
     if (std::strcmp(name, "small_eligible") == 0) return e->small.ok ? 1 : 0;
     if (std::strcmp(name, "small_waves") == 0) return e->small.ok ? e->small.waves : 0;
     if (std::strcmp(name, "small_lds_bytes") == 0) return e->small.ok ? int64_t(e->small.lds_bytes) : 0;
@@ -2171,6 +2357,13 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
     if (!e || !pi_msg_out || !lambda_msg_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only || !e->have_run) return fail(BN_ERR_STATE, "no belief propagation run yet");
     ON_DEVICE(e);
+    if (e->last_path == 5) {  // bn_dag.hip: CSR edge order, four doubles per edge, two buffers: the run stopped in buffer n_sweeps & 1
+        const int64_t E = e->dag.E, n = e->dag.n;
+        const int par = e->last_ctl.n_sweeps & 1;
+        HIPCHK(hipMemcpy(pi_msg_out, e->d_g_state + 2 * dag_off_pim(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lambda_msg_out, e->d_g_state + 2 * dag_off_lam(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+        return BN_OK;
+    }
     if (e->last_path == 4) {  // bn_mid.hip keeps them in CSR edge order, two buffers: the run stopped in buffer n_sweeps & 1
         const size_t M = size_t(e->mid.parts[0].M), par = size_t(e->last_ctl.n_sweeps & 1);
         HIPCHK(hipMemcpy(pi_msg_out, e->d_m_state + par * M, sizeof(double) * M, hipMemcpyDeviceToHost));
@@ -2234,6 +2427,27 @@ static int small_plan_copy(const SmallPlan& sp, const SmallPlan& tables, int32_t
     if (bslot) std::memcpy(bslot, sp.bslot.data(), sp.bslot.size() * sizeof(SmallSlot));
     if (cslot) std::memcpy(cslot, sp.cslot.data(), sp.cslot.size() * sizeof(SmallSlot));
     if (npi_init) std::copy(tables.npi_init.begin(), tables.npi_init.end(), npi_init);
+    return BN_OK;
+}
+
+// The plan of the register-resident DAG path (bn_dag.hpp; tests emulate the kernel on it).
+extern "C" int bn_dag_plan_get(bn_engine* e, int32_t* dims_out, int32_t* tiles, int32_t* slot_ptr, int32_t* cnode, int32_t* pitem,
+                               int32_t* oedge, double* cpt_img, double* npi_init) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    const DagPlan& dp = e->dag;
+    if (!dp.ok) return fail(BN_ERR_STATE, "not eligible for the register-resident DAG path: " + (dp.why.empty() ? std::string("disabled") : dp.why));
+    if (dims_out) {
+        const int32_t d[8] = {dp.n, dp.E, int32_t(dp.tiles.size()), dp.blocks, dp.stream ? 1 : 0, dp.n_child_tiles, dp.n_parent_tiles,
+                              int32_t(dp.cpt_img.size())};
+        std::copy(d, d + 8, dims_out);
+    }
+    if (tiles) std::memcpy(tiles, dp.tiles.data(), dp.tiles.size() * sizeof(DagTile));
+    if (slot_ptr) std::copy(dp.slot_ptr.begin(), dp.slot_ptr.end(), slot_ptr);
+    if (cnode) std::memcpy(cnode, dp.cnode.data(), dp.cnode.size() * sizeof(DagChildLane));
+    if (pitem) std::memcpy(pitem, dp.pitem.data(), dp.pitem.size() * sizeof(DagParentLane));
+    if (oedge) std::copy(dp.oedge.begin(), dp.oedge.end(), oedge);
+    if (cpt_img) std::copy(dp.cpt_img.begin(), dp.cpt_img.end(), cpt_img);
+    if (npi_init) std::copy(dp.npi_init.begin(), dp.npi_init.end(), npi_init);
     return BN_OK;
 }
 

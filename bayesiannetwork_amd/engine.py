@@ -169,7 +169,8 @@ class Engine:
         return _lib.check(_lib.lib().bn_get_info(self._h, name.encode()))
 
     def last_path(self) -> int:
-        """2: the last run was one launch for the whole run (resident tiles); 0: one launch per sweep."""
+        """0: one launch per sweep; 2: resident tiles; 3: one workgroup (small networks); 4: several workgroups (mid-size);
+        5: register-resident child tiles + parent items (k = 4 networks with <= 5 parents)."""
         return _lib.check(_lib.lib().bn_bp_last_path(self._h))
 
     # ---- multi-GPU ---------------------------------------------------------------------
@@ -233,6 +234,29 @@ class Engine:
             d.update(ent=ent, ent_cpt=ent_cpt, term=term[:d["TT"]], clist=clist[:d["CL"]], bslot=bslot, cslot=cslot, npi_init=init)
             parts.append(d)
         return parts
+
+    def dag_plan(self):
+        """The plan of the register-resident DAG path (bn_dag_plan_get; k = 4 networks with <= 5 parents per node), or None when
+        the network is not eligible: dict(n, E, n_tiles, blocks, stream, child_tiles, parent_tiles, tiles [n_tiles, 8], slot_ptr,
+        cnode [n_tiles * 64, 2], pitem [n_tiles * 64, 4], oedge, cpt_img, npi_init [n, 4])."""
+        if not self.info("dag_eligible"):
+            return None
+        L = _lib.lib()
+        dims = np.zeros(8, dtype=np.int32)
+        _lib.check(L.bn_dag_plan_get(self._h, _p(dims, ctypes.c_int32), None, None, None, None, None, None, None))
+        names = ["n", "E", "n_tiles", "blocks", "stream", "child_tiles", "parent_tiles", "cpt_doubles"]
+        d = {k: int(v) for k, v in zip(names, dims)}
+        tiles = np.zeros((d["n_tiles"], 8), dtype=np.int32)
+        slot_ptr = np.zeros(d["blocks"] * 8 + 1, dtype=np.int32)
+        cnode = np.zeros((d["n_tiles"] * 64, 2), dtype=np.int32)
+        pitem = np.zeros((d["n_tiles"] * 64, 4), dtype=np.int32)
+        oedge = np.zeros(max(d["E"], 1), dtype=np.int32)
+        img = np.zeros(max(d["cpt_doubles"], 1), dtype=np.float64)
+        init = np.zeros((d["n"], 4), dtype=np.float64)
+        _lib.check(L.bn_dag_plan_get(self._h, None, _p(tiles, ctypes.c_int32), _p(slot_ptr, ctypes.c_int32), _p(cnode, ctypes.c_int32),
+                                     _p(pitem, ctypes.c_int32), _p(oedge, ctypes.c_int32), _p(img, ctypes.c_double), _p(init, ctypes.c_double)))
+        d.update(tiles=tiles, slot_ptr=slot_ptr, cnode=cnode, pitem=pitem, oedge=oedge[:d["E"]], cpt_img=img[:d["cpt_doubles"]], npi_init=init)
+        return d
 
     def small_plan(self):
         """The plan of the one-workgroup path for small networks (bn_small_plan_get), or None when the network is not

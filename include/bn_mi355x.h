@@ -212,8 +212,18 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * "poll_sleep" n -- dataflow form: pause between two polls of a waiting tile, n x 512 cycles (default 2).
  * "beliefs_direct" 1/0 -- bn_bp_run_view: the kernels write the marginals straight into the engine's mapped host
  *   buffer (default 1, outputs up to 16 MB) instead of a copy command queued behind the run.
+ * "dag" 0/1/2 -- networks whose nodes all have arity 4 and at most 5 parents (BASELINE configs[1], the 10 k-node random DAG): one
+ *   launch per run with every CPT entry resident in a register; a node's child role (pi(v), lambda-messages: one wavefront of
+ *   nodes / lane groups per tile) and parent role (lambda(v), pi-messages: one lane per message) run on different waves, the state
+ *   lives in device memory in CSR edge order, one grid barrier per iteration.  Nodes with <= 2 parents keep the reference's
+ *   operation order; with >= 3 parents the contraction is factored (sums over the two trailing parents shared by all outputs):
+ *   results agree with the reference to rounding (<= 1e-12; its own products over >= 3 parents are unordered,
+ *   belief_propagation.hpp:253).  Networks beyond one tile per wave run the same code walking several tiles per wave ("stream"
+ *   form).  0 = never, 1 = where eligible and no other one-launch path takes the network (default), 2 = wherever eligible.
+ *   bn_get_info "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts".
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run), 3 = one workgroup, state in LDS
- *   (small networks, one launch per run), 4 = the same items over several workgroups (mid-size networks). */
+ *   (small networks, one launch per run), 4 = the same items over several workgroups (mid-size networks), 5 = register-resident
+ *   child tiles + parent items (k = 4 networks with <= 5 parents). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
@@ -331,6 +341,15 @@ int bn_small_plan_get(bn_engine *eng, int32_t *dims_out, uint32_t *ent, double *
  * dims_out[14]: the twelve values above, then the part's node range [v0, v1). */
 int bn_mid_plan_get(bn_engine *eng, int32_t part, int32_t *dims_out, uint32_t *ent, double *ent_cpt, uint32_t *term, uint16_t *clist,
                     uint32_t *bslot, uint32_t *cslot, double *npi_init);
+
+/* The plan of the register-resident DAG path (csrc/bn_dag.hpp: k = 4 networks with <= 5 parents per node; tests emulate the
+ * kernel on it).  dims_out[8] = n, E, tiles, blocks, stream (1: some wave walks several tiles per iteration), child tiles, parent
+ * tiles, doubles of the CPT image; the arrays (any may be NULL) are sized from those: tiles [tiles][8] (kind, active nodes / items,
+ * first per-lane entry, first double2 of the CPT image, largest child count, 3 unused), slot_ptr [blocks * 8 + 1], cnode
+ * [tiles * 64][2] (node, first in-edge), pitem [tiles * 64][4] (node, target out-edge or -1, first out-edge entry, child count |
+ * target's rank << 16), oedge [max(E, 1)], cpt_img [dims_out[7]], npi_init [4 n].  BN_ERR_STATE: the network is not eligible. */
+int bn_dag_plan_get(bn_engine *eng, int32_t *dims_out, int32_t *tiles, int32_t *slot_ptr, int32_t *cnode, int32_t *pitem,
+                    int32_t *oedge, double *cpt_img, double *npi_init);
 
 #ifdef __cplusplus
 }

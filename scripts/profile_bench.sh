@@ -6,7 +6,7 @@
 # Every pass puts the program itself after `--` (no env / shell hop); switches travel as exported
 # environment variables.  A pass that fails is recorded in failed_passes.txt and reported by the summary.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
@@ -29,6 +29,7 @@ trace trace_grid316 $B --steps 20 --warmup 3
 pmc fetch_grid316 FETCH_SIZE $B --steps 5 --warmup 2
 pmc write_grid316 WRITE_SIZE $B --steps 5 --warmup 2
 pmc sq_grid316 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --steps 5 --warmup 2
+pmc sq2_grid316 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --steps 5 --warmup 2
 # the same grid with one launch per sweep
 export BN_MULTISWEEP=0
 trace trace_grid316_launch $B --steps 20 --warmup 3
@@ -36,11 +37,18 @@ pmc fetch_grid316_launch FETCH_SIZE $B --steps 5 --warmup 2
 pmc write_grid316_launch WRITE_SIZE $B --steps 5 --warmup 2
 pmc sq_grid316_launch "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --steps 5 --warmup 2
 export BN_MULTISWEEP=1
-# config 2: 10 k-node DAG
+# config 2: 10 k-node DAG, default path (register-resident child tiles + parent items, one launch per run: bn_dag.hip)
 trace trace_dag10k $B --workload dag --steps 20 --warmup 3
 pmc fetch_dag10k FETCH_SIZE $B --workload dag --steps 5 --warmup 2
 pmc write_dag10k WRITE_SIZE $B --workload dag --steps 5 --warmup 2
 pmc sq_dag10k "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload dag --steps 5 --warmup 2
+pmc sq2_dag10k "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload dag --steps 5 --warmup 2
+# ... and with one launch per sweep (the tile kernels)
+export BN_DAG=0
+trace trace_dag10k_launch $B --workload dag --steps 20 --warmup 3
+pmc fetch_dag10k_launch FETCH_SIZE $B --workload dag --steps 5 --warmup 2
+pmc write_dag10k_launch WRITE_SIZE $B --workload dag --steps 5 --warmup 2
+unset BN_DAG
 # config 0's network on the GPU: the ALARM-shaped net, one workgroup per run (bn_small.hip)
 trace trace_alarm --no-cpu --workload alarm
 pmc sq_alarm "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" --no-cpu --workload alarm
@@ -52,6 +60,7 @@ trace trace_lw $B --workload lw --steps 3
 pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
 pmc write_lw WRITE_SIZE $B --workload lw --steps 2
 pmc sq_lw "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload lw --steps 2
+pmc sq2_lw "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload lw --steps 2
 # the HBM-resident point (4M nodes)
 trace trace_grid2048 $B --rows 2048 --cols 2048 --steps 3 --warmup 1
 pmc fetch_grid2048 FETCH_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1

@@ -17,7 +17,7 @@ import shutil
 import statistics
 import sys
 
-DOMINANT = {"grid316": ["bp_resident_kernel"], "grid316_launch": ["bp_sweep_kernel"], "dag10k": ["bp_sweep_kernel"],
+DOMINANT = {"grid316": ["bp_resident_kernel"], "grid316_launch": ["bp_sweep_kernel"], "dag10k": ["bp_dag_kernel"], "dag10k_launch": ["bp_sweep_kernel"],
             "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample_kernel", "lw_hist_kernel"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"]}
 
 
@@ -109,20 +109,25 @@ def main():
             traffic += (2.0 * fetch + write) * 1024.0
         if have_traffic and kernels:
             summary[f"{label}_traffic_bytes_per_launch"] = traffic
-        sq_dir = os.path.join(src, "sq_" + label)
-        if os.path.isdir(sq_dir):
-            sq = {}
+        sq = {}
+        for sq_dir in (os.path.join(src, "sq_" + label), os.path.join(src, "sq2_" + label)):   # (the SQ counters take two passes)
+            if not os.path.isdir(sq_dir):
+                continue
             names = sorted({r["Counter_Name"] for r in rows_of(sq_dir, "*counter_collection.csv")})
             for name in names:
                 v = counter_per_launch(sq_dir, kernels[0], name)
                 if v is not None:
                     sq[name] = v
+        if sq:
             summary[f"{label}_sq_counters_per_launch"] = sq
         log = os.path.join(src, f"trace_{label}.log")
         if os.path.exists(log):
             lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
             if lines:
                 summary[f"{label}_bench_line"] = json.loads(lines[-1])
+                spl = (summary[f"{label}_bench_line"].get("roofline") or {}).get("sweeps_per_launch")
+                if spl:
+                    summary[f"{label}_sweeps_per_launch"] = spl   # the counters above are per launch: bench.py divides by this
     json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if not k.endswith("_bench_line")}, indent=1))
 

@@ -1,0 +1,155 @@
+"""k = 4 networks with up to 5 parents per node (BASELINE configs[1], the 10 k-node random DAG): child tiles with the CPT in
+registers + parent items on waves of their own, state in device memory, one launch per run (csrc/bn_dag.hip,
+bn_bp_last_path == 5).  Nodes with <= 2 parents keep the reference's operation order (bit-identical to the oracle on networks
+made of such nodes); with >= 3 parents the contraction is factored: <= 1e-12 against the oracle (whose products over >= 3
+parents follow one fixed order where the reference's own follow an unordered_map's, belief_propagation.hpp:253), equal sweep
+counts everywhere."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine(bnlib):
+    from bayesiannetwork_amd.engine import Engine
+    return Engine
+
+
+def _nets():
+    from bayesiannetwork_amd import synth
+    return [("grid12", synth.grid(12, 12, 4, seed=3), True),             # <= 2 parents: the reference's order, bit for bit
+            ("chain300", synth.random_dag(300, 1, 1, 4, seed=4), True),
+            ("grid40", synth.grid(40, 40, 4, seed=5), True),
+            ("dag300", synth.random_dag(300, 4, 32, 4, seed=5), False),  # lane groups of 4 and 16
+            ("dag200_p5", synth.random_dag(200, 5, 32, 4, seed=6), False),  # ... and 64 (5 parents: 4 096-entry tables)
+            ("dag3000", synth.random_dag(3000, 4, 64, 4, seed=8), False),   # nodes with up to ~9 children
+            ("hub", _hub(), True)]
+
+
+def _hub():
+    """one node with 20 children (more than a parent item keeps in registers), each with one more parent"""
+    from bayesiannetwork_amd import from_parent_lists
+    from bayesiannetwork_amd.synth import uniform01
+    parents = [[]] + [[] for _ in range(20)] + [[0, 1 + c] for c in range(20)]
+    k = [4] * len(parents)
+    cpts = []
+    at = 0
+    for ps in parents:
+        rows = 4 ** len(ps)
+        r = 0.1 + 0.9 * uniform01(77, at, rows * 4).reshape(rows, 4)
+        at += rows * 4
+        cpts.append((r / r.sum(axis=1, keepdims=True)).ravel().tolist())
+    return from_parent_lists(k=k, parents=parents, cpts=cpts, name="hub20")
+
+
+@pytest.mark.parametrize("name", [n for n, _, _ in _nets()])
+def test_dag_path_vs_oracle(Engine, oracle_mod, name):
+    from bayesiannetwork_amd import Evidence, synth
+    g, exact = {n: (m, x) for n, m, x in _nets()}[name]
+    with Engine(g) as eng:
+        assert eng.info("dag_eligible") == 1
+        eng.set_option("dag", 2)
+        for ev, eps, cap in ((Evidence.none(), 1e-6, 0), (synth.random_evidence(g, 0.1, seed=3), 1e-9, 0),
+                             (synth.random_evidence(g, 0.3, seed=5), 1e-3, 0), (synth.random_evidence(g, 0.05, seed=6), 1e-12, 3)):
+            o = oracle_mod.bp_run(g, ev, eps, cap, dump_msgs=True)
+            first = None
+            for _ in range(3):   # repeated runs: nothing of one run leaks into the next, and the bits repeat
+                r = eng.bp_run(ev, eps, cap)
+                assert eng.last_path() == 5 and eng.bp_stats()["sweep_launches"] == 1 and eng.info("dag_aborts") == 0
+                assert r["sweeps"] == o["sweeps"]
+                pi, lam = eng.bp_messages()
+                if exact:
+                    assert np.array_equal(r["beliefs"], o["beliefs"])
+                    assert np.array_equal(eng.bp_residuals(), o["residuals"]) and r["residual"] == o["residuals"][-1]
+                    assert np.array_equal(pi, o["pi_msg"]) and np.array_equal(lam, o["lambda_msg"])
+                else:
+                    assert np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+                    assert np.abs(eng.bp_residuals() - o["residuals"]).max() < 1e-12
+                    assert np.abs(pi - o["pi_msg"]).max() < 1e-12 and np.abs(lam - o["lambda_msg"]).max() < 1e-12
+                if first is None:
+                    first = r["beliefs"].copy()
+                assert np.array_equal(first, r["beliefs"])
+        # the other paths on the same engine, alternating with this one: staged evidence survives the switch
+        ev = synth.random_evidence(g, 0.1, seed=3)
+        o = oracle_mod.bp_run(g, ev, 1e-6)
+        eng.bp_set_evidence(ev)
+        for dag, want5 in ((2, True), (0, False), (2, True)):
+            eng.set_option("dag", dag)
+            r = eng.bp_run_device(1e-6)
+            assert (eng.last_path() == 5) == want5 and r["sweeps"] == o["sweeps"]
+            assert np.abs(eng.bp_beliefs() - o["beliefs"]).max() < 1e-12
+
+
+def test_dag_soft_and_zero_evidence_and_a_two_launch_run(Engine, oracle_mod):
+    from bayesiannetwork_amd import Evidence, synth
+    g = synth.random_dag(300, 4, 32, 4, seed=5)
+    soft = Evidence.from_dict(g, {3: np.full(4, 0.25), 40: np.arange(1.0, 5.0), 70: 0, 299: 2})
+    zero = Evidence.from_dict(g, {5: np.zeros(4)})   # 0/0 -> NaN in the reference (no zero guard, :298-311)
+    with Engine(g) as eng:
+        eng.set_option("dag", 2)
+        for ev, eps, cap in ((soft, 1e-9, 0), (zero, 1e-6, 6)):
+            o = oracle_mod.bp_run(g, ev, eps, cap)
+            r = eng.bp_run(ev, eps, cap)
+            assert eng.last_path() == 5 and r["sweeps"] == o["sweeps"]
+            assert rel_err(r["beliefs"], o["beliefs"]) < 1e-9      # (NaNs must coincide)
+        assert np.isnan(eng.bp_run(zero, 1e-6, 6)["beliefs"]).any()
+        # a launch executes at most 1 024 iterations; the run goes on in another launch from the state in memory
+        ev = synth.random_evidence(g, 0.05, seed=1)
+        o = oracle_mod.bp_run(g, ev, 0.0, 1100, res_cap=1100)
+        r = eng.bp_run(ev, 0.0, 1100)
+        assert eng.last_path() == 5 and eng.bp_stats()["sweep_launches"] == 2
+        assert r["sweeps"] == 1100 and np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+        assert np.abs(eng.bp_residuals()[:1100] - o["residuals"]).max() < 1e-12
+
+
+def test_dag_view_and_functor(Engine, oracle_mod):
+    """bn_bp_run_view (the drop-in's host path: marginals written straight into the mapped host buffer) on this path."""
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import BeliefPropagation
+    g = synth.random_dag(1500, 4, 64, 4, seed=31)
+    evs = [synth.random_evidence(g, f, seed=20 + q) for q, f in enumerate([0.0, 0.05, 0.1, 0.3, 0.02])]
+    bp = BeliefPropagation(g)
+    bp.engine.set_option("dag", 2)
+    for q in range(15):
+        got = np.concatenate([np.asarray(m).ravel() for m in bp(evs[q % 5], 1e-6)])
+        o = oracle_mod.bp_run(g, evs[q % 5], 1e-6)
+        assert bp.last["sweeps"] == o["sweeps"] and np.abs(got - o["beliefs"]).max() < 1e-12, q
+    assert bp.engine.last_path() == 5
+
+
+def test_dag_config2_full_size_default_path(Engine, oracle_mod):
+    """BASELINE configs[1] takes this path by default (beyond the item kernels, not covered by the resident tiles)."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(10000, 4, 64, 4, seed=1)
+    ev = synth.random_evidence(d, 0.01, seed=7)
+    with Engine(d) as eng:
+        assert eng.info("dag_eligible") == 1 and eng.info("dag_stream") == 0 and eng.info("mid_eligible") == 0
+        for eps in (1e-3, 1e-6):
+            o = oracle_mod.bp_run(d, ev, eps, threads=8)
+            r = eng.bp_run(ev, eps)
+            assert eng.last_path() == 5 and eng.info("dag_aborts") == 0
+            assert r["sweeps"] == o["sweeps"]
+            assert rel_err(r["beliefs"], o["beliefs"]) < 1e-9 and np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+            assert np.abs(eng.bp_residuals() - o["residuals"]).max() < 1e-12
+
+
+def test_dag_100k_nodes_stream_form(Engine, oracle_mod):
+    """A 100 k-node DAG of the same kind (218 MB of CPTs: beyond the chip's registers): the same kernel, every wave walking
+    several tiles per iteration."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(100000, 4, 64, 4, seed=11)
+    ev = synth.random_evidence(d, 0.01, seed=7)
+    o = oracle_mod.bp_run(d, ev, 1e-4, threads=8)
+    with Engine(d) as eng:
+        assert eng.info("dag_eligible") == 1 and eng.info("dag_stream") == 1
+        eng.set_option("dag", 2)
+        r = eng.bp_run(ev, 1e-4)
+        assert eng.last_path() == 5 and eng.info("dag_aborts") == 0
+        assert r["sweeps"] == o["sweeps"]
+        assert rel_err(r["beliefs"], o["beliefs"]) < 1e-9 and np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+        eng.set_option("dag", 0)
+        r0 = eng.bp_run(ev, 1e-4)
+        assert eng.last_path() == 0 and r0["sweeps"] == o["sweeps"] and np.abs(r0["beliefs"] - r["beliefs"]).max() < 1e-12

@@ -360,6 +360,87 @@ def test_mid_plan_emulated_equals_oracle(bnlib, oracle_mod):
         assert e.info("mid_eligible") == 0 and e.mid_plan() is None
 
 
+def test_dag_plan_emulated_equals_oracle(bnlib, oracle_mod):
+    """k = 4 networks with up to 5 parents per node: the plan of the register-resident DAG path (bn_dag_plan.cpp), executed
+    tile by tile and lane by lane on the CPU (tests/dag_emulator.py: the kernel's operation order, shuffle butterflies
+    included).  Networks of nodes with <= 2 parents: the oracle bit for bit; lane-group tiles (factored contraction):
+    <= 1e-12, equal sweep counts.  (On the GPU: tests/test_dag_gpu.py.)"""
+    import dag_emulator
+    from bayesiannetwork_amd import Evidence, _lib, engine, synth
+    grid = synth.grid(12, 12, 4, seed=3)
+    dag4 = synth.random_dag(300, 4, 32, 4, seed=5)
+    dag5 = synth.random_dag(200, 5, 32, 4, seed=6)
+    soft = Evidence.from_dict(dag4, {3: np.full(4, 0.25), 40: np.arange(1.0, 5.0), 70: 0})
+    cases = [(grid, synth.random_evidence(grid, 0.05, seed=1), 1e-6, 0, True), (grid, Evidence.none(), 1e-9, 0, True),
+             (dag4, synth.random_evidence(dag4, 0.05, seed=2), 1e-6, 0, False), (dag4, soft, 1e-9, 0, False),
+             (dag5, synth.random_evidence(dag5, 0.05, seed=3), 1e-6, 0, False), (dag5, Evidence.none(), 1e-12, 5, False)]
+    for g, ev, eps, cap, exact in cases:
+        with engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+            assert e.info("dag_eligible") == 1
+            plan = e.dag_plan()
+        got = dag_emulator.emulate(plan, g, ev, eps, cap)
+        want = oracle_mod.bp_run(g, ev, eps, cap, dump_msgs=True)
+        assert got["sweeps"] == want["sweeps"]
+        if exact:
+            assert np.array_equal(got["beliefs"], want["beliefs"]) and np.array_equal(got["residuals"], want["residuals"])
+            assert np.array_equal(got["pi_msg"], want["pi_msg"]) and np.array_equal(got["lambda_msg"], want["lambda_msg"])
+        else:
+            assert np.abs(got["beliefs"] - want["beliefs"]).max() < 1e-12 and np.abs(got["residuals"] - want["residuals"]).max() < 1e-12
+            assert np.abs(got["pi_msg"] - want["pi_msg"]).max() < 1e-12 and np.abs(got["lambda_msg"] - want["lambda_msg"]).max() < 1e-12
+
+
+def test_dag_plan_invariants(bnlib):
+    """Every node sits in exactly one child tile (all lanes of its group), every edge and every node has exactly one parent
+    item, the wave slots cover the tiles; BASELINE configs[1] fits the chip at one tile per wave, ten times the nodes do not
+    (stream form); networks with another arity or more than 5 parents are not eligible; the kernel does not spill."""
+    import importlib.util
+    from bayesiannetwork_amd import _lib, engine, synth
+    g = synth.random_dag(10000, 4, 64, 4, seed=1)
+    with engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("dag_eligible") == 1 and e.info("dag_stream") == 0 and e.info("mid_eligible") == 0
+        p = e.dag_plan()
+    assert p["n_tiles"] == p["child_tiles"] + p["parent_tiles"] <= p["blocks"] * 8 and p["blocks"] % 8 == 0 and p["blocks"] <= 224
+    assert p["slot_ptr"][0] == 0 and p["slot_ptr"][-1] == p["n_tiles"] and (np.diff(p["slot_ptr"]) <= 1).all()
+    kinds = p["tiles"][:, 0]
+    m_of = np.diff(g.in_ptr)
+    seen = np.zeros(g.n, dtype=np.int64)
+    for t in np.nonzero(kinds <= 5)[0]:
+        m = int(kinds[t])
+        G = 1 if m <= 2 else 4 ** (m - 2)
+        cn = p["cnode"][p["tiles"][t, 2]:p["tiles"][t, 2] + 64]
+        nodes = cn[::G, 0]
+        assert (cn[:, 0].reshape(-1, G) == nodes[:, None]).all()          # the lanes of a group share the node
+        act = nodes[nodes >= 0]
+        assert len(act) == p["tiles"][t, 1] and (m_of[act] == m).all() and (cn[::G, 1][nodes >= 0] == g.in_ptr[act]).all()
+        seen[act] += 1
+    assert (seen == 1).all()
+    it = np.concatenate([p["pitem"][b:b + 64] for b in p["tiles"][kinds == 8][:, 2]])
+    it = it[it[:, 0] >= 0]
+    assert sorted(it[it[:, 1] >= 0][:, 1].tolist()) == list(range(g.n_edges))      # one item per pi-message
+    assert sorted(it[it[:, 1] < 0][:, 0].tolist()) == list(range(g.n))             # one per lambda(v)
+    deg = np.bincount(g.in_idx, minlength=g.n)
+    assert ((it[:, 3] & 0xffff) == deg[it[:, 0]]).all()
+    msg = it[it[:, 1] >= 0]
+    assert (p["oedge"][msg[:, 2] + (msg[:, 3] >> 16)] == msg[:, 1]).all()             # the target's rank among the node's children
+    assert (g.in_idx[msg[:, 1]] == msg[:, 0]).all()
+    big = synth.random_dag(30000, 4, 64, 4, seed=2)
+    with engine.Engine(big, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("dag_eligible") == 1 and e.info("dag_stream") == 1 and e.info("dag_blocks") == 224
+        assert e.info("dag_tiles") > 224 * 8
+    for other in (synth.random_dag(200, 4, 32, [4, 4, 3], seed=1), synth.random_dag(100, 6, 32, 4, seed=1), synth.pearl()):
+        with engine.Engine(other, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+            assert e.info("dag_eligible") == 0 and e.dag_plan() is None
+    obj = os.path.join(ROOT, "bayesiannetwork_amd", "csrc", "bn_dag.o")
+    if os.path.exists(obj) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+        kr = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(kr)
+        res = {k: v for k, v in kr.kernel_resources(obj).items() if "bp_dag_kernel" in k}
+        assert len(res) == 2
+        for name, r in res.items():   # two waves per SIMD: 256 registers each, the 64 CPT entries of a lane among them
+            assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
+
+
 def test_small_plan_invariants(bnlib):
     """Every output element has exactly one work item; a vector's elements sit in adjacent lanes of one wave; no two
     staged terms share a place and none lands in the zero padding of another run; the lanes of a wave add equally
