@@ -20,10 +20,24 @@ namespace bnmi {
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 #ifdef BN_TILE_CLOCK
-__device__ unsigned long long g_dag_clock[kDagMaxBlocks * kDagWaves][8];
+__device__ unsigned long long g_dag_clock[kDagMaxBlocks * kDagWaves][12];
 #define DSTAMP(k, it) do { if ((it) == 5 && lane == 0) g_dag_clock[blockIdx.x * kDagWaves + wave][k] = wall_clock64(); } while (0)
+// inside a tile's sweep, once its inputs have arrived (the wait is part of the diagnostic build only)
+#define DSTAMP_INPUTS(a, s)                                                                          \
+    do {                                                                                             \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+        if ((s) - (a).sweep_begin == 5 && (threadIdx.x & 63) == 0)                                   \
+            g_dag_clock[blockIdx.x * kDagWaves + (threadIdx.x >> 6)][2] = wall_clock64();            \
+    } while (0)
+#define DSTAMP_AT(k, a, s)                                                                          \
+    do {                                                                                             \
+        if ((s) - (a).sweep_begin == 5 && (threadIdx.x & 63) == 0)                                   \
+            g_dag_clock[blockIdx.x * kDagWaves + (threadIdx.x >> 6)][k] = wall_clock64();            \
+    } while (0)
 #else
 #define DSTAMP(k, it) ((void)0)
+#define DSTAMP_INPUTS(a, s) ((void)0)
+#define DSTAMP_AT(k, a, s) ((void)0)
 #endif
 
 typedef unsigned dag_u32x4 __attribute__((ext_vector_type(4)));
@@ -49,6 +63,13 @@ __device__ __forceinline__ void dag_st4(__amdgpu_buffer_rsrc_t r, int64_t idx2, 
 struct DagShared {
     unsigned long long slot[kDagWaves];  // per-wave residual bit patterns
     int verdict;
+    unsigned long long t_arrive;         // 100 MHz clock when this block published its granules
+    int skew_ticks;                      // how long after this block the LAST block arrived in the previous iteration (10 ns ticks)
+    // per wave: 128 16-byte units through which the lanes of a lane group / of a node's parent items hand each other the records
+    // they loaded -- one vector-memory instruction per lane and iteration instead of one per record and lane (a CU's eight waves
+    // share ONE texture-address pipe at 64 bytes per cycle: with every lane requesting all of its node's records that pipe,
+    // not the memory latency, set the length of the load phase -- 0.8 us for the first waves served, 2.6 us for the last)
+    double2_t xch[kDagWaves][2 * kWave];
 };
 enum : int { kDagGoOn = 0, kDagConverged = 1, kDagCapped = 2, kDagAbort = 3 };
 
@@ -70,6 +91,7 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, DagShared& sh, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have reached memory
     DSTAMP(4, it);
     __syncthreads();
+    DSTAMP(5, it);
     if (threadIdx.x == 0) {
         unsigned long long m = 0;
         for (int w = 0; w < kDagWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
@@ -79,16 +101,25 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, DagShared& sh, int 
         } else {
             // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
             // overwrite what a slower block still has to read
+            // Second granule: {arrival time, 16 bits of the 100 MHz clock | low 16 bits of the generation (enough to tell a torn
+            // pair: a slot is reused every second generation) | residual low half}.  The arrival times let every block predict
+            // WHEN the last block will arrive in the next iteration -- the work per iteration is static -- and place its first
+            // poll there instead of polling from its own arrival on: a poll is a ~1 us round trip, and one that leaves just
+            // before the last granule becomes visible costs the block a whole second trip (fixed delays, config 2: 7.5 -> 6.6 us
+            // per sweep).
             const unsigned gen = a.gen_base + unsigned(it) + 1u;
             unsigned long long* g = (it & 1) ? a.sync->blk_odd[blockIdx.x] : a.sync->blk[blockIdx.x];
+            const unsigned long long now = wall_clock64();
+            sh.t_arrive = now;
             __hip_atomic_store(g, ((unsigned long long)gen << 32) | unsigned(m >> 32), RLX_AGENT);
-            __hip_atomic_store(g + 1, ((unsigned long long)gen << 32) | unsigned(m), RLX_AGENT);
+            __hip_atomic_store(g + 1, ((now & 0xffffull) << 48) | ((unsigned long long)(gen & 0xffffu) << 32) | unsigned(m), RLX_AGENT);
         }
     }
 }
 
 // lane l requests the pairs of blocks l, l + 64, l + 128, l + 192 back to back (one round trip) -- bn_resident.hip sweep_granules
-__device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc) {
+__device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc,
+                                                   unsigned own16, int& late) {
     static_assert(kDagMaxBlocks == 4 * kWave, "four pairs per lane cover the table");
     const unsigned voff = unsigned(lane) * 16u;
     dag_u32x4 r0, r1, r2, r3;
@@ -103,11 +134,14 @@ __device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl
                      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
     bool mine = true;
     acc = 0;
-    auto take = [&](const dag_u32x4& r, int blk) {  // words: {residual high half, generation, residual low half, generation}
+    late = 0;
+    auto take = [&](const dag_u32x4& r, int blk) {  // words: {residual high half, generation, residual low half, arrival time << 16 | generation & 0xffff}
         if (blk < nb) {
-            mine = mine && r.y == gen && r.w == gen;
+            mine = mine && r.y == gen && (r.w & 0xffffu) == (gen & 0xffffu);
             const unsigned long long v = (unsigned long long)r.x << 32 | r.z;
             acc = v > acc ? v : acc;
+            const int d = int(short((r.w >> 16) - own16));   // that block's arrival after this one's, ticks (wraps every 655 us)
+            late = d > late ? d : late;
         }
     };
     take(r0, lane);
@@ -125,18 +159,28 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, DagShared& sh, int it)
         unsigned long long m = 0;
         bool ok = true;
         const unsigned long long t0 = wall_clock64();
+        // first poll: when the last block is expected to arrive (this block's arrival + the previous iteration's skew) + a margin
+        const unsigned long long t_arr = sh.t_arrive;
+        const unsigned own16 = unsigned(t_arr) & 0xffffu;
+        const unsigned long long first_at = t_arr + (unsigned long long)(sh.skew_ticks + a.first_poll_delay);
+        while (wall_clock64() < first_at) __builtin_amdgcn_s_sleep(1);
+        int late = 0;
         for (unsigned n = 1;; ++n) {
-            if (__all(dag_sweep_granules(tbl, lane, nb, gen, m)) != 0) break;
+            if (__all(dag_sweep_granules(tbl, lane, nb, gen, m, own16, late)) != 0) break;
             if ((n & 7u) == 0) {   // the abort word and the clock are round trips of their own: every 8th poll
                 if (__hip_atomic_load(&a.sync->abort, RLX_AGENT) != 0) { ok = false; break; }
                 if (wall_clock64() - t0 > a.timeout_ticks) {
-                    if (__all(dag_sweep_granules(tbl, lane, nb, gen, m)) != 0) break;
+                    if (__all(dag_sweep_granules(tbl, lane, nb, gen, m, own16, late)) != 0) break;
                     __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
                     ok = false;
                     break;
                 }
             }
-            __builtin_amdgcn_s_sleep(1);
+            for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+        }
+        {   // the latest arrival of this iteration, relative to this block's: the next iteration's prediction
+            const int mx = int(wave_umax32_dpp(unsigned(late)));   // (late >= 0)
+            if (lane == 0) sh.skew_ticks = ok ? (mx < 400 ? mx : 400) : 0;   // (bounded: 4 us)
         }
         m = wave_umax64_dpp(m);
         if (lane == 0) {
@@ -220,7 +264,7 @@ struct DagChildU {
             cpt[2 * q] = x.x; cpt[2 * q + 1] = x.y;
         }
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
         const bool first = s == 0;
         const int cur = s & 1, nxt = cur ^ 1;
         double pim[M > 0 ? M : 1][K], lold[M > 0 ? M : 1][K], lav[K], pold[K];
@@ -241,6 +285,7 @@ struct DagChildU {
             dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), lav);
             dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), pold);
         }
+        DSTAMP_INPUTS(a, s);
         // calculate_pi (:174-200): assignments ascending, cpt * pi-messages in ascending parent order;
         // calculate_lambda_k (:240-266): bucket out[jt][ct] receives, own state outer and assignment inner,
         // (lambda[i] * cpt) * the OTHER parents' pi-messages
@@ -304,6 +349,28 @@ struct DagChildU {
     }
 };
 
+// sum over the aligned group of G = 4, 16 or 64 lanes, left in every lane of the group: the pairing of an xor butterfly
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int G>
+__device__ __forceinline__ double group_allreduce(double x) {
+    x += dpp_mov_d<0xB1>(x);                       // quad_perm [1, 0, 3, 2]: lane ^ 1
+    x += dpp_mov_d<0x4E>(x);                       // quad_perm [2, 3, 0, 1]: lane ^ 2
+    if constexpr (G >= 16) {
+        x += dpp_mov_d<0x141>(x);                  // row_half_mirror: the other quad of the half row
+        x += dpp_mov_d<0x140>(x);                  // row_mirror: the other half row
+    }
+    if constexpr (G >= 64) {
+        x += shfl_xor_d(x, 16);
+        x += shfl_xor_d(x, 32);
+    }
+    return x;
+}
+
 // ---- child tile, M = D + 2 parents: G = 4^D lanes per node, lane g holds the 64 entries of one assignment of the D leading
 // parents.  The sums over the two trailing parents (states c, d) are formed ONCE per lane and shared by the five outputs:
 //   Q[c][d] = sum_i lambda(v)[i] P[c][d][i]       R[c][i] = sum_d P[c][d][i] piD[d]       S[i] = sum_c piC[c] R[c][i]
@@ -334,56 +401,74 @@ struct DagChildG {
             cpt[2 * q] = x.x; cpt[2 * q + 1] = x.y;
         }
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
         const bool first = s == 0;
         const int cur = s & 1, nxt = cur ^ 1;
-        double pim[M][K], lav[K], fold[K];
+        // The node's inputs -- its M pi-messages and lambda(v), 2 (M + 1) 16-byte halves -- are requested ONCE per group: lane g
+        // loads half g (and g + G where the group has fewer lanes than halves), the group shares them through the wave's scratch.
+        constexpr int HN = 2 * (M + 1), LPL = (HN + G - 1) / G;
+        static_assert(NPT * HN <= 2 * kWave, "the groups' halves fit the wave's scratch");
+        double fold[K];
 #pragma unroll
-        for (int j = 0; j < M; ++j)
+        for (int i = 0; i < K; ++i) fold[i] = 1.0;
+        double2_t mine[LPL];
 #pragma unroll
-            for (int i = 0; i < K; ++i) pim[j][i] = 1.0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) { lav[i] = 1.0; fold[i] = 1.0; }
-        if (!first) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) dag_ld4(rs, dag_off_pim(a.E, a.n, cur, ebase + j), pim[j]);
+        for (int q = 0; q < LPL; ++q) {
+            const int h = g + q * G;
+            mine[q].x = 1.0; mine[q].y = 1.0;
+            if (h < 2 * M) {
+                if (!first) mine[q] = dag_ld(rs, dag_off_pim(a.E, a.n, cur, ebase + (h >> 1)) + (h & 1));
+            } else if (h < HN) {
+                if (!first || frozen) mine[q] = dag_ld(rs, dag_off_nlam(a.E, a.n, cur, node) + (h - 2 * M));
+            }
         }
-        if (!first || frozen) dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), lav);
         // lane 0 of the group finishes pi(v), lane 1 + jt the lambda-message to parent jt: each requests the previous value
         // of ITS vector now (residual :105-131; an evidence node's pi is carried over, :177)
         const bool fin_msg = g >= 1 && g <= M;
         if (fin_msg && !first) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + g - 1), fold);
         if (g == 0 && frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), fold);
-
+        double2_t* xn = xch + nl * HN;
+#pragma unroll
+        for (int q = 0; q < LPL; ++q)
+            if (g + q * G < HN) xn[g + q * G] = mine[q];
+        lds_fence();
+        double pC[K], pD[K], lav[K];
+        {
+            const double2_t c0 = xn[2 * D], c1 = xn[2 * D + 1], d0 = xn[2 * D + 2], d1 = xn[2 * D + 3], l0 = xn[2 * M], l1 = xn[2 * M + 1];
+            pC[0] = c0.x; pC[1] = c0.y; pC[2] = c1.x; pC[3] = c1.y;
+            pD[0] = d0.x; pD[1] = d0.y; pD[2] = d1.x; pD[3] = d1.y;
+            lav[0] = l0.x; lav[1] = l0.y; lav[2] = l1.x; lav[3] = l1.y;
+        }
         double pfix[D > 0 ? D : 1];
 #pragma unroll
-        for (int j = 0; j < D; ++j) pfix[j] = pick4(pim[j], (g >> (2 * (D - 1 - j))) & 3);
-        const double (&pC)[K] = pim[D];
-        const double (&pD)[K] = pim[D + 1];
+        for (int j = 0; j < D; ++j)   // the entry of leading parent j's pi-message that the lane's digit j selects
+            pfix[j] = reinterpret_cast<const double*>(xn)[4 * j + ((g >> (2 * (D - 1 - j))) & 3)];
+        lds_fence();
+        DSTAMP_INPUTS(a, s);
         double S[K], LC[K], LD[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) { S[i] = 0.0; LD[i] = 0.0; }
 #pragma unroll
-        for (int c = 0; c < K; ++c) {
+        for (int c = 0; c < K; ++c) {   // (fused multiply-adds: this form is its own rounding anyway, see the struct's comment)
             double R[K], lc = 0.0;
 #pragma unroll
             for (int i = 0; i < K; ++i) R[i] = 0.0;
 #pragma unroll
             for (int d = 0; d < K; ++d) {
                 const double* e = &cpt[(c * K + d) * K];
-                const double q = (lav[0] * e[0] + lav[1] * e[1]) + (lav[2] * e[2] + lav[3] * e[3]);
+                const double q = __builtin_fma(lav[3], e[3], __builtin_fma(lav[2], e[2], __builtin_fma(lav[1], e[1], lav[0] * e[0])));
 #pragma unroll
-                for (int i = 0; i < K; ++i) R[i] += e[i] * pD[d];
-                lc += q * pD[d];
-                LD[d] += pC[c] * q;
+                for (int i = 0; i < K; ++i) R[i] = __builtin_fma(e[i], pD[d], R[i]);
+                lc = __builtin_fma(q, pD[d], lc);
+                LD[d] = __builtin_fma(pC[c], q, LD[d]);
             }
 #pragma unroll
-            for (int i = 0; i < K; ++i) S[i] += pC[c] * R[i];
+            for (int i = 0; i < K; ++i) S[i] = __builtin_fma(pC[c], R[i], S[i]);
             LC[c] = lc;
         }
         double L = 0.0;
 #pragma unroll
-        for (int c = 0; c < K; ++c) L += pC[c] * LC[c];
+        for (int c = 0; c < K; ++c) L = __builtin_fma(pC[c], LC[c], L);
         double w = 1.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) w *= pfix[j];
@@ -398,16 +483,17 @@ struct DagChildG {
                 if (j != jt) x *= pfix[j];
             sf[jt] = x;
         }
+        DSTAMP_AT(7, a, s);
         // ---- combine inside the G-lane group
+        // (xor butterflies; inside a 16-lane row as DPP moves -- quad_perm for 1 and 2, row_half_mirror and row_mirror for 4 and
+        // 8: after each step the lanes of a sub-group hold the same value, so the mirrored partner carries what the xor partner
+        // would: the same bits as __shfl_xor, without the LDS round trips)
 #pragma unroll
-        for (int mask = 1; mask < G; mask <<= 1) {
+        for (int i = 0; i < K; ++i) pp[i] = group_allreduce<G>(pp[i]);
 #pragma unroll
-            for (int i = 0; i < K; ++i) pp[i] += shfl_xor_d(pp[i], mask);
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int ct = 0; ct < K; ++ct) ol[t][ct] += shfl_xor_d(ol[t][ct], mask);
-        }
+            for (int ct = 0; ct < K; ++ct) ol[t][ct] = group_allreduce<G>(ol[t][ct]);
         // leading parent jt: sum over the lanes that share digit jt, then collect the four buckets from the lanes whose
         // other digits are zero
         double of[D > 0 ? D : 1][K];
@@ -423,6 +509,7 @@ struct DagChildG {
 #pragma unroll
             for (int ct = 0; ct < K; ++ct) of[jt][ct] = shfl_d(x, nl * G + (ct << (2 * (D - 1 - jt))));
         }
+        DSTAMP_AT(8, a, s);
         // ---- lanes 0 .. M of the group finish the node: normalise (:298-311), residual, stores
         double o[K];
 #pragma unroll
@@ -451,7 +538,7 @@ struct DagChildG {
     }
 };
 
-// ---- parent items: a lane per pi-message (:202-218) and per lambda(v) (:220-238); the product runs over the node's children
+// ---- parent items (kDagParentWide: nodes with more children than a wave has lanes): a lane per pi-message (:202-218) and per lambda(v) (:220-238); the product runs over the node's children
 // in ascending order, the target left out -- the reference's multiplication sequence
 struct DagParent {
     static constexpr int K = 4, RC = kDagRegChildren;
@@ -471,7 +558,7 @@ struct DagParent {
 #pragma unroll
         for (int x = 0; x < RC; ++x) oe[x] = (x < deg) ? a.oedge[obeg + x] : 0;
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
         const bool first = s == 0;
         const int cur = s & 1, nxt = cur ^ 1;
         const bool is_msg = tedge >= 0;
@@ -500,6 +587,7 @@ struct DagParent {
                     if (x < deg) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, oe[x]), lk[x]);
                 }
         }
+        DSTAMP_INPUTS(a, s);
 #pragma unroll
         for (int x = 0; x < RC; ++x)
             if (x < dmax) {
@@ -538,6 +626,83 @@ struct DagParent {
     }
 };
 
+// ---- the same with a node's c + 1 items in ADJACENT lanes of the wave (the planner's default: kDagParent).  Every lane loads ONE
+// record -- the lambda(v) item pi(v), the item of the pi-message to child r that child's lambda-message -- and the node's lanes
+// read each other's through the wave's scratch: 4 vector-memory instructions per lane and iteration whatever the child count.
+struct DagParentX {
+    static constexpr int K = 4;
+    int node, tedge, deg, tpos, first_lane, dmax, lane;
+    bool active, frozen;
+    __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane_) {
+        const DagParentLane it = a.pitem[t.lane_base + lane_];
+        lane = lane_;
+        active = it.node >= 0;
+        node = active ? it.node : 0;
+        tedge = active ? it.tedge : -1;
+        deg = active ? (it.deg_tpos & 0xffff) : 0;
+        tpos = active ? (it.deg_tpos >> 16) : -1;   // -1: the lambda(v) item, the first of its node's lanes
+        first_lane = lane - (tpos + 1);
+        dmax = t.dmax;
+        frozen = active && a.frz[node] == a.frz_mark;
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        const bool first = s == 0;
+        const int cur = s & 1, nxt = cur ^ 1;
+        const bool is_msg = tedge >= 0;
+        double rec[K], old[K], acc[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { rec[i] = 1.0; old[i] = 1.0; }
+        if (is_msg) {
+            if (!first) {
+                dag_ld4(rs, dag_off_lam(a.E, a.n, cur, tedge), rec);   // the lambda-message of this item's own child
+                dag_ld4(rs, dag_off_pim(a.E, a.n, cur, tedge), old);   // the previous pi-message, for the residual
+            }
+        } else {
+            // pi(v): the previous sweep's, or in sweep 0 the initial one (1.0, a root's CPT row, the evidence)
+            if (!first || frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), rec);
+            else if (active) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) rec[i] = a.npi_init[int64_t(node) * 4 + i];
+            }
+            if (frozen) dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), old);  // an evidence node's lambda is carried over (:223)
+        }
+        double2_t r0, r1;
+        r0.x = rec[0]; r0.y = rec[1]; r1.x = rec[2]; r1.y = rec[3];
+        xch[2 * lane] = r0;
+        xch[2 * lane + 1] = r1;
+        lds_fence();
+        DSTAMP_INPUTS(a, s);
+        {
+            const double2_t p0 = xch[2 * first_lane], p1 = xch[2 * first_lane + 1];
+            acc[0] = is_msg ? p0.x : 1.0; acc[1] = is_msg ? p0.y : 1.0; acc[2] = is_msg ? p1.x : 1.0; acc[3] = is_msg ? p1.y : 1.0;
+        }
+        for (int x = 0; x < dmax; ++x) {   // ascending children, the target left out (:207-214, :229-235); wave-uniform trip count
+            const int src = (x < deg) ? first_lane + 1 + x : lane;
+            const double2_t l0 = xch[2 * src], l1 = xch[2 * src + 1];
+            const bool use = x < deg && x != tpos;
+            acc[0] *= use ? l0.x : 1.0;   // x * 1.0 == x
+            acc[1] *= use ? l0.y : 1.0;
+            acc[2] *= use ? l1.x : 1.0;
+            acc[3] *= use ? l1.y : 1.0;
+        }
+        lds_fence();
+        normalize_k<K>(acc);
+        double wres = 0.0;
+        if (active) {
+            if (is_msg) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(acc[i] - old[i]));
+                dag_st4(rs, dag_off_pim(a.E, a.n, nxt, tedge), acc);
+            } else if (frozen) {
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), old);
+            } else {
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), acc);
+            }
+        }
+        return wres;
+    }
+};
+
 // one tile, whatever its kind: state set up, f(state) called
 template <class F>
 __device__ __forceinline__ void dag_with_tile(const DagArgs& a, const DagTile& t, int lane, F&& f) {
@@ -548,11 +713,13 @@ __device__ __forceinline__ void dag_with_tile(const DagArgs& a, const DagTile& t
         case 3: { DagChildG<1> st; st.init(a, t, lane); f(st); break; }
         case 4: { DagChildG<2> st; st.init(a, t, lane); f(st); break; }
         case 5: { DagChildG<3> st; st.init(a, t, lane); f(st); break; }
+        case kDagParent: { DagParentX st; st.init(a, t, lane); f(st); break; }
         default: { DagParent st; st.init(a, t, lane); f(st); break; }
     }
 }
 template <class T> struct dag_has_belief { static constexpr bool value = true; };
 template <> struct dag_has_belief<DagParent> { static constexpr bool value = false; };
+template <> struct dag_has_belief<DagParentX> { static constexpr bool value = false; };
 
 // STREAM = false: at most one tile per wave, its static state (CPT, ids, marks) in registers for the whole run.
 // STREAM = true: a wave walks its tiles [slot_ptr[slot], slot_ptr[slot + 1]) every iteration, setting each up again.
@@ -562,6 +729,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) a.host_ctl->t_first = wall_clock64();
+    if (threadIdx.x == 0) { sh.skew_ticks = 0; sh.t_arrive = 0; }
     const int slot = blockIdx.x * kDagWaves + wave;
     const int t0 = a.slot_ptr[slot], t1 = a.slot_ptr[slot + 1];
     const __amdgpu_buffer_rsrc_t rs =
@@ -575,7 +743,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
                            double w = 0.0;
                            for (int t = t0; t < t1; ++t) {
                                const DagTile td = a.tiles[t];
-                               dag_with_tile(a, td, lane, [&](auto& st) { w = res_acc(w, st.sweep(a, rs, s)); });
+                               dag_with_tile(a, td, lane, [&](auto& st) { w = res_acc(w, st.sweep(a, rs, s, sh.xch[wave])); });
                            }
                            return w;
                        },
@@ -583,7 +751,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
                            if (done == 0) return;
                            for (int t = t0; t < t1; ++t) {
                                const DagTile td = a.tiles[t];
-                               if (td.kind == kDagParent) continue;
+                               if (td.kind >= kDagParent) continue;
                                dag_with_tile(a, td, lane, [&](auto& st) {
                                    if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) st.belief(a, rs, n);
                                });
@@ -592,7 +760,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     } else {
         const DagTile td = a.tiles[t0];
         dag_with_tile(a, td, lane, [&](auto& st) {
-            ok = dag_drive(a, sh, lane, wave, [&](int s) { return st.sweep(a, rs, s); },
+            ok = dag_drive(a, sh, lane, wave, [&](int s) { return st.sweep(a, rs, s, sh.xch[wave]); },
                            [&](int n, int done) {
                                if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) {
                                    if (done != 0) st.belief(a, rs, n);
@@ -645,6 +813,6 @@ int launch_dag_evidence(const DagEvidenceArgs& a, void* stream_handle) {
 #ifdef BN_TILE_CLOCK
 extern "C" int bn_debug_dag_clock(unsigned long long* out, int n_waves) {
     if (n_waves > bnmi::kDagMaxBlocks * bnmi::kDagWaves) n_waves = bnmi::kDagMaxBlocks * bnmi::kDagWaves;
-    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_dag_clock), sizeof(unsigned long long) * 8 * n_waves));
+    return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnmi::g_dag_clock), sizeof(unsigned long long) * 12 * n_waves));
 }
 #endif

@@ -35,11 +35,12 @@ constexpr int kDagBudget = kResidentBudget;        // iterations per launch (Res
 constexpr int kDagMaxParents = 5;
 constexpr int kDagRegChildren = 8;      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
 
-enum : int32_t { kDagChild0 = 0, /* 1..5: child tile of nodes with that many parents */ kDagParent = 8 };
+enum : int32_t { kDagChild0 = 0, /* 1..5: child tile of nodes with that many parents */ kDagParent = 8, kDagParentWide = 9 };
 
 // One wavefront of work.  32 bytes.
 struct DagTile {
-    int32_t kind;       // 0..5: child tile, nodes with `kind` parents; kDagParent: 64 parent items
+    int32_t kind;       // 0..5: child tile, nodes with `kind` parents; kDagParent: parent items, a node's in adjacent lanes of this wave;
+                        // kDagParentWide: items of nodes with more than 63 children
     int32_t n_active;   // nodes (child tile) / items (parent tile) in use
     int32_t lane_base;  // first entry of the tile in the per-lane tables (cnode / pitem): 64 per tile
     int32_t cpt_base;   // child tile: first double2 of its CPT image; entry pair q of lane l at cpt_base + q * 64 + l
@@ -60,6 +61,7 @@ struct DagPlan {
     std::vector<int32_t> slot_ptr;         // [blocks * kDagWaves + 1]; slot = block * kDagWaves + wave
     int32_t blocks = 0;
     bool stream = false;                   // some wave walks more than one tile per iteration
+    bool has_groups = false;               // some node has 3..5 parents (lane-group tiles)
     std::vector<DagChildLane> cnode;       // [n_tiles * 64] (child tiles' entries)
     std::vector<DagParentLane> pitem;      // [n_tiles * 64] (parent tiles' entries)
     std::vector<int32_t> oedge;            // out-edges (CSR edge ids) of every node, children ascending
@@ -91,6 +93,8 @@ struct DagArgs {
     double* state;            // pi-messages [2][E][4], lambda-messages [2][E][4], pi(v) [2][n][4], lambda(v) [2][n][4]
     const uint8_t* frz;       // [n] evidence marks: observed when == frz_mark
     uint8_t frz_mark;
+    int32_t poll_sleep;       // pause between two polls of the barrier, x 64 cycles
+    int32_t first_poll_delay; // ... and between a block's arrival and its first poll
 };
 struct DagEvidenceArgs {
     int32_t ne, n, E;

@@ -2,7 +2,9 @@
 #include "bn_dag.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <numeric>
+#include <queue>
 
 namespace bnmi {
 
@@ -18,7 +20,7 @@ inline double cost_of(const DagTile& t) {
         case 3: return 0.90;
         case 4: return 1.00;
         case 5: return 1.10;
-        default: return 0.20 + 0.04 * t.dmax;
+        default: return 0.25 + 0.03 * t.dmax;   // parent items
     }
 }
 }  // namespace
@@ -102,51 +104,74 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
         }
     }
     dp.n_child_tiles = int32_t(tiles.size());
+    for (const DagTile& t : tiles) dp.has_groups = dp.has_groups || t.kind >= 3;
     {
+        // Parent items, nodes in order of their child count.  The c + 1 items of a node (lambda(v), then the pi-message to each
+        // child in ascending order) sit in ADJACENT lanes of ONE wave: every lane loads one record -- pi(v), or the lambda-message
+        // of its own child -- and the node's lanes exchange them through the wave's LDS scratch (kDagParent).  A node with more
+        // than 63 children does not fit a wave: its items load every record themselves (kDagParentWide).
         std::vector<int32_t> order(n);
         std::iota(order.begin(), order.end(), 0);
         std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
             return out_ptr[a + 1] - out_ptr[a] < out_ptr[b + 1] - out_ptr[b];
         });
         int fill = kWave;
-        DagTile* cur = nullptr;
-        auto push = [&](const DagParentLane& it) {
-            if (fill == kWave) { cur = &new_tile(kDagParent); fill = 0; }
-            pitem[size_t(cur->lane_base) + fill++] = it;
-            cur->n_active = fill;
-            cur->dmax = std::max(cur->dmax, it.deg_tpos & 0xffff);
+        int32_t cur = -1, cur_kind = -1;
+        auto push = [&](int32_t kind, const DagParentLane& it) {
+            if (fill == kWave || kind != cur_kind) { new_tile(kind); cur = int32_t(tiles.size()) - 1; cur_kind = kind; fill = 0; }
+            pitem[size_t(tiles[cur].lane_base) + fill++] = it;
+            tiles[cur].n_active = fill;
+            tiles[cur].dmax = std::max(tiles[cur].dmax, it.deg_tpos & 0xffff);
         };
         for (int32_t u : order) {
             const int32_t deg = out_ptr[u + 1] - out_ptr[u];
-            push(DagParentLane{u, -1, out_ptr[u], int32_t(uint32_t(deg) | 0xffff0000u)});   // lambda(v): no child is skipped
-            for (int32_t r = 0; r < deg; ++r) push(DagParentLane{u, dp.oedge[out_ptr[u] + r], out_ptr[u], deg | (r << 16)});
+            const int32_t kind = deg + 1 <= kWave ? kDagParent : kDagParentWide;
+            if (kind == kDagParent && fill + deg + 1 > kWave) fill = kWave;   // the node would straddle two waves: start a new one
+            push(kind, DagParentLane{u, -1, out_ptr[u], int32_t(uint32_t(deg) | 0xffff0000u)});   // lambda(v): no child is skipped
+            for (int32_t r = 0; r < deg; ++r) push(kind, DagParentLane{u, dp.oedge[out_ptr[u] + r], out_ptr[u], deg | (r << 16)});
         }
     }
     dp.n_parent_tiles = int32_t(tiles.size()) - dp.n_child_tiles;
 
-    // ---- wave slots.  One block per CU, kDagWaves waves: waves w and w + 4 share a SIMD.  Tiles in order of decreasing
-    // cost go to the slots wave-major (every block's wave 0, then every block's wave 1, ...), alternate passes reversed:
-    // every SIMD gets one of the heaviest tiles before any gets a second, and the light ones fill up beside them.
+    // ---- wave slots.  One block per CU, kDagWaves waves: waves w and w + 4 share a SIMD.  Blocks: enough for every SIMD's load
+    // to stay near ONE heavy tile's (the iteration's critical path is the slowest SIMD), at most cap_blocks.
     const int64_t total = int64_t(tiles.size());
-    int64_t heavy = 0;
-    for (const DagTile& t : tiles) heavy += t.kind >= 2 && t.kind <= kDagMaxParents;
-    int64_t want = std::max((total + kDagWaves - 1) / kDagWaves, (heavy + 3) / 4);
+    double cost_sum = 0.0;
+    for (const DagTile& t : tiles) cost_sum += cost_of(t);
+    int64_t want = std::max<int64_t>((total + kDagWaves - 1) / kDagWaves, int64_t(cost_sum / 0.9 / 4.0) + 1);
     want = (std::max<int64_t>(want, 1) + 7) & ~int64_t(7);
     if (total <= kDagWaves) want = 1;   // one block: no grid barrier at all
     const int32_t nb = int32_t(std::min<int64_t>(want, cap_blocks));
     const int32_t slots = nb * kDagWaves;
     dp.blocks = nb;
     dp.stream = total > slots;
+    // Longest-processing-time-first: tiles in order of decreasing cost, each to the least loaded SIMD that still has a free wave
+    // (two per SIMD; stream form: to the least loaded wave).  SIMDs are numbered SIMD-major (SIMD 0 of every block, then SIMD 1
+    // of every block, ...), so that the heavy tiles -- placed first, onto empty SIMDs -- spread over all blocks' CUs.
     std::vector<int32_t> by_cost(tiles.size());
     std::iota(by_cost.begin(), by_cost.end(), 0);
     std::stable_sort(by_cost.begin(), by_cost.end(), [&](int32_t a, int32_t b) { return cost_of(tiles[a]) > cost_of(tiles[b]); });
     std::vector<std::vector<int32_t>> of_slot(slots);
-    for (size_t i = 0; i < by_cost.size(); ++i) {
-        const int64_t pass = int64_t(i) / slots, at = int64_t(i) % slots;
-        const int64_t pos = (pass & 1) ? slots - 1 - at : at;           // wave-major position
-        const int32_t w = int32_t(pos / nb), bq = int32_t(pos % nb);
-        const int32_t blk = (w & 1) ? nb - 1 - bq : bq;
-        of_slot[size_t(blk) * kDagWaves + w].push_back(by_cost[i]);
+    {
+        typedef std::pair<double, int32_t> Bin;   // (load, bin)
+        std::priority_queue<Bin, std::vector<Bin>, std::greater<Bin>> pq;
+        const int32_t nbins = dp.stream ? slots : nb * 4;
+        std::vector<int32_t> used(nbins, 0);
+        for (int32_t q = 0; q < nbins; ++q) pq.push(Bin(0.0, q));
+        for (int32_t t : by_cost) {
+            const Bin top = pq.top();
+            pq.pop();
+            const int32_t q = top.second;
+            int32_t slot;
+            if (dp.stream) {   // bin = wave: wave w of every block, then wave w + 1, ...
+                slot = (q % nb) * kDagWaves + q / nb;
+                pq.push(Bin(top.first + cost_of(tiles[t]), q));
+            } else {           // bin = SIMD: its first wave, then the one four further
+                slot = (q % nb) * kDagWaves + q / nb + 4 * used[q];
+                if (++used[q] < kDagWaves / 4) pq.push(Bin(top.first + cost_of(tiles[t]), q));
+            }
+            of_slot[slot].push_back(t);
+        }
     }
     dp.slot_ptr.assign(size_t(slots) + 1, 0);
     dp.tiles.reserve(tiles.size());

@@ -188,6 +188,7 @@ struct ResidentArgs {
     int32_t poll_sleep;               // pause between two polls of a waiting tile, in units of s_sleep(8) = 512 cycles
     unsigned* host_abort;             // pinned: set by whoever gives up a bounded wait
     int32_t direct;                   // grid-barrier form, one evidence set: every tile block reads all blocks' granules itself (no service block)
+    int32_t first_poll_delay;         // direct form: margin, in 10 ns ticks, between the predicted arrival of the last block and a block's first poll
 };
 int launch_bp_resident(const ResidentArgs& a, int grid_blocks, int lean_k, void* stream);  // a.flow != nullptr: the dataflow form  // lean_k: uniform arity with <= 2 children per node, else 0
 

@@ -159,6 +159,7 @@ struct bn_engine {
     int resident_lean = 0;          // ... and every node has this arity (2, 3 or 4) and <= 2 children; else 0
     int grid_resident = 0;
     int resident_waves = kResidentWaves;  // tiles per block of the resident kernel (8, or 4 on networks small enough)
+    int resident_poll_margin = 30;  // direct form: 10 ns ticks between the predicted arrival of the last block and a block's first poll (BN_RESIDENT_DELAY)
     int resident_direct = 1;        // option "direct" / BN_RESIDENT_DIRECT: the grid barrier without a service block (bn_resident.hip wait_verdict);
                                     // measured against the service block, us per sweep: 32 x 32 grid 6.98 -> 6.46, 128 x 128 7.25 -> 6.80, 316 x 316 11.46 -> 11.04
     ResidentSync* d_rsync = nullptr;
@@ -563,6 +564,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             }
             if (const char* f = std::getenv("BN_RESIDENT_FLOW")) e->flow = std::atoi(f) != 0;
             if (const char* f = std::getenv("BN_RESIDENT_DIRECT")) e->resident_direct = std::atoi(f) != 0;
+            if (const char* f = std::getenv("BN_RESIDENT_DELAY")) e->resident_poll_margin = std::max(-1, std::min(std::atoi(f), 1000));
             if (const char* z = std::getenv("BN_POLL_SLEEP")) e->poll_sleep = std::max(0, std::min(std::atoi(z), 64));
         }
         {
@@ -631,7 +633,8 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             e->mid_ok = true;
         }
         if (e->dag.ok) {
-            const int32_t cap = int32_t((int64_t(e->n_cus) * 9 / 10) & ~int64_t(7));
+            int32_t cap = int32_t((int64_t(e->n_cus) * 9 / 10) & ~int64_t(7));
+            if (const char* c = std::getenv("BN_DAG_CAP")) cap = std::max(8, std::min(cap, std::atoi(c) & ~7));   // experiments: fewer blocks
             if (cap != kDagDefaultCap) build_dag_plan(p, cap, e->dag);
         }
         if (e->dag.ok) {
@@ -954,7 +957,7 @@ static int run_resident(bn_engine* e, double eps, int32_t max_sweeps, double* co
                        shard ? 200000000ull : 5000000ull, e->d_rsync, e->h_ctl_dev,
                        e->grid_resident, e->resident_waves, 1, 1u, 0, 0, 0, 0, 0, flow ? e->d_flow : nullptr,
                        shard ? e->d_peers : nullptr, shard ? e->d_pub_mask : nullptr, shard ? e->plan.n_interior_tiles : 0,
-                       e->d_nbr, e->plan.nbr_chunks, e->poll_sleep, e->h_abort_dev, (!flow && !shard) ? e->resident_direct : 0};
+                       e->d_nbr, e->plan.nbr_chunks, e->poll_sleep, e->h_abort_dev, (!flow && !shard) ? e->resident_direct : 0, e->resident_poll_margin};
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -1162,7 +1165,13 @@ static int run_mid(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
 static bool dag_applies(const bn_engine* e) {
     if (!e->dag_ok || e->multisweep == 0 || e->dag_mode == 0) return false;
     if (e->dag_mode == 2) return true;
-    return !e->small_ok && !e->resident_ok && !mid_applies(e);
+    if (e->small_ok) return false;   // one workgroup with the state in LDS
+    // Networks with lane-group tiles (some node has 3-5 parents), measured us per sweep, this path / the item kernels over several
+    // workgroups / per-sweep launches (scripts/time_dag.py): 300 nodes 4.4 / 7.5 / 8.7, 1 000 nodes 4.8 / 10.3 / 9.4, 3 000 nodes
+    // 5.8 / - / 9.6, 10 000 nodes (BASELINE configs[1]) 6.6 / - / 12.0.  Networks of nodes with at most two parents keep the
+    // resident tiles / item kernels where those apply (both bit-identical to the reference there, like this path).
+    if (e->dag.has_groups) return true;
+    return !e->dag.stream && !e->resident_ok && !mid_applies(e);   // (large networks of <= 2 parents: the per-sweep kernels stream their CPTs at 60-70 % of the HBM peak)
 }
 
 // The evidence in force (staging block) -> the state arrays of the DAG path: marks of this set's own value, vectors in both buffers.
@@ -1208,6 +1217,10 @@ static int run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
         a.n = dp.n; a.E = dp.E; a.n_blocks = dp.blocks;
         a.tiles = e->d_g_tiles; a.slot_ptr = e->d_g_slotptr; a.cnode = e->d_g_cnode; a.pitem = e->d_g_pitem; a.oedge = e->d_g_oedge;
         a.cpt_img = e->d_g_cpt; a.npi_init = e->d_g_init; a.state = e->d_g_state; a.frz = e->d_g_frz; a.frz_mark = e->dag_mark;
+        static const int poll_sleep = std::getenv("BN_DAG_SLEEP") ? std::atoi(std::getenv("BN_DAG_SLEEP")) : 1;
+        a.poll_sleep = poll_sleep;
+        static const int first_delay = std::getenv("BN_DAG_DELAY") ? std::atoi(std::getenv("BN_DAG_DELAY")) : 30;   // 10 ns ticks: measured flat from 20 to 60 (config 2: 6.9 us per sweep at 0, 6.5-6.6 there)
+        a.first_poll_delay = first_delay;
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -1296,7 +1309,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] register-resident DAG kernel aborted (%s); other paths for the next 64 runs\n", g_err.c_str());
         return BN_ERR_STATE;
     };
-    if (e->dag_mode == 2 && (rc = attempt_dag()) != BN_ERR_STATE) return rc;
+    if (e->dag_mode == 2 && (rc = attempt_dag()) != BN_ERR_STATE) return rc;   // forced: ahead of the one-workgroup path too
     const bool small_pays = !(e->resident_ok && e->grid_resident == 1) ||
                             (e->small.rb == 1 && e->small.rc == 1 && (e->small.mmax >= 2 || (e->small.re == 1 && e->small.n <= 128)));
     if (e->small_ok && e->multisweep != 0 && (e->small_mode == 2 || (e->small_mode == 1 && small_pays))) {
@@ -1306,6 +1319,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         if (residual_out) *residual_out = e->last_ctl.last_res;
         return BN_OK;
     }
+    if ((rc = attempt_dag()) != BN_ERR_STATE) return rc;
     // networks beyond one workgroup's LDS that the resident tiles do not cover: the same items over several workgroups (bn_mid.hip)
     const bool try_mid = mid_applies(e);
     if (try_mid && e->mid_cooldown > 0) --e->mid_cooldown;
@@ -1322,7 +1336,6 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         e->mid_cooldown = 64;   // something else holds CUs: the tile kernels for a while
         if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] mid-size kernel aborted (%s); tile kernels for the next 64 runs\n", g_err.c_str());
     }
-    if ((rc = attempt_dag()) != BN_ERR_STATE) return rc;
     if ((rc = flush_evidence(e))) return rc;  // the tile kernels read the evidence from their own buffers
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
     else if (try_resident) {
@@ -1518,6 +1531,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
     if (!e->plan.latency_rules_applied || e->plan.nranks > 1 || n_sets < 2) return nullptr;
     if (e->small_ok && e->small_mode != 0 && e->multisweep != 0) return nullptr;  // one workgroup per set (bn_small.hip): the layout plays no part
     if (mid_applies(e)) return nullptr;                                           // ... or a few per set (bn_mid.hip)
+    if (dag_applies(e)) return nullptr;                                           // ... or the register-resident DAG path, set by set (bn_dag.hip)
     if (!e->dense) {
         const Plan& p = e->plan;
         bn_model_desc d;
@@ -1621,7 +1635,7 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     bt.ev_node_at = node_at; bt.ev_off_at = off_at; bt.ev_val_at = val_at;
     bt.ev_deferred = true;
     bt.beliefs_on_host = false;
-    if (e->small_ok || e->mid_ok) {
+    if (e->small_ok || e->mid_ok || dag_applies(e)) {
         // Small networks: the block is page-locked host memory that the kernels read in place -- the one-workgroup kernel (one
         // workgroup per set) each set's arrays, no copy command, no evidence launch per set, no synchronisation here; the tile
         // buffers get the marks and vectors only if another path runs the batch (flush_batch_evidence).  (No kernel is in
@@ -1918,6 +1932,53 @@ static int run_batch_mid(bn_engine* e, double eps, int32_t max_sweeps) {
     return BN_OK;
 }
 
+// The register-resident DAG path (bn_dag.hip) answers a batch one set after another: every set is a single query's launch -- the
+// same kernel, the same bits -- reading its evidence from the batch's staging block and writing its marginals and residual history
+// into the set's slots.  BN_ERR_STATE: a grid wait gave up.
+static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
+    bn_engine::Batch& bt = e->batch;
+    const Plan& p = e->plan;
+    const int32_t keep_ne = e->ev_ne;
+    int32_t* const keep_node = e->d_ev_node;
+    int32_t* const keep_off = e->d_ev_off;
+    double* const keep_val = e->d_ev_val;
+    double* const keep_override = e->beliefs_override;
+    int rc = BN_OK;
+    int32_t launches = 0, max_sw = 0;
+    double dev_ms = 0.0;
+    for (int32_t q = 0; q < bt.n_sets && rc == BN_OK; ++q) {
+        e->ev_ne = bt.ne[q];
+        e->d_ev_node = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[q];
+        e->d_ev_off = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[q];
+        e->d_ev_val = reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[q];
+        e->dag_ev_applied = false;
+        e->beliefs_override = bt.d_beliefs + size_t(q) * p.node_off[p.n];
+        rc = run_dag(e, eps, max_sweeps, nullptr);
+        if (rc != BN_OK) break;
+        bt.sweeps[q] = e->last_ctl.n_sweeps;
+        bt.residual[q] = e->last_ctl.last_res;
+        const int32_t cnt = std::min(e->last_ctl.n_sweeps, e->res_cap);
+        if (cnt > 0)
+            HIPCHK(hipMemcpyAsync(bt.d_res_hist + size_t(q) * e->res_cap, e->d_res_hist, sizeof(double) * cnt, hipMemcpyDeviceToDevice, e->stream));
+        launches += e->stats.sweep_launches;
+        dev_ms += e->stats.sweep_devclock_ms;
+        max_sw = std::max(max_sw, e->last_ctl.n_sweeps);
+    }
+    // the single-query evidence in force is what the engine's own staging block holds: applied again at its next run
+    e->ev_ne = keep_ne; e->d_ev_node = keep_node; e->d_ev_off = keep_off; e->d_ev_val = keep_val;
+    e->dag_ev_applied = false;
+    e->beliefs_override = keep_override;
+    if (rc != BN_OK) return rc;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    bt.predicted_sweeps = max_sw;
+    e->last_path = 5;
+    e->stats.sweep_launches = launches;
+    e->stats.sweep_kernel_ms = 0.f;
+    e->stats.sweep_devclock_ms = float(dev_ms);
+    e->stats.sweeps = max_sw;
+    return BN_OK;
+}
+
 extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->batch_on_dense && e->dense) {
@@ -1948,6 +2009,27 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
     const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
     const bool batch_small = e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state != nullptr;
+    bool batch_dag = !batch_small && dag_applies(e) && bt.ev_base != nullptr && e->plan.nranks == 1;
+    if (batch_dag && e->dag_cooldown > 0) { --e->dag_cooldown; batch_dag = false; }
+    if (batch_dag) {
+        rc = run_batch_dag(e, eps, max_sweeps);
+        if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
+        if (rc == BN_ERR_STATE) {   // a grid wait gave up: the whole batch again on the other paths
+            ++e->dag_aborts;
+            e->dag_cooldown = 64;
+            batch_dag = false;
+            bt.sweeps.assign(bt.n_sets, 0);
+            bt.residual.assign(bt.n_sets, 0.0);
+        } else {
+            bt.have_run = true;
+            e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+            for (int32_t q = 0; q < bt.n_sets; ++q) {
+                if (sweeps_out) sweeps_out[q] = bt.sweeps[q];
+                if (residual_out) residual_out[q] = bt.residual[q];
+            }
+            return BN_OK;
+        }
+    }
     bool batch_mid = !batch_small && mid_applies(e) && bt.ev_base != nullptr;
     if (batch_mid && e->mid_cooldown > 0) { --e->mid_cooldown; batch_mid = false; }
     if (batch_mid) {

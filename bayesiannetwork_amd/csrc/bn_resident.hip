@@ -85,6 +85,8 @@ __device__ __forceinline__ void pin_here(double& x) { asm volatile("" : "+v"(x))
 struct BlockShared {
     unsigned long long slot[kResidentMaxSets][kResidentWaves];  // per-set, per-wave residual bit patterns
     int verdict[kResidentMaxSets];                              // of a set's last barrier: kGoOn / kConverged / kCapped / kAbort
+    unsigned long long t_arrive;                                // direct form: 100 MHz clock when this block published its granules
+    int skew_ticks;                                             // ... and how long after this block the LAST block arrived in the previous iteration
 };
 enum : int { kGoOn = 0, kConverged = 1, kCapped = 2, kAbort = 3 };
 
@@ -144,8 +146,15 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
             // direct form: the granules of consecutive iterations alternate between two tables -- a block that is already past
             // this barrier must not overwrite what a slower block still has to read
             unsigned long long* g = (a.direct != 0 && (it & 1)) ? sy->blk_odd[blockIdx.x] : sy->blk[blockIdx.x];
+            // Second granule: {arrival time: 16 bits of the 100 MHz clock | low 16 bits of the generation (tells a torn pair: a slot
+            // is reused every second generation at the earliest) | residual low half}.  The work per iteration is static, so the
+            // arrival times of one iteration predict when the LAST block arrives in the next: a collecting wave places its first
+            // poll there instead of polling from its own arrival on -- a poll is a ~1 us round trip, and one that leaves just before
+            // the last granule becomes visible costs the block a whole second trip (round 4).
+            const unsigned long long now = wall_clock64();
+            sh.t_arrive = now;
             __hip_atomic_store(g, granule(gen, unsigned(m >> 32)), RLX_AGENT);
-            __hip_atomic_store(g + 1, granule(gen, unsigned(m)), RLX_AGENT);
+            __hip_atomic_store(g + 1, ((now & 0xffffull) << 48) | ((unsigned long long)(gen & 0xffffu) << 32) | unsigned(m), RLX_AGENT);
         }
     }
 }
@@ -176,7 +185,8 @@ __device__ __forceinline__ bool poll_until(const ResidentArgs& a, Pred&& pred) {
 // to arrive is seen one whole sweep later (headline query 0.139 -> 0.130 ms).  Generation and value come with the same load; a
 // pair may be torn between its halves, each of which carries its own generation.  Slots of blocks >= nb lie inside the table,
 // are never written and are ignored.  Returns whether every block of this lane carries `gen`; acc = maximum of their values.
-__device__ __forceinline__ bool sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc) {
+__device__ __forceinline__ bool sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc,
+                                               unsigned own16 = 0u, int* late_out = nullptr) {
     static_assert(kResidentMaxBlocks == 4 * kWave, "four pairs per lane cover the table");
     const unsigned voff = unsigned(lane) * 16u;
     u32x4 r0, r1, r2, r3;
@@ -191,15 +201,19 @@ __device__ __forceinline__ bool sweep_granules(const unsigned long long* tbl, in
                      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
     bool mine = true;
     acc = 0;
-    auto take = [&](const u32x4& r, int blk) {  // words: {residual high half, generation, residual low half, generation}
+    int late = 0;
+    auto take = [&](const u32x4& r, int blk) {  // words: {residual high half, generation, residual low half, arrival time << 16 | generation & 0xffff}
         if (blk < nb) {
-            mine = mine && r.y == gen && r.w == gen;
+            mine = mine && r.y == gen && (r.w & 0xffffu) == (gen & 0xffffu);
             const unsigned long long v = (unsigned long long)r.x << 32 | r.z;
             acc = v > acc ? v : acc;
+            const int d = int(short((r.w >> 16) - own16));   // that block's arrival after this one's, 10 ns ticks
+            late = d > late ? d : late;
         }
     };
     take(r0, lane);
     if (nb > kWave) { take(r1, lane + kWave); take(r2, lane + 2 * kWave); take(r3, lane + 3 * kWave); }
+    if (late_out) *late_out = late;
     return mine;
 }
 
@@ -219,8 +233,22 @@ __device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& 
             const int nb = a.n_tile_blocks;
             const unsigned long long* tbl = (it & 1) ? &sy->blk_odd[0][0] : &sy->blk[0][0];
             unsigned long long m = 0;
-            const bool ok = poll_until(a, [&] { return __all(sweep_granules(tbl, lane, nb, gen, m)) != 0; });
+            // first poll: when the last block is expected to arrive (this block's arrival + the previous iteration's skew) + a margin
+            const unsigned long long t_arr = sh.t_arrive;
+            const unsigned own16 = unsigned(t_arr) & 0xffffu;
+            if (a.first_poll_delay >= 0) {   // (negative: poll from this block's own arrival on)
+                const unsigned long long first_at = t_arr + (unsigned long long)(sh.skew_ticks + a.first_poll_delay);
+                while (wall_clock64() < first_at) __builtin_amdgcn_s_sleep(1);
+            }
+            int late = 0;
+            const bool ok = poll_until(a, [&] { return __all(sweep_granules(tbl, lane, nb, gen, m, own16, &late)) != 0; });
             m = wave_umax(m);
+            {
+                int mx = late;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mx, off, kWave); mx = o > mx ? o : mx; }
+                if (lane == 0) sh.skew_ticks = ok ? (mx < 400 ? mx : 400) : 0;
+            }
             if (lane == 0) {
                 if (blockIdx.x == 0 && ok) __hip_atomic_store(&sy->res[it], m, RLX_AGENT);   // the residual history (read back by this block)
                 sh.verdict[set] = ok ? verdict_of(a, residual_of(m), a.sweep_begin + it + 1) : kAbort;
@@ -1032,6 +1060,7 @@ __global__ __launch_bounds__(WMAX * kWave, WMAX == kResidentWaves ? 2 : 1) void 
     const BpBuffers& b = a.b;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) { sh.t_arrive = 0; sh.skew_ticks = 0; }
     if constexpr (!FLOW) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {  // written now rather than kept in registers for the whole run
             const unsigned long long t_first = wall_clock64();

@@ -217,6 +217,47 @@ def _parent(plan, st, tile, s):
     return md
 
 
+def _parent_packed(plan, st, tile, s):
+    """kDagParent: a node's c + 1 items in adjacent lanes; every lane loads ONE record, the node's lanes read each other's"""
+    first = s == 0
+    cur, nxt = s & 1, (s & 1) ^ 1
+    it = plan["pitem"][int(tile[2]):int(tile[2]) + 64]
+    active = it[:, 0] >= 0
+    node = np.where(active, it[:, 0], 0)
+    tedge = np.where(active, it[:, 1], -1)
+    deg = np.where(active, it[:, 3] & 0xffff, 0)
+    tpos = np.where(active, it[:, 3] >> 16, -1)
+    first_lane = LANES - (tpos + 1)
+    dmax = int(tile[4])
+    frozen = active & st.frz[node]
+    is_msg = tedge >= 0
+    rec = np.ones((64, K))
+    old = np.ones((64, K))
+    if not first:
+        rec[is_msg] = st.lam[cur, tedge[is_msg]]
+        old[is_msg] = st.pim[cur, tedge[is_msg]]
+    a = ~is_msg & (np.full(64, not first) | frozen)
+    rec[a] = st.npi[cur, node[a]]
+    b = ~is_msg & ~a & active
+    rec[b] = plan["npi_init"][node[b]]
+    c = ~is_msg & frozen
+    old[c] = st.nlam[cur, node[c]]
+    assert (first_lane >= 0).all() and (first_lane[active] + deg[active] <= 63).all()
+    acc = np.where(is_msg[:, None], rec[first_lane], 1.0)
+    for x in range(dmax):
+        src = np.where(x < deg, first_lane + 1 + x, LANES)
+        use = (x < deg) & (x != tpos)
+        acc = acc * np.where(use[:, None], rec[src], 1.0)
+    acc = _norm(acc)
+    md = 0.0
+    m = active & is_msg
+    md = _resmax(md, np.abs(acc - old)[m].ravel())
+    st.pim[nxt, tedge[m]] = acc[m]
+    nm = active & ~is_msg
+    st.nlam[nxt, node[nm]] = np.where(frozen[nm, None], old[nm], acc[nm])
+    return md
+
+
 def emulate(plan, model, evidence, eps, max_sweeps=0):
     n, E = plan["n"], plan["E"]
     st = _State(n, E)
@@ -237,6 +278,8 @@ def emulate(plan, model, evidence, eps, max_sweeps=0):
                 md = max(md, _child_u(plan, st, t, kind, s))
             elif kind <= 5:
                 md = max(md, _child_g(plan, st, t, kind - 2, s))
+            elif kind == 8:
+                md = max(md, _parent_packed(plan, st, t, s))
             else:
                 md = max(md, _parent(plan, st, t, s))
         md = max(md, tiny)

@@ -51,3 +51,17 @@ def margin_ok(residuals, eps, ulp=1e-13):
     sweep cannot flip on last-bit differences ('stopping at the same sweep')."""
     r = np.asarray(residuals, float)
     return bool((np.abs(r - eps) > ulp * max(eps, 1e-300)).all())
+
+
+def hub_network(n_children, seed=77):
+    """k = 4: one node with `n_children` children, each of which has one more parent of its own (a root)"""
+    from bayesiannetwork_amd import from_parent_lists
+    from bayesiannetwork_amd.synth import uniform01
+    parents = [[]] + [[] for _ in range(n_children)] + [[0, 1 + c] for c in range(n_children)]
+    cpts, at = [], 0
+    for ps in parents:
+        rows = 4 ** len(ps)
+        r = 0.1 + 0.9 * uniform01(seed, at, rows * 4).reshape(rows, 4)
+        at += rows * 4
+        cpts.append((r / r.sum(axis=1, keepdims=True)).ravel().tolist())
+    return from_parent_lists(k=[4] * len(parents), parents=parents, cpts=cpts, name=f"hub{n_children}")

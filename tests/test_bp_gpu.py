@@ -89,6 +89,10 @@ def _vs_oracle(Engine, oracle_mod, model, ev, eps, exact):
             # re-associate the sums of nodes with three and more parents: equal to rounding, not to the bit
             assert g3["sweeps"] == g["sweeps"] and np.allclose(g3["beliefs"], g["beliefs"], rtol=0, atol=1e-12, equal_nan=True)
             assert np.array_equal(g["beliefs"], o["beliefs"], equal_nan=True) and np.array_equal(res, o["residuals"])
+        elif path == 5 and not exact:
+            # the register-resident DAG path (bn_dag.hip) factors the contraction of nodes with three and more parents, the tile
+            # kernels re-associate it another way: both within rounding of the reference, not equal to the bit
+            assert g3["sweeps"] == g["sweeps"] and np.allclose(g3["beliefs"], g["beliefs"], rtol=0, atol=1e-12, equal_nan=True)
         else:
             assert g3["sweeps"] == g["sweeps"] and np.array_equal(g3["beliefs"], g["beliefs"], equal_nan=True)
             assert np.array_equal(eng.bp_residuals(), res)
@@ -200,6 +204,7 @@ def test_layout_options_same_results(Engine, oracle_mod):
     res, tiles = {}, {}
     for lanes in (0, 2, 3, 4):
         with Engine(d, lanes_per_node=lanes) as eng:
+            eng.set_option("dag", 0)   # the tile layouts are what this test compares (by default this network takes bn_dag.hip)
             res[lanes] = eng.bp_run(ev, 1e-6)
             tiles[lanes] = eng.layout()["n_tiles"]
             assert res[lanes]["sweeps"] == o["sweeps"]

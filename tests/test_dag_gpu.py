@@ -7,7 +7,7 @@ counts everywhere."""
 import numpy as np
 import pytest
 
-from helpers import rel_err
+from helpers import hub_network, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -26,23 +26,8 @@ def _nets():
             ("dag300", synth.random_dag(300, 4, 32, 4, seed=5), False),  # lane groups of 4 and 16
             ("dag200_p5", synth.random_dag(200, 5, 32, 4, seed=6), False),  # ... and 64 (5 parents: 4 096-entry tables)
             ("dag3000", synth.random_dag(3000, 4, 64, 4, seed=8), False),   # nodes with up to ~9 children
-            ("hub", _hub(), True)]
-
-
-def _hub():
-    """one node with 20 children (more than a parent item keeps in registers), each with one more parent"""
-    from bayesiannetwork_amd import from_parent_lists
-    from bayesiannetwork_amd.synth import uniform01
-    parents = [[]] + [[] for _ in range(20)] + [[0, 1 + c] for c in range(20)]
-    k = [4] * len(parents)
-    cpts = []
-    at = 0
-    for ps in parents:
-        rows = 4 ** len(ps)
-        r = 0.1 + 0.9 * uniform01(77, at, rows * 4).reshape(rows, 4)
-        at += rows * 4
-        cpts.append((r / r.sum(axis=1, keepdims=True)).ravel().tolist())
-    return from_parent_lists(k=k, parents=parents, cpts=cpts, name="hub20")
+            ("hub20", hub_network(20), True),       # a node's 21 parent items share a wave and hand each other their records
+            ("hub70", hub_network(70), True)]       # more children than a wave has lanes: every item loads all records itself
 
 
 @pytest.mark.parametrize("name", [n for n, _, _ in _nets()])
@@ -118,6 +103,32 @@ def test_dag_view_and_functor(Engine, oracle_mod):
         o = oracle_mod.bp_run(g, evs[q % 5], 1e-6)
         assert bp.last["sweeps"] == o["sweeps"] and np.abs(got - o["beliefs"]).max() < 1e-12, q
     assert bp.engine.last_path() == 5
+
+
+def test_dag_batch_is_a_sequence_of_single_queries(Engine, oracle_mod):
+    """bn_bp_run_batch on a network this path takes by default: every set is a single query's launch -- same sweep count, same bits,
+    its own residual history -- and the single-query evidence staged before the batch is still in force after it."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(800, 4, 48, 4, seed=41)
+    evs = [synth.random_evidence(g, f, seed=30 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1, 0.3])]
+    with Engine(g) as eng:
+        singles = [eng.bp_run(ev, 1e-6) for ev in evs]
+        assert eng.last_path() == 5
+        hists = []
+        for ev in evs:
+            eng.bp_run(ev, 1e-6)
+            hists.append(eng.bp_residuals().copy())
+        eng.bp_set_evidence(evs[2])
+        out = eng.bp_run_batch(evs, 1e-6)
+        assert eng.last_path() == 5 and eng.info("dag_aborts") == 0
+        assert len(set(out["sweeps"].tolist())) > 1
+        for q, r in enumerate(singles):
+            assert out["sweeps"][q] == r["sweeps"] and np.array_equal(out["beliefs"][q], r["beliefs"]), q
+            assert np.array_equal(eng.bp_residuals_batch(q), hists[q]), q
+            o = oracle_mod.bp_run(g, evs[q], 1e-6)
+            assert r["sweeps"] == o["sweeps"] and np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+        r = eng.bp_run_device(1e-6)          # the evidence staged by bn_bp_set_evidence before the batch
+        assert r["sweeps"] == singles[2]["sweeps"] and np.array_equal(eng.bp_beliefs(), singles[2]["beliefs"])
 
 
 def test_dag_config2_full_size_default_path(Engine, oracle_mod):

@@ -371,7 +371,10 @@ def test_dag_plan_emulated_equals_oracle(bnlib, oracle_mod):
     dag4 = synth.random_dag(300, 4, 32, 4, seed=5)
     dag5 = synth.random_dag(200, 5, 32, 4, seed=6)
     soft = Evidence.from_dict(dag4, {3: np.full(4, 0.25), 40: np.arange(1.0, 5.0), 70: 0})
+    from helpers import hub_network
+    hub20, hub70 = hub_network(20), hub_network(70)   # 21 parent items in one wave; more children than a wave has lanes
     cases = [(grid, synth.random_evidence(grid, 0.05, seed=1), 1e-6, 0, True), (grid, Evidence.none(), 1e-9, 0, True),
+             (hub20, synth.random_evidence(hub20, 0.1, seed=1), 1e-9, 0, True), (hub70, synth.random_evidence(hub70, 0.1, seed=1), 1e-9, 0, True),
              (dag4, synth.random_evidence(dag4, 0.05, seed=2), 1e-6, 0, False), (dag4, soft, 1e-9, 0, False),
              (dag5, synth.random_evidence(dag5, 0.05, seed=3), 1e-6, 0, False), (dag5, Evidence.none(), 1e-12, 5, False)]
     for g, ev, eps, cap, exact in cases:
@@ -414,6 +417,13 @@ def test_dag_plan_invariants(bnlib):
         assert len(act) == p["tiles"][t, 1] and (m_of[act] == m).all() and (cn[::G, 1][nodes >= 0] == g.in_ptr[act]).all()
         seen[act] += 1
     assert (seen == 1).all()
+    for b in p["tiles"][kinds == 8][:, 2]:   # a node's items sit in adjacent lanes of one wave, lambda(v) first, then the children ascending
+        w = p["pitem"][b:b + 64]
+        act = w[:, 0] >= 0
+        rank = np.where(act, w[:, 3] >> 16, 0)
+        first = np.arange(64) - (rank + 1)
+        assert (first[act] >= 0).all() and (w[first[act], 0] == w[act, 0]).all() and ((w[first[act], 3] >> 16) == -1).all()
+    assert (kinds == 9).sum() == 0
     it = np.concatenate([p["pitem"][b:b + 64] for b in p["tiles"][kinds == 8][:, 2]])
     it = it[it[:, 0] >= 0]
     assert sorted(it[it[:, 1] >= 0][:, 1].tolist()) == list(range(g.n_edges))      # one item per pi-message

@@ -77,6 +77,8 @@ def test_wide_split_batch_equals_single_queries(Engine):
     g = synth.random_dag(260, 4, 24, 4, seed=23)
     evs = [synth.random_evidence(g, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
     with Engine(g) as auto, Engine(g, lanes_per_node=2) as dense:   # the automatic layout applies the split by itself ...
+        auto.set_option("dag", 0)    # (the tile layouts are what this test is about; by default this network takes bn_dag.hip,
+        dense.set_option("dag", 0)   # where a batch is a sequence of single-query launches)
         assert any(c["variant"] == 2 and c["lanes_per_node"] == 4 ** (c["m"] - 1) for c in auto.layout_classes())
         assert all(c["lanes_per_node"] == 4 ** (c["m"] - 2) for c in dense.layout_classes() if c["variant"] == 2)   # ... the dense one never
         a, d = auto.bp_run(evs[1], 1e-6), dense.bp_run(evs[1], 1e-6)
@@ -85,6 +87,7 @@ def test_wide_split_batch_equals_single_queries(Engine):
         for q, ev in enumerate(evs):                                                                   # and batches keep the bits
             assert np.array_equal(out["beliefs"][q], auto.bp_run(ev, 1e-6)["beliefs"])
     with Engine(g, lanes_per_node=3) as eng:
+        eng.set_option("dag", 0)
         cls = eng.layout_classes()
         # the case must exercise both rules: wide lane groups (m = 3 -> 16 lanes, m = 4 -> 64) and any-arity tiles for
         # one-lane shapes with more than four children
@@ -110,3 +113,27 @@ def test_many_evidence_sets_wrap_the_mark_value(Engine, oracle_mod):
             r = eng.bp_run_view(evs[q], 1e-6)
             if i % 37 == 0 or i > 590:
                 assert r["sweeps"] == wants[q]["sweeps"] and np.array_equal(r["beliefs"], wants[q]["beliefs"]), i
+
+
+def test_step_api_after_a_view_run(Engine, oracle_mod):
+    """bn_bp_run_view leaves its marginals in the engine's page-locked buffer only; a run through the single-step API afterwards
+    writes d_beliefs and the tile buffers: bn_bp_copy_beliefs / bn_bp_beliefs_device / bn_bp_messages must then read THOSE, not the
+    view's stale copy or another path's state arrays."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(400, 3, 16, [2, 3, 4, 3], seed=3)      # the view run takes the item kernel over several workgroups (path 4)
+    ev_a = synth.random_evidence(g, 0.05, seed=1)
+    ev_b = synth.random_evidence(g, 0.3, seed=2)
+    with Engine(g) as eng:
+        va = eng.bp_run_view(ev_a, 1e-6)["beliefs"].copy()
+        assert eng.last_path() in (3, 4)
+        eng.bp_set_evidence(ev_b)
+        eng.step_begin()
+        o = oracle_mod.bp_run(g, ev_b, 1e-6, dump_msgs=True)
+        for s in range(o["sweeps"]):
+            eng.step_sweep(s, 1e-6)
+        done, sweeps, _ = eng.step_finish(o["sweeps"], False, 1e-6)
+        assert done == 1 and sweeps == o["sweeps"] and eng.last_path() == 0
+        bel = eng.bp_beliefs()
+        assert np.abs(bel - o["beliefs"]).max() < 1e-12 and np.abs(bel - va).max() > 1e-3
+        pi, lam = eng.bp_messages()
+        assert np.abs(pi - o["pi_msg"]).max() < 1e-12 and np.abs(lam - o["lambda_msg"]).max() < 1e-12

@@ -31,6 +31,7 @@ def test_mid_equals_oracle_bitwise(Engine, oracle_mod, name):
     from bayesiannetwork_amd import Evidence, synth
     g = dict(_nets())[name]
     with Engine(g) as eng:
+        eng.set_option("dag", 0)   # (the k = 4 networks of this list would by default take the register-resident DAG path, bn_dag.hip)
         assert eng.info("small_eligible") == 0 and eng.info("mid_eligible") == 1 and eng.info("mid_parts") >= 2
         for ev, eps, cap in ((Evidence.none(), 1e-6, 0), (synth.random_evidence(g, 0.1, seed=3), 1e-9, 0), (synth.random_evidence(g, 0.3, seed=5), 1e-3, 0),
                              (synth.random_evidence(g, 0.05, seed=6), 1e-12, 3)):

@@ -35,6 +35,7 @@ def _check(eng, model, ev, eps, nranks, owner=None):
     with eng.Engine(model) as single:
         single.set_option("small", 0)   # the shards run the tile kernels: the reference run too (same bits)
         single.set_option("mid", 0)
+        single.set_option("dag", 0)
         want = single.bp_run(ev, eps)
         want_res = single.bp_residuals()
         want_pi, want_lam = single.bp_messages()
