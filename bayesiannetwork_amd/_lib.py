@@ -60,6 +60,7 @@ SYMBOLS = [
     ("bn_small_plan_get", ctypes.c_int, [ctypes.c_void_p, i32p, ctypes.POINTER(ctypes.c_uint32), f64p, ctypes.POINTER(ctypes.c_uint32),
                                          ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
                                          f64p]),
+    ("bn_reload_cpt", ctypes.c_int, [ctypes.c_void_p, f64p, ctypes.c_int64]),
     ("bn_dag_plan_get", ctypes.c_int, [ctypes.c_void_p, i32p, i32p, i32p, i32p, i32p, i32p, f64p, f64p]),
     ("bn_comm_unique_id", ctypes.c_int, [ctypes.c_void_p]),
     ("bn_comm_init", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

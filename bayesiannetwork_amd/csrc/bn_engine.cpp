@@ -1349,6 +1349,17 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
             return BN_OK;
         }
         if (rc != BN_ERR_STATE) return rc;
+        if (e->plan.nranks > 1) {
+            // Sharded engines: NO unilateral fall-back inside the library.  A peer whose service block had already published the
+            // final verdict may have returned BN_OK: it would never enter the RCCL all-gather this rank would now wait in, and
+            // peers may still be storing into this rank's exchange region.  The caller's control plane decides for ALL ranks
+            // (multigpu.run_collective: all-reduce of the outcome, then "multisweep" 0 everywhere, or a collective retry);
+            // nothing of the engine's state has been touched.
+            ++e->resident_aborts;
+            const std::string why = g_err;
+            return fail(BN_ERR_STATE, "the in-kernel exchange gave up a bounded wait on this rank (" + why + "): every rank must switch together -- "
+                                      "set \"multisweep\" 0 on ALL ranks (RCCL exchange) or retry collectively");
+        }
         // a bounded wait gave up (e.g. not every block became resident): this run and the next few go down the
         // per-sweep launches, then the resident path is tried again
         ++e->resident_aborts;
@@ -2530,6 +2541,78 @@ extern "C" int bn_dag_plan_get(bn_engine* e, int32_t* dims_out, int32_t* tiles, 
     if (oedge) std::copy(dp.oedge.begin(), dp.oedge.end(), oedge);
     if (cpt_img) std::copy(dp.cpt_img.begin(), dp.cpt_img.end(), cpt_img);
     if (npi_init) std::copy(dp.npi_init.begin(), dp.npi_init.end(), npi_init);
+    return BN_OK;
+}
+
+// New CPT values on an unchanged structure (belief_propagation.hpp:61,186,252: the reference reads node->cpt on every call, so a
+// table edited or re-fitted after the functor was built IS seen there; here the tables are device images made at bn_create).
+// Re-derives every image that holds CPT values -- the lane-striped tile image, the entry tables of the item kernels, the
+// register image of the DAG path, the initial pi(v) of the roots -- from the new flat array and copies them over the old ones;
+// the sampler state is rebuilt at its next call.  No allocation changes size.
+template <class T>
+static int reupload(T* dst, const std::vector<T>& src, size_t expect, hipStream_t s, const char* what) {
+    if (src.size() != expect) return fail(BN_ERR_STATE, std::string("bn_reload_cpt: the ") + what + " changed size (structure changed?)");
+    if (!src.empty()) HIPCHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return BN_OK;
+}
+extern "C" int bn_reload_cpt(bn_engine* e, const double* cpt, int64_t n_entries) {
+    if (!e) return fail(BN_ERR_ARG, "null engine");
+    Plan& p = e->plan;
+    const int64_t want = p.n > 0 ? p.cpt_off[p.n] : 0;
+    if (n_entries != want) return fail(BN_ERR_ARG, "bn_reload_cpt: " + std::to_string(n_entries) + " entries given, the model has " + std::to_string(want));
+    if (want > 0 && !cpt) return fail(BN_ERR_ARG, "null cpt");
+    p.cpt_flat.assign(cpt, cpt + want);
+    if (e->dense) { free_engine(e->dense); e->dense = nullptr; e->batch_on_dense = false; }   // (rebuilt from the new tables on demand)
+    try {
+        const size_t s_cpt = e->small.ent_cpt.size(), s_init = e->small.npi_init.size();
+        if (e->small.ok) {
+            build_small_plan(p, e->small);
+            if (!e->small.ok || e->small.ent_cpt.size() != s_cpt || e->small.npi_init.size() != s_init)
+                return fail(BN_ERR_STATE, "bn_reload_cpt: the one-workgroup plan changed");
+        }
+        std::vector<size_t> m_sizes;
+        for (const SmallPlan& sp : e->mid.parts) m_sizes.push_back(sp.ent_cpt.size());
+        if (e->mid.ok) {
+            build_mid_plan(p, e->mid);
+            bool same = e->mid.ok && e->mid.parts.size() == m_sizes.size();
+            for (size_t q = 0; same && q < m_sizes.size(); ++q) same = e->mid.parts[q].ent_cpt.size() == m_sizes[q];
+            if (!same) return fail(BN_ERR_STATE, "bn_reload_cpt: the plan of the several-workgroup path changed");
+        }
+        const size_t g_img = e->dag.cpt_img.size();
+        if (e->dag.ok) {
+            const int32_t blocks = e->dag.blocks;
+            build_dag_plan(p, e->host_only ? 224 : std::max(blocks, 8), e->dag);   // (the same cap gives the same plan; only the values differ)
+            if (!e->dag.ok || e->dag.cpt_img.size() != g_img || e->dag.blocks != blocks)
+                return fail(BN_ERR_STATE, "bn_reload_cpt: the plan of the register-resident DAG path changed");
+        }
+        if (e->host_only) return BN_OK;
+        ON_DEVICE(e);
+        hipStream_t s = e->stream;
+        HIPCHK(hipStreamSynchronize(s));   // nothing of the old tables is in use any more
+        stripe_cpt(p, cpt);
+        int rc;
+        if ((rc = reupload(e->d_cpt, p.cpt_striped, size_t(p.cpt_doubles), s, "tile image"))) return rc;
+        if (e->small_ok) {
+            if ((rc = reupload(e->d_s_cpt, e->small.ent_cpt, s_cpt, s, "entry table"))) return rc;
+            if ((rc = reupload(e->d_s_init, e->small.npi_init, s_init, s, "initial pi"))) return rc;
+        }
+        if (e->mid_ok) {
+            std::vector<double> all;
+            for (const SmallPlan& sp : e->mid.parts) all.insert(all.end(), sp.ent_cpt.begin(), sp.ent_cpt.end());
+            if ((rc = reupload(e->d_m_cpt, all, all.size(), s, "entry tables"))) return rc;
+            HIPCHK(hipStreamSynchronize(s));   // `all` is a local
+            if ((rc = reupload(e->d_m_init, e->mid.parts[0].npi_init, e->mid.parts[0].npi_init.size(), s, "initial pi"))) return rc;
+        }
+        if (e->dag_ok) {
+            if ((rc = reupload(e->d_g_cpt, e->dag.cpt_img, g_img, s, "register image"))) return rc;
+            if ((rc = reupload(e->d_g_init, e->dag.npi_init, e->dag.npi_init.size(), s, "initial pi"))) return rc;
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<double>().swap(p.cpt_striped);
+        lw_free(e->lw);   // the sampler uploads its copy of the tables at its next call
+    } catch (const std::bad_alloc&) {
+        return fail(BN_ERR_ALLOC, "out of host memory in bn_reload_cpt");
+    }
     return BN_OK;
 }
 

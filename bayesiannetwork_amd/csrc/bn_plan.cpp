@@ -39,6 +39,39 @@ void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>&
     }
 }
 
+// The lane-striped CPT image of the plan's tiles from a flat CPT array in the model's layout (bn_model_desc.cpt): into
+// p.cpt_striped (p.cpt_doubles doubles).  Also what bn_reload_cpt re-runs when only the CPT values changed.
+void stripe_cpt(Plan& p, const double* cpt) {
+    const int32_t n = p.n;
+    p.cpt_striped.assign(size_t(p.cpt_doubles), 0.0);
+    for (int32_t v = 0; v < n; ++v) {
+        if (p.node_class[v] < 0) continue;
+        const ClassDesc& c = p.classes[p.node_class[v]];
+        const TileDesc& td = p.tiles[p.node_tile[v]];
+        const double* src = cpt + p.cpt_off[v];
+        if (c.variant == kVariantFlat) {  // entry e of the reference's row-major table: lane e % G of the node's group, slot e / G
+            double* dst = p.cpt_striped.data() + td.cpt_base;
+            const int64_t S = int64_t(c.kv) * c.rows;
+            for (int64_t e = 0; e < S; ++e) {
+                const int64_t q = e / c.G, lane = int64_t(p.node_nl[v]) * c.G + e % c.G;
+                dst[(q >> 1) * 128 + lane * 2 + (q & 1)] = src[e];
+            }
+            continue;
+        }
+        const int32_t cpl = c.rows / c.G;  // assignments per lane
+        for (int g = 0; g < c.G; ++g) {
+            const int lane = p.node_nl[v] * c.G + g;
+            double* dst = p.cpt_striped.data() + td.cpt_base + lane * 2;
+            for (int32_t i = 0; i < c.kv; ++i)
+                for (int32_t cl = 0; cl < cpl; ++cl) {
+                    const int32_t q = i * cpl + cl;
+                    const int32_t cond = g * cpl + cl;
+                    dst[int64_t(q >> 1) * 128 + (q & 1)] = src[int64_t(cond) * c.kv + i];
+                }
+        }
+    }
+}
+
 std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& p) {
     // lanes_per_node: 0 automatic, 2 dense (automatic without the any-arity rule for nodes with many children),
     // 3 / 4 = 0 / 2 plus the wide lane-group split on small networks (bn_mi355x.h)
@@ -425,32 +458,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     if (n > 0) p.cpt_off.assign(d.cpt_off, d.cpt_off + n + 1);
     else p.cpt_off.assign(1, 0);
     p.cpt_flat.assign(d.cpt, d.cpt + (n ? d.cpt_off[n] : 0));
-    for (int32_t v = 0; v < n; ++v) {
-        if (p.node_class[v] < 0) continue;
-        const ClassDesc& c = p.classes[p.node_class[v]];
-        const TileDesc& td = p.tiles[p.node_tile[v]];
-        const double* src = d.cpt + d.cpt_off[v];
-        if (c.variant == kVariantFlat) {  // entry e of the reference's row-major table: lane e % G of the node's group, slot e / G
-            double* dst = p.cpt_striped.data() + td.cpt_base;
-            const int64_t S = int64_t(c.kv) * c.rows;
-            for (int64_t e = 0; e < S; ++e) {
-                const int64_t q = e / c.G, lane = int64_t(p.node_nl[v]) * c.G + e % c.G;
-                dst[(q >> 1) * 128 + lane * 2 + (q & 1)] = src[e];
-            }
-            continue;
-        }
-        const int32_t cpl = c.rows / c.G;  // assignments per lane
-        for (int g = 0; g < c.G; ++g) {
-            const int lane = p.node_nl[v] * c.G + g;
-            double* dst = p.cpt_striped.data() + td.cpt_base + lane * 2;
-            for (int32_t i = 0; i < c.kv; ++i)
-                for (int32_t cl = 0; cl < cpl; ++cl) {
-                    const int32_t q = i * cpl + cl;
-                    const int32_t cond = g * cpl + cl;
-                    dst[int64_t(q >> 1) * 128 + (q & 1)] = src[int64_t(cond) * c.kv + i];
-                }
-        }
-    }
+    stripe_cpt(p, d.cpt);
 
     // ---- where each edge's messages live on this rank
     auto seg_index = [&](int32_t r, int64_t off) { return int32_t(p.g_base + int64_t(r) * p.seg_d2 + off); };

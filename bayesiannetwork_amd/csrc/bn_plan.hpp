@@ -205,6 +205,9 @@ void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>&
 // Builds the plan.  Returns empty string on success, else an error message (BN_ERR_ARG).
 std::string build_plan(const bn_model_desc& d, const ShardSpec& shard, Plan& out);
 
+// p.cpt_striped (p.cpt_doubles doubles) from a flat CPT array in the model's layout; build_plan and bn_reload_cpt
+void stripe_cpt(Plan& p, const double* cpt);
+
 // (Re)builds Plan::nbr / nbr_max / nbr_chunks: local neighbour tiles (nbl_*) + the given slots of neighbour tiles on
 // other ranks, per tile.  Returns an error text when a tile has too many neighbours (nbr is then empty).
 std::string build_neighbour_table(Plan& p, const std::vector<std::vector<int32_t>>& remote_slots);

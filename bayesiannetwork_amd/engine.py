@@ -160,6 +160,12 @@ class Engine:
         _lib.check(_lib.lib().bn_bp_last_stats(self._h, ctypes.byref(st)))
         return {f: getattr(st, f) for f, _ in st._fields_}
 
+    def reload_cpt(self, cpt) -> None:
+        """bn_reload_cpt: new CPT values (the whole flat array, the model's layout) on the unchanged structure."""
+        cpt = np.ascontiguousarray(cpt, dtype=np.float64)
+        _lib.check(_lib.lib().bn_reload_cpt(self._h, _p(cpt, ctypes.c_double), cpt.shape[0]))
+        self.model = FlatModel(self.model.k, self.model.in_ptr, self.model.in_idx, self.model.cpt_off, cpt.copy(), name=self.model.name)
+
     def set_option(self, name: str, value: int) -> None:
         _lib.check(_lib.lib().bn_set_option(self._h, name.encode(), int(value)))
 

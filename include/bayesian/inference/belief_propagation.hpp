@@ -28,7 +28,7 @@ public:
     // The reference copies the graph (graph_t const graph_); vertices are shared_ptrs, so the
     // keys of the returned map are the caller's vertices either way.
     explicit belief_propagation(graph_t const& graph)
-        : model_(mi355x::flatten(graph)), engine_(model_)
+        : graph_(graph), model_(mi355x::flatten(graph)), engine_(model_)
     {
     }
 
@@ -36,13 +36,14 @@ public:
     // belief_propagation.hpp:12-21, :320-333): the copy owns a second device engine built from the
     // same flat model, so two copies never share mutable state.
     belief_propagation(belief_propagation const& other)
-        : model_(other.model_), engine_(model_), last_sweeps_(other.last_sweeps_), last_residual_(other.last_residual_)
+        : graph_(other.graph_), model_(other.model_), engine_(model_), last_sweeps_(other.last_sweeps_), last_residual_(other.last_residual_)
     {
     }
     belief_propagation& operator=(belief_propagation const& other)
     {
         if(this != &other)
         {
+            graph_ = other.graph_;
             model_ = other.model_;
             engine_ = mi355x::engine_handle(model_);
             last_sweeps_ = other.last_sweeps_;
@@ -152,11 +153,20 @@ public:
         return results;
     }
 
+    // DIFFERENCE FROM THE REFERENCE: it reads node->cpt at every call (:61, :186, :252), so a table edited or re-fitted
+    // (sampler::make_cpt) after the functor was built is seen by the next operator().  This functor flattens the tables ONCE, in
+    // its constructor, into device images.  reload() brings them up to date -- through the functor's own copy of the graph
+    // (vertices are shared_ptrs: it sees the caller's edits, like the reference's graph_ member), or through a graph passed
+    // in; the structure (vertices, arities, edges) must be unchanged.  One pass over the tables + one host-to-device copy.
+    void reload() { mi355x::reload_cpts(graph_, model_, engine_); }
+    void reload(graph_t const& graph) { mi355x::reload_cpts(graph, model_, engine_); graph_ = graph; }
+
     // Not in the reference (its operator() hides them): iterations and last maximum_difference.
     int last_sweeps() const { return last_sweeps_; }
     double last_residual() const { return last_residual_; }
 
 private:
+    graph_t graph_;   // the reference keeps a copy too (graph_t const graph_, :320)
     mi355x::flat_model model_;
     mi355x::engine_handle engine_;
     int last_sweeps_ = 0;

@@ -34,13 +34,19 @@ public:
     typedef std::unordered_map<vertex_type, matrix_type> return_type;
 
     explicit likelihood_weighting(graph_t const& graph)
-        : model_(mi355x::flatten(graph)), engine_(model_)
+        : graph_(graph), model_(mi355x::flatten(graph)), engine_(model_)
     {
         std::random_device rand_dev;
         seed_ = (static_cast<std::uint64_t>(rand_dev()) << 32) ^ rand_dev();
     }
 
     virtual ~likelihood_weighting() = default;
+
+    // DIFFERENCE FROM THE REFERENCE: it reads node->cpt while it samples, so tables edited or re-fitted after the functor was built
+    // are seen by the next call; this functor flattened them once, in its constructor.  reload() brings the device images up to
+    // date (same structure required) -- through the functor's own copy of the graph, whose vertices are the caller's.
+    void reload() { mi355x::reload_cpts(graph_, model_, engine_); }
+    void reload(graph_t const& graph) { mi355x::reload_cpts(graph, model_, engine_); graph_ = graph; }
 
     // deterministic runs (tests)
     void seed(std::uint64_t s) { seed_ = s; next_sample_ = 0; }
@@ -162,6 +168,7 @@ public:
     }
 
 private:
+    graph_t graph_;   // the reference keeps a copy too
     mi355x::flat_model model_;
     mi355x::engine_handle engine_;
     std::uint64_t seed_ = 0;

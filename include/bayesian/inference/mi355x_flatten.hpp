@@ -169,6 +169,18 @@ private:
     bn_engine* handle_ = nullptr;
 };
 
+// New CPT values on an unchanged structure -> the engine (bn_reload_cpt).  The reference's functors read node->cpt at every call
+// (belief_propagation.hpp:61,186,252; likelihood_weighting.hpp:148-158), the engines hold device images made when the functor was
+// built: a functor's reload() brings them up to date.  Throws when vertices, arities or edges are no longer the ones flattened.
+inline void reload_cpts(graph_t const& graph, flat_model& fm, engine_handle& engine)
+{
+    flat_model now = flatten(graph);
+    if(now.nodes != fm.nodes || now.k != fm.k || now.in_ptr != fm.in_ptr || now.in_idx != fm.in_idx)
+        throw std::runtime_error("bn::mi355x::reload_cpts: the graph's structure changed since the functor was built (build a new one)");
+    engine_handle::check(bn_reload_cpt(engine.get(), now.cpt.data(), static_cast<std::int64_t>(now.cpt.size())));
+    fm.cpt.swap(now.cpt);
+}
+
 } // namespace mi355x
 } // namespace bn
 

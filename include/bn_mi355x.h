@@ -75,6 +75,15 @@ typedef struct bn_engine bn_engine;
 /* Validate the model, build the device layout, upload it.  Replaces the functor constructors. */
 int bn_create(const bn_model_desc *desc, bn_engine **out);
 void bn_destroy(bn_engine *eng);
+/*
+ * New CPT values on the SAME structure.  The reference reads node->cpt on every call (belief_propagation.hpp:61,186,252;
+ * likelihood_weighting.hpp:148-158), so a table edited or re-fitted (sampler::make_cpt) after a functor was built is seen by
+ * its next call; an engine holds device images made at bn_create and sees new values only through this call.
+ * cpt [n_entries] is the whole flat array in bn_model_desc.cpt's layout; n_entries must equal the model's cpt_off[n].
+ * Costs one pass over the tables on the host and one host-to-device copy per image; every later bn_bp_run* / bn_lw_run /
+ * bn_rs_run uses the new values.  Staged evidence stays in force.
+ */
+int bn_reload_cpt(bn_engine *eng, const double *cpt, int64_t n_entries);
 
 /*
  * Multi-GPU: one process per GPU, each creating shard `rank` of `nranks` from the SAME global

@@ -281,6 +281,50 @@ int main(int argc, char** argv)
         print_marginals("rejection", net, result);
         std::printf("\"rejection_drawn\":%llu,", static_cast<unsigned long long>(func.last_drawn()));
     }
+    {   // CPT liveness.  The reference reads node->cpt at every call (belief_propagation.hpp:61, :186, :252): an edited table is
+        // seen by the next operator().  The drop-in flattens the tables once, in its constructor: WITHOUT reload() the next call
+        // still answers for the old tables (documented difference), WITH it the functor equals one built from the edited network.
+        bn::graph_t const net = build(resume_spec());
+        auto const v = net.vertex_list();
+        std::unordered_map<bn::vertex_type, bn::matrix_type> pre;
+        pre[v[3]] = one_hot({0, 0, 1});
+        bn::inference::belief_propagation bp(net);
+        bn::inference::likelihood_weighting lw(net);
+        lw.seed(5);
+        bn::inference::likelihood_weighting::evidence_list lev;
+        lev[v[3]] = 2;
+        print_marginals("reload_before", net, bp(pre));
+        auto const lw_before = lw(lev, 20000);
+        bn::condition_t cond;
+        cond[v[1]] = 1;
+        std::vector<double> const row = {0.1, 0.9};          // P(C | B = 1): was {0.7, 0.3}
+        v[2]->cpt[cond].second.assign(row.begin(), row.end());
+        print_marginals("reload_stale", net, bp(pre));
+        bp.reload();
+        print_marginals("reload_fresh", net, bp(pre));
+        bn::inference::belief_propagation rebuilt(net);
+        print_marginals("reload_rebuilt", net, rebuilt(pre));
+        lw.reload();
+        lw.seed(5);
+        auto const lw_fresh = lw(lev, 20000);
+        bn::inference::likelihood_weighting lw2(net);
+        lw2.seed(5);
+        auto const lw_rebuilt = lw2(lev, 20000);
+        bool same = true, moved = false;
+        for(auto const& node : v)
+            for(std::size_t j = 0; j < lw_fresh.at(node).width(); ++j)
+            {
+                // (the weighted histogram is summed with fp64 atomics: equal to rounding, not to the bit)
+                if(std::fabs(lw_fresh.at(node)[0][j] - lw_rebuilt.at(node)[0][j]) > 1e-9) same = false;
+                if(std::fabs(lw_fresh.at(node)[0][j] - lw_before.at(node)[0][j]) > 0.02) moved = true;
+            }
+        if(!same || !moved) { ++failures; std::printf("FAIL likelihood_weighting::reload (same %d, moved %d)\n", int(same), int(moved)); }
+        // a changed STRUCTURE is refused
+        bn::graph_t other = build(pearl_spec());
+        bool threw = false;
+        try { bp.reload(other); } catch(std::runtime_error const&) { threw = true; }
+        if(!threw) { ++failures; std::printf("FAIL reload accepted another structure\n"); }
+    }
     {   // sampler::make_cpt (reference sampler.hpp:81-163): the pattern table make_samples returns,
         // loaded into bn::sampler, refits the CPTs of a structure-only copy of the network
         auto const v = pearl.vertex_list();

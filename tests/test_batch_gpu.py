@@ -73,6 +73,7 @@ def test_batch_on_per_sweep_launches_every_tile_variant(Engine):
     d = synth.random_dag(3000, 4, 64, 4, seed=5)                    # register-resident + lane-group tiles
     evs = [synth.random_evidence(d, f, seed=q) for q, f in enumerate([0.0, 0.02, 0.1])]
     with Engine(d) as eng:
+        eng.set_option("dag", 0)   # (by default this network takes the register-resident DAG path: tests/test_dag_gpu.py)
         sweeps = _check_batch(eng, evs, 1e-6, want_path=0)
         assert len(set(sweeps)) > 1
         _check_batch(eng, evs, 1e-12, max_sweeps=4, want_path=0)    # every set capped together

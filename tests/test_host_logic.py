@@ -451,6 +451,36 @@ def test_dag_plan_invariants(bnlib):
             assert r["vgpr"] <= 256 and r["spill"] == 0 and r["scratch"] == 0, (name, r)
 
 
+def test_reload_cpt_rebuilds_every_plan_host_only(bnlib, oracle_mod):
+    """bn_reload_cpt on a host-only engine: the plans of the item kernels and of the register-resident DAG path carry the NEW
+    tables afterwards (the emulators, run on them, give the oracle's result for the new network); a wrong length is refused.
+    (The device images: tests/test_reload_gpu.py.)"""
+    import dag_emulator
+    import small_emulator
+    from bayesiannetwork_amd import FlatModel, _lib, engine, synth
+    from bayesiannetwork_amd.synth import _random_cpts
+    for make, kind in ((lambda: synth.random_dag(24, 4, 12, [2, 3, 4, 3, 2, 5], seed=12), "small"),
+                       (lambda: synth.random_dag(90, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=17), "mid"),
+                       (lambda: synth.random_dag(300, 4, 32, 4, seed=5), "dag")):
+        a = make()
+        _, cpt = _random_cpts(a.k, a.in_ptr, a.in_idx, 99)
+        b = FlatModel(a.k, a.in_ptr, a.in_idx, a.cpt_off, cpt)
+        ev = synth.random_evidence(a, 0.08, seed=2)
+        want = oracle_mod.bp_run(b, ev, 1e-6)
+        with engine.Engine(a, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+            with pytest.raises(_lib.BnError, match="entries given"):
+                e.reload_cpt(b.cpt[1:])
+            e.reload_cpt(b.cpt)
+            plan = {"small": e.small_plan, "mid": e.mid_plan, "dag": e.dag_plan}[kind]()
+        assert plan is not None
+        got = (dag_emulator if kind == "dag" else small_emulator).emulate(plan, b, ev, 1e-6)
+        assert got["sweeps"] == want["sweeps"]
+        if kind == "dag":
+            assert np.abs(got["beliefs"] - want["beliefs"]).max() < 1e-12
+        else:
+            assert np.array_equal(got["beliefs"], want["beliefs"])
+
+
 def test_small_plan_invariants(bnlib):
     """Every output element has exactly one work item; a vector's elements sit in adjacent lanes of one wave; no two
     staged terms share a place and none lands in the zero padding of another run; the lanes of a wave add equally
