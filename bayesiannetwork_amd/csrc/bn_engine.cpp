@@ -287,6 +287,9 @@ struct bn_engine {
     bool ev_deferred = false;       // the evidence in force sits in the staging block only: the one-workgroup kernel reads it there
                                     // itself (no evidence launch in front of the run); the tile buffers get it -- marks, vectors --
                                     // when another path needs them (flush_evidence)
+    bool autotune_pending = false;  // option "autotune": the next run first times every eligible path on the staged evidence and keeps the fastest
+    int32_t autotuned_path = -1;    // ... the path it kept (bn_bp_last_path numbering), -1: never tuned
+    bool abort_reported = false;    // the one stderr line about a one-launch path that gave up a bounded wait has been printed
     int multisweep = 1;             // resident one-launch path: 0 never, 1 where it was measured faster (one block, or
                                     // >= kResidentMinTiles tiles), 2 wherever eligible (tests, experiments)
     int32_t last_path = 0;          // 0 per-sweep launches, 2 one launch for the whole run (resident tiles), 3 one workgroup, state in LDS (bn_small.hip)
@@ -1261,9 +1264,76 @@ static int run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
     return BN_OK;
 }
 
+// A one-launch path gave up a bounded wait: its workgroups were not all on the chip together -- another engine, stream or process
+// holds compute units.  The run is repeated on a slower path and the result is the same, but the caller should know why its
+// queries got slower: ONE line per engine on stderr (not gated by BN_DEBUG); the counters keep counting
+// (bn_bp_stats.resident_aborts, bn_get_info "mid_aborts" / "dag_aborts").
+static void report_abort_once(bn_engine* e, const char* what, int pause_runs) {
+    if (e->abort_reported && !std::getenv("BN_DEBUG")) return;
+    e->abort_reported = true;
+    std::fprintf(stderr,
+                 "[bn_mi355x] %s gave up a bounded wait (%s): its workgroups were not all resident -- does another engine, stream or "
+                 "process use this GPU?  This run and the next %d take a slower path (same results); further such events are counted, "
+                 "not printed (bn_bp_stats.resident_aborts, bn_get_info \"mid_aborts\" / \"dag_aborts\").\n",
+                 what, g_err.c_str(), pause_runs);
+}
+
+static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
+                           double* copy_to);
+
+// Option "autotune": time every execution path this engine is eligible for ONCE, on the evidence in force, and keep the fastest
+// for all later runs (the built-in choice between them rests on thresholds measured on a handful of networks on one pool of
+// machines).  A trial is one run capped at 6 sweeps, evidence staged, host wall clock, best of two after one warm-up.  The
+// choice is expressed through the engine's own options ("multisweep", "small", "mid", "dag"), so bn_set_option can still
+// override it.  Paths whose >= 3-parent arithmetic differs in the last bits (bn_mi355x.h) may be exchanged by this.
+static int autotune_paths(bn_engine* e, double eps) {
+    struct Cand { int path, multisweep, small, mid, dag; bool ok; };
+    const Cand cands[] = {
+        {0, 0, 0, 0, 0, true},                               // one launch per sweep
+        {2, 2, 0, 0, 0, e->resident_ok},                     // resident tiles
+        {3, 1, 2, 0, 0, e->small_ok},                        // one workgroup, state in LDS
+        {4, 1, 0, 2, 0, e->mid_ok},                          // the same items over several workgroups
+        {5, 1, 0, 0, 2, e->dag_ok},                          // register-resident child tiles + parent items
+    };
+    const int keep[4] = {e->multisweep, e->small_mode, e->mid_mode, e->dag_mode};
+    const bool keep_timing = e->timing;
+    e->timing = false;
+    double best = 1e300;
+    int best_i = -1;
+    for (int i = 0; i < 5; ++i) {
+        if (!cands[i].ok) continue;
+        e->multisweep = cands[i].multisweep; e->small_mode = cands[i].small; e->mid_mode = cands[i].mid; e->dag_mode = cands[i].dag;
+        double t_best = 1e300;
+        bool took = true;
+        for (int rep = 0; rep < 3 && took; ++rep) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = run_device_impl(e, eps, 6, nullptr, nullptr, nullptr);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rc != BN_OK) { e->multisweep = keep[0]; e->small_mode = keep[1]; e->mid_mode = keep[2]; e->dag_mode = keep[3]; e->timing = keep_timing; return rc; }
+            took = e->last_path == cands[i].path;        // (a path in its pause after an abort, or refused by a policy: not a candidate now)
+            if (rep > 0 && took) t_best = std::min(t_best, dt);
+        }
+        if (took && t_best < best) { best = t_best; best_i = i; }
+    }
+    e->timing = keep_timing;
+    if (best_i < 0) { e->multisweep = keep[0]; e->small_mode = keep[1]; e->mid_mode = keep[2]; e->dag_mode = keep[3]; return BN_OK; }
+    e->multisweep = cands[best_i].multisweep; e->small_mode = cands[best_i].small; e->mid_mode = cands[best_i].mid; e->dag_mode = cands[best_i].dag;
+    e->autotuned_path = cands[best_i].path;
+    if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] autotune: path %d (%.1f us per 6-sweep run)\n", e->autotuned_path, best * 1e6);
+    return BN_OK;
+}
+
 static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
                            double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->autotune_pending && !e->host_only && e->plan.nranks == 1) {
+        e->autotune_pending = false;
+        double* const keep_override = e->beliefs_override;
+        e->beliefs_override = nullptr;          // (trial runs write into the engine's own buffer)
+        const int rc = autotune_paths(e, eps);
+        e->beliefs_override = keep_override;
+        if (rc != BN_OK) return rc;
+    }
     e->beliefs_on_host_only = false;  // (bn_bp_run_view sets it again when its kernels wrote to the host buffer)
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
@@ -1306,7 +1376,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         if (r != BN_ERR_STATE) return r;
         ++e->dag_aborts;
         e->dag_cooldown = 64;   // something else holds CUs: the other paths for a while
-        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] register-resident DAG kernel aborted (%s); other paths for the next 64 runs\n", g_err.c_str());
+        report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip)", 64);
         return BN_ERR_STATE;
     };
     if (e->dag_mode == 2 && (rc = attempt_dag()) != BN_ERR_STATE) return rc;   // forced: ahead of the one-workgroup path too
@@ -1334,7 +1404,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         if (rc != BN_ERR_STATE) return rc;
         ++e->mid_aborts;
         e->mid_cooldown = 64;   // something else holds CUs: the tile kernels for a while
-        if (std::getenv("BN_DEBUG")) std::fprintf(stderr, "[bn_mi355x] mid-size kernel aborted (%s); tile kernels for the next 64 runs\n", g_err.c_str());
+        report_abort_once(e, "the several-workgroup item kernel (bn_mid.hip)", 64);
     }
     if ((rc = flush_evidence(e))) return rc;  // the tile kernels read the evidence from their own buffers
     if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
@@ -1365,9 +1435,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         ++e->resident_aborts;
         e->resident_cooldown = e->resident_backoff;
         e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
-        if (std::getenv("BN_DEBUG"))
-            std::fprintf(stderr, "[bn_mi355x] resident launch aborted (%s); per-sweep launches for the next %d runs\n", g_err.c_str(),
-                         e->resident_cooldown);
+        report_abort_once(e, "the resident-tile kernel (bn_resident.hip)", e->resident_cooldown);
     }
     e->last_path = 0;
     if (e->plan.nranks > 1 && !e->comm)
@@ -1436,6 +1504,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "direct") == 0) { e->resident_direct = value != 0; return BN_OK; }
     if (std::strcmp(name, "mid") == 0) { e->mid_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "dag") == 0) { e->dag_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
+    if (std::strcmp(name, "autotune") == 0) { e->autotune_pending = value != 0; if (value == 0) e->autotuned_path = -1; return BN_OK; }
     if (std::strcmp(name, "small") == 0) { e->small_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "poll_sleep") == 0) { e->poll_sleep = std::max(0, std::min(value, 64)); return BN_OK; }
     if (std::strcmp(name, "multisweep") == 0) { e->multisweep = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
@@ -1457,6 +1526,7 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "mid_eligible") == 0) return e->mid.ok ? 1 : 0;
     if (std::strcmp(name, "mid_parts") == 0) return e->mid.ok ? int64_t(e->mid.parts.size()) : 0;
     if (std::strcmp(name, "mid_aborts") == 0) return e->mid_aborts;
+    if (std::strcmp(name, "autotuned_path") == 0) return e->autotuned_path;
     if (std::strcmp(name, "dag_eligible") == 0) return e->dag.ok ? 1 : 0;
     if (std::strcmp(name, "dag_blocks") == 0) return e->dag.ok ? e->dag.blocks : 0;
     if (std::strcmp(name, "dag_tiles") == 0) return e->dag.ok ? int64_t(e->dag.tiles.size()) : 0;
@@ -2068,9 +2138,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
             ++e->resident_aborts;
             e->resident_cooldown = e->resident_backoff;
             e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
-            if (std::getenv("BN_DEBUG"))
-                std::fprintf(stderr, "[bn_mi355x] resident launch aborted (%s); per-sweep launches for the next %d runs\n", g_err.c_str(),
-                             e->resident_cooldown);
+            report_abort_once(e, "the resident-tile kernel (bn_resident.hip, batch)", e->resident_cooldown);
             aborted = true;
         } else {
             e->resident_backoff = 8;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <queue>
 #include <vector>
@@ -21,7 +22,7 @@ namespace bnmi {
     } while (0)
 
 void lw_free(LwState& s) {
-    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
+    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s.h_ev) (void)hipHostFree(s.h_ev);
@@ -115,6 +116,26 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         if ((r = up(&s.d_k, p.k.data(), p.k.size(), st, err))) return r;
         if ((r = up(&s.d_node_off, p.node_off.data(), p.node_off.size(), st, err))) return r;
         if ((r = up(&s.d_cpt, p.cpt_flat.data(), p.cpt_flat.size(), st, err))) return r;
+        {   // selection thresholds: the running totals of every row, added up left to right as make_random_by_weight does
+            // (likelihood_weighting.hpp:177-193), as integers ceil(total * 2^53): "u >= total" for u = U * 2^-53 is "U >= threshold"
+            std::vector<unsigned long long> thr(p.cpt_flat.size(), ~0ull);
+            for (int32_t v = 0; v < p.n; ++v) {
+                const int32_t kv = p.k[v];
+                for (int64_t o = p.cpt_off[v]; o < p.cpt_off[v + 1]; o += kv) {
+                    double total = 0.0;
+                    for (int32_t i = 0; i + 1 < kv; ++i) {
+                        total = i == 0 ? p.cpt_flat[o] : total + p.cpt_flat[o + i];
+                        const double y = std::ceil(std::ldexp(total, 53));
+                        thr[o + i] = y >= 18446744073709551616.0 ? ~0ull : static_cast<unsigned long long>(y);
+                    }
+                }
+            }
+            std::vector<uint32_t> top(thr.size() + 4, 0xffffffffu);   // (+ 4: a 16-byte load at the last row stays inside)
+            for (size_t q = 0; q < thr.size(); ++q) top[q] = thr[q] == ~0ull ? 0xffffffffu : uint32_t(std::min<unsigned long long>(thr[q] >> 21, 0xffffffffull));
+            if ((r = up(&s.d_thr, thr.data(), thr.size(), st, err))) return r;
+            if ((r = up(&s.d_thr32, top.data(), top.size(), st, err))) return r;
+            LWCHK(hipStreamSynchronize(st));  // `thr`, `top` are locals
+        }
         if ((r = up(&s.d_steps, steps.data(), steps.size(), st, err))) return r;
         if ((r = up(&s.d_parents, parents.data(), parents.size(), st, err))) return r;
         LWCHK(hipStreamSynchronize(st));  // steps / parents are locals
@@ -170,7 +191,7 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     uint64_t done = 0;
     while (done < n_samples) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
-        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st) || launch_lw_hist(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
@@ -206,7 +227,7 @@ int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     uint64_t drawn = 0, accepted = 0;
     while (accepted < n_accept && drawn < max_draw) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, max_draw - drawn);
-        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st)) { err = "sampling kernel launch failed"; return BN_ERR_HIP; }

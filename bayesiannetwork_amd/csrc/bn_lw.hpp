@@ -36,6 +36,8 @@ struct LwState {
     int32_t* d_k = nullptr;
     int64_t* d_node_off = nullptr;
     double* d_cpt = nullptr;       // flat, reference row order (row lookup = k contiguous doubles)
+    unsigned long long* d_thr = nullptr;  // same layout: entry i of a row = ceil(running total up to state i x 2^53), the selection thresholds (bn_lw_kernels.hip pick_states)
+    uint32_t* d_thr32 = nullptr;   // ... and their top halves (threshold >> 21): what a draw is compared with first, 4 bytes per entry
     LwStep* d_steps = nullptr;     // [n] in topological order
     LwParent* d_parents = nullptr; // [E] grouped by position, first parent first
     int32_t* d_ev_topo = nullptr;  // [n] clamped state or -1 of the node at each position
@@ -63,6 +65,8 @@ struct LwArgs {
     const int32_t* k;
     const int64_t* node_off;
     const double* cpt;
+    const unsigned long long* thr;
+    const uint32_t* thr32;
     uint8_t* states;
     double* weights;
     double* hist;

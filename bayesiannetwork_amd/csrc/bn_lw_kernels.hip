@@ -78,33 +78,63 @@ __device__ __forceinline__ void draw_uniforms(uint4 (&rng)[S], double (&u)[S]) {
 // States of the S samples of one thread at one node: first i with cum_{i-1} <= u < cum_i, else
 // KV-1 (:177-193).  All rows are loaded before the first compare so the S gathers overlap.
 // The uniforms are drawn between issuing the row gathers and using them (latency cover).
+// KV = 2, 3, 4: the running totals of a row were added up ONCE, on the host, in the reference's left-to-right order, and are kept
+// as 64-bit integer thresholds T_i = ceil(total_i * 2^53).  A uniform is u = U * 2^-53 with the 53-bit integer U the two generator
+// words give, so "u >= total_i" (the comparison the per-draw additions fed) is EXACTLY "U >= T_i": total_i * 2^53 is the same double
+// scaled by a power of two, and an integer is >= a real number iff it is >= its ceiling.  Same states bit for bit, without k - 1 fp64
+// additions per draw and without the integer -> double conversion of the uniform.
+// The top 32 bits of U are the generator's second word as it stands, so the draw is settled by 32-bit compares against the top
+// halves T_i >> 21 -- ONE 16-byte gather per draw (the sampler is bound by its row gathers as much as by its vector ALU: 32-byte
+// rows of doubles were two gather instructions and twice the cache lines) -- unless a top half ties (3 x 2^-32 per draw): then
+// the wave repeats that draw against the full thresholds.
+typedef unsigned lw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lw_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned lw_u32x2 __attribute__((ext_vector_type(2)));
+template <int KV>
+__device__ __forceinline__ void load_top(__amdgpu_buffer_rsrc_t rs, uint32_t row, uint32_t (&t)[3]) {
+    t[0] = t[1] = t[2] = 0xffffffffu;
+    if constexpr (KV == 4) {
+        const lw_u32x4 q = __builtin_bit_cast(lw_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, int(row * 16u), 0, 0));
+        t[0] = q.x; t[1] = q.y; t[2] = q.z;
+    } else if constexpr (KV == 3) {
+        const lw_u32x3 q = __builtin_bit_cast(lw_u32x3, __builtin_amdgcn_raw_buffer_load_b96(rs, int(row * 12u), 0, 0));
+        t[0] = q.x; t[1] = q.y;
+    } else {
+        const lw_u32x2 q = __builtin_bit_cast(lw_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, int(row * 8u), 0, 0));
+        t[0] = q.x;
+    }
+}
 template <int KV, int S>
-__device__ __forceinline__ void pick_states(const double* __restrict__ base, const uint32_t (&row)[S],
-                                            uint4 (&rng)[S], int kv, int (&st)[S]) {
-    double u[S];
+__device__ __forceinline__ void pick_states(const double* __restrict__ base, const unsigned long long* __restrict__ tbase,
+                                            const uint32_t* __restrict__ tbase32, const uint32_t (&row)[S], uint4 (&rng)[S], int kv,
+                                            int (&st)[S]) {
     if (KV > 0) {
-        double x[S][KV > 0 ? KV : 1];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tbase32), 0, 0x7fffffff, 0x00020000);
+        uint32_t t[S][3];
+#pragma unroll
+        for (int r = 0; r < S; ++r) load_top<KV>(rs, row[r], t[r]);
 #pragma unroll
         for (int r = 0; r < S; ++r) {
-            const double* rowp = base + uint64_t(row[r]) * KV;
-#pragma unroll
-            for (int i = 0; i < KV; ++i) x[r][i] = rowp[i];
-        }
-        draw_uniforms<S>(rng, u);
-        // The running totals are non-decreasing (the host rejects negative / non-finite entries), so
-        // "first i with cum_{i-1} <= u < cum_i, else KV-1" is the number of totals u has reached.
-#pragma unroll
-        for (int r = 0; r < S; ++r) {
-            double total = x[r][0];
+            const uint32_t lo = xoshiro_next(rng[r]);
+            const uint32_t hi = xoshiro_next(rng[r]);
             int c = 0;
+            bool tie = false;
 #pragma unroll
             for (int i = 0; i < KV - 1; ++i) {
-                c += (u[r] >= total) ? 1 : 0;
-                total += x[r][i + 1];
+                c += (hi > t[r][i]) ? 1 : 0;
+                tie = tie || hi == t[r][i];
+            }
+            if (__any(tie)) {   // (wave-uniform branch, ~never taken)
+                const unsigned long long U = ((uint64_t(hi) << 32) | lo) >> 11;
+                const unsigned long long* rowp = tbase + uint64_t(row[r]) * KV;
+                c = 0;
+#pragma unroll
+                for (int i = 0; i < KV - 1; ++i) c += (U >= rowp[i]) ? 1 : 0;
             }
             st[r] = c;
         }
     } else {
+        double u[S];
         bool found[S];
         double total[S];
         const double* rowp[S];
@@ -135,8 +165,9 @@ struct LwStepWords {  // LwStep as two 16-byte words
 template <bool ROWS24, bool INLINE>
 __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_WAVES, BN_LW_WAVES))) void lw_sample_kernel(
     const LwStepWords* __restrict__ steps, const uint4* __restrict__ parents, const int32_t* __restrict__ ev_topo,
-    const double* __restrict__ cpt, uint8_t* states, double* __restrict__ weights, int32_t n, uint64_t batch,
-    uint64_t sample_base, uint64_t seed, int32_t mode) {
+    const double* __restrict__ cpt, const unsigned long long* __restrict__ thr, const uint32_t* __restrict__ thr32, uint8_t* states,
+    double* __restrict__ weights, int32_t n,
+    uint64_t batch, uint64_t sample_base, uint64_t seed, int32_t mode) {
     constexpr int S = kLwPerThread;
     static_assert(S == 4, "one dword of states per thread and node");
     static_assert(sizeof(LwStep) == 32 && sizeof(LwParent) == 8, "descriptor layout");
@@ -205,7 +236,10 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
                 for (int r = 0; r < S; ++r)
                     row[r] = (ROWS24 ? __umul24(row[r], kk[q]) : row[r] * kk[q]) + ((wd[q] >> (8 * r)) & 0xffu);
         }
-        const double* base = cpt + ((uint64_t(sd.w & 0xffffu) << 32) | sd.x);
+        const uint64_t coff = (uint64_t(sd.w & 0xffffu) << 32) | sd.x;
+        const double* base = cpt + coff;
+        const unsigned long long* tbase = thr + coff;
+        const uint32_t* tbase32 = thr32 + coff;
         uint32_t packed = 0;
         if (!draws) {
             double x[S];
@@ -219,10 +253,10 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         } else {
             int st[S];
             switch (kv) {
-                case 2: pick_states<2, S>(base, row, rng, 2, st); break;
-                case 3: pick_states<3, S>(base, row, rng, 3, st); break;
-                case 4: pick_states<4, S>(base, row, rng, 4, st); break;
-                default: pick_states<0, S>(base, row, rng, kv, st); break;
+                case 2: pick_states<2, S>(base, tbase, tbase32, row, rng, 2, st); break;
+                case 3: pick_states<3, S>(base, tbase, tbase32, row, rng, 3, st); break;
+                case 4: pick_states<4, S>(base, tbase, tbase32, row, rng, 4, st); break;
+                default: pick_states<0, S>(base, tbase, tbase32, row, rng, kv, st); break;
             }
 #pragma unroll
             for (int r = 0; r < S; ++r) {
@@ -360,7 +394,7 @@ int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
 #define BN_LW_LAUNCH(R24, INL)                                                                                    \
     hipLaunchKernelGGL((lw_sample_kernel<R24, INL>), dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream,       \
                        reinterpret_cast<const LwStepWords*>(a.steps), reinterpret_cast<const uint4*>(a.parents),   \
-                       a.ev_topo, a.cpt, a.states, a.weights, a.n, a.batch, a.sample_base, a.seed, a.mode)
+                       a.ev_topo, a.cpt, a.thr, a.thr32, a.states, a.weights, a.n, a.batch, a.sample_base, a.seed, a.mode)
     if (a.rows24 && a.inline_parents) BN_LW_LAUNCH(true, true);
     else if (a.rows24) BN_LW_LAUNCH(true, false);
     else if (a.inline_parents) BN_LW_LAUNCH(false, true);

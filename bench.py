@@ -564,18 +564,32 @@ def leg_lw(a, local_rank, torch):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     rate = a.samples * steps / dt
-    # algorithmic traffic: per node-sample 1 B state written, its parents' states read, 1 B re-read
-    # by the histogram pass (informational, CPTs are cache-resident)
-    bytes_per_sample = d.n * 2 + d.n_edges
-    roof = {"bound": "hbm", "achieved": rate * bytes_per_sample / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": rate * bytes_per_sample / 1e9 / HBM_PEAK_GBS, "kernel": "lw_sample_kernel + lw_hist_kernel",
-            "algorithmic_bytes_per_sample": bytes_per_sample,
-            "note": "informational: the sampler is VALU/latency-bound (DESIGN.md section 4), not HBM-bound"}
+    # What bounds the sampler: not HBM (the CPTs are cache-resident) but the vector ALU and the row gathers.  The
+    # bound reported is VALU ISSUE: vector instructions per second (SQ_INSTS_VALU of the committed counter pass, per sample, x the
+    # measured sample rate) against what the chip can issue (CUs x 4 SIMDs x clock / 4 cycles per 64-lane instruction).
+    bytes_per_sample = d.n * 2 + d.n_edges   # state written, parents' states read, re-read by the histogram pass (informational)
+    peak_ginst = 256 * 4 * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_INST    # G wave-instructions / s
+    roof = {"bound": "valu", "peak": peak_ginst, "unit": "G wave-instructions/s", "achieved": None, "frac": None,
+            "kernel": "lw_sample_kernel + lw_hist_kernel", "hbm_algorithmic_bytes_per_sample": bytes_per_sample,
+            "hbm_algorithmic_gbs": rate * bytes_per_sample / 1e9,
+            "note": "VALU-issue bound: SQ_INSTS_VALU per sample (committed SQ pass) x measured samples/s over the chip's issue rate; "
+                    "the 16-byte row gathers (one per draw) are the co-limiter (DESIGN.md section 4.6)"}
     roof.update(profiled_traffic("lw"))
-    roof.update(profiled_valu("lw", 5))  # lw_sample_kernel: 91-93 VGPRs -> 5 waves per SIMD (7 816 waves per step on 1 024 SIMDs)
-    roof["limiter"] = "valu+latency"
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_summary.json"):
+            dd = json.load(open(os.path.join(pdir, name)))
+            sq = dd.get("lw_sq_counters_per_launch") or {}
+            per_launch = dd.get("lw_samples_per_launch")
+            if sq.get("SQ_INSTS_VALU") and per_launch:
+                # (the counters are those of the sample kernel's launches; the histogram kernel adds ~8 instructions per node-sample)
+                inst_per_sample = sq["SQ_INSTS_VALU"] / per_launch
+                roof.update({"valu_insts_per_sample": inst_per_sample, "valu_insts_per_node_sample_lane": inst_per_sample * 64 / d.n,
+                             "achieved": rate * inst_per_sample / 1e9, "frac": rate * inst_per_sample / 1e9 / peak_ginst,
+                             "valu_source": f"profiles/{name}",
+                             "valu_stale": not (dd.get("lib_sha256") is not None and dd.get("lib_sha256") == lib_sha256())})
     out = {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
-                       f"{a.samples} samples per step (BASELINE.json configs[4]; 10 M samples = {10000000 / rate:.3f} s at this rate)",
+                       f"{a.samples} samples per call = per step (BASELINE.json configs[4]: 10 M weighted samples)",
            "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "node_samples_per_s": rate * d.n, "roofline": roof}
     if not a.no_cpu:
@@ -660,7 +674,7 @@ def main():
     ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm", "mid"], default="grid",
                     help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG; "
                          "lw = configs[4], likelihood weighting on the 10 k-node DAG")
-    ap.add_argument("--samples", type=int, default=2000000, help="lw: weighted samples per step")
+    ap.add_argument("--samples", type=int, default=10000000, help="lw: weighted samples per step = per bn_lw_run call (BASELINE configs[4]: 10 M)")
     ap.add_argument("--rows", type=int, default=316)
     ap.add_argument("--cols", type=int, default=316)
     ap.add_argument("--eps", type=float, default=1e-3)

@@ -128,6 +128,13 @@ def main():
                 spl = (summary[f"{label}_bench_line"].get("roofline") or {}).get("sweeps_per_launch")
                 if spl:
                     summary[f"{label}_sweeps_per_launch"] = spl   # the counters above are per launch: bench.py divides by this
+                if label == "lw":   # samples one launch of the sample kernel draws (a call is cut into launches of at most 32 GiB of states)
+                    import re
+                    m = re.search(r"(\d+) samples per call", summary[f"{label}_bench_line"].get("config", {}).get("workload", ""))
+                    launches = (summary.get("lw_lw_sample_kernel") or {}).get("launches")
+                    steps = summary[f"{label}_bench_line"].get("steps")
+                    if m and launches and steps:
+                        summary["lw_samples_per_launch"] = int(m.group(1)) * (steps + 2) / launches   # (+ 2 warm-up calls)
     json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if not k.endswith("_bench_line")}, indent=1))
 

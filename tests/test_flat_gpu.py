@@ -72,6 +72,41 @@ def test_flat_variant_matches_oracle(Engine, oracle_mod, name, make, exact, frac
         assert np.allclose(pi, want["pi_msg"], rtol=1e-11, atol=1e-14) and np.allclose(lam, want["lambda_msg"], rtol=1e-11, atol=1e-14)
 
 
+def many_parents(m, seed):
+    """m binary roots, one binary node with all of them as parents (2^m rows), and a child of that node"""
+    rng = np.random.default_rng(seed)
+    parents = [[] for _ in range(m)] + [list(range(m))] + [[m]]
+    ks = [2] * (m + 2)
+    cpts = []
+    for v, ps in enumerate(parents):
+        t = 0.1 + 0.9 * rng.random((2 ** len(ps), 2))
+        cpts.append(t / t.sum(axis=1, keepdims=True))
+    return from_parent_lists(ks, parents, cpts)
+
+
+@pytest.mark.parametrize("m", [9, 12, 16])
+def test_nodes_with_9_to_16_parents(Engine, oracle_mod, m):
+    """The reference's cpt_t / graph_t accept any in-degree (graph.hpp:57-154, :490-525); this engine up to BN_MAX_PARENTS = 16.
+    Nodes with 9-16 parents are beyond the lane-group and any-arity variants (<= 8 parents) and run on the one-lane generic
+    tile: a 12-parent binary node has a 4 096-row table, a 16-parent one 65 536 rows (1 MB).  Same sweep count as the oracle,
+    marginals within 1e-9 (the reference's own products over >= 3 parents are unordered, belief_propagation.hpp:253)."""
+    g = many_parents(m, seed=50 + m)
+    evs = [Evidence.none(), Evidence.from_dict(g, {0: 1, m - 1: 0, m + 1: 1}), Evidence.from_dict(g, {m: 0})]
+    with Engine(g) as eng:
+        assert eng.info("small_eligible") == 0 and eng.info("mid_eligible") == 0 and eng.info("dag_eligible") == 0
+        for ev in evs:
+            want = oracle_mod.bp_run(g, ev, 1e-9, dump_msgs=True)
+            got = eng.bp_run(ev, 1e-9)
+            assert eng.last_path() == 0 and got["sweeps"] == want["sweeps"]
+            assert np.allclose(got["beliefs"], want["beliefs"], rtol=1e-9, atol=1e-14)
+            assert np.allclose(eng.bp_residuals(), want["residuals"], rtol=1e-8, atol=1e-15)
+            pi, lam = eng.bp_messages()
+            assert np.allclose(pi, want["pi_msg"], rtol=1e-9, atol=1e-14) and np.allclose(lam, want["lambda_msg"], rtol=1e-9, atol=1e-14)
+        hist = eng.lw_run(evs[1].hard_states(g), 20000, seed=3)     # the samplers read the same tables
+        want = oracle_mod.lw_run(g, evs[1].hard_states(g), 20000, seed=3)["hist"]
+        assert np.allclose(hist, want, rtol=1e-9, atol=1e-12)
+
+
 def test_flat_equals_one_lane_generic_path(Engine):
     """lanes_per_node = 1 keeps the old one-lane-per-node generic path: same sweeps, same marginals."""
     m = synth.random_dag(250, 3, 24, [2, 3, 4, 5], seed=41)

@@ -56,6 +56,24 @@ def test_model_validation_errors(bnlib):
     bad(in_idx=np.array([0, 0, 7], np.int32))                      # parent out of range
     bad(in_idx=np.array([2, 0, 1], np.int32))                      # node 2 its own parent
     bad(cpt_off=np.array([0, 2, 4, 8, 15], np.int64))              # the reference's missing-row UB -> error
+    # the stated limits of the input domain (the reference's graph_t / cpt_t have none, graph.hpp:57-154): at most
+    # BN_MAX_PARENTS = 16 parents per node, arities 1..255 -- refused with a message that names the node and the limit
+    def limit(model_kw, text):
+        with pytest.raises(_lib.BnError, match=text) as ei:
+            engine.Engine(FlatModel(**model_kw), device=_lib.BN_DEVICE_HOST_ONLY)
+        assert ei.value.code == _lib.BN_ERR_ARG
+    n = 18                                                          # 17 binary roots and a node with all of them as parents
+    k = np.full(n, 2, np.int32)
+    in_ptr = np.zeros(n + 1, np.int32)
+    in_ptr[n] = 17
+    cpt_off = np.concatenate([np.arange(0, 2 * 17 + 1, 2), [2 * 17 + 2 ** 18]]).astype(np.int64)
+    limit(dict(k=k, in_ptr=in_ptr, in_idx=np.arange(17, dtype=np.int32), cpt_off=cpt_off, cpt=np.full(int(cpt_off[-1]), 0.5)),
+          r"node 17 has 17 parents \(max 16\)")
+    limit(dict(k=np.array([256], np.int32), in_ptr=np.zeros(2, np.int32), in_idx=np.zeros(0, np.int32),
+               cpt_off=np.array([0, 256], np.int64), cpt=np.full(256, 1 / 256)), r"selectable_num of node 0 outside \[1,255\]")
+    ok = FlatModel(k=np.array([255], np.int32), in_ptr=np.zeros(2, np.int32), in_idx=np.zeros(0, np.int32),
+                   cpt_off=np.array([0, 255], np.int64), cpt=np.full(255, 1 / 255))
+    engine.Engine(ok, device=_lib.BN_DEVICE_HOST_ONLY).close()     # arity 255 is inside
     with pytest.raises(_lib.BnError):
         engine.Engine(m, device=_lib.BN_DEVICE_HOST_ONLY, rank=3, nranks=2)
     with pytest.raises(_lib.BnError):
