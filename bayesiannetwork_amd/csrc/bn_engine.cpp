@@ -1169,12 +1169,13 @@ static bool dag_applies(const bn_engine* e) {
     if (!e->dag_ok || e->multisweep == 0 || e->dag_mode == 0) return false;
     if (e->dag_mode == 2) return true;
     if (e->small_ok) return false;   // one workgroup with the state in LDS
-    // Networks with lane-group tiles (some node has 3-5 parents), measured us per sweep, this path / the item kernels over several
-    // workgroups / per-sweep launches (scripts/time_dag.py): 300 nodes 4.4 / 7.5 / 8.7, 1 000 nodes 4.8 / 10.3 / 9.4, 3 000 nodes
-    // 5.8 / - / 9.6, 10 000 nodes (BASELINE configs[1]) 6.6 / - / 12.0.  Networks of nodes with at most two parents keep the
-    // resident tiles / item kernels where those apply (both bit-identical to the reference there, like this path).
+    // Measured, us per query (evidence staged, profiles/r04_paths.json), this path / the best of the others:
+    //   lane-group tiles (some node has 3-5 parents): 200 nodes 76 / 122, 1 000 nodes 87 / 165, 3 000 nodes 101 / 182, 10 000 nodes
+    //   (BASELINE configs[1]) 117 / 215; nodes of <= 2 parents: 16 x 16 grid 86 / 95, 40 x 40 117 / 135, 64 x 64 113 / 139, 128 x 128
+    //   133 / 146, 3 000-node DAG 106 / 119, 200-node chain 74 / 74 -- but 200 x 200 grid 283 / 151, 316 x 316 634 / 234: there the
+    //   network no longer fits the chip at one tile per wave (stream form) and the resident tiles keep it.
     if (e->dag.has_groups) return true;
-    return !e->dag.stream && !e->resident_ok && !mid_applies(e);   // (large networks of <= 2 parents: the per-sweep kernels stream their CPTs at 60-70 % of the HBM peak)
+    return !e->dag.stream;
 }
 
 // The evidence in force (staging block) -> the state arrays of the DAG path: marks of this set's own value, vectors in both buffers.
@@ -1526,7 +1527,8 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "mid_eligible") == 0) return e->mid.ok ? 1 : 0;
     if (std::strcmp(name, "mid_parts") == 0) return e->mid.ok ? int64_t(e->mid.parts.size()) : 0;
     if (std::strcmp(name, "mid_aborts") == 0) return e->mid_aborts;
-    if (std::strcmp(name, "autotuned_path") == 0) return e->autotuned_path;
+    if (std::strcmp(name, "autotuned") == 0) return e->autotuned_path >= 0 ? 1 : 0;
+    if (std::strcmp(name, "autotuned_path") == 0) return e->autotuned_path >= 0 ? e->autotuned_path : 0;   // (valid when "autotuned" is 1)
     if (std::strcmp(name, "dag_eligible") == 0) return e->dag.ok ? 1 : 0;
     if (std::strcmp(name, "dag_blocks") == 0) return e->dag.ok ? e->dag.blocks : 0;
     if (std::strcmp(name, "dag_tiles") == 0) return e->dag.ok ? int64_t(e->dag.tiles.size()) : 0;
@@ -1627,6 +1629,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
     e->dense->multisweep = e->multisweep;
     e->dense->small_mode = e->small_mode;
     e->dense->mid_mode = e->mid_mode;
+    e->dense->dag_mode = e->dag_mode;
     e->dense->timing = e->timing;
     return e->dense;
 }
@@ -2066,6 +2069,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
         e->dense->multisweep = e->multisweep;
         e->dense->small_mode = e->small_mode;
         e->dense->mid_mode = e->mid_mode;
+        e->dense->dag_mode = e->dag_mode;
         const int rc = bn_bp_run_batch_device(e->dense, eps, max_sweeps, sweeps_out, residual_out);
         if (rc == BN_OK) adopt_batch_outcome(e);
         return rc;

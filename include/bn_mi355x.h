@@ -228,12 +228,13 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   operation order; with >= 3 parents the contraction is factored (sums over the two trailing parents shared by all outputs):
  *   results agree with the reference to rounding (<= 1e-12; its own products over >= 3 parents are unordered,
  *   belief_propagation.hpp:253).  Networks beyond one tile per wave run the same code walking several tiles per wave ("stream"
- *   form).  0 = never, 1 = where eligible and no other one-launch path takes the network (default), 2 = wherever eligible.
+ *   form).  0 = never, 1 = where measured faster (default: networks with 3-5-parent nodes, and networks of <= 2-parent nodes that fit
+ *   the chip at one tile per wave -- unless the one-workgroup path takes the network), 2 = wherever eligible.
  *   bn_get_info "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts".
  * "autotune" 1 -- the NEXT run first times every execution path the engine is eligible for on the evidence in force (one warm-up and
  *   two timed runs of 6 sweeps each, host wall clock) and keeps the fastest for all later runs: the built-in choice between the
  *   paths rests on thresholds measured on a handful of networks on one pool of machines.  The choice is written into the options
- *   above, which can still be set afterwards; bn_get_info "autotuned_path" tells it (-1: never tuned).  0 clears a pending
+ *   above, which can still be set afterwards; bn_get_info "autotuned" (0 / 1) and "autotuned_path" tell.  0 clears a pending
  *   request.  Single-rank engines only.  Exchanging paths may change the last bits of networks with >= 3-parent nodes.
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run), 3 = one workgroup, state in LDS
  *   (small networks, one launch per run), 4 = the same items over several workgroups (mid-size networks), 5 = register-resident
@@ -242,7 +243,7 @@ int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
  * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
- * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned_path"; unknown name: BN_ERR_ARG.
+ * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path"; unknown name: BN_ERR_ARG.
  * When a one-launch path gives up a bounded wait (its workgroups were not all on the chip: another engine, stream or process uses the
  * GPU) the run is repeated on a slower path; the first such event of an engine prints ONE line on stderr, all are counted. */
 int64_t bn_get_info(bn_engine *eng, const char *name);

@@ -42,7 +42,7 @@ def test_autotune_keeps_the_fastest_path(Engine, oracle_mod, name):
     ev = synth.random_evidence(g, 0.02, seed=7)
     want = oracle_mod.bp_run(g, ev, 1e-6)
     with Engine(g) as eng:
-        assert eng.info("autotuned_path") == -1
+        assert eng.info("autotuned") == 0
         eng.bp_set_evidence(ev)
         times = {}
         for path, opts in FORCE.items():
@@ -57,6 +57,7 @@ def test_autotune_keeps_the_fastest_path(Engine, oracle_mod, name):
             eng.set_option(k, v)
         eng.set_option("autotune", 1)
         r = eng.bp_run_device(1e-6)
+        assert eng.info("autotuned") == 1
         chosen = eng.info("autotuned_path")
         assert chosen in times and eng.last_path() == chosen
         assert r["sweeps"] == want["sweeps"] and np.abs(eng.bp_beliefs() - want["beliefs"]).max() < 1e-12
