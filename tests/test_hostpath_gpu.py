@@ -8,6 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _without_the_dag_path(monkeypatch):
+    """These tests are about the host path of the tile kernels; k = 4 networks that fit the chip would by default take the register-resident DAG
+    path (bn_dag.hip, tests/test_dag_gpu.py).  BN_DAG sets the option's default for engines created from here on."""
+    monkeypatch.setenv("BN_DAG", "0")
+
+
 @pytest.fixture(scope="module")
 def Engine(bnlib):
     from bayesiannetwork_amd.engine import Engine

@@ -9,6 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _without_the_dag_path(monkeypatch):
+    """These tests are about the resident tiles; k = 4 networks that fit the chip would by default take the register-resident DAG
+    path (bn_dag.hip, tests/test_dag_gpu.py).  BN_DAG sets the option's default for engines created from here on."""
+    monkeypatch.setenv("BN_DAG", "0")
+
+
 @pytest.fixture(scope="module")
 def Engine(bnlib):
     from bayesiannetwork_amd.engine import Engine
@@ -143,10 +150,10 @@ def test_paths_are_chosen_by_eligibility(Engine):
     with Engine(synth.random_dag(3000, 4, 64, 4, seed=5)) as eng:  # lane-group tiles (3-4 parents): never on the resident TILES --
         eng.set_option("multisweep", 2)
         eng.bp_run(None, 1e-3)
-        assert eng.last_path() == 5                                 # the register-resident DAG path takes such networks (bn_dag.hip)
-        eng.set_option("dag", 0)
-        eng.bp_run(None, 1e-3)
         assert eng.last_path() == 0
+        eng.set_option("dag", 1)
+        eng.bp_run(None, 1e-3)
+        assert eng.last_path() == 5                                 # the register-resident DAG path takes such networks (bn_dag.hip)
     with Engine(synth.grid(64, 64, 4, seed=1)) as eng:  # 66 tiles: four waves per block (one per SIMD), where the resident
         eng.bp_run(None, 1e-3)                           # kernel beats the launches from the smallest networks on
         assert eng.last_path() == 2 and eng.info("resident_waves") == 4
