@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 #include <vector>
@@ -22,7 +23,7 @@ namespace bnmi {
     } while (0)
 
 void lw_free(LwState& s) {
-    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
+    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s.h_ev) (void)hipHostFree(s.h_ev);
@@ -74,7 +75,7 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
             return BN_ERR_ARG;
         }
         // per-position descriptors: the kernel reads them with scalar loads, one position ahead
-        std::vector<LwStep> steps(size_t(p.n) + 1);  // one spare: the kernel reads a position ahead
+        std::vector<LwStep> steps(size_t(p.n) + 2);  // two spare: the kernel reads two positions ahead
         std::vector<LwParent> parents;
         parents.reserve(size_t(p.E) + size_t(p.n) + 4);
         s.kmax = 0;
@@ -87,6 +88,16 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                 err = "likelihood weighting needs finite, non-negative CPT entries";
                 return BN_ERR_ARG;
             }
+        s.small = s.inline_parents && p.n < (1 << 24) - 1;
+        s.small_pow2 = true;
+        for (int32_t v = 0; v < p.n && s.small; ++v) {
+            const int64_t rows = (p.cpt_off[v + 1] - p.cpt_off[v]) / p.k[v];
+            if (p.in_ptr[v + 1] - p.in_ptr[v] > 4 || rows > 256 || p.k[v] > 4) s.small = false;
+            if (p.k[v] & (p.k[v] - 1)) s.small_pow2 = false;
+        }
+        if (const char* e = getenv("BN_LW_SMALL")) s.small = s.small && atoi(e) != 0;   // (A/B: 0 = the generic kernel)
+        std::vector<int64_t> row16(p.n, -1);   // first row of the node's table in thr16, nodes the kernel stages in LDS only
+        uint32_t rows16 = 0;
         for (int32_t t = 0; t < p.n; ++t) {
             const int32_t v = s.topo[t];
             const int64_t coff = p.cpt_off[v];
@@ -106,6 +117,24 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                 parents.push_back(LwParent{uint32_t(p.in_idx[e]), uint32_t(p.k[p.in_idx[e]])});
                 const int32_t j = e - p.in_ptr[v];
                 if (j < 4 && s.inline_parents) sd.par[j] = uint32_t(p.in_idx[e]) | (uint32_t(p.k[p.in_idx[e]]) << 24);
+            }
+            if (s.inline_parents && sd.m <= 4 && (p.cpt_off[v + 1] - coff) / p.k[v] <= 256) {
+                bool pow2 = true;
+                for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) pow2 = pow2 && (p.k[p.in_idx[e]] & (p.k[p.in_idx[e]] - 1)) == 0;
+                sd.m |= uint8_t(kLwStepPacked | (pow2 ? kLwStepPow2 : 0));
+                if (p.k[v] <= 4) {
+                    row16[v] = rows16;
+                    sd.par_off = rows16;   // (<= 4 parents: all inline, the list offset is not looked at)
+                    rows16 += uint32_t(((p.cpt_off[v + 1] - coff) / p.k[v] + 1) & ~int64_t(1));
+                }
+            }
+            if (s.small) {   // lw_sample_small_kernel's form of the parent words
+                const int32_t m = p.in_ptr[v + 1] - p.in_ptr[v];
+                for (int32_t j = 0; j < 4; ++j) {
+                    const uint32_t node = j < m ? uint32_t(p.in_idx[p.in_ptr[v] + j]) : uint32_t(p.n);
+                    const uint32_t kk = j < m ? uint32_t(p.k[node]) : 1u;
+                    sd.par[j] = node | ((s.small_pow2 ? uint32_t(__builtin_ctz(kk)) : kk) << 24);
+                }
             }
             if (parents.size() & 1) parents.push_back(LwParent{0, 1});  // pairs: 16-byte aligned loads
             s.kmax = std::max(s.kmax, p.k[v]);
@@ -132,6 +161,19 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
             }
             std::vector<uint32_t> top(thr.size() + 4, 0xffffffffu);   // (+ 4: a 16-byte load at the last row stays inside)
             for (size_t q = 0; q < thr.size(); ++q) top[q] = thr[q] == ~0ull ? 0xffffffffu : uint32_t(std::min<unsigned long long>(thr[q] >> 21, 0xffffffffull));
+            std::vector<uint32_t> t16((size_t(rows16) + 256) * 2, 0xffffffffu);   // (+ 256 rows: the kernel copies 2 KB whatever the table's size)
+            for (int32_t v = 0; v < p.n; ++v) {
+                if (row16[v] < 0) continue;
+                const int32_t kv = p.k[v];
+                size_t q = size_t(row16[v]) * 2;
+                for (int64_t o = p.cpt_off[v]; o < p.cpt_off[v + 1]; o += kv, q += 2) {
+                    uint32_t e[3] = {0xffffu, 0xffffu, 0xffffu};
+                    for (int32_t i = 0; i + 1 < kv; ++i) e[i] = thr[o + i] == ~0ull ? 0xffffu : uint32_t(std::min<unsigned long long>(thr[o + i] >> 37, 0xffffull));
+                    t16[q] = e[0] | (e[1] << 16);
+                    t16[q + 1] = e[2] | 0xffff0000u;
+                }
+            }
+            if ((r = up(&s.d_thr16, t16.data(), t16.size(), st, err))) return r;
             if ((r = up(&s.d_thr, thr.data(), thr.size(), st, err))) return r;
             if ((r = up(&s.d_thr32, top.data(), top.size(), st, err))) return r;
             LWCHK(hipStreamSynchronize(st));  // `thr`, `top` are locals
@@ -139,8 +181,8 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         if ((r = up(&s.d_steps, steps.data(), steps.size(), st, err))) return r;
         if ((r = up(&s.d_parents, parents.data(), parents.size(), st, err))) return r;
         LWCHK(hipStreamSynchronize(st));  // steps / parents are locals
-        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_topo), (size_t(p.n) + 1) * sizeof(int32_t)));
-        LWCHK(hipMemsetAsync(s.d_ev_topo, 0xff, (size_t(p.n) + 1) * sizeof(int32_t), st));
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_topo), (size_t(p.n) + 2) * sizeof(int32_t)));
+        LWCHK(hipMemsetAsync(s.d_ev_topo, 0xff, (size_t(p.n) + 2) * sizeof(int32_t), st));
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double)));
         LWCHK(hipHostMalloc(reinterpret_cast<void**>(&s.h_ev), (size_t(p.n) + 1) * sizeof(int32_t), hipHostMallocDefault));
         LWCHK(hipHostMalloc(reinterpret_cast<void**>(&s.h_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double), hipHostMallocDefault));
@@ -161,7 +203,8 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         if (s.d_weights) (void)hipFree(s.d_weights);
         s.d_states = nullptr;
         s.d_weights = nullptr;
-        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), std::max<uint64_t>(uint64_t(p.n) * batch, 1)));
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), (uint64_t(p.n) + 1) * batch));
+        LWCHK(hipMemsetAsync(s.d_states + uint64_t(p.n) * batch, 0, batch, st));   // row n: the "parent" of nodes with fewer than four (lw_sample_small_kernel)
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_weights), batch * sizeof(double)));
         s.batch = batch;
     }
@@ -191,7 +234,7 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     uint64_t done = 0;
     while (done < n_samples) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
-        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st) || launch_lw_hist(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
@@ -227,7 +270,7 @@ int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     uint64_t drawn = 0, accepted = 0;
     while (accepted < n_accept && drawn < max_draw) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, max_draw - drawn);
-        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st)) { err = "sampling kernel launch failed"; return BN_ERR_HIP; }

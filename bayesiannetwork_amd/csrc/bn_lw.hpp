@@ -22,11 +22,13 @@ constexpr int kLwBlockSamples = kLwThreads * kLwPerThread;
 struct LwStep {
     uint32_t coff_lo;  // offset of the node's CPT in the flat array (doubles), 48 bits
     int32_t v;         // node id (row of the state matrix)
-    uint32_t par_off;  // first entry of the node's parents in LwParent[] (even)
+    uint32_t par_off;  // first entry of the node's parents in LwParent[] (even); kLwStepPacked steps (<= 4 parents, all inline): first row of the node's table in LwState::d_thr16 (even)
     uint16_t coff_hi;
-    uint8_t kv, m;     // arity, number of parents
+    uint8_t kv, m;     // arity; number of parents (low five bits) | kLwStepPacked | kLwStepPow2
     uint32_t par[4];   // parents 0..3: node | arity << 24
 };
+constexpr int kLwStepPacked = 0x80;  // <= 4 parents and <= 256 CPT rows: the kernel keeps four samples' row numbers in the bytes of one register
+constexpr int kLwStepPow2 = 0x40;    // ... and every parent's arity is a power of two: shifts instead of multiplies
 struct LwParent {
     uint32_t node, k;  // parent node id and its arity (mixed-radix digit base)
 };
@@ -38,12 +40,16 @@ struct LwState {
     double* d_cpt = nullptr;       // flat, reference row order (row lookup = k contiguous doubles)
     unsigned long long* d_thr = nullptr;  // same layout: entry i of a row = ceil(running total up to state i x 2^53), the selection thresholds (bn_lw_kernels.hip pick_states)
     uint32_t* d_thr32 = nullptr;   // ... and their top halves (threshold >> 21): what a draw is compared with first, 4 bytes per entry
+    uint32_t* d_thr16 = nullptr;   // nodes with <= 256 rows (kLwStepPacked): per row 8 bytes {t0 | t1 << 16, t2 | 0xffff << 16}, t = threshold >> 37 -- the copy a wave stages in LDS
     LwStep* d_steps = nullptr;     // [n] in topological order
     LwParent* d_parents = nullptr; // [E] grouped by position, first parent first
     int32_t* d_ev_topo = nullptr;  // [n] clamped state or -1 of the node at each position
     int32_t kmax = 0;              // largest arity
     bool rows24 = false;           // every CPT has < 2^24 rows: 24-bit row arithmetic
     bool inline_parents = false;   // n <= 2^24: LwStep::par is filled
+    bool small = false;            // every node has <= 4 parents, <= 256 CPT rows and <= 4 states (and n < 2^24 - 1): lw_sample_small_kernel; LwStep::par of a
+                                   // missing parent then names the all-zero row n of the state matrix with arity 1
+    bool small_pow2 = false;       // ... and every arity is a power of two: LwStep::par holds log2 of the arity in its top byte
     uint8_t* d_states = nullptr;   // [n][batch] sampled states of the current batch
     double* d_weights = nullptr;   // [batch]
     double* d_hist = nullptr;      // [sum k]
@@ -59,6 +65,7 @@ struct LwArgs {
     int32_t kmax;
     bool rows24;
     bool inline_parents;
+    bool small, small_pow2;
     const LwStep* steps;
     const LwParent* parents;
     const int32_t* ev_topo;
@@ -67,6 +74,7 @@ struct LwArgs {
     const double* cpt;
     const unsigned long long* thr;
     const uint32_t* thr32;
+    const uint32_t* thr16;
     uint8_t* states;
     double* weights;
     double* hist;

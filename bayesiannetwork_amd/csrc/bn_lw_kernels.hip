@@ -13,10 +13,13 @@
 // (rejection / logic sampling, reference rejection_sampling.hpp:33-167, is the same walk with the
 // evidence nodes sampled like any other and w = 1 if every one of them came out as observed, else 0).
 // Uniforms: every sample owns a xoshiro128++ stream seeded by one Philox4x32-10 block keyed by
-// (seed, global sample id) and advanced by two 32-bit outputs at every topological position -- see
-// oracle/lw_oracle.c for the exact mapping, which this kernel reproduces bit for bit, so sampled
-// states are identical.  (Philox for every draw, 20 quarter-rate 32x32->64 multiplies per pair of
-// positions, made the kernel VALU-bound at 62 % Philox; xoshiro is 20 full-rate ops per uniform.)
+// (seed, global sample id) and advanced by ONE step at every topological position: the ++ output
+// is the top 32 bits of the 53-bit uniform, the ** scrambler of the state the step left behind its
+// low 21 -- see oracle/lw_oracle.c for the exact mapping, which this kernel reproduces bit for bit,
+// so sampled states are identical.  (Philox for every draw, 20 quarter-rate 32x32->64 multiplies per
+// pair of positions, made the kernel VALU-bound at 62 % Philox; two xoshiro steps per uniform were 20
+// full-rate ops of which ten produced bits that decide 3 draws in 2^32; one step is ten, and the low
+// bits cost three more only where they are looked at.)
 //
 // Histogram (lw_hist_kernel, :45-49, run once the weights are FINAL): lane = node, each lane
 // streams its own row of the state matrix 16 samples at a time and adds the (wave-uniform) weights
@@ -59,19 +62,23 @@ __device__ __forceinline__ uint32_t xoshiro_next(uint4& g) {
     return result;
 }
 
-__device__ __forceinline__ double to_unit(uint32_t lo, uint32_t hi) {
-    const uint64_t x = (uint64_t(hi) << 32) | lo;
-    return double(x >> 11) * (1.0 / 9007199254740992.0);
+// the ** scrambler on the state as it stands: the low bits of a position's uniform (taken AFTER the position's step)
+__device__ __forceinline__ uint32_t xoshiro_low(const uint4& g) {
+    const uint32_t x = g.y * 5u;
+    return ((x << 7) | (x >> 25)) * 9u;
+}
+// the 53-bit integer of a position's uniform: u = U * 2^-53
+__device__ __forceinline__ unsigned long long unit53(uint32_t hi, const uint4& g_after) {
+    return (uint64_t(hi) << 21) | (xoshiro_low(g_after) >> 11);
 }
 
-// two outputs per sample and position, low word first
+// one step per sample and position
 template <int S>
 __device__ __forceinline__ void draw_uniforms(uint4 (&rng)[S], double (&u)[S]) {
 #pragma unroll
     for (int r = 0; r < S; ++r) {
-        const uint32_t lo = xoshiro_next(rng[r]);
         const uint32_t hi = xoshiro_next(rng[r]);
-        u[r] = to_unit(lo, hi);
+        u[r] = double(unit53(hi, rng[r])) * (1.0 / 9007199254740992.0);
     }
 }
 
@@ -83,7 +90,7 @@ __device__ __forceinline__ void draw_uniforms(uint4 (&rng)[S], double (&u)[S]) {
 // words give, so "u >= total_i" (the comparison the per-draw additions fed) is EXACTLY "U >= T_i": total_i * 2^53 is the same double
 // scaled by a power of two, and an integer is >= a real number iff it is >= its ceiling.  Same states bit for bit, without k - 1 fp64
 // additions per draw and without the integer -> double conversion of the uniform.
-// The top 32 bits of U are the generator's second word as it stands, so the draw is settled by 32-bit compares against the top
+// The top 32 bits of U are the generator's output as it stands, so the draw is settled by 32-bit compares against the top
 // halves T_i >> 21 -- ONE 16-byte gather per draw (the sampler is bound by its row gathers as much as by its vector ALU: 32-byte
 // rows of doubles were two gather instructions and twice the cache lines) -- unless a top half ties (3 x 2^-32 per draw): then
 // the wave repeats that draw against the full thresholds.
@@ -113,25 +120,29 @@ __device__ __forceinline__ void pick_states(const double* __restrict__ base, con
         uint32_t t[S][3];
 #pragma unroll
         for (int r = 0; r < S; ++r) load_top<KV>(rs, row[r], t[r]);
+        uint32_t hi[S];
+        bool tie = false;
 #pragma unroll
         for (int r = 0; r < S; ++r) {
-            const uint32_t lo = xoshiro_next(rng[r]);
-            const uint32_t hi = xoshiro_next(rng[r]);
+            hi[r] = xoshiro_next(rng[r]);
             int c = 0;
-            bool tie = false;
 #pragma unroll
             for (int i = 0; i < KV - 1; ++i) {
-                c += (hi > t[r][i]) ? 1 : 0;
-                tie = tie || hi == t[r][i];
-            }
-            if (__any(tie)) {   // (wave-uniform branch, ~never taken)
-                const unsigned long long U = ((uint64_t(hi) << 32) | lo) >> 11;
-                const unsigned long long* rowp = tbase + uint64_t(row[r]) * KV;
-                c = 0;
-#pragma unroll
-                for (int i = 0; i < KV - 1; ++i) c += (U >= rowp[i]) ? 1 : 0;
+                c += (hi[r] > t[r][i]) ? 1 : 0;
+                tie = tie || hi[r] == t[r][i];
             }
             st[r] = c;
+        }
+        if (__any(tie)) {   // (wave-uniform branch, ~never taken: the four draws again, against the full thresholds)
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                const unsigned long long U = unit53(hi[r], rng[r]);
+                const unsigned long long* rowp = tbase + uint64_t(row[r]) * KV;
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < KV - 1; ++i) c += (U >= rowp[i]) ? 1 : 0;
+                st[r] = c;
+            }
         }
     } else {
         double u[S];
@@ -155,6 +166,51 @@ __device__ __forceinline__ void pick_states(const double* __restrict__ base, con
     }
 }
 
+// The same selection for nodes with <= 256 CPT rows (kLwStepPacked), thresholds read from the WAVE'S OWN COPY of the node's table
+// in LDS.  What bounded the sampler (round 4, TCP counters: the vector L1 busy 97 % of the kernel, 160 tag look-ups per wave
+// and position, 110 of them the four row gathers -- 64 lanes x 16 bytes scattered over a 4 KB table are ~28 cache lines per
+// instruction) was the gather, not arithmetic and not latency.  So the table comes in with COALESCED loads (the whole table, 16
+// bytes per lane and instruction), goes to LDS, and the per-sample rows are ds_reads.  To halve both the copy and the LDS
+// traffic the copy holds the top 16 bits of each threshold (T >> 37): one 8-byte row {t0 | t1 << 16, t2 | pad}.  A draw whose
+// top 16 bits equal one of its row's entries is undecided (3 x 2^-16 per draw, ~1 % of a wave's positions): the wave then
+// repeats the position's draws against the full 64-bit thresholds in memory.  States are the same bit for bit either way.
+template <int KV, int S>
+__device__ __forceinline__ void pick_states16(const uint2* tab, const unsigned long long* __restrict__ tbase, const uint32_t (&row)[S],
+                                              uint4 (&rng)[S], int (&st)[S]) {
+    uint2 t[S];
+#pragma unroll
+    for (int r = 0; r < S; ++r) t[r] = tab[row[r]];
+    uint32_t hi[S];
+    bool tie = false;
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+        hi[r] = xoshiro_next(rng[r]);
+        const uint32_t h = hi[r] >> 16;
+        const uint32_t e[3] = {t[r].x & 0xffffu, t[r].x >> 16, t[r].y & 0xffffu};
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < KV - 1; ++i) {
+            c += (h > e[i]) ? 1 : 0;
+            tie = tie || h == e[i];
+        }
+        st[r] = c;
+    }
+    if (__any(tie)) {
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const unsigned long long U = unit53(hi[r], rng[r]);
+            const unsigned long long* rowp = tbase + uint64_t(row[r]) * KV;
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < KV - 1; ++i) c += (U >= rowp[i]) ? 1 : 0;
+            st[r] = c;
+        }
+    }
+}
+
+typedef uint8_t __attribute__((address_space(1))) * lw_global_bytes;   // (global address space spelled out: a pointer made from an integer is a flat one otherwise)
+typedef uint32_t __attribute__((address_space(1))) * lw_global_u32;
+
 struct LwStepWords {  // LwStep as two 16-byte words
     uint4 a, b;
 };
@@ -162,17 +218,19 @@ struct LwStepWords {  // LwStep as two 16-byte words
 #ifndef BN_LW_WAVES
 #define BN_LW_WAVES 5
 #endif
-template <bool ROWS24, bool INLINE>
+template <bool ROWS24, bool INLINE, bool REJECT>
 __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_WAVES, BN_LW_WAVES))) void lw_sample_kernel(
     const LwStepWords* __restrict__ steps, const uint4* __restrict__ parents, const int32_t* __restrict__ ev_topo,
-    const double* __restrict__ cpt, const unsigned long long* __restrict__ thr, const uint32_t* __restrict__ thr32, uint8_t* states,
+    const double* __restrict__ cpt, const unsigned long long* __restrict__ thr, const uint32_t* __restrict__ thr32,
+    const uint4* __restrict__ thr16, uint8_t* states,
     double* __restrict__ weights, int32_t n,
-    uint64_t batch, uint64_t sample_base, uint64_t seed, int32_t mode) {
+    uint64_t batch, uint64_t sample_base, uint64_t seed) {
     constexpr int S = kLwPerThread;
     static_assert(S == 4, "one dword of states per thread and node");
     static_assert(sizeof(LwStep) == 32 && sizeof(LwParent) == 8, "descriptor layout");
-    const uint64_t col = (uint64_t(blockIdx.x) * kLwThreads + threadIdx.x) * S;  // first sample of this thread
-    const bool reject = mode == 1;
+    const uint32_t col32 = (blockIdx.x * kLwThreads + threadIdx.x) * S;  // first sample of this thread: its byte offset in a row of the state matrix (batch < 2^31, bn_lw.cpp)
+    const uint64_t col = col32;
+    constexpr bool reject = REJECT;  // logic (rejection) sampling: evidence nodes are drawn like any other, w in {0, 1}
     double w[S];
     uint4 rng[S];
     const uint32_t key0 = uint32_t(seed), key1 = uint32_t(seed >> 32);
@@ -184,57 +242,108 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         if ((rng[r].x | rng[r].y | rng[r].z | rng[r].w) == 0) rng[r].x = 1;
     }
 
-    LwStepWords nxt = steps[0];  // both arrays have a spare entry at the end
+    // A row of the state matrix is addressed as {scalar base of the node's row} + {this thread's 32-bit byte offset}: the base
+    // is scalar arithmetic and the load takes it from SGPRs -- no vector arithmetic per parent (node * batch + col as a 64-bit
+    // vector mad was a quarter-rate instruction per parent and position).
+    // (the halves of the base go through an empty asm with an SGPR constraint: left alone, the compiler re-associates the sum into
+    // one 64-bit vector multiply-add per row)
+    auto row_of = [&](uint32_t node) {
+        const uint64_t b = reinterpret_cast<uint64_t>(states) + uint64_t(node) * batch;
+        uint32_t lo = uint32_t(b), hi = uint32_t(b >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        return reinterpret_cast<lw_global_bytes>((uint64_t(hi) << 32) | lo);
+    };
+    // (... and the 32-bit offset through one with a VGPR constraint in every iteration: hoisted out of the loop as a 64-bit value, it is no
+    // longer recognised as the zero-extended offset of the SGPR-base addressing form)
+    uint32_t c32 = col32;
+    auto off32 = [&]() { return c32; };
+    auto ld = [&](uint32_t node) { return *reinterpret_cast<lw_global_u32>(row_of(node) + off32()); };
+    __shared__ uint4 lw_tab[kLwThreads / 64][128];   // per wave: the 16-bit thresholds of the node it is at (<= 256 rows x 8 bytes)
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4* const my_tab = lw_tab[threadIdx.x >> 6];
+
+    // the first four parents of a position: one branch-free load group per parent count
+    auto request = [&](const uint4& sdw, const uint4& pw, uint32_t (&w4)[4]) {
+        switch (int((sdw.w >> 24) & 0x1fu) < 4 ? int((sdw.w >> 24) & 0x1fu) : 4) {
+            case 0: break;
+            case 1: w4[0] = ld(pw.x & 0xffffffu); break;
+            case 2: w4[0] = ld(pw.x & 0xffffffu); w4[1] = ld(pw.y & 0xffffffu); break;
+            case 3: w4[0] = ld(pw.x & 0xffffffu); w4[1] = ld(pw.y & 0xffffffu); w4[2] = ld(pw.z & 0xffffffu); break;
+            default:
+                w4[0] = ld(pw.x & 0xffffffu); w4[1] = ld(pw.y & 0xffffffu); w4[2] = ld(pw.z & 0xffffffu); w4[3] = ld(pw.w & 0xffffffu);
+                break;
+        }
+    };
+
+    // (Requesting the parents' states of position t + 1 before position t is worked on -- wherever t's node is not among them --
+    // was built and measured SLOWER, 32.1 vs 28.4 ms per 2 M samples: the kernel was bound by the vector L1's look-up rate, and
+    // more loads in flight only queue there.)  Descriptors come through scalar loads one position ahead (both arrays have
+    // spare entries at the end).
+    LwStepWords nxt = steps[0];
     int ev_nxt = ev_topo[0];
     for (int t = 0; t < n; ++t) {
-        const uint4 sd = nxt.a;  // LwStep: coff_lo, v, par_off, coff_hi | kv << 16 | m << 24
+        asm volatile("" : "+v"(c32));
+        const uint4 sd = nxt.a;  // LwStep: coff_lo, v, par_off, coff_hi | kv << 16 | (m | flags) << 24
         const uint4 pin = nxt.b;  // parents 0..3 inline: node | arity << 24
         const int ev = ev_nxt;
         nxt = steps[t + 1];
         ev_nxt = ev_topo[t + 1];
-        const int kv = int((sd.w >> 16) & 0xffu), m = int(sd.w >> 24);
+        const int kv = int((sd.w >> 16) & 0xffu), m = int((sd.w >> 24) & 0x1fu);
+        const bool byte_rows = INLINE && (sd.w & (uint32_t(kLwStepPacked) << 24)) != 0;
         const bool draws = reject || ev < 0;  // logic sampling draws evidence nodes too
+        const bool staged = byte_rows && draws && kv <= 4;
+        uint4 q0, q1;   // (only looked at when staged)
+        if (staged) {   // the node's table of 16-bit thresholds: two coalesced 1 KB pieces (sd.z = its place in thr16, in rows)
+            const uint4* src = thr16 + (sd.z >> 1);
+            q0 = src[lane];
+            q1 = src[64 + lane];
+        }
+        uint32_t wd[4] = {0, 0, 0, 0};
+        if (INLINE) request(sd, pin, wd);
         uint32_t row[S];
 #pragma unroll
         for (int r = 0; r < S; ++r) row[r] = 0;
-        uint32_t wd[4] = {0, 0, 0, 0};
-        if (INLINE) {  // the first four parents: one branch-free load group per parent count
-            auto ld = [&](uint32_t pw) {
-                return *reinterpret_cast<const uint32_t*>(states + uint64_t(pw & 0xffffffu) * batch + col);
-            };
-            auto mix = [&](uint32_t pw, uint32_t word) {
+        if (INLINE) {
+            const uint32_t pk[4] = {pin.x >> 24, pin.y >> 24, pin.z >> 24, pin.w >> 24};   // arities; 0 = no such parent (its word is 0)
+            if (byte_rows) {
+                // <= 4 parents and <= 256 rows: the four samples' row numbers as the four BYTES of one register.  Every partial
+                // row number is below the product of the arities so far (<= 256), so a byte never carries into its neighbour:
+                // one multiply-add (arities that are powers of two: one shift-add) per parent for all four samples, instead
+                // of an extract and a multiply-add per parent AND sample.
+                uint32_t rp = 0;
+                if (sd.w & (uint32_t(kLwStepPow2) << 24)) {
 #pragma unroll
-                for (int r = 0; r < S; ++r)
-                    row[r] = (ROWS24 ? __umul24(row[r], pw >> 24) : row[r] * (pw >> 24)) + ((word >> (8 * r)) & 0xffu);
-            };
-            switch (m < 4 ? m : 4) {
-                case 0: break;
-                case 1: wd[0] = ld(pin.x); mix(pin.x, wd[0]); break;
-                case 2: wd[0] = ld(pin.x); wd[1] = ld(pin.y); mix(pin.x, wd[0]); mix(pin.y, wd[1]); break;
-                case 3:
-                    wd[0] = ld(pin.x); wd[1] = ld(pin.y); wd[2] = ld(pin.z);
-                    mix(pin.x, wd[0]); mix(pin.y, wd[1]); mix(pin.z, wd[2]);
-                    break;
-                default:
-                    wd[0] = ld(pin.x); wd[1] = ld(pin.y); wd[2] = ld(pin.z); wd[3] = ld(pin.w);
-                    mix(pin.x, wd[0]); mix(pin.y, wd[1]); mix(pin.z, wd[2]); mix(pin.w, wd[3]);
-                    break;
+                    for (int j = 0; j < 4; ++j) rp = (rp << (pk[j] ? __builtin_ctz(pk[j]) : 0)) + wd[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rp = rp * (pk[j] ? pk[j] : 1u) + wd[j];
+                }
+#pragma unroll
+                for (int r = 0; r < S; ++r) row[r] = (rp >> (8 * r)) & 0xffu;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < m) {
+#pragma unroll
+                        for (int r = 0; r < S; ++r)
+                            row[r] = (ROWS24 ? __umul24(row[r], pk[j]) : row[r] * pk[j]) + ((wd[j] >> (8 * r)) & 0xffu);
+                    }
+                }
             }
         }
         for (int j0 = INLINE ? 4 : 0; j0 < m; j0 += 4) {  // parent lists are padded to pairs: two LwParent per uint4
             const uint4 pa = parents[(sd.z + j0) >> 1];
             const uint4 pb = (j0 + 2 < m) ? parents[((sd.z + j0) >> 1) + 1] : make_uint4(0, 1, 0, 1);
-            wd[0] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pa.x) * batch + col);
-            wd[1] = wd[2] = wd[3] = 0;
-            if (j0 + 1 < m) wd[1] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pa.z) * batch + col);
-            if (j0 + 2 < m) wd[2] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pb.x) * batch + col);
-            if (j0 + 3 < m) wd[3] = *reinterpret_cast<const uint32_t*>(states + uint64_t(pb.z) * batch + col);
+            uint32_t we[4] = {ld(pa.x), 0, 0, 0};
+            if (j0 + 1 < m) we[1] = ld(pa.z);
+            if (j0 + 2 < m) we[2] = ld(pb.x);
+            if (j0 + 3 < m) we[3] = ld(pb.z);
             const uint32_t kk[4] = {pa.y, (j0 + 1 < m) ? pa.w : 1u, (j0 + 2 < m) ? pb.y : 1u, (j0 + 3 < m) ? pb.w : 1u};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int r = 0; r < S; ++r)
-                    row[r] = (ROWS24 ? __umul24(row[r], kk[q]) : row[r] * kk[q]) + ((wd[q] >> (8 * r)) & 0xffu);
+                    row[r] = (ROWS24 ? __umul24(row[r], kk[q]) : row[r] * kk[q]) + ((we[q] >> (8 * r)) & 0xffu);
         }
         const uint64_t coff = (uint64_t(sd.w & 0xffffu) << 32) | sd.x;
         const double* base = cpt + coff;
@@ -252,7 +361,18 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             packed = uint32_t(ev) * 0x01010101u;
         } else {
             int st[S];
-            switch (kv) {
+            if (staged) {
+                my_tab[lane] = q0;
+                my_tab[64 + lane] = q1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const uint2* tab = reinterpret_cast<const uint2*>(my_tab);
+                switch (kv) {
+                    case 2: pick_states16<2, S>(tab, tbase, row, rng, st); break;
+                    case 3: pick_states16<3, S>(tab, tbase, row, rng, st); break;
+                    default: pick_states16<4, S>(tab, tbase, row, rng, st); break;
+                }
+            } else switch (kv) {
                 case 2: pick_states<2, S>(base, tbase, tbase32, row, rng, 2, st); break;
                 case 3: pick_states<3, S>(base, tbase, tbase32, row, rng, 3, st); break;
                 case 4: pick_states<4, S>(base, tbase, tbase32, row, rng, 4, st); break;
@@ -260,14 +380,133 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             }
 #pragma unroll
             for (int r = 0; r < S; ++r) {
-                if (ev >= 0 && st[r] != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
+                if (REJECT && ev >= 0 && st[r] != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
                 packed |= uint32_t(st[r]) << (8 * r);
             }
         }
-        *reinterpret_cast<uint32_t*>(states + uint64_t(sd.y) * batch + col) = packed;
+        *reinterpret_cast<lw_global_u32>(row_of(sd.y) + off32()) = packed;
     }
 #pragma unroll
     for (int r = 0; r < S; ++r) weights[col + r] = w[r];
+}
+
+// Networks in which EVERY node has <= 4 parents, <= 256 CPT rows and <= 4 states (LwState::small; n < 2^24): the same walk without
+// the generic kernel's case distinctions.  Round 4's counters, after the gathers had been taken off the vector L1: the kernel
+// is bound by instruction ISSUE -- per wave and position 128 vector + 108 scalar instructions + 21 branches, a wave issuing one
+// instruction per turn.  Here a position is straight-line code with two wave-uniform branches (evidence node; a tie):
+//   * four parent loads always -- a missing parent points at the all-zero row behind the state matrix, with arity 1;
+//   * the row numbers of the thread's four samples are the four BYTES of one register (three shift-adds, or multiply-adds, for
+//     all four samples; every partial row number is below 256, so a byte never carries into its neighbour);
+//   * the node's 16-bit thresholds (8 bytes per row, 2 KB copied whatever the table's size) go through the wave's LDS slice;
+//     always three compares per draw -- a node with fewer states has 0xffff in the unused places, which no draw exceeds.
+// POW2: every arity of the network is a power of two (LwStep::par holds log2 of the arity instead of the arity).
+#ifndef BN_LW_SMALL_WAVES
+#define BN_LW_SMALL_WAVES 8
+#endif
+template <bool POW2, bool REJECT>
+__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_SMALL_WAVES, BN_LW_SMALL_WAVES))) void lw_sample_small_kernel(
+    const LwStepWords* __restrict__ steps, const int32_t* __restrict__ ev_topo, const double* __restrict__ cpt,
+    const unsigned long long* __restrict__ thr, const uint4* __restrict__ thr16, uint8_t* states, double* __restrict__ weights, int32_t n,
+    uint64_t batch, uint64_t sample_base, uint64_t seed) {
+    constexpr int S = kLwPerThread;
+    static_assert(S == 4, "one dword of states per thread and node");
+    const uint32_t col32 = (blockIdx.x * kLwThreads + threadIdx.x) * S;
+    double w[S];
+    uint4 rng[S];
+    const uint32_t key0 = uint32_t(seed), key1 = uint32_t(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+        w[r] = 1.0;  // :124
+        const uint64_t s = sample_base + col32 + r;
+        rng[r] = philox4x32_10(uint32_t(s), uint32_t(s >> 32), 0u, 0u, key0, key1);
+        if ((rng[r].x | rng[r].y | rng[r].z | rng[r].w) == 0) rng[r].x = 1;
+    }
+    auto row_of = [&](uint32_t node) {   // (see lw_sample_kernel)
+        const uint64_t b = reinterpret_cast<uint64_t>(states) + uint64_t(node) * batch;
+        uint32_t lo = uint32_t(b), hi = uint32_t(b >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        return reinterpret_cast<lw_global_bytes>((uint64_t(hi) << 32) | lo);
+    };
+    uint32_t c32 = col32;
+    auto ld = [&](uint32_t node) { return *reinterpret_cast<lw_global_u32>(row_of(node) + c32); };
+    __shared__ uint4 lw_tab[kLwThreads / 64][128];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint4* const my_tab = lw_tab[threadIdx.x >> 6];
+    const uint2* const tab = reinterpret_cast<const uint2*>(my_tab);
+
+    LwStepWords nxt = steps[0];
+    int ev_nxt = ev_topo[0];
+    for (int t = 0; t < n; ++t) {
+        asm volatile("" : "+v"(c32));
+        const uint4 sd = nxt.a;   // coff_lo, v, first row in thr16, coff_hi | kv << 16
+        const uint4 pin = nxt.b;  // four parents: node | (POW2 ? log2 arity : arity) << 24
+        const int ev = ev_nxt;
+        nxt = steps[t + 1];
+        ev_nxt = ev_topo[t + 1];
+        const uint4* src = thr16 + (sd.z >> 1);
+        const uint4 q0 = src[lane], q1 = src[64 + lane];
+        const uint32_t w0 = ld(pin.x & 0xffffffu), w1 = ld(pin.y & 0xffffffu), w2 = ld(pin.z & 0xffffffu), w3 = ld(pin.w & 0xffffffu);
+        // the table goes to LDS whether or not this is an evidence node (1 % are): left inside the branch, the copy's loads are
+        // sunk into it, behind the wait for the parents -- a second round trip per position
+        my_tab[lane] = q0;
+        my_tab[64 + lane] = q1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t rp;
+        if (POW2) rp = ((((((w0 << (pin.y >> 24)) + w1) << (pin.z >> 24)) + w2) << (pin.w >> 24))) + w3;
+        else rp = ((w0 * (pin.y >> 24) + w1) * (pin.z >> 24) + w2) * (pin.w >> 24) + w3;
+        uint32_t row[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) row[r] = (rp >> (8 * r)) & 0xffu;
+        const int kv = int((sd.w >> 16) & 0xffu);
+        const uint64_t coff = (uint64_t(sd.w & 0xffffu) << 32) | sd.x;
+        uint32_t packed = 0;
+        if (!REJECT && ev >= 0) {   // evidence node: w *= cpt[row][ev] (:148-153); the stream advances all the same
+            double x[S];
+#pragma unroll
+            for (int r = 0; r < S; ++r) x[r] = cpt[coff + uint64_t(row[r]) * kv + ev];
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                (void)xoshiro_next(rng[r]);
+                w[r] *= x[r];
+            }
+            packed = uint32_t(ev) * 0x01010101u;
+        } else {
+            uint2 e[S];
+#pragma unroll
+            for (int r = 0; r < S; ++r) e[r] = tab[row[r]];
+            uint32_t hi[S];
+            int st[S];
+            bool tie = false;
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                hi[r] = xoshiro_next(rng[r]);
+                const uint32_t h = hi[r] >> 16;
+                const uint32_t e0 = e[r].x & 0xffffu, e1 = e[r].x >> 16, e2 = e[r].y & 0xffffu;
+                st[r] = (h > e0 ? 1 : 0) + (h > e1 ? 1 : 0) + (h > e2 ? 1 : 0);
+                tie = tie || h == e0 || h == e1 || h == e2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (the next position's copy comes after these reads)
+            if (__any(tie)) {   // ~1 % of a wave's positions: the four draws again, against the full thresholds
+#pragma unroll
+                for (int r = 0; r < S; ++r) {
+                    const unsigned long long U = unit53(hi[r], rng[r]);
+                    const unsigned long long* rowp = thr + coff + uint64_t(row[r]) * kv;
+                    int c = 0;
+                    for (int i = 0; i + 1 < kv; ++i) c += (U >= rowp[i]) ? 1 : 0;
+                    st[r] = c;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < S; ++r) {
+                if (REJECT && ev >= 0 && st[r] != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
+                packed |= uint32_t(st[r]) << (8 * r);
+            }
+        }
+        *reinterpret_cast<lw_global_u32>(row_of(sd.y) + c32) = packed;
+    }
+#pragma unroll
+    for (int r = 0; r < S; ++r) weights[col32 + r] = w[r];
 }
 
 // acc[i] += w on the lanes whose state is i: compare into vcc, run the fp64 add under that mask
@@ -391,14 +630,30 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_wide_kernel(const uint8_t*
 
 int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
-#define BN_LW_LAUNCH(R24, INL)                                                                                    \
-    hipLaunchKernelGGL((lw_sample_kernel<R24, INL>), dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream,       \
+#define BN_LW_LAUNCH3(R24, INL, REJ)                                                                              \
+    hipLaunchKernelGGL((lw_sample_kernel<R24, INL, REJ>), dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream,  \
                        reinterpret_cast<const LwStepWords*>(a.steps), reinterpret_cast<const uint4*>(a.parents),   \
-                       a.ev_topo, a.cpt, a.thr, a.thr32, a.states, a.weights, a.n, a.batch, a.sample_base, a.seed, a.mode)
-    if (a.rows24 && a.inline_parents) BN_LW_LAUNCH(true, true);
+                       a.ev_topo, a.cpt, a.thr, a.thr32, reinterpret_cast<const uint4*>(a.thr16), a.states, a.weights, a.n, a.batch, a.sample_base, a.seed)
+#define BN_LW_LAUNCH(R24, INL)                                \
+    do {                                                      \
+        if (a.mode == 1) BN_LW_LAUNCH3(R24, INL, true);       \
+        else BN_LW_LAUNCH3(R24, INL, false);                  \
+    } while (0)
+#define BN_LW_SMALL(P2, REJ)                                                                                           \
+    hipLaunchKernelGGL((lw_sample_small_kernel<P2, REJ>), dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream,       \
+                       reinterpret_cast<const LwStepWords*>(a.steps), a.ev_topo, a.cpt, a.thr,                          \
+                       reinterpret_cast<const uint4*>(a.thr16), a.states, a.weights, a.n, a.batch, a.sample_base, a.seed)
+    if (a.small) {
+        if (a.small_pow2 && a.mode == 1) BN_LW_SMALL(true, true);
+        else if (a.small_pow2) BN_LW_SMALL(true, false);
+        else if (a.mode == 1) BN_LW_SMALL(false, true);
+        else BN_LW_SMALL(false, false);
+    } else if (a.rows24 && a.inline_parents) BN_LW_LAUNCH(true, true);
     else if (a.rows24) BN_LW_LAUNCH(true, false);
     else if (a.inline_parents) BN_LW_LAUNCH(false, true);
     else BN_LW_LAUNCH(false, false);
+#undef BN_LW_LAUNCH3
+#undef BN_LW_SMALL
 #undef BN_LW_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);

@@ -17,8 +17,11 @@
  * seeded by one block of the counter-based Philox4x32-10 generator (Salmon et al., SC'11):
  *   state(sample s) = philox4x32_10(counter = {s_lo, s_hi, 0, 0}, key = {seed_lo, seed_hi})
  *                     (an all-zero state, which xoshiro cannot leave, becomes {1,0,0,0})
- *   at every topological position t = 0, 1, ... (evidence node or not) the stream yields
- *   lo = next(), hi = next();   u(s, t) = ((hi<<32 | lo) >> 11) * 2^-53
+ *   at every topological position t = 0, 1, ... (evidence node or not) the stream takes ONE step:
+ *   hi = next()  (the ++ output, 32 bits);   lo = the ** scrambler rotl(x[1] * 5, 7) * 9 of the state
+ *   the step left behind;   U = hi << 21 | lo >> 11  (53 bits);   u(s, t) = U * 2^-53
+ *   (until round 4 two ++ outputs per position; the low 21 bits decide a draw only when the top 32
+ *   tie with a threshold, 3 x 2^-32 per draw, so the second step bought nothing but work)
  * so u(s, t) depends on (seed, s, t) only -- not on the evidence set, the batch or the GPU --
  * which makes sampled STATES bit-reproducible between this file and the HIP kernel.
  * Parity with the reference itself is statistical (tests/golden holds the reference's
@@ -69,11 +72,14 @@ static void stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]) {
     if ((x[0] | x[1] | x[2] | x[3]) == 0) x[0] = 1;
 }
 
+/* the ** scrambler of xoshiro128 on the state as it stands (no step) */
+uint32_t oracle_xoshiro128ss_peek(const uint32_t x[4]) { return rotl32(x[1] * 5u, 7) * 9u; }
+
 static double stream_uniform(uint32_t x[4]) {
-    uint32_t lo = oracle_xoshiro128pp_next(x);
     uint32_t hi = oracle_xoshiro128pp_next(x);
-    uint64_t v = ((uint64_t)hi << 32) | lo;
-    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+    uint32_t lo = oracle_xoshiro128ss_peek(x);
+    uint64_t v = ((uint64_t)hi << 21) | (lo >> 11);
+    return (double)v * (1.0 / 9007199254740992.0);
 }
 
 /* the uniform of (sample s, position t): test hook */

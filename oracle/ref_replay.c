@@ -36,6 +36,7 @@
 
 void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint32_t oracle_xoshiro128pp_next(uint32_t x[4]);
+uint32_t oracle_xoshiro128ss_peek(const uint32_t x[4]);
 
 /* ---- std::mt19937 ------------------------------------------------------------------------ */
 typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
@@ -141,8 +142,8 @@ static void repo_stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]) {
     if ((x[0] | x[1] | x[2] | x[3]) == 0) x[0] = 1;
 }
 static double repo_stream_uniform(uint32_t x[4]) {
-    uint32_t lo = oracle_xoshiro128pp_next(x), hi = oracle_xoshiro128pp_next(x);
-    return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+    uint32_t hi = oracle_xoshiro128pp_next(x), lo = oracle_xoshiro128ss_peek(x);
+    return (double)(((uint64_t)hi << 21) | (lo >> 11)) * (1.0 / 9007199254740992.0);
 }
 
 /* likelihood_weighting.hpp:177-193 */

@@ -69,8 +69,9 @@ def test_philox_known_answers(oracle_mod):
 
 def test_sampler_stream_definition(oracle_mod):
     """The sampler's stream, restated independently in Python: xoshiro128++ 1.0 (Blackman & Vigna)
-    seeded per sample by philox4x32_10({s_lo, s_hi, 0, 0}, {seed_lo, seed_hi}); two 32-bit outputs
-    (low word first) per topological position; u = (64 bits >> 11) * 2^-53."""
+    seeded per sample by philox4x32_10({s_lo, s_hi, 0, 0}, {seed_lo, seed_hi}); one step per topological
+    position: the ++ output is the top 32 bits of the uniform, the ** scrambler of the state the step
+    left behind gives the low 21; u = (hi << 21 | lo >> 11) * 2^-53."""
     M = 0xffffffff
     rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M
 
@@ -90,8 +91,9 @@ def test_sampler_stream_definition(oracle_mod):
     for seed, sample in [(0, 0), (1234, 77), (2 ** 63 + 5, 2 ** 40 + 3)]:
         st = oracle_mod.philox([sample & M, sample >> 32, 0, 0], [seed & M, seed >> 32])
         for pos in range(6):
-            lo, hi = nxt(st), nxt(st)
-            u = float(((hi << 32) | lo) >> 11) * 2.0 ** -53
+            hi = nxt(st)
+            lo = (rotl((st[1] * 5) & M, 7) * 9) & M
+            u = float((hi << 21) | (lo >> 11)) * 2.0 ** -53
             if pos in (0, 3, 5):
                 assert oracle_mod.lw_uniform(seed, sample, pos) == u
 
