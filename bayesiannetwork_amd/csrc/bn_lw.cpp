@@ -23,7 +23,7 @@ namespace bnmi {
     } while (0)
 
 void lw_free(LwState& s) {
-    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16, s.d_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
+    void* ptrs[] = {s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_states, s.d_weights, s.d_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s.h_ev) (void)hipHostFree(s.h_ev);
@@ -128,13 +128,21 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                     rows16 += uint32_t(((p.cpt_off[v + 1] - coff) / p.k[v] + 1) & ~int64_t(1));
                 }
             }
-            if (s.small) {   // lw_sample_small_kernel's form of the parent words
+            if (s.small) {   // lw_sample_small_kernel's descriptor (node numbers for now: the row stride is not known yet)
+                if (s.h_small.empty()) s.h_small.assign(size_t(p.n) + 3, LwSmallStep{{uint64_t(p.n), uint64_t(p.n), uint64_t(p.n), uint64_t(p.n)}, uint64_t(p.n), 0, 0, 0, {0, 0}});
+                LwSmallStep& ss = s.h_small[t];
                 const int32_t m = p.in_ptr[v + 1] - p.in_ptr[v];
+                uint32_t shape = uint32_t(p.k[v]);
                 for (int32_t j = 0; j < 4; ++j) {
-                    const uint32_t node = j < m ? uint32_t(p.in_idx[p.in_ptr[v] + j]) : uint32_t(p.n);
+                    const int32_t node = j < m ? p.in_idx[p.in_ptr[v] + j] : p.n;
                     const uint32_t kk = j < m ? uint32_t(p.k[node]) : 1u;
-                    sd.par[j] = node | ((s.small_pow2 ? uint32_t(__builtin_ctz(kk)) : kk) << 24);
+                    ss.par[j] = uint64_t(node);
+                    if (j > 0) shape |= (s.small_pow2 ? uint32_t(__builtin_ctz(kk)) : kk) << (8 * j);
                 }
+                ss.own = uint64_t(v);
+                ss.coff = uint64_t(coff);
+                ss.thr16 = uint32_t(row16[v]);
+                ss.shape = shape;
             }
             if (parents.size() & 1) parents.push_back(LwParent{0, 1});  // pairs: 16-byte aligned loads
             s.kmax = std::max(s.kmax, p.k[v]);
@@ -181,8 +189,8 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         if ((r = up(&s.d_steps, steps.data(), steps.size(), st, err))) return r;
         if ((r = up(&s.d_parents, parents.data(), parents.size(), st, err))) return r;
         LWCHK(hipStreamSynchronize(st));  // steps / parents are locals
-        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_topo), (size_t(p.n) + 2) * sizeof(int32_t)));
-        LWCHK(hipMemsetAsync(s.d_ev_topo, 0xff, (size_t(p.n) + 2) * sizeof(int32_t), st));
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_ev_topo), (size_t(p.n) + 3) * sizeof(int32_t)));
+        LWCHK(hipMemsetAsync(s.d_ev_topo, 0xff, (size_t(p.n) + 3) * sizeof(int32_t), st));
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double)));
         LWCHK(hipHostMalloc(reinterpret_cast<void**>(&s.h_ev), (size_t(p.n) + 1) * sizeof(int32_t), hipHostMallocDefault));
         LWCHK(hipHostMalloc(reinterpret_cast<void**>(&s.h_hist), std::max<size_t>(p.node_off[p.n], 1) * sizeof(double), hipHostMallocDefault));
@@ -205,6 +213,16 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         s.d_weights = nullptr;
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), (uint64_t(p.n) + 1) * batch));
         LWCHK(hipMemsetAsync(s.d_states + uint64_t(p.n) * batch, 0, batch, st));   // row n: the "parent" of nodes with fewer than four (lw_sample_small_kernel)
+        if (s.small) {   // the descriptors hold byte offsets of rows: made for this stride
+            std::vector<LwSmallStep> dev(s.h_small);
+            for (LwSmallStep& ss : dev) {
+                for (uint64_t& x : ss.par) x *= batch;
+                ss.own *= batch;
+            }
+            if (!s.d_small_steps) LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_small_steps), dev.size() * sizeof(LwSmallStep)));
+            LWCHK(hipMemcpyAsync(s.d_small_steps, dev.data(), dev.size() * sizeof(LwSmallStep), hipMemcpyHostToDevice, st));
+            LWCHK(hipStreamSynchronize(st));   // `dev` is a local
+        }
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_weights), batch * sizeof(double)));
         s.batch = batch;
     }
@@ -234,7 +252,7 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     uint64_t done = 0;
     while (done < n_samples) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
-        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st) || launch_lw_hist(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
@@ -270,7 +288,7 @@ int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     uint64_t drawn = 0, accepted = 0;
     while (accepted < n_accept && drawn < max_draw) {
         const uint64_t cnt = std::min<uint64_t>(s.batch, max_draw - drawn);
-        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
+        LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st)) { err = "sampling kernel launch failed"; return BN_ERR_HIP; }

@@ -3,6 +3,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "bn_plan.hpp"
 
@@ -29,6 +30,15 @@ struct LwStep {
 };
 constexpr int kLwStepPacked = 0x80;  // <= 4 parents and <= 256 CPT rows: the kernel keeps four samples' row numbers in the bytes of one register
 constexpr int kLwStepPow2 = 0x40;    // ... and every parent's arity is a power of two: shifts instead of multiplies
+// lw_sample_small_kernel's descriptor of one topological position: 64 bytes, wave-uniform, one scalar load a position ahead
+struct LwSmallStep {
+    uint64_t par[4];   // byte offset of each parent's row in the state matrix (node x row stride); a missing parent: row n, all zero
+    uint64_t own;      // ... of the node's own row
+    uint64_t coff;     // offset of the node's CPT / thresholds in the flat arrays (entries)
+    uint32_t thr16;    // first row of the node's table in LwState::d_thr16 (even)
+    uint32_t shape;    // arity | a1 << 8 | a2 << 16 | a3 << 24: parents 1..3's arities (small_pow2: log2 of them); a missing parent: arity 1
+    uint32_t pad_[2];
+};
 struct LwParent {
     uint32_t node, k;  // parent node id and its arity (mixed-radix digit base)
 };
@@ -41,7 +51,9 @@ struct LwState {
     unsigned long long* d_thr = nullptr;  // same layout: entry i of a row = ceil(running total up to state i x 2^53), the selection thresholds (bn_lw_kernels.hip pick_states)
     uint32_t* d_thr32 = nullptr;   // ... and their top halves (threshold >> 21): what a draw is compared with first, 4 bytes per entry
     uint32_t* d_thr16 = nullptr;   // nodes with <= 256 rows (kLwStepPacked): per row 8 bytes {t0 | t1 << 16, t2 | 0xffff << 16}, t = threshold >> 37 -- the copy a wave stages in LDS
-    LwStep* d_steps = nullptr;     // [n] in topological order
+    LwStep* d_steps = nullptr;
+    LwSmallStep* d_small_steps = nullptr;   // [n + 2] in topological order (LwState::small), written for the row stride LwState::batch
+    std::vector<LwSmallStep> h_small;       // the same with NODE numbers in par / own: what the device copy is made from when the stride changes     // [n] in topological order
     LwParent* d_parents = nullptr; // [E] grouped by position, first parent first
     int32_t* d_ev_topo = nullptr;  // [n] clamped state or -1 of the node at each position
     int32_t kmax = 0;              // largest arity
@@ -67,6 +79,7 @@ struct LwArgs {
     bool inline_parents;
     bool small, small_pow2;
     const LwStep* steps;
+    const LwSmallStep* small_steps;
     const LwParent* parents;
     const int32_t* ev_topo;
     const int32_t* k;

@@ -399,17 +399,23 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
 //     all four samples; every partial row number is below 256, so a byte never carries into its neighbour);
 //   * the node's 16-bit thresholds (8 bytes per row, 2 KB copied whatever the table's size) go through the wave's LDS slice;
 //     always three compares per draw -- a node with fewer states has 0xffff in the unused places, which no draw exceeds.
-// POW2: every arity of the network is a power of two (LwStep::par holds log2 of the arity instead of the arity).
+// POW2: every arity of the network is a power of two (LwSmallStep::shape holds log2 of the arities instead of the arities).
+// The descriptor (LwSmallStep, 64 bytes, one scalar load a position ahead) holds the rows' BYTE OFFSETS in the state matrix ready:
+// a row's base is one 64-bit scalar add (node x stride as scalar multiplies was 8 scalar instructions per row, 40 per position).
 #ifndef BN_LW_SMALL_WAVES
 #define BN_LW_SMALL_WAVES 8
 #endif
+struct LwSmallWords {  // LwSmallStep as four 16-byte words
+    uint4 a, b, c, d;
+};
 template <bool POW2, bool REJECT>
 __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_SMALL_WAVES, BN_LW_SMALL_WAVES))) void lw_sample_small_kernel(
-    const LwStepWords* __restrict__ steps, const int32_t* __restrict__ ev_topo, const double* __restrict__ cpt,
+    const LwSmallWords* __restrict__ steps, const int32_t* __restrict__ ev_topo, const double* __restrict__ cpt,
     const unsigned long long* __restrict__ thr, const uint4* __restrict__ thr16, uint8_t* states, double* __restrict__ weights, int32_t n,
-    uint64_t batch, uint64_t sample_base, uint64_t seed) {
+    uint64_t sample_base, uint64_t seed) {
     constexpr int S = kLwPerThread;
     static_assert(S == 4, "one dword of states per thread and node");
+    static_assert(sizeof(LwSmallStep) == 64, "descriptor layout");
     const uint32_t col32 = (blockIdx.x * kLwThreads + threadIdx.x) * S;
     double w[S];
     uint4 rng[S];
@@ -421,66 +427,71 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         rng[r] = philox4x32_10(uint32_t(s), uint32_t(s >> 32), 0u, 0u, key0, key1);
         if ((rng[r].x | rng[r].y | rng[r].z | rng[r].w) == 0) rng[r].x = 1;
     }
-    auto row_of = [&](uint32_t node) {   // (see lw_sample_kernel)
-        const uint64_t b = reinterpret_cast<uint64_t>(states) + uint64_t(node) * batch;
+    // a row of the state matrix = {scalar base: the matrix + the row's byte offset, which the descriptor holds ready} + {this thread's
+    // 32-bit offset}; see lw_sample_kernel for the two empty asm statements
+    auto row_at = [&](uint32_t off_lo, uint32_t off_hi) {
+        const uint64_t b = reinterpret_cast<uint64_t>(states) + ((uint64_t(off_hi) << 32) | off_lo);
         uint32_t lo = uint32_t(b), hi = uint32_t(b >> 32);
         asm volatile("" : "+s"(lo), "+s"(hi));
         return reinterpret_cast<lw_global_bytes>((uint64_t(hi) << 32) | lo);
     };
     uint32_t c32 = col32;
-    auto ld = [&](uint32_t node) { return *reinterpret_cast<lw_global_u32>(row_of(node) + c32); };
     __shared__ uint4 lw_tab[kLwThreads / 64][128];
     const uint32_t lane = threadIdx.x & 63u;
     uint4* const my_tab = lw_tab[threadIdx.x >> 6];
     const uint2* const tab = reinterpret_cast<const uint2*>(my_tab);
 
-    LwStepWords nxt = steps[0];
+    // (Requesting the parents' states of position t + 1 before position t is worked on, wherever t's node is not among them, was
+    // measured slower here too, 20.0 vs 18.3 ms per 2 M samples: with eight waves per SIMD the latency of a position is covered,
+    // and the bookkeeping of a second descriptor in flight costs issue slots.)
+    LwSmallWords nxt = steps[0];
     int ev_nxt = ev_topo[0];
     for (int t = 0; t < n; ++t) {
         asm volatile("" : "+v"(c32));
-        const uint4 sd = nxt.a;   // coff_lo, v, first row in thr16, coff_hi | kv << 16
-        const uint4 pin = nxt.b;  // four parents: node | (POW2 ? log2 arity : arity) << 24
+        const LwSmallWords sd = nxt;   // a, b: the four parents' rows; c: own row, CPT offset; d: thr16 row, kv | shifts (or arities) of parents 1..3
         const int ev = ev_nxt;
         nxt = steps[t + 1];
         ev_nxt = ev_topo[t + 1];
-        const uint4* src = thr16 + (sd.z >> 1);
+        const uint4* src = thr16 + (sd.d.x >> 1);
         const uint4 q0 = src[lane], q1 = src[64 + lane];
-        const uint32_t w0 = ld(pin.x & 0xffffffu), w1 = ld(pin.y & 0xffffffu), w2 = ld(pin.z & 0xffffffu), w3 = ld(pin.w & 0xffffffu);
+        const uint32_t w0 = *reinterpret_cast<lw_global_u32>(row_at(sd.a.x, sd.a.y) + c32);
+        const uint32_t w1 = *reinterpret_cast<lw_global_u32>(row_at(sd.a.z, sd.a.w) + c32);
+        const uint32_t w2 = *reinterpret_cast<lw_global_u32>(row_at(sd.b.x, sd.b.y) + c32);
+        const uint32_t w3 = *reinterpret_cast<lw_global_u32>(row_at(sd.b.z, sd.b.w) + c32);
         // the table goes to LDS whether or not this is an evidence node (1 % are): left inside the branch, the copy's loads are
         // sunk into it, behind the wait for the parents -- a second round trip per position
         my_tab[lane] = q0;
         my_tab[64 + lane] = q1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const uint32_t a1 = (sd.d.y >> 8) & 0xffu, a2 = (sd.d.y >> 16) & 0xffu, a3 = sd.d.y >> 24;
         uint32_t rp;
-        if (POW2) rp = ((((((w0 << (pin.y >> 24)) + w1) << (pin.z >> 24)) + w2) << (pin.w >> 24))) + w3;
-        else rp = ((w0 * (pin.y >> 24) + w1) * (pin.z >> 24) + w2) * (pin.w >> 24) + w3;
+        if (POW2) rp = ((((((w0 << a1) + w1) << a2) + w2) << a3)) + w3;
+        else rp = ((w0 * a1 + w1) * a2 + w2) * a3 + w3;
         uint32_t row[S];
 #pragma unroll
         for (int r = 0; r < S; ++r) row[r] = (rp >> (8 * r)) & 0xffu;
-        const int kv = int((sd.w >> 16) & 0xffu);
-        const uint64_t coff = (uint64_t(sd.w & 0xffffu) << 32) | sd.x;
+        const int kv = int(sd.d.y & 0xffu);
+        const uint64_t coff = (uint64_t(sd.c.w) << 32) | sd.c.z;
+        uint32_t hi[S];   // the position's step of every stream, evidence node or not
+#pragma unroll
+        for (int r = 0; r < S; ++r) hi[r] = xoshiro_next(rng[r]);
         uint32_t packed = 0;
-        if (!REJECT && ev >= 0) {   // evidence node: w *= cpt[row][ev] (:148-153); the stream advances all the same
+        if (!REJECT && ev >= 0) {   // evidence node: w *= cpt[row][ev] (:148-153)
             double x[S];
 #pragma unroll
             for (int r = 0; r < S; ++r) x[r] = cpt[coff + uint64_t(row[r]) * kv + ev];
 #pragma unroll
-            for (int r = 0; r < S; ++r) {
-                (void)xoshiro_next(rng[r]);
-                w[r] *= x[r];
-            }
+            for (int r = 0; r < S; ++r) w[r] *= x[r];
             packed = uint32_t(ev) * 0x01010101u;
         } else {
             uint2 e[S];
 #pragma unroll
             for (int r = 0; r < S; ++r) e[r] = tab[row[r]];
-            uint32_t hi[S];
             int st[S];
             bool tie = false;
 #pragma unroll
             for (int r = 0; r < S; ++r) {
-                hi[r] = xoshiro_next(rng[r]);
                 const uint32_t h = hi[r] >> 16;
                 const uint32_t e0 = e[r].x & 0xffffu, e1 = e[r].x >> 16, e2 = e[r].y & 0xffffu;
                 st[r] = (h > e0 ? 1 : 0) + (h > e1 ? 1 : 0) + (h > e2 ? 1 : 0);
@@ -503,25 +514,26 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
                 packed |= uint32_t(st[r]) << (8 * r);
             }
         }
-        *reinterpret_cast<lw_global_u32>(row_of(sd.y) + c32) = packed;
+        asm volatile("" : "+v"(c32));
+        *reinterpret_cast<lw_global_u32>(row_at(sd.c.x, sd.c.y) + c32) = packed;
     }
 #pragma unroll
     for (int r = 0; r < S; ++r) weights[col32 + r] = w[r];
 }
 
-// acc[i] += w on the lanes whose state is i: compare into vcc, run the fp64 add under that mask
-// (2 VALU instructions; a select would need the add plus two v_cndmask per state).
+// acc[i] += w on the lanes whose state is i: the compare writes exec itself (v_cmpx), the fp64 add runs under it, exec is set back to
+// all lanes (the kernel runs with every lane enabled: no divergent exit before, lanes past the last node accumulate into registers
+// nobody reads).  2 vector + 1 scalar instruction per state and sample; compare into vcc + s_and_saveexec + add + s_mov was 2 + 2, and
+// the kernel, 9 vector and 8 scalar instructions per 64 node-samples, ran at 69 % of its vector-issue floor.
 template <int KMAX>
 __device__ __forceinline__ void masked_add(double (&acc)[KMAX], int i, double w, uint32_t st) {
-    uint64_t saved;
     asm volatile(
-        "v_cmp_eq_u32_e64 vcc, %2, %3\n\t"
-        "s_and_saveexec_b64 %1, vcc\n\t"
-        "v_add_f64 %0, %0, %4\n\t"
-        "s_mov_b64 exec, %1"
-        : "+v"(acc[i]), "=&s"(saved)
+        "v_cmpx_eq_u32_e32 vcc, %2, %1\n\t"
+        "v_add_f64 %0, %0, %3\n\t"
+        "s_mov_b64 exec, -1"
+        : "+v"(acc[i])
         : "v"(st), "s"(uint32_t(i)), "s"(w)
-        : "vcc", "scc");
+        : "vcc");
 }
 
 // hist[v][state_v] += w over samples [range*R, (range+1)*R) of the first n_valid; lane = node.
@@ -545,18 +557,23 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(const uint8_t* __re
     typedef double double8 __attribute__((ext_vector_type(8)));
     typedef const double8 __attribute__((address_space(4))) * const_double8s;
     uint64_t s = s0;
-    // 64 samples (one 64-byte segment of the lane's row) per trip, the next segment in flight while
-    // this one is accumulated (two register sets, no copies).  s0 and the row stride are multiples of 64.
-    auto fetch = [&](uint4 (&q)[4], uint64_t at) {
+    // 128 samples (one 128-byte line of the lane's row) per trip, the next line in flight while this one is accumulated (two
+    // register sets, no copies).  s0 and the row stride are multiples of 128.  (64 bytes per trip until round 4: the two halves of a
+    // line were then requested a trip -- ~8 us -- apart, and the L2 had dropped the line in between: TCC_MISS = TCC_REQ, 2.1 x the
+    // matrix fetched from memory.)
+    constexpr int NQ = 8;
+    auto fetch = [&](uint4 (&q)[NQ], uint64_t at) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[c] = *reinterpret_cast<const uint4*>(rowp + at + 16 * c);
+        for (int c = 0; c < NQ; ++c) q[c] = *reinterpret_cast<const uint4*>(rowp + at + 16 * c);
     };
-    auto consume = [&](const uint4 (&q)[4], uint64_t at) {
+    auto consume = [&](const uint4 (&q)[NQ], uint64_t at) {
+        // the 16 weights of a chunk are requested while the chunk before it is accumulated (scalar loads, two chunks' worth of SGPRs)
+        double8 wlo = ((const_double8s)(weights + at))[0], whi = ((const_double8s)(weights + at))[1];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            __builtin_amdgcn_sched_barrier(0);  // keep the scalar weight loads of a chunk with its chunk
-            const const_double8s wp = (const_double8s)(weights + at + 16 * c);
-            const double8 wlo = wp[0], whi = wp[1];
+        for (int c = 0; c < NQ; ++c) {
+            __builtin_amdgcn_sched_barrier(0);  // keep the scalar weight loads of a chunk with the chunk before it
+            const const_double8s wp = (const_double8s)(weights + at + 16 * (c < NQ - 1 ? c + 1 : NQ - 1));
+            const double8 nlo = wp[0], nhi = wp[1];
             const uint32_t word[4] = {q[c].x, q[c].y, q[c].z, q[c].w};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -565,21 +582,24 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(const uint8_t* __re
 #pragma unroll
                 for (int i = 0; i < KMAX; ++i) masked_add<KMAX>(acc, i, wj, st);
             }
+            wlo = nlo;
+            whi = nhi;
         }
     };
     // the segment after the last one is fetched too (clamped to the last): no branch around the
     // prefetch, so the wait before the first use can leave those four loads outstanding
-    const uint64_t n_seg = (s1 - s0) / 64;
-    uint4 qa[4], qb[4];
+    constexpr uint64_t SEG = 16 * NQ;
+    const uint64_t n_seg = (s1 - s0) / SEG;
+    uint4 qa[NQ], qb[NQ];
     if (n_seg > 0) fetch(qa, s0);
     for (uint64_t g = 0; g < n_seg; g += 2) {
-        fetch(qb, s0 + 64 * (g + 1 < n_seg ? g + 1 : n_seg - 1));
-        consume(qa, s0 + 64 * g);
+        fetch(qb, s0 + SEG * (g + 1 < n_seg ? g + 1 : n_seg - 1));
+        consume(qa, s0 + SEG * g);
         if (g + 1 >= n_seg) break;
-        fetch(qa, s0 + 64 * (g + 2 < n_seg ? g + 2 : n_seg - 1));
-        consume(qb, s0 + 64 * (g + 1));
+        fetch(qa, s0 + SEG * (g + 2 < n_seg ? g + 2 : n_seg - 1));
+        consume(qb, s0 + SEG * (g + 1));
     }
-    s = s0 + 64 * n_seg;
+    s = s0 + SEG * n_seg;
     for (; s < s1; ++s) {
         const double wj = weights[s];
         const uint32_t st = rowp[s];
@@ -641,8 +661,8 @@ int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
     } while (0)
 #define BN_LW_SMALL(P2, REJ)                                                                                           \
     hipLaunchKernelGGL((lw_sample_small_kernel<P2, REJ>), dim3(blocks), dim3(kLwThreads), 0, (hipStream_t)stream,       \
-                       reinterpret_cast<const LwStepWords*>(a.steps), a.ev_topo, a.cpt, a.thr,                          \
-                       reinterpret_cast<const uint4*>(a.thr16), a.states, a.weights, a.n, a.batch, a.sample_base, a.seed)
+                       reinterpret_cast<const LwSmallWords*>(a.small_steps), a.ev_topo, a.cpt, a.thr,                   \
+                       reinterpret_cast<const uint4*>(a.thr16), a.states, a.weights, a.n, a.sample_base, a.seed)
     if (a.small) {
         if (a.small_pow2 && a.mode == 1) BN_LW_SMALL(true, true);
         else if (a.small_pow2) BN_LW_SMALL(true, false);

@@ -20,8 +20,13 @@ def Engine(bnlib):
 
 @pytest.mark.parametrize("n,maxp,k,frac,ns", [
     (300, 3, [2, 3, 4], 0.05, 5000), (1000, 4, 4, 0.02, 3000), (64, 2, 9, 0.1, 2048), (500, 4, 2, 0.0, 4096),
+    # nodes with 5 parents (1 024-row tables: thresholds gathered from memory) among nodes whose tables go through LDS; binary nodes with
+    # up to 6 parents (parent lists beyond the four inline ones)
+    (400, 5, [2, 3, 4], 0.03, 3000), (200, 6, 2, 0.05, 3000),
 ])
 def test_lw_states_bit_exact_vs_oracle(Engine, oracle_mod, n, maxp, k, frac, ns):
+    """Which sampling kernel runs follows from the network: <= 4 parents, <= 256 rows and <= 4 states everywhere -> the straight-line
+    kernel (arities all powers of two or not: two instantiations); anything else -> the generic one."""
     from bayesiannetwork_amd import synth
     d = synth.random_dag(n, maxp, 32, k, seed=n + 1)
     ev = synth.random_evidence(d, frac, seed=4).hard_states(d)
@@ -34,6 +39,26 @@ def test_lw_states_bit_exact_vs_oracle(Engine, oracle_mod, n, maxp, k, frac, ns)
     assert np.allclose(hist, want["hist"], rtol=1e-9, atol=1e-12)
     if frac == 0.0:  # unit weights: histograms are integer counts, exact in fp64
         assert np.array_equal(hist, want["hist"])
+
+
+@pytest.mark.parametrize("n,maxp,k", [(300, 3, [2, 3, 4]), (600, 4, 4)])
+def test_lw_generic_kernel_on_a_small_arity_network(Engine, oracle_mod, monkeypatch, n, maxp, k):
+    """BN_LW_SMALL=0 sends a network the straight-line kernel would take through the generic kernel (its LDS-staged thresholds, its
+    byte-packed row numbers): the same states bit for bit, from both."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(n, maxp, 32, k, seed=n + 3)
+    ev = synth.random_evidence(d, 0.04, seed=5).hard_states(d)
+    want = oracle_mod.lw_run(d, ev, 4096, seed=99, s_begin=5, states_cap=4096)
+    got = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("BN_LW_SMALL", small)
+        with Engine(d) as eng:
+            hist = eng.lw_run(ev, 4096, seed=99, sample_begin=5)
+            states, weights = eng.lw_states(4096)
+        assert np.array_equal(states, want["states"]) and np.allclose(weights, want["weights"], rtol=1e-12, atol=0)
+        assert np.allclose(hist, want["hist"], rtol=1e-9, atol=1e-12)
+        got.append(states)
+    assert np.array_equal(got[0], got[1])
 
 
 def test_lw_config5_full_size(Engine, oracle_mod):
