@@ -27,3 +27,19 @@ def test_gloo_sharded_exchange(bnlib, oracle_mod, case, world, order, tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert f"DIST_OK case={case} world={world} order={order}" in p.stdout
+
+
+@pytest.mark.parametrize("failing", ["none", "0", "1"])
+def test_run_collective_resolves_a_failed_in_kernel_run_on_every_rank(failing):
+    """multigpu.run_collective (what a sharded caller runs a query through): a rank whose in-kernel exchange gave up gets
+    BN_ERR_STATE from the library, which does not fall back on its own; all ranks then switch to the RCCL exchange together and
+    repeat the run -- also the rank whose first run had succeeded.  World 2 over gloo, a stand-in engine (tests/collective_worker.py)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "collective_worker.py"), failing]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert f"COLLECTIVE_OK failing={failing} world=2" in p.stdout
