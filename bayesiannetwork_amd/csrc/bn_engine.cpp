@@ -1533,6 +1533,7 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "dag_blocks") == 0) return e->dag.ok ? e->dag.blocks : 0;
     if (std::strcmp(name, "dag_tiles") == 0) return e->dag.ok ? int64_t(e->dag.tiles.size()) : 0;
     if (std::strcmp(name, "dag_stream") == 0) return e->dag.ok && e->dag.stream ? 1 : 0;
+    if (std::strcmp(name, "lw_small") == 0) return e->lw.ready && e->lw.small ? 1 : 0;   // (known after the first sampler call)
     if (std::strcmp(name, "dag_aborts") == 0) return e->dag_aborts;
     if (std::strcmp(name, "small_eligible") == 0) return e->small.ok ? 1 : 0;
     if (std::strcmp(name, "small_waves") == 0) return e->small.ok ? e->small.waves : 0;

@@ -563,6 +563,7 @@ def leg_lw(a, local_rank, torch):
             eng.lw_run(ev, a.samples, seed=1, sample_begin=(i + 2) * a.samples)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        small_kernel = bool(eng.info("lw_small"))
     rate = a.samples * steps / dt
     # What bounds the sampler: not HBM (the CPTs are cache-resident) but the vector ALU and the row gathers.  The
     # bound reported is VALU ISSUE: vector instructions per second (SQ_INSTS_VALU of the committed counter pass, per sample, x the
@@ -570,10 +571,10 @@ def leg_lw(a, local_rank, torch):
     bytes_per_sample = d.n * 2 + d.n_edges   # state written, parents' states read, re-read by the histogram pass (informational)
     peak_ginst = 256 * 4 * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_INST    # G wave-instructions / s
     roof = {"bound": "valu", "peak": peak_ginst, "unit": "G wave-instructions/s", "achieved": None, "frac": None,
-            "kernel": "lw_sample_kernel + lw_hist_kernel", "hbm_algorithmic_bytes_per_sample": bytes_per_sample,
+            "kernel": ("lw_sample_small_kernel" if small_kernel else "lw_sample_kernel") + " + lw_hist_kernel", "hbm_algorithmic_bytes_per_sample": bytes_per_sample,
             "hbm_algorithmic_gbs": rate * bytes_per_sample / 1e9,
-            "note": "VALU-issue bound: SQ_INSTS_VALU per sample (committed SQ pass) x measured samples/s over the chip's issue rate; "
-                    "the 16-byte row gathers (one per draw) are the co-limiter (DESIGN.md section 4.6)"}
+            "note": "VALU-issue bound: SQ_INSTS_VALU per sample (committed SQ pass, sampling + histogram kernels) x measured samples/s over "
+                    "the chip's issue rate (DESIGN.md section 4.6)"}
     roof.update(profiled_traffic("lw"))
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -581,9 +582,11 @@ def leg_lw(a, local_rank, torch):
             dd = json.load(open(os.path.join(pdir, name)))
             sq = dd.get("lw_sq_counters_per_launch") or {}
             per_launch = dd.get("lw_samples_per_launch")
+            hq = dd.get("lw_hist_sq_counters_per_launch") or {}
             if sq.get("SQ_INSTS_VALU") and per_launch:
-                # (the counters are those of the sample kernel's launches; the histogram kernel adds ~8 instructions per node-sample)
-                inst_per_sample = sq["SQ_INSTS_VALU"] / per_launch
+                inst_per_sample = (sq["SQ_INSTS_VALU"] + hq.get("SQ_INSTS_VALU", 0.0)) / per_launch   # (both kernels run once per launch of samples)
+                roof["valu_insts_per_sample_sampler"] = sq["SQ_INSTS_VALU"] / per_launch
+                roof["valu_insts_per_sample_histogram"] = hq.get("SQ_INSTS_VALU", 0.0) / per_launch
                 roof.update({"valu_insts_per_sample": inst_per_sample, "valu_insts_per_node_sample_lane": inst_per_sample * 64 / d.n,
                              "achieved": rate * inst_per_sample / 1e9, "frac": rate * inst_per_sample / 1e9 / peak_ginst,
                              "valu_source": f"profiles/{name}",

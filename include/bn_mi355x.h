@@ -243,7 +243,7 @@ int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
  * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
- * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path"; unknown name: BN_ERR_ARG.
+ * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path", "lw_small" (1 once a sampler call has run: the straight-line sampling kernel for networks whose every node has <= 4 parents, <= 256 CPT rows and <= 4 states is in use); unknown name: BN_ERR_ARG.
  * When a one-launch path gives up a bounded wait (its workgroups were not all on the chip: another engine, stream or process uses the
  * GPU) the run is repeated on a slower path; the first such event of an engine prints ONE line on stderr, all are counted. */
 int64_t bn_get_info(bn_engine *eng, const char *name);
@@ -281,7 +281,8 @@ int bn_bp_last_stats(bn_engine *eng, bn_bp_stats *out);
  * Returns the UN-normalised weighted histogram [sum k] (node-major) of samples
  * [sample_begin, sample_begin + n_samples) so that several GPUs / calls can be summed; the
  * caller applies the reference's normalise rule (:197-221).  Every sample id owns one
- * xoshiro128++ stream seeded by a Philox4x32-10 block keyed by (`seed`, sample id) (the reference seeds an mt19937 from std::random_device, :224-244).
+ * xoshiro128++ stream seeded by a Philox4x32-10 block keyed by (`seed`, sample id) and advanced by one step per topological position
+ * (oracle/lw_oracle.c states the mapping; the reference seeds an mt19937 from std::random_device, :224-244).
  */
 int bn_lw_run(bn_engine *eng, int32_t ne, const int32_t *ev_node, const int32_t *ev_state,
               uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double *hist_out);

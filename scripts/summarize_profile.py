@@ -18,7 +18,7 @@ import statistics
 import sys
 
 DOMINANT = {"grid316": ["bp_resident_kernel"], "grid316_launch": ["bp_sweep_kernel"], "dag10k": ["bp_dag_kernel"], "dag10k_launch": ["bp_sweep_kernel"],
-            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample_kernel", "lw_hist_kernel"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"]}
+            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist_kernel"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"]}
 
 
 def rows_of(path, pattern):
@@ -120,6 +120,16 @@ def main():
                     sq[name] = v
         if sq:
             summary[f"{label}_sq_counters_per_launch"] = sq
+        if label == "lw":   # the histogram pass is part of a sample's cost: its counters beside the sampler's
+            hq = {}
+            for sq_dir in (os.path.join(src, "sq_lw"), os.path.join(src, "sq2_lw")):
+                if os.path.isdir(sq_dir):
+                    for name in sorted({r["Counter_Name"] for r in rows_of(sq_dir, "*counter_collection.csv")}):
+                        v = counter_per_launch(sq_dir, "lw_hist_kernel", name)
+                        if v is not None:
+                            hq[name] = v
+            if hq:
+                summary["lw_hist_sq_counters_per_launch"] = hq
         log = os.path.join(src, f"trace_{label}.log")
         if os.path.exists(log):
             lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
@@ -131,7 +141,7 @@ def main():
                 if label == "lw":   # samples one launch of the sample kernel draws (a call is cut into launches of at most 32 GiB of states)
                     import re
                     m = re.search(r"(\d+) samples per call", summary[f"{label}_bench_line"].get("config", {}).get("workload", ""))
-                    launches = (summary.get("lw_lw_sample_kernel") or {}).get("launches")
+                    launches = (summary.get("lw_lw_sample") or {}).get("launches")
                     steps = summary[f"{label}_bench_line"].get("steps")
                     if m and launches and steps:
                         summary["lw_samples_per_launch"] = int(m.group(1)) * (steps + 2) / launches   # (+ 2 warm-up calls)
