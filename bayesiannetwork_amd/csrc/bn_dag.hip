@@ -60,11 +60,14 @@ __device__ __forceinline__ void dag_st4(__amdgpu_buffer_rsrc_t r, int64_t idx2, 
     dag_st(r, idx2 + 1, b);
 }
 
-struct DagShared {
+struct DagSetShared {                    // per evidence set of the launch
     unsigned long long slot[kDagWaves];  // per-wave residual bit patterns
     int verdict;
     unsigned long long t_arrive;         // 100 MHz clock when this block published its granules
     int skew_ticks;                      // how long after this block the LAST block arrived in the previous iteration (10 ns ticks)
+};
+struct DagShared {
+    DagSetShared set[kDagMaxSets];
     // per wave: 128 16-byte units through which the lanes of a lane group / of a node's parent items hand each other the records
     // they loaded -- one vector-memory instruction per lane and iteration instead of one per record and lane (a CU's eight waves
     // share ONE texture-address pipe at 64 bytes per cycle: with every lane requesting all of its node's records that pipe,
@@ -84,7 +87,7 @@ __device__ __forceinline__ int dag_verdict_of(const DagArgs& a, double r, int n_
 }
 
 // ---- grid barrier (bn_resident.hip's direct form) ------------------------------------------------------------------
-__device__ __forceinline__ void dag_arrive(const DagArgs& a, DagShared& sh, int it, int s, double wres, int lane, int wave) {
+__device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it, int s, double wres, int lane, int wave) {
     const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
     if (lane == 0) sh.slot[wave] = bits;
     DSTAMP(3, it);
@@ -96,7 +99,7 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, DagShared& sh, int 
         unsigned long long m = 0;
         for (int w = 0; w < kDagWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
         if (a.n_blocks == 1) {
-            a.sync->res[it] = m;
+            sync->res[it] = m;
             sh.verdict = dag_verdict_of(a, dag_residual_of(m), s + 1);
         } else {
             // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
@@ -108,7 +111,7 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, DagShared& sh, int 
             // before the last granule becomes visible costs the block a whole second trip (fixed delays, config 2: 7.5 -> 6.6 us
             // per sweep).
             const unsigned gen = a.gen_base + unsigned(it) + 1u;
-            unsigned long long* g = (it & 1) ? a.sync->blk_odd[blockIdx.x] : a.sync->blk[blockIdx.x];
+            unsigned long long* g = (it & 1) ? sync->blk_odd[blockIdx.x] : sync->blk[blockIdx.x];
             const unsigned long long now = wall_clock64();
             sh.t_arrive = now;
             __hip_atomic_store(g, ((unsigned long long)gen << 32) | unsigned(m >> 32), RLX_AGENT);
@@ -149,13 +152,13 @@ __device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl
     return mine;
 }
 
-__device__ __forceinline__ int dag_wait(const DagArgs& a, DagShared& sh, int it) {
+__device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it) {
     if (a.n_blocks > 1 && threadIdx.x < kWave) {
         int lane = int(threadIdx.x);
         asm volatile("" : "+v"(lane));  // (keeps the per-lane granule addresses out of the iteration loop's live registers)
         const unsigned gen = a.gen_base + unsigned(it) + 1u;
         const int nb = a.n_blocks;
-        const unsigned long long* tbl = (it & 1) ? &a.sync->blk_odd[0][0] : &a.sync->blk[0][0];
+        const unsigned long long* tbl = (it & 1) ? &sync->blk_odd[0][0] : &sync->blk[0][0];
         unsigned long long m = 0;
         bool ok = true;
         const unsigned long long t0 = wall_clock64();
@@ -184,7 +187,7 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, DagShared& sh, int it)
         }
         m = wave_umax64_dpp(m);
         if (lane == 0) {
-            if (blockIdx.x == 0 && ok) __hip_atomic_store(&a.sync->res[it], m, RLX_AGENT);
+            if (blockIdx.x == 0 && ok) __hip_atomic_store(&sync->res[it], m, RLX_AGENT);
             sh.verdict = ok ? dag_verdict_of(a, dag_residual_of(m), a.sweep_begin + it + 1) : kDagAbort;
         }
     }
@@ -195,45 +198,57 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, DagShared& sh, int it)
 // The launch's loop over iterations.  phase(s): one sweep of this wave's tile(s), returns the wave's share of
 // maximum_difference; finalize(n, done): the run stopped after n sweeps (done = kDagConverged / kDagCapped) or the launch's
 // budget ran out (done = 0).  false: a bounded wait gave up.
+// Several evidence sets (bn_bp_run_batch): the sets take turns inside an iteration -- sweep of set A, arrival at A's barrier, sweep
+// of set B, arrival at B's, ... -- so the ~3.4 us a barrier needs to complete are spent on the other sets' sweeps, and ONE set of CPT
+// registers serves them all.  Every set has its own state, marks, barrier words, residual history and control block, and stops
+// on the sweep its single run stops on (same arithmetic: same bits).
 template <class Phase, class Finalize>
 __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int lane, int wave, Phase&& phase, Finalize&& finalize) {
-    for (int it = 0; it <= a.budget; ++it) {  // the pass it == budget only collects the verdict
+    unsigned live = a.set_mask;
+    for (int it = 0; it <= a.budget && live != 0; ++it) {  // the pass it == budget only collects the verdicts
         const int s = a.sweep_begin + it;
-        int v = kDagGoOn;
-        DSTAMP(0, it);
-        if (it > 0) {
-            v = dag_wait(a, sh, it - 1);
-            if (v == kDagAbort) return false;
-        }
-        DSTAMP(1, it);
-        if (v != kDagGoOn || it == a.budget) {
-            const int done = v != kDagGoOn ? v : 0;
-            finalize(s, done);
-            if (blockIdx.x == 0 && wave == 0) {  // report: residual history, outcome
-                int q0 = lane;
-                asm volatile("" : "+v"(q0));
-                for (int q = q0; q < it; q += kWave)
-                    if (a.sweep_begin + q < a.b.res_cap)
-                        a.b.res_hist[a.sweep_begin + q] = dag_residual_of(__hip_atomic_load(&a.sync->res[q], RLX_AGENT));
-                if (lane == 0) {
-                    Ctl* hc = a.host_ctl;
-                    hc->last_res = it > 0 ? dag_residual_of(__hip_atomic_load(&a.sync->res[it - 1], RLX_AGENT)) : 0.0;
-                    hc->n_sweeps = s;
-                    hc->run_id = a.run_id;
-                    hc->done = done;
-                }
+        for (int q = 0; q < a.n_sets; ++q) {
+            if (((live >> q) & 1u) == 0) continue;
+            ResidentSync* sync = a.sync + q;
+            DagSetShared& ss = sh.set[q];
+            int v = kDagGoOn;
+            DSTAMP(0, it);
+            if (it > 0) {
+                v = dag_wait(a, sync, ss, it - 1);
+                if (v == kDagAbort) return false;
             }
-            return true;
+            DSTAMP(1, it);
+            if (v != kDagGoOn || it == a.budget) {
+                const int done = v != kDagGoOn ? v : 0;
+                finalize(q, s, done);
+                if (blockIdx.x == 0 && wave == 0) {  // report: residual history, outcome
+                    int q0 = lane;
+                    asm volatile("" : "+v"(q0));
+                    double* hist = a.b.res_hist + int64_t(q) * a.res_hist_stride;
+                    for (int x = q0; x < it; x += kWave)
+                        if (a.sweep_begin + x < a.b.res_cap)
+                            hist[a.sweep_begin + x] = dag_residual_of(__hip_atomic_load(&sync->res[x], RLX_AGENT));
+                    if (lane == 0) {
+                        Ctl* hc = a.host_ctl + q;
+                        hc->last_res = it > 0 ? dag_residual_of(__hip_atomic_load(&sync->res[it - 1], RLX_AGENT)) : 0.0;
+                        hc->n_sweeps = s;
+                        hc->run_id = a.run_id;
+                        hc->done = done;
+                    }
+                }
+                live &= ~(1u << q);
+                continue;
+            }
+            const double wres = phase(q, s);
+            dag_arrive(a, sync, ss, it, s, wres, lane, wave);
+            DSTAMP(6, it);
         }
-        const double wres = phase(s);
-        dag_arrive(a, sh, it, s, wres, lane, wave);
-        DSTAMP(6, it);
     }
     return true;
 }
 
 // belief = normalize(pi % lambda) (:151-158) of `node` from the state after n sweeps
-__device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int node, int n) {
+__device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int node, int n, double* beliefs) {
     double pv[4], lv[4], bel[4];
     dag_ld4(rs, dag_off_npi(a.E, a.n, n & 1, node), pv);
     dag_ld4(rs, dag_off_nlam(a.E, a.n, n & 1, node), lv);
@@ -241,7 +256,15 @@ __device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsr
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bel[i] = pv[i] * lv[i]; sum += bel[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a.b.beliefs[int64_t(node) * 4 + i] = bel[i] / sum;
+    for (int i = 0; i < 4; ++i) beliefs[int64_t(node) * 4 + i] = bel[i] / sum;
+}
+
+// bit q: `node` carries set q's evidence mark (a single query: bit 0)
+__device__ __forceinline__ unsigned dag_frozen_bits(const DagArgs& a, bool active, int node) {
+    unsigned bits = 0;
+    if (active)
+        for (int q = 0; q < a.n_sets; ++q) bits |= (a.frz[int64_t(q) * a.frz_stride + node] == a.frz_mark ? 1u : 0u) << q;
+    return bits;
 }
 
 // ---- child tile, at most two parents: one lane per node, the reference's operation order (bn_tiles.hpp tile_uniform) ----
@@ -250,13 +273,15 @@ struct DagChildU {
     static constexpr int K = 4, C = ipow(K, M), S = K * C, CB = (M > 0) ? C / K : 0;
     int node, ebase;
     bool active, frozen;
+    unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
+    __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
     double cpt[S];  // entry cond * 4 + i
     __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
         const DagChildLane cl = a.cnode[t.lane_base + lane];
         active = cl.node >= 0;
         node = active ? cl.node : 0;  // idle lanes shadow node 0 and store nothing
         ebase = active ? cl.ebase : 0;
-        frozen = active && a.frz[node] == a.frz_mark;
+        frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
         const double2_t* cp = reinterpret_cast<const double2_t*>(a.cpt_img) + t.cpt_base + lane;
 #pragma unroll
         for (int q = 0; q < S / 2; ++q) {
@@ -344,8 +369,8 @@ struct DagChildU {
         }
         return active ? wres : 0.0;
     }
-    __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n) {
-        if (active) dag_belief(a, rs, node, n);
+    __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n, double* beliefs) {
+        if (active) dag_belief(a, rs, node, n, beliefs);
     }
 };
 
@@ -386,6 +411,8 @@ struct DagChildG {
     static_assert(G >= M + 1, "a group has a lane per finished vector");
     int node, ebase, nl, g;
     bool active, frozen;
+    unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
+    __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
     double cpt[64];  // entry (c * 4 + d) * 4 + i
     __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
         const DagChildLane cl = a.cnode[t.lane_base + lane];
@@ -393,7 +420,7 @@ struct DagChildG {
         active = cl.node >= 0;
         node = active ? cl.node : 0;
         ebase = active ? cl.ebase : 0;
-        frozen = active && a.frz[node] == a.frz_mark;
+        frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
         const double2_t* cp = reinterpret_cast<const double2_t*>(a.cpt_img) + t.cpt_base + lane;
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
@@ -533,8 +560,8 @@ struct DagChildG {
         }
         return wres;
     }
-    __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n) {
-        if (active && g == 0) dag_belief(a, rs, node, n);
+    __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n, double* beliefs) {
+        if (active && g == 0) dag_belief(a, rs, node, n, beliefs);
     }
 };
 
@@ -544,6 +571,8 @@ struct DagParent {
     static constexpr int K = 4, RC = kDagRegChildren;
     int node, tedge, obeg, deg, tpos, dmax;
     bool active, frozen;
+    unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
+    __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
     int oe[RC];  // the first out-edges' CSR ids
     __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
         const DagParentLane it = a.pitem[t.lane_base + lane];
@@ -554,7 +583,7 @@ struct DagParent {
         deg = active ? (it.deg_tpos & 0xffff) : 0;
         tpos = it.deg_tpos >> 16;  // (0xffff for the lambda(v) item: no child is left out)
         dmax = t.dmax;
-        frozen = active && a.frz[node] == a.frz_mark;
+        frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
 #pragma unroll
         for (int x = 0; x < RC; ++x) oe[x] = (x < deg) ? a.oedge[obeg + x] : 0;
     }
@@ -633,6 +662,8 @@ struct DagParentX {
     static constexpr int K = 4;
     int node, tedge, deg, tpos, first_lane, dmax, lane;
     bool active, frozen;
+    unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
+    __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
     __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane_) {
         const DagParentLane it = a.pitem[t.lane_base + lane_];
         lane = lane_;
@@ -643,7 +674,7 @@ struct DagParentX {
         tpos = active ? (it.deg_tpos >> 16) : -1;   // -1: the lambda(v) item, the first of its node's lanes
         first_lane = lane - (tpos + 1);
         dmax = t.dmax;
-        frozen = active && a.frz[node] == a.frz_mark;
+        frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
         const bool first = s == 0;
@@ -728,42 +759,49 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     __shared__ DagShared sh;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.host_ctl->t_first = wall_clock64();
-    if (threadIdx.x == 0) { sh.skew_ticks = 0; sh.t_arrive = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long now = wall_clock64();
+        for (int q = 0; q < a.n_sets; ++q) a.host_ctl[q].t_first = now;
+    }
+    if (threadIdx.x < kDagMaxSets) { sh.set[threadIdx.x].skew_ticks = 0; sh.set[threadIdx.x].t_arrive = 0; }
     const int slot = blockIdx.x * kDagWaves + wave;
     const int t0 = a.slot_ptr[slot], t1 = a.slot_ptr[slot + 1];
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(a.state, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
+    auto rs_of = [&](int q) {   // set q's state
+        return __builtin_amdgcn_make_buffer_rsrc(a.state + int64_t(q) * a.state_stride, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
+    };
+    auto beliefs_of = [&](int q) { return a.b.beliefs + int64_t(q) * a.belief_stride; };
     bool ok = true;
     if (t1 <= t0) {
-        ok = dag_drive(a, sh, lane, wave, [](int) { return 0.0; }, [](int, int) {});
+        ok = dag_drive(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int) {});
     } else if constexpr (STREAM) {
         ok = dag_drive(a, sh, lane, wave,
-                       [&](int s) {
+                       [&](int q, int s) {
                            double w = 0.0;
+                           const __amdgpu_buffer_rsrc_t rs = rs_of(q);
                            for (int t = t0; t < t1; ++t) {
                                const DagTile td = a.tiles[t];
-                               dag_with_tile(a, td, lane, [&](auto& st) { w = res_acc(w, st.sweep(a, rs, s, sh.xch[wave])); });
+                               dag_with_tile(a, td, lane, [&](auto& st) { st.turn(q); w = res_acc(w, st.sweep(a, rs, s, sh.xch[wave])); });
                            }
                            return w;
                        },
-                       [&](int n, int done) {
+                       [&](int q, int n, int done) {
                            if (done == 0) return;
+                           const __amdgpu_buffer_rsrc_t rs = rs_of(q);
                            for (int t = t0; t < t1; ++t) {
                                const DagTile td = a.tiles[t];
                                if (td.kind >= kDagParent) continue;
                                dag_with_tile(a, td, lane, [&](auto& st) {
-                                   if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) st.belief(a, rs, n);
+                                   if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) st.belief(a, rs, n, beliefs_of(q));
                                });
                            }
                        });
     } else {
         const DagTile td = a.tiles[t0];
         dag_with_tile(a, td, lane, [&](auto& st) {
-            ok = dag_drive(a, sh, lane, wave, [&](int s) { return st.sweep(a, rs, s, sh.xch[wave]); },
-                           [&](int n, int done) {
+            ok = dag_drive(a, sh, lane, wave, [&](int q, int s) { st.turn(q); return st.sweep(a, rs_of(q), s, sh.xch[wave]); },
+                           [&](int q, int n, int done) {
                                if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) {
-                                   if (done != 0) st.belief(a, rs, n);
+                                   if (done != 0) st.belief(a, rs_of(q), n, beliefs_of(q));
                                }
                            });
         });
@@ -771,8 +809,11 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     // a block that gave up a bounded wait says so itself: block 0 may long have reported its own outcome
     if (!ok && threadIdx.x == 0 && a.host_abort) __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.host_ctl->t_last = wall_clock64();
-        if (!ok) { a.host_ctl->run_id = a.run_id; a.host_ctl->done = -1; }
+        const unsigned long long now = wall_clock64();
+        for (int q = 0; q < a.n_sets; ++q) {
+            a.host_ctl[q].t_last = now;
+            if (!ok) { a.host_ctl[q].run_id = a.run_id; a.host_ctl[q].done = -1; }
+        }
     }
 }
 

@@ -33,7 +33,8 @@ constexpr int kDagWaves = 8;            // per block: two per SIMD, 256 VGPRs ea
 constexpr int kDagMaxBlocks = kResidentMaxBlocks;  // one granule pair per block, four pairs per polling lane
 constexpr int kDagBudget = kResidentBudget;        // iterations per launch (ResidentSync::res)
 constexpr int kDagMaxParents = 5;
-constexpr int kDagRegChildren = 8;      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
+constexpr int kDagRegChildren = 8;
+constexpr int kDagMaxSets = 8;      // evidence sets one launch can walk (bn_bp_run_batch): per-set state, marks, barrier words; the CPT registers serve all      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
 
 enum : int32_t { kDagChild0 = 0, /* 1..5: child tile of nodes with that many parents */ kDagParent = 8, kDagParentWide = 9 };
 
@@ -95,6 +96,13 @@ struct DagArgs {
     uint8_t frz_mark;
     int32_t poll_sleep;       // pause between two polls of the barrier, x 64 cycles
     int32_t first_poll_delay; // ... and between a block's arrival and its first poll
+    // several evidence sets per launch (n_sets > 1; a single query: n_sets = 1, strides unused): set q's state at state + q * state_stride
+    // (doubles), its marks at frz + q * frz_stride, its barrier words in sync[q], its control block host_ctl[q], its marginals at
+    // b.beliefs + q * belief_stride, its residual history at b.res_hist + q * res_hist_stride
+    int32_t n_sets;
+    uint32_t set_mask;
+    int64_t state_stride, frz_stride, belief_stride;
+    int32_t res_hist_stride;
 };
 struct DagEvidenceArgs {
     int32_t ne, n, E;

@@ -198,6 +198,14 @@ struct bn_engine {
         bool sync_dirty = true;
         uint32_t gen_base = 0;
         double* d_s_state = nullptr;  // one-workgroup path (bn_small.hip): [cap_sets][2 M + 2 N]
+        // register-resident DAG path (bn_dag.hip), several sets per launch: [dag_sets] states, marks, barrier words (allocated at first use)
+        double* d_g_state = nullptr;
+        uint8_t* d_g_frz = nullptr;
+        ResidentSync* d_g_sync = nullptr;
+        int32_t dag_sets = 0;
+        uint8_t dag_mark = 0;
+        bool dag_sync_dirty = true;
+        uint32_t dag_gen_base = 0;
         bool ev_deferred = false;     // the sets' evidence sits in d_ev only (read there by that kernel); d_ev_meta: per set {count, first node / offset / value}
         int32_t* d_ev_meta = nullptr;   // (inside the staging block)
         char* h_ev = nullptr;           // small networks: the staging block is page-locked host memory the kernels read in place
@@ -329,7 +337,8 @@ static void free_engine(bn_engine* e) {
                         e->d_m_init, e->d_m_nodeoff, e->d_m_msgfirst, e->d_m_state, e->d_m_frz, e->d_m_sync,
                         e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
-                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state};
+                        e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state,
+                        e->batch.d_g_state, e->batch.d_g_frz, e->batch.d_g_sync};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (e->h_ctl) (void)hipHostFree(e->h_ctl);
@@ -1225,6 +1234,7 @@ static int run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
         a.poll_sleep = poll_sleep;
         static const int first_delay = std::getenv("BN_DAG_DELAY") ? std::atoi(std::getenv("BN_DAG_DELAY")) : 30;   // 10 ns ticks: measured flat from 20 to 60 (config 2: 6.9 us per sweep at 0, 6.5-6.6 there)
         a.first_poll_delay = first_delay;
+        a.n_sets = 1; a.set_mask = 1u;
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -1557,7 +1567,7 @@ static int batch_reserve(bn_engine* e, int32_t n_sets) {
     const Plan& p = e->plan;
     HIPCHK(hipStreamSynchronize(e->stream));
     void* old[] = {bt.d_rec[0], bt.d_rec[1], bt.d_node[0], bt.d_node[1], bt.d_frozen, bt.d_beliefs, bt.d_res_hist, bt.d_sync, bt.d_ctl, bt.d_s_state,
-                   bt.d_ev};
+                   bt.d_ev, bt.d_g_state, bt.d_g_frz, bt.d_g_sync};
     if (bt.h_ev) (void)hipHostFree(bt.h_ev);
     if (bt.h_beliefs) (void)hipHostFree(bt.h_beliefs);
     for (void* q : old)
@@ -2020,18 +2030,123 @@ static int run_batch_mid(bn_engine* e, double eps, int32_t max_sweeps) {
 // The register-resident DAG path (bn_dag.hip) answers a batch one set after another: every set is a single query's launch -- the
 // same kernel, the same bits -- reading its evidence from the batch's staging block and writing its marginals and residual history
 // into the set's slots.  BN_ERR_STATE: a grid wait gave up.
+// Sets [first, first + count) of the batch in ONE launch of the register-resident DAG kernel: the sets take turns inside an
+// iteration, so a set's barrier completes while the others sweep, and one set of CPT registers serves them all (bn_dag.hip,
+// dag_drive).  Every set has its own state, marks, barrier words, residual history and control block and keeps the bits and the
+// sweep count of its single run.  left[q] = true: set q did not finish here (more than kDagBudget sweeps) and is run on its own.
+// BN_ERR_STATE: a grid wait gave up.
+static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int32_t first, int32_t count, std::vector<char>& left,
+                               int32_t& launches, double& dev_ms, int32_t& max_sw) {
+    bn_engine::Batch& bt = e->batch;
+    const Plan& p = e->plan;
+    const DagPlan& dp = e->dag;
+    hipStream_t s = e->stream;
+    const size_t state_d = size_t(dag_state_doubles(dp.E, dp.n));
+    if (bt.dag_sets < kDagMaxSets) {   // first use: every set's state, marks and barrier words
+        int r;
+        if ((r = dalloc(&bt.d_g_state, state_d * kDagMaxSets))) return r;
+        if ((r = dalloc(&bt.d_g_frz, size_t(dp.n) * kDagMaxSets))) return r;
+        if ((r = dalloc(&bt.d_g_sync, size_t(kDagMaxSets)))) return r;
+        HIPCHK(hipMemsetAsync(bt.d_g_state, 0, state_d * kDagMaxSets * sizeof(double), s));
+        HIPCHK(hipMemsetAsync(bt.d_g_frz, 0, size_t(dp.n) * kDagMaxSets, s));
+        bt.dag_sets = kDagMaxSets;
+        bt.dag_mark = 0;
+        bt.dag_sync_dirty = true;
+    }
+    if (bt.dag_mark == 255) {  // the mark values are used up: start over
+        HIPCHK(hipMemsetAsync(bt.d_g_frz, 0, size_t(dp.n) * kDagMaxSets, s));
+        bt.dag_mark = 0;
+    }
+    ++bt.dag_mark;
+    for (int32_t q = 0; q < count; ++q) {   // pi(v) = lambda(v) = the given vector in both buffers, node marked (:68-73)
+        const int32_t g = first + q;
+        DagEvidenceArgs ea{bt.ne[g], dp.n, dp.E, reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[g],
+                           reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[g],
+                           reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[g], bt.d_g_state + size_t(q) * state_d,
+                           bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark};
+        if (int code = launch_dag_evidence(ea, s))
+            return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
+    if (bt.dag_sync_dirty || bt.dag_gen_base > (1u << 29)) {
+        HIPCHK(hipMemsetAsync(bt.d_g_sync, 0, sizeof(ResidentSync) * size_t(kDagMaxSets), s));
+        bt.dag_sync_dirty = false;
+        bt.dag_gen_base = 0;
+    }
+    ++e->run_id;
+    if (e->run_id == 0) e->run_id = 1;
+    *e->h_abort = 0;
+    DagArgs a{};
+    a.b = buffers_of(e);
+    a.b.beliefs = bt.d_beliefs + size_t(first) * p.node_off[p.n];
+    a.b.res_hist = bt.d_res_hist + size_t(first) * e->res_cap;
+    a.eps = eps; a.max_sweeps = max_sweeps; a.sweep_begin = 0; a.budget = kDagBudget; a.run_id = e->run_id;
+    a.gen_base = bt.dag_gen_base;
+    a.timeout_ticks = 5000000ull;
+    a.sync = bt.d_g_sync; a.host_ctl = bt.h_ctl_dev + first; a.host_abort = e->h_abort_dev;
+    a.n = dp.n; a.E = dp.E; a.n_blocks = dp.blocks;
+    a.tiles = e->d_g_tiles; a.slot_ptr = e->d_g_slotptr; a.cnode = e->d_g_cnode; a.pitem = e->d_g_pitem; a.oedge = e->d_g_oedge;
+    a.cpt_img = e->d_g_cpt; a.npi_init = e->d_g_init; a.state = bt.d_g_state; a.frz = bt.d_g_frz; a.frz_mark = bt.dag_mark;
+    static const int poll_sleep = std::getenv("BN_DAG_SLEEP") ? std::atoi(std::getenv("BN_DAG_SLEEP")) : 1;
+    static const int first_delay = std::getenv("BN_DAG_DELAY") ? std::atoi(std::getenv("BN_DAG_DELAY")) : 30;
+    a.poll_sleep = poll_sleep;
+    a.first_poll_delay = first_delay;
+    a.n_sets = count; a.set_mask = (1u << count) - 1u;
+    a.state_stride = int64_t(state_d); a.frz_stride = dp.n; a.belief_stride = p.node_off[p.n]; a.res_hist_stride = e->res_cap;
+    for (int32_t q = 0; q < count; ++q) bt.h_ctl[first + q].run_id = 0;
+    if (int code = launch_bp_dag(a, dp.stream, s))
+        return fail(BN_ERR_HIP, std::string("bp_dag launch failed: ") + hipGetErrorString(hipError_t(code)));
+    HIPCHK(hipStreamSynchronize(s));
+    ++launches;
+    bt.dag_gen_base += kDagBudget + 1;
+    bool gave_up = *e->h_abort != 0, stale = false;
+    for (int32_t q = 0; q < count; ++q) {
+        gave_up = gave_up || bt.h_ctl[first + q].done < 0;
+        stale = stale || bt.h_ctl[first + q].run_id != e->run_id;
+    }
+    if (gave_up || stale) bt.dag_sync_dirty = true;
+    if (gave_up) {
+        *e->h_abort = 0;
+        return fail(BN_ERR_STATE, "a block of the register-resident DAG kernel gave up its grid wait");
+    }
+    if (stale) return fail(BN_ERR_HIP, "bp_dag kernel did not report (stale control block)");
+    dev_ms += double(bt.h_ctl[first].t_last - bt.h_ctl[first].t_first) * 1e-5;
+    for (int32_t q = 0; q < count; ++q) {
+        const Ctl& c = bt.h_ctl[first + q];
+        if (c.done == 0) { left[first + q] = 1; continue; }   // the budget of one launch ran out: this set goes on alone
+        bt.sweeps[first + q] = c.n_sweeps;
+        bt.residual[first + q] = c.last_res;
+        max_sw = std::max(max_sw, c.n_sweeps);
+    }
+    return BN_OK;
+}
+
 static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
     bn_engine::Batch& bt = e->batch;
     const Plan& p = e->plan;
+    int rc = BN_OK;
+    int32_t launches = 0, max_sw = 0;
+    double dev_ms = 0.0;
+    std::vector<char> left(size_t(bt.n_sets), 0);
+    // how many sets share a launch (BN_DAG_SETS, default 8; 1 = one after another).  Config 2, us per set-sweep at B = 16: 8.7 / 6.9 / 6.2 / 5.9
+    // with 1 / 2 / 4 / 8 sets per launch (scripts/time_dag_batch.py)
+    static const int per_launch = std::max(1, std::min(kDagMaxSets, std::getenv("BN_DAG_SETS") ? std::atoi(std::getenv("BN_DAG_SETS")) : kDagMaxSets));
+    if (per_launch > 1 && bt.n_sets > 1) {
+        for (int32_t first = 0; first < bt.n_sets && rc == BN_OK; first += per_launch)
+            rc = run_batch_dag_chunk(e, eps, max_sweeps, first, std::min(per_launch, bt.n_sets - first), left, launches, dev_ms, max_sw);
+        if (rc != BN_OK) return rc;
+    } else {
+        std::fill(left.begin(), left.end(), 1);
+    }
+    // sets left over (a run beyond one launch's budget; a batch of one): through the single-query path, one after another
     const int32_t keep_ne = e->ev_ne;
     int32_t* const keep_node = e->d_ev_node;
     int32_t* const keep_off = e->d_ev_off;
     double* const keep_val = e->d_ev_val;
     double* const keep_override = e->beliefs_override;
-    int rc = BN_OK;
-    int32_t launches = 0, max_sw = 0;
-    double dev_ms = 0.0;
+    bool any_left = false;
     for (int32_t q = 0; q < bt.n_sets && rc == BN_OK; ++q) {
+        if (!left[q]) continue;
+        any_left = true;
         e->ev_ne = bt.ne[q];
         e->d_ev_node = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[q];
         e->d_ev_off = reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[q];
@@ -2049,10 +2164,12 @@ static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
         dev_ms += e->stats.sweep_devclock_ms;
         max_sw = std::max(max_sw, e->last_ctl.n_sweeps);
     }
-    // the single-query evidence in force is what the engine's own staging block holds: applied again at its next run
-    e->ev_ne = keep_ne; e->d_ev_node = keep_node; e->d_ev_off = keep_off; e->d_ev_val = keep_val;
-    e->dag_ev_applied = false;
-    e->beliefs_override = keep_override;
+    if (any_left) {
+        // the single-query evidence in force is what the engine's own staging block holds: applied again at its next run
+        e->ev_ne = keep_ne; e->d_ev_node = keep_node; e->d_ev_off = keep_off; e->d_ev_val = keep_val;
+        e->dag_ev_applied = false;
+        e->beliefs_override = keep_override;
+    }
     if (rc != BN_OK) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
     bt.predicted_sweeps = max_sw;

@@ -164,3 +164,32 @@ def test_dag_100k_nodes_stream_form(Engine, oracle_mod):
         eng.set_option("dag", 0)
         r0 = eng.bp_run(ev, 1e-4)
         assert eng.last_path() == 0 and r0["sweeps"] == o["sweeps"] and np.abs(r0["beliefs"] - r["beliefs"]).max() < 1e-12
+
+
+def test_dag_batch_shares_launches(Engine, oracle_mod):
+    """Several sets per launch (the sets take turns inside an iteration; up to 8 share the CPT registers): 11 sets = two launches, sets
+    that stop on different sweeps, caps; every set keeps the sweep count, the bits and the residual history of its single run, and a
+    set that needs more than one launch's 1 024 iterations is finished on its own."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(600, 4, 48, 4, seed=43)
+    evs = [synth.random_evidence(g, f, seed=50 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1, 0.3, 0.02, 0.15, 0.0, 0.4, 0.07])]
+    with Engine(g) as eng:
+        singles, hists = [], []
+        for ev in evs:
+            singles.append(eng.bp_run(ev, 1e-7))
+            hists.append(eng.bp_residuals().copy())
+        assert eng.last_path() == 5
+        out = eng.bp_run_batch(evs, 1e-7)
+        assert eng.last_path() == 5 and eng.info("dag_aborts") == 0 and eng.bp_stats()["sweep_launches"] == 2
+        assert len(set(out["sweeps"].tolist())) > 1
+        for q, r in enumerate(singles):
+            assert out["sweeps"][q] == r["sweeps"] and np.array_equal(out["beliefs"][q], r["beliefs"]), q
+            assert np.array_equal(eng.bp_residuals_batch(q), hists[q]) and out["residual"][q] == r["residual"], q
+        capped = eng.bp_run_batch(evs[:3], 0.0, 5)
+        assert capped["sweeps"].tolist() == [5, 5, 5]
+        for q in range(3):
+            assert np.array_equal(capped["beliefs"][q], eng.bp_run(evs[q], 0.0, 5)["beliefs"])
+        long = eng.bp_run_batch(evs[:2], 0.0, 1030)      # beyond a launch's budget: the sets go on alone
+        for q in range(2):
+            r = eng.bp_run(evs[q], 0.0, 1030)
+            assert long["sweeps"][q] == 1030 == r["sweeps"] and np.array_equal(long["beliefs"][q], r["beliefs"])
