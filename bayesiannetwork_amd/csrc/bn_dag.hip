@@ -65,6 +65,8 @@ struct DagSetShared {                    // per evidence set of the launch
     int verdict;
     unsigned long long t_arrive;         // 100 MHz clock when this block published its granules
     int skew_ticks;                      // how long after this block the LAST block arrived in the previous iteration (10 ns ticks)
+    int arrived;                         // waves of the block that have finished the set's sweep in hand (the last one publishes)
+    int pub_it;                          // the iteration whose granules the block has published
 };
 struct DagShared {
     DagSetShared set[kDagMaxSets];
@@ -87,37 +89,61 @@ __device__ __forceinline__ int dag_verdict_of(const DagArgs& a, double r, int n_
 }
 
 // ---- grid barrier (bn_resident.hip's direct form) ------------------------------------------------------------------
+// A wave that has finished its sweep of a set does NOT wait for the block's other waves: it counts itself in (LDS) and goes on --
+// with several sets per launch to the next set's sweep; the wave that completes the count publishes the block's granules.  (With
+// a __syncthreads here every set-sweep of a batch cost the block's SLOWEST wave, 5.9 us on config 2; the waves with light tiles
+// now run ahead through the other sets and wait once per set, where the verdict is needed.)
+template <bool BATCH>
 __device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it, int s, double wres, int lane, int wave) {
     const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
-    if (lane == 0) sh.slot[wave] = bits;
+    if (lane == 0) sh.slot[wave] = bits;   // (in front of the drain: the LDS write passes while the stores are waited for)
     DSTAMP(3, it);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have reached memory
     DSTAMP(4, it);
-    __syncthreads();
-    DSTAMP(5, it);
-    if (threadIdx.x == 0) {
-        unsigned long long m = 0;
-        for (int w = 0; w < kDagWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
-        if (a.n_blocks == 1) {
-            sync->res[it] = m;
-            sh.verdict = dag_verdict_of(a, dag_residual_of(m), s + 1);
-        } else {
-            // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
-            // overwrite what a slower block still has to read
-            // Second granule: {arrival time, 16 bits of the 100 MHz clock | low 16 bits of the generation (enough to tell a torn
-            // pair: a slot is reused every second generation) | residual low half}.  The arrival times let every block predict
-            // WHEN the last block will arrive in the next iteration -- the work per iteration is static -- and place its first
-            // poll there instead of polling from its own arrival on: a poll is a ~1 us round trip, and one that leaves just
-            // before the last granule becomes visible costs the block a whole second trip (fixed delays, config 2: 7.5 -> 6.6 us
-            // per sweep).
-            const unsigned gen = a.gen_base + unsigned(it) + 1u;
-            unsigned long long* g = (it & 1) ? sync->blk_odd[blockIdx.x] : sync->blk[blockIdx.x];
-            const unsigned long long now = wall_clock64();
-            sh.t_arrive = now;
-            __hip_atomic_store(g, ((unsigned long long)gen << 32) | unsigned(m >> 32), RLX_AGENT);
-            __hip_atomic_store(g + 1, ((now & 0xffffull) << 48) | ((unsigned long long)(gen & 0xffffu) << 32) | unsigned(m), RLX_AGENT);
+    // (a single query has nothing to run ahead to: a plain block barrier, thread 0 publishes -- measured 0.3-0.8 us per sweep faster
+    // there than counting the waves in)
+    constexpr bool single = !BATCH;
+    if (single) __syncthreads();
+    if (lane == 0) {
+        int before = kDagWaves - 1;
+        if (!single) {
+            before = __hip_atomic_fetch_add(&sh.arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (wave != 0) {
+            before = -1;
+        }
+        if (before == kDagWaves - 1) {   // the block's last wave (a single query: its first): every wave's stores are out, every slot is written
+            if (!single) {
+                __hip_atomic_store(&sh.arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (next used behind dag_wait's block barrier)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            // (plain loads, requested together: as eight atomic loads they were eight LDS round trips in a row on the path to the
+            // granule store -- 0.3 us per sweep)
+            unsigned long long m = 0;
+#pragma unroll
+            for (int w = 0; w < kDagWaves; ++w) m = sh.slot[w] > m ? sh.slot[w] : m;
+            if (a.n_blocks == 1) {
+                sync->res[it] = m;
+                sh.verdict = dag_verdict_of(a, dag_residual_of(m), s + 1);
+            } else {
+                // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
+                // overwrite what a slower block still has to read
+                // Second granule: {arrival time, 16 bits of the 100 MHz clock | low 16 bits of the generation (enough to tell a torn
+                // pair: a slot is reused every second generation) | residual low half}.  The arrival times let every block predict
+                // WHEN the last block will arrive in the next iteration -- the work per iteration is static -- and place its first
+                // poll there instead of polling from its own arrival on: a poll is a ~1 us round trip, and one that leaves just
+                // before the last granule becomes visible costs the block a whole second trip (fixed delays, config 2: 7.5 -> 6.6 us
+                // per sweep).
+                const unsigned gen = a.gen_base + unsigned(it) + 1u;
+                unsigned long long* g = (it & 1) ? sync->blk_odd[blockIdx.x] : sync->blk[blockIdx.x];
+                const unsigned long long now = wall_clock64();
+                sh.t_arrive = now;
+                __hip_atomic_store(g, ((unsigned long long)gen << 32) | unsigned(m >> 32), RLX_AGENT);
+                __hip_atomic_store(g + 1, ((now & 0xffffull) << 48) | ((unsigned long long)(gen & 0xffffu) << 32) | unsigned(m), RLX_AGENT);
+            }
+            if (!single) __hip_atomic_store(&sh.pub_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    DSTAMP(5, it);
 }
 
 // lane l requests the pairs of blocks l, l + 64, l + 128, l + 192 back to back (one round trip) -- bn_resident.hip sweep_granules
@@ -152,6 +178,7 @@ __device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl
     return mine;
 }
 
+template <bool BATCH>
 __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it) {
     if (a.n_blocks > 1 && threadIdx.x < kWave) {
         int lane = int(threadIdx.x);
@@ -162,6 +189,11 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, Da
         unsigned long long m = 0;
         bool ok = true;
         const unsigned long long t0 = wall_clock64();
+        // (this block's own granules first: its slower waves may still be sweeping)
+        while (BATCH && __hip_atomic_load(&sh.pub_it, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it) {
+            if (wall_clock64() - t0 > a.timeout_ticks) break;   // (the polls below then give up in their own way)
+            __builtin_amdgcn_s_sleep(1);
+        }
         // first poll: when the last block is expected to arrive (this block's arrival + the previous iteration's skew) + a margin
         const unsigned long long t_arr = sh.t_arrive;
         const unsigned own16 = unsigned(t_arr) & 0xffffu;
@@ -202,19 +234,20 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, Da
 // of set B, arrival at B's, ... -- so the ~3.4 us a barrier needs to complete are spent on the other sets' sweeps, and ONE set of CPT
 // registers serves them all.  Every set has its own state, marks, barrier words, residual history and control block, and stops
 // on the sweep its single run stops on (same arithmetic: same bits).
-template <class Phase, class Finalize>
+template <bool BATCH, class Phase, class Finalize>
 __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int lane, int wave, Phase&& phase, Finalize&& finalize) {
-    unsigned live = a.set_mask;
+    unsigned live = BATCH ? a.set_mask : 1u;
+    const int n_sets = BATCH ? a.n_sets : 1;
     for (int it = 0; it <= a.budget && live != 0; ++it) {  // the pass it == budget only collects the verdicts
         const int s = a.sweep_begin + it;
-        for (int q = 0; q < a.n_sets; ++q) {
+        for (int q = 0; q < n_sets; ++q) {
             if (((live >> q) & 1u) == 0) continue;
             ResidentSync* sync = a.sync + q;
             DagSetShared& ss = sh.set[q];
             int v = kDagGoOn;
             DSTAMP(0, it);
             if (it > 0) {
-                v = dag_wait(a, sync, ss, it - 1);
+                v = dag_wait<BATCH>(a, sync, ss, it - 1);
                 if (v == kDagAbort) return false;
             }
             DSTAMP(1, it);
@@ -240,7 +273,7 @@ __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int l
                 continue;
             }
             const double wres = phase(q, s);
-            dag_arrive(a, sync, ss, it, s, wres, lane, wave);
+            dag_arrive<BATCH>(a, sync, ss, it, s, wres, lane, wave);
             DSTAMP(6, it);
         }
     }
@@ -261,9 +294,14 @@ __device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsr
 
 // bit q: `node` carries set q's evidence mark (a single query: bit 0)
 __device__ __forceinline__ unsigned dag_frozen_bits(const DagArgs& a, bool active, int node) {
+    // all sets' marks requested together and looked at when first used (as a loop over a.n_sets every load was waited for on the
+    // spot: a memory round trip per set in front of the tile's CPT loads); a set beyond the last reads the last set's mark again
+    unsigned char v[kDagMaxSets];
+#pragma unroll
+    for (int q = 0; q < kDagMaxSets; ++q) v[q] = a.frz[int64_t(q < a.n_sets ? q : a.n_sets - 1) * a.frz_stride + node];
     unsigned bits = 0;
-    if (active)
-        for (int q = 0; q < a.n_sets; ++q) bits |= (a.frz[int64_t(q) * a.frz_stride + node] == a.frz_mark ? 1u : 0u) << q;
+#pragma unroll
+    for (int q = 0; q < kDagMaxSets; ++q) bits |= (active && q < a.n_sets && v[q] == a.frz_mark ? 1u : 0u) << q;
     return bits;
 }
 
@@ -754,7 +792,7 @@ template <> struct dag_has_belief<DagParentX> { static constexpr bool value = fa
 
 // STREAM = false: at most one tile per wave, its static state (CPT, ids, marks) in registers for the whole run.
 // STREAM = true: a wave walks its tiles [slot_ptr[slot], slot_ptr[slot + 1]) every iteration, setting each up again.
-template <bool STREAM>
+template <bool STREAM, bool BATCH>
 __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     __shared__ DagShared sh;
     const int lane = threadIdx.x & (kWave - 1);
@@ -763,24 +801,30 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
         const unsigned long long now = wall_clock64();
         for (int q = 0; q < a.n_sets; ++q) a.host_ctl[q].t_first = now;
     }
-    if (threadIdx.x < kDagMaxSets) { sh.set[threadIdx.x].skew_ticks = 0; sh.set[threadIdx.x].t_arrive = 0; }
+    if (threadIdx.x < kDagMaxSets) {
+        DagSetShared& z = sh.set[threadIdx.x];
+        z.skew_ticks = 0; z.t_arrive = 0; z.arrived = 0; z.pub_it = -1;
+    }
+    if constexpr (BATCH) __syncthreads();   // (a single query reads these words behind its first block barrier only)
     const int slot = blockIdx.x * kDagWaves + wave;
     const int t0 = a.slot_ptr[slot], t1 = a.slot_ptr[slot + 1];
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
     auto rs_of = [&](int q) {   // set q's state
-        return __builtin_amdgcn_make_buffer_rsrc(a.state + int64_t(q) * a.state_stride, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
+        if constexpr (!BATCH) return rs0;
+        else return __builtin_amdgcn_make_buffer_rsrc(a.state + int64_t(q) * a.state_stride, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
     };
     auto beliefs_of = [&](int q) { return a.b.beliefs + int64_t(q) * a.belief_stride; };
     bool ok = true;
     if (t1 <= t0) {
-        ok = dag_drive(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int) {});
+        ok = dag_drive<BATCH>(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int) {});
     } else if constexpr (STREAM) {
-        ok = dag_drive(a, sh, lane, wave,
+        ok = dag_drive<BATCH>(a, sh, lane, wave,
                        [&](int q, int s) {
                            double w = 0.0;
                            const __amdgpu_buffer_rsrc_t rs = rs_of(q);
                            for (int t = t0; t < t1; ++t) {
                                const DagTile td = a.tiles[t];
-                               dag_with_tile(a, td, lane, [&](auto& st) { st.turn(q); w = res_acc(w, st.sweep(a, rs, s, sh.xch[wave])); });
+                               dag_with_tile(a, td, lane, [&](auto& st) { if constexpr (BATCH) st.turn(q); w = res_acc(w, st.sweep(a, rs, s, sh.xch[wave])); });
                            }
                            return w;
                        },
@@ -798,7 +842,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     } else {
         const DagTile td = a.tiles[t0];
         dag_with_tile(a, td, lane, [&](auto& st) {
-            ok = dag_drive(a, sh, lane, wave, [&](int q, int s) { st.turn(q); return st.sweep(a, rs_of(q), s, sh.xch[wave]); },
+            ok = dag_drive<BATCH>(a, sh, lane, wave, [&](int q, int s) { if constexpr (BATCH) st.turn(q); return st.sweep(a, rs_of(q), s, sh.xch[wave]); },
                            [&](int q, int n, int done) {
                                if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) {
                                    if (done != 0) st.belief(a, rs_of(q), n, beliefs_of(q));
@@ -836,8 +880,11 @@ __global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) {
 int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle) {
     (void)hipGetLastError();
     const dim3 g(a.n_blocks), t(kDagWaves * kWave);
-    if (stream) hipLaunchKernelGGL(bp_dag_kernel<true>, g, t, 0, (hipStream_t)stream_handle, a);
-    else hipLaunchKernelGGL(bp_dag_kernel<false>, g, t, 0, (hipStream_t)stream_handle, a);
+    const bool batch = a.n_sets > 1;
+    if (stream && batch) hipLaunchKernelGGL((bp_dag_kernel<true, true>), g, t, 0, (hipStream_t)stream_handle, a);
+    else if (stream) hipLaunchKernelGGL((bp_dag_kernel<true, false>), g, t, 0, (hipStream_t)stream_handle, a);
+    else if (batch) hipLaunchKernelGGL((bp_dag_kernel<false, true>), g, t, 0, (hipStream_t)stream_handle, a);
+    else hipLaunchKernelGGL((bp_dag_kernel<false, false>), g, t, 0, (hipStream_t)stream_handle, a);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }
