@@ -67,6 +67,8 @@ struct DagSetShared {                    // per evidence set of the launch
     int skew_ticks;                      // how long after this block the LAST block arrived in the previous iteration (10 ns ticks)
     int arrived;                         // waves of the block that have finished the set's sweep in hand (the last one publishes)
     int pub_it;                          // the iteration whose granules the block has published
+    int poll_it;                         // several sets: the last iteration for whose barrier a wave of the block has taken the polling on
+    int ver_it;                          // ... and the last one whose verdict stands in `verdict`
 };
 struct DagShared {
     DagSetShared set[kDagMaxSets];
@@ -113,7 +115,7 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync,
         }
         if (before == kDagWaves - 1) {   // the block's last wave (a single query: its first): every wave's stores are out, every slot is written
             if (!single) {
-                __hip_atomic_store(&sh.arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (next used behind dag_wait's block barrier)
+                __hip_atomic_store(&sh.arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (next used by a wave that has seen this barrier's verdict)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             // (plain loads, requested together: as eight atomic loads they were eight LDS round trips in a row on the path to the
@@ -124,6 +126,7 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync,
             if (a.n_blocks == 1) {
                 sync->res[it] = m;
                 sh.verdict = dag_verdict_of(a, dag_residual_of(m), s + 1);
+                if (!single) __hip_atomic_store(&sh.ver_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
                 // overwrite what a slower block still has to read
@@ -178,10 +181,20 @@ __device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl
     return mine;
 }
 
+// Several sets per launch (BATCH): no block barrier here either.  The FIRST wave of the block to need this barrier's verdict does the
+// polling (an LDS fetch-max on poll_it decides who), publishes verdict and ver_it; the others wait for ver_it in LDS.  A wave with a
+// light tile is thus never held up by the block's slower waves -- it sweeps the next sets while they finish this one -- and a set's
+// sweep costs the block what its slowest wave needs for the arithmetic, not that plus a block barrier per set.
 template <bool BATCH>
 __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it) {
-    if (a.n_blocks > 1 && threadIdx.x < kWave) {
-        int lane = int(threadIdx.x);
+    bool poller = threadIdx.x < kWave;
+    if constexpr (BATCH) {
+        int before = it;
+        if ((threadIdx.x & (kWave - 1)) == 0) before = __hip_atomic_fetch_max(&sh.poll_it, it, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        poller = __builtin_amdgcn_readfirstlane(before) < it;
+    }
+    if (a.n_blocks > 1 && poller) {
+        int lane = int(threadIdx.x & (kWave - 1));
         asm volatile("" : "+v"(lane));  // (keeps the per-lane granule addresses out of the iteration loop's live registers)
         const unsigned gen = a.gen_base + unsigned(it) + 1u;
         const int nb = a.n_blocks;
@@ -221,10 +234,23 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, Da
         if (lane == 0) {
             if (blockIdx.x == 0 && ok) __hip_atomic_store(&sync->res[it], m, RLX_AGENT);
             sh.verdict = ok ? dag_verdict_of(a, dag_residual_of(m), a.sweep_begin + it + 1) : kDagAbort;
+            if constexpr (BATCH) __hip_atomic_store(&sh.ver_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-    __syncthreads();
-    return sh.verdict;
+    if constexpr (!BATCH) {
+        __syncthreads();
+        return sh.verdict;
+    } else {
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned n = 1; __hip_atomic_load(&sh.ver_it, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it; ++n) {
+            if ((n & 63u) == 0 && wall_clock64() - t0 > 2 * a.timeout_ticks) {   // (the poller gives up first and says so here)
+                __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
+                return kDagAbort;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return __hip_atomic_load(&sh.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 
 // The launch's loop over iterations.  phase(s): one sweep of this wave's tile(s), returns the wave's share of
@@ -803,7 +829,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     }
     if (threadIdx.x < kDagMaxSets) {
         DagSetShared& z = sh.set[threadIdx.x];
-        z.skew_ticks = 0; z.t_arrive = 0; z.arrived = 0; z.pub_it = -1;
+        z.skew_ticks = 0; z.t_arrive = 0; z.arrived = 0; z.pub_it = -1; z.poll_it = -1; z.ver_it = -1;
     }
     if constexpr (BATCH) __syncthreads();   // (a single query reads these words behind its first block barrier only)
     const int slot = blockIdx.x * kDagWaves + wave;
