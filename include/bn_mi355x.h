@@ -230,6 +230,8 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   belief_propagation.hpp:253).  Networks beyond one tile per wave run the same code walking several tiles per wave ("stream"
  *   form).  0 = never, 1 = where measured faster (default: networks with 3-5-parent nodes, and networks of <= 2-parent nodes that fit
  *   the chip at one tile per wave -- unless the one-workgroup path takes the network), 2 = wherever eligible.
+ *   bn_bp_run_batch on such a network: up to 8 evidence sets share a launch and its CPT registers, taking turns inside an iteration;
+ *   every set keeps the sweep count and the bits of its single run.
  *   bn_get_info "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts".
  * "autotune" 1 -- the NEXT run first times every execution path the engine is eligible for on the evidence in force (one warm-up and
  *   two timed runs of 6 sweeps each, host wall clock) and keeps the fastest for all later runs: the built-in choice between the
