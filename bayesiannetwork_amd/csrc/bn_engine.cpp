@@ -2211,7 +2211,8 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     constexpr int64_t kResidentBatchMinTiles = 900;
     const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
     const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
-    const bool batch_small = e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state != nullptr;
+    // ("dag" = 2 puts the register-resident DAG path in front of the one-workgroup path, as for single queries)
+    const bool batch_small = e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state != nullptr && !(e->dag_mode == 2 && e->dag_ok);
     bool batch_dag = !batch_small && dag_applies(e) && bt.ev_base != nullptr && e->plan.nranks == 1;
     if (batch_dag && e->dag_cooldown > 0) { --e->dag_cooldown; batch_dag = false; }
     if (batch_dag) {

@@ -193,3 +193,46 @@ def test_dag_batch_shares_launches(Engine, oracle_mod):
         for q in range(2):
             r = eng.bp_run(evs[q], 0.0, 1030)
             assert long["sweeps"][q] == 1030 == r["sweeps"] and np.array_equal(long["beliefs"][q], r["beliefs"])
+
+
+@pytest.mark.parametrize("case", ["stream", "one_block"])
+def test_dag_batch_other_forms(Engine, oracle_mod, case):
+    """The several-sets launch in the kernel's other two forms: the stream form (waves walking several tiles per iteration and set: a
+    15 k-node DAG) and a one-block grid (no granules: the block's last wave decides)."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(15000, 4, 64, 4, seed=3) if case == "stream" else synth.random_dag(24, 3, 8, 4, seed=12)
+    evs = [synth.random_evidence(g, f, seed=70 + q) for q, f in enumerate([0.0, 0.05, 0.2])]
+    with Engine(g) as eng:
+        eng.set_option("dag", 2)
+        assert eng.info("dag_eligible") == 1 and eng.info("dag_stream") == (1 if case == "stream" else 0)
+        assert case == "stream" or eng.info("dag_blocks") == 1
+        singles = [eng.bp_run(ev, 1e-5) for ev in evs]
+        assert eng.last_path() == 5
+        out = eng.bp_run_batch(evs, 1e-5)
+        assert eng.last_path() == 5 and eng.bp_stats()["sweep_launches"] == 1 and eng.info("dag_aborts") == 0
+        for q, r in enumerate(singles):
+            assert out["sweeps"][q] == r["sweeps"] and np.array_equal(out["beliefs"][q], r["beliefs"]), q
+        o = oracle_mod.bp_run(g, evs[1], 1e-5, threads=8)
+        assert out["sweeps"][1] == o["sweeps"] and np.abs(out["beliefs"][1] - o["beliefs"]).max() < 1e-12
+
+
+def test_dag_batch_after_reload(Engine, oracle_mod):
+    """bn_reload_cpt between two batches: the second batch runs on the new tables (register images rebuilt, batch state kept)."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(500, 4, 32, 4, seed=21)
+    g2 = synth.random_dag(500, 4, 32, 4, seed=21)
+    rng = np.random.default_rng(5)
+    cpt = g2.cpt.reshape(-1, 4).copy()
+    cpt[::7] = rng.dirichlet(np.ones(4), size=len(cpt[::7]))
+    g2.cpt[:] = cpt.ravel()
+    evs = [synth.random_evidence(g, f, seed=80 + q) for q, f in enumerate([0.02, 0.1, 0.0, 0.3])]
+    with Engine(g) as eng:
+        a = eng.bp_run_batch(evs, 1e-6)
+        assert eng.last_path() == 5
+        eng.reload_cpt(g2.cpt)
+        b = eng.bp_run_batch(evs, 1e-6)
+        assert eng.last_path() == 5
+    for q, ev in enumerate(evs):
+        o1, o2 = oracle_mod.bp_run(g, ev, 1e-6), oracle_mod.bp_run(g2, ev, 1e-6)
+        assert a["sweeps"][q] == o1["sweeps"] and np.abs(a["beliefs"][q] - o1["beliefs"]).max() < 1e-12
+        assert b["sweeps"][q] == o2["sweeps"] and np.abs(b["beliefs"][q] - o2["beliefs"]).max() < 1e-12
