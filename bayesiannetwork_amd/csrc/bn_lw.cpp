@@ -314,13 +314,15 @@ int lw_states(LwState& s, const Plan& p, void* stream, uint64_t n, uint8_t* stat
     hipStream_t st = (hipStream_t)stream;
     if (!s.ready || s.last_batch_samples == 0) { err = "no likelihood-weighting run yet"; return BN_ERR_STATE; }
     if (n > s.last_batch_samples) { err = "more samples requested than the last batch holds"; return BN_ERR_ARG; }
-    if (states_out) {
-        std::vector<uint8_t> col(n);
-        for (int32_t v = 0; v < p.n; ++v) {  // diagnostic path: one strided copy per node
-            LWCHK(hipMemcpyAsync(col.data(), s.d_states + uint64_t(v) * s.batch, n, hipMemcpyDeviceToHost, st));
-            LWCHK(hipStreamSynchronize(st));
-            for (uint64_t i = 0; i < n; ++i) states_out[i * uint64_t(p.n) + v] = col[i];
-        }
+    if (states_out && n > 0) {   // transposed on the device (sample-major), then one copy
+        uint8_t* d_t = nullptr;
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&d_t), n * uint64_t(p.n)));
+        int rc = launch_lw_transpose(s.d_states, d_t, p.n, s.batch, n, st);
+        hipError_t ce = rc ? hipSuccess : hipMemcpyAsync(states_out, d_t, n * uint64_t(p.n), hipMemcpyDeviceToHost, st);
+        if (!rc && ce == hipSuccess) ce = hipStreamSynchronize(st);
+        (void)hipFree(d_t);
+        if (rc) { err = "transpose kernel launch failed"; return BN_ERR_HIP; }
+        if (ce != hipSuccess) { err = std::string("copying the sampled states: ") + hipGetErrorString(ce); return BN_ERR_HIP; }
     }
     if (weights_out) {
         LWCHK(hipMemcpyAsync(weights_out, s.d_weights, n * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -100,6 +100,7 @@ struct LwArgs {
 
 int launch_lw_sample(const LwArgs& a, int blocks, void* stream);
 int launch_lw_hist(const LwArgs& a, int blocks, void* stream);
+int launch_lw_transpose(const uint8_t* states, uint8_t* out, int32_t n, uint64_t batch, uint64_t n_samples, void* stream);
 
 void lw_free(LwState& s);
 // hist_out == nullptr: leave the histogram in s.d_hist (the caller reduces it across ranks first)

@@ -648,6 +648,36 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_wide_kernel(const uint8_t*
     }
 }
 
+// bn_lw_states: the [node][sample] byte matrix of the last batch, transposed to sample-major [sample][node] (what make_samples
+// counts joint patterns from, likelihood_weighting.hpp:62-118) through a 64 x 64 LDS tile: coalesced reads along the samples of a
+// node, coalesced writes along the nodes of a sample.  (One strided copy per NODE before: 10 000 copy commands on config 5.)
+__global__ __launch_bounds__(256) void lw_transpose_kernel(const uint8_t* __restrict__ states, uint8_t* __restrict__ out, int32_t n,
+                                                           uint64_t batch, uint64_t n_samples) {
+    __shared__ uint8_t tile[64][65];
+    const uint64_t s0 = uint64_t(blockIdx.x) * 64;
+    const int v0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    for (int r = ty; r < 64; r += 4) {   // row r of the tile = node v0 + r, column tx = sample s0 + tx
+        const int v = v0 + r;
+        const uint64_t smp = s0 + tx;
+        tile[r][tx] = (v < n && smp < n_samples) ? states[uint64_t(v) * batch + smp] : uint8_t(0);
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {   // row r of the output tile = sample s0 + r, column tx = node v0 + tx
+        const uint64_t smp = s0 + r;
+        const int v = v0 + tx;
+        if (v < n && smp < n_samples) out[smp * uint64_t(n) + v] = tile[tx][r];
+    }
+}
+int launch_lw_transpose(const uint8_t* states, uint8_t* out, int32_t n, uint64_t batch, uint64_t n_samples, void* stream) {
+    (void)hipGetLastError();
+    if (n_samples == 0 || n <= 0) return 0;
+    const dim3 grid(unsigned((n_samples + 63) / 64), unsigned((n + 63) / 64));
+    hipLaunchKernelGGL(lw_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, states, out, n, batch, n_samples);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+
 int launch_lw_sample(const LwArgs& a, int blocks, void* stream) {
     (void)hipGetLastError();  // drop any stale error of this thread
 #define BN_LW_LAUNCH3(R24, INL, REJ)                                                                              \
