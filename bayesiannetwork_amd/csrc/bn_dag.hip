@@ -313,9 +313,17 @@ __device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsr
     dag_ld4(rs, dag_off_nlam(a.E, a.n, n & 1, node), lv);
     double sum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { bel[i] = pv[i] * lv[i]; sum += bel[i]; }
+    for (int i = 0; i < 4; ++i) { bel[i] = pv[i] * lv[i]; sum += bel[i]; }   // (padding entries are 0: they add nothing)
+    if (a.node_k == nullptr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) beliefs[int64_t(node) * 4 + i] = bel[i] / sum;
+        for (int i = 0; i < 4; ++i) beliefs[int64_t(node) * 4 + i] = bel[i] / sum;
+    } else {
+        const int kv = a.node_k[node];
+        double* out = beliefs + a.node_off[node];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < kv) out[i] = bel[i] / sum;
+    }
 }
 
 // bit q: `node` carries set q's evidence mark (a single query: bit 0)
@@ -354,7 +362,7 @@ struct DagChildU {
         }
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
-        const bool first = s == 0;
+        const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
         const int cur = s & 1, nxt = cur ^ 1;
         double pim[M > 0 ? M : 1][K], lold[M > 0 ? M : 1][K], lav[K], pold[K];
 #pragma unroll
@@ -493,7 +501,7 @@ struct DagChildG {
         }
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
-        const bool first = s == 0;
+        const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
         const int cur = s & 1, nxt = cur ^ 1;
         // The node's inputs -- its M pi-messages and lambda(v), 2 (M + 1) 16-byte halves -- are requested ONCE per group: lane g
         // loads half g (and g + G where the group has fewer lanes than halves), the group shares them through the wave's scratch.
@@ -633,7 +641,7 @@ struct DagChildG {
 // in ascending order, the target left out -- the reference's multiplication sequence
 struct DagParent {
     static constexpr int K = 4, RC = kDagRegChildren;
-    int node, tedge, obeg, deg, tpos, dmax;
+    int node, tedge, obeg, deg, tpos, dmax, kv;
     bool active, frozen;
     unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
     __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
@@ -647,17 +655,18 @@ struct DagParent {
         deg = active ? (it.deg_tpos & 0xffff) : 0;
         tpos = it.deg_tpos >> 16;  // (0xffff for the lambda(v) item: no child is left out)
         dmax = t.dmax;
+        kv = a.node_k ? a.node_k[node] : 4;
         frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
 #pragma unroll
         for (int x = 0; x < RC; ++x) oe[x] = (x < deg) ? a.oedge[obeg + x] : 0;
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
-        const bool first = s == 0;
+        const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
         const int cur = s & 1, nxt = cur ^ 1;
         const bool is_msg = tedge >= 0;
         double acc[K], old[K], lk[RC][K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) { acc[i] = 1.0; old[i] = 1.0; }
+        for (int i = 0; i < K; ++i) { acc[i] = i < kv ? 1.0 : 0.0; old[i] = 1.0; }   // (the empty product over a leaf's children: ones over the node's OWN states)
 #pragma unroll
         for (int x = 0; x < RC; ++x)
 #pragma unroll
@@ -724,7 +733,7 @@ struct DagParent {
 // read each other's through the wave's scratch: 4 vector-memory instructions per lane and iteration whatever the child count.
 struct DagParentX {
     static constexpr int K = 4;
-    int node, tedge, deg, tpos, first_lane, dmax, lane;
+    int node, tedge, deg, tpos, first_lane, dmax, lane, kv;
     bool active, frozen;
     unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
     __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
@@ -738,10 +747,11 @@ struct DagParentX {
         tpos = active ? (it.deg_tpos >> 16) : -1;   // -1: the lambda(v) item, the first of its node's lanes
         first_lane = lane - (tpos + 1);
         dmax = t.dmax;
+        kv = a.node_k ? a.node_k[node] : 4;
         frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
-        const bool first = s == 0;
+        const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
         const int cur = s & 1, nxt = cur ^ 1;
         const bool is_msg = tedge >= 0;
         double rec[K], old[K], acc[K];
@@ -769,7 +779,8 @@ struct DagParentX {
         DSTAMP_INPUTS(a, s);
         {
             const double2_t p0 = xch[2 * first_lane], p1 = xch[2 * first_lane + 1];
-            acc[0] = is_msg ? p0.x : 1.0; acc[1] = is_msg ? p0.y : 1.0; acc[2] = is_msg ? p1.x : 1.0; acc[3] = is_msg ? p1.y : 1.0;
+            // (lambda(v): the product over the children starts from ones over the node's OWN states -- a leaf's stays there)
+            acc[0] = is_msg ? p0.x : 1.0; acc[1] = is_msg ? p0.y : (kv > 1 ? 1.0 : 0.0); acc[2] = is_msg ? p1.x : (kv > 2 ? 1.0 : 0.0); acc[3] = is_msg ? p1.y : (kv > 3 ? 1.0 : 0.0);
         }
         for (int x = 0; x < dmax; ++x) {   // ascending children, the target left out (:207-214, :229-235); wave-uniform trip count
             const int src = (x < deg) ? first_lane + 1 + x : lane;
@@ -893,8 +904,9 @@ __global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.ne) return;
     const int v = a.ev_node[j];
+    const int kv = a.node_k ? a.node_k[v] : 4;
     for (int i = 0; i < 4; ++i) {
-        const double x = a.ev_val[a.ev_off[j] + i];
+        const double x = i < kv ? a.ev_val[a.ev_off[j] + i] : 0.0;
         for (int par = 0; par < 2; ++par) {
             a.state[dag_off_npi(a.E, a.n, par, v) * 2 + i] = x;
             a.state[dag_off_nlam(a.E, a.n, par, v) * 2 + i] = x;
@@ -903,6 +915,32 @@ __global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) {
     a.frz[v] = a.frz_mark;
 }
 
+__global__ __launch_bounds__(256) void dag_init_kernel(DagInitArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < a.E) {   // both messages of edge t: ones over the states of its PARENT
+        const int kp = a.node_k[a.in_idx[t]];
+        for (int i = 0; i < 4; ++i) {
+            const double x = i < kp ? 1.0 : 0.0;
+            a.state[dag_off_pim(a.E, a.n, 0, t) * 2 + i] = x;
+            a.state[dag_off_lam(a.E, a.n, 0, t) * 2 + i] = x;
+        }
+    }
+    if (t < a.n && a.frz[t] != a.frz_mark) {
+        const int kv = a.node_k[t];
+        for (int i = 0; i < 4; ++i) {
+            a.state[dag_off_npi(a.E, a.n, 0, t) * 2 + i] = a.npi_init[int64_t(t) * 4 + i];
+            a.state[dag_off_nlam(a.E, a.n, 0, t) * 2 + i] = i < kv ? 1.0 : 0.0;
+        }
+    }
+}
+int launch_dag_init(const DagInitArgs& a, void* stream_handle) {
+    (void)hipGetLastError();
+    const int work = a.E > a.n ? a.E : a.n;
+    if (work <= 0) return 0;
+    hipLaunchKernelGGL(dag_init_kernel, dim3((work + 255) / 256), dim3(256), 0, (hipStream_t)stream_handle, a);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
 int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle) {
     (void)hipGetLastError();
     const dim3 g(a.n_blocks), t(kDagWaves * kWave);

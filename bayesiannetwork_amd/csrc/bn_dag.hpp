@@ -63,11 +63,12 @@ struct DagPlan {
     int32_t blocks = 0;
     bool stream = false;                   // some wave walks more than one tile per iteration
     bool has_groups = false;               // some node has 3..5 parents (lane-group tiles)
+    bool uniform4 = true;                  // every arity is 4; false: arities 2..4 padded to 4, the initial state is written to memory before a run
     std::vector<DagChildLane> cnode;       // [n_tiles * 64] (child tiles' entries)
     std::vector<DagParentLane> pitem;      // [n_tiles * 64] (parent tiles' entries)
     std::vector<int32_t> oedge;            // out-edges (CSR edge ids) of every node, children ascending
     std::vector<double> cpt_img;           // child tiles' images, double2 units x 2
-    std::vector<double> npi_init;          // [n][4] initial pi(v): the CPT row of a root (:58-64, not normalised), else 1.0
+    std::vector<double> npi_init;          // [n][4] initial pi(v): the CPT row of a root (:58-64, not normalised), else 1.0; 0 beyond the node's arity
     int32_t n_child_tiles = 0, n_parent_tiles = 0;
 };
 
@@ -103,6 +104,11 @@ struct DagArgs {
     uint32_t set_mask;
     int64_t state_stride, frz_stride, belief_stride;
     int32_t res_hist_stride;
+    // arities below 4 (padded to 4, DagPlan::uniform4 == false): the run's initial state stands in memory (dag_init_kernel), nothing
+    // is synthesised in sweep 0; node_k / node_off say which entries of a node's padded vectors exist and where its marginal goes
+    int32_t state_init;
+    const int32_t* node_k;     // nullptr: every arity is 4
+    const int64_t* node_off;
 };
 struct DagEvidenceArgs {
     int32_t ne, n, E;
@@ -112,7 +118,21 @@ struct DagEvidenceArgs {
     double* state;
     uint8_t* frz;
     uint8_t frz_mark;
+    const int32_t* node_k;     // nullptr: every arity is 4
 };
+// the initial state of a run of a padded network, buffer parity 0: messages = ones over the PARENT's states (:38-56), pi(v) = npi_init,
+// lambda(v) = ones over the node's states, zeros in the padding; nodes that carry the evidence mark keep their vectors
+struct DagInitArgs {
+    int32_t n, E;
+    const int32_t* in_ptr;     // [n + 1] CSR of the in-edges (edge e belongs to child c: in_ptr[c] <= e < in_ptr[c + 1])
+    const int32_t* in_idx;     // [E] parent of edge e
+    const int32_t* node_k;
+    const double* npi_init;
+    double* state;
+    const uint8_t* frz;
+    uint8_t frz_mark;
+};
+int launch_dag_init(const DagInitArgs& a, void* stream_handle);
 int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle);
 int launch_dag_evidence(const DagEvidenceArgs& a, void* stream_handle);
 

@@ -1,4 +1,8 @@
-// bn_dag_plan.cpp -- host plan of the register-resident path for k = 4 networks with up to 5 parents per node (bn_dag.hpp).
+// bn_dag_plan.cpp -- host plan of the register-resident path for networks of arity <= 4 with up to 5 parents per node (bn_dag.hpp).
+// Arities below 4 are PADDED to 4: a node's table is laid out as if it and its parents had four states, with zeros wherever a state
+// does not exist.  A zero entry adds +0.0 to a sum and makes a product 0: the real entries of every vector keep the reference's bits,
+// the padding entries stay 0 -- provided the run STARTS with zeros there, which is why such a network's initial state is written
+// to memory before a run (DagPlan::uniform4 == false, dag_init_kernel) instead of being synthesised as all-ones in registers.
 #include "bn_dag.hpp"
 
 #include <algorithm>
@@ -32,7 +36,8 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
     if (n < 1) { dp.why = "empty network"; return; }
     if (p.E + int64_t(n) >= (int64_t(1) << 23)) { dp.why = "state beyond 32-bit byte offsets"; return; }
     for (int32_t v = 0; v < n; ++v) {
-        if (p.k[v] != 4) { dp.why = "a node's arity is not 4"; return; }
+        if (p.k[v] > 4) { dp.why = "a node's arity is above 4"; return; }
+        if (p.k[v] != 4) dp.uniform4 = false;
         if (p.in_ptr[v + 1] - p.in_ptr[v] > kDagMaxParents) { dp.why = "a node has more than 5 parents"; return; }
     }
     cap_blocks = std::min<int32_t>(cap_blocks & ~7, kDagMaxBlocks);
@@ -53,10 +58,11 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
                 dp.oedge[out_ptr[u] + fill[u]++] = e;
             }
     }
-    dp.npi_init.assign(size_t(n) * 4, 1.0);
+    // initial pi(v): a root's CPT row (:58-64, not normalised), else ones -- over the node's OWN states, 0 in the padding
+    dp.npi_init.assign(size_t(n) * 4, 0.0);
     for (int32_t v = 0; v < n; ++v)
-        if (p.in_ptr[v + 1] == p.in_ptr[v])
-            for (int i = 0; i < 4; ++i) dp.npi_init[size_t(v) * 4 + i] = p.cpt_flat[p.cpt_off[v] + i];
+        for (int i = 0; i < p.k[v]; ++i)
+            dp.npi_init[size_t(v) * 4 + i] = p.in_ptr[v + 1] == p.in_ptr[v] ? p.cpt_flat[p.cpt_off[v] + i] : 1.0;
 
     // ---- tiles in natural order: child tiles by parent count, then parent items by child count
     std::vector<DagTile> tiles;
@@ -92,11 +98,22 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
                     // the lane's leading-parent digits (first parent most significant) are the digits of g; its entries run
                     // over the trailing parents (the last one fastest) and the own state: entry cl * 4 + i
                     const int trailing = m < 2 ? m : 2, ncl = 1 << (2 * trailing);
+                    const int kv = p.k[v];
                     for (int cl = 0; cl < ncl; ++cl)
                         for (int i = 0; i < 4; ++i) {
-                            const int64_t row = (int64_t(g) << (2 * trailing)) | cl;   // assignment index, first parent most significant
+                            // the assignment in base 4, first parent most significant; the entry it names in the node's REAL table
+                            // (mixed radix of the parents' arities), or none: a parent state or an own state that does not exist
+                            const int64_t row4 = (int64_t(g) << (2 * trailing)) | cl;
+                            int64_t row = 0;
+                            bool real = i < kv;
+                            for (int j = 0; j < m; ++j) {
+                                const int digit = int((row4 >> (2 * (m - 1 - j))) & 3);
+                                const int kj = p.k[p.in_idx[p.in_ptr[v] + j]];
+                                real = real && digit < kj;
+                                row = row * kj + digit;
+                            }
                             const int q = cl * 4 + i;
-                            im[size_t(q >> 1) * (2 * kWave) + size_t(lane) * 2 + (q & 1)] = cpt[row * 4 + i];
+                            im[size_t(q >> 1) * (2 * kWave) + size_t(lane) * 2 + (q & 1)] = real ? cpt[row * kv + i] : 0.0;
                         }
                     (void)D;
                 }

@@ -285,6 +285,10 @@ struct bn_engine {
     int32_t* d_g_oedge = nullptr;
     double* d_g_cpt = nullptr;
     double* d_g_init = nullptr;
+    int32_t* d_g_k = nullptr;       // networks with arities below 4 (DagPlan::uniform4 == false): arity, in-edge CSR and marginal offsets for the padded form
+    int32_t* d_g_inptr = nullptr;
+    int32_t* d_g_inidx = nullptr;
+    int64_t* d_g_noff = nullptr;
     double* d_g_state = nullptr;    // pi-/lambda-messages (CSR edge order), pi(v), lambda(v): two buffers each (bn_dag.hpp dag_off_*)
     uint8_t* d_g_frz = nullptr;
     uint8_t dag_mark = 0;           // mark value of the evidence set applied to d_g_state / d_g_frz
@@ -335,7 +339,7 @@ static void free_engine(bn_engine* e) {
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
                         e->d_m_parts, e->d_m_ent, e->d_m_cpt, e->d_m_term, e->d_m_clist, e->d_m_bslot, e->d_m_cslot, e->d_m_nvidx, e->d_m_nvslot,
                         e->d_m_init, e->d_m_nodeoff, e->d_m_msgfirst, e->d_m_state, e->d_m_frz, e->d_m_sync,
-                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync,
+                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync, e->d_g_k, e->d_g_inptr, e->d_g_inidx, e->d_g_noff,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state,
                         e->batch.d_g_state, e->batch.d_g_frz, e->batch.d_g_sync};
@@ -659,6 +663,12 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             if ((r2 = upload(&e->d_g_oedge, dp.oedge, e->stream))) return r2;
             if ((r2 = upload(&e->d_g_cpt, dp.cpt_img, e->stream))) return r2;
             if ((r2 = upload(&e->d_g_init, dp.npi_init, e->stream))) return r2;
+            if (!dp.uniform4) {
+                if ((r2 = upload(&e->d_g_k, p.k, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_inptr, p.in_ptr, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_inidx, p.in_idx, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_noff, p.node_off, e->stream))) return r2;
+            }
             const size_t sd = size_t(dag_state_doubles(dp.E, dp.n));
             if ((r2 = dalloc(&e->d_g_state, sd))) return r2;
             HIPCHK(hipMemsetAsync(e->d_g_state, 0, std::max<size_t>(sd, 1) * 8, e->stream));
@@ -1178,6 +1188,7 @@ static bool dag_applies(const bn_engine* e) {
     if (!e->dag_ok || e->multisweep == 0 || e->dag_mode == 0) return false;
     if (e->dag_mode == 2) return true;
     if (e->small_ok) return false;   // one workgroup with the state in LDS
+    if (!e->dag.uniform4) return false;   // arities below 4 (padded form): where asked for ("dag" = 2) or chosen by "autotune" -- the item kernels give the oracle's bits for any parent count there
     // Measured, us per query (evidence staged, profiles/r04_paths.json), this path / the best of the others:
     //   lane-group tiles (some node has 3-5 parents): 200 nodes 76 / 122, 1 000 nodes 87 / 165, 3 000 nodes 101 / 182, 10 000 nodes
     //   (BASELINE configs[1]) 117 / 215; nodes of <= 2 parents: 16 x 16 grid 86 / 95, 40 x 40 117 / 135, 64 x 64 113 / 139, 128 x 128
@@ -1195,7 +1206,7 @@ static int flush_dag_evidence(bn_engine* e) {
         e->dag_mark = 0;
     }
     ++e->dag_mark;
-    DagEvidenceArgs ea{e->ev_ne, e->dag.n, e->dag.E, e->d_ev_node, e->d_ev_off, e->d_ev_val, e->d_g_state, e->d_g_frz, e->dag_mark};
+    DagEvidenceArgs ea{e->ev_ne, e->dag.n, e->dag.E, e->d_ev_node, e->d_ev_off, e->d_ev_val, e->d_g_state, e->d_g_frz, e->dag_mark, e->d_g_k};
     if (int code = launch_dag_evidence(ea, e->stream))
         return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
     e->dag_ev_applied = true;
@@ -1214,6 +1225,11 @@ static int run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
     float ms = 0.f;
     double dev_ticks = 0.0;
     const BpBuffers b = buffers_of(e);
+    if (!dp.uniform4) {   // arities below 4: the run's initial state stands in memory (zeros in the padding), bn_dag_plan.cpp
+        DagInitArgs ia{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, e->d_g_state, e->d_g_frz, e->dag_mark};
+        if (int code = launch_dag_init(ia, s))
+            return fail(BN_ERR_HIP, std::string("dag_init launch failed: ") + hipGetErrorString(hipError_t(code)));
+    }
     for (;;) {
         // polled words: generations count on from launch to launch; zeroed at creation, after an abort and before they would wrap
         if (e->dag_sync_dirty || e->dag_gen_base > (1u << 29)) {
@@ -1235,6 +1251,7 @@ static int run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
         static const int first_delay = std::getenv("BN_DAG_DELAY") ? std::atoi(std::getenv("BN_DAG_DELAY")) : 30;   // 10 ns ticks: measured flat from 20 to 60 (config 2: 6.9 us per sweep at 0, 6.5-6.6 there)
         a.first_poll_delay = first_delay;
         a.n_sets = 1; a.set_mask = 1u;
+        a.state_init = dp.uniform4 ? 0 : 1; a.node_k = e->d_g_k; a.node_off = e->d_g_noff;
         if (e->timing) {
             int rc = ensure_events(e, 2);
             if (rc) return rc;
@@ -2063,9 +2080,15 @@ static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int
         DagEvidenceArgs ea{bt.ne[g], dp.n, dp.E, reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[g],
                            reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[g],
                            reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[g], bt.d_g_state + size_t(q) * state_d,
-                           bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark};
+                           bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark, e->d_g_k};
         if (int code = launch_dag_evidence(ea, s))
             return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
+        if (!dp.uniform4) {
+            DagInitArgs ia{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, bt.d_g_state + size_t(q) * state_d,
+                           bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark};
+            if (int code = launch_dag_init(ia, s))
+                return fail(BN_ERR_HIP, std::string("dag_init launch failed: ") + hipGetErrorString(hipError_t(code)));
+        }
     }
     if (bt.dag_sync_dirty || bt.dag_gen_base > (1u << 29)) {
         HIPCHK(hipMemsetAsync(bt.d_g_sync, 0, sizeof(ResidentSync) * size_t(kDagMaxSets), s));
@@ -2091,6 +2114,7 @@ static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int
     a.poll_sleep = poll_sleep;
     a.first_poll_delay = first_delay;
     a.n_sets = count; a.set_mask = (1u << count) - 1u;
+    a.state_init = dp.uniform4 ? 0 : 1; a.node_k = e->d_g_k; a.node_off = e->d_g_noff;
     a.state_stride = int64_t(state_d); a.frz_stride = dp.n; a.belief_stride = p.node_off[p.n]; a.res_hist_stride = e->res_cap;
     for (int32_t q = 0; q < count; ++q) bt.h_ctl[first + q].run_id = 0;
     if (int code = launch_bp_dag(a, dp.stream, s))
@@ -2644,8 +2668,20 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
     if (e->last_path == 5) {  // bn_dag.hip: CSR edge order, four doubles per edge, two buffers: the run stopped in buffer n_sweeps & 1
         const int64_t E = e->dag.E, n = e->dag.n;
         const int par = e->last_ctl.n_sweeps & 1;
-        HIPCHK(hipMemcpy(pi_msg_out, e->d_g_state + 2 * dag_off_pim(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(lambda_msg_out, e->d_g_state + 2 * dag_off_lam(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+        if (e->dag.uniform4) {
+            HIPCHK(hipMemcpy(pi_msg_out, e->d_g_state + 2 * dag_off_pim(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(lambda_msg_out, e->d_g_state + 2 * dag_off_lam(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+            return BN_OK;
+        }
+        // arities below 4: the padded records, of which edge e's first k(parent of e) entries exist
+        std::vector<double> pm(size_t(E) * 4), lm(size_t(E) * 4);
+        HIPCHK(hipMemcpy(pm.data(), e->d_g_state + 2 * dag_off_pim(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lm.data(), e->d_g_state + 2 * dag_off_lam(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
+        size_t at = 0;
+        for (int64_t ed = 0; ed < E; ++ed) {
+            const int kp = e->plan.k[e->plan.in_idx[ed]];
+            for (int i = 0; i < kp; ++i, ++at) { pi_msg_out[at] = pm[size_t(ed) * 4 + i]; lambda_msg_out[at] = lm[size_t(ed) * 4 + i]; }
+        }
         return BN_OK;
     }
     if (e->last_path == 4) {  // bn_mid.hip keeps them in CSR edge order, two buffers: the run stopped in buffer n_sweeps & 1

@@ -40,7 +40,7 @@ def _cpt_of(plan, tile, entries):
 
 
 def _child_u(plan, st, tile, M, s):
-    first = s == 0
+    first = s == 0 and not plan.get("state_init", False)   # (a padded network's initial state stands in memory)
     cur, nxt = s & 1, (s & 1) ^ 1
     C = K ** M
     cn = plan["cnode"][int(tile[2]):int(tile[2]) + 64]
@@ -95,7 +95,7 @@ def _child_u(plan, st, tile, M, s):
 
 
 def _child_g(plan, st, tile, D, s):
-    first = s == 0
+    first = s == 0 and not plan.get("state_init", False)   # (a padded network's initial state stands in memory)
     cur, nxt = s & 1, (s & 1) ^ 1
     M, G = D + 2, 4 ** D
     cn = plan["cnode"][int(tile[2]):int(tile[2]) + 64]
@@ -178,7 +178,7 @@ def _child_g(plan, st, tile, D, s):
 
 
 def _parent(plan, st, tile, s):
-    first = s == 0
+    first = s == 0 and not plan.get("state_init", False)   # (a padded network's initial state stands in memory)
     cur, nxt = s & 1, (s & 1) ^ 1
     it = plan["pitem"][int(tile[2]):int(tile[2]) + 64]
     active = it[:, 0] >= 0
@@ -189,7 +189,7 @@ def _parent(plan, st, tile, s):
     dmax = int(tile[4])
     frozen = active & st.frz[node]
     is_msg = tedge >= 0
-    acc = np.ones((64, K))
+    acc = (np.arange(K)[None, :] < plan["node_k"][node][:, None]).astype(np.float64)
     old = np.ones((64, K))
     a = is_msg & (np.full(64, not first) | frozen)
     acc[a] = st.npi[cur, node[a]]
@@ -219,7 +219,7 @@ def _parent(plan, st, tile, s):
 
 def _parent_packed(plan, st, tile, s):
     """kDagParent: a node's c + 1 items in adjacent lanes; every lane loads ONE record, the node's lanes read each other's"""
-    first = s == 0
+    first = s == 0 and not plan.get("state_init", False)   # (a padded network's initial state stands in memory)
     cur, nxt = s & 1, (s & 1) ^ 1
     it = plan["pitem"][int(tile[2]):int(tile[2]) + 64]
     active = it[:, 0] >= 0
@@ -243,7 +243,7 @@ def _parent_packed(plan, st, tile, s):
     c = ~is_msg & frozen
     old[c] = st.nlam[cur, node[c]]
     assert (first_lane >= 0).all() and (first_lane[active] + deg[active] <= 63).all()
-    acc = np.where(is_msg[:, None], rec[first_lane], 1.0)
+    acc = np.where(is_msg[:, None], rec[first_lane], (np.arange(K)[None, :] < plan["node_k"][node][:, None]).astype(np.float64))
     for x in range(dmax):
         src = np.where(x < deg, first_lane + 1 + x, LANES)
         use = (x < deg) & (x != tpos)
@@ -261,12 +261,21 @@ def _parent_packed(plan, st, tile, s):
 def emulate(plan, model, evidence, eps, max_sweeps=0):
     n, E = plan["n"], plan["E"]
     st = _State(n, E)
+    k = np.asarray(model.k, dtype=np.int64)
+    plan = dict(plan, node_k=k, state_init=bool((k != K).any()))
     for j in range(evidence.ne):
         v = int(evidence.node[j])
-        vec = evidence.val[evidence.off[j]:evidence.off[j + 1]]
+        vec = np.zeros(K)
+        vec[:k[v]] = evidence.val[evidence.off[j]:evidence.off[j + 1]]
         st.npi[:, v] = vec
         st.nlam[:, v] = vec
         st.frz[v] = True
+    if plan["state_init"]:   # dag_init_kernel: ones over the states that exist, zeros in the padding; evidence nodes keep their vectors
+        kp = k[np.asarray(model.in_idx, dtype=np.int64)] if E else np.zeros(0, np.int64)
+        st.pim[0, :E] = st.lam[0, :E] = (np.arange(K)[None, :] < kp[:, None]).astype(np.float64)
+        free = ~st.frz
+        st.npi[0, free] = plan["npi_init"][free]
+        st.nlam[0, free] = (np.arange(K)[None, :] < k[free][:, None]).astype(np.float64)
     residuals = []
     s = 0
     tiny = np.finfo(np.float64).tiny
@@ -289,6 +298,9 @@ def emulate(plan, model, evidence, eps, max_sweeps=0):
             break
     fin = s & 1
     bel = st.npi[fin] * st.nlam[fin]
-    beliefs = _norm(bel).reshape(-1)
+    exists = np.arange(K)[None, :] < k[:, None]
+    beliefs = _norm(bel)[exists]
+    kp = k[np.asarray(model.in_idx, dtype=np.int64)] if E else np.zeros(0, np.int64)
+    ex_e = np.arange(K)[None, :] < kp[:, None]
     return {"beliefs": beliefs, "sweeps": s, "residuals": np.array(residuals),
-            "pi_msg": st.pim[fin, :E].reshape(-1).copy(), "lambda_msg": st.lam[fin, :E].reshape(-1).copy()}
+            "pi_msg": st.pim[fin, :E][ex_e].copy(), "lambda_msg": st.lam[fin, :E][ex_e].copy()}

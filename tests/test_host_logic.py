@@ -379,7 +379,7 @@ def test_mid_plan_emulated_equals_oracle(bnlib, oracle_mod):
 
 
 def test_dag_plan_emulated_equals_oracle(bnlib, oracle_mod):
-    """k = 4 networks with up to 5 parents per node: the plan of the register-resident DAG path (bn_dag_plan.cpp), executed
+    """Networks of arity <= 4 with up to 5 parents per node: the plan of the register-resident DAG path (bn_dag_plan.cpp), executed
     tile by tile and lane by lane on the CPU (tests/dag_emulator.py: the kernel's operation order, shuffle butterflies
     included).  Networks of nodes with <= 2 parents: the oracle bit for bit; lane-group tiles (factored contraction):
     <= 1e-12, equal sweep counts.  (On the GPU: tests/test_dag_gpu.py.)"""
@@ -395,6 +395,15 @@ def test_dag_plan_emulated_equals_oracle(bnlib, oracle_mod):
              (hub20, synth.random_evidence(hub20, 0.1, seed=1), 1e-9, 0, True), (hub70, synth.random_evidence(hub70, 0.1, seed=1), 1e-9, 0, True),
              (dag4, synth.random_evidence(dag4, 0.05, seed=2), 1e-6, 0, False), (dag4, soft, 1e-9, 0, False),
              (dag5, synth.random_evidence(dag5, 0.05, seed=3), 1e-6, 0, False), (dag5, Evidence.none(), 1e-12, 5, False)]
+    # arities 2..4, padded to 4 (zeros where a state does not exist; the initial state in memory): the real entries keep the
+    # reference's bits on networks of <= 2-parent nodes -- a zero term adds nothing to a sum -- and <= 1e-12 with lane groups
+    mix2 = synth.random_dag(200, 2, 16, [2, 3, 4], seed=17)
+    mixg = synth.grid(9, 9, 3, seed=4)
+    mix4 = synth.random_dag(250, 4, 32, [2, 3, 4, 2], seed=18)
+    softm = Evidence.from_dict(mix4, {v: np.linspace(0.2, 1.0, mix4.k[v]) for v in (5, 60, 200)})
+    cases += [(mix2, synth.random_evidence(mix2, 0.1, seed=4), 1e-9, 0, True), (mix2, Evidence.none(), 1e-6, 0, True),
+              (mixg, synth.random_evidence(mixg, 0.1, seed=5), 1e-9, 0, True),
+              (mix4, synth.random_evidence(mix4, 0.05, seed=6), 1e-6, 0, False), (mix4, softm, 1e-9, 0, False), (mix4, Evidence.none(), 0.0, 4, False)]
     for g, ev, eps, cap, exact in cases:
         with engine.Engine(g, device=_lib.BN_DEVICE_HOST_ONLY) as e:
             assert e.info("dag_eligible") == 1
@@ -455,9 +464,12 @@ def test_dag_plan_invariants(bnlib):
     with engine.Engine(big, device=_lib.BN_DEVICE_HOST_ONLY) as e:
         assert e.info("dag_eligible") == 1 and e.info("dag_stream") == 1 and e.info("dag_blocks") == 224
         assert e.info("dag_tiles") > 224 * 8
-    for other in (synth.random_dag(200, 4, 32, [4, 4, 3], seed=1), synth.random_dag(100, 6, 32, 4, seed=1), synth.pearl()):
+    for other in (synth.random_dag(200, 4, 32, [4, 4, 5], seed=1), synth.random_dag(100, 6, 32, 4, seed=1)):   # an arity above 4; six parents
         with engine.Engine(other, device=_lib.BN_DEVICE_HOST_ONLY) as e:
             assert e.info("dag_eligible") == 0 and e.dag_plan() is None
+    for padded in (synth.random_dag(200, 4, 32, [4, 4, 3], seed=1), synth.pearl()):   # arities below 4 are padded to 4
+        with engine.Engine(padded, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+            assert e.info("dag_eligible") == 1 and e.dag_plan() is not None
     obj = os.path.join(ROOT, "bayesiannetwork_amd", "csrc", "bn_dag.o")
     if os.path.exists(obj) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
