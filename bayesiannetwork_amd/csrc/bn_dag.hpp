@@ -63,6 +63,7 @@ struct DagPlan {
     int32_t blocks = 0;
     bool stream = false;                   // some wave walks more than one tile per iteration
     bool has_groups = false;               // some node has 3..5 parents (lane-group tiles)
+    double fill = 1.0;                     // real CPT entries / entries of the padded tables
     bool uniform4 = true;                  // every arity is 4; false: arities 2..4 padded to 4, the initial state is written to memory before a run
     std::vector<DagChildLane> cnode;       // [n_tiles * 64] (child tiles' entries)
     std::vector<DagParentLane> pitem;      // [n_tiles * 64] (parent tiles' entries)

@@ -121,6 +121,11 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
         }
     }
     dp.n_child_tiles = int32_t(tiles.size());
+    {
+        double padded = 0.0;
+        for (int32_t v = 0; v < n; ++v) padded += double(int64_t(4) << (2 * (p.in_ptr[v + 1] - p.in_ptr[v])));
+        dp.fill = padded > 0.0 ? double(p.cpt_off[n]) / padded : 1.0;
+    }
     for (const DagTile& t : tiles) dp.has_groups = dp.has_groups || t.kind >= 3;
     {
         // Parent items, nodes in order of their child count.  The c + 1 items of a node (lambda(v), then the pi-message to each

@@ -1188,7 +1188,11 @@ static bool dag_applies(const bn_engine* e) {
     if (!e->dag_ok || e->multisweep == 0 || e->dag_mode == 0) return false;
     if (e->dag_mode == 2) return true;
     if (e->small_ok) return false;   // one workgroup with the state in LDS
-    if (!e->dag.uniform4) return false;   // arities below 4 (padded form): where asked for ("dag" = 2) or chosen by "autotune" -- the item kernels give the oracle's bits for any parent count there
+    // Arities below 4 (padded form), us per sweep, this path / the default before (scripts/time_dag_mixed.py): mixed arities 2-4 with
+    // <= 3 parents 300 / 3 000 / 10 000 nodes 4.6 / 5.4, 5.7 / 7.1, 6.5 / 9.2 (item kernels); <= 4 parents, 10 000 nodes (723 k entries:
+    // beyond the item kernels) 6.5 / 32.5; binary, <= 4 parents, 10 000 nodes 6.2 / 7.7; k = 3 grid 64 x 64 5.0 / 6.1 -- but k = 2 grid
+    // 128 x 128 6.4 / 5.5 (resident tiles): an eighth of every padded table is real there.
+    if (!e->dag.uniform4 && !e->dag.has_groups && e->dag.fill < 0.25) return false;
     // Measured, us per query (evidence staged, profiles/r04_paths.json), this path / the best of the others:
     //   lane-group tiles (some node has 3-5 parents): 200 nodes 76 / 122, 1 000 nodes 87 / 165, 3 000 nodes 101 / 182, 10 000 nodes
     //   (BASELINE configs[1]) 117 / 215; nodes of <= 2 parents: 16 x 16 grid 86 / 95, 40 x 40 117 / 135, 64 x 64 113 / 139, 128 x 128

@@ -114,6 +114,7 @@ def test_mid_batch_on_a_network_of_more_than_100_workgroups(Engine, oracle_mod):
     evs = [synth.random_evidence(g, f, seed=40 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1])]
     with Engine(g) as eng:
         assert eng.info("mid_eligible") == 1 and eng.info("mid_parts") > 100
+        eng.set_option("dag", 0)   # (arities 2..4 with <= 4 parents: the register-resident DAG path would take it by default)
         out = eng.bp_run_batch(evs, 1e-6)
         assert eng.last_path() == 4 and eng.info("mid_aborts") == 0
         for q, ev in enumerate(evs):
