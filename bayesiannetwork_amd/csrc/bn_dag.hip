@@ -1,4 +1,4 @@
-// bn_dag.hip -- k = 4 networks with up to 5 parents per node: the whole belief-propagation run in ONE launch, every CPT
+// bn_dag.hip -- networks of arity <= 4 (2 and 3 padded to 4: bn_dag_plan.cpp) with up to 5 parents per node: the whole belief-propagation run in ONE launch, every CPT
 // entry resident in a register, a node's two roles on different waves (bn_dag.hpp).  Reference:
 // bayesian/inference/belief_propagation.hpp:33-158.
 //

@@ -1,4 +1,4 @@
-// bn_dag.hpp -- k = 4 networks with up to 5 parents per node (BASELINE.json configs[1]: the 10 k-node random DAG, 2.7 M
+// bn_dag.hpp -- networks of arity <= 4 (2 and 3 padded to 4: bn_dag_plan.cpp) with up to 5 parents per node (BASELINE.json configs[1]: the 10 k-node random DAG, 2.7 M
 // CPT entries): the whole run in ONE launch with every CPT entry resident in a register (bn_dag.hip).
 //
 // The tile layout (bn_plan.hpp) runs such a network at 12.4 us per sweep: 2.9 us of launch gap, then ONE lane-group tile's

@@ -206,7 +206,7 @@ PATH_NAME = {0: "one launch per sweep", 2: "resident tiles, one launch for the w
              3: "one workgroup, state in LDS, one launch for the whole run (small networks)",
              4: "the same items over several workgroups, state in memory, grid barrier per iteration, one launch for the whole run (mid-size networks)",
              5: "child tiles with the CPT in registers + parent items on waves of their own, state in memory, grid barrier per iteration, "
-                "one launch for the whole run (k = 4 networks with <= 5 parents)"}
+                "one launch for the whole run (networks of arity <= 4 with <= 5 parents)"}
 
 
 ENGINE_CLOCK_GHZ = 2.4  # MI355X peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md

@@ -221,7 +221,8 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  * "poll_sleep" n -- dataflow form: pause between two polls of a waiting tile, n x 512 cycles (default 2).
  * "beliefs_direct" 1/0 -- bn_bp_run_view: the kernels write the marginals straight into the engine's mapped host
  *   buffer (default 1, outputs up to 16 MB) instead of a copy command queued behind the run.
- * "dag" 0/1/2 -- networks whose nodes all have arity 4 and at most 5 parents (BASELINE configs[1], the 10 k-node random DAG): one
+ * "dag" 0/1/2 -- networks whose nodes all have arity <= 4 and at most 5 parents (BASELINE configs[1], the 10 k-node random DAG; arities 2
+ *   and 3 are padded to 4 with zeros, which leaves the real entries' bits alone): one
  *   launch per run with every CPT entry resident in a register; a node's child role (pi(v), lambda-messages: one wavefront of
  *   nodes / lane groups per tile) and parent role (lambda(v), pi-messages: one lane per message) run on different waves, the state
  *   lives in device memory in CSR edge order, one grid barrier per iteration.  Nodes with <= 2 parents keep the reference's
@@ -229,7 +230,8 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   results agree with the reference to rounding (<= 1e-12; its own products over >= 3 parents are unordered,
  *   belief_propagation.hpp:253).  Networks beyond one tile per wave run the same code walking several tiles per wave ("stream"
  *   form).  0 = never, 1 = where measured faster (default: networks with 3-5-parent nodes, and networks of <= 2-parent nodes that fit
- *   the chip at one tile per wave -- unless the one-workgroup path takes the network), 2 = wherever eligible.
+ *   the chip at one tile per wave -- unless the one-workgroup path takes the network, or less than a quarter of the padded tables
+ *   is real: binary networks of <= 2-parent nodes), 2 = wherever eligible.
  *   bn_bp_run_batch on such a network: up to 8 evidence sets share a launch and its CPT registers, taking turns inside an iteration;
  *   every set keeps the sweep count and the bits of its single run.
  *   bn_get_info "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts".
@@ -240,7 +242,7 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   request.  Single-rank engines only.  Exchanging paths may change the last bits of networks with >= 3-parent nodes.
  * bn_bp_last_path: 0 = one launch per sweep, 2 = resident tiles (one launch per run), 3 = one workgroup, state in LDS
  *   (small networks, one launch per run), 4 = the same items over several workgroups (mid-size networks), 5 = register-resident
- *   child tiles + parent items (k = 4 networks with <= 5 parents). */
+ *   child tiles + parent items (networks of arity <= 4 with <= 5 parents). */
 int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
@@ -362,7 +364,7 @@ int bn_small_plan_get(bn_engine *eng, int32_t *dims_out, uint32_t *ent, double *
 int bn_mid_plan_get(bn_engine *eng, int32_t part, int32_t *dims_out, uint32_t *ent, double *ent_cpt, uint32_t *term, uint16_t *clist,
                     uint32_t *bslot, uint32_t *cslot, double *npi_init);
 
-/* The plan of the register-resident DAG path (csrc/bn_dag.hpp: k = 4 networks with <= 5 parents per node; tests emulate the
+/* The plan of the register-resident DAG path (csrc/bn_dag.hpp: networks of arity <= 4 with <= 5 parents per node; tests emulate the
  * kernel on it).  dims_out[8] = n, E, tiles, blocks, stream (1: some wave walks several tiles per iteration), child tiles, parent
  * tiles, doubles of the CPT image; the arrays (any may be NULL) are sized from those: tiles [tiles][8] (kind, active nodes / items,
  * first per-lane entry, first double2 of the CPT image, largest child count, 3 unused), slot_ptr [blocks * 8 + 1], cnode
