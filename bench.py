@@ -387,6 +387,20 @@ def leg_dag(a, local_rank, torch):
                             "frac": tl["achieved"] / HBM_PEAK_GBS}, "batch": batch}
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps, budget_s=6.0)
+    # the same path on a network of MIXED arities (2..4, padded to 4 in registers; <= 4 parents, 10 000 nodes, 723 k CPT entries --
+    # beyond the item kernels): device-resident runs on a cycle of evidence sets, the tile kernels beside it
+    gm = synth.random_dag(10000, 4, 64, [2, 3, 4], seed=8)
+    evm = evidence_cycle(gm, a.evidence)
+    with Engine(gm, device=local_rank) as eng:
+        cm = time_cycled(eng, gm, evm, a.eps, 16)
+        pm = eng.last_path()
+        eng.set_option("dag", 0)
+        c0 = time_cycled(eng, gm, evm, a.eps, 8)
+        p0 = eng.last_path()
+    out["mixed_arity_10k"] = {"workload": f"10 k-node random DAG, arities 2-4, <=4 parents, {gm.n_edges} edges, {int(gm.cpt_off[-1])} CPT entries",
+                              "value": cm["value"], "unit": "edge-messages/s", "ms_per_step": cm["ms_per_step"], "sweeps_per_step": cm["sweeps_per_step"],
+                              "run_path": PATH_NAME.get(pm),
+                              "without_this_path": {"value": c0["value"], "ms_per_step": c0["ms_per_step"], "run_path": PATH_NAME.get(p0)}}
     return out
 
 
