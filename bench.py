@@ -15,6 +15,7 @@ The default single-GPU line also carries, as extra keys measured after the timed
   config5_lw         : BASELINE configs[4], likelihood weighting on that DAG
   grid2048           : the HBM-resident point (4.2 M nodes, 3.76 GB per sweep)
   batch              : 2 / 4 / 8 evidence sets per call on the headline grid (bn_bp_run_batch_device)
+  dropin_cpp         : the class surface, bn::inference::belief_propagation::operator() / run(), timed in C++ (tests/cpp/bench_dropin.cpp)
 each with its own value / roofline / cpu_baseline (--no-extras skips them).
 """
 from __future__ import annotations
@@ -247,39 +248,62 @@ def resident_record(t, label, waves_per_simd):
 
 
 def roofline_of(t, label):
-    """achieved = algorithmic bytes of the sweeps one launch executes / that launch's duration."""
+    """The dominant kernel against the bound that applies to it.  Scalars first, nested records last (a reader that keeps
+    only the leading scalars of this object must still see the figure that means something).
+
+    One launch per sweep (path 0): SURVEY 8(d) -- achieved = algorithmic bytes of a sweep / the launch's duration, against the
+    HBM peak.  One-launch paths that keep the CPTs on chip (2: resident tiles, 5: register-resident DAG): SURVEY 8(d)'s figure
+    prices a CPT read per sweep these kernels do not perform (it reaches 1.0 while the memory system moves a third of those
+    bytes), so `frac` is frac_resident -- the larger of (message + node-vector bytes that must still move, at the HBM peak) and
+    (the vector instructions that must issue) over the measured sweep time -- and the 8(d) figure stays as frac_survey_8d."""
     st = t["stats"]
     spl = t["sweeps_per_launch"]
-    out = {"bound": "hbm", "achieved": t["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": t["achieved"] / HBM_PEAK_GBS, "kernel": PATH_KERNEL.get(t["path"], "?"),
-           "avg_launch_us": t["avg_launch_s"] * 1e6, "sweeps_per_launch": spl,
-           "avg_sweep_us": t["avg_sweep_s"] * 1e6,
-           "avg_launch_us_source": f"HIP events on the engine's stream, {t['event_steps']} repeated steps after the timed region "
-                                   f"({t['ms_per_step_with_events']:.4f} ms per step with the events in the queue)",
-           "avg_sweep_us_devclock": t["avg_sweep_devclock_s"] * 1e6,
-           "achieved_devclock": st["algorithmic_bytes_per_sweep"] / max(t["avg_sweep_devclock_s"], 1e-12) / 1e9,
-           "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"] * spl,
-           "algorithmic_bytes_per_sweep": st["algorithmic_bytes_per_sweep"],
-           "layout_bytes_per_sweep": st["layout_bytes_per_sweep"]}
-    out.update(profiled_traffic(label))
+    achieved_8d = t["achieved"]
+    out = {"bound": "hbm", "achieved": achieved_8d, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_8d / HBM_PEAK_GBS}
+    traffic = profiled_traffic(label)
+    out["traffic"] = traffic["traffic"]
+    out["frac_survey_8d"] = achieved_8d / HBM_PEAK_GBS
+    out["achieved_survey_8d"] = achieved_8d
+    nested = {}
+    if t["path"] in (2, 5):
+        # resident tiles: 8 waves per 512-thread block on 4 SIMDs
+        wps = (t["waves_per_block"] or 8) / 4.0
+        res = resident_record(t, label, wps)
+        out["bound"] = res["bound"]
+        out["frac"] = out["frac_resident"] = res["frac_resident"]
+        if res["bound"] == "hbm":
+            out["achieved"] = res["achieved_gbs"]
+        else:   # vector issue: wave-instructions per second over what the occupied SIMDs can issue, scaled to the chip
+            out["unit"] = "G wave-instructions/s"
+            out["peak"] = 256 * 4 * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_INST
+            out["achieved"] = out["peak"] * res["frac_resident"]
+        out["floor_hbm_us"] = res["floor_hbm_us"]
+        out["floor_valu_us"] = res["floor_valu_us"]
+        out["must_move_bytes_per_sweep"] = res["bytes_per_sweep"]
+        out["limiter"] = "latency: barrier hand-off + dependent message round trips above the " + res["bound"] + " floor"
+        out["note"] = ("frac = frac_resident = max(message + node-vector bytes at the HBM peak, VALU issue time) / measured sweep time; "
+                       "frac_survey_8d = SURVEY 8(d) algorithmic bytes (a CPT read per node and sweep) / time, kept for comparison with "
+                       "the per-sweep formulation: this kernel keeps the CPTs in registers, so that figure is not a roofline for it")
+        nested["resident"] = res
+    out.update({"kernel": PATH_KERNEL.get(t["path"], "?"),
+                "avg_launch_us": t["avg_launch_s"] * 1e6, "sweeps_per_launch": spl,
+                "avg_sweep_us": t["avg_sweep_s"] * 1e6,
+                "avg_launch_us_source": f"HIP events on the engine's stream, {t['event_steps']} repeated steps after the timed region "
+                                        f"({t['ms_per_step_with_events']:.4f} ms per step with the events in the queue)",
+                "avg_sweep_us_devclock": t["avg_sweep_devclock_s"] * 1e6,
+                "achieved_devclock": st["algorithmic_bytes_per_sweep"] / max(t["avg_sweep_devclock_s"], 1e-12) / 1e9,
+                "algorithmic_bytes_per_launch": st["algorithmic_bytes_per_sweep"] * spl,
+                "algorithmic_bytes_per_sweep": st["algorithmic_bytes_per_sweep"],
+                "layout_bytes_per_sweep": st["layout_bytes_per_sweep"],
+                "traffic_source": traffic["traffic_source"], "traffic_stale": traffic.get("traffic_stale")})
     if out.get("traffic"):
         out["traffic_gbs"] = out["traffic"] / max(t["avg_launch_s"], 1e-12) / 1e9  # what the memory system actually moved
     # resident tiles: 8 waves per 512-thread block on 4 SIMDs; per-sweep launches: 256-thread blocks, 2 blocks per CU
-    out.update(profiled_valu(label, 2 if t["path"] == 2 else min(2.0, max(1.0, t["n_tiles"] / 1024.0))))
-    if t["path"] in (2, 5):
-        # Paths that keep the CPTs on chip: SURVEY 8(d)'s `frac` prices a CPT read per sweep that these kernels do not perform
-        # (it can exceed 1), so it is no bound for them.  `resident` holds the bounds they cannot beat -- the bytes that must
-        # still move at the HBM peak, the vector instructions they must issue -- and `frac_resident` <= 1 against the larger.
-        wps = (t["waves_per_block"] or 8) / 4.0
-        res = resident_record(t, label, wps)
-        out["resident"] = res
-        out["frac_resident"] = res["frac_resident"]
-        out["frac_survey_8d"] = out["frac"]
-        out["bound"] = res["bound"]
-        out["limiter"] = "latency: barrier hand-off + dependent message round trips above the " + res["bound"] + " floor"
-        out["note"] = ("frac / achieved = SURVEY 8(d) algorithmic bytes (a CPT read per node and sweep) / time, kept for comparison with "
-                       "the per-sweep formulation; this kernel keeps the CPTs in registers, so the figure is not a roofline for it. "
-                       "frac_resident = max(message + node-vector bytes at the HBM peak, VALU issue time) / measured sweep time")
+    valu = profiled_valu(label, 2 if t["path"] == 2 else min(2.0, max(1.0, t["n_tiles"] / 1024.0)))
+    if "valu_counters" in valu:
+        nested["valu_counters"] = valu.pop("valu_counters")
+    out.update(valu)
+    out.update(nested)
     return out
 
 
@@ -351,6 +375,52 @@ def time_cycled(eng, g, evs, eps, steps):
             "steps": steps, "evidence_sets_cycled": len(evs), "sweeps_per_step": sweeps / steps,
             "sweep_launches_per_step": launches / steps, "ms_per_step_blocks": [round(b[0] / steps * 1e3, 4) for b in blocks],
             "what": "bn_bp_run_device on a cycle of different staged evidence sets; clock around the run only; median of three blocks"}
+
+
+def wsum64(arr):
+    """Order-sensitive checksum tests/cpp/bench_dropin.cpp states in C++: sum_i word_i * (2 i + 1) mod 2^64."""
+    import numpy as np
+    w = np.ascontiguousarray(arr, dtype=np.float64).view(np.uint64)
+    with np.errstate(over="ignore"):
+        return int((w * (np.arange(w.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+
+
+def leg_dropin_cpp(a, local_rank, torch):
+    """The drop-in where the reference's user calls it: bn::inference::belief_propagation::operator()(precondition, epsilon)
+    (reference belief_propagation.hpp:31-159) timed by a C++ program over include/compat's graph_t (tests/cpp/bench_dropin.cpp,
+    plain g++), on BASELINE configs[0], [1], [2], with its split -- evidence marshal / bn_bp_run_view / building the reference's
+    unordered_map<vertex_type, matrix_type> / the caller destroying it -- beside run(), the same query through the non-owning
+    marginals_view.  A child process, outside every timed region of this script; its sweeps and a checksum of query 0's
+    marginals are compared with this process' own run of the same network and evidence through ctypes."""
+    import subprocess
+
+    import __graft_entry__
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.dsc import load_dsc
+    from bayesiannetwork_amd.engine import Engine
+    exe = __graft_entry__.build_bench_dropin()
+    env = dict(os.environ)
+    env.setdefault("HIP_VISIBLE_DEVICES", str(local_rank))
+    p = subprocess.run([exe, "--dsc", os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    if p.returncode != 0:
+        return {"error": f"bench_dropin rc {p.returncode}: {p.stderr[-300:]}"}
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    nets = {"config1_alarm": (lambda: load_dsc(os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"))[0], 0.1, 1e-6),
+            "config2_dag": (lambda: synth.random_dag(10000, 4, 64, 4, seed=1), 0.01, 1e-3),
+            "config3_grid": (lambda: synth.grid(316, 316, 4, seed=2), 0.01, 1e-3)}
+    for key, (make, frac, eps) in nets.items():
+        if key not in out:
+            continue
+        g = make()
+        with Engine(g, device=local_rank) as eng:
+            r = eng.bp_run_view(synth.random_evidence(g, frac, seed=7), eps)
+        out[key]["matches_c_abi"] = bool(r["sweeps"] == out[key]["sweeps_query0"]
+                                         and f"{wsum64(r['beliefs']):016x}" == out[key]["wsum64_query0"])
+    out["what"] = ("tests/cpp/bench_dropin.cpp: medians per query, ms; operator_ms = bn::inference::belief_propagation::operator() called, "
+                   "its map used and dropped; run_view_ms = run() (marshal + bn_bp_run_view, marginals read in place); map_build_copy_assign_ms = "
+                   "how the map was built before this round (default-constructed entry + copy assignment per node)")
+    return out
 
 
 def leg_dag(a, local_rank, torch):
@@ -797,6 +867,9 @@ def main():
         out["frac_host_to_host"] = h2h["value"] * bytes_per_msg / (HBM_PEAK_GBS * 1e9)
         out["ms_per_step_host_to_host"] = h2h["ms_per_step"]
         out["host_to_host"] = h2h
+        # the same scalars inside `config` (a reader that keeps only the contract's keys still sees them)
+        out["config"].update({"value_host_to_host": h2h["value"], "frac_host_to_host_survey_8d": out["frac_host_to_host"],
+                              "ms_per_step_host_to_host": h2h["ms_per_step"]})
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(g, ev, a.eps)
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -807,6 +880,16 @@ def main():
             out["cpu_reference_small"] = ref
     eng.close()
     if default_run and not a.no_extras:
+        try:
+            dc = leg_dropin_cpp(a, local_rank, torch)
+        except Exception as ex:  # noqa: BLE001 - an extra must never lose the headline
+            dc = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
+        out["dropin_cpp"] = dc
+        if "config3_grid" in dc:
+            gd = dc["config3_grid"]
+            out["config"].update({"ms_per_query_dropin_cpp": gd["operator_ms"], "ms_per_query_dropin_cpp_run_view": gd["run_view_ms"],
+                                  "ms_dropin_cpp_map_build": gd["map_build_ms"], "ms_dropin_cpp_map_destroy": gd["map_destroy_ms"],
+                                  "dropin_cpp_matches_c_abi": gd.get("matches_c_abi")})
         for key, fn in (("batch", leg_batch), ("config1_alarm", leg_alarm), ("mid_mixed300", leg_mid), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
             try:
                 out[key] = fn(a, local_rank, torch)

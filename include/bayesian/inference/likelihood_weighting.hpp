@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "mi355x_flatten.hpp"
+#include "mi355x_marginals.hpp"
 
 namespace bn {
 namespace inference {
@@ -57,6 +58,14 @@ public:
     // Run: Likelihood Weighting (reference :28-59)
     return_type operator()(evidence_list const& evidence, std::uint64_t const sample_num = 10000)
     {
+        return run(evidence, sample_num).to_map();
+    }
+
+    // Not in the reference: the same call with the marginals read in place (mi355x_marginals.hpp) instead of the
+    // reference's map of 1 x k matrices (three heap blocks per node); valid until the next call on this functor.
+    typedef mi355x::marginals_view view_type;
+    view_type run(evidence_list const& evidence, std::uint64_t const sample_num = 10000)
+    {
         std::vector<std::int32_t> ev_node, ev_state;
         for(auto const& e : evidence)
         {
@@ -65,25 +74,22 @@ public:
             ev_node.push_back(it->second);
             ev_state.push_back(e.second);
         }
-        std::vector<double> hist(static_cast<std::size_t>(model_.node_off.back()));
+        marginals_.resize(static_cast<std::size_t>(model_.node_off.back()));
         mi355x::engine_handle::check(bn_lw_run(
             engine_.get(), static_cast<std::int32_t>(ev_node.size()), ev_node.data(), ev_state.data(), next_sample_,
-            sample_num, seed_, hist.data()));
+            sample_num, seed_, marginals_.data()));
         next_sample_ += sample_num;
 
-        return_type ret;
         for(std::size_t i = 0; i < model_.nodes.size(); ++i)
         {
             std::size_t const kv = static_cast<std::size_t>(model_.k[i]);
-            matrix_type m(1, kv);
+            double* const h = marginals_.data() + model_.node_off[i];
             // Normalization, reference :197-221: uniform when the weights vanish
             double sum = 0;
-            for(std::size_t j = 0; j < kv; ++j) sum += hist[model_.node_off[i] + j];
-            for(std::size_t j = 0; j < kv; ++j)
-                m[0][j] = (sum < 1.0e-20) ? 1.00 / kv : hist[model_.node_off[i] + j] / sum;
-            ret[model_.nodes[i]] = m;
+            for(std::size_t j = 0; j < kv; ++j) sum += h[j];
+            for(std::size_t j = 0; j < kv; ++j) h[j] = (sum < 1.0e-20) ? 1.00 / kv : h[j] / sum;
         }
-        return ret;
+        return view_type(model_, marginals_.data());
     }
 
     // Make: accurate sample (reference :62-117).  Units of unit_size weighted samples are drawn
@@ -157,20 +163,14 @@ public:
             for(std::size_t v = 0; v < n; ++v) pattern[model_.nodes[v]] = static_cast<unsigned char>(kv.first[v]);
             patterns[pattern] = kv.second;
         }
-        return_type marginals;
-        for(std::size_t v = 0; v < n; ++v)
-        {
-            matrix_type m(1, static_cast<std::size_t>(model_.k[v]));
-            m.assign(probabilities.begin() + model_.node_off[v], probabilities.begin() + model_.node_off[v + 1]);
-            marginals[model_.nodes[v]] = m;
-        }
-        return std::make_pair(std::move(patterns), std::move(marginals));
+        return std::make_pair(std::move(patterns), view_type(model_, probabilities.data()).to_map());
     }
 
 private:
     graph_t graph_;   // the reference keeps a copy too
     mi355x::flat_model model_;
     mi355x::engine_handle engine_;
+    std::vector<double> marginals_;   // what run()'s view reads
     std::uint64_t seed_ = 0;
     std::uint64_t next_sample_ = 0;
     std::uint64_t last_units_ = 0;

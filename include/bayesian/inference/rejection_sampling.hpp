@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "mi355x_flatten.hpp"
+#include "mi355x_marginals.hpp"
 
 namespace bn {
 namespace inference {
@@ -56,6 +57,14 @@ public:
     // Run: Logic Sampling (a.k.a. Rejection Sampling) (reference :33-62)
     return_type operator()(std::vector<std::pair<vertex_type, int>> const& condition, int const generate_sample_num = 10000)
     {
+        return run(condition, generate_sample_num).to_map();
+    }
+
+    // Not in the reference: the same call with the marginals read in place (mi355x_marginals.hpp) instead of the
+    // reference's map of 1 x k matrices; valid until the next call on this functor.
+    typedef mi355x::marginals_view view_type;
+    view_type run(std::vector<std::pair<vertex_type, int>> const& condition, int const generate_sample_num = 10000)
+    {
         std::vector<std::int32_t> ev_node, ev_state;
         for(auto const& c : condition)
         {
@@ -65,31 +74,24 @@ public:
             ev_node.push_back(it->second);
             ev_state.push_back(c.second);
         }
-        std::vector<double> counts(static_cast<std::size_t>(model_.node_off.back()));
+        marginals_.resize(static_cast<std::size_t>(model_.node_off.back()));
         std::uint64_t drawn = 0, accepted = 0;
         mi355x::engine_handle::check(bn_rs_run(
             engine_.get(), static_cast<std::int32_t>(ev_node.size()), ev_node.data(), ev_state.data(), next_sample_,
-            static_cast<std::uint64_t>(generate_sample_num), max_draws_, seed_, counts.data(), &drawn, &accepted));
+            static_cast<std::uint64_t>(generate_sample_num), max_draws_, seed_, marginals_.data(), &drawn, &accepted));
         next_sample_ += drawn;
         last_drawn_ = drawn;
         if(accepted < static_cast<std::uint64_t>(generate_sample_num))
             throw std::runtime_error("rejection_sampling: condition too unlikely, gave up after max_draws() samples");
-
-        return_type result;
-        for(std::size_t i = 0; i < model_.nodes.size(); ++i)
-        {
-            std::size_t const kv = static_cast<std::size_t>(model_.k[i]);
-            matrix_type mat(1, kv, 0.0);
-            for(std::size_t j = 0; j < kv; ++j) mat[0][j] = counts[model_.node_off[i] + j] / static_cast<double>(accepted);
-            result[model_.nodes[i]] = mat;
-        }
-        return result;
+        for(double& c : marginals_) c = c / static_cast<double>(accepted);
+        return view_type(model_, marginals_.data());
     }
 
 private:
     graph_t graph_;   // the reference keeps a copy too
     mi355x::flat_model model_;
     mi355x::engine_handle engine_;
+    std::vector<double> marginals_;   // what run()'s view reads
     std::uint64_t seed_ = 0, next_sample_ = 0, last_drawn_ = 0;
     std::uint64_t max_draws_ = std::uint64_t(1) << 34;
 };

@@ -127,6 +127,33 @@ void print_marginals(char const* name, bn::graph_t const& g,
     std::printf("]%s", last ? "" : ",");
 }
 
+// run()'s non-owning view against operator()'s map: same vertices, same arities, same bits
+template<class View, class Map>
+void view_equals_map(View const& view, Map const& map, bn::graph_t const& g, char const* what)
+{
+    auto const vl = g.vertex_list();
+    bool ok = view.size() == map.size() && view.size() == vl.size();
+    std::size_t i = 0, doubles = 0;
+    for(auto const& e : view)
+    {
+        if(i >= vl.size() || e.vertex != vl[i]) { ok = false; break; }   // iteration is in vertex_list() order
+        auto const it = map.find(e.vertex);
+        if(it == map.end() || it->second.height() != 1 || it->second.width() != e.k || view.k(e.vertex) != e.k || view[e.vertex] != e.p)
+        { ok = false; break; }
+        for(std::size_t j = 0; j < e.k; ++j)
+            if(std::memcmp(&it->second[0][j], e.p + j, sizeof(double)) != 0) ok = false;
+        auto const cell = view.matrix(e.vertex);
+        for(std::size_t j = 0; j < e.k; ++j)
+            if(std::memcmp(&cell[0][j], e.p + j, sizeof(double)) != 0) ok = false;
+        doubles += e.k;
+        ++i;
+    }
+    if(doubles != view.doubles() || view.data() != (vl.empty() ? view.data() : view[vl[0]])) ok = false;
+    bool threw = false;
+    try { view[std::make_shared<bn::vertex_t>()]; } catch(std::out_of_range const&) { threw = true; }
+    if(!ok || !threw) { ++failures; std::printf("FAIL %s: marginals_view differs from the returned map\n", what); }
+}
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -175,6 +202,8 @@ int main(int argc, char** argv)
         for(int i = 0; i < 4; ++i)
             for(int j = 0; j < 2; ++j) close_pct(r2.at(v[i])[0][j], t2[i][j], 0.1, "pearl part2");
         print_marginals("pearl_part2", pearl, r2);
+        view_equals_map(bp.run(pre), r2, pearl, "belief_propagation pearl part2");
+        view_equals_map(bp.run(), r1, pearl, "belief_propagation pearl part1");
         std::printf("\"pearl_part2_sweeps\":%d,", bp.last_sweeps());
     }
     {   // belief_propagation_resume_ex, _sample1 .. _sample4  (3 % tolerance, one queried node each)
@@ -196,6 +225,7 @@ int main(int argc, char** argv)
             auto const res = func(pre);
             for(std::size_t j = 0; j < c.teacher.size(); ++j) close_pct(res.at(v[c.query])[0][j], c.teacher[j], 3.0, "resume");
             print_marginals(("resume_" + std::to_string(idx++)).c_str(), chain, res);
+            view_equals_map(func.run(pre), res, chain, "belief_propagation resume");
         }
         // the same five queries in ONE call (run_batch, an extension): bit-for-bit what the single calls return
         std::vector<std::unordered_map<bn::vertex_type, bn::matrix_type>> queries;
@@ -228,6 +258,11 @@ int main(int argc, char** argv)
         for(int i = 0; i < 3; ++i)
             for(int j = 0; j < 2; ++j) close_pct(res.at(v[i])[0][j], exact[i][j], 2.0, "lw pearl");
         print_marginals("lw_pearl", pearl, res);
+        lw.seed(2024);   // the same samples again: the fp64 atomics of the histogram may round differently, the view reads what this call made
+        auto const view = lw.run(ev, 400000);
+        for(int i = 0; i < 3; ++i)
+            for(int j = 0; j < 2; ++j) close_pct(view[v[i]][j], res.at(v[i])[0][j], 1e-7, "lw run() vs operator()");
+        view_equals_map(view, view.to_map(), pearl, "likelihood_weighting");
     }
     {   // make_samples (reference likelihood_weighting.hpp:62-117) on Pearl, H = 0
         auto const v = pearl.vertex_list();
@@ -279,6 +314,8 @@ int main(int argc, char** argv)
         close_pct(result.at(v[1])[0][1], 0.38, 10, "rejection v2[1]");
         close_pct(result.at(v[3])[0][1], 1.0, 1e-9, "rejection keeps the condition");
         print_marginals("rejection", net, result);
+        func.seed(99);   // integer counts: the view of the same draws is the map bit for bit
+        view_equals_map(func.run({{v[3], 1}, {v[0], 0}}), result, net, "rejection_sampling");
         std::printf("\"rejection_drawn\":%llu,", static_cast<unsigned long long>(func.last_drawn()));
     }
     {   // CPT liveness.  The reference reads node->cpt at every call (belief_propagation.hpp:61, :186, :252): an edited table is

@@ -136,3 +136,59 @@ def test_reference_cases_through_cpp_classes(bnlib, tmp_path):
     counts, drawn, acc = oracle.rs_run(net, np.array([0, -1, -1, 1, -1], np.int32), 10000, seed=99)
     assert d["rejection_drawn"] == drawn and acc == 10000
     assert np.array_equal(np.asarray(d["rejection"]), counts / 10000.0)
+
+
+# ---- tests/cpp/bench_dropin.cpp: the C++ bench of the class surface (bench.py's `dropin_cpp` leg) ----
+
+def _wsum64(arr, as_int=False):
+    a = np.ascontiguousarray(arr)
+    w = a.astype(np.int64).view(np.uint64) if as_int else a.astype(np.float64).view(np.uint64)
+    with np.errstate(over="ignore"):
+        return int((w * (np.arange(w.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+
+
+def _bench_networks():
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.dsc import load_dsc
+    return {"config1_alarm": (load_dsc(os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc"))[0], 0.1, 1e-6),
+            "config2_dag": (synth.random_dag(10000, 4, 64, 4, seed=1), 0.01, 1e-3),
+            "config3_grid": (synth.grid(316, 316, 4, seed=2), 0.01, 1e-3)}
+
+
+def test_bench_dropin_builds_the_bench_networks(bnlib):
+    """The C++ bench builds BASELINE configs[0..2] through graph_t / cpt_t with the generators of synth.py restated in C++:
+    flat model and evidence of query 0 equal the Python side's (checksums over every parent index, CPT entry, evidence pair)."""
+    import __graft_entry__
+    from bayesiannetwork_amd import synth
+    exe = __graft_entry__.build_bench_dropin()
+    out = subprocess.run([exe, "--checksum"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout)
+    for key, (g, frac, _) in _bench_networks().items():
+        st = synth.random_evidence(g, frac, seed=7).hard_states(g)
+        nodes = np.nonzero(st >= 0)[0]
+        assert d[key]["nodes"] == g.n and d[key]["edges"] == g.n_edges
+        assert d[key]["in_idx"] == f"{_wsum64(g.in_idx, True):016x}"
+        assert d[key]["cpt"] == f"{_wsum64(g.cpt):016x}"
+        assert d[key]["evidence"] == f"{_wsum64(nodes * 256 + st[nodes], True):016x}"
+
+
+@pytest.mark.gpu
+def test_bench_dropin_view_equals_map_equals_c_abi(bnlib):
+    """run()'s marginals_view == operator()'s map bit for bit on configs[0..2] at full size, and both equal what the ctypes
+    path gets for the same network and evidence (sweep count, checksum over all marginals)."""
+    import __graft_entry__
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+    exe = __graft_entry__.build_bench_dropin()
+    out = subprocess.run([exe, "--reps", "3", "--dsc", os.path.join(ROOT, "tests", "golden", "alarm_shaped.dsc")],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    for key, (g, frac, eps) in _bench_networks().items():
+        assert d[key]["map_equals_view"] is True
+        with Engine(g, device=0) as eng:
+            r = eng.bp_run_view(synth.random_evidence(g, frac, seed=7), eps)
+        assert r["sweeps"] == d[key]["sweeps_query0"]
+        assert f"{_wsum64(r['beliefs']):016x}" == d[key]["wsum64_query0"]
+        assert d[key]["run_view_ms"] > 0 and d[key]["operator_ms"] >= d[key]["run_view_ms"]
