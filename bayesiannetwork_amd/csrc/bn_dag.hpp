@@ -33,6 +33,8 @@ constexpr int kDagWaves = 8;            // per block: two per SIMD, 256 VGPRs ea
 constexpr int kDagMaxBlocks = kResidentMaxBlocks;  // one granule pair per block, four pairs per polling lane
 constexpr int kDagBudget = kResidentBudget;        // iterations per launch (ResidentSync::res)
 constexpr int kDagMaxParents = 5;
+constexpr int kDagMaxChildren = 1024;   // per node: DagParentLane::deg_tpos holds count | rank << 16 (signed), wide items cost deg^2 loads
+constexpr int64_t kDagMaxImageBytes = int64_t(256) << 20;   // padded CPT image (registers, or re-read per sweep in stream form)
 constexpr int kDagRegChildren = 8;
 constexpr int kDagMaxSets = 8;      // evidence sets one launch can walk (bn_bp_run_batch): per-set state, marks, barrier words; the CPT registers serve all      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
 

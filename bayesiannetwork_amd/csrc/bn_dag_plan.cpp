@@ -42,6 +42,17 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
     }
     cap_blocks = std::min<int32_t>(cap_blocks & ~7, kDagMaxBlocks);
     if (cap_blocks < 8) { dp.why = "device too small"; return; }
+    {
+        // The padded register image: 4^(m+1) entries per node whatever its arities.  Beyond kDagMaxImageBytes the path is refused: in
+        // stream form the image is re-read every sweep (a padded binary network with 5-parent nodes is 64x its model), the tile
+        // kernels read the unpadded tables at the HBM rate, and DagTile::cpt_base is a 32-bit double2 index.
+        int64_t img_entries = 0;
+        for (int32_t v = 0; v < n; ++v) {
+            const int m = p.in_ptr[v + 1] - p.in_ptr[v];
+            img_entries += int64_t(4) << (2 * m);   // (tiles are padded to 64 lanes: at most one tile per parent count more)
+        }
+        if (img_entries * 8 > kDagMaxImageBytes) { dp.why = "padded CPT image beyond 256 MB"; return; }
+    }
     dp.n = n;
     dp.E = int32_t(p.E);
 
@@ -49,6 +60,14 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
     std::vector<int32_t> out_ptr(n + 1, 0);
     for (int64_t e = 0; e < p.E; ++e) out_ptr[p.in_idx[e] + 1]++;
     for (int32_t v = 0; v < n; ++v) out_ptr[v + 1] += out_ptr[v];
+    for (int32_t v = 0; v < n; ++v)
+        if (out_ptr[v + 1] - out_ptr[v] > kDagMaxChildren) {
+            // DagParentLane packs child count | rank << 16, and the items of a node with more than 63 children each walk ALL its
+            // children (deg^2 record loads per sweep): hubs beyond this stay on the tile / item kernels
+            dp = DagPlan();
+            dp.why = "a node has more than " + std::to_string(kDagMaxChildren) + " children";
+            return;
+        }
     dp.oedge.assign(std::max<int64_t>(p.E, 1), 0);
     {
         std::vector<int32_t> fill(n, 0);

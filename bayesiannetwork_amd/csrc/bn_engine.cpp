@@ -98,6 +98,7 @@ static int load_rccl() {
 struct bn_engine {
     Plan plan;
     bool host_only = true;
+    bool poisoned = false;          // a bn_reload_cpt upload failed half-way: device images of mixed age, every compute call is refused
     int device = -1;
     hipStream_t stream = nullptr;
     // device images
@@ -446,9 +447,9 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     if (p.nranks == 1 && !std::getenv("BN_NO_DAG")) {  // k = 4, <= 5 parents: register-resident child tiles + parent items (bn_dag.hpp)
         try {
             build_dag_plan(p, kDagDefaultCap, e->dag);
-        } catch (const std::bad_alloc&) {
-            delete e;
-            return fail(BN_ERR_ALLOC, "out of host memory while building the plan of the register-resident DAG path");
+        } catch (const std::bad_alloc&) {   // the other paths can still run the network
+            e->dag = DagPlan();
+            e->dag.why = "out of host memory while building the plan";
         }
     }
     if (desc->device == BN_DEVICE_HOST_ONLY) {
@@ -651,7 +652,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         if (e->dag.ok) {
             int32_t cap = int32_t((int64_t(e->n_cus) * 9 / 10) & ~int64_t(7));
             if (const char* c = std::getenv("BN_DAG_CAP")) cap = std::max(8, std::min(cap, std::atoi(c) & ~7));   // experiments: fewer blocks
-            if (cap != kDagDefaultCap) build_dag_plan(p, cap, e->dag);
+            if (cap != kDagDefaultCap) {
+                try {
+                    build_dag_plan(p, cap, e->dag);
+                } catch (const std::bad_alloc&) {
+                    e->dag = DagPlan();
+                    e->dag.why = "out of host memory while building the plan";
+                }
+            }
         }
         if (e->dag.ok) {
             const DagPlan& dp = e->dag;
@@ -796,6 +804,7 @@ static int set_evidence_impl(bn_engine* e, int32_t ne, const int32_t* ev_node, c
                              const double* ev_val, bool wait) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     const Plan& p = e->plan;
     int rc = check_evidence(p, ne, ev_node, ev_off, e->ev_seen, e->ev_epoch);
     if (rc) return rc;
@@ -1198,6 +1207,9 @@ static bool dag_applies(const bn_engine* e) {
     //   (BASELINE configs[1]) 117 / 215; nodes of <= 2 parents: 16 x 16 grid 86 / 95, 40 x 40 117 / 135, 64 x 64 113 / 139, 128 x 128
     //   133 / 146, 3 000-node DAG 106 / 119, 200-node chain 74 / 74 -- but 200 x 200 grid 283 / 151, 316 x 316 634 / 234: there the
     //   network no longer fits the chip at one tile per wave (stream form) and the resident tiles keep it.
+    // stream form re-reads the padded image every sweep: not where less than a quarter of it is real (a padded binary network
+    // with 5-parent nodes is 64x its model), whatever the parent counts -- only <= 10 k-node networks were measured in that form
+    if (e->dag.stream && e->dag.fill < 0.25) return false;
     if (e->dag.has_groups) return true;
     return !e->dag.stream;
 }
@@ -1368,6 +1380,7 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     }
     e->beliefs_on_host_only = false;  // (bn_bp_run_view sets it again when its kernels wrote to the host buffer)
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
     if (e->plan.nranks > 1 && !e->comm && !(e->shard_flow_ok && e->multisweep != 0))
         return fail(BN_ERR_COMM, "sharded engine: call bn_comm_init (RCCL exchange) or bn_peer_import (in-kernel exchange) before running");
@@ -1695,6 +1708,7 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
                                         const int32_t* ev_off, const double* ev_val) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     e->batch_on_dense = false;
     if (n_sets >= 1 && n_sets <= BN_MAX_BATCH_SETS) {
         int rc;
@@ -2221,6 +2235,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
         return rc;
     }
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     if (max_sweeps < 0) return fail(BN_ERR_ARG, "max_sweeps < 0");
     bn_engine::Batch& bt = e->batch;
     if (bt.n_sets < 1) return fail(BN_ERR_STATE, "call bn_bp_set_evidence_batch first");
@@ -2249,6 +2264,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
         if (rc == BN_ERR_STATE) {   // a grid wait gave up: the whole batch again on the other paths
             ++e->dag_aborts;
             e->dag_cooldown = 64;
+            report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip, batch)", 64);
             batch_dag = false;
             bt.sweeps.assign(bt.n_sets, 0);
             bt.residual.assign(bt.n_sets, 0.0);
@@ -2270,6 +2286,7 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
         if (rc == BN_ERR_STATE) {   // a grid wait gave up: the whole batch again on the tile kernels
             ++e->mid_aborts;
             e->mid_cooldown = 64;
+            report_abort_once(e, "the several-workgroup item kernel (bn_mid.hip, batch)", 64);
             batch_mid = false;
             bt.sweeps.assign(bt.n_sets, 0);
             bt.residual.assign(bt.n_sets, 0.0);
@@ -2788,44 +2805,64 @@ static int reupload(T* dst, const std::vector<T>& src, size_t expect, hipStream_
 }
 extern "C" int bn_reload_cpt(bn_engine* e, const double* cpt, int64_t n_entries) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: an earlier bn_reload_cpt failed while uploading (destroy it and create a new one)");
     Plan& p = e->plan;
     const int64_t want = p.n > 0 ? p.cpt_off[p.n] : 0;
     if (n_entries != want) return fail(BN_ERR_ARG, "bn_reload_cpt: " + std::to_string(n_entries) + " entries given, the model has " + std::to_string(want));
     if (want > 0 && !cpt) return fail(BN_ERR_ARG, "null cpt");
-    p.cpt_flat.assign(cpt, cpt + want);
-    if (e->dense) { free_engine(e->dense); e->dense = nullptr; e->batch_on_dense = false; }   // (rebuilt from the new tables on demand)
+    // Two phases.  (1) every host plan that holds CPT values is rebuilt from the new array into TEMPORARIES and checked against
+    // the one in use; a mismatch returns with the engine exactly as it was.  (2) the temporaries are swapped in and the device
+    // images overwritten; a HIP failure there leaves device images of mixed age, so the engine is marked unusable.
+    std::vector<double> old_flat;
+    bool swapped_flat = false;
     try {
-        const size_t s_cpt = e->small.ent_cpt.size(), s_init = e->small.npi_init.size();
+        old_flat.assign(cpt, cpt + want);
+        old_flat.swap(p.cpt_flat);   // the planners read p.cpt_flat; old_flat now holds the values in force
+        swapped_flat = true;
+        auto refuse = [&](const char* what) {
+            p.cpt_flat.swap(old_flat);
+            return fail(BN_ERR_STATE, std::string("bn_reload_cpt: ") + what);
+        };
+        SmallPlan n_small;
+        MidPlan n_mid;
+        DagPlan n_dag;
         if (e->small.ok) {
-            build_small_plan(p, e->small);
-            if (!e->small.ok || e->small.ent_cpt.size() != s_cpt || e->small.npi_init.size() != s_init)
-                return fail(BN_ERR_STATE, "bn_reload_cpt: the one-workgroup plan changed");
+            build_small_plan(p, n_small);
+            if (!n_small.ok || n_small.ent_cpt.size() != e->small.ent_cpt.size() || n_small.npi_init.size() != e->small.npi_init.size())
+                return refuse("the one-workgroup plan changed");
         }
-        std::vector<size_t> m_sizes;
-        for (const SmallPlan& sp : e->mid.parts) m_sizes.push_back(sp.ent_cpt.size());
         if (e->mid.ok) {
-            build_mid_plan(p, e->mid);
-            bool same = e->mid.ok && e->mid.parts.size() == m_sizes.size();
-            for (size_t q = 0; same && q < m_sizes.size(); ++q) same = e->mid.parts[q].ent_cpt.size() == m_sizes[q];
-            if (!same) return fail(BN_ERR_STATE, "bn_reload_cpt: the plan of the several-workgroup path changed");
+            build_mid_plan(p, n_mid);
+            bool same = n_mid.ok && n_mid.parts.size() == e->mid.parts.size();
+            for (size_t q = 0; same && q < n_mid.parts.size(); ++q) same = n_mid.parts[q].ent_cpt.size() == e->mid.parts[q].ent_cpt.size();
+            same = same && (n_mid.parts.empty() || n_mid.parts[0].npi_init.size() == e->mid.parts[0].npi_init.size());
+            if (!same) return refuse("the plan of the several-workgroup path changed");
         }
-        const size_t g_img = e->dag.cpt_img.size();
         if (e->dag.ok) {
-            const int32_t blocks = e->dag.blocks;
-            build_dag_plan(p, e->host_only ? 224 : std::max(blocks, 8), e->dag);   // (the same cap gives the same plan; only the values differ)
-            if (!e->dag.ok || e->dag.cpt_img.size() != g_img || e->dag.blocks != blocks)
-                return fail(BN_ERR_STATE, "bn_reload_cpt: the plan of the register-resident DAG path changed");
+            build_dag_plan(p, e->host_only ? 224 : std::max(e->dag.blocks, 8), n_dag);   // (the same cap gives the same plan; only the values differ)
+            if (!n_dag.ok || n_dag.cpt_img.size() != e->dag.cpt_img.size() || n_dag.blocks != e->dag.blocks || n_dag.npi_init.size() != e->dag.npi_init.size())
+                return refuse("the plan of the register-resident DAG path changed");
         }
+        if (!e->host_only) {
+            ON_DEVICE(e);
+            if (hipStreamSynchronize(e->stream) != hipSuccess) return refuse("the engine's stream reports an error");   // nothing of the old tables is in use any more
+            stripe_cpt(p, cpt);
+            if (p.cpt_striped.size() != size_t(p.cpt_doubles)) { std::vector<double>().swap(p.cpt_striped); return refuse("the tile image changed size"); }
+        }
+        // ---- commit
+        if (e->small.ok) e->small = std::move(n_small);
+        if (e->mid.ok) e->mid = std::move(n_mid);
+        if (e->dag.ok) e->dag = std::move(n_dag);
+        if (e->dense) { free_engine(e->dense); e->dense = nullptr; e->batch_on_dense = false; }   // (rebuilt from the new tables on demand)
         if (e->host_only) return BN_OK;
+        e->poisoned = true;   // until every image has arrived
         ON_DEVICE(e);
         hipStream_t s = e->stream;
-        HIPCHK(hipStreamSynchronize(s));   // nothing of the old tables is in use any more
-        stripe_cpt(p, cpt);
         int rc;
         if ((rc = reupload(e->d_cpt, p.cpt_striped, size_t(p.cpt_doubles), s, "tile image"))) return rc;
         if (e->small_ok) {
-            if ((rc = reupload(e->d_s_cpt, e->small.ent_cpt, s_cpt, s, "entry table"))) return rc;
-            if ((rc = reupload(e->d_s_init, e->small.npi_init, s_init, s, "initial pi"))) return rc;
+            if ((rc = reupload(e->d_s_cpt, e->small.ent_cpt, e->small.ent_cpt.size(), s, "entry table"))) return rc;
+            if ((rc = reupload(e->d_s_init, e->small.npi_init, e->small.npi_init.size(), s, "initial pi"))) return rc;
         }
         if (e->mid_ok) {
             std::vector<double> all;
@@ -2835,13 +2872,15 @@ extern "C" int bn_reload_cpt(bn_engine* e, const double* cpt, int64_t n_entries)
             if ((rc = reupload(e->d_m_init, e->mid.parts[0].npi_init, e->mid.parts[0].npi_init.size(), s, "initial pi"))) return rc;
         }
         if (e->dag_ok) {
-            if ((rc = reupload(e->d_g_cpt, e->dag.cpt_img, g_img, s, "register image"))) return rc;
+            if ((rc = reupload(e->d_g_cpt, e->dag.cpt_img, e->dag.cpt_img.size(), s, "register image"))) return rc;
             if ((rc = reupload(e->d_g_init, e->dag.npi_init, e->dag.npi_init.size(), s, "initial pi"))) return rc;
         }
         HIPCHK(hipStreamSynchronize(s));
         std::vector<double>().swap(p.cpt_striped);
         lw_free(e->lw);   // the sampler uploads its copy of the tables at its next call
+        e->poisoned = false;
     } catch (const std::bad_alloc&) {
+        if (swapped_flat && !e->poisoned) p.cpt_flat.swap(old_flat);   // phase 1: nothing was committed
         return fail(BN_ERR_ALLOC, "out of host memory in bn_reload_cpt");
     }
     return BN_OK;
@@ -2908,6 +2947,7 @@ extern "C" int bn_lw_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
                          uint64_t sample_begin, uint64_t n_samples, uint64_t seed, double* hist_out) {
     if (!e || !hist_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad evidence arguments");
     ON_DEVICE(e);
     std::string err;
@@ -2922,6 +2962,7 @@ extern "C" int bn_lw_run_allreduce(bn_engine* e, int32_t ne, const int32_t* ev_n
                                    uint64_t sample_begin, uint64_t n_samples_total, uint64_t seed, double* hist_out) {
     if (!e || !hist_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad evidence arguments");
     if (!e->comm) return fail(BN_ERR_COMM, "call bn_comm_init first");
     ON_DEVICE(e);
@@ -2944,6 +2985,7 @@ extern "C" int bn_rs_run(bn_engine* e, int32_t ne, const int32_t* ev_node, const
                          uint64_t* drawn_out, uint64_t* accepted_out) {
     if (!e || !counts_out) return fail(BN_ERR_ARG, "null argument");
     if (e->host_only) return fail(BN_ERR_STATE, "engine was created with BN_DEVICE_HOST_ONLY: no GPU, no compute");
+    if (e->poisoned) return fail(BN_ERR_STATE, "engine unusable: bn_reload_cpt failed while uploading (destroy it and create a new one)");
     if (ne < 0 || (ne > 0 && (!ev_node || !ev_state))) return fail(BN_ERR_ARG, "bad condition arguments");
     if (max_draw == 0) return fail(BN_ERR_ARG, "max_draw must be > 0 (the reference loops forever on impossible evidence)");
     ON_DEVICE(e);

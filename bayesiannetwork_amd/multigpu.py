@@ -74,23 +74,41 @@ def verify_in_kernel_exchange(eng: Engine, model, ev, eps: float, device: int, r
     owned = np.repeat(eng.node_slots() >= 0, model.k)
     with Engine(model, device=device) as one:
         wants = [(one.bp_run(e_, eps), one.bp_residuals()) for e_ in sets]
-    try:
-        for e_, (want, want_hist) in zip(sets, wants):
+    # Every rank executes the SAME sequence of collectives whatever happens to its own runs: one barrier before and one
+    # all-reduce(MIN) of the verdict after every run, and all ranks leave the loop together on the first failure anywhere.  (A rank
+    # that jumped out on an exception while its peers went on to their next barrier would pair a barrier with an all-reduce.)
+    flag = torch.zeros(1, dtype=torch.int32)
+    for e_, (want, want_hist) in zip(sets, wants):
+        try:
             eng.bp_set_evidence(e_)
-            for _ in range(repeats):
-                dist.barrier()  # the ranks' kernels wait for each other (bounded: 2 s): enter the run together
-                got = eng.bp_run_device(eps)
-                bel = eng.bp_beliefs()
-                if (eng.last_path() != 2 or got["sweeps"] != want["sweeps"] or not np.array_equal(eng.bp_residuals(), want_hist)
-                        or not np.array_equal(bel[owned], want["beliefs"][owned], equal_nan=True)):
+        except Exception as ex:  # noqa: BLE001
+            print(f"[multigpu] rank {eng.rank}: staging evidence for the verification failed: {ex}", flush=True)
+            ok = 0
+        for _ in range(repeats):
+            dist.barrier()  # the ranks' kernels wait for each other (bounded: 2 s): enter the run together
+            if ok:
+                try:
+                    got = eng.bp_run_device(eps)
+                    bel = eng.bp_beliefs()
+                    if (eng.last_path() != 2 or got["sweeps"] != want["sweeps"] or not np.array_equal(eng.bp_residuals(), want_hist)
+                            or not np.array_equal(bel[owned], want["beliefs"][owned], equal_nan=True)):
+                        ok = 0
+                except Exception as ex:  # noqa: BLE001 - e.g. a bounded wait gave up
+                    print(f"[multigpu] rank {eng.rank}: in-kernel exchange failed verification: {ex}", flush=True)
                     ok = 0
-    except Exception as ex:  # noqa: BLE001 - e.g. a bounded wait gave up
-        print(f"[multigpu] rank {eng.rank}: in-kernel exchange failed verification: {ex}", flush=True)
-        ok = 0
-    t = torch.tensor([ok], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    if int(t[0]) == 0:
+            flag[0] = ok
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag[0])
+            if not ok:
+                break
+        if not ok:
+            break
+    if not ok:
         eng.set_option("multisweep", 0)
+        try:
+            eng.bp_set_evidence(ev)   # the caller's set stays staged, as after a clean verification
+        except Exception:  # noqa: BLE001
+            pass
         return False
     return True
 

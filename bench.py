@@ -414,7 +414,7 @@ def leg_dropin_cpp(a, local_rank, torch):
             continue
         g = make()
         with Engine(g, device=local_rank) as eng:
-            r = eng.bp_run_view(synth.random_evidence(g, frac, seed=7), eps)
+            r = eng.bp_run(synth.random_evidence(g, frac, seed=7), eps)   # (a copy: bp_run_view's array dies with the engine)
         out[key]["matches_c_abi"] = bool(r["sweeps"] == out[key]["sweeps_query0"]
                                          and f"{wsum64(r['beliefs']):016x}" == out[key]["wsum64_query0"])
     out["what"] = ("tests/cpp/bench_dropin.cpp: medians per query, ms; operator_ms = bn::inference::belief_propagation::operator() called, "
@@ -754,6 +754,8 @@ def leg_grid2048(a, local_rank, torch):
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()   # a native crash prints the Python stack on stderr instead of dying silently
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

@@ -84,17 +84,27 @@ public:
     }
     view_type run(std::unordered_map<vertex_type, matrix_type> const& precondition, double const epsilon = 0.001)
     {
-        // scratch kept between calls: a query allocates nothing once the vectors have grown
+        // scratch kept between calls: a query allocates nothing once the vectors have grown.  Two passes, so that the
+        // misses overlap instead of queueing up: walk the caller's map and request every vertex's table line, then look
+        // the positions up and copy the vectors (998 evidence nodes on the 99 856-node grid: 0.12 ms -> see INTEGRATION.md)
         ev_node_.clear();
         ev_val_.clear();
         ev_off_.assign(1, 0);
+        ev_key_.clear();
+        ev_row_.clear();
         for(auto const& p : precondition)
         {
-            auto const it = model_.index.find(p.first);
-            if(it == model_.index.end()) throw std::runtime_error("belief_propagation: evidence on an unknown vertex");
             if(p.second.height() != 1) throw std::runtime_error("belief_propagation: evidence must be a 1 x k matrix");
-            ev_node_.push_back(it->second);
-            ev_val_.insert(ev_val_.end(), p.second[0].begin(), p.second[0].end());
+            model_.lookup.prefetch(p.first.get());
+            ev_key_.push_back(p.first.get());
+            ev_row_.push_back(&p.second[0]);
+        }
+        for(std::size_t j = 0; j < ev_key_.size(); ++j)
+        {
+            std::int32_t const position = model_.lookup.find(ev_key_[j]);
+            if(position < 0) throw std::runtime_error("belief_propagation: evidence on an unknown vertex");
+            ev_node_.push_back(position);
+            ev_val_.insert(ev_val_.end(), ev_row_[j]->begin(), ev_row_[j]->end());
             ev_off_.push_back(static_cast<std::int32_t>(ev_val_.size()));
         }
         // the marginals arrive in a page-locked buffer the engine owns (one DMA behind the run, one
@@ -174,6 +184,8 @@ private:
     mi355x::engine_handle engine_;
     std::vector<std::int32_t> ev_node_, ev_off_;   // evidence marshalling scratch of run()
     std::vector<double> ev_val_;
+    std::vector<void const*> ev_key_;
+    std::vector<std::vector<double> const*> ev_row_;
     int last_sweeps_ = 0;
     double last_residual_ = 0;
 };

@@ -72,7 +72,7 @@ public:
     double const* operator[](vertex_type const& v) const { return data_ + model_->node_off[position(v)]; }
     double const* at(vertex_type const& v) const { return operator[](v); }
     std::size_t k(vertex_type const& v) const { return static_cast<std::size_t>(model_->k[position(v)]); }
-    bool count(vertex_type const& v) const { return model_ && model_->index.count(v) != 0; }
+    bool count(vertex_type const& v) const { return model_ && model_->lookup.find(v.get()) >= 0; }
     // a copy in the reference's cell type: what return_type::at(v) holds
     matrix_type matrix(vertex_type const& v) const
     {
@@ -118,9 +118,9 @@ private:
     std::size_t position(vertex_type const& v) const
     {
         if(!model_) throw std::out_of_range("bn::mi355x::marginals_view: empty view");
-        auto const it = model_->index.find(v);
-        if(it == model_->index.end()) throw std::out_of_range("bn::mi355x::marginals_view: vertex is not in the graph");
-        return static_cast<std::size_t>(it->second);
+        std::int32_t const i = model_->lookup.find(v.get());
+        if(i < 0) throw std::out_of_range("bn::mi355x::marginals_view: vertex is not in the graph");
+        return static_cast<std::size_t>(i);
     }
 
     flat_model const* model_ = nullptr;

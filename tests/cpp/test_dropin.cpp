@@ -202,9 +202,9 @@ int main(int argc, char** argv)
         for(int i = 0; i < 4; ++i)
             for(int j = 0; j < 2; ++j) close_pct(r2.at(v[i])[0][j], t2[i][j], 0.1, "pearl part2");
         print_marginals("pearl_part2", pearl, r2);
+        std::printf("\"pearl_part2_sweeps\":%d,", bp.last_sweeps());
         view_equals_map(bp.run(pre), r2, pearl, "belief_propagation pearl part2");
         view_equals_map(bp.run(), r1, pearl, "belief_propagation pearl part1");
-        std::printf("\"pearl_part2_sweeps\":%d,", bp.last_sweeps());
     }
     {   // belief_propagation_resume_ex, _sample1 .. _sample4  (3 % tolerance, one queried node each)
         auto const v = chain.vertex_list();

@@ -286,3 +286,30 @@ def test_dag_arities_below_four(Engine, oracle_mod, name):
         r = eng.bp_run(evs[1], 0.0, 1030)
         assert r["sweeps"] == 1030 and eng.bp_stats()["sweep_launches"] == 2
         assert (np.array_equal(r["beliefs"], o["beliefs"]) if exact else np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12)
+
+
+def test_dag_hubs_near_and_beyond_the_child_bound(Engine, oracle_mod):
+    """A node's parent items carry `child count | target's rank << 16` in one signed word (bn_dag.hpp), and a node with more than
+    63 children costs deg^2 record loads per sweep: the plan takes hubs up to kDagMaxChildren = 1 024 children -- every rank intact,
+    the oracle's bits (<= 2 parents per node) -- and refuses larger ones, which run on the other paths with the same result."""
+    from bayesiannetwork_amd import Evidence, synth
+    for nch in (200, 1000):
+        g = hub_network(nch)
+        with Engine(g) as eng:
+            assert eng.info("dag_eligible") == 1
+            eng.set_option("dag", 2)
+            for ev, eps in ((Evidence.none(), 1e-6), (synth.random_evidence(g, 0.05, seed=3), 1e-9)):
+                o = oracle_mod.bp_run(g, ev, eps, dump_msgs=True)
+                r = eng.bp_run(ev, eps)
+                assert eng.last_path() == 5 and r["sweeps"] == o["sweeps"]
+                assert np.array_equal(r["beliefs"], o["beliefs"]) and np.array_equal(eng.bp_residuals(), o["residuals"])
+                pi, lam = eng.bp_messages()
+                assert np.array_equal(pi, o["pi_msg"]) and np.array_equal(lam, o["lambda_msg"])
+    g = hub_network(1025)
+    with Engine(g) as eng:
+        assert eng.info("dag_eligible") == 0
+        eng.set_option("dag", 2)   # asking for it changes nothing: the network is not eligible
+        ev = synth.random_evidence(g, 0.05, seed=3)
+        o = oracle_mod.bp_run(g, ev, 1e-9)
+        r = eng.bp_run(ev, 1e-9)
+        assert eng.last_path() != 5 and r["sweeps"] == o["sweeps"] and np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12

@@ -470,6 +470,24 @@ def test_dag_plan_invariants(bnlib):
     for padded in (synth.random_dag(200, 4, 32, [4, 4, 3], seed=1), synth.pearl()):   # arities below 4 are padded to 4
         with engine.Engine(padded, device=_lib.BN_DEVICE_HOST_ONLY) as e:
             assert e.info("dag_eligible") == 1 and e.dag_plan() is not None
+    # out-degree bound (DagParentLane packs child count | target's rank << 16 into a signed word; a node with more than 63
+    # children costs deg^2 record loads per sweep): 1 024 children are planned with every rank intact, 1 025 are refused
+    from helpers import hub_network
+    with engine.Engine(hub_network(1024), device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("dag_eligible") == 1
+        ph = e.dag_plan()
+    ih = ph["pitem"][ph["pitem"][:, 0] == 0]
+    assert ih.shape[0] == 1025 and ((ih[:, 3] & 0xffff) == 1024).all()
+    mh = ih[ih[:, 1] >= 0]
+    assert np.array_equal(np.sort(mh[:, 3] >> 16), np.arange(1024)) and (ph["oedge"][mh[:, 2] + (mh[:, 3] >> 16)] == mh[:, 1]).all()
+    with engine.Engine(hub_network(1025), device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("dag_eligible") == 0 and e.dag_plan() is None
+    # image bound: the padded register image (4^(m+1) entries per node whatever the arities) stops at 256 MB -- a binary network
+    # with 5-parent nodes is 64x its model there, and the stream form would re-read it every sweep
+    wide = synth.random_dag(40000, 5, 32, 2, seed=3)
+    assert sum(4 ** (m + 1) for m in np.diff(wide.in_ptr)) * 8 > 256 << 20
+    with engine.Engine(wide, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+        assert e.info("dag_eligible") == 0
     obj = os.path.join(ROOT, "bayesiannetwork_amd", "csrc", "bn_dag.o")
     if os.path.exists(obj) and os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
