@@ -13,13 +13,15 @@
 // (rejection / logic sampling, reference rejection_sampling.hpp:33-167, is the same walk with the
 // evidence nodes sampled like any other and w = 1 if every one of them came out as observed, else 0).
 // Uniforms: every sample owns a xoshiro128++ stream seeded by one Philox4x32-10 block keyed by
-// (seed, global sample id) and advanced by ONE step at every topological position: the ++ output
-// is the top 32 bits of the 53-bit uniform, the ** scrambler of the state the step left behind its
-// low 21 -- see oracle/lw_oracle.c for the exact mapping, which this kernel reproduces bit for bit,
-// so sampled states are identical.  (Philox for every draw, 20 quarter-rate 32x32->64 multiplies per
-// pair of positions, made the kernel VALU-bound at 62 % Philox; two xoshiro steps per uniform were 20
-// full-rate ops of which ten produced bits that decide 3 draws in 2^32; one step is ten, and the low
-// bits cost three more only where they are looked at.)
+// (seed, global sample id) and advanced by ONE step per TWO topological positions: the top half of
+// the ++ output is the top 16 bits of the even position's 53-bit uniform, the bottom half those of
+// the odd position after it; the 37 bits below come from the ** scrambler of words of the state the
+// step left behind and are looked at only when the top 16 tie with a threshold -- see
+// oracle/lw_oracle.c for the exact mapping, which this kernel reproduces bit for bit, so sampled
+// states are identical.  (Philox for every draw, 20 quarter-rate 32x32->64 multiplies per pair of
+// positions, made the kernel VALU-bound at 62 % Philox; two xoshiro steps per uniform were 20
+// full-rate ops; one step per position, round 4, was ten -- a fifth of the vector instructions of a
+// kernel bound by vector issue, for 32 deciding bits where 16 decide all but 3 draws in 2^16.)
 //
 // Histogram (lw_hist_kernel, :45-49, run once the weights are FINAL): lane = node, each lane
 // streams its own row of the state matrix 16 samples at a time and adds the (wave-uniform) weights
@@ -28,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "bn_lw.hpp"
 
@@ -62,24 +65,20 @@ __device__ __forceinline__ uint32_t xoshiro_next(uint4& g) {
     return result;
 }
 
-// the ** scrambler on the state as it stands: the low bits of a position's uniform (taken AFTER the position's step)
-__device__ __forceinline__ uint32_t xoshiro_low(const uint4& g) {
-    const uint32_t x = g.y * 5u;
+// the ** scrambler of one state word
+__device__ __forceinline__ uint32_t xoshiro_ss(uint32_t w) {
+    const uint32_t x = w * 5u;
     return ((x << 7) | (x >> 25)) * 9u;
 }
-// the 53-bit integer of a position's uniform: u = U * 2^-53
-__device__ __forceinline__ unsigned long long unit53(uint32_t hi, const uint4& g_after) {
-    return (uint64_t(hi) << 21) | (xoshiro_low(g_after) >> 11);
-}
-
-// one step per sample and position
-template <int S>
-__device__ __forceinline__ void draw_uniforms(uint4 (&rng)[S], double (&u)[S]) {
-#pragma unroll
-    for (int r = 0; r < S; ++r) {
-        const uint32_t hi = xoshiro_next(rng[r]);
-        u[r] = double(unit53(hi, rng[r])) * (1.0 / 9007199254740992.0);
-    }
+// Position parity PAR (0: the position whose step this was, 1: the one after it).  h16 = the position's half of the step's output;
+// the 53-bit integer of its uniform, u = U * 2^-53, takes 37 more bits from the state as the step left it (oracle/lw_oracle.c)
+template <int PAR>
+__device__ __forceinline__ uint32_t half_of(uint32_t out) { return PAR == 0 ? out >> 16 : out & 0xffffu; }
+template <int PAR>
+__device__ __forceinline__ unsigned long long unit53(uint32_t h16, const uint4& g_after) {
+    const unsigned long long low = PAR == 0 ? (uint64_t(xoshiro_ss(g_after.y)) << 5) | (xoshiro_ss(g_after.z) >> 27)
+                                            : (uint64_t(xoshiro_ss(g_after.w)) << 5) | (xoshiro_ss(g_after.x) >> 27);
+    return (uint64_t(h16) << 37) | low;
 }
 
 // States of the S samples of one thread at one node: first i with cum_{i-1} <= u < cum_i, else
@@ -111,32 +110,34 @@ __device__ __forceinline__ void load_top(__amdgpu_buffer_rsrc_t rs, uint32_t row
         t[0] = q.x;
     }
 }
-template <int KV, int S>
+// `out`: the ++ outputs of the step the position belongs to (taken by the caller at the even position); PAR: the position's parity.
+// A draw is settled by its 16 bits against the top 16 of the thresholds (the top halves T_i >> 21 of d_thr32, shifted) unless
+// they tie (3 x 2^-16 per draw): then the wave repeats the position's draws against the full thresholds.
+template <int KV, int S, int PAR>
 __device__ __forceinline__ void pick_states(const double* __restrict__ base, const unsigned long long* __restrict__ tbase,
-                                            const uint32_t* __restrict__ tbase32, const uint32_t (&row)[S], uint4 (&rng)[S], int kv,
-                                            int (&st)[S]) {
+                                            const uint32_t* __restrict__ tbase32, const uint32_t (&row)[S], const uint32_t (&out)[S],
+                                            const uint4 (&rng)[S], int kv, int (&st)[S]) {
     if (KV > 0) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tbase32), 0, 0x7fffffff, 0x00020000);
         uint32_t t[S][3];
 #pragma unroll
         for (int r = 0; r < S; ++r) load_top<KV>(rs, row[r], t[r]);
-        uint32_t hi[S];
         bool tie = false;
 #pragma unroll
         for (int r = 0; r < S; ++r) {
-            hi[r] = xoshiro_next(rng[r]);
+            const uint32_t h = half_of<PAR>(out[r]);
             int c = 0;
 #pragma unroll
             for (int i = 0; i < KV - 1; ++i) {
-                c += (hi[r] > t[r][i]) ? 1 : 0;
-                tie = tie || hi[r] == t[r][i];
+                c += (h > (t[r][i] >> 16)) ? 1 : 0;
+                tie = tie || h == (t[r][i] >> 16);
             }
             st[r] = c;
         }
-        if (__any(tie)) {   // (wave-uniform branch, ~never taken: the four draws again, against the full thresholds)
+        if (__any(tie)) {   // (wave-uniform branch: the four draws again, against the full thresholds)
 #pragma unroll
             for (int r = 0; r < S; ++r) {
-                const unsigned long long U = unit53(hi[r], rng[r]);
+                const unsigned long long U = unit53<PAR>(half_of<PAR>(out[r]), rng[r]);
                 const unsigned long long* rowp = tbase + uint64_t(row[r]) * KV;
                 int c = 0;
 #pragma unroll
@@ -150,8 +151,10 @@ __device__ __forceinline__ void pick_states(const double* __restrict__ base, con
         double total[S];
         const double* rowp[S];
 #pragma unroll
-        for (int r = 0; r < S; ++r) { found[r] = false; total[r] = 0.0; st[r] = kv - 1; rowp[r] = base + uint64_t(row[r]) * kv; }
-        draw_uniforms<S>(rng, u);
+        for (int r = 0; r < S; ++r) {
+            found[r] = false; total[r] = 0.0; st[r] = kv - 1; rowp[r] = base + uint64_t(row[r]) * kv;
+            u[r] = double(unit53<PAR>(half_of<PAR>(out[r]), rng[r])) * (1.0 / 9007199254740992.0);
+        }
         for (int i = 0; i < kv; ++i) {
             double x[S];
 #pragma unroll
@@ -174,18 +177,16 @@ __device__ __forceinline__ void pick_states(const double* __restrict__ base, con
 // traffic the copy holds the top 16 bits of each threshold (T >> 37): one 8-byte row {t0 | t1 << 16, t2 | pad}.  A draw whose
 // top 16 bits equal one of its row's entries is undecided (3 x 2^-16 per draw, ~1 % of a wave's positions): the wave then
 // repeats the position's draws against the full 64-bit thresholds in memory.  States are the same bit for bit either way.
-template <int KV, int S>
+template <int KV, int S, int PAR>
 __device__ __forceinline__ void pick_states16(const uint2* tab, const unsigned long long* __restrict__ tbase, const uint32_t (&row)[S],
-                                              uint4 (&rng)[S], int (&st)[S]) {
+                                              const uint32_t (&out)[S], const uint4 (&rng)[S], int (&st)[S]) {
     uint2 t[S];
 #pragma unroll
     for (int r = 0; r < S; ++r) t[r] = tab[row[r]];
-    uint32_t hi[S];
     bool tie = false;
 #pragma unroll
     for (int r = 0; r < S; ++r) {
-        hi[r] = xoshiro_next(rng[r]);
-        const uint32_t h = hi[r] >> 16;
+        const uint32_t h = half_of<PAR>(out[r]);
         const uint32_t e[3] = {t[r].x & 0xffffu, t[r].x >> 16, t[r].y & 0xffffu};
         int c = 0;
 #pragma unroll
@@ -198,7 +199,7 @@ __device__ __forceinline__ void pick_states16(const uint2* tab, const unsigned l
     if (__any(tie)) {
 #pragma unroll
         for (int r = 0; r < S; ++r) {
-            const unsigned long long U = unit53(hi[r], rng[r]);
+            const unsigned long long U = unit53<PAR>(half_of<PAR>(out[r]), rng[r]);
             const unsigned long long* rowp = tbase + uint64_t(row[r]) * KV;
             int c = 0;
 #pragma unroll
@@ -219,7 +220,7 @@ struct LwStepWords {  // LwStep as two 16-byte words
 #define BN_LW_WAVES 5
 #endif
 template <bool ROWS24, bool INLINE, bool REJECT>
-__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_WAVES, BN_LW_WAVES))) void lw_sample_kernel(
+__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_WAVES - 1, BN_LW_WAVES))) void lw_sample_kernel(
     const LwStepWords* __restrict__ steps, const uint4* __restrict__ parents, const int32_t* __restrict__ ev_topo,
     const double* __restrict__ cpt, const unsigned long long* __restrict__ thr, const uint32_t* __restrict__ thr32,
     const uint4* __restrict__ thr16, uint8_t* states,
@@ -281,7 +282,11 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
     // spare entries at the end).
     LwStepWords nxt = steps[0];
     int ev_nxt = ev_topo[0];
-    for (int t = 0; t < n; ++t) {
+    uint32_t out[S];   // the ++ outputs of the last even position's step: their top halves decide it, the bottom halves the odd position after it
+#pragma unroll
+    for (int r = 0; r < S; ++r) out[r] = 0;
+    auto position = [&](int t, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
         asm volatile("" : "+v"(c32));
         const uint4 sd = nxt.a;  // LwStep: coff_lo, v, par_off, coff_hi | kv << 16 | (m | flags) << 24
         const uint4 pin = nxt.b;  // parents 0..3 inline: node | arity << 24
@@ -300,6 +305,10 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         }
         uint32_t wd[4] = {0, 0, 0, 0};
         if (INLINE) request(sd, pin, wd);
+        if (PAR == 0) {   // the step of this position and the next, evidence node or not: u(s, t) does not depend on the evidence
+#pragma unroll
+            for (int r = 0; r < S; ++r) out[r] = xoshiro_next(rng[r]);
+        }
         uint32_t row[S];
 #pragma unroll
         for (int r = 0; r < S; ++r) row[r] = 0;
@@ -354,8 +363,6 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             double x[S];
 #pragma unroll
             for (int r = 0; r < S; ++r) x[r] = base[uint64_t(row[r]) * kv + ev];
-            double unused[S];  // the stream advances at every position: u(s, t) does not depend on the evidence
-            draw_uniforms<S>(rng, unused);
 #pragma unroll
             for (int r = 0; r < S; ++r) w[r] *= x[r];
             packed = uint32_t(ev) * 0x01010101u;
@@ -368,15 +375,15 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
                 __builtin_amdgcn_wave_barrier();
                 const uint2* tab = reinterpret_cast<const uint2*>(my_tab);
                 switch (kv) {
-                    case 2: pick_states16<2, S>(tab, tbase, row, rng, st); break;
-                    case 3: pick_states16<3, S>(tab, tbase, row, rng, st); break;
-                    default: pick_states16<4, S>(tab, tbase, row, rng, st); break;
+                    case 2: pick_states16<2, S, PAR>(tab, tbase, row, out, rng, st); break;
+                    case 3: pick_states16<3, S, PAR>(tab, tbase, row, out, rng, st); break;
+                    default: pick_states16<4, S, PAR>(tab, tbase, row, out, rng, st); break;
                 }
             } else switch (kv) {
-                case 2: pick_states<2, S>(base, tbase, tbase32, row, rng, 2, st); break;
-                case 3: pick_states<3, S>(base, tbase, tbase32, row, rng, 3, st); break;
-                case 4: pick_states<4, S>(base, tbase, tbase32, row, rng, 4, st); break;
-                default: pick_states<0, S>(base, tbase, tbase32, row, rng, kv, st); break;
+                case 2: pick_states<2, S, PAR>(base, tbase, tbase32, row, out, rng, 2, st); break;
+                case 3: pick_states<3, S, PAR>(base, tbase, tbase32, row, out, rng, 3, st); break;
+                case 4: pick_states<4, S, PAR>(base, tbase, tbase32, row, out, rng, 4, st); break;
+                default: pick_states<0, S, PAR>(base, tbase, tbase32, row, out, rng, kv, st); break;
             }
 #pragma unroll
             for (int r = 0; r < S; ++r) {
@@ -385,7 +392,13 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             }
         }
         *reinterpret_cast<lw_global_u32>(row_of(sd.y) + off32()) = packed;
+    };
+    int t = 0;
+    for (; t + 1 < n; t += 2) {
+        position(t, std::integral_constant<int, 0>());
+        position(t + 1, std::integral_constant<int, 1>());
     }
+    if (t < n) position(t, std::integral_constant<int, 0>());
 #pragma unroll
     for (int r = 0; r < S; ++r) weights[col + r] = w[r];
 }
@@ -398,7 +411,8 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
 //   * the row numbers of the thread's four samples are the four BYTES of one register (three shift-adds, or multiply-adds, for
 //     all four samples; every partial row number is below 256, so a byte never carries into its neighbour);
 //   * the node's 16-bit thresholds (8 bytes per row, 2 KB copied whatever the table's size) go through the wave's LDS slice;
-//     always three compares per draw -- a node with fewer states has 0xffff in the unused places, which no draw exceeds.
+//     always three compares per draw -- a node with fewer states has 0xffff in the unused places, which no draw exceeds;
+//   * the stream steps at the even positions only: the loop body is instantiated for both parities and runs them in turn.
 // POW2: every arity of the network is a power of two (LwSmallStep::shape holds log2 of the arities instead of the arities).
 // The descriptor (LwSmallStep, 64 bytes, one scalar load a position ahead) holds the rows' BYTE OFFSETS in the state matrix ready:
 // a row's base is one 64-bit scalar add (node x stride as scalar multiplies was 8 scalar instructions per row, 40 per position).
@@ -446,7 +460,11 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
     // and the bookkeeping of a second descriptor in flight costs issue slots.)
     LwSmallWords nxt = steps[0];
     int ev_nxt = ev_topo[0];
-    for (int t = 0; t < n; ++t) {
+    uint32_t out[S];   // the ++ outputs of the last even position's step: their top halves decide it, the bottom halves the odd position after it
+#pragma unroll
+    for (int r = 0; r < S; ++r) out[r] = 0;
+    auto position = [&](int t, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
         asm volatile("" : "+v"(c32));
         const LwSmallWords sd = nxt;   // a, b: the four parents' rows; c: own row, CPT offset; d: thr16 row, kv | shifts (or arities) of parents 1..3
         const int ev = ev_nxt;
@@ -473,9 +491,10 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         for (int r = 0; r < S; ++r) row[r] = (rp >> (8 * r)) & 0xffu;
         const int kv = int(sd.d.y & 0xffu);
         const uint64_t coff = (uint64_t(sd.c.w) << 32) | sd.c.z;
-        uint32_t hi[S];   // the position's step of every stream, evidence node or not
+        if (PAR == 0) {   // the step of this position and the next, evidence node or not
 #pragma unroll
-        for (int r = 0; r < S; ++r) hi[r] = xoshiro_next(rng[r]);
+            for (int r = 0; r < S; ++r) out[r] = xoshiro_next(rng[r]);
+        }
         uint32_t packed = 0;
         if (!REJECT && ev >= 0) {   // evidence node: w *= cpt[row][ev] (:148-153)
             double x[S];
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             bool tie = false;
 #pragma unroll
             for (int r = 0; r < S; ++r) {
-                const uint32_t h = hi[r] >> 16;
+                const uint32_t h = half_of<PAR>(out[r]);
                 const uint32_t e0 = e[r].x & 0xffffu, e1 = e[r].x >> 16, e2 = e[r].y & 0xffffu;
                 st[r] = (h > e0 ? 1 : 0) + (h > e1 ? 1 : 0) + (h > e2 ? 1 : 0);
                 tie = tie || h == e0 || h == e1 || h == e2;
@@ -501,7 +520,7 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             if (__any(tie)) {   // ~1 % of a wave's positions: the four draws again, against the full thresholds
 #pragma unroll
                 for (int r = 0; r < S; ++r) {
-                    const unsigned long long U = unit53(hi[r], rng[r]);
+                    const unsigned long long U = unit53<PAR>(half_of<PAR>(out[r]), rng[r]);
                     const unsigned long long* rowp = thr + coff + uint64_t(row[r]) * kv;
                     int c = 0;
                     for (int i = 0; i + 1 < kv; ++i) c += (U >= rowp[i]) ? 1 : 0;
@@ -516,7 +535,13 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         }
         asm volatile("" : "+v"(c32));
         *reinterpret_cast<lw_global_u32>(row_at(sd.c.x, sd.c.y) + c32) = packed;
+    };
+    int t = 0;
+    for (; t + 1 < n; t += 2) {
+        position(t, std::integral_constant<int, 0>());
+        position(t + 1, std::integral_constant<int, 1>());
     }
+    if (t < n) position(t, std::integral_constant<int, 0>());
 #pragma unroll
     for (int r = 0; r < S; ++r) weights[col32 + r] = w[r];
 }

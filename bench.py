@@ -418,7 +418,8 @@ def leg_dropin_cpp(a, local_rank, torch):
         out[key]["matches_c_abi"] = bool(r["sweeps"] == out[key]["sweeps_query0"]
                                          and f"{wsum64(r['beliefs']):016x}" == out[key]["wsum64_query0"])
     out["what"] = ("tests/cpp/bench_dropin.cpp: medians per query, ms; operator_ms = bn::inference::belief_propagation::operator() called, "
-                   "its map used and dropped; run_view_ms = run() (marshal + bn_bp_run_view, marginals read in place); map_build_copy_assign_ms = "
+                   "its map used and dropped; run_view_ms = run() (marshal + bn_bp_run_view, marginals read in place); run_prepared_ms = run() on evidence prepared "
+                   "once (prepare(): no walk over the caller's map); map_build_copy_assign_ms = "
                    "how the map was built before this round (default-constructed entry + copy assignment per node)")
     return out
 
@@ -890,6 +891,7 @@ def main():
         if "config3_grid" in dc:
             gd = dc["config3_grid"]
             out["config"].update({"ms_per_query_dropin_cpp": gd["operator_ms"], "ms_per_query_dropin_cpp_run_view": gd["run_view_ms"],
+                                  "ms_per_query_dropin_cpp_run_prepared": gd.get("run_prepared_ms"),
                                   "ms_dropin_cpp_map_build": gd["map_build_ms"], "ms_dropin_cpp_map_destroy": gd["map_destroy_ms"],
                                   "dropin_cpp_matches_c_abi": gd.get("matches_c_abi")})
         for key, fn in (("batch", leg_batch), ("config1_alarm", leg_alarm), ("mid_mixed300", leg_mid), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):

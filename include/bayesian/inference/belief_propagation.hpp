@@ -84,36 +84,34 @@ public:
     }
     view_type run(std::unordered_map<vertex_type, matrix_type> const& precondition, double const epsilon = 0.001)
     {
-        // scratch kept between calls: a query allocates nothing once the vectors have grown.  Two passes, so that the
-        // misses overlap instead of queueing up: walk the caller's map and request every vertex's table line, then look
-        // the positions up and copy the vectors (998 evidence nodes on the 99 856-node grid: 0.12 ms -> see INTEGRATION.md)
-        ev_node_.clear();
-        ev_val_.clear();
-        ev_off_.assign(1, 0);
-        ev_key_.clear();
-        ev_row_.clear();
-        for(auto const& p : precondition)
-        {
-            if(p.second.height() != 1) throw std::runtime_error("belief_propagation: evidence must be a 1 x k matrix");
-            model_.lookup.prefetch(p.first.get());
-            ev_key_.push_back(p.first.get());
-            ev_row_.push_back(&p.second[0]);
-        }
-        for(std::size_t j = 0; j < ev_key_.size(); ++j)
-        {
-            std::int32_t const position = model_.lookup.find(ev_key_[j]);
-            if(position < 0) throw std::runtime_error("belief_propagation: evidence on an unknown vertex");
-            ev_node_.push_back(position);
-            ev_val_.insert(ev_val_.end(), ev_row_[j]->begin(), ev_row_[j]->end());
-            ev_off_.push_back(static_cast<std::int32_t>(ev_val_.size()));
-        }
+        marshal(precondition, scratch_);
+        return run(scratch_, epsilon);
+    }
+
+    // An evidence set in the form the C ABI takes (bn_bp_run: positions in vertex_list(), offsets, the 1 x k vectors end to
+    // end).  A caller that asks the same query again -- or builds its evidence as arrays in the first place -- prepares it once
+    // and skips the walk over the map: run(prepared, eps) is the bare bn_bp_run_view call.
+    struct evidence_arrays {
+        std::vector<std::int32_t> node, off;
+        std::vector<double> val;
+    };
+    evidence_arrays prepare(std::unordered_map<vertex_type, matrix_type> const& precondition)
+    {
+        evidence_arrays out;
+        marshal(precondition, out);
+        return out;
+    }
+    view_type run(evidence_arrays const& evidence, double const epsilon = 0.001)
+    {
         // the marginals arrive in a page-locked buffer the engine owns (one DMA behind the run, one
         // synchronisation for upload + run + download)
         double const* beliefs = nullptr;
         std::int32_t sweeps = 0;
         double residual = 0;
+        static std::int32_t const zero = 0;
         mi355x::engine_handle::check(bn_bp_run_view(
-            engine_.get(), static_cast<std::int32_t>(ev_node_.size()), ev_node_.data(), ev_off_.data(), ev_val_.data(),
+            engine_.get(), static_cast<std::int32_t>(evidence.node.size()), evidence.node.data(),
+            evidence.off.empty() ? &zero : evidence.off.data(), evidence.val.data(),
             epsilon, 0 /* unbounded, like the reference */, &beliefs, &sweeps, &residual));
         last_sweeps_ = sweeps;
         last_residual_ = residual;
@@ -179,12 +177,49 @@ public:
     double last_residual() const { return last_residual_; }
 
 private:
+    // precondition -> evidence_arrays
+    void marshal(std::unordered_map<vertex_type, matrix_type> const& precondition, evidence_arrays& out)
+    {
+        // Scratch kept between calls: a query allocates nothing once the vectors have grown.  The caller's map is a linked
+        // list of heap nodes, each pointing at a row table that points at a row: walked entry by entry that is four
+        // dependent cache misses per evidence node (0.12 ms for 998 of them on the 99 856-node grid, half of the GPU's share).
+        // So it is walked in STAGES -- the list itself, then all row tables, then all rows -- each a loop of independent
+        // loads the core overlaps, with the position-table line of every vertex requested in the first.
+        out.node.clear();
+        out.val.clear();
+        out.off.assign(1, 0);
+        ev_key_.clear();
+        ev_mat_.clear();
+        ev_row_.clear();
+        for(auto const& p : precondition)
+        {
+            model_.lookup.prefetch(p.first.get());
+            ev_key_.push_back(p.first.get());
+            ev_mat_.push_back(&p.second);
+        }
+        for(matrix_type const* m : ev_mat_)
+        {
+            if(m->height() != 1) throw std::runtime_error("belief_propagation: evidence must be a 1 x k matrix");
+            ev_row_.push_back(&(*m)[0]);
+        }
+        for(std::size_t j = 0; j < ev_key_.size(); ++j)
+        {
+            std::int32_t const position = model_.lookup.find(ev_key_[j]);
+            if(position < 0) throw std::runtime_error("belief_propagation: evidence on an unknown vertex");
+            out.node.push_back(position);
+            out.off.push_back(out.off.back() + static_cast<std::int32_t>(ev_row_[j]->size()));
+        }
+        out.val.resize(static_cast<std::size_t>(out.off.back()));
+        for(std::size_t j = 0; j < ev_row_.size(); ++j)
+            std::copy(ev_row_[j]->begin(), ev_row_[j]->end(), out.val.begin() + out.off[j]);
+    }
+
     graph_t graph_;   // the reference keeps a copy too (graph_t const graph_, :320)
     mi355x::flat_model model_;
     mi355x::engine_handle engine_;
-    std::vector<std::int32_t> ev_node_, ev_off_;   // evidence marshalling scratch of run()
-    std::vector<double> ev_val_;
+    evidence_arrays scratch_;   // evidence marshalling scratch of run(precondition)
     std::vector<void const*> ev_key_;
+    std::vector<matrix_type const*> ev_mat_;
     std::vector<std::vector<double> const*> ev_row_;
     int last_sweeps_ = 0;
     double last_residual_ = 0;

@@ -30,7 +30,7 @@ def build(quiet: bool = True) -> None:
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.environ.get("BN_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")   # BN_ORACLE_LIB: the sanitizer build (scripts/san_cpu.sh)
         if not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)

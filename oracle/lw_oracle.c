@@ -17,11 +17,18 @@
  * seeded by one block of the counter-based Philox4x32-10 generator (Salmon et al., SC'11):
  *   state(sample s) = philox4x32_10(counter = {s_lo, s_hi, 0, 0}, key = {seed_lo, seed_hi})
  *                     (an all-zero state, which xoshiro cannot leave, becomes {1,0,0,0})
- *   at every topological position t = 0, 1, ... (evidence node or not) the stream takes ONE step:
- *   hi = next()  (the ++ output, 32 bits);   lo = the ** scrambler rotl(x[1] * 5, 7) * 9 of the state
- *   the step left behind;   U = hi << 21 | lo >> 11  (53 bits);   u(s, t) = U * 2^-53
- *   (until round 4 two ++ outputs per position; the low 21 bits decide a draw only when the top 32
- *   tie with a threshold, 3 x 2^-32 per draw, so the second step bought nothing but work)
+ *   the stream takes ONE step per TWO topological positions (evidence nodes or not): at every EVEN
+ *   position t = 0, 2, ...  out = next()  (the ++ output, 32 bits), and
+ *       h(t) = out >> 16,   h(t + 1) = out & 0xffff            the top 16 bits of each position's uniform
+ *       low(t)     = ss(x[1]) << 5 | ss(x[2]) >> 27             the 37 bits below them: the ** scrambler
+ *       low(t + 1) = ss(x[3]) << 5 | ss(x[0]) >> 27             ss(w) = rotl(w * 5, 7) * 9 of words of the
+ *                                                              state the step left behind
+ *       U = h << 37 | low  (53 bits);   u(s, t) = U * 2^-53
+ *   A draw is decided by its top 16 bits unless they equal the top 16 bits of a running total (3 x 2^-16
+ *   per draw); only then are the low 37 looked at, and they come from state words the output function
+ *   did not use.  (Round 4: one step per position, top 32 bits from the output.  The ten operations of a
+ *   step were a fifth of the sampling kernel's vector instructions, and the kernel is bound by exactly
+ *   those; 16 bits decide a draw as well as 32 do, so one output serves two positions.)
  * so u(s, t) depends on (seed, s, t) only -- not on the evidence set, the batch or the GPU --
  * which makes sampled STATES bit-reproducible between this file and the HIP kernel.
  * Parity with the reference itself is statistical (tests/golden holds the reference's
@@ -72,22 +79,33 @@ static void stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]) {
     if ((x[0] | x[1] | x[2] | x[3]) == 0) x[0] = 1;
 }
 
-/* the ** scrambler of xoshiro128 on the state as it stands (no step) */
-uint32_t oracle_xoshiro128ss_peek(const uint32_t x[4]) { return rotl32(x[1] * 5u, 7) * 9u; }
+/* the ** scrambler of xoshiro128 on one word of the state as it stands (no step) */
+static uint32_t ss32(uint32_t w) { return rotl32(w * 5u, 7) * 9u; }
+uint32_t oracle_xoshiro128ss_peek(const uint32_t x[4]) { return ss32(x[1]); }
 
-static double stream_uniform(uint32_t x[4]) {
-    uint32_t hi = oracle_xoshiro128pp_next(x);
-    uint32_t lo = oracle_xoshiro128ss_peek(x);
-    uint64_t v = ((uint64_t)hi << 21) | (lo >> 11);
+/* u(s, t) for t = 0, 1, 2, ... in order: *cur carries the output of the even position's step to the odd one */
+double oracle_lw_stream_uniform(uint32_t x[4], uint32_t *cur, uint32_t t) {
+    uint32_t h;
+    uint64_t low;
+    if ((t & 1u) == 0) {
+        *cur = oracle_xoshiro128pp_next(x);
+        h = *cur >> 16;
+        low = ((uint64_t)ss32(x[1]) << 5) | (ss32(x[2]) >> 27);
+    } else {
+        h = *cur & 0xffffu;
+        low = ((uint64_t)ss32(x[3]) << 5) | (ss32(x[0]) >> 27);
+    }
+    uint64_t v = ((uint64_t)h << 37) | low;
     return (double)v * (1.0 / 9007199254740992.0);
 }
+void oracle_lw_stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]) { stream_seed(seed, s, x); }
 
 /* the uniform of (sample s, position t): test hook */
 double oracle_lw_uniform(uint64_t seed, uint64_t s, uint32_t t) {
-    uint32_t x[4];
+    uint32_t x[4], cur = 0;
     stream_seed(seed, s, x);
     double u = 0;
-    for (uint32_t i = 0; i <= t; ++i) u = stream_uniform(x);
+    for (uint32_t i = 0; i <= t; ++i) u = oracle_lw_stream_uniform(x, &cur, i);
     return u;
 }
 
@@ -121,11 +139,11 @@ int oracle_lw_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
     for (uint64_t si = 0; si < n_samples; ++si) {
         uint64_t s = s_begin + si;
         double w = 1.0; /* :124 */
-        uint32_t rng[4];
+        uint32_t rng[4], cur = 0;
         stream_seed(seed, s, rng);
         for (int t = 0; t < n; ++t) {
             int v = topo[t];
-            double u = stream_uniform(rng); /* drawn at every position */
+            double u = oracle_lw_stream_uniform(rng, &cur, (uint32_t)t); /* every position has its uniform, evidence node or not */
             int64_t row = 0; /* parent assignment -> CPT row, first parent most significant */
             for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + state[in_idx[e]];
             const double *r = cpt + cpt_off[v] + row * k[v];
@@ -175,11 +193,11 @@ int oracle_rs_run(int n, const int32_t *k, const int32_t *in_ptr, const int32_t 
     while (accepted < n_accept && drawn < max_draw) {
         uint64_t s = s_begin + drawn;
         int ok = 1;
-        uint32_t rng[4];
+        uint32_t rng[4], cur = 0;
         stream_seed(seed, s, rng);
         for (int t = 0; t < n; ++t) {
             int v = topo[t];
-            double u = stream_uniform(rng);
+            double u = oracle_lw_stream_uniform(rng, &cur, (uint32_t)t);
             int64_t row = 0;
             for (int32_t e = in_ptr[v]; e < in_ptr[v + 1]; ++e) row = row * k[in_idx[e]] + state[in_idx[e]];
             state[v] = pick_state(u, cpt + cpt_off[v] + row * k[v], k[v]);

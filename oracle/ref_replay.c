@@ -135,16 +135,9 @@ static const double *row_of(const walker_t *w, int v, const int32_t *state) {
     return w->cpt + w->cpt_off[v] + row * w->k[v];
 }
 
-static void repo_stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]) {
-    uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), 0u, 0u};
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    oracle_philox4x32_10(ctr, key, x);
-    if ((x[0] | x[1] | x[2] | x[3]) == 0) x[0] = 1;
-}
-static double repo_stream_uniform(uint32_t x[4]) {
-    uint32_t hi = oracle_xoshiro128pp_next(x), lo = oracle_xoshiro128ss_peek(x);
-    return (double)(((uint64_t)hi << 21) | (lo >> 11)) * (1.0 / 9007199254740992.0);
-}
+/* the repository's stream: defined in lw_oracle.c (one xoshiro128++ step per two positions) */
+void oracle_lw_stream_seed(uint64_t seed, uint64_t s, uint32_t x[4]);
+double oracle_lw_stream_uniform(uint32_t x[4], uint32_t *cur, uint32_t t);
 
 /* likelihood_weighting.hpp:177-193 */
 static int make_random_by_weight(double value, const double *weight, int k) {
@@ -160,12 +153,12 @@ static int make_random_by_weight(double value, const double *weight, int k) {
 /* weighted_sample :122-173; sample_id is used by the repo stream only */
 static double weighted_sample(walker_t *w, const int32_t *ev_state, uint64_t sample_id, int32_t *state) {
     double weight = 1.0;
-    uint32_t x[4];
-    if (w->stream_kind == 1) repo_stream_seed(w->seed, sample_id, x);
+    uint32_t x[4], cur = 0;
+    if (w->stream_kind == 1) oracle_lw_stream_seed(w->seed, sample_id, x);
     for (int t = 0; t < w->n; ++t) {
         int v = w->order[t];
         double u = 0.0;
-        if (w->stream_kind == 1) u = repo_stream_uniform(x); /* drawn at every position */
+        if (w->stream_kind == 1) u = oracle_lw_stream_uniform(x, &cur, (uint32_t)t); /* every position has its uniform */
         const double *r = row_of(w, v, state);
         if (ev_state[v] >= 0) { /* :148-153 */
             weight *= r[ev_state[v]];

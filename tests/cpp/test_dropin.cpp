@@ -204,6 +204,7 @@ int main(int argc, char** argv)
         print_marginals("pearl_part2", pearl, r2);
         std::printf("\"pearl_part2_sweeps\":%d,", bp.last_sweeps());
         view_equals_map(bp.run(pre), r2, pearl, "belief_propagation pearl part2");
+        view_equals_map(bp.run(bp.prepare(pre)), r2, pearl, "belief_propagation pearl part2, prepared evidence");
         view_equals_map(bp.run(), r1, pearl, "belief_propagation pearl part1");
     }
     {   // belief_propagation_resume_ex, _sample1 .. _sample4  (3 % tolerance, one queried node each)

@@ -64,7 +64,7 @@ def test_lw_generic_kernel_on_a_small_arity_network(Engine, oracle_mod, monkeypa
 def test_lw_config5_full_size(Engine, oracle_mod):
     """BASELINE.json configs[4] at its workload: the 10 k-node DAG with 1 % evidence.
     (a) integer work: the first 2048 sampled states are bit-equal to the oracle;
-    (b) a 2 M-sample batch (the bench step) on the GPU: split-range additivity at that size, and a
+    (b) a 2 M-sample batch on the GPU (the bench step is 10 M: test_lw_config5_ten_million_samples below): split-range additivity at that size, and a
         subset of the same sample ids re-drawn in isolation equals the oracle's histogram of those ids
         (the oracle draws 3e3 samples/s, so the subset is what it finishes in seconds);
     (c) size-independent properties of the 2 M-sample histogram: every node's bins sum to the total
@@ -98,6 +98,80 @@ def test_lw_config5_full_size(Engine, oracle_mod):
     for v in np.nonzero(ev >= 0)[0]:
         row = whole[d.node_off[v]:d.node_off[v + 1]]
         assert row[ev[v]] > 0 and np.count_nonzero(row) == 1
+
+
+def test_lw_config5_ten_million_samples(Engine):
+    """BASELINE.json configs[4] AT ITS SIZE: one bn_lw_run of 10 M weighted samples on the 10 k-node DAG -- more than the state
+    matrix holds at once (32 GiB / 10 000 nodes = 3.4 M samples), so the call walks three batches (bn_lw.cpp lw_run) -- equals the
+    sum of four calls over disjoint windows of its sample ids, each of which fits one batch; every node's bins sum to the total
+    weight; evidence nodes hold all of it in the observed state.  Reference path: likelihood_weighting.hpp:28-59 (sample_num)."""
+    from bayesiannetwork_amd import synth
+    d = synth.random_dag(10000, 4, 64, 4, seed=1)
+    ev = synth.random_evidence(d, 0.01, seed=7).hard_states(d)
+    n_all, seed = 10_000_000, 3
+    windows = [(0, 3_000_000), (3_000_000, 3_000_000), (6_000_000, 3_000_000), (9_000_000, 1_000_000)]
+    with Engine(d) as eng:
+        whole = eng.lw_run(ev, n_all, seed=seed)
+        parts = sum(eng.lw_run(ev, cnt, seed=seed, sample_begin=lo) for lo, cnt in windows)
+    assert np.allclose(whole, parts, rtol=1e-9, atol=1e-300)
+    sums = np.add.reduceat(whole, d.node_off[:-1])
+    assert sums[0] > 0 and np.allclose(sums, sums[0], rtol=1e-9)
+    for v in np.nonzero(ev >= 0)[0]:
+        row = whole[d.node_off[v]:d.node_off[v + 1]]
+        assert row[ev[v]] > 0 and np.count_nonzero(row) == 1
+
+
+def _tie_network(wide):
+    """Tables whose running totals sit exactly ON a multiple of 2^-16, one step of the 53-bit grid BELOW and one ABOVE: a draw
+    whose top 16 bits equal a threshold's is decided by the 37 bits below (bn_lw_kernels.hip: the tie branch), and those three
+    placements are where an off-by-one in that branch would show.  Roots of arity 4 / 3 / 2, children with one and two parents
+    (tables staged through LDS), and a binary node with five parents (thresholds gathered from memory by the generic kernel)."""
+    from bayesiannetwork_amd import from_parent_lists
+    g = 2.0 ** -53
+
+    def row(totals):   # probabilities whose left-to-right running totals are exactly `totals` (all on the 2^-53 grid: exact in fp64)
+        t = [0.0] + list(totals) + [1.0]
+        return [t[i + 1] - t[i] for i in range(len(t) - 1)]
+
+    j = lambda x: x / 65536.0
+    k = [4, 3, 2, 4, 4, 2, 2, 2, 2]
+    parents = [[], [], [], [0], [1, 2], [2], [5], [2, 5, 6], [0, 2, 5, 6, 7]]   # node 8: five parents, 4 * 2 * 2 * 2 * 2 = 64 rows, not a packed step
+    cpts = [row([j(9000), j(30000) - g, j(50000) + g]), row([j(20000) + g, j(45000)]), row([j(32768) - g]),
+            sum((row([j(1000 + 700 * r), j(21000 + 900 * r) + (g if r % 2 else -g), j(60000 - 1100 * r)]) for r in range(4)), []),
+            sum((row([j(5000 + 3000 * r) - g, j(33000 + 2000 * r), j(52000 + 1500 * r) + g]) for r in range(6)), []),
+            sum((row([j(12345 + 111 * r) + (g if r else 0.0)]) for r in range(2)), []),
+            sum((row([j(40000 - 7 * r) - (g if r else 0.0)]) for r in range(2)), []),
+            sum((row([j(100 + 8000 * r)]) for r in range(8)), []),
+            sum((row([j(300 + 1000 * r) + (g, 0.0, -g)[r % 3]]) for r in range(64)), [])]
+    if not wide:   # without the five-parent node every node has <= 4 parents, <= 256 rows, <= 4 states: the straight-line kernel's domain
+        k, parents, cpts = k[:8], parents[:8], cpts[:8]
+    return from_parent_lists(k=k, parents=parents, cpts=cpts, name="tie_network")
+
+
+@pytest.mark.parametrize("small,wide", [("1", False), ("0", False), ("1", True)])
+def test_lw_draws_that_tie_with_a_threshold(Engine, oracle_mod, monkeypatch, small, wide):
+    """make_random_by_weight (likelihood_weighting.hpp:177-193): first i with cum_{i-1} <= u < cum_i.  The kernels decide a draw
+    by the top 16 bits of its uniform and fall back to the full 53-bit thresholds when those tie; here the ties are forced
+    (thresholds on, just below and just above a multiple of 2^-16) and every state of 400 000 samples must equal the oracle's
+    fp64 rule -- from the straight-line kernel, from the generic kernel on the same network (BN_LW_SMALL=0: every table staged
+    through LDS), and from the generic kernel with the five-parent node (its thresholds gathered from memory)."""
+    monkeypatch.setenv("BN_LW_SMALL", small)
+    d = _tie_network(wide)
+    ns, seed = 400_000, 20251003
+    ev = np.full(d.n, -1, dtype=np.int32)
+    want = oracle_mod.lw_run(d, ev, ns, seed=seed, states_cap=ns)
+    with Engine(d) as eng:
+        hist = eng.lw_run(ev, ns, seed=seed)
+        assert eng.info("lw_small") == int(small == "1" and not wide)
+        states, _ = eng.lw_states(ns)
+    assert np.array_equal(states, want["states"])
+    assert np.array_equal(hist, want["hist"])   # unit weights: integer counts
+    # the forced ties did occur: samples whose top 16 bits at position 0 (node 0) equal one of its thresholds' top 16 bits
+    hits = 0
+    for smp in range(0, 120_000):
+        h = int(oracle_mod.lw_uniform(seed, smp, 0) * 65536.0)
+        hits += h in (9000, 29999, 30000, 50000)
+    assert hits >= 1
 
 
 def test_lw_split_runs_sum(Engine):

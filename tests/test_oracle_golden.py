@@ -69,11 +69,13 @@ def test_philox_known_answers(oracle_mod):
 
 def test_sampler_stream_definition(oracle_mod):
     """The sampler's stream, restated independently in Python: xoshiro128++ 1.0 (Blackman & Vigna)
-    seeded per sample by philox4x32_10({s_lo, s_hi, 0, 0}, {seed_lo, seed_hi}); one step per topological
-    position: the ++ output is the top 32 bits of the uniform, the ** scrambler of the state the step
-    left behind gives the low 21; u = (hi << 21 | lo >> 11) * 2^-53."""
+    seeded per sample by philox4x32_10({s_lo, s_hi, 0, 0}, {seed_lo, seed_hi}); ONE step per TWO topological
+    positions: the even position's uniform has the top half of the ++ output as its top 16 bits, the odd one the
+    bottom half; the 37 bits below come from the ** scrambler of words of the state the step left behind
+    (x[1], x[2] for the even position; x[3], x[0] for the odd one); u = (h << 37 | low) * 2^-53."""
     M = 0xffffffff
     rotl = lambda x, k: ((x << k) | (x >> (32 - k))) & M
+    ss = lambda w: (rotl((w * 5) & M, 7) * 9) & M
 
     def nxt(s):
         result = (rotl((s[0] + s[3]) & M, 7) + s[0]) & M
@@ -90,11 +92,16 @@ def test_sampler_stream_definition(oracle_mod):
     assert mine[:2] == [641, 1573767]            # by hand: rotl(1+4,7)+1 ; second from the updated state
     for seed, sample in [(0, 0), (1234, 77), (2 ** 63 + 5, 2 ** 40 + 3)]:
         st = oracle_mod.philox([sample & M, sample >> 32, 0, 0], [seed & M, seed >> 32])
-        for pos in range(6):
-            hi = nxt(st)
-            lo = (rotl((st[1] * 5) & M, 7) * 9) & M
-            u = float((hi << 21) | (lo >> 11)) * 2.0 ** -53
-            if pos in (0, 3, 5):
+        out = 0
+        for pos in range(7):
+            if pos % 2 == 0:
+                out = nxt(st)
+                h, low = out >> 16, (ss(st[1]) << 5) | (ss(st[2]) >> 27)
+            else:
+                h, low = out & 0xffff, (ss(st[3]) << 5) | (ss(st[0]) >> 27)
+            u = float((h << 37) | low) * 2.0 ** -53
+            assert 0.0 <= u < 1.0
+            if pos in (0, 1, 3, 4, 6):
                 assert oracle_mod.lw_uniform(seed, sample, pos) == u
 
 
