@@ -88,7 +88,7 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                 err = "likelihood weighting needs finite, non-negative CPT entries";
                 return BN_ERR_ARG;
             }
-        s.small = s.inline_parents && p.n < (1 << 24) - 1;
+        s.small = s.inline_parents && p.n < (1 << 24) - 1 && p.cpt_off[p.n] < (int64_t(1) << 32);
         s.small_pow2 = true;
         for (int32_t v = 0; v < p.n && s.small; ++v) {
             const int64_t rows = (p.cpt_off[v + 1] - p.cpt_off[v]) / p.k[v];
@@ -129,7 +129,7 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                 }
             }
             if (s.small) {   // lw_sample_small_kernel's descriptor (node numbers for now: the row stride is not known yet)
-                if (s.h_small.empty()) s.h_small.assign(size_t(p.n) + 3, LwSmallStep{{uint64_t(p.n), uint64_t(p.n), uint64_t(p.n), uint64_t(p.n)}, uint64_t(p.n), 0, 0, 0, {0, 0}});
+                if (s.h_small.empty()) s.h_small.assign(size_t(p.n) + 3, LwSmallStep{{uint64_t(p.n), uint64_t(p.n), uint64_t(p.n), uint64_t(p.n)}, uint64_t(p.n), {0, 0, 0, 0}, 0, 0});
                 LwSmallStep& ss = s.h_small[t];
                 const int32_t m = p.in_ptr[v + 1] - p.in_ptr[v];
                 uint32_t shape = uint32_t(p.k[v]);
@@ -140,8 +140,9 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                     if (j > 0) shape |= (s.small_pow2 ? uint32_t(__builtin_ctz(kk)) : kk) << (8 * j);
                 }
                 ss.own = uint64_t(v);
-                ss.coff = uint64_t(coff);
-                ss.thr16 = uint32_t(row16[v]);
+                ss.coff = uint32_t(coff);
+                ss.tab[0] = uint32_t(row16[v]);   // (host copy: first row in d_thr16 and the table's bytes; the device copy holds the descriptor)
+                ss.tab[1] = uint32_t((((p.cpt_off[v + 1] - coff) / p.k[v] + 1) & ~int64_t(1)) * 8);
                 ss.shape = shape;
             }
             if (parents.size() & 1) parents.push_back(LwParent{0, 1});  // pairs: 16-byte aligned loads
@@ -206,6 +207,14 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
     uint64_t want = (want_samples + kLwBlockSamples - 1) / kLwBlockSamples * kLwBlockSamples;
     uint64_t batch = std::min<uint64_t>({want, cap, uint64_t(16384) * kLwBlockSamples});
     batch = std::max<uint64_t>(batch, kLwBlockSamples);
+    // (Launches of whole rounds of resident waves -- 8 192 waves = 2.1 M samples on 256 CUs instead of the 13 420 waves of a 3.4 M-sample
+    // batch -- were tried in round 5: 7.4 vs 7.5 ns per sample.  The kernel is bound by vector issue, not by occupancy: waves of a
+    // half-empty second round simply run faster.)
+    s.launch_samples = batch;   // (the state matrix may be larger, from an earlier call: its row stride stays s.batch)
+    // Row stride of the state matrix = samples per launch + 33 x 128 bytes: never a power of two.  With rows exactly 2^21 bytes apart
+    // the histogram pass, whose 64 lanes read 64 consecutive rows at the same offset, ran 48 % slower per sample (4.1 vs 2.7 ns) --
+    // every lane's line in the same cache set / memory channel.
+    batch += 33 * 128;
     if (batch > s.batch) {
         if (s.d_states) (void)hipFree(s.d_states);
         if (s.d_weights) (void)hipFree(s.d_weights);
@@ -213,11 +222,18 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         s.d_weights = nullptr;
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), (uint64_t(p.n) + 1) * batch));
         LWCHK(hipMemsetAsync(s.d_states + uint64_t(p.n) * batch, 0, batch, st));   // row n: the "parent" of nodes with fewer than four (lw_sample_small_kernel)
-        if (s.small) {   // the descriptors hold byte offsets of rows: made for this stride
+        if (s.small) {   // the descriptors hold ADDRESSES: of rows of this state matrix, of the tables in d_thr16
             std::vector<LwSmallStep> dev(s.h_small);
+            const uint64_t st_base = reinterpret_cast<uint64_t>(s.d_states), th_base = reinterpret_cast<uint64_t>(s.d_thr16);
             for (LwSmallStep& ss : dev) {
-                for (uint64_t& x : ss.par) x *= batch;
-                ss.own *= batch;
+                for (uint64_t& x : ss.par) x = st_base + x * batch;
+                ss.own = st_base + ss.own * batch;
+                const uint64_t tb = th_base + uint64_t(ss.tab[0]) * 8;
+                const uint32_t bytes = ss.tab[1];
+                ss.tab[0] = uint32_t(tb);
+                ss.tab[1] = uint32_t(tb >> 32) & 0xffffu;   // (stride 0)
+                ss.tab[2] = bytes;
+                ss.tab[3] = 0x00020000u;                    // raw buffer, dword data format
             }
             if (!s.d_small_steps) LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_small_steps), dev.size() * sizeof(LwSmallStep)));
             LWCHK(hipMemcpyAsync(s.d_small_steps, dev.data(), dev.size() * sizeof(LwSmallStep), hipMemcpyHostToDevice, st));
@@ -251,7 +267,7 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     LWCHK(hipMemsetAsync(s.d_hist, 0, std::max<size_t>(hist_n, 1) * sizeof(double), st));
     uint64_t done = 0;
     while (done < n_samples) {
-        const uint64_t cnt = std::min<uint64_t>(s.batch, n_samples - done);
+        const uint64_t cnt = std::min<uint64_t>(s.launch_samples, n_samples - done);
         LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
@@ -287,7 +303,7 @@ int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     std::vector<double> w(s.batch);
     uint64_t drawn = 0, accepted = 0;
     while (accepted < n_accept && drawn < max_draw) {
-        const uint64_t cnt = std::min<uint64_t>(s.batch, max_draw - drawn);
+        const uint64_t cnt = std::min<uint64_t>(s.launch_samples, max_draw - drawn);
         LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
                  s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);

@@ -30,14 +30,17 @@ struct LwStep {
 };
 constexpr int kLwStepPacked = 0x80;  // <= 4 parents and <= 256 CPT rows: the kernel keeps four samples' row numbers in the bytes of one register
 constexpr int kLwStepPow2 = 0x40;    // ... and every parent's arity is a power of two: shifts instead of multiplies
-// lw_sample_small_kernel's descriptor of one topological position: 64 bytes, wave-uniform, one scalar load a position ahead
+// lw_sample_small_kernel's descriptor of one topological position: 64 bytes, wave-uniform, one scalar load a position ahead.  Everything a
+// position addresses is in it READY TO USE -- row addresses, the table's buffer descriptor: the kernel is bound by scalar issue (a SIMD
+// issues one scalar instruction per four cycles, like one vector instruction; round 5 counted ~108 scalar against ~80 vector
+// instructions per position, 25 of the former 64-bit address arithmetic on values that never change between launches).
 struct LwSmallStep {
-    uint64_t par[4];   // byte offset of each parent's row in the state matrix (node x row stride); a missing parent: row n, all zero
+    uint64_t par[4];   // ADDRESS of each parent's row in the state matrix (states + node x row stride); a missing parent: row n, all zero
     uint64_t own;      // ... of the node's own row
-    uint64_t coff;     // offset of the node's CPT / thresholds in the flat arrays (entries)
-    uint32_t thr16;    // first row of the node's table in LwState::d_thr16 (even)
+    uint32_t tab[4];   // buffer descriptor of the node's table in LwState::d_thr16: base, num_records = its bytes (8 per row, rounded
+                       // up to 16): what the wave copies to LDS -- lanes beyond the table read zeros and request nothing
+    uint32_t coff;     // offset of the node's CPT / thresholds in the flat arrays (entries; below 2^32 on this path)
     uint32_t shape;    // arity | a1 << 8 | a2 << 16 | a3 << 24: parents 1..3's arities (small_pow2: log2 of them); a missing parent: arity 1
-    uint32_t pad_[2];
 };
 struct LwParent {
     uint32_t node, k;  // parent node id and its arity (mixed-radix digit base)
@@ -52,8 +55,8 @@ struct LwState {
     uint32_t* d_thr32 = nullptr;   // ... and their top halves (threshold >> 21): what a draw is compared with first, 4 bytes per entry
     uint32_t* d_thr16 = nullptr;   // nodes with <= 256 rows (kLwStepPacked): per row 8 bytes {t0 | t1 << 16, t2 | 0xffff << 16}, t = threshold >> 37 -- the copy a wave stages in LDS
     LwStep* d_steps = nullptr;
-    LwSmallStep* d_small_steps = nullptr;   // [n + 2] in topological order (LwState::small), written for the row stride LwState::batch
-    std::vector<LwSmallStep> h_small;       // the same with NODE numbers in par / own: what the device copy is made from when the stride changes     // [n] in topological order
+    LwSmallStep* d_small_steps = nullptr;   // [n + 3] in topological order (LwState::small), written for the state matrix in use (d_states, batch)
+    std::vector<LwSmallStep> h_small;       // the same with NODE numbers in par / own and {first row in d_thr16, bytes} in tab[0..1]: what the device copy is made from
     LwParent* d_parents = nullptr; // [E] grouped by position, first parent first
     int32_t* d_ev_topo = nullptr;  // [n] clamped state or -1 of the node at each position
     int32_t kmax = 0;              // largest arity
@@ -68,6 +71,7 @@ struct LwState {
     int32_t* h_ev = nullptr;       // page-locked staging of d_ev_topo: the upload needs no synchronisation of its own
     double* h_hist = nullptr;      // page-locked landing place of the histogram
     uint64_t batch = 0;            // samples per launch (multiple of kLwBlockSamples)
+    uint64_t launch_samples = 0;   // samples per launch of the current call (<= batch, the row stride)
     uint64_t last_batch_samples = 0;
     std::vector<int32_t> topo;
 };

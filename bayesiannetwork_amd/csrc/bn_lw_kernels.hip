@@ -410,7 +410,7 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
 //   * four parent loads always -- a missing parent points at the all-zero row behind the state matrix, with arity 1;
 //   * the row numbers of the thread's four samples are the four BYTES of one register (three shift-adds, or multiply-adds, for
 //     all four samples; every partial row number is below 256, so a byte never carries into its neighbour);
-//   * the node's 16-bit thresholds (8 bytes per row, 2 KB copied whatever the table's size) go through the wave's LDS slice;
+//   * the node's 16-bit thresholds (8 bytes per row; the copy stops where the table ends) go through the wave's LDS slice;
 //     always three compares per draw -- a node with fewer states has 0xffff in the unused places, which no draw exceeds;
 //   * the stream steps at the even positions only: the loop body is instantiated for both parities and runs them in turn.
 // POW2: every arity of the network is a power of two (LwSmallStep::shape holds log2 of the arities instead of the arities).
@@ -441,11 +441,10 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         rng[r] = philox4x32_10(uint32_t(s), uint32_t(s >> 32), 0u, 0u, key0, key1);
         if ((rng[r].x | rng[r].y | rng[r].z | rng[r].w) == 0) rng[r].x = 1;
     }
-    // a row of the state matrix = {scalar base: the matrix + the row's byte offset, which the descriptor holds ready} + {this thread's
-    // 32-bit offset}; see lw_sample_kernel for the two empty asm statements
-    auto row_at = [&](uint32_t off_lo, uint32_t off_hi) {
-        const uint64_t b = reinterpret_cast<uint64_t>(states) + ((uint64_t(off_hi) << 32) | off_lo);
-        uint32_t lo = uint32_t(b), hi = uint32_t(b >> 32);
+    // a row of the state matrix = {scalar base: the row's address, which the descriptor holds ready} + {this thread's 32-bit offset};
+    // see lw_sample_kernel for the two empty asm statements
+    auto row_at = [&](uint32_t addr_lo, uint32_t addr_hi) {
+        uint32_t lo = addr_lo, hi = addr_hi;
         asm volatile("" : "+s"(lo), "+s"(hi));
         return reinterpret_cast<lw_global_bytes>((uint64_t(hi) << 32) | lo);
     };
@@ -466,12 +465,18 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
     auto position = [&](int t, auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
         asm volatile("" : "+v"(c32));
-        const LwSmallWords sd = nxt;   // a, b: the four parents' rows; c: own row, CPT offset; d: thr16 row, kv | shifts (or arities) of parents 1..3
+        const LwSmallWords sd = nxt;   // a, b: the four parents' rows; c: own row, the table's base; d: the table's bytes, (flags), CPT offset, kv | shifts (or arities) of parents 1..3
         const int ev = ev_nxt;
         nxt = steps[t + 1];
         ev_nxt = ev_topo[t + 1];
-        const uint4* src = thr16 + (sd.d.x >> 1);
-        const uint4 q0 = src[lane], q1 = src[64 + lane];
+        // The node's table of 16-bit thresholds, 16 bytes per lane and load, through a buffer descriptor that ENDS with the table:
+        // lanes beyond it get zeros and request nothing.  (Round 4 copied 2 KB whatever the table's size -- a k = 4 node with
+        // m parents has 4^m rows of 8 bytes, 545 bytes on average over config 5's nodes -- and the copies alone were ~10 TB/s of
+        // L2 traffic: with the generator's step halved the kernel ran 5 % faster, not 20 %; the vector ALU was not what bound it.)
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>((uint64_t(sd.c.w) << 32) | sd.c.z), 0, int(sd.d.x), 0x00020000);   // (LwSmallStep::tab: base, bytes)
+        const uint4 q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u), 0, 0));
+        const uint4 q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u + 1024u), 0, 0));
         const uint32_t w0 = *reinterpret_cast<lw_global_u32>(row_at(sd.a.x, sd.a.y) + c32);
         const uint32_t w1 = *reinterpret_cast<lw_global_u32>(row_at(sd.a.z, sd.a.w) + c32);
         const uint32_t w2 = *reinterpret_cast<lw_global_u32>(row_at(sd.b.x, sd.b.y) + c32);
@@ -482,15 +487,15 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         my_tab[64 + lane] = q1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t a1 = (sd.d.y >> 8) & 0xffu, a2 = (sd.d.y >> 16) & 0xffu, a3 = sd.d.y >> 24;
+        const uint32_t a1 = (sd.d.w >> 8) & 0xffu, a2 = (sd.d.w >> 16) & 0xffu, a3 = sd.d.w >> 24;
         uint32_t rp;
         if (POW2) rp = ((((((w0 << a1) + w1) << a2) + w2) << a3)) + w3;
         else rp = ((w0 * a1 + w1) * a2 + w2) * a3 + w3;
         uint32_t row[S];
 #pragma unroll
         for (int r = 0; r < S; ++r) row[r] = (rp >> (8 * r)) & 0xffu;
-        const int kv = int(sd.d.y & 0xffu);
-        const uint64_t coff = (uint64_t(sd.c.w) << 32) | sd.c.z;
+        const int kv = int(sd.d.w & 0xffu);
+        const uint64_t coff = sd.d.z;
         if (PAR == 0) {   // the step of this position and the next, evidence node or not
 #pragma unroll
             for (int r = 0; r < S; ++r) out[r] = xoshiro_next(rng[r]);
