@@ -132,13 +132,16 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                 if (s.h_small.empty()) s.h_small.assign(size_t(p.n) + 3, LwSmallStep{{uint64_t(p.n), uint64_t(p.n), uint64_t(p.n), uint64_t(p.n)}, uint64_t(p.n), {0, 0, 0, 0}, 0, 0});
                 LwSmallStep& ss = s.h_small[t];
                 const int32_t m = p.in_ptr[v + 1] - p.in_ptr[v];
-                uint32_t shape = uint32_t(p.k[v]);
+                uint32_t shape = uint32_t(p.k[v]) | (uint32_t(m) << 4);
                 for (int32_t j = 0; j < 4; ++j) {
                     const int32_t node = j < m ? p.in_idx[p.in_ptr[v] + j] : p.n;
                     const uint32_t kk = j < m ? uint32_t(p.k[node]) : 1u;
                     ss.par[j] = uint64_t(node);
                     if (j > 0) shape |= (s.small_pow2 ? uint32_t(__builtin_ctz(kk)) : kk) << (8 * j);
                 }
+                if (t > 0)   // bit 7 of the arity byte: this position reads the row the position before it writes (its loads cannot be issued ahead)
+                    for (int32_t j = 0; j < m; ++j)
+                        if (p.in_idx[p.in_ptr[v] + j] == s.topo[t - 1]) shape |= 0x80u | (uint32_t(j) << 12);   // (which parent: bits 12-13, above a1)
                 ss.own = uint64_t(v);
                 ss.coff = uint32_t(coff);
                 ss.tab[0] = uint32_t(row16[v]);   // (host copy: first row in d_thr16 and the table's bytes; the device copy holds the descriptor)
@@ -202,32 +205,33 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
 #ifndef BN_LW_STATE_GIB
 #define BN_LW_STATE_GIB 32
 #endif
-    uint64_t cap = (uint64_t(BN_LW_STATE_GIB) << 30) / std::max<uint64_t>(p.n, 1);
+    // (LwState::small: four samples per byte)
+    const uint64_t per_byte = s.small ? 4 : 1;
+    uint64_t cap = (uint64_t(BN_LW_STATE_GIB) << 30) / std::max<uint64_t>(p.n, 1) * per_byte;
     cap = std::max<uint64_t>(kLwBlockSamples, cap / kLwBlockSamples * kLwBlockSamples);
     uint64_t want = (want_samples + kLwBlockSamples - 1) / kLwBlockSamples * kLwBlockSamples;
     uint64_t batch = std::min<uint64_t>({want, cap, uint64_t(16384) * kLwBlockSamples});
     batch = std::max<uint64_t>(batch, kLwBlockSamples);
     // (Launches of whole rounds of resident waves -- 8 192 waves = 2.1 M samples on 256 CUs instead of the 13 420 waves of a 3.4 M-sample
-    // batch -- were tried in round 5: 7.4 vs 7.5 ns per sample.  The kernel is bound by vector issue, not by occupancy: waves of a
-    // half-empty second round simply run faster.)
-    s.launch_samples = batch;   // (the state matrix may be larger, from an earlier call: its row stride stays s.batch)
-    // Row stride of the state matrix = samples per launch + 33 x 128 bytes: never a power of two.  With rows exactly 2^21 bytes apart
-    // the histogram pass, whose 64 lanes read 64 consecutive rows at the same offset, ran 48 % slower per sample (4.1 vs 2.7 ns) --
-    // every lane's line in the same cache set / memory channel.
-    batch += 33 * 128;
+    // batch -- were tried in round 5: 7.4 vs 7.5 ns per sample: waves of a half-empty second round simply run faster.)
+    s.launch_samples = batch;   // (the state matrix may be larger, from an earlier call: its rows stay as long as they are)
     if (batch > s.batch) {
         if (s.d_states) (void)hipFree(s.d_states);
         if (s.d_weights) (void)hipFree(s.d_weights);
         s.d_states = nullptr;
         s.d_weights = nullptr;
-        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), (uint64_t(p.n) + 1) * batch));
-        LWCHK(hipMemsetAsync(s.d_states + uint64_t(p.n) * batch, 0, batch, st));   // row n: the "parent" of nodes with fewer than four (lw_sample_small_kernel)
+        // Row stride = the row's bytes + 33 x 128: never a power of two.  With rows exactly 2^21 bytes apart the histogram pass, whose 64
+        // lanes read 64 consecutive rows at the same offset, ran 48 % slower per sample (4.1 vs 2.7 ns) -- every lane's line in the
+        // same cache set / memory channel.
+        const uint64_t stride = batch / per_byte + 33 * 128;
+        LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_states), (uint64_t(p.n) + 1) * stride));
+        LWCHK(hipMemsetAsync(s.d_states + uint64_t(p.n) * stride, 0, stride, st));   // row n: all zero (the generic kernel's "parent" of nodes with fewer than four inline parents)
         if (s.small) {   // the descriptors hold ADDRESSES: of rows of this state matrix, of the tables in d_thr16
             std::vector<LwSmallStep> dev(s.h_small);
             const uint64_t st_base = reinterpret_cast<uint64_t>(s.d_states), th_base = reinterpret_cast<uint64_t>(s.d_thr16);
             for (LwSmallStep& ss : dev) {
-                for (uint64_t& x : ss.par) x = st_base + x * batch;
-                ss.own = st_base + ss.own * batch;
+                for (uint64_t& x : ss.par) x = st_base + x * stride;
+                ss.own = st_base + ss.own * stride;
                 const uint64_t tb = th_base + uint64_t(ss.tab[0]) * 8;
                 const uint32_t bytes = ss.tab[1];
                 ss.tab[0] = uint32_t(tb);
@@ -239,6 +243,7 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
             LWCHK(hipMemcpyAsync(s.d_small_steps, dev.data(), dev.size() * sizeof(LwSmallStep), hipMemcpyHostToDevice, st));
             LWCHK(hipStreamSynchronize(st));   // `dev` is a local
         }
+        s.stride = stride;
         LWCHK(hipMalloc(reinterpret_cast<void**>(&s.d_weights), batch * sizeof(double)));
         s.batch = batch;
     }
@@ -269,7 +274,7 @@ int lw_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     while (done < n_samples) {
         const uint64_t cnt = std::min<uint64_t>(s.launch_samples, n_samples - done);
         LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
-                 s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + done, cnt, seed, 0};
+                 s.d_states, s.d_weights, s.d_hist, s.stride, s.small, sample_begin + done, cnt, seed, 0};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st) || launch_lw_hist(a, blocks, st)) { err = "lw kernel launch failed"; return BN_ERR_HIP; }
         s.last_batch_samples = cnt;
@@ -305,7 +310,7 @@ int rs_run(LwState& s, const Plan& p, void* stream, int32_t ne, const int32_t* e
     while (accepted < n_accept && drawn < max_draw) {
         const uint64_t cnt = std::min<uint64_t>(s.launch_samples, max_draw - drawn);
         LwArgs a{p.n, s.kmax, s.rows24, s.inline_parents, s.small, s.small_pow2, s.d_steps, s.d_small_steps, s.d_parents, s.d_ev_topo, s.d_k, s.d_node_off, s.d_cpt, s.d_thr, s.d_thr32, s.d_thr16,
-                 s.d_states, s.d_weights, s.d_hist, s.batch, sample_begin + drawn, cnt, seed, 1};
+                 s.d_states, s.d_weights, s.d_hist, s.stride, s.small, sample_begin + drawn, cnt, seed, 1};
         const int blocks = int((cnt + kLwBlockSamples - 1) / kLwBlockSamples);
         if (launch_lw_sample(a, blocks, st)) { err = "sampling kernel launch failed"; return BN_ERR_HIP; }
         LWCHK(hipMemcpyAsync(w.data(), s.d_weights, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -333,7 +338,7 @@ int lw_states(LwState& s, const Plan& p, void* stream, uint64_t n, uint8_t* stat
     if (states_out && n > 0) {   // transposed on the device (sample-major), then one copy
         uint8_t* d_t = nullptr;
         LWCHK(hipMalloc(reinterpret_cast<void**>(&d_t), n * uint64_t(p.n)));
-        int rc = launch_lw_transpose(s.d_states, d_t, p.n, s.batch, n, st);
+        int rc = launch_lw_transpose(s.d_states, d_t, p.n, s.stride, s.small, n, st);
         hipError_t ce = rc ? hipSuccess : hipMemcpyAsync(states_out, d_t, n * uint64_t(p.n), hipMemcpyDeviceToHost, st);
         if (!rc && ce == hipSuccess) ce = hipStreamSynchronize(st);
         (void)hipFree(d_t);

@@ -40,7 +40,8 @@ struct LwSmallStep {
     uint32_t tab[4];   // buffer descriptor of the node's table in LwState::d_thr16: base, num_records = its bytes (8 per row, rounded
                        // up to 16): what the wave copies to LDS -- lanes beyond the table read zeros and request nothing
     uint32_t coff;     // offset of the node's CPT / thresholds in the flat arrays (entries; below 2^32 on this path)
-    uint32_t shape;    // arity | a1 << 8 | a2 << 16 | a3 << 24: parents 1..3's arities (small_pow2: log2 of them); a missing parent: arity 1
+    uint32_t shape;    // arity | parents << 4 | a1 << 8 | a2 << 16 | a3 << 24: parents 1..3's arities (small_pow2: log2 of them); a missing parent: arity 1;
+                       // bit 7: parent j (bits 12-13) is the node of the position before -- its byte is taken from that position's store, not from memory
 };
 struct LwParent {
     uint32_t node, k;  // parent node id and its arity (mixed-radix digit base)
@@ -65,12 +66,14 @@ struct LwState {
     bool small = false;            // every node has <= 4 parents, <= 256 CPT rows and <= 4 states (and n < 2^24 - 1): lw_sample_small_kernel; LwStep::par of a
                                    // missing parent then names the all-zero row n of the state matrix with arity 1
     bool small_pow2 = false;       // ... and every arity is a power of two: LwStep::par holds log2 of the arity in its top byte
-    uint8_t* d_states = nullptr;   // [n][batch] sampled states of the current batch
+    uint8_t* d_states = nullptr;   // sampled states of the current batch, [n + 1] rows of `stride` bytes: one byte per sample, or -- LwState::small,
+                                   // every arity <= 4 -- FOUR samples per byte, two bits each (sample s: bits 2 (s & 3) of byte s >> 2)
+    uint64_t stride = 0;           // bytes per row of d_states: batch (or batch / 4) + 33 x 128
     double* d_weights = nullptr;   // [batch]
     double* d_hist = nullptr;      // [sum k]
     int32_t* h_ev = nullptr;       // page-locked staging of d_ev_topo: the upload needs no synchronisation of its own
     double* h_hist = nullptr;      // page-locked landing place of the histogram
-    uint64_t batch = 0;            // samples per launch (multiple of kLwBlockSamples)
+    uint64_t batch = 0;            // samples a row of d_states holds (multiple of kLwBlockSamples)
     uint64_t launch_samples = 0;   // samples per launch of the current call (<= batch, the row stride)
     uint64_t last_batch_samples = 0;
     std::vector<int32_t> topo;
@@ -95,7 +98,8 @@ struct LwArgs {
     uint8_t* states;
     double* weights;
     double* hist;
-    uint64_t batch;        // row stride of `states`
+    uint64_t batch;        // row stride of `states` in bytes
+    bool packed2;          // `states` holds four samples per byte, two bits each (the straight-line kernel's networks: every arity <= 4)
     uint64_t sample_base;  // global index of the batch's sample 0
     uint64_t n_valid;      // samples of this batch that count
     uint64_t seed;
@@ -104,7 +108,7 @@ struct LwArgs {
 
 int launch_lw_sample(const LwArgs& a, int blocks, void* stream);
 int launch_lw_hist(const LwArgs& a, int blocks, void* stream);
-int launch_lw_transpose(const uint8_t* states, uint8_t* out, int32_t n, uint64_t batch, uint64_t n_samples, void* stream);
+int launch_lw_transpose(const uint8_t* states, uint8_t* out, int32_t n, uint64_t stride, bool packed2, uint64_t n_samples, void* stream);
 
 void lw_free(LwState& s);
 // hist_out == nullptr: leave the histogram in s.d_hist (the caller reduces it across ranks first)

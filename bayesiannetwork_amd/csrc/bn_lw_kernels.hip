@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
 // The descriptor (LwSmallStep, 64 bytes, one scalar load a position ahead) holds the rows' BYTE OFFSETS in the state matrix ready:
 // a row's base is one 64-bit scalar add (node x stride as scalar multiplies was 8 scalar instructions per row, 40 per position).
 #ifndef BN_LW_SMALL_WAVES
-#define BN_LW_SMALL_WAVES 8
+#define BN_LW_SMALL_WAVES 7
 #endif
 struct LwSmallWords {  // LwSmallStep as four 16-byte words
     uint4 a, b, c, d;
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
     constexpr int S = kLwPerThread;
     static_assert(S == 4, "one dword of states per thread and node");
     static_assert(sizeof(LwSmallStep) == 64, "descriptor layout");
-    const uint32_t col32 = (blockIdx.x * kLwThreads + threadIdx.x) * S;
+    const uint32_t col32 = (blockIdx.x * kLwThreads + threadIdx.x) * S;   // first sample of this thread
+    const uint32_t colb = blockIdx.x * kLwThreads + threadIdx.x;          // ... and its byte in a row of the state matrix: four samples per byte
     double w[S];
     uint4 rng[S];
     const uint32_t key0 = uint32_t(seed), key1 = uint32_t(seed >> 32);
@@ -448,54 +449,88 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         asm volatile("" : "+s"(lo), "+s"(hi));
         return reinterpret_cast<lw_global_bytes>((uint64_t(hi) << 32) | lo);
     };
-    uint32_t c32 = col32;
+    uint32_t c32 = colb;
+    // THE STATE MATRIX HOLDS TWO BITS PER STATE (every arity of these networks is <= 4): a thread's four samples of a node are one
+    // byte.  Round 5: with one byte per state the sampler wrote 10 KB per sample, read ~20 KB of parents' rows back (a wave's rows of
+    // the last 64 nodes are 16 KB, times 8 192 waves: beyond the L2) and the histogram pass read the 10 KB again -- 43 KB per sample,
+    // 4.3 TB/s at 1.0e8 samples/s, on a box whose device-to-device copy reaches 5.2: every on-chip change (vector, scalar, LDS,
+    // vector-memory instruction counts) left the sampling kernel's time where it was.  A parent's byte is spread to the four bytes
+    // of a register (three vector instructions) so that the row numbers are still formed for four samples at once.
+    typedef uint8_t __attribute__((address_space(1))) * lw_global_u8;
+    auto spread = [](uint32_t b) {   // bits 2r .. 2r + 1 -> byte r
+        uint32_t x = b | (b << 6);
+        x = x | (x << 12);
+        return x & 0x03030303u;
+    };
     __shared__ uint4 lw_tab[kLwThreads / 64][128];
     const uint32_t lane = threadIdx.x & 63u;
     uint4* const my_tab = lw_tab[threadIdx.x >> 6];
     const uint2* const tab = reinterpret_cast<const uint2*>(my_tab);
 
-    // (Requesting the parents' states of position t + 1 before position t is worked on, wherever t's node is not among them, was
-    // measured slower here too, 20.0 vs 18.3 ms per 2 M samples: with eight waves per SIMD the latency of a position is covered,
-    // and the bookkeeping of a second descriptor in flight costs issue slots.)
-    LwSmallWords nxt = steps[0];
-    int ev_nxt = ev_topo[0];
+    // What a position reads from memory, and only what it needs (the descriptor says how many parents the node has and how long its
+    // table is; the branches on them are scalar):
+    //   * the parents' states of this thread's four samples, one byte each -- m loads, not always four;
+    //   * this lane's 16 bytes of the node's table of 16-bit thresholds, through a buffer descriptor that ENDS with the table (lanes
+    //     beyond it get zeros and request nothing); the second kilobyte only for tables that have one (256 rows);
+    //   * a ROOT has one row: its three thresholds are wave-uniform and come through a scalar load -- no table copy, no LDS.
+    // (Round 4 copied 2 KB per position whatever the table's size -- ~10 TB/s of L2 traffic on config 5 -- and always loaded four
+    // parents, the missing ones from an all-zero row.)
+    struct Pre { uint32_t b0, b1, b2, b3; uint4 q0, q1; };
+    // ALWAYS six loads, so that the number in flight is known when the code is compiled: a wave waits for "all but the six issued
+    // last" (s_waitcnt vmcnt(6)), i.e. for its own position's loads and not for the next one's.  With a number of loads that depends
+    // on the node the compiler has to wait for all of them, and the pipeline below overlaps nothing (measured: 68.3 ms either way).
+    // A missing parent is the all-zero row n; a table load beyond the table's end requests nothing.
+    auto fetch = [&](const LwSmallWords& d, Pre& p) {
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>((uint64_t(d.c.w) << 32) | d.c.z), 0, int(d.d.x), 0x00020000);   // (LwSmallStep::tab: base, bytes)
+        p.q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u), 0, 0));
+        p.q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u + 1024u), 0, 0));
+        p.b0 = *reinterpret_cast<lw_global_u8>(row_at(d.a.x, d.a.y) + c32);
+        p.b1 = *reinterpret_cast<lw_global_u8>(row_at(d.a.z, d.a.w) + c32);
+        p.b2 = *reinterpret_cast<lw_global_u8>(row_at(d.b.x, d.b.y) + c32);
+        p.b3 = *reinterpret_cast<lw_global_u8>(row_at(d.b.z, d.b.w) + c32);
+    };
+    // SOFTWARE PIPELINE (round 5).  With two bits per state the kernel is bound by LATENCY -- 4 / 6 / 8 waves per SIMD draw 73 / 93 /
+    // 105 M samples/s, and a wave spends ~3 000 cycles per position, most of them waiting for its parents' bytes (a wave's rows of the
+    // last 64 nodes, times 8 192 waves, do not fit the L2: the reads come back from the Infinity Cache).  So the loads of position
+    // t + 1 are issued BEFORE position t is worked on; where t's node is one of t + 1's parents (LwSmallStep::shape bit 7, ~6 % of
+    // config 5's positions) that one byte is replaced, behind t's store, by the byte just stored.  (Rounds 4 and 5 measured the same pipeline SLOWER while the state
+    // matrix held a byte per state: the kernel was then bound by memory traffic, and more loads in flight only queued.)
+    // Descriptors are read two positions ahead; both arrays have three spare entries.
+    LwSmallWords cur = steps[0], nxt = steps[1];
+    int ev_cur = ev_topo[0], ev_nxt = ev_topo[1];
+    Pre pre;
+    fetch(cur, pre);
     uint32_t out[S];   // the ++ outputs of the last even position's step: their top halves decide it, the bottom halves the odd position after it
 #pragma unroll
     for (int r = 0; r < S; ++r) out[r] = 0;
     auto position = [&](int t, auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
         asm volatile("" : "+v"(c32));
-        const LwSmallWords sd = nxt;   // a, b: the four parents' rows; c: own row, the table's base; d: the table's bytes, (flags), CPT offset, kv | shifts (or arities) of parents 1..3
-        const int ev = ev_nxt;
-        nxt = steps[t + 1];
-        ev_nxt = ev_topo[t + 1];
-        // The node's table of 16-bit thresholds, 16 bytes per lane and load, through a buffer descriptor that ENDS with the table:
-        // lanes beyond it get zeros and request nothing.  (Round 4 copied 2 KB whatever the table's size -- a k = 4 node with
-        // m parents has 4^m rows of 8 bytes, 545 bytes on average over config 5's nodes -- and the copies alone were ~10 TB/s of
-        // L2 traffic: with the generator's step halved the kernel ran 5 % faster, not 20 %; the vector ALU was not what bound it.)
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>((uint64_t(sd.c.w) << 32) | sd.c.z), 0, int(sd.d.x), 0x00020000);   // (LwSmallStep::tab: base, bytes)
-        const uint4 q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u), 0, 0));
-        const uint4 q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u + 1024u), 0, 0));
-        const uint32_t w0 = *reinterpret_cast<lw_global_u32>(row_at(sd.a.x, sd.a.y) + c32);
-        const uint32_t w1 = *reinterpret_cast<lw_global_u32>(row_at(sd.a.z, sd.a.w) + c32);
-        const uint32_t w2 = *reinterpret_cast<lw_global_u32>(row_at(sd.b.x, sd.b.y) + c32);
-        const uint32_t w3 = *reinterpret_cast<lw_global_u32>(row_at(sd.b.z, sd.b.w) + c32);
-        // the table goes to LDS whether or not this is an evidence node (1 % are): left inside the branch, the copy's loads are
-        // sunk into it, behind the wait for the parents -- a second round trip per position
-        my_tab[lane] = q0;
-        my_tab[64 + lane] = q1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t a1 = (sd.d.w >> 8) & 0xffu, a2 = (sd.d.w >> 16) & 0xffu, a3 = sd.d.w >> 24;
+        const LwSmallWords sd = cur;   // a, b: the four parents' rows; c: own row, the table's base; d: the table's bytes, (flags), CPT offset, kv | parents << 4 | reads-the-previous-node << 7 | shifts (or arities) of parents 1..3
+        const int ev = ev_cur;
+        const Pre mine = pre;
+        const LwSmallWords ahead_sd = nxt;
+        const LwSmallWords nn = steps[t + 2];
+        const int ev_nn = ev_topo[t + 2];
+        const bool late = (ahead_sd.d.w & 0x80u) != 0;   // t + 1 reads the row this position writes: that one byte is read again behind the store
+        Pre ahead;
+        fetch(ahead_sd, ahead);
+        const int kv = int(sd.d.w & 0xfu);
+        const uint64_t coff = sd.d.z;
+        const uint32_t a1 = (sd.d.w >> 8) & 0xfu, a2 = (sd.d.w >> 16) & 0xffu, a3 = sd.d.w >> 24;
+        // the row numbers of the thread's four samples as the four bytes of one register: mixed radix over the parents, first most significant
+        const uint32_t w0 = spread(mine.b0), w1 = spread(mine.b1), w2 = spread(mine.b2), w3 = spread(mine.b3);
         uint32_t rp;
         if (POW2) rp = ((((((w0 << a1) + w1) << a2) + w2) << a3)) + w3;
         else rp = ((w0 * a1 + w1) * a2 + w2) * a3 + w3;
+        my_tab[lane] = mine.q0;
+        my_tab[64 + lane] = mine.q1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         uint32_t row[S];
 #pragma unroll
         for (int r = 0; r < S; ++r) row[r] = (rp >> (8 * r)) & 0xffu;
-        const int kv = int(sd.d.w & 0xffu);
-        const uint64_t coff = sd.d.z;
         if (PAR == 0) {   // the step of this position and the next, evidence node or not
 #pragma unroll
             for (int r = 0; r < S; ++r) out[r] = xoshiro_next(rng[r]);
@@ -507,7 +542,7 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
             for (int r = 0; r < S; ++r) x[r] = cpt[coff + uint64_t(row[r]) * kv + ev];
 #pragma unroll
             for (int r = 0; r < S; ++r) w[r] *= x[r];
-            packed = uint32_t(ev) * 0x01010101u;
+            packed = uint32_t(ev) * 0x55u;
         } else {
             uint2 e[S];
 #pragma unroll
@@ -535,11 +570,21 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
 #pragma unroll
             for (int r = 0; r < S; ++r) {
                 if (REJECT && ev >= 0 && st[r] != ev) w[r] = 0.0;  // rejected (rejection_sampling.hpp:70-84)
-                packed |= uint32_t(st[r]) << (8 * r);
+                packed |= uint32_t(st[r]) << (2 * r);
             }
         }
         asm volatile("" : "+v"(c32));
-        *reinterpret_cast<lw_global_u32>(row_at(sd.c.x, sd.c.y) + c32) = packed;
+        *reinterpret_cast<lw_global_u8>(row_at(sd.c.x, sd.c.y) + c32) = uint8_t(packed);
+        if (late) {   // (~6 % of config 5's positions) parent j of the next position is this node: its byte as just stored
+            const uint32_t j = (ahead_sd.d.w >> 12) & 3u;
+            if (j == 0) ahead.b0 = packed;
+            else if (j == 1) ahead.b1 = packed;
+            else if (j == 2) ahead.b2 = packed;
+            else ahead.b3 = packed;
+        }
+        pre = ahead;
+        cur = ahead_sd; ev_cur = ev_nxt;
+        nxt = nn; ev_nxt = ev_nn;
     };
     int t = 0;
     for (; t + 1 < n; t += 2) {
@@ -644,6 +689,78 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_kernel(const uint8_t* __re
         if (i < kv && acc[i] != 0.0) atomicAdd(h + i, acc[i]);
 }
 
+// The same pass over a state matrix of TWO bits per state (LwArgs::packed2: four samples per byte): a 128-byte line of a lane's row is
+// 512 samples.  Per 16 samples one dword of states and sixteen wave-uniform weights (two scalar 64-byte loads, requested while the
+// dword before is accumulated).  s0 and the ranges are multiples of 512 samples, the row stride a multiple of 128 bytes.
+#ifndef BN_LW_HIST2_NQ
+#define BN_LW_HIST2_NQ 4
+#endif
+template <int KMAX>
+__global__ __launch_bounds__(kLwThreads) void lw_hist2_kernel(const uint8_t* __restrict__ states, const double* __restrict__ weights,
+                                                              const int32_t* __restrict__ k, const int64_t* __restrict__ node_off,
+                                                              double* __restrict__ hist, int32_t n, uint64_t stride, uint64_t n_valid,
+                                                              uint64_t range) {
+    const int v = blockIdx.x * kLwThreads + threadIdx.x;
+    const uint64_t s0 = uint64_t(blockIdx.y) * range;
+    const uint64_t s1 = s0 + range < n_valid ? s0 + range : n_valid;
+    if (s0 >= s1) return;
+    const bool live = v < n;
+    const uint8_t* rowp = states + uint64_t(live ? v : 0) * stride;
+    double acc[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) acc[i] = 0.0;
+    typedef double double8 __attribute__((ext_vector_type(8)));
+    typedef const double8 __attribute__((address_space(4))) * const_double8s;
+    constexpr int NQ = BN_LW_HIST2_NQ;    // 16-byte pieces per trip
+    constexpr uint64_t SEG = 64 * NQ;     // samples per trip
+    auto fetch = [&](uint4 (&q)[NQ], uint64_t at) {   // `at`: first sample of the trip
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) q[c] = *reinterpret_cast<const uint4*>(rowp + (at >> 2) + 16 * c);
+    };
+    auto consume = [&](const uint4 (&q)[NQ], uint64_t at) {
+        double8 wlo = ((const_double8s)(weights + at))[0], whi = ((const_double8s)(weights + at))[1];
+#pragma unroll
+        for (int ch = 0; ch < 4 * NQ; ++ch) {   // one dword = 16 samples
+            __builtin_amdgcn_sched_barrier(0);  // keep the scalar weight loads of a chunk with the chunk before it
+            const const_double8s wp = (const_double8s)(weights + at + 16 * (ch < 4 * NQ - 1 ? ch + 1 : 4 * NQ - 1));
+            const double8 nlo = wp[0], nhi = wp[1];
+            const uint4 qq = q[ch >> 2];
+            const uint32_t word = (ch & 3) == 0 ? qq.x : (ch & 3) == 1 ? qq.y : (ch & 3) == 2 ? qq.z : qq.w;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double wj = j < 8 ? wlo[j & 7] : whi[j & 7];
+                const uint32_t st = (word >> (2 * j)) & 3u;
+#pragma unroll
+                for (int i = 0; i < KMAX; ++i) masked_add<KMAX>(acc, i, wj, st);
+            }
+            wlo = nlo;
+            whi = nhi;
+        }
+    };
+    const uint64_t n_seg = (s1 - s0) / SEG;
+    uint4 qa[NQ], qb[NQ];
+    if (n_seg > 0) fetch(qa, s0);
+    for (uint64_t g = 0; g < n_seg; g += 2) {
+        fetch(qb, s0 + SEG * (g + 1 < n_seg ? g + 1 : n_seg - 1));
+        consume(qa, s0 + SEG * g);
+        if (g + 1 >= n_seg) break;
+        fetch(qa, s0 + SEG * (g + 2 < n_seg ? g + 2 : n_seg - 1));
+        consume(qb, s0 + SEG * (g + 1));
+    }
+    for (uint64_t s = s0 + SEG * n_seg; s < s1; ++s) {
+        const double wj = weights[s];
+        const uint32_t st = (uint32_t(rowp[s >> 2]) >> (2 * (s & 3))) & 3u;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) masked_add<KMAX>(acc, i, wj, st);
+    }
+    if (!live) return;
+    const int kv = k[v];
+    double* h = hist + node_off[v];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+        if (i < kv && acc[i] != 0.0) atomicAdd(h + i, acc[i]);
+}
+
 // Any arity: a block walks the nodes, thread = sample (4 per thread), LDS histogram per node.
 __global__ __launch_bounds__(kLwThreads) void lw_hist_wide_kernel(const uint8_t* __restrict__ states,
                                                                   const double* __restrict__ weights,
@@ -681,6 +798,7 @@ __global__ __launch_bounds__(kLwThreads) void lw_hist_wide_kernel(const uint8_t*
 // bn_lw_states: the [node][sample] byte matrix of the last batch, transposed to sample-major [sample][node] (what make_samples
 // counts joint patterns from, likelihood_weighting.hpp:62-118) through a 64 x 64 LDS tile: coalesced reads along the samples of a
 // node, coalesced writes along the nodes of a sample.  (One strided copy per NODE before: 10 000 copy commands on config 5.)
+template <bool PACKED2>   // PACKED2: four samples per byte in `states`, two bits each; `out` is one byte per state either way
 __global__ __launch_bounds__(256) void lw_transpose_kernel(const uint8_t* __restrict__ states, uint8_t* __restrict__ out, int32_t n,
                                                            uint64_t batch, uint64_t n_samples) {
     __shared__ uint8_t tile[64][65];
@@ -690,7 +808,10 @@ __global__ __launch_bounds__(256) void lw_transpose_kernel(const uint8_t* __rest
     for (int r = ty; r < 64; r += 4) {   // row r of the tile = node v0 + r, column tx = sample s0 + tx
         const int v = v0 + r;
         const uint64_t smp = s0 + tx;
-        tile[r][tx] = (v < n && smp < n_samples) ? states[uint64_t(v) * batch + smp] : uint8_t(0);
+        uint8_t x = 0;
+        if (v < n && smp < n_samples)
+            x = PACKED2 ? uint8_t((states[uint64_t(v) * batch + (smp >> 2)] >> (2 * (smp & 3))) & 3u) : states[uint64_t(v) * batch + smp];
+        tile[r][tx] = x;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {   // row r of the output tile = sample s0 + r, column tx = node v0 + tx
@@ -699,11 +820,12 @@ __global__ __launch_bounds__(256) void lw_transpose_kernel(const uint8_t* __rest
         if (v < n && smp < n_samples) out[smp * uint64_t(n) + v] = tile[tx][r];
     }
 }
-int launch_lw_transpose(const uint8_t* states, uint8_t* out, int32_t n, uint64_t batch, uint64_t n_samples, void* stream) {
+int launch_lw_transpose(const uint8_t* states, uint8_t* out, int32_t n, uint64_t batch, bool packed2, uint64_t n_samples, void* stream) {
     (void)hipGetLastError();
     if (n_samples == 0 || n <= 0) return 0;
     const dim3 grid(unsigned((n_samples + 63) / 64), unsigned((n + 63) / 64));
-    hipLaunchKernelGGL(lw_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, states, out, n, batch, n_samples);
+    if (packed2) hipLaunchKernelGGL(lw_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, states, out, n, batch, n_samples);
+    else hipLaunchKernelGGL(lw_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, states, out, n, batch, n_samples);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : int(e);
 }
@@ -748,15 +870,22 @@ int launch_lw_hist(const LwArgs& a, int blocks, void* stream) {
     } else if (a.n_valid > 0) {
         // enough (node block, sample range) pairs to fill the chip; ranges are multiples of 256 (a block walks its range 64 samples
         // at a time: with multiples of 1024 the reference's default of 10 000 samples on a 37-node network was 10 blocks of 16
-        // trips each, 70 us -- more than the sampling itself)
+        // trips each, 70 us -- more than the sampling itself); two-bit states: multiples of 512 (a trip is a 128-byte line)
         const unsigned xb = unsigned((a.n + kLwThreads - 1) / kLwThreads);
+        const uint64_t gran = a.packed2 ? 512 : 256;
         uint64_t ranges = (4096 + xb - 1) / xb;
         uint64_t range = (a.n_valid + ranges - 1) / ranges;
         range = std::max<uint64_t>(range, (a.n_valid + 1023) / 1024);  // ... and at most ~1 000 ranges: every range ends in atomics on the same bins
-        range = (range + 255) / 256 * 256;
+        range = (range + gran - 1) / gran * gran;
         const unsigned yb = unsigned((a.n_valid + range - 1) / range);
         const dim3 grid(xb, yb);
-        if (a.kmax <= 2)
+        if (a.packed2 && a.kmax <= 2)
+            hipLaunchKernelGGL(lw_hist2_kernel<2>, grid, dim3(kLwThreads), 0, st, a.states, a.weights, a.k, a.node_off,
+                               a.hist, a.n, a.batch, a.n_valid, range);
+        else if (a.packed2)
+            hipLaunchKernelGGL(lw_hist2_kernel<4>, grid, dim3(kLwThreads), 0, st, a.states, a.weights, a.k, a.node_off,
+                               a.hist, a.n, a.batch, a.n_valid, range);
+        else if (a.kmax <= 2)
             hipLaunchKernelGGL(lw_hist_kernel<2>, grid, dim3(kLwThreads), 0, st, a.states, a.weights, a.k, a.node_off,
                                a.hist, a.n, a.batch, a.n_valid, range);
         else if (a.kmax <= 4)
