@@ -1196,7 +1196,12 @@ static int run_mid(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to
 static bool dag_applies(const bn_engine* e) {
     if (!e->dag_ok || e->multisweep == 0 || e->dag_mode == 0) return false;
     if (e->dag_mode == 2) return true;
-    if (e->small_ok) return false;   // one workgroup with the state in LDS
+    // Networks the one-workgroup path (state in LDS) takes as well, us per query (profiles/r05_paths.json), that path / this one: one
+    // round of entry items (ALARM-sized) 48.6 / 68.7, Pearl's four nodes 19.3 / 24.5 -- but 8 x 8 grid, k = 4 (four rounds) 86.0 / 64.4,
+    // 60 nodes of mixed arity with <= 3 parents (three rounds) 72.3 / 64.6.  Chains and trees the resident tiles run in ONE block
+    // stay there (200-node chain: 71.9 resident, 81.6 this path, 113.6 one workgroup).
+    if (e->small_ok && e->small.re <= 2) return false;   // (two rounds: not measured; the one-workgroup path also keeps the reference's order for >= 3 parents)
+    if (e->small_ok && e->small.mmax <= 1 && e->resident_ok && e->grid_resident == 1) return false;
     // Arities below 4 (padded form), us per sweep, this path / the default before (scripts/time_dag_mixed.py): mixed arities 2-4 with
     // <= 3 parents 300 / 3 000 / 10 000 nodes 4.6 / 5.4, 5.7 / 7.1, 6.5 / 9.2 (item kernels); <= 4 parents, 10 000 nodes (723 k entries:
     // beyond the item kernels) 6.5 / 32.5; binary, <= 4 parents, 10 000 nodes 6.2 / 7.7; k = 3 grid 64 x 64 5.0 / 6.1 -- but k = 2 grid
@@ -1424,7 +1429,8 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
         report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip)", 64);
         return BN_ERR_STATE;
     };
-    if (e->dag_mode == 2 && (rc = attempt_dag()) != BN_ERR_STATE) return rc;   // forced: ahead of the one-workgroup path too
+    // ahead of the one-workgroup path: forced ("dag" 2), or a small network of several rounds of entry items (dag_applies)
+    if ((e->dag_mode == 2 || (e->small_ok && e->small_mode != 2)) && (rc = attempt_dag()) != BN_ERR_STATE) return rc;
     const bool small_pays = !(e->resident_ok && e->grid_resident == 1) ||
                             (e->small.rb == 1 && e->small.rc == 1 && (e->small.mmax >= 2 || (e->small.re == 1 && e->small.n <= 128)));
     if (e->small_ok && e->multisweep != 0 && (e->small_mode == 2 || (e->small_mode == 1 && small_pays))) {

@@ -18,7 +18,7 @@ import statistics
 import sys
 
 DOMINANT = {"grid316": ["bp_resident_kernel"], "grid316_launch": ["bp_sweep_kernel"], "dag10k": ["bp_dag_kernel"], "dag10k_launch": ["bp_sweep_kernel"],
-            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist_kernel"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"]}
+            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"]}
 
 
 def rows_of(path, pattern):

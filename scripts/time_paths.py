@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every execution path an engine is eligible for, forced one after another on the same staged query, against the path the engine
 picks by default and the one option "autotune" keeps: us per query (host wall clock, evidence staged) and us per sweep (device
-clock).  GPU box only:  python scripts/time_paths.py [--json profiles/r04_paths.json] [names...]"""
+clock).  GPU box only:  python scripts/time_paths.py [--json gpurun_out/r05_paths.json] [names...]"""
 import json
 import os
 import sys
@@ -89,6 +89,9 @@ def main():
               f"{r['autotuned']['us_per_query']:7.1f} us | " + "  ".join(f"{k}: {v['us_per_query']:.1f}" for k, v in r["paths"].items())
               + f" | default/best {r['default_over_best']:.2f} autotuned/best {r['autotuned_over_best']:.2f}", flush=True)
     if out_path:
+        import hashlib
+        from bayesiannetwork_amd import _lib
+        out["lib_sha256"] = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()   # the build these timings belong to (bench.py checks it)
         json.dump(out, open(out_path, "w"), indent=1)
 
 

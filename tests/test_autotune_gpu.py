@@ -106,3 +106,26 @@ def test_two_functors_on_one_device_from_two_threads(Engine, oracle_mod, capfd):
         assert err.count("gave up a bounded wait") == sum(1 for a in aborts if a > 0)   # one line per engine, however many events
     else:
         assert all(p == 2 for p in paths) and "gave up a bounded wait" not in err
+
+
+@pytest.mark.gpu
+def test_default_path_of_small_networks(bnlib, oracle_mod):
+    """Which one-launch path a SMALL network takes by default (bn_engine.cpp dag_applies; timings in profiles/r05_paths.json): one or
+    two rounds of entry items -> one workgroup, state in LDS (path 3: ALARM-sized); three or more with arities <= 4 -> the
+    register-resident DAG path (path 5: 8 x 8 grid, k = 4, 64 vs 86 us per query); a chain the resident tiles run in one block stays
+    there (path 2).  Whatever the path, the oracle's sweep count and marginals."""
+    import os
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.dsc import load_dsc
+    from bayesiannetwork_amd.engine import Engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alarm, _ = load_dsc(os.path.join(root, "tests", "golden", "alarm_shaped.dsc"))
+    for g, want_path, exact in ((alarm, 3, True), (synth.pearl(), 3, True), (synth.grid(8, 8, 4, seed=1), 5, True),
+                                (synth.grid(200, 1, 4, seed=5), 2, True), (synth.random_dag(30, 4, 12, [2, 3, 4, 3], seed=7), 3, True)):
+        ev = synth.random_evidence(g, 0.1, seed=3)
+        o = oracle_mod.bp_run(g, ev, 1e-6)
+        with Engine(g) as eng:
+            r = eng.bp_run(ev, 1e-6)
+            assert eng.last_path() == want_path, (g.name, eng.last_path())
+            assert r["sweeps"] == o["sweeps"]
+            assert np.array_equal(r["beliefs"], o["beliefs"]) if exact else np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12

@@ -49,6 +49,7 @@ def test_small_equals_oracle_bitwise(Engine, oracle_mod, name):
     from bayesiannetwork_amd import Evidence, synth
     g = dict(_nets())[name]
     with Engine(g) as eng:
+        eng.set_option("small", 2)   # this file is about the one-workgroup path: wherever eligible (by default a network of several rounds of entry items takes the register-resident DAG path, bn_engine.cpp dag_applies)
         assert eng.info("small_eligible") == 1 and 1 <= eng.info("small_waves") <= 16
         for ev, eps in ((Evidence.none(), 1e-6), (synth.random_evidence(g, 0.1, seed=3), 1e-9), (synth.random_evidence(g, 0.3, seed=5), 1e-3)):
             o = oracle_mod.bp_run(g, ev, eps, dump_msgs=True)
@@ -63,7 +64,7 @@ def test_small_equals_oracle_bitwise(Engine, oracle_mod, name):
         r0 = eng.bp_run(ev, 1e-6)
         assert eng.last_path() != 3 and r0["sweeps"] == o["sweeps"]
         assert np.allclose(r0["beliefs"], o["beliefs"], rtol=0, atol=1e-12)
-        eng.set_option("small", 1)
+        eng.set_option("small", 2)
         r = eng.bp_run(ev, 1e-6)
         assert eng.last_path() == 3 and np.array_equal(r["beliefs"], o["beliefs"])
         eng.set_option("multisweep", 0)      # "one launch per sweep" switches this path off as well
@@ -78,6 +79,7 @@ def test_small_soft_zero_evidence_and_caps(Engine, oracle_mod):
     soft = Evidence.from_dict(g, {3: np.full(int(k[3]), 1.0 / k[3]), 10: np.arange(1, int(k[10]) + 1, dtype=float), 20: 0})
     zero = Evidence.from_dict(g, {5: np.zeros(int(k[5]))})   # 0/0 -> NaN in the reference (no zero guard, :298-311)
     with Engine(g) as eng:
+        eng.set_option("small", 2)   # this file is about the one-workgroup path: wherever eligible (by default a network of several rounds of entry items takes the register-resident DAG path, bn_engine.cpp dag_applies)
         for ev, eps, cap in ((soft, 1e-9, 0), (zero, 1e-6, 6), (soft, 1e-12, 1), (soft, 1e-12, 2), (soft, 1e-12, 5)):
             o = oracle_mod.bp_run(g, ev, eps, cap, dump_msgs=True)
             r = eng.bp_run(ev, eps, cap)
@@ -99,6 +101,7 @@ def test_small_run_longer_than_one_launch(Engine, oracle_mod):
     g = synth.pearl()
     ev = synth.random_evidence(g, 0.0, seed=1)
     with Engine(g) as eng:
+        eng.set_option("small", 2)   # this file is about the one-workgroup path: wherever eligible (by default a network of several rounds of entry items takes the register-resident DAG path, bn_engine.cpp dag_applies)
         o = oracle_mod.bp_run(g, ev, 0.0, 70000, res_cap=70000)   # eps = 0: never converges, stopped at max_sweeps
         r = eng.bp_run(ev, 0.0, 70000)
         assert eng.last_path() == 3 and eng.bp_stats()["sweep_launches"] == 2
@@ -115,6 +118,7 @@ def test_small_batch_one_workgroup_per_set(Engine, oracle_mod):
     evs = [synth.random_evidence(g, f, seed=20 + q) for q, f in enumerate([0.0, 0.05, 0.1, 0.3, 0.02, 0.5, 0.2])]
     evs.append(Evidence.from_dict(g, {4: np.full(int(g.k[4]), 0.5)}))
     with Engine(g) as eng:
+        eng.set_option("small", 2)   # this file is about the one-workgroup path: wherever eligible (by default a network of several rounds of entry items takes the register-resident DAG path, bn_engine.cpp dag_applies)
         for sets, eps, cap in ((evs, 1e-6, 0), (evs[:3], 1e-12, 4), (evs[:1], 1e-6, 0), (evs * 8, 1e-9, 0), (evs * 32, 1e-6, 0)):   # up to 256 sets: one workgroup per CU
             out = eng.bp_run_batch(sets, eps, cap)
             assert eng.last_path() == 3 and eng.bp_stats()["sweep_launches"] == 1
@@ -156,6 +160,7 @@ def test_small_evidence_is_read_in_place_and_survives_path_changes(Engine, oracl
     ev, ev2 = synth.random_evidence(g, 0.15, seed=31), synth.random_evidence(g, 0.1, seed=32)
     o, o2 = oracle_mod.bp_run(g, ev, 1e-6), oracle_mod.bp_run(g, ev2, 1e-6)
     with Engine(g) as eng:
+        eng.set_option("small", 2)   # this file is about the one-workgroup path: wherever eligible (by default a network of several rounds of entry items takes the register-resident DAG path, bn_engine.cpp dag_applies)
         eng.bp_set_evidence(ev)
         for small, path in ((1, 3), (0, 0), (1, 3), (0, 0)):
             eng.set_option("small", small)
@@ -164,7 +169,7 @@ def test_small_evidence_is_read_in_place_and_survives_path_changes(Engine, oracl
             assert np.array_equal(eng.bp_beliefs(), o["beliefs"])   # (ALARM's tables take the ordered path of the tile kernels: same bits)
         eng.set_option("small", 0)
         eng.bp_set_evidence(ev2)            # staged while the tile path is selected, run on this one
-        eng.set_option("small", 1)
+        eng.set_option("small", 2)
         r = eng.bp_run_device(1e-6)
         assert eng.last_path() == 3 and np.array_equal(eng.bp_beliefs(), o2["beliefs"])
         # batches: staged for one path, run on the other
@@ -179,7 +184,7 @@ def test_small_evidence_is_read_in_place_and_survives_path_changes(Engine, oracl
             bel = eng.bp_beliefs_batch()
             for q, w in enumerate(want):
                 assert out["sweeps"][q] == w["sweeps"] and np.array_equal(bel[q], w["beliefs"]), (small_at_set, small_at_run, q)
-        eng.set_option("small", 1)
+        eng.set_option("small", 2)
         assert np.array_equal(eng.bp_run(ev2, 1e-6)["beliefs"], o2["beliefs"])
 
 
@@ -203,6 +208,7 @@ def test_small_degenerate_networks(Engine, oracle_mod):
         full = Evidence.from_dict(g, {v: int(v % g.k[v]) for v in range(g.n)})
         some = synth.random_evidence(g, 0.3, seed=2)
         with Engine(g) as eng:
+            eng.set_option("small", 2)   # this file is about the one-workgroup path: wherever eligible (by default a network of several rounds of entry items takes the register-resident DAG path, bn_engine.cpp dag_applies)
             assert eng.info("small_eligible") == 1, name
             for ev in (Evidence.none(), some, full):
                 o = oracle_mod.bp_run(g, ev, 1e-9, dump_msgs=True)
