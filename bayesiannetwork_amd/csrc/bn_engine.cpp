@@ -255,6 +255,7 @@ struct bn_engine {
     MidPlan mid;
     bool mid_ok = false;
     int mid_mode = 1;               // option "mid": 0 never, 1 where eligible and the resident tiles do not cover the network, 2 wherever eligible
+    int32_t small_cooldown = 0;     // (never set: the one-workgroup path waits for nobody; the path table wants a member)
     int32_t mid_cooldown = 0, mid_aborts = 0;   // runs left on the tile kernels after a grid wait gave up; how often that happened
     MidPart* d_m_parts = nullptr;
     SmallEntry* d_m_ent = nullptr;
@@ -1372,6 +1373,89 @@ static int autotune_paths(bn_engine* e, double eps) {
     return BN_OK;
 }
 
+// ---- the one-launch execution paths of a single query: one driver per path ------------------------------------------------------
+// wanted(): eligible AND chosen -- by the option ("small" / "mid" / "dag" / "multisweep": 0 never, 2 wherever eligible) or, at 1, by
+// the defaults measured on 20 networks (scripts/time_paths.py, profiles/r05_paths.json).  run(): BN_OK, BN_ERR_STATE (a bounded wait
+// gave up: the launch's workgroups were not all on the chip), or an error.  gave_up(): the path's bookkeeping of such an abort.
+struct PathDriver {
+    int id;                                             // bn_bp_last_path
+    bool (*wanted)(const bn_engine*);
+    int (*run)(bn_engine*, double eps, int32_t max_sweeps, double* copy_to);
+    int (*gave_up)(bn_engine*);                         // BN_OK: go on with the next path
+    void (*ran_ok)(bn_engine*);                         // may be null
+    int32_t bn_engine::*cooldown;                       // runs left before the path is tried again
+    bool reads_tile_evidence;                           // flush_evidence() first
+};
+
+// resident tiles pay on one block (no grid barrier at all) and on large networks (the CPT traffic saved outweighs the barrier); with 8
+// waves per block the crossover was measured at ~600 tiles (160x160 grid, 402 tiles: 8.2 vs 8.9 us per sweep; 200x200, 627: 9.5 vs
+// 9.2); at 4 waves per block (networks up to ~900 tiles: every wave has a SIMD of its own) it is faster than the launches from the
+// smallest multi-block network on (32x32 grid 7.2 vs 7.4-7.8, 128x128 7.7 vs 8.0, 200x200 8.7 vs 9.5).  Shards: the in-kernel exchange
+// wherever every rank's tiles qualify and the peers are mapped ("multisweep" 0 = per-sweep launches + one RCCL all-gather per sweep).
+static bool resident_wanted(const bn_engine* e) {
+    constexpr int64_t kResidentMinTiles = 600;
+    if (e->plan.nranks > 1) return e->shard_flow_ok && e->multisweep != 0;
+    const bool pays = e->grid_resident == 1 || e->resident_waves < kResidentWaves || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
+    return e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && pays));
+}
+static int resident_gave_up(bn_engine* e) {
+    ++e->resident_aborts;
+    if (e->plan.nranks > 1) {
+        // Sharded engines: NO unilateral fall-back inside the library.  A peer whose service block had already published the
+        // final verdict may have returned BN_OK: it would never enter the RCCL all-gather this rank would now wait in, and
+        // peers may still be storing into this rank's exchange region.  The caller's control plane decides for ALL ranks
+        // (multigpu.run_collective: all-reduce of the outcome, then "multisweep" 0 everywhere, or a collective retry);
+        // nothing of the engine's state has been touched.
+        const std::string why = g_err;
+        return fail(BN_ERR_STATE, "the in-kernel exchange gave up a bounded wait on this rank (" + why + "): every rank must switch together -- "
+                                  "set \"multisweep\" 0 on ALL ranks (RCCL exchange) or retry collectively");
+    }
+    // this run and the next few go down the per-sweep launches (8, 16, ... 1 024 runs), then the path is tried again
+    e->resident_cooldown = e->resident_backoff;
+    e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
+    report_abort_once(e, "the resident-tile kernel (bn_resident.hip)", e->resident_cooldown);
+    return BN_OK;
+}
+static void resident_ran_ok(bn_engine* e) { e->resident_backoff = 8; }
+
+// The one-workgroup path is taken wherever the network fits, except where the resident-tile kernel runs the network in ONE block and
+// was measured faster (scripts/experiments/small_vs_resident.py, us per sweep small / resident): chains and trees (one parent per
+// node) beyond ~128 nodes or one round of entry items (200-node chain, k = 4: 5.2 / 2.8; 100 nodes: 2.9 / 2.6), and networks that
+// need two rounds of accumulator or product items (16 x 16 grid, k = 2: 4.3 / 3.5).  With two parents per node the tile kernel's
+// 64-entry contraction costs more than the items (8 x 8 grid, k = 4: 4.2 / 5.1; 40-node DAG: 2.6 / 6.4).
+static bool small_wanted(const bn_engine* e) {
+    if (!e->small_ok || e->multisweep == 0 || e->small_mode == 0) return false;
+    if (e->small_mode == 2) return true;
+    return !(e->resident_ok && e->grid_resident == 1) ||
+           (e->small.rb == 1 && e->small.rc == 1 && (e->small.mmax >= 2 || (e->small.re == 1 && e->small.n <= 128)));
+}
+static int small_gave_up(bn_engine*) { return BN_OK; }   // (one workgroup: it waits for nobody)
+
+// the register-resident DAG path AHEAD of the one-workgroup path: forced ("dag" 2), or a small network of three or more rounds of
+// entry items (dag_applies has the measurements)
+static bool dag_first_wanted(const bn_engine* e) { return (e->dag_mode == 2 || (e->small_ok && e->small_mode != 2)) && dag_applies(e); }
+static bool dag_later_wanted(const bn_engine* e) { return !dag_first_wanted(e) && dag_applies(e); }
+static int dag_gave_up(bn_engine* e) {
+    ++e->dag_aborts;
+    e->dag_cooldown = 64;   // something else holds CUs: the other paths for a while
+    report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip)", 64);
+    return BN_OK;
+}
+static int mid_gave_up(bn_engine* e) {
+    ++e->mid_aborts;
+    e->mid_cooldown = 64;
+    report_abort_once(e, "the several-workgroup item kernel (bn_mid.hip)", 64);
+    return BN_OK;
+}
+
+static const PathDriver kOneLaunchPaths[] = {
+    {5, dag_first_wanted, run_dag, dag_gave_up, nullptr, &bn_engine::dag_cooldown, false},
+    {3, small_wanted, run_small, small_gave_up, nullptr, &bn_engine::small_cooldown, false},
+    {5, dag_later_wanted, run_dag, dag_gave_up, nullptr, &bn_engine::dag_cooldown, false},   // (its place by default: behind the one-workgroup path)
+    {4, mid_applies, run_mid, mid_gave_up, nullptr, &bn_engine::mid_cooldown, false},
+    {2, resident_wanted, run_resident, resident_gave_up, resident_ran_ok, &bn_engine::resident_cooldown, true},
+};
+
 static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out,
                            double* copy_to) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
@@ -1393,101 +1477,31 @@ static int run_device_impl(bn_engine* e, double eps, int32_t max_sweeps, int32_t
     ON_DEVICE(e);
     hipStream_t s = e->stream;
     int rc;
-    // resident tiles pay on one block (no grid barrier at all) and on large networks (the CPT traffic saved
-    // outweighs the ~4.5 us barrier); in between a per-sweep launch is faster (measured)
-    constexpr int64_t kResidentMinTiles = 600;  // measured crossover: 160x160 grid (402 tiles) 8.2 vs 8.9 us per sweep, 200x200 (627) 9.5 vs 9.2
-    // ... with 8 waves per block; at 4 (networks up to ~900 tiles: every wave has a SIMD of its own) it is faster than the
-    // launches from the smallest multi-block network on (32x32 grid 7.2 vs 7.4-7.8 us per sweep, 128x128 7.7 vs 8.0, 200x200 8.7 vs 9.5)
-    const bool resident_pays = e->grid_resident == 1 || e->resident_waves < kResidentWaves || int64_t(e->plan.tiles.size()) >= kResidentMinTiles;
     if (e->plan.nranks > 1) ++e->shard_run_seq;
-    // shards: the in-kernel exchange wherever every rank's tiles qualify and the peers are mapped ("multisweep" 0 = the
-    // per-sweep launches with one RCCL all-gather per sweep)
-    const bool try_resident = e->plan.nranks > 1 ? (e->shard_flow_ok && e->multisweep != 0)
-                                                 : (e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays)));
-    // The one-workgroup path is taken wherever the network fits, except where the resident-tile kernel runs the network in ONE
-    // block and was measured faster (scripts/experiments/small_vs_resident.py, us per sweep small / resident): chains and trees
-    // (one parent per node) beyond ~128 nodes or one round of entry items (200-node chain, k = 4: 5.2 / 2.8; 100 nodes: 2.9 /
-    // 2.6), and networks that need two rounds of accumulator or product items (16 x 16 grid, k = 2: 4.3 / 3.5).  With two
-    // parents per node the tile kernel's 64-entry contraction costs more than the items (8 x 8 grid, k = 4: 4.2 / 5.1;
-    // 40-node DAG: 2.6 / 6.4).  "small" 2 = wherever eligible.
-    // the register-resident DAG path (bn_dag.hip): after the item kernels by default, ahead of them when forced ("dag" 2)
-    bool dag_tried = false;
-    auto attempt_dag = [&]() -> int {   // BN_OK: the run is done; BN_ERR_STATE: not taken / aborted, go on with the next path
-        if (dag_tried || !dag_applies(e)) return BN_ERR_STATE;
-        dag_tried = true;
-        if (e->dag_cooldown > 0) { --e->dag_cooldown; return BN_ERR_STATE; }
-        const int r = run_dag(e, eps, max_sweeps, copy_to);
-        if (r == BN_OK) {
-            e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
-            if (residual_out) *residual_out = e->last_ctl.last_res;
-            return BN_OK;
+    // The one-launch paths, in the order of kOneLaunchPaths: the first one that wants the network (eligible, and chosen by the
+    // options / the measured defaults) and is not paused runs the query; one that gives up a bounded wait pauses itself and
+    // hands the query to the next; what none of them takes runs with one launch per sweep (below).
+    bool evidence_flushed = false;
+    for (const PathDriver& d : kOneLaunchPaths) {
+        if (!d.wanted(e)) continue;
+        if (d.reads_tile_evidence && !evidence_flushed) {   // the tile kernels read the evidence from their own buffers
+            if ((rc = flush_evidence(e))) return rc;
+            evidence_flushed = true;
         }
-        if (r != BN_ERR_STATE) return r;
-        ++e->dag_aborts;
-        e->dag_cooldown = 64;   // something else holds CUs: the other paths for a while
-        report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip)", 64);
-        return BN_ERR_STATE;
-    };
-    // ahead of the one-workgroup path: forced ("dag" 2), or a small network of several rounds of entry items (dag_applies)
-    if ((e->dag_mode == 2 || (e->small_ok && e->small_mode != 2)) && (rc = attempt_dag()) != BN_ERR_STATE) return rc;
-    const bool small_pays = !(e->resident_ok && e->grid_resident == 1) ||
-                            (e->small.rb == 1 && e->small.rc == 1 && (e->small.mmax >= 2 || (e->small.re == 1 && e->small.n <= 128)));
-    if (e->small_ok && e->multisweep != 0 && (e->small_mode == 2 || (e->small_mode == 1 && small_pays))) {
-        if ((rc = run_small(e, eps, max_sweeps, copy_to))) return rc;
-        e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-        if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
-        if (residual_out) *residual_out = e->last_ctl.last_res;
-        return BN_OK;
-    }
-    if ((rc = attempt_dag()) != BN_ERR_STATE) return rc;
-    // networks beyond one workgroup's LDS that the resident tiles do not cover: the same items over several workgroups (bn_mid.hip)
-    const bool try_mid = mid_applies(e);
-    if (try_mid && e->mid_cooldown > 0) --e->mid_cooldown;
-    else if (try_mid) {
-        rc = run_mid(e, eps, max_sweeps, copy_to);
+        int32_t& cooldown = e->*(d.cooldown);
+        if (cooldown > 0) { --cooldown; continue; }   // paused after a launch that gave up
+        rc = d.run(e, eps, max_sweeps, copy_to);
         if (rc == BN_OK) {
+            if (d.ran_ok) d.ran_ok(e);
             e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
             if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
             if (residual_out) *residual_out = e->last_ctl.last_res;
             return BN_OK;
         }
         if (rc != BN_ERR_STATE) return rc;
-        ++e->mid_aborts;
-        e->mid_cooldown = 64;   // something else holds CUs: the tile kernels for a while
-        report_abort_once(e, "the several-workgroup item kernel (bn_mid.hip)", 64);
+        if ((rc = d.gave_up(e)) != BN_OK) return rc;   // counters, pause, one line on stderr (a shard: an error, see resident_gave_up)
     }
-    if ((rc = flush_evidence(e))) return rc;  // the tile kernels read the evidence from their own buffers
-    if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
-    else if (try_resident) {
-        rc = run_resident(e, eps, max_sweeps, copy_to);
-        if (rc == BN_OK) {
-            e->resident_backoff = 8;
-            e->stats.total_ms =
-                std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-            if (sweeps_out) *sweeps_out = e->last_ctl.n_sweeps;
-            if (residual_out) *residual_out = e->last_ctl.last_res;
-            return BN_OK;
-        }
-        if (rc != BN_ERR_STATE) return rc;
-        if (e->plan.nranks > 1) {
-            // Sharded engines: NO unilateral fall-back inside the library.  A peer whose service block had already published the
-            // final verdict may have returned BN_OK: it would never enter the RCCL all-gather this rank would now wait in, and
-            // peers may still be storing into this rank's exchange region.  The caller's control plane decides for ALL ranks
-            // (multigpu.run_collective: all-reduce of the outcome, then "multisweep" 0 everywhere, or a collective retry);
-            // nothing of the engine's state has been touched.
-            ++e->resident_aborts;
-            const std::string why = g_err;
-            return fail(BN_ERR_STATE, "the in-kernel exchange gave up a bounded wait on this rank (" + why + "): every rank must switch together -- "
-                                      "set \"multisweep\" 0 on ALL ranks (RCCL exchange) or retry collectively");
-        }
-        // a bounded wait gave up (e.g. not every block became resident): this run and the next few go down the
-        // per-sweep launches, then the resident path is tried again
-        ++e->resident_aborts;
-        e->resident_cooldown = e->resident_backoff;
-        e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
-        report_abort_once(e, "the resident-tile kernel (bn_resident.hip)", e->resident_cooldown);
-    }
+    if (!evidence_flushed && (rc = flush_evidence(e))) return rc;
     e->last_path = 0;
     if (e->plan.nranks > 1 && !e->comm)
         return fail(BN_ERR_COMM, "the in-kernel exchange gave up and no RCCL communicator is set up to fall back on (bn_comm_init)");

@@ -761,7 +761,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm", "mid"], default="grid",
+    ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm", "mid", "batch", "dagbatch"], default="grid",
                     help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG; "
                          "lw = configs[4], likelihood weighting on the 10 k-node DAG")
     ap.add_argument("--samples", type=int, default=10000000, help="lw: weighted samples per step = per bn_lw_run call (BASELINE configs[4]: 10 M)")
@@ -805,6 +805,27 @@ def main():
                "roofline": leg["roofline"]}
         if "cpu_baseline" in leg:
             out["cpu_baseline"] = leg["cpu_baseline"]
+        print(json.dumps(out))
+        return
+    if a.workload in ("batch", "dagbatch"):
+        # 16 evidence sets per call (bn_bp_run_batch_device) on the headline grid / on BASELINE configs[1]: the legs `batch` and
+        # `config2_dag.batch` of the default line on their own, for the profile passes (scripts/profile_bench.sh)
+        g = synth.grid(a.rows, a.cols, 4, seed=2) if a.workload == "batch" else synth.random_dag(10000, 4, 64, 4, seed=1)
+        with Engine(g, device=local_rank) as eng:
+            b = time_batches(eng, g, a, torch, (16,))["B16"]
+            st = eng.bp_stats()
+        must_move = st["algorithmic_bytes_per_sweep"] - 8 * len(g.cpt)
+        floor_us = must_move / (HBM_PEAK_GBS * 1e9) * 1e6
+        out = {"metric": "edge-messages/sec to BP convergence, 16 evidence sets per call", "value": b["value"], "unit": "edge-messages/s", "n_gpus": 1,
+               "steps": max(10, a.steps // 2), "warmup": 3, "ms_per_step": b["ms_per_call"], "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{g.name}: 16 evidence sets per call ({a.evidence:g} evidence each), eps={a.eps:g}", "run_path": b["path"],
+                          "set_sweeps_per_call": b["set_sweeps_per_call"], "us_per_set_sweep": b["us_per_set_sweep"]},
+               "roofline": {"bound": "hbm", "achieved": must_move / (b["us_per_set_sweep"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": floor_us / b["us_per_set_sweep"], "traffic": None, "frac_resident": floor_us / b["us_per_set_sweep"],
+                            "frac_survey_8d": b["algorithmic_gbs"] / HBM_PEAK_GBS, "must_move_bytes_per_set_sweep": must_move,
+                            "floor_hbm_us": floor_us, "note": "frac = message + node-vector bytes of a set-sweep at the HBM peak / measured time per set-sweep "
+                                                              "(the CPTs stay on chip and serve every set)"}}
         print(json.dumps(out))
         return
     if a.workload == "alarm":
@@ -894,6 +915,12 @@ def main():
                                   "ms_per_query_dropin_cpp_run_prepared": gd.get("run_prepared_ms"),
                                   "ms_dropin_cpp_map_build": gd["map_build_ms"], "ms_dropin_cpp_map_destroy": gd["map_destroy_ms"],
                                   "dropin_cpp_matches_c_abi": gd.get("matches_c_abi")})
+            # SURVEY 8(d)'s `t` (evidence in -> marginals on the host) as a COMPILED caller of the C ABI sees it: the same bn_bp_run_view
+            # call, timed in C++ (the host_to_host leg above goes through Python / ctypes: ~25 us more per query)
+            if gd.get("c_abi_ms"):
+                v_cpp = g.messages_per_sweep() * gd["sweeps_per_query"] / (gd["c_abi_ms"] * 1e-3)
+                out["config"].update({"ms_per_step_host_to_host_cpp": gd["c_abi_ms"], "value_host_to_host_cpp": v_cpp,
+                                      "frac_host_to_host_cpp_survey_8d": v_cpp * t["stats"]["algorithmic_bytes_per_sweep"] / g.messages_per_sweep() / (HBM_PEAK_GBS * 1e9)})
         for key, fn in (("batch", leg_batch), ("config1_alarm", leg_alarm), ("mid_mixed300", leg_mid), ("config2_dag", leg_dag), ("config5_lw", leg_lw), ("grid2048", leg_grid2048)):
             try:
                 out[key] = fn(a, local_rank, torch)

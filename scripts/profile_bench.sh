@@ -6,7 +6,7 @@
 # Every pass puts the program itself after `--` (no env / shell hop); switches travel as exported
 # environment variables.  A pass that fails is recorded in failed_passes.txt and reported by the summary.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p $OUT
@@ -61,6 +61,17 @@ pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
 pmc write_lw WRITE_SIZE $B --workload lw --steps 2
 pmc sq_lw "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload lw --steps 2
 pmc sq2_lw "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload lw --steps 2
+# several evidence sets per call on the headline grid and on the 10 k-node DAG (bn_bp_run_batch_device, B = 16): bench.py --workload batch / dagbatch
+trace trace_batch_grid316 $B --workload batch --steps 10 --warmup 3
+pmc fetch_batch_grid316 FETCH_SIZE $B --workload batch --steps 4 --warmup 2
+pmc write_batch_grid316 WRITE_SIZE $B --workload batch --steps 4 --warmup 2
+pmc sq_batch_grid316 "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload batch --steps 4 --warmup 2
+pmc sq2_batch_grid316 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload batch --steps 4 --warmup 2
+trace trace_batch_dag10k $B --workload dagbatch --steps 10 --warmup 3
+pmc fetch_batch_dag10k FETCH_SIZE $B --workload dagbatch --steps 4 --warmup 2
+pmc write_batch_dag10k WRITE_SIZE $B --workload dagbatch --steps 4 --warmup 2
+pmc sq_batch_dag10k "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload dagbatch --steps 4 --warmup 2
+pmc sq2_batch_dag10k "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload dagbatch --steps 4 --warmup 2
 # the HBM-resident point (4M nodes)
 trace trace_grid2048 $B --rows 2048 --cols 2048 --steps 3 --warmup 1
 pmc fetch_grid2048 FETCH_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1

@@ -18,7 +18,8 @@ import statistics
 import sys
 
 DOMINANT = {"grid316": ["bp_resident_kernel"], "grid316_launch": ["bp_sweep_kernel"], "dag10k": ["bp_dag_kernel"], "dag10k_launch": ["bp_sweep_kernel"],
-            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"]}
+            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"],
+            "batch_grid316": ["bp_resident_kernel"], "batch_dag10k": ["bp_dag_kernel"]}
 
 
 def rows_of(path, pattern):
@@ -125,7 +126,7 @@ def main():
             for sq_dir in (os.path.join(src, "sq_lw"), os.path.join(src, "sq2_lw")):
                 if os.path.isdir(sq_dir):
                     for name in sorted({r["Counter_Name"] for r in rows_of(sq_dir, "*counter_collection.csv")}):
-                        v = counter_per_launch(sq_dir, "lw_hist_kernel", name)
+                        v = counter_per_launch(sq_dir, "lw_hist", name)
                         if v is not None:
                             hq[name] = v
             if hq:
