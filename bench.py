@@ -653,13 +653,17 @@ def leg_lw(a, local_rank, torch):
     # What bounds the sampler: not HBM (the CPTs are cache-resident) but the vector ALU and the row gathers.  The
     # bound reported is VALU ISSUE: vector instructions per second (SQ_INSTS_VALU of the committed counter pass, per sample, x the
     # measured sample rate) against what the chip can issue (CUs x 4 SIMDs x clock / 4 cycles per 64-lane instruction).
-    bytes_per_sample = d.n * 2 + d.n_edges   # state written, parents' states read, re-read by the histogram pass (informational)
+    bytes_per_sample = (d.n * 2 + d.n_edges) // (4 if small_kernel else 1)   # state written, parents' states read, re-read by the histogram pass (informational); two bits per state on the straight-line kernel
     peak_ginst = 256 * 4 * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_INST    # G wave-instructions / s
     roof = {"bound": "valu", "peak": peak_ginst, "unit": "G wave-instructions/s", "achieved": None, "frac": None,
             "kernel": ("lw_sample_small_kernel" if small_kernel else "lw_sample_kernel") + " + lw_hist_kernel", "hbm_algorithmic_bytes_per_sample": bytes_per_sample,
             "hbm_algorithmic_gbs": rate * bytes_per_sample / 1e9,
-            "note": "VALU-issue bound: SQ_INSTS_VALU per sample (committed SQ pass, sampling + histogram kernels) x measured samples/s over "
-                    "the chip's issue rate (DESIGN.md section 4.6)"}
+            "limiter": "latency: a wave's position waits for its parents' bytes from the Infinity Cache (4 / 6 / 8 waves per SIMD drew 73 / 93 / 105 M samples/s "
+                       "before the load pipeline); the histogram pass runs at ~80 % of its fp64 issue rate",
+            "peak_measured_integer_issue": 700.0,
+            "note": "frac = vector instructions issued per second (SQ_INSTS_VALU per sample of the committed SQ pass, sampling + histogram kernels, x measured "
+                    "samples/s) over one instruction per SIMD and four cycles at 2.4 GHz; on dependent integer code this chip sustains 700 G/s "
+                    "(scripts/experiments/valu_clock.hip).  What bounds the sampler is in `limiter` (DESIGN.md section 4.7)"}
     roof.update(profiled_traffic("lw"))
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
