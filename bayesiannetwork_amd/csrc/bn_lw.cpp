@@ -139,9 +139,12 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
                     ss.par[j] = uint64_t(node);
                     if (j > 0) shape |= (s.small_pow2 ? uint32_t(__builtin_ctz(kk)) : kk) << (8 * j);
                 }
-                if (t > 0)   // bit 7 of the arity byte: this position reads the row the position before it writes (its loads cannot be issued ahead)
-                    for (int32_t j = 0; j < m; ++j)
-                        if (p.in_idx[p.in_ptr[v] + j] == s.topo[t - 1]) shape |= 0x80u | (uint32_t(j) << 12);   // (which parent: bits 12-13, above a1)
+                // the sampling kernel loads a position's parents two positions ahead: a parent that is the node of the position before (bit 7,
+                // which one: bits 12-13) or of the one before that (bit 22, bits 20-21) is patched from that position's store instead
+                for (int32_t j = 0; j < m; ++j) {
+                    if (t > 0 && p.in_idx[p.in_ptr[v] + j] == s.topo[t - 1]) shape |= 0x80u | (uint32_t(j) << 12);
+                    if (t > 1 && p.in_idx[p.in_ptr[v] + j] == s.topo[t - 2]) shape |= 0x400000u | (uint32_t(j) << 20);
+                }
                 ss.own = uint64_t(v);
                 ss.coff = uint32_t(coff);
                 ss.tab[0] = uint32_t(row16[v]);   // (host copy: first row in d_thr16 and the table's bytes; the device copy holds the descriptor)

@@ -423,7 +423,7 @@ struct LwSmallWords {  // LwSmallStep as four 16-byte words
     uint4 a, b, c, d;
 };
 template <bool POW2, bool REJECT>
-__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_SMALL_WAVES, BN_LW_SMALL_WAVES))) void lw_sample_small_kernel(
+__global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_LW_SMALL_WAVES - (REJECT ? 1 : 0), BN_LW_SMALL_WAVES))) void lw_sample_small_kernel(
     const LwSmallWords* __restrict__ steps, const int32_t* __restrict__ ev_topo, const double* __restrict__ cpt,
     const unsigned long long* __restrict__ thr, const uint4* __restrict__ thr16, uint8_t* states, double* __restrict__ weights, int32_t n,
     uint64_t sample_base, uint64_t seed) {
@@ -475,57 +475,72 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
     //   * a ROOT has one row: its three thresholds are wave-uniform and come through a scalar load -- no table copy, no LDS.
     // (Round 4 copied 2 KB per position whatever the table's size -- ~10 TB/s of L2 traffic on config 5 -- and always loaded four
     // parents, the missing ones from an all-zero row.)
-    struct Pre { uint32_t b0, b1, b2, b3; uint4 q0, q1; };
-    // ALWAYS six loads, so that the number in flight is known when the code is compiled: a wave waits for "all but the six issued
-    // last" (s_waitcnt vmcnt(6)), i.e. for its own position's loads and not for the next one's.  With a number of loads that depends
-    // on the node the compiler has to wait for all of them, and the pipeline below overlaps nothing (measured: 68.3 ms either way).
-    // A missing parent is the all-zero row n; a table load beyond the table's end requests nothing.
-    auto fetch = [&](const LwSmallWords& d, Pre& p) {
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>((uint64_t(d.c.w) << 32) | d.c.z), 0, int(d.d.x), 0x00020000);   // (LwSmallStep::tab: base, bytes)
-        p.q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u), 0, 0));
-        p.q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u + 1024u), 0, 0));
+    struct Bytes { uint32_t b0, b1, b2, b3; };
+    struct Tabs { uint4 q0, q1; };
+    // ALWAYS the same loads per position, so that the number in flight is known when the code is compiled: a wave waits for "all but
+    // the six issued last" (s_waitcnt vmcnt(6)), i.e. for its own position's loads and not for the later positions'.  With a number of
+    // loads that depends on the node the compiler has to wait for all of them, and the pipeline overlaps nothing (measured: 68.3 ms either
+    // way).  A missing parent is the all-zero row n; a table load beyond the table's end requests nothing.
+    auto fetch_bytes = [&](const LwSmallWords& d, Bytes& p) {
         p.b0 = *reinterpret_cast<lw_global_u8>(row_at(d.a.x, d.a.y) + c32);
         p.b1 = *reinterpret_cast<lw_global_u8>(row_at(d.a.z, d.a.w) + c32);
         p.b2 = *reinterpret_cast<lw_global_u8>(row_at(d.b.x, d.b.y) + c32);
         p.b3 = *reinterpret_cast<lw_global_u8>(row_at(d.b.z, d.b.w) + c32);
     };
+    auto fetch_tabs = [&](const LwSmallWords& d, Tabs& p) {
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>((uint64_t(d.c.w) << 32) | d.c.z), 0, int(d.d.x), 0x00020000);   // (LwSmallStep::tab: base, bytes)
+        p.q0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u), 0, 0));
+        p.q1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(trs, int(lane * 16u + 1024u), 0, 0));
+    };
+    auto patch = [&](Bytes& p, uint32_t j, uint32_t byte) {
+        if (j == 0) p.b0 = byte;
+        else if (j == 1) p.b1 = byte;
+        else if (j == 2) p.b2 = byte;
+        else p.b3 = byte;
+    };
     // SOFTWARE PIPELINE (round 5).  With two bits per state the kernel is bound by LATENCY -- 4 / 6 / 8 waves per SIMD draw 73 / 93 /
     // 105 M samples/s, and a wave spends ~3 000 cycles per position, most of them waiting for its parents' bytes (a wave's rows of the
-    // last 64 nodes, times 8 192 waves, do not fit the L2: the reads come back from the Infinity Cache).  So the loads of position
-    // t + 1 are issued BEFORE position t is worked on; where t's node is one of t + 1's parents (LwSmallStep::shape bit 7, ~6 % of
-    // config 5's positions) that one byte is replaced, behind t's store, by the byte just stored.  (Rounds 4 and 5 measured the same pipeline SLOWER while the state
-    // matrix held a byte per state: the kernel was then bound by memory traffic, and more loads in flight only queued.)
-    // Descriptors are read two positions ahead; both arrays have three spare entries.
-    LwSmallWords cur = steps[0], nxt = steps[1];
-    int ev_cur = ev_topo[0], ev_nxt = ev_topo[1];
-    Pre pre;
-    fetch(cur, pre);
+    // last 64 nodes, times 8 192 waves, do not fit the L2: the reads come back from the Infinity Cache).  So a position's loads are
+    // issued AHEAD: its parents' bytes two positions before it is worked on, its table one position before.  Where a parent is the
+    // node of the position before or of the one before that (LwSmallStep::shape bits 7 and 22: ~6 % of config 5's positions each) the
+    // byte loaded ahead is stale: it is replaced, behind that position's store, by the byte just stored.  (Rounds 4 and 5 measured a
+    // one-position pipeline SLOWER while the state matrix held a byte per state: the kernel was then bound by memory traffic, and more
+    // loads in flight only queued.)  Descriptors are read three positions ahead; both arrays have three spare entries.
+    LwSmallWords cur = steps[0], nxt = steps[1], nn = steps[2];
+    int ev_cur = ev_topo[0], ev_nxt = ev_topo[1], ev_nn = ev_topo[2];
+    Bytes byt, byt1;   // the parents' bytes of `cur` and of `nxt`
+    Tabs tab0;         // the table lines of `cur`
+    fetch_bytes(cur, byt);
+    fetch_tabs(cur, tab0);
+    fetch_bytes(nxt, byt1);
     uint32_t out[S];   // the ++ outputs of the last even position's step: their top halves decide it, the bottom halves the odd position after it
 #pragma unroll
     for (int r = 0; r < S; ++r) out[r] = 0;
     auto position = [&](int t, auto par_c) {
         constexpr int PAR = decltype(par_c)::value;
         asm volatile("" : "+v"(c32));
-        const LwSmallWords sd = cur;   // a, b: the four parents' rows; c: own row, the table's base; d: the table's bytes, (flags), CPT offset, kv | parents << 4 | reads-the-previous-node << 7 | shifts (or arities) of parents 1..3
+        const LwSmallWords sd = cur;   // a, b: the four parents' rows; c: own row, the table's base; d: the table's bytes, (flags), CPT offset, kv | parents << 4 | a1 << 8 | a2 << 16 | a3 << 24 and the pipeline's flags
         const int ev = ev_cur;
-        const Pre mine = pre;
-        const LwSmallWords ahead_sd = nxt;
-        const LwSmallWords nn = steps[t + 2];
-        const int ev_nn = ev_topo[t + 2];
-        const bool late = (ahead_sd.d.w & 0x80u) != 0;   // t + 1 reads the row this position writes: that one byte is read again behind the store
-        Pre ahead;
-        fetch(ahead_sd, ahead);
+        const Bytes mine = byt;
+        const Tabs mine_tab = tab0;
+        const LwSmallWords sd1 = nxt, sd2 = nn;
+        const LwSmallWords sd3 = steps[t + 3];
+        const int ev3 = ev_topo[t + 3];
+        Tabs tab1;
+        Bytes byt2;
+        fetch_tabs(sd1, tab1);
+        fetch_bytes(sd2, byt2);
         const int kv = int(sd.d.w & 0xfu);
         const uint64_t coff = sd.d.z;
-        const uint32_t a1 = (sd.d.w >> 8) & 0xfu, a2 = (sd.d.w >> 16) & 0xffu, a3 = sd.d.w >> 24;
+        const uint32_t a1 = (sd.d.w >> 8) & 0xfu, a2 = (sd.d.w >> 16) & 0xfu, a3 = sd.d.w >> 24;
         // the row numbers of the thread's four samples as the four bytes of one register: mixed radix over the parents, first most significant
         const uint32_t w0 = spread(mine.b0), w1 = spread(mine.b1), w2 = spread(mine.b2), w3 = spread(mine.b3);
         uint32_t rp;
         if (POW2) rp = ((((((w0 << a1) + w1) << a2) + w2) << a3)) + w3;
         else rp = ((w0 * a1 + w1) * a2 + w2) * a3 + w3;
-        my_tab[lane] = mine.q0;
-        my_tab[64 + lane] = mine.q1;
+        my_tab[lane] = mine_tab.q0;
+        my_tab[64 + lane] = mine_tab.q1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t row[S];
@@ -575,16 +590,13 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         }
         asm volatile("" : "+v"(c32));
         *reinterpret_cast<lw_global_u8>(row_at(sd.c.x, sd.c.y) + c32) = uint8_t(packed);
-        if (late) {   // (~6 % of config 5's positions) parent j of the next position is this node: its byte as just stored
-            const uint32_t j = (ahead_sd.d.w >> 12) & 3u;
-            if (j == 0) ahead.b0 = packed;
-            else if (j == 1) ahead.b1 = packed;
-            else if (j == 2) ahead.b2 = packed;
-            else ahead.b3 = packed;
-        }
-        pre = ahead;
-        cur = ahead_sd; ev_cur = ev_nxt;
-        nxt = nn; ev_nxt = ev_nn;
+        // a later position that reads THIS node: the byte it loaded ahead is older than the store above
+        if (sd1.d.w & 0x80u) patch(byt1, (sd1.d.w >> 12) & 3u, packed);        // the next position's parent j
+        if (sd2.d.w & 0x400000u) patch(byt2, (sd2.d.w >> 20) & 3u, packed);    // ... the one after it
+        byt = byt1; byt1 = byt2; tab0 = tab1;
+        cur = sd1; ev_cur = ev_nxt;
+        nxt = sd2; ev_nxt = ev_nn;
+        nn = sd3; ev_nn = ev3;
     };
     int t = 0;
     for (; t + 1 < n; t += 2) {

@@ -29,6 +29,7 @@ class Engine:
         """rank/nranks/owner: shard `rank` of an edge-cut partition (bn_create_sharded);
         owner[v] in [0, nranks), None = balanced contiguous node ranges."""
         self.model = model
+        self._nbel = int(model.k.sum())   # doubles of a node-major result (summing k per call cost 28 us on the 99 856-node grid: 12 % of a query)
         self.rank, self.nranks = rank, nranks
         self._h = ctypes.c_void_p()
         L = _lib.lib()
@@ -79,7 +80,7 @@ class Engine:
         ev = evidence if evidence is not None else Evidence.none()
         sweeps = ctypes.c_int32(0)
         res = ctypes.c_double(0.0)
-        bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
+        bel = np.empty(self._nbel, dtype=np.float64)
         _lib.check(_lib.lib().bn_bp_run(self._h, ev.ne, _p(ev.node, ctypes.c_int32), _p(ev.off, ctypes.c_int32),
                                         _p(ev.val, ctypes.c_double), float(eps), int(max_sweeps),
                                         _p(bel, ctypes.c_double), ctypes.byref(sweeps), ctypes.byref(res)))
@@ -95,7 +96,7 @@ class Engine:
         _lib.check(_lib.lib().bn_bp_run_view(self._h, ev.ne, _p(ev.node, ctypes.c_int32), _p(ev.off, ctypes.c_int32),
                                              _p(ev.val, ctypes.c_double), float(eps), int(max_sweeps),
                                              ctypes.byref(view), ctypes.byref(sweeps), ctypes.byref(res)))
-        n = int(self.model.k.sum())
+        n = self._nbel
         bel = np.ctypeslib.as_array(view, shape=(n,)) if n else np.zeros(0)
         return {"beliefs": bel, "sweeps": sweeps.value, "residual": res.value}
 
@@ -123,7 +124,7 @@ class Engine:
         return {"sweeps": sweeps, "residual": res}
 
     def bp_beliefs_batch(self) -> np.ndarray:
-        bel = np.empty((self._n_sets, int(self.model.k.sum())), dtype=np.float64)
+        bel = np.empty((self._n_sets, self._nbel), dtype=np.float64)
         _lib.check(_lib.lib().bn_bp_copy_beliefs_batch(self._h, _p(bel, ctypes.c_double)))
         return bel
 
@@ -140,7 +141,7 @@ class Engine:
         return out
 
     def bp_beliefs(self) -> np.ndarray:
-        bel = np.empty(int(self.model.k.sum()), dtype=np.float64)
+        bel = np.empty(self._nbel, dtype=np.float64)
         _lib.check(_lib.lib().bn_bp_copy_beliefs(self._h, _p(bel, ctypes.c_double)))
         return bel
 
@@ -316,7 +317,7 @@ class Engine:
         ev_state = np.asarray(ev_state, dtype=np.int32)
         nodes = np.ascontiguousarray(np.nonzero(ev_state >= 0)[0], dtype=np.int32)
         states = np.ascontiguousarray(ev_state[nodes], dtype=np.int32)
-        hist = np.zeros(int(self.model.k.sum()), dtype=np.float64)
+        hist = np.zeros(self._nbel, dtype=np.float64)
         _lib.check(_lib.lib().bn_lw_run(self._h, nodes.size, _p(nodes, ctypes.c_int32), _p(states, ctypes.c_int32),
                                         ctypes.c_uint64(sample_begin), ctypes.c_uint64(n_samples),
                                         ctypes.c_uint64(seed), _p(hist, ctypes.c_double)))
@@ -327,7 +328,7 @@ class Engine:
         ev_state = np.asarray(ev_state, dtype=np.int32)
         nodes = np.ascontiguousarray(np.nonzero(ev_state >= 0)[0], dtype=np.int32)
         states = np.ascontiguousarray(ev_state[nodes], dtype=np.int32)
-        hist = np.zeros(int(self.model.k.sum()), dtype=np.float64)
+        hist = np.zeros(self._nbel, dtype=np.float64)
         _lib.check(_lib.lib().bn_lw_run_allreduce(self._h, nodes.size, _p(nodes, ctypes.c_int32),
                                                   _p(states, ctypes.c_int32), ctypes.c_uint64(sample_begin),
                                                   ctypes.c_uint64(n_samples_total), ctypes.c_uint64(seed),
@@ -339,7 +340,7 @@ class Engine:
         ev_state = np.asarray(ev_state, dtype=np.int32)
         nodes = np.ascontiguousarray(np.nonzero(ev_state >= 0)[0], dtype=np.int32)
         states = np.ascontiguousarray(ev_state[nodes], dtype=np.int32)
-        counts = np.zeros(int(self.model.k.sum()), dtype=np.float64)
+        counts = np.zeros(self._nbel, dtype=np.float64)
         drawn, acc = ctypes.c_uint64(0), ctypes.c_uint64(0)
         _lib.check(_lib.lib().bn_rs_run(self._h, nodes.size, _p(nodes, ctypes.c_int32), _p(states, ctypes.c_int32),
                                         ctypes.c_uint64(sample_begin), ctypes.c_uint64(n_accept),
