@@ -40,7 +40,7 @@ struct MidLds {
     uint32_t* term;     // [TT]
     uint16_t* clist;    // [CL]
     double* scratch;    // [waves][64] normalisation: a line per wave
-    unsigned long long* red;  // [2][16]
+    unsigned long long* red;  // [2][16] + [32]: what the last grid barrier collected
     unsigned* flag;     // [1] set by the polling thread: the grid wait gave up
 };
 
@@ -49,7 +49,7 @@ __device__ __forceinline__ MidLds mid_carve(char* base, const MidPart& pt) {
     double* d = reinterpret_cast<double*>(base);
     L.stg = d; d += pt.T;
     L.scratch = d; d += kSmallMaxWaves * kWave;
-    L.red = reinterpret_cast<unsigned long long*>(d); d += 2 * 16;
+    L.red = reinterpret_cast<unsigned long long*>(d); d += 2 * 16 + 2;   // [2][16] per-wave residuals, [32]: the barrier's maximum
     L.term = reinterpret_cast<uint32_t*>(d);
     char* c = reinterpret_cast<char*>(L.term + (((pt.TT > 0 ? pt.TT : 1) + 1) & ~1));
     L.clist = reinterpret_cast<uint16_t*>(c);
@@ -122,28 +122,55 @@ __device__ __forceinline__ double mid_normalize(double* line, int lane, int k, i
     return val / sum;
 }
 
-// Grid barrier number `gen` (1, 2, ...).  Every workgroup has a flag word on a line of its own: once the workgroup's stores are
-// out, it STORES the generation there (no atomic: arrivals on one counter are serialised in L2, ~30 ns each -- 2.5 us at 30
-// workgroups, ~5 us at 60-85 even in two levels), and its first wave reads all flags, a lane per workgroup, until none is behind.
-// Bounded: returns false when the wait gave up (or another workgroup has).
-__device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds& L, unsigned gen, int tid) {
+// Grid barrier number `gen` (1, 2, ...) that also carries maximum_difference (round 5; bn_resident.hip's granule form).  Once a
+// workgroup's stores are out, ONE thread stores a 16-byte granule {gen | residual high half}, {gen | residual low half} into a PACKED
+// table (16 bytes per workgroup; two tables, by the parity of gen: a workgroup already past this barrier writes its next granule
+// elsewhere than where a slower one still reads this one); its first wave reads all granules in one round trip -- lane l those of
+// workgroups l, l + 64, l + 128, l + 192 -- until every one carries `gen`, and reduces the residual: every workgroup gets the same
+// maximum and takes the same stop decision.  No atomics, no residual word of its own, nothing to reset between barriers.
+// (Rounds 3-4: a flag word per workgroup on a 128-byte line of its own + one atomic max per workgroup on a shared word + a read
+// of that word behind the barrier: with 213 workgroups -- `mixed10k` -- every poll touched 213 lines and the atomics queued on one.)
+// Bounded: returns false when the wait gave up (or another workgroup has).  *res_out: the maximum over all workgroups' `res_bits`.
+typedef unsigned mid_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds& L, unsigned gen, int tid, unsigned long long res_bits,
+                                                 unsigned long long* res_out) {
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
     __syncthreads();
     if (tid < kWave) {
-        unsigned* flags = a.bar + 32;
-        if (tid == 0) __hip_atomic_store(flags + 32 * blockIdx.x, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        static_assert(kMidMaxParts <= 4 * kWave, "a poll reads every workgroup's flag: lane l those of workgroups l, l + 64, l + 128, l + 192");
-        const int rounds = (a.nparts + kWave - 1) / kWave;   // uniform: the loads of a poll are issued back to back, one round trip
-        const int last = a.nparts - 1;
+        unsigned long long* tbl = reinterpret_cast<unsigned long long*>(a.bar + 32) + (gen & 1u) * (2 * kMidMaxParts);
+        if (tid == 0) {
+            __hip_atomic_store(tbl + 2 * blockIdx.x, ((unsigned long long)gen << 32) | unsigned(res_bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tbl + 2 * blockIdx.x + 1, ((unsigned long long)gen << 32) | unsigned(res_bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        static_assert(kMidMaxParts <= 4 * kWave, "a poll reads every workgroup's granule: lane l those of workgroups l, l + 64, l + 128, l + 192");
+        const int np = a.nparts;
+        const unsigned voff = unsigned(tid) * 16u;
         const unsigned long long t0 = wall_clock64();
         unsigned polls = 0, give_up = 0;
+        unsigned long long mx = 0;
         for (;;) {
-            // (a lane past the last workgroup looks at the last one's flag again)
-            unsigned v0 = __hip_atomic_load(flags + 32 * (tid < last ? tid : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v1 = gen, v2 = gen, v3 = gen;
-            if (rounds > 1) v1 = __hip_atomic_load(flags + 32 * (tid + kWave < last ? tid + kWave : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rounds > 2) v2 = __hip_atomic_load(flags + 32 * (tid + 2 * kWave < last ? tid + 2 * kWave : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rounds > 3) v3 = __hip_atomic_load(flags + 32 * (tid + 3 * kWave < last ? tid + 3 * kWave : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot(v0 < gen || v1 < gen || v2 < gen || v3 < gen) == 0ull) break;
+            mid_u32x4 r0, r1, r2, r3;   // words of a granule: {residual high half, generation, residual low half, generation}
+            if (np <= kWave)
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(voff), "s"(tbl) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %4, %5 sc1\n\t"
+                             "global_load_dwordx4 %1, %4, %5 offset:1024 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, %5 offset:2048 sc1\n\t"
+                             "global_load_dwordx4 %3, %4, %5 offset:3072 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
+            bool mine = true;
+            mx = 0;
+            auto take = [&](const mid_u32x4& r, int part) {
+                if (part < np) {
+                    mine = mine && r.y == gen && r.w == gen;
+                    const unsigned long long v = (unsigned long long)r.x << 32 | r.z;
+                    mx = v > mx ? v : mx;
+                }
+            };
+            take(r0, tid);
+            if (np > kWave) { take(r1, tid + kWave); take(r2, tid + 2 * kWave); take(r3, tid + 3 * kWave); }
+            if (__all(mine) != 0) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++polls & 255u) == 0) {
                 const unsigned ab = __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -154,9 +181,11 @@ __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds&
                 }
             }
         }
-        if (tid == 0) *L.flag = give_up;
+        mx = wave_umax64_dpp(mx);
+        if (tid == 0) { *L.flag = give_up; L.red[32] = mx; }
     }
     __syncthreads();
+    *res_out = L.red[32];
     return *L.flag == 0;
 }
 
@@ -254,7 +283,8 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
         }
     }
     unsigned gen = 1;
-    bool alive = mid_grid_barrier(a, L, gen, tid);
+    unsigned long long all_res = 0;
+    bool alive = mid_grid_barrier(a, L, gen, tid, 0ull, &all_res);
     // the evidence marks of this thread's pi(v) / lambda(v) items do not change during a run: read once (a byte from memory in
     // front of every store was a round trip on each phase's critical path)
     bool frz_b[ROUNDS], frz_c[ROUNDS];
@@ -277,8 +307,6 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
         double* npi_new = a.npi + (cur ^ 1) * a.N;
         double* nlam_new = a.nlam + (cur ^ 1) * a.N;
         double wres = 0.0;
-        // the residual word of the iteration after this one: its readers (iteration s - 2) are all behind the last barrier
-        if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.res + (s + 1) % 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- everything phase 2 needs of the OLD state is requested now (its previous values for the residual, the pi(v)
         // element a pi-message starts from, the first four children's lambda-messages): a trip to L2 costs about as much as a
         // whole phase here, and these travel while the entry items run
@@ -380,20 +408,18 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
             }
         }
         MID_STAMP(4);
-        // maximum_difference (:105-131): wave -> workgroup (LDS) -> one atomic max per workgroup -> grid barrier -> the same word
+        // maximum_difference (:105-131): wave -> workgroup (LDS) -> the workgroup's granule -> every workgroup reduces all granules
         const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
         if (lane == 0) L.red[cur * 16 + wave] = bits;
         __syncthreads();
-        if (wave == 0) {
-            const unsigned long long bm = wave_umax64_dpp<true>(L.red[cur * 16 + (lane & 15)]);
-            if (lane == 0 && bm != 0ull) __hip_atomic_fetch_max(a.res + s % 3, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        unsigned long long bm = 0;
+        if (wave == 0) bm = wave_umax64_dpp<true>(L.red[cur * 16 + (lane & 15)]);   // (thread 0, which publishes the granule, is in wave 0)
         MID_STAMP(5);
         ++gen;
-        alive = mid_grid_barrier(a, L, gen, tid);
+        unsigned long long mx = 0;
+        alive = mid_grid_barrier(a, L, gen, tid, bm, &mx);
         MID_STAMP(6);
         if (!alive) break;
-        const unsigned long long mx = __hip_atomic_load(a.res + s % 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double rr = __longlong_as_double((long long)mx);
         rr = rr < DBL_MIN ? DBL_MIN : rr;
         r_last = rr;

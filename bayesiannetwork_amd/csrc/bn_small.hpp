@@ -61,7 +61,8 @@ struct SmallPlan {
 // A network spread over several workgroups (bn_mid.hip): one SmallPlan per contiguous node range, message / node-vector indices
 // global (the state lives in memory, exchanged through L2 with agent-scope accesses and a grid barrier per iteration).
 constexpr int kMidMaxParts = 224;   // workgroups of one run: all co-resident, one per CU (the engine admits a plan only below 0.9 x CUs); <= 4 x 64 flags per barrier poll
-constexpr int kMidSyncBytes = 128 + 128 * kMidMaxParts;   // per state slot: the three residual words (8 bytes on), then one 128-byte line per workgroup: its barrier flag
+constexpr int kMidSyncBytes = 128 + 128 * kMidMaxParts;   // per state slot: 128 bytes (unused), then two granule tables of 16 bytes per workgroup (bn_mid.hip mid_grid_barrier); sized for the
+                                                          // flag-per-line form of rounds 3-4
 constexpr int kMidPreferredParts = 96;   // parts of at least 2 000 staged terms, about this many where the network is large enough (measured, bn_small_plan.cpp)
 struct MidPlan {
     bool ok = false;
@@ -144,8 +145,9 @@ struct MidArgs {
     double* npi;
     double* nlam;
     uint8_t* frz;
-    unsigned* bar;               // the slot's barrier words: workgroup p's flag at bar[32 + 32 p] (a line of its own), zeroed by the host before a launch
-    unsigned long long* res;     // [3] maximum_difference of iteration s in word s % 3, zeroed by the host before a launch
+    unsigned* bar;               // the slot's barrier words, zeroed by the host before a launch: from byte 128 on two tables (by the parity of the
+                                 // barrier's number) of one 16-byte granule per workgroup, {number | residual high half}, {number | residual low half}
+    unsigned long long* res;     // (unused since round 5: maximum_difference travels in the granules)
     unsigned* abort;             // page-locked host word
     unsigned long long timeout_ticks;
     // several evidence sets in one launch (gridDim.y): set blockIdx.y of the launch is set `set_base + blockIdx.y` of the batch

@@ -283,7 +283,7 @@ static void build_plan_of_range(const Plan& p, int v0, int v1, bool part, SmallP
     bytes += (size_t(std::max(ncl, 1)) * 2 + 7) & ~size_t(7);
     bytes += part ? size_t(kSmallMaxWaves) * kWave * 8 : (size_t(N) + 7) & ~size_t(7);  // (parts: a normalisation scratch line per wave)
     bytes += 2 * 16 * 8;  // the residual words: [iteration parity][wave]
-    if (part) bytes += 64;  // (the grid barrier's flag word)
+    if (part) bytes += 64 + 16;  // (the grid barrier's flag word; the maximum it collects)
     sp.lds_bytes = bytes;
     if (bytes > size_t(kSmallLdsBytes)) return no("state does not fit the LDS");
     sp.ok = true;
