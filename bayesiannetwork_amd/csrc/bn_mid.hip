@@ -132,11 +132,17 @@ __device__ __forceinline__ double mid_normalize(double* line, int lane, int k, i
 // of that word behind the barrier: with 213 workgroups -- `mixed10k` -- every poll touched 213 lines and the atomics queued on one.)
 // Bounded: returns false when the wait gave up (or another workgroup has).  *res_out: the maximum over all workgroups' `res_bits`.
 typedef unsigned mid_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds& L, unsigned gen, int tid, unsigned long long res_bits,
+// red_slot >= 0: the workgroup's residual is the maximum of the 16 per-wave words L.red[red_slot .. red_slot + 15], written by the waves
+// before the call (the block barrier that makes every wave's stores final also makes those words visible: ONE block barrier per
+// iteration in front of the granule, where the residual reduction used to have one of its own -- 0.76 us of an 7.9 us iteration);
+// red_slot < 0: no residual (the barrier behind the initial state).
+__device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds& L, unsigned gen, int tid, int red_slot,
                                                  unsigned long long* res_out) {
     __builtin_amdgcn_s_waitcnt(0);   // this wave's stores are acknowledged
     __syncthreads();
     if (tid < kWave) {
+        unsigned long long res_bits = 0;
+        if (red_slot >= 0) res_bits = wave_umax64_dpp<true>(L.red[red_slot + (tid & 15)]);
         unsigned long long* tbl = reinterpret_cast<unsigned long long*>(a.bar + 32) + (gen & 1u) * (2 * kMidMaxParts);
         if (tid == 0) {
             __hip_atomic_store(tbl + 2 * blockIdx.x, ((unsigned long long)gen << 32) | unsigned(res_bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
     }
     unsigned gen = 1;
     unsigned long long all_res = 0;
-    bool alive = mid_grid_barrier(a, L, gen, tid, 0ull, &all_res);
+    bool alive = mid_grid_barrier(a, L, gen, tid, -1, &all_res);
     // the evidence marks of this thread's pi(v) / lambda(v) items do not change during a run: read once (a byte from memory in
     // front of every store was a round trip on each phase's critical path)
     bool frz_b[ROUNDS], frz_c[ROUNDS];
@@ -411,13 +417,10 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
         // maximum_difference (:105-131): wave -> workgroup (LDS) -> the workgroup's granule -> every workgroup reduces all granules
         const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
         if (lane == 0) L.red[cur * 16 + wave] = bits;
-        __syncthreads();
-        unsigned long long bm = 0;
-        if (wave == 0) bm = wave_umax64_dpp<true>(L.red[cur * 16 + (lane & 15)]);   // (thread 0, which publishes the granule, is in wave 0)
         MID_STAMP(5);
         ++gen;
         unsigned long long mx = 0;
-        alive = mid_grid_barrier(a, L, gen, tid, bm, &mx);
+        alive = mid_grid_barrier(a, L, gen, tid, cur * 16, &mx);
         MID_STAMP(6);
         if (!alive) break;
         double rr = __longlong_as_double((long long)mx);

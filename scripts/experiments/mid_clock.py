@@ -12,16 +12,16 @@ sys.path.insert(0, ROOT)
 from bayesiannetwork_amd import _lib, synth  # noqa: E402
 from bayesiannetwork_amd.engine import Engine  # noqa: E402
 
-n, mp, seed = {"mixed80": (80, 3, 10), "mixed300": (300, 3, 12), "mixed1000": (1000, 3, 14)}[sys.argv[1] if len(sys.argv) > 1 else "mixed300"]
+n, mp, seed = {"mixed80": (80, 3, 10), "mixed300": (300, 3, 12), "mixed1000": (1000, 3, 14), "mixed10k": (10000, 3, 20)}[sys.argv[1] if len(sys.argv) > 1 else "mixed300"]
 g = synth.random_dag(n, mp, 16, [2, 3, 4, 3, 2, 4, 5], seed=seed)
-ev = synth.random_evidence(g, 0.05, seed=3)
+ev = synth.random_evidence(g, 0.01 if n >= 10000 else 0.05, seed=3)
 L = _lib.lib()
 with Engine(g) as e:
     e.bp_set_evidence(ev)
     for _ in range(3):
         r = e.bp_run_device(1e-6)
     assert e.last_path() == 4
-    buf = np.zeros((32, 8), dtype=np.uint64)
+    buf = np.zeros((224, 8), dtype=np.uint64)
     assert L.bn_debug_mid_clock(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     st = buf[: e.info("mid_parts")].astype(np.int64)
     names = ["loads requested + entry items", "block barrier", "accumulator items", "product items", "residual", "grid barrier"]
@@ -29,4 +29,5 @@ with Engine(g) as e:
     print(f"{n} nodes, {e.info('mid_parts')} workgroups, {r['sweeps']} sweeps, {e.bp_stats()['sweep_devclock_ms'] * 1e3 / r['sweeps']:.2f} us per sweep; iteration 3, thread 0 of each workgroup, ns: median / max")
     for i, nm in enumerate(names):
         print(f"  {nm:32s} {np.median(d[:, i]):7.0f} {d[:, i].max():7.0f}")
-    print("  start -> barrier released:", (st[:, 6] - st[:, 0]).tolist())
+    print("  start -> barrier released, ns: median", int(np.median(st[:, 6] - st[:, 0]) * 10), "max", int((st[:, 6] - st[:, 0]).max() * 10))
+    print("  arrival at the grid barrier after the first workgroup, ns: median", int(np.median(st[:, 5] - st[:, 5].min()) * 10), "max", int((st[:, 5] - st[:, 5].min()).max() * 10))
