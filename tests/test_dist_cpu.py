@@ -43,3 +43,20 @@ def test_run_collective_resolves_a_failed_in_kernel_run_on_every_rank(failing):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert f"COLLECTIVE_OK failing={failing} world=2" in p.stdout
+
+
+@pytest.mark.parametrize("failing,mode,fail_at", [("none", "ok", 0), ("1", "raise", 2), ("0", "raise", 7), ("1", "bits", 5), ("0", "bits", 12)])
+def test_verify_in_kernel_exchange_keeps_one_collective_schedule(failing, mode, fail_at):
+    """multigpu.verify_in_kernel_exchange (what bench.py --gpus N runs before it times the in-kernel exchange): when one rank's
+    verification run raises or returns other bits while its peer's succeeds, both ranks leave the loop after the same run with the
+    same answer and the same number of collectives issued (a barrier before and an all-reduce after every run) -- no hang, no
+    off-by-one collective.  World 2 over gloo, stand-in engines (tests/verify_worker.py)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "verify_worker.py"), failing, mode, str(fail_at)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert f"VERIFY_OK failing={failing} mode={mode} world=2" in p.stdout
