@@ -169,6 +169,46 @@ __device__ __forceinline__ void pick_states(const double* __restrict__ base, con
     }
 }
 
+// One draw against the three 16-bit thresholds of its row (ex = e0 | e1 << 16, ey = e2 | 0xffff << 16; h = the position's half of
+// `out`): count = how many of them h exceeds, nearest = min_i (e_i - h) mod 2^32, zero exactly when h ties with one.  The subtraction's
+// borrow IS "h > e_i": subtract-with-carry-out (operands picked out of their registers by SDWA selects, no extraction) followed by
+// add-with-carry.  Hand-written because the compiler, given the same arithmetic, parks every borrow in a scalar register pair and
+// extracts every half with an instruction of its own.  An SDWA instruction that writes VCC needs two wait states before a vector
+// instruction reads it (the compiler's own code keeps that distance): s_nop 1.
+template <int PAR>
+__device__ __forceinline__ void count_and_tie(uint32_t ex, uint32_t ey, uint32_t out, uint32_t& count, uint32_t& nearest) {
+    uint32_t d0, d1, d2, c;
+    if (PAR == 0) {
+        asm("v_sub_co_u32_sdwa %0, vcc, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %3, 0, 1, vcc\n\t"
+            "v_sub_co_u32_sdwa %1, vcc, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            "v_sub_co_u32_sdwa %2, vcc, %5, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(c)
+            : "v"(ex), "v"(ey), "v"(out)
+            : "vcc");
+    } else {
+        asm("v_sub_co_u32_sdwa %0, vcc, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %3, 0, 1, vcc\n\t"
+            "v_sub_co_u32_sdwa %1, vcc, %4, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"
+            "v_sub_co_u32_sdwa %2, vcc, %5, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc"
+            : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(c)
+            : "v"(ex), "v"(ey), "v"(out)
+            : "vcc");
+    }
+    count = c;
+    nearest = min(min(d0, d1), d2);
+}
+
 // The same selection for nodes with <= 256 CPT rows (kLwStepPacked), thresholds read from the WAVE'S OWN COPY of the node's table
 // in LDS.  What bounded the sampler (round 4, TCP counters: the vector L1 busy 97 % of the kernel, 160 tag look-ups per wave
 // and position, 110 of them the four row gathers -- 64 lanes x 16 bytes scattered over a 4 KB table are ~28 cache lines per
@@ -563,14 +603,18 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
 #pragma unroll
             for (int r = 0; r < S; ++r) e[r] = tab[row[r]];
             int st[S];
-            bool tie = false;
+            // state = how many thresholds the draw exceeds; a tie = some threshold equals it.  Both from the three differences
+            // e_i - h (count_and_tie): seven vector instructions per sample, where three compares for ">", two selects, an add and
+            // three compares for "==" (+ their scalar ORs) were nine vector and three scalar
+            uint32_t nearest = 0xffffffffu;
 #pragma unroll
             for (int r = 0; r < S; ++r) {
-                const uint32_t h = half_of<PAR>(out[r]);
-                const uint32_t e0 = e[r].x & 0xffffu, e1 = e[r].x >> 16, e2 = e[r].y & 0xffffu;
-                st[r] = (h > e0 ? 1 : 0) + (h > e1 ? 1 : 0) + (h > e2 ? 1 : 0);
-                tie = tie || h == e0 || h == e1 || h == e2;
+                uint32_t c, nr;
+                count_and_tie<PAR>(e[r].x, e[r].y, out[r], c, nr);
+                st[r] = int(c);
+                nearest = min(nearest, nr);
             }
+            const bool tie = nearest == 0u;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (the next position's copy comes after these reads)
             if (__any(tie)) {   // ~1 % of a wave's positions: the four draws again, against the full thresholds
 #pragma unroll
@@ -604,8 +648,10 @@ __global__ __launch_bounds__(kLwThreads) __attribute__((amdgpu_waves_per_eu(BN_L
         position(t + 1, std::integral_constant<int, 1>());
     }
     if (t < n) position(t, std::integral_constant<int, 0>());
+    // (the address from c32, whose value the loop keeps opaque: formed here, not before the loop and carried through it in scratch)
+    asm volatile("" : "+v"(c32));
 #pragma unroll
-    for (int r = 0; r < S; ++r) weights[col32 + r] = w[r];
+    for (int r = 0; r < S; ++r) weights[uint64_t(c32) * S + r] = w[r];
 }
 
 // acc[i] += w on the lanes whose state is i: the compare writes exec itself (v_cmpx), the fp64 add runs under it, exec is set back to
