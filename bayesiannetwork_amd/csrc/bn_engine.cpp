@@ -2243,6 +2243,53 @@ static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
     return BN_OK;
 }
 
+// ---- the one-launch paths of a batch (bn_bp_run_batch_device): the PathDriver table of single queries, batch forms ----------------
+// Which way a batch goes (measured, scripts/time_batch.py, us per set-sweep at the best batch size of either path): a small network runs one
+// workgroup per set; otherwise the register-resident DAG path and the several-workgroup item kernel where their single-query policy
+// chooses them; the resident tiles from ~900 tiles up -- per-sweep launches with one set per blockIdx.y share the launch latency among
+// the sets, which is what smaller networks pay for (128x128 grid: 1.8 vs 7.7 resident, 200x200: 5.0 vs 8.0); on larger ones the CPT
+// traffic the resident kernel saves weighs more (250x250: 9.1 vs 8.2, 316x316: 14.6 vs 8.6).  "multisweep" 2 forces the resident
+// kernel wherever eligible, 0 the launches; "dag" 2 puts the DAG path in front of the one-workgroup path, as for single queries.
+static bool batch_small_wanted(const bn_engine* e) {
+    return e->small_ok && e->small_mode != 0 && e->multisweep != 0 && e->batch.d_s_state != nullptr && !(e->dag_mode == 2 && e->dag_ok);
+}
+static bool batch_dag_wanted(const bn_engine* e) { return !batch_small_wanted(e) && dag_applies(e) && e->batch.ev_base != nullptr && e->plan.nranks == 1; }
+static bool batch_mid_wanted(const bn_engine* e) { return !batch_small_wanted(e) && mid_applies(e) && e->batch.ev_base != nullptr; }
+static bool batch_resident_wanted(const bn_engine* e) {
+    constexpr int64_t kResidentBatchMinTiles = 900;
+    if (batch_small_wanted(e)) return false;
+    return e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles));
+}
+static int run_batch_small_d(bn_engine* e, double eps, int32_t max_sweeps, double*) { return run_batch_small(e, eps, max_sweeps); }
+static int run_batch_dag_d(bn_engine* e, double eps, int32_t max_sweeps, double*) { return run_batch_dag(e, eps, max_sweeps); }
+static int run_batch_mid_d(bn_engine* e, double eps, int32_t max_sweeps, double*) { return run_batch_mid(e, eps, max_sweeps); }
+static int run_batch_resident_d(bn_engine* e, double eps, int32_t max_sweeps, double*) { return run_batch_resident(e, eps, max_sweeps); }
+static int batch_dag_gave_up(bn_engine* e) {
+    ++e->dag_aborts;
+    e->dag_cooldown = 64;
+    report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip, batch)", 64);
+    return BN_OK;
+}
+static int batch_mid_gave_up(bn_engine* e) {
+    ++e->mid_aborts;
+    e->mid_cooldown = 64;
+    report_abort_once(e, "the several-workgroup item kernel (bn_mid.hip, batch)", 64);
+    return BN_OK;
+}
+static int batch_resident_gave_up(bn_engine* e) {
+    ++e->resident_aborts;
+    e->resident_cooldown = e->resident_backoff;
+    e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
+    report_abort_once(e, "the resident-tile kernel (bn_resident.hip, batch)", e->resident_cooldown);
+    return BN_OK;
+}
+static const PathDriver kBatchPaths[] = {
+    {3, batch_small_wanted, run_batch_small_d, small_gave_up, nullptr, &bn_engine::small_cooldown, false},
+    {5, batch_dag_wanted, run_batch_dag_d, batch_dag_gave_up, nullptr, &bn_engine::dag_cooldown, false},
+    {4, batch_mid_wanted, run_batch_mid_d, batch_mid_gave_up, nullptr, &bn_engine::mid_cooldown, false},
+    {2, batch_resident_wanted, run_batch_resident_d, batch_resident_gave_up, resident_ran_ok, &bn_engine::resident_cooldown, true},
+};
+
 extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_sweeps, int32_t* sweeps_out, double* residual_out) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
     if (e->batch_on_dense && e->dense) {
@@ -2264,77 +2311,33 @@ extern "C" int bn_bp_run_batch_device(bn_engine* e, double eps, int32_t max_swee
     bt.sweeps.assign(bt.n_sets, 0);
     bt.residual.assign(bt.n_sets, 0.0);
     bt.beliefs_on_host = false;
+    // The one-launch paths of a batch, in the order of kBatchPaths (the same drivers' table as a single query's, with the batch forms of
+    // wanted / run): the first that wants the batch and is not paused runs every set; one that gives up a bounded wait pauses itself,
+    // and the whole batch is run again by the next; what none of them takes runs with one launch per sweep, one set per blockIdx.y.
     int rc = BN_ERR_STATE;
-    bool aborted = false;
-    // Which way a batch goes (measured, scripts/time_batch.py, us per set-sweep at the best batch size of either path):
-    // per-sweep launches with one set per blockIdx.y share the launch latency among the sets, which is what networks
-    // up to ~900 tiles pay for (128x128 grid: 1.8 vs 7.7 resident, 200x200: 5.0 vs 8.0); on larger ones the CPT
-    // traffic the resident kernel saves weighs more (250x250: 9.1 vs 8.2, 316x316: 14.6 vs 8.6).
-    // "multisweep" = 2 forces the resident kernel wherever eligible, 0 the launches.
-    constexpr int64_t kResidentBatchMinTiles = 900;
-    const bool resident_pays = int64_t(e->plan.tiles.size()) >= kResidentBatchMinTiles;
-    const bool try_resident = e->resident_ok && (e->multisweep == 2 || (e->multisweep == 1 && resident_pays));
-    // ("dag" = 2 puts the register-resident DAG path in front of the one-workgroup path, as for single queries)
-    const bool batch_small = e->small_ok && e->small_mode != 0 && e->multisweep != 0 && bt.d_s_state != nullptr && !(e->dag_mode == 2 && e->dag_ok);
-    bool batch_dag = !batch_small && dag_applies(e) && bt.ev_base != nullptr && e->plan.nranks == 1;
-    if (batch_dag && e->dag_cooldown > 0) { --e->dag_cooldown; batch_dag = false; }
-    if (batch_dag) {
-        rc = run_batch_dag(e, eps, max_sweeps);
-        if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
-        if (rc == BN_ERR_STATE) {   // a grid wait gave up: the whole batch again on the other paths
-            ++e->dag_aborts;
-            e->dag_cooldown = 64;
-            report_abort_once(e, "the register-resident DAG kernel (bn_dag.hip, batch)", 64);
-            batch_dag = false;
-            bt.sweeps.assign(bt.n_sets, 0);
-            bt.residual.assign(bt.n_sets, 0.0);
-        } else {
-            bt.have_run = true;
-            e->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-            for (int32_t q = 0; q < bt.n_sets; ++q) {
-                if (sweeps_out) sweeps_out[q] = bt.sweeps[q];
-                if (residual_out) residual_out[q] = bt.residual[q];
-            }
-            return BN_OK;
+    bool evidence_flushed = false, restage = false;
+    for (const PathDriver& d : kBatchPaths) {
+        if (!d.wanted(e)) continue;
+        if (d.reads_tile_evidence && !evidence_flushed) {   // the tile kernels read the sets' evidence from their own buffers
+            if ((rc = flush_batch_evidence(e))) return rc;
+            evidence_flushed = true;
         }
-    }
-    bool batch_mid = !batch_small && mid_applies(e) && bt.ev_base != nullptr;
-    if (batch_mid && e->mid_cooldown > 0) { --e->mid_cooldown; batch_mid = false; }
-    if (batch_mid) {
-        rc = run_batch_mid(e, eps, max_sweeps);
-        if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
-        if (rc == BN_ERR_STATE) {   // a grid wait gave up: the whole batch again on the tile kernels
-            ++e->mid_aborts;
-            e->mid_cooldown = 64;
-            report_abort_once(e, "the several-workgroup item kernel (bn_mid.hip, batch)", 64);
-            batch_mid = false;
-            bt.sweeps.assign(bt.n_sets, 0);
-            bt.residual.assign(bt.n_sets, 0.0);
+        int32_t& cooldown = e->*(d.cooldown);
+        if (cooldown > 0) { --cooldown; rc = BN_ERR_STATE; continue; }   // paused after a launch that gave up
+        rc = d.run(e, eps, max_sweeps, nullptr);
+        if (rc == BN_OK) {
+            if (d.ran_ok) d.ran_ok(e);
+            break;
         }
-    }
-    if (!batch_small && !batch_mid && (rc = flush_batch_evidence(e))) return rc;
-    if (!batch_mid) rc = BN_ERR_STATE;
-    if (batch_small) {
-        if ((rc = run_batch_small(e, eps, max_sweeps))) return rc;
-    } else if (batch_mid) {
-        // done above
-    } else if (try_resident && e->resident_cooldown > 0) --e->resident_cooldown;  // paused after an aborted launch
-    else if (try_resident) {
-        rc = run_batch_resident(e, eps, max_sweeps);
-        if (rc != BN_OK && rc != BN_ERR_STATE) return rc;
-        if (rc == BN_ERR_STATE) {
-            ++e->resident_aborts;
-            e->resident_cooldown = e->resident_backoff;
-            e->resident_backoff = std::min(e->resident_backoff * 2, 1024);
-            report_abort_once(e, "the resident-tile kernel (bn_resident.hip, batch)", e->resident_cooldown);
-            aborted = true;
-        } else {
-            e->resident_backoff = 8;
-        }
+        if (rc != BN_ERR_STATE) return rc;
+        if (int g = d.gave_up(e)) return g;   // counters, pause, one line on stderr
+        bt.sweeps.assign(bt.n_sets, 0);       // the whole batch again on the next path
+        bt.residual.assign(bt.n_sets, 0.0);
+        restage = restage || d.reads_tile_evidence;
     }
     if (rc != BN_OK) {
-        if (aborted) {
-            // marks / vectors possibly half-written by the aborted launch: apply every set's evidence again
+        if (restage) {
+            // marks / vectors possibly half-written by an aborted launch of the tile kernels: apply every set's evidence again
             std::vector<int32_t> ne = bt.ne, ev_node = bt.ev_node, ev_off = bt.ev_off;
             std::vector<double> ev_val = bt.ev_val;
             rc = bn_bp_set_evidence_batch(e, int32_t(ne.size()), ne.data(), ev_node.data(), ev_off.data(), ev_val.data());
