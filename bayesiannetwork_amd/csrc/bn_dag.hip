@@ -95,9 +95,15 @@ __device__ __forceinline__ int dag_verdict_of(const DagArgs& a, double r, int n_
 // with several sets per launch to the next set's sweep; the wave that completes the count publishes the block's granules.  (With
 // a __syncthreads here every set-sweep of a batch cost the block's SLOWEST wave, 5.9 us on config 2; the waves with light tiles
 // now run ahead through the other sets and wait once per set, where the verdict is needed.)
-template <bool BATCH>
-__device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it, int s, double wres, int lane, int wave) {
+// the wave's share of maximum_difference as a wave-uniform bit pattern (non-negative doubles order like their bits)
+__device__ __forceinline__ unsigned long long dag_wave_residual(double wres) {
     const unsigned long long bits = wave_umax64_dpp((unsigned long long)__double_as_longlong(wres));
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(bits)), hi = __builtin_amdgcn_readfirstlane(unsigned(bits >> 32));
+    return (unsigned long long)hi << 32 | lo;
+}
+template <bool BATCH>
+__device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it, int s, unsigned long long bits, int lane, int wave) {
+    // bits: the wave's share of maximum_difference, dag_wave_residual(wres)
     if (lane == 0) sh.slot[wave] = bits;   // (in front of the drain: the LDS write passes while the stores are waited for)
     DSTAMP(3, it);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have reached memory
@@ -149,21 +155,10 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync,
     DSTAMP(5, it);
 }
 
-// lane l requests the pairs of blocks l, l + 64, l + 128, l + 192 back to back (one round trip) -- bn_resident.hip sweep_granules
-__device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc,
-                                                   unsigned own16, int& late) {
-    static_assert(kDagMaxBlocks == 4 * kWave, "four pairs per lane cover the table");
-    const unsigned voff = unsigned(lane) * 16u;
-    dag_u32x4 r0, r1, r2, r3;
-    if (nb <= kWave)
-        asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(voff), "s"(tbl) : "memory");
-    else
-        asm volatile("global_load_dwordx4 %0, %4, %5 sc1\n\t"
-                     "global_load_dwordx4 %1, %4, %5 offset:1024 sc1\n\t"
-                     "global_load_dwordx4 %2, %4, %5 offset:2048 sc1\n\t"
-                     "global_load_dwordx4 %3, %4, %5 offset:3072 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
+// what a lane's (up to) four granule pairs say -- of blocks lane, lane + 64, lane + 128, lane + 192: true when all of them carry
+// generation `gen`; acc = the largest residual among them, late = the latest arrival after this block's own (ticks)
+__device__ __forceinline__ bool dag_take_granules(const dag_u32x4& r0, const dag_u32x4& r1, const dag_u32x4& r2, const dag_u32x4& r3, int lane, int nb,
+                                                  unsigned gen, unsigned long long& acc, unsigned own16, int& late) {
     bool mine = true;
     acc = 0;
     late = 0;
@@ -179,6 +174,38 @@ __device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl
     take(r0, lane);
     if (nb > kWave) { take(r1, lane + kWave); take(r2, lane + 2 * kWave); take(r3, lane + 3 * kWave); }
     return mine;
+}
+// lane l requests the pairs of blocks l, l + 64, l + 128, l + 192 back to back (one round trip) -- bn_resident.hip sweep_granules
+__device__ __forceinline__ bool dag_sweep_granules(const unsigned long long* tbl, int lane, int nb, unsigned gen, unsigned long long& acc,
+                                                   unsigned own16, int& late) {
+    static_assert(kDagMaxBlocks == 4 * kWave, "four pairs per lane cover the table");
+    const unsigned voff = unsigned(lane) * 16u;
+    dag_u32x4 r0, r1 = {0u, 0u, 0u, 0u}, r2 = r1, r3 = r1;
+    if (nb <= kWave)
+        asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(voff), "s"(tbl) : "memory");
+    else
+        asm volatile("global_load_dwordx4 %0, %4, %5 sc1\n\t"
+                     "global_load_dwordx4 %1, %4, %5 offset:1024 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, %5 offset:2048 sc1\n\t"
+                     "global_load_dwordx4 %3, %4, %5 offset:3072 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
+    return dag_take_granules(r0, r1, r2, r3, lane, nb, gen, acc, own16, late);
+}
+// every block has arrived at the barrier of iteration `it` of a set: block 0 files the residual, the verdict goes out to the block's waves
+template <bool BATCH>
+__device__ __forceinline__ void dag_publish_verdict(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it, unsigned long long m_lane, int late,
+                                                    bool ok, int lane) {
+    {   // the latest arrival of this iteration, relative to this block's: the next iteration's prediction
+        const int mx = int(wave_umax32_dpp(unsigned(late)));   // (late >= 0)
+        if (lane == 0) sh.skew_ticks = ok ? (mx < 400 ? mx : 400) : 0;   // (bounded: 4 us)
+    }
+    const unsigned long long m = wave_umax64_dpp(m_lane);
+    if (lane == 0) {
+        if (blockIdx.x == 0 && ok) __hip_atomic_store(&sync->res[it], m, RLX_AGENT);
+        sh.verdict = ok ? dag_verdict_of(a, dag_residual_of(m), a.sweep_begin + it + 1) : kDagAbort;
+        if constexpr (BATCH) __hip_atomic_store(&sh.ver_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 }
 
 // Several sets per launch (BATCH): no block barrier here either.  The FIRST wave of the block to need this barrier's verdict does the
@@ -226,16 +253,7 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, Da
             }
             for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
         }
-        {   // the latest arrival of this iteration, relative to this block's: the next iteration's prediction
-            const int mx = int(wave_umax32_dpp(unsigned(late)));   // (late >= 0)
-            if (lane == 0) sh.skew_ticks = ok ? (mx < 400 ? mx : 400) : 0;   // (bounded: 4 us)
-        }
-        m = wave_umax64_dpp(m);
-        if (lane == 0) {
-            if (blockIdx.x == 0 && ok) __hip_atomic_store(&sync->res[it], m, RLX_AGENT);
-            sh.verdict = ok ? dag_verdict_of(a, dag_residual_of(m), a.sweep_begin + it + 1) : kDagAbort;
-            if constexpr (BATCH) __hip_atomic_store(&sh.ver_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        dag_publish_verdict<BATCH>(a, sync, sh, it, m, late, ok, lane);
     }
     if constexpr (!BATCH) {
         __syncthreads();
@@ -260,10 +278,22 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, Da
 // of set B, arrival at B's, ... -- so the ~3.4 us a barrier needs to complete are spent on the other sets' sweeps, and ONE set of CPT
 // registers serves them all.  Every set has its own state, marks, barrier words, residual history and control block, and stops
 // on the sweep its single run stops on (same arithmetic: same bits).
-template <bool BATCH, class Phase, class Finalize>
-__device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int lane, int wave, Phase&& phase, Finalize&& finalize) {
+// With several sets the sweep of a set is cut in two: request(q, s) asks for its inputs, finish(q, s) does the rest and returns the
+// wave's residual.  The arrival of the PREVIOUS set-turn is published between the two: its `s_waitcnt vmcnt(0)` then covers that
+// turn's stores and this turn's loads together -- a set-turn costs the wave max(store drain, load round trip) + arithmetic instead
+// of their sum.  (The barrier this turn waits on belongs to an earlier turn than the one whose arrival is still held back, as long
+// as another set is live; with one set left the arrival goes out before the wait.)  What was tried on top of this and dropped --
+// looks ahead at the next turns' barriers and inputs fetched a turn ahead through LDS -- is in EXPERIMENTS.md R5.6.
+template <bool BATCH, class Request, class Finish, class Finalize>
+__device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int lane, int wave, Request&& request, Finish&& finish, Finalize&& finalize) {
     unsigned live = BATCH ? a.set_mask : 1u;
     const int n_sets = BATCH ? a.n_sets : 1;
+    int held_q = -1, held_it = 0, held_s = 0;   // several sets: the set-turn whose arrival is still to be published
+    unsigned long long held_bits = 0;
+    auto publish_held = [&]() {
+        if (held_q >= 0) dag_arrive<BATCH>(a, a.sync + held_q, sh.set[held_q], held_it, held_s, held_bits, lane, wave);
+        held_q = -1;
+    };
     for (int it = 0; it <= a.budget && live != 0; ++it) {  // the pass it == budget only collects the verdicts
         const int s = a.sweep_begin + it;
         for (int q = 0; q < n_sets; ++q) {
@@ -273,11 +303,15 @@ __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int l
             int v = kDagGoOn;
             DSTAMP(0, it);
             if (it > 0) {
+                if constexpr (BATCH) {
+                    if (held_q == q) publish_held();   // the only set left: its own arrival is what this wait waits for
+                }
                 v = dag_wait<BATCH>(a, sync, ss, it - 1);
                 if (v == kDagAbort) return false;
             }
             DSTAMP(1, it);
             if (v != kDagGoOn || it == a.budget) {
+                if constexpr (BATCH) publish_held();
                 const int done = v != kDagGoOn ? v : 0;
                 finalize(q, s, done);
                 if (blockIdx.x == 0 && wave == 0) {  // report: residual history, outcome
@@ -298,11 +332,19 @@ __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int l
                 live &= ~(1u << q);
                 continue;
             }
-            const double wres = phase(q, s);
-            dag_arrive<BATCH>(a, sync, ss, it, s, wres, lane, wave);
+            request(q, s);
+            DSTAMP(9, it);
+            if constexpr (BATCH) publish_held();
+            const unsigned long long bits = dag_wave_residual(finish(q, s));
+            if constexpr (BATCH) {
+                held_q = q; held_it = it; held_s = s; held_bits = bits;
+            } else {
+                dag_arrive<BATCH>(a, sync, ss, it, s, bits, lane, wave);
+            }
             DSTAMP(6, it);
         }
     }
+    if constexpr (BATCH) publish_held();
     return true;
 }
 
@@ -361,10 +403,12 @@ struct DagChildU {
             cpt[2 * q] = x.x; cpt[2 * q + 1] = x.y;
         }
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+    // the inputs of the sweep in hand: requested by request(), consumed by finish() -- with several evidence sets per launch the
+    // previous set's stores drain while these loads are under way (dag_drive)
+    double pim[M > 0 ? M : 1][K], lold[M > 0 ? M : 1][K], lav[K], pold[K];
+    __device__ __forceinline__ void request(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
         const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
-        const int cur = s & 1, nxt = cur ^ 1;
-        double pim[M > 0 ? M : 1][K], lold[M > 0 ? M : 1][K], lav[K], pold[K];
+        const int cur = s & 1;
 #pragma unroll
         for (int j = 0; j < M; ++j)
 #pragma unroll
@@ -382,6 +426,13 @@ struct DagChildU {
             dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), lav);
             dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), pold);
         }
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        request(a, rs, s);
+        return finish(a, rs, s, xch);
+    }
+    __device__ __forceinline__ double finish(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t*) {
+        const int nxt = (s & 1) ^ 1;
         DSTAMP_INPUTS(a, s);
         // calculate_pi (:174-200): assignments ascending, cpt * pi-messages in ascending parent order;
         // calculate_lambda_k (:240-266): bucket out[jt][ct] receives, own state outer and assignment inner,
@@ -500,17 +551,18 @@ struct DagChildG {
             cpt[2 * q] = x.x; cpt[2 * q + 1] = x.y;
         }
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+    // The node's inputs -- its M pi-messages and lambda(v), 2 (M + 1) 16-byte halves -- are requested ONCE per group: lane g
+    // loads half g (and g + G where the group has fewer lanes than halves), the group shares them through the wave's scratch.
+    static constexpr int HN = 2 * (M + 1), LPL = (HN + G - 1) / G;
+    static_assert(NPT * HN <= 2 * kWave, "the groups' halves fit the wave's scratch");
+    // the inputs of the sweep in hand: requested by request(), consumed by finish() (see DagChildU)
+    double fold[K];
+    double2_t mine[LPL];
+    __device__ __forceinline__ void request(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
         const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
-        const int cur = s & 1, nxt = cur ^ 1;
-        // The node's inputs -- its M pi-messages and lambda(v), 2 (M + 1) 16-byte halves -- are requested ONCE per group: lane g
-        // loads half g (and g + G where the group has fewer lanes than halves), the group shares them through the wave's scratch.
-        constexpr int HN = 2 * (M + 1), LPL = (HN + G - 1) / G;
-        static_assert(NPT * HN <= 2 * kWave, "the groups' halves fit the wave's scratch");
-        double fold[K];
+        const int cur = s & 1;
 #pragma unroll
         for (int i = 0; i < K; ++i) fold[i] = 1.0;
-        double2_t mine[LPL];
 #pragma unroll
         for (int q = 0; q < LPL; ++q) {
             const int h = g + q * G;
@@ -526,6 +578,13 @@ struct DagChildG {
         const bool fin_msg = g >= 1 && g <= M;
         if (fin_msg && !first) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + g - 1), fold);
         if (g == 0 && frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), fold);
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        request(a, rs, s);
+        return finish(a, rs, s, xch);
+    }
+    __device__ __forceinline__ double finish(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        const int nxt = (s & 1) ^ 1;
         double2_t* xn = xch + nl * HN;
 #pragma unroll
         for (int q = 0; q < LPL; ++q)
@@ -660,11 +719,12 @@ struct DagParent {
 #pragma unroll
         for (int x = 0; x < RC; ++x) oe[x] = (x < deg) ? a.oedge[obeg + x] : 0;
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+    // the inputs of the sweep in hand: requested by request(), consumed by finish() (see DagChildU)
+    double acc[K], old[K], lk[RC][K];
+    __device__ __forceinline__ void request(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
         const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
-        const int cur = s & 1, nxt = cur ^ 1;
+        const int cur = s & 1;
         const bool is_msg = tedge >= 0;
-        double acc[K], old[K], lk[RC][K];
 #pragma unroll
         for (int i = 0; i < K; ++i) { acc[i] = i < kv ? 1.0 : 0.0; old[i] = 1.0; }   // (the empty product over a leaf's children: ones over the node's OWN states)
 #pragma unroll
@@ -689,6 +749,15 @@ struct DagParent {
                     if (x < deg) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, oe[x]), lk[x]);
                 }
         }
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        request(a, rs, s);
+        return finish(a, rs, s, xch);
+    }
+    __device__ __forceinline__ double finish(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t*) {
+        const bool first = s == 0 && a.state_init == 0;
+        const int cur = s & 1, nxt = cur ^ 1;
+        const bool is_msg = tedge >= 0;
         DSTAMP_INPUTS(a, s);
 #pragma unroll
         for (int x = 0; x < RC; ++x)
@@ -750,11 +819,12 @@ struct DagParentX {
         kv = a.node_k ? a.node_k[node] : 4;
         frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
     }
-    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+    // the inputs of the sweep in hand: requested by request(), consumed by finish() (see DagChildU)
+    double rec[K], old[K];
+    __device__ __forceinline__ void request(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s) {
         const bool first = s == 0 && a.state_init == 0;   // (a padded network's initial state stands in memory)
-        const int cur = s & 1, nxt = cur ^ 1;
+        const int cur = s & 1;
         const bool is_msg = tedge >= 0;
-        double rec[K], old[K], acc[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) { rec[i] = 1.0; old[i] = 1.0; }
         if (is_msg) {
@@ -771,6 +841,15 @@ struct DagParentX {
             }
             if (frozen) dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), old);  // an evidence node's lambda is carried over (:223)
         }
+    }
+    __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        request(a, rs, s);
+        return finish(a, rs, s, xch);
+    }
+    __device__ __forceinline__ double finish(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
+        const int nxt = (s & 1) ^ 1;
+        const bool is_msg = tedge >= 0;
+        double acc[K];
         double2_t r0, r1;
         r0.x = rec[0]; r0.y = rec[1]; r1.x = rec[2]; r1.y = rec[3];
         xch[2 * lane] = r0;
@@ -853,9 +932,9 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     auto beliefs_of = [&](int q) { return a.b.beliefs + int64_t(q) * a.belief_stride; };
     bool ok = true;
     if (t1 <= t0) {
-        ok = dag_drive<BATCH>(a, sh, lane, wave, [](int, int) { return 0.0; }, [](int, int, int) {});
+        ok = dag_drive<BATCH>(a, sh, lane, wave, [](int, int) {}, [](int, int) { return 0.0; }, [](int, int, int) {});
     } else if constexpr (STREAM) {
-        ok = dag_drive<BATCH>(a, sh, lane, wave,
+        ok = dag_drive<BATCH>(a, sh, lane, wave, [](int, int) {},
                        [&](int q, int s) {
                            double w = 0.0;
                            const __amdgpu_buffer_rsrc_t rs = rs_of(q);
@@ -879,7 +958,8 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     } else {
         const DagTile td = a.tiles[t0];
         dag_with_tile(a, td, lane, [&](auto& st) {
-            ok = dag_drive<BATCH>(a, sh, lane, wave, [&](int q, int s) { if constexpr (BATCH) st.turn(q); return st.sweep(a, rs_of(q), s, sh.xch[wave]); },
+            ok = dag_drive<BATCH>(a, sh, lane, wave, [&](int q, int s) { if constexpr (BATCH) st.turn(q); st.request(a, rs_of(q), s); },
+                           [&](int q, int s) { return st.finish(a, rs_of(q), s, sh.xch[wave]); },
                            [&](int q, int n, int done) {
                                if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) {
                                    if (done != 0) st.belief(a, rs_of(q), n, beliefs_of(q));
@@ -900,7 +980,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
 
 // bn_bp_set_evidence for this path (:68-73): pi(v) = lambda(v) = the given vector in BOTH buffers (an observed node's vectors
 // are carried over by every sweep), node marked with this set's mark value (the previous set's marks need no clearing)
-__global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) {
+__device__ __forceinline__ void dag_apply_evidence(const DagEvidenceArgs& a) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.ne) return;
     const int v = a.ev_node[j];
@@ -914,8 +994,10 @@ __global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) {
     }
     a.frz[v] = a.frz_mark;
 }
+__global__ __launch_bounds__(256) void dag_evidence_kernel(DagEvidenceArgs a) { dag_apply_evidence(a); }
+__global__ __launch_bounds__(256) void dag_evidence_batch_kernel(DagEvidenceBatch b) { dag_apply_evidence(b.set[blockIdx.y]); }
 
-__global__ __launch_bounds__(256) void dag_init_kernel(DagInitArgs a) {
+__device__ __forceinline__ void dag_apply_init(const DagInitArgs& a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < a.E) {   // both messages of edge t: ones over the states of its PARENT
         const int kp = a.node_k[a.in_idx[t]];
@@ -932,6 +1014,25 @@ __global__ __launch_bounds__(256) void dag_init_kernel(DagInitArgs a) {
             a.state[dag_off_nlam(a.E, a.n, 0, t) * 2 + i] = i < kv ? 1.0 : 0.0;
         }
     }
+}
+__global__ __launch_bounds__(256) void dag_init_kernel(DagInitArgs a) { dag_apply_init(a); }
+__global__ __launch_bounds__(256) void dag_init_batch_kernel(DagInitBatch b) { dag_apply_init(b.set[blockIdx.y]); }
+int launch_dag_init_batch(const DagInitBatch& b, int n_sets, void* stream_handle) {
+    (void)hipGetLastError();
+    const int work = b.set[0].E > b.set[0].n ? b.set[0].E : b.set[0].n;   // (one network: the same for every set)
+    if (work <= 0 || n_sets <= 0) return 0;
+    hipLaunchKernelGGL(dag_init_batch_kernel, dim3((work + 255) / 256, n_sets), dim3(256), 0, (hipStream_t)stream_handle, b);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
+}
+int launch_dag_evidence_batch(const DagEvidenceBatch& b, int n_sets, void* stream_handle) {
+    (void)hipGetLastError();
+    int ne_max = 0;
+    for (int q = 0; q < n_sets; ++q) ne_max = b.set[q].ne > ne_max ? b.set[q].ne : ne_max;
+    if (ne_max <= 0) return 0;
+    hipLaunchKernelGGL(dag_evidence_batch_kernel, dim3((ne_max + 255) / 256, n_sets), dim3(256), 0, (hipStream_t)stream_handle, b);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : int(e);
 }
 int launch_dag_init(const DagInitArgs& a, void* stream_handle) {
     (void)hipGetLastError();

@@ -135,9 +135,14 @@ struct DagInitArgs {
     const uint8_t* frz;
     uint8_t frz_mark;
 };
+// several evidence sets of a batch in one launch (blockIdx.y = the set): a launch per set cost a batch of 16 sets 0.1 ms per call
+struct DagEvidenceBatch { DagEvidenceArgs set[kDagMaxSets]; };
+struct DagInitBatch { DagInitArgs set[kDagMaxSets]; };
 int launch_dag_init(const DagInitArgs& a, void* stream_handle);
+int launch_dag_init_batch(const DagInitBatch& b, int n_sets, void* stream_handle);
 int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle);
 int launch_dag_evidence(const DagEvidenceArgs& a, void* stream_handle);
+int launch_dag_evidence_batch(const DagEvidenceBatch& b, int n_sets, void* stream_handle);
 
 // where things live in DagArgs::state, in double2 units (a record = 4 doubles = two of them)
 __host__ __device__ inline int64_t dag_off_pim(int64_t E, int64_t, int par, int64_t e) { return (int64_t(par) * E + e) * 2; }

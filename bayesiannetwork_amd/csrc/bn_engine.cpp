@@ -2090,8 +2090,10 @@ static int run_batch_mid(bn_engine* e, double eps, int32_t max_sweeps) {
 // dag_drive).  Every set has its own state, marks, barrier words, residual history and control block and keeps the bits and the
 // sweep count of its single run.  left[q] = true: set q did not finish here (more than kDagBudget sweeps) and is run on its own.
 // BN_ERR_STATE: a grid wait gave up.
-static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int32_t first, int32_t count, std::vector<char>& left,
-                               int32_t& launches, double& dev_ms, int32_t& max_sw) {
+// (enqueue only: the chunks of a batch follow each other on the stream -- the next chunk's evidence lands in the state slots when the
+// previous chunk's kernel has left them -- and the host waits once, for all of them: collect_batch_dag_chunk reads the outcome.)
+struct DagChunk { int32_t first, count; uint32_t run_id; };
+static int enqueue_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int32_t first, int32_t count, DagChunk& chunk) {
     bn_engine::Batch& bt = e->batch;
     const Plan& p = e->plan;
     const DagPlan& dp = e->dag;
@@ -2113,18 +2115,22 @@ static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int
         bt.dag_mark = 0;
     }
     ++bt.dag_mark;
-    for (int32_t q = 0; q < count; ++q) {   // pi(v) = lambda(v) = the given vector in both buffers, node marked (:68-73)
-        const int32_t g = first + q;
-        DagEvidenceArgs ea{bt.ne[g], dp.n, dp.E, reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[g],
-                           reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[g],
-                           reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[g], bt.d_g_state + size_t(q) * state_d,
-                           bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark, e->d_g_k};
-        if (int code = launch_dag_evidence(ea, s))
+    {   // pi(v) = lambda(v) = the given vector in both buffers, node marked (:68-73): every set of the chunk in one launch
+        DagEvidenceBatch eb{};
+        DagInitBatch ib{};
+        for (int32_t q = 0; q < count; ++q) {
+            const int32_t g = first + q;
+            eb.set[q] = DagEvidenceArgs{bt.ne[g], dp.n, dp.E, reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[g],
+                                        reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[g],
+                                        reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[g], bt.d_g_state + size_t(q) * state_d,
+                                        bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark, e->d_g_k};
+            ib.set[q] = DagInitArgs{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, bt.d_g_state + size_t(q) * state_d,
+                                    bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark};
+        }
+        if (int code = launch_dag_evidence_batch(eb, count, s))
             return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
         if (!dp.uniform4) {
-            DagInitArgs ia{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, bt.d_g_state + size_t(q) * state_d,
-                           bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark};
-            if (int code = launch_dag_init(ia, s))
+            if (int code = launch_dag_init_batch(ib, count, s))
                 return fail(BN_ERR_HIP, std::string("dag_init launch failed: ") + hipGetErrorString(hipError_t(code)));
         }
     }
@@ -2135,7 +2141,7 @@ static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int
     }
     ++e->run_id;
     if (e->run_id == 0) e->run_id = 1;
-    *e->h_abort = 0;
+    chunk = DagChunk{first, count, e->run_id};
     DagArgs a{};
     a.b = buffers_of(e);
     a.b.beliefs = bt.d_beliefs + size_t(first) * p.node_off[p.n];
@@ -2157,19 +2163,21 @@ static int run_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps, int
     for (int32_t q = 0; q < count; ++q) bt.h_ctl[first + q].run_id = 0;
     if (int code = launch_bp_dag(a, dp.stream, s))
         return fail(BN_ERR_HIP, std::string("bp_dag launch failed: ") + hipGetErrorString(hipError_t(code)));
-    HIPCHK(hipStreamSynchronize(s));
-    ++launches;
     bt.dag_gen_base += kDagBudget + 1;
+    return BN_OK;
+}
+
+// after the stream has drained.  left[q] = true: set q did not finish in its launch (more than kDagBudget sweeps) and is run on its own.
+static int collect_batch_dag_chunk(bn_engine* e, const DagChunk& chunk, std::vector<char>& left, double& dev_ms, int32_t& max_sw) {
+    bn_engine::Batch& bt = e->batch;
+    const int32_t first = chunk.first, count = chunk.count;
     bool gave_up = *e->h_abort != 0, stale = false;
     for (int32_t q = 0; q < count; ++q) {
         gave_up = gave_up || bt.h_ctl[first + q].done < 0;
-        stale = stale || bt.h_ctl[first + q].run_id != e->run_id;
+        stale = stale || bt.h_ctl[first + q].run_id != chunk.run_id;
     }
     if (gave_up || stale) bt.dag_sync_dirty = true;
-    if (gave_up) {
-        *e->h_abort = 0;
-        return fail(BN_ERR_STATE, "a block of the register-resident DAG kernel gave up its grid wait");
-    }
+    if (gave_up) return fail(BN_ERR_STATE, "a block of the register-resident DAG kernel gave up its grid wait");
     if (stale) return fail(BN_ERR_HIP, "bp_dag kernel did not report (stale control block)");
     dev_ms += double(bt.h_ctl[first].t_last - bt.h_ctl[first].t_first) * 1e-5;
     for (int32_t q = 0; q < count; ++q) {
@@ -2193,8 +2201,22 @@ static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
     // with 1 / 2 / 4 / 8 sets per launch (scripts/time_dag_batch.py)
     static const int per_launch = std::max(1, std::min(kDagMaxSets, std::getenv("BN_DAG_SETS") ? std::atoi(std::getenv("BN_DAG_SETS")) : kDagMaxSets));
     if (per_launch > 1 && bt.n_sets > 1) {
-        for (int32_t first = 0; first < bt.n_sets && rc == BN_OK; first += per_launch)
-            rc = run_batch_dag_chunk(e, eps, max_sweeps, first, std::min(per_launch, bt.n_sets - first), left, launches, dev_ms, max_sw);
+        std::vector<DagChunk> chunks;
+        *e->h_abort = 0;
+        for (int32_t first = 0; first < bt.n_sets && rc == BN_OK; first += per_launch) {
+            chunks.emplace_back();
+            rc = enqueue_batch_dag_chunk(e, eps, max_sweeps, first, std::min(per_launch, bt.n_sets - first), chunks.back());
+            if (rc != BN_OK) chunks.pop_back();
+        }
+        // (also after a failed enqueue: what is on the stream writes into the batch's buffers)
+        const hipError_t drained = hipStreamSynchronize(e->stream);
+        if (drained != hipSuccess && rc == BN_OK) rc = fail(BN_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(drained));
+        launches += int32_t(chunks.size());
+        for (const DagChunk& c : chunks) {
+            const int rc_c = collect_batch_dag_chunk(e, c, left, dev_ms, max_sw);
+            if (rc == BN_OK) rc = rc_c;
+        }
+        if (*e->h_abort != 0) { *e->h_abort = 0; bt.dag_sync_dirty = true; }
         if (rc != BN_OK) return rc;
     } else {
         std::fill(left.begin(), left.end(), 1);

@@ -25,4 +25,5 @@ with Engine(g) as eng:
         dt = (time.perf_counter() - t0) / reps
         ss = float(sum(out["sweeps"]))
         print(f"sets per launch {os.environ.get('BN_DAG_SETS', '8')}  B={B:3d}  {dt * 1e6:8.1f} us per call  {dt * 1e6 / ss:6.2f} us per set-sweep  "
-              f"{g.messages_per_sweep() * ss / dt / 1e9:6.2f} G edge-messages/s  path {eng.last_path()}")
+              f"{g.messages_per_sweep() * ss / dt / 1e9:6.2f} G edge-messages/s  path {eng.last_path()}  "
+              f"in the kernels {eng.bp_stats()['sweep_devclock_ms'] * 1e3 / ss:5.2f} us per set-sweep")
