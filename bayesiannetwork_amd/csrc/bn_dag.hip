@@ -68,7 +68,7 @@ struct DagSetShared {                    // per evidence set of the launch
     int arrived;                         // waves of the block that have finished the set's sweep in hand (the last one publishes)
     int pub_it;                          // the iteration whose granules the block has published
     int poll_it;                         // several sets: the last iteration for whose barrier a wave of the block has taken the polling on
-    int ver_it;                          // ... and the last one whose verdict stands in `verdict`
+    int ver;                             // ... and the last one whose verdict is out, with the verdict: iteration << 2 | verdict (one LDS read tells both)
 };
 struct DagShared {
     DagSetShared set[kDagMaxSets];
@@ -132,7 +132,7 @@ __device__ __forceinline__ void dag_arrive(const DagArgs& a, ResidentSync* sync,
             if (a.n_blocks == 1) {
                 sync->res[it] = m;
                 sh.verdict = dag_verdict_of(a, dag_residual_of(m), s + 1);
-                if (!single) __hip_atomic_store(&sh.ver_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!single) __hip_atomic_store(&sh.ver, it << 2 | sh.verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
                 // the granules of consecutive iterations alternate between two tables: a block already past this barrier must not
                 // overwrite what a slower block still has to read
@@ -204,18 +204,22 @@ __device__ __forceinline__ void dag_publish_verdict(const DagArgs& a, ResidentSy
     if (lane == 0) {
         if (blockIdx.x == 0 && ok) __hip_atomic_store(&sync->res[it], m, RLX_AGENT);
         sh.verdict = ok ? dag_verdict_of(a, dag_residual_of(m), a.sweep_begin + it + 1) : kDagAbort;
-        if constexpr (BATCH) __hip_atomic_store(&sh.ver_it, it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (BATCH) __hip_atomic_store(&sh.ver, it << 2 | sh.verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
 // Several sets per launch (BATCH): no block barrier here either.  The FIRST wave of the block to need this barrier's verdict does the
-// polling (an LDS fetch-max on poll_it decides who), publishes verdict and ver_it; the others wait for ver_it in LDS.  A wave with a
+// polling (an LDS fetch-max on poll_it decides who), publishes the verdict (`ver`); the others wait for it in LDS.  A wave with a
 // light tile is thus never held up by the block's slower waves -- it sweeps the next sets while they finish this one -- and a set's
 // sweep costs the block what its slowest wave needs for the arithmetic, not that plus a block barrier per set.
 template <bool BATCH>
 __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, DagSetShared& sh, int it) {
     bool poller = threadIdx.x < kWave;
     if constexpr (BATCH) {
+        // (the block's faster waves have been here as a rule and the verdict is out: one LDS read instead of the three that the
+        // claim, the wait and the verdict take -- the slowest wave's set-turn sets the pace of the whole launch)
+        const int out = __hip_atomic_load(&sh.ver, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((out >> 2) == it) return out & 3;
         int before = it;
         if ((threadIdx.x & (kWave - 1)) == 0) before = __hip_atomic_fetch_max(&sh.poll_it, it, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         poller = __builtin_amdgcn_readfirstlane(before) < it;
@@ -260,14 +264,15 @@ __device__ __forceinline__ int dag_wait(const DagArgs& a, ResidentSync* sync, Da
         return sh.verdict;
     } else {
         const unsigned long long t0 = wall_clock64();
-        for (unsigned n = 1; __hip_atomic_load(&sh.ver_it, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != it; ++n) {
+        int out;
+        for (unsigned n = 1; ((out = __hip_atomic_load(&sh.ver, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != it; ++n) {
             if ((n & 63u) == 0 && wall_clock64() - t0 > 2 * a.timeout_ticks) {   // (the poller gives up first and says so here)
                 __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
                 return kDagAbort;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        return __hip_atomic_load(&sh.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return out & 3;
     }
 }
 
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
     }
     if (threadIdx.x < kDagMaxSets) {
         DagSetShared& z = sh.set[threadIdx.x];
-        z.skew_ticks = 0; z.t_arrive = 0; z.arrived = 0; z.pub_it = -1; z.poll_it = -1; z.ver_it = -1;
+        z.skew_ticks = 0; z.t_arrive = 0; z.arrived = 0; z.pub_it = -1; z.poll_it = -1; z.ver = -1;
     }
     if constexpr (BATCH) __syncthreads();   // (a single query reads these words behind its first block barrier only)
     const int slot = blockIdx.x * kDagWaves + wave;
