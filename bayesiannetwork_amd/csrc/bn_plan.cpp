@@ -85,7 +85,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     if (n > 0 && (!d.k || !d.in_ptr || !d.cpt_off)) return "null model array";
     if (shard.nranks < 1 || shard.rank < 0 || shard.rank >= shard.nranks) return "bad rank / nranks";
     p = Plan();
-    p.wide_requested = wide_requested;  // after the reset: dense_engine_for_batch (bn_engine.cpp) reads it
+    p.wide_requested = wide_requested;  // after the reset: dense_engine_for_batch (bn_engine_batch.cpp) reads it
     p.n = n;
     p.rank = shard.rank;
     p.nranks = shard.nranks;
@@ -493,7 +493,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
 
     // ---- neighbour tiles (dataflow form of the resident kernel): the tiles of the parents and children of a tile's
     // nodes on this rank, ascending, without the tile itself; across a cut edge the peer's node stands in for its
-    // tile until the peer's export blob names it (bn_engine.cpp: bn_peer_import)
+    // tile until the peer's export blob names it (bn_engine_shard.cpp: bn_peer_import)
     {
         std::vector<std::vector<int32_t>> nb(nt);
         std::vector<uint8_t> is_boundary(n, 0);

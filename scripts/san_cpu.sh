@@ -1,7 +1,7 @@
 #!/bin/bash
 # scripts/san_cpu.sh -- the HOST side under AddressSanitizer + UndefinedBehaviorSanitizer, on a CPU box:
 #   * libbn_mi355x_san.so (make -C bayesiannetwork_amd/csrc SAN=1): planners (bn_plan.cpp, bn_small_plan.cpp, bn_dag_plan.cpp), engine
-#     (bn_engine.cpp) and the sampler's host driver (bn_lw.cpp), exercised by tests/test_host_logic.py on BN_DEVICE_HOST_ONLY engines;
+#     (bn_engine*.cpp) and the sampler's host driver (bn_lw.cpp), exercised by tests/test_host_logic.py on BN_DEVICE_HOST_ONLY engines;
 #   * liboracle_san.so (make -C oracle SAN=1): the checker, exercised by tests/test_oracle_golden.py;
 #   * the header-only drop-in (flatten, DSC loader) in tests/cpp/test_dropin.cpp --flatten / --dsc ... --flatten, over include/compat and,
 #     where /root/reference exists, over the reference's own graph.hpp / matrix.hpp / serializer.
