@@ -210,77 +210,110 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     return BN_OK;
 }
 
-// sets [first, first + count) through the resident kernel, round-robin in one launch (count <= kResidentMaxSets)
-static int run_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps, int32_t first, int32_t count, int32_t& launches,
-                                    float& ms, double& dev_ticks) {
+// sets [first, first + count) through the resident kernel, round-robin in one launch (count <= kResidentMaxSets): enqueue only.  The
+// chunks of a batch follow each other on the stream and the host waits once for all of them (a wait per chunk cost a batch of 16 sets
+// four wake-ups and four launch latencies); consecutive launches share the barrier words -- the generations count on.
+static int enqueue_batch_resident_chunk(bn_engine* e, double eps, int32_t max_sweeps, int32_t first, int32_t count, int32_t begin, uint32_t mask) {
     bn_engine::Batch& bt = e->batch;
     const Plan& p = e->plan;
     hipStream_t s = e->stream;
-    int32_t begin = 0;
-    uint32_t mask = (1u << count) - 1u;
-    for (;;) {
-        if (bt.sync_dirty || bt.gen_base > (1u << 29)) {
-            HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(std::min(bt.cap_sets, kResidentMaxSets)), s));
-            bt.sync_dirty = false;
-            bt.gen_base = 0;
-        }
-        *e->h_abort = 0;
-        ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
-                       bt.h_ctl_dev + first, e->grid_resident, e->resident_waves, count, mask, p.rec_total_doubles, p.node_doubles,
-                       int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, nullptr, 0, nullptr, 1, 0, e->h_abort_dev};
-        if (e->timing) {
-            int rc = ensure_events(e, 2);
-            if (rc) return rc;
-            HIPCHK(hipEventRecord(e->events[0], s));
-        }
-        if (int code = launch_bp_resident(a, e->grid_resident + resident_service_blocks(e->grid_resident), e->resident_lean, s))
-            return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
-        if (e->timing) HIPCHK(hipEventRecord(e->events[1], s));
-        HIPCHK(hipStreamSynchronize(s));
-        ++launches;
-        if (e->timing) {
-            float t = 0.f;
-            HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
-            ms += t;
-        }
-        bt.gen_base += kResidentBudget + 1;
-        if (*e->h_abort != 0) {
-            bt.sync_dirty = true;
-            return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
-        }
-        uint32_t next = 0;
-        for (int32_t q = 0; q < count; ++q) {
-            if (!((mask >> q) & 1u)) continue;
-            const Ctl& c = bt.h_ctl[first + q];
-            if (c.run_id != e->run_id || c.done < 0) bt.sync_dirty = true;
-            if (c.run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
-            if (c.done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
-            bt.sweeps[first + q] = c.n_sweeps;
-            bt.residual[first + q] = c.last_res;
-            if (c.done == 0) next |= 1u << q;
-        }
-        dev_ticks += double(bt.h_ctl[first].t_last - bt.h_ctl[first].t_first);
-        if (next == 0) break;
-        mask = next;
-        begin += kResidentBudget;
+    if (bt.sync_dirty || bt.gen_base > (1u << 29)) {
+        HIPCHK(hipMemsetAsync(bt.d_sync, 0, sizeof(ResidentSync) * size_t(std::min(bt.cap_sets, kResidentMaxSets)), s));
+        bt.sync_dirty = false;
+        bt.gen_base = 0;
     }
+    ResidentArgs a{batch_buffers_of(e, first), eps, max_sweeps, begin, kResidentBudget, e->run_id, bt.gen_base, 5000000ull, bt.d_sync,
+                   bt.h_ctl_dev + first, e->grid_resident, e->resident_waves, count, mask, p.rec_total_doubles, p.node_doubles,
+                   int64_t(std::max(p.n_slots, 1)), p.node_off[p.n], e->res_cap, nullptr, nullptr, nullptr, 0, nullptr, 1, 0, e->h_abort_dev};
+    if (int code = launch_bp_resident(a, e->grid_resident + resident_service_blocks(e->grid_resident), e->resident_lean, s))
+        return fail(BN_ERR_HIP, std::string("bp_resident launch failed: ") + hipGetErrorString(hipError_t(code)));
+    bt.gen_base += kResidentBudget + 1;
+    return BN_OK;
+}
+
+// after the stream has drained: what the launch of sets [first, first + count) (those in `mask`) reported.  next = the sets whose run
+// goes on beyond the launch's budget of iterations.
+static int collect_batch_resident_chunk(bn_engine* e, int32_t first, int32_t count, uint32_t mask, uint32_t& next, double& dev_ticks) {
+    bn_engine::Batch& bt = e->batch;
+    next = 0;
+    if (*e->h_abort != 0) {
+        bt.sync_dirty = true;
+        return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
+    }
+    for (int32_t q = 0; q < count; ++q) {
+        if (!((mask >> q) & 1u)) continue;
+        const Ctl& c = bt.h_ctl[first + q];
+        if (c.run_id != e->run_id || c.done < 0) bt.sync_dirty = true;
+        if (c.run_id != e->run_id) return fail(BN_ERR_STATE, "resident kernel did not report (stale control block)");
+        if (c.done < 0) return fail(BN_ERR_STATE, "resident kernel gave up a barrier wait");
+        bt.sweeps[first + q] = c.n_sweeps;
+        bt.residual[first + q] = c.last_res;
+        if (c.done == 0) next |= 1u << q;
+    }
+    dev_ticks += double(bt.h_ctl[first].t_last - bt.h_ctl[first].t_first);
     return BN_OK;
 }
 
 // every set through the resident kernel: up to kResidentMaxSets per launch, further sets in further launches
 static int run_batch_resident(bn_engine* e, double eps, int32_t max_sweeps) {
     bn_engine::Batch& bt = e->batch;
+    hipStream_t s = e->stream;
     ++e->run_id;
     if (e->run_id == 0) e->run_id = 1;
     int32_t launches = 0;
     double dev_ticks = 0.0;
     float ms = 0.f;
-    const int32_t chunks = (bt.n_sets + kResidentMaxSets - 1) / kResidentMaxSets;
-    for (int32_t c = 0, first = 0; c < chunks; ++c) {
-        const int32_t count = (bt.n_sets - first + (chunks - c) - 1) / (chunks - c);  // balanced chunk sizes
-        int rc = run_batch_resident_chunk(e, eps, max_sweeps, first, count, launches, ms, dev_ticks);
-        if (rc) return rc;
+    struct Chunk { int32_t first, count; uint32_t next; };
+    std::vector<Chunk> chunks;
+    const int32_t n_chunks = (bt.n_sets + kResidentMaxSets - 1) / kResidentMaxSets;
+    for (int32_t c = 0, first = 0; c < n_chunks; ++c) {
+        const int32_t count = (bt.n_sets - first + (n_chunks - c) - 1) / (n_chunks - c);  // balanced chunk sizes
+        chunks.push_back(Chunk{first, count, 0u});
         first += count;
+    }
+    *e->h_abort = 0;
+    for (int32_t q = 0; q < bt.n_sets; ++q) bt.h_ctl[q].run_id = 0;
+    if (e->timing) {
+        int rc = ensure_events(e, 2);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(e->events[0], s));
+    }
+    int rc = BN_OK;
+    size_t enqueued = 0;
+    for (; enqueued < chunks.size() && rc == BN_OK; ++enqueued)
+        rc = enqueue_batch_resident_chunk(e, eps, max_sweeps, chunks[enqueued].first, chunks[enqueued].count, 0, (1u << chunks[enqueued].count) - 1u);
+    if (rc != BN_OK) --enqueued;   // (the last one was not launched)
+    if (e->timing && rc == BN_OK) HIPCHK(hipEventRecord(e->events[1], s));
+    // (also after a failed enqueue: what is on the stream writes into the batch's buffers)
+    const hipError_t drained = hipStreamSynchronize(s);
+    if (drained != hipSuccess && rc == BN_OK) rc = fail(BN_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(drained));
+    launches += int32_t(enqueued);
+    if (rc != BN_OK) { bt.sync_dirty = true; *e->h_abort = 0; return rc; }
+    if (e->timing) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
+        ms += t;
+    }
+    for (Chunk& c : chunks) {
+        const int rc_c = collect_batch_resident_chunk(e, c.first, c.count, (1u << c.count) - 1u, c.next, dev_ticks);
+        if (rc == BN_OK) rc = rc_c;
+    }
+    if (*e->h_abort != 0) { *e->h_abort = 0; bt.sync_dirty = true; }
+    if (rc != BN_OK) return rc;
+    // runs beyond one launch's budget of iterations (rare): those sets go on, chunk by chunk, a launch and a wait at a time
+    for (Chunk& c : chunks) {
+        int32_t begin = 0;
+        while (c.next != 0) {
+            const uint32_t mask = c.next;
+            begin += kResidentBudget;
+            *e->h_abort = 0;
+            for (int32_t q = 0; q < c.count; ++q)
+                if ((mask >> q) & 1u) bt.h_ctl[c.first + q].run_id = 0;
+            if ((rc = enqueue_batch_resident_chunk(e, eps, max_sweeps, c.first, c.count, begin, mask))) return rc;
+            HIPCHK(hipStreamSynchronize(s));
+            ++launches;
+            if ((rc = collect_batch_resident_chunk(e, c.first, c.count, mask, c.next, dev_ticks))) { *e->h_abort = 0; return rc; }
+        }
     }
     e->last_path = 2;
     e->stats.sweep_launches = launches;

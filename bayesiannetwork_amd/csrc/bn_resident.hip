@@ -87,6 +87,10 @@ struct BlockShared {
     int verdict[kResidentMaxSets];                              // of a set's last barrier: kGoOn / kConverged / kCapped / kAbort
     unsigned long long t_arrive;                                // direct form: 100 MHz clock when this block published its granules
     int skew_ticks;                                             // ... and how long after this block the LAST block arrived in the previous iteration
+    // several sets per launch: the block's waves are not held together by block barriers (arrive_batch / wait_verdict_batch)
+    int arrived[kResidentMaxSets];                              // waves that have finished the set's sweep in hand (the last one publishes)
+    int poll_it[kResidentMaxSets];                              // the last iteration for whose barrier a wave of the block has taken the polling on
+    int ver[kResidentMaxSets];                                  // the last iteration whose verdict is out, with the verdict: iteration << 2 | verdict
 };
 enum : int { kGoOn = 0, kConverged = 1, kCapped = 2, kAbort = 3 };
 
@@ -157,6 +161,39 @@ __device__ __forceinline__ void arrive(const ResidentArgs& a, BlockShared& sh, i
             __hip_atomic_store(g + 1, ((now & 0xffffull) << 48) | ((unsigned long long)(gen & 0xffffu) << 32) | unsigned(m), RLX_AGENT);
         }
     }
+}
+
+// Several sets per launch (service-block form): no block barrier.  A wave that has finished its sweep of a set counts itself in and goes
+// on to the next set's sweep; the wave that completes the count publishes the block's granules (bn_dag.hip dag_arrive: with a
+// __syncthreads here and another behind the verdict every set-turn cost the block its slowest wave twice -- stamps, 316 x 316 grid, four
+// sets: 0.4 us median / 1.6 us at the 90th percentile in this barrier, 0.8 us in the verdict's).
+__device__ __forceinline__ void arrive_batch(const ResidentArgs& a, BlockShared& sh, int set, int it, int s, double wres, int lane, int wave) {
+    const unsigned long long bits = wave_umax((unsigned long long)__double_as_longlong(wres));
+    if (lane == 0) sh.slot[set][wave] = bits;
+    RSTAMP(3, it, lane, wave);
+    drain_stores();  // this wave's write-through stores have reached memory
+    RSTAMP(4, it, lane, wave);
+    if (lane == 0) {
+        const int before = __hip_atomic_fetch_add(&sh.arrived[set], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (before == a.waves - 1) {   // the block's last wave: every wave's stores are out, every slot is written
+            __hip_atomic_store(&sh.arrived[set], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (next used by a wave that has seen this barrier's verdict)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            unsigned long long m = 0;
+            for (int w = 0; w < a.waves; ++w) m = sh.slot[set][w] > m ? sh.slot[set][w] : m;
+            ResidentSync* sy = a.sync + set;
+            if (a.n_tile_blocks == 1) {
+                sy->res[it] = m;
+                __hip_atomic_store(&sh.ver[set], it << 2 | verdict_of(a, residual_of(m), s + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                const unsigned gen = a.gen_base + unsigned(it) + 1u;
+                unsigned long long* g = sy->blk[blockIdx.x];   // (the service block reads one table: it is never behind a tile block's next arrival)
+                const unsigned long long now = wall_clock64();
+                __hip_atomic_store(g, granule(gen, unsigned(m >> 32)), RLX_AGENT);
+                __hip_atomic_store(g + 1, ((now & 0xffffull) << 48) | ((unsigned long long)(gen & 0xffffu) << 32) | unsigned(m), RLX_AGENT);   // (arrive()'s format)
+            }
+        }
+    }
+    RSTAMP(5, it, lane, wave);
 }
 
 // polls until pred() or abort / timeout; false = give up (abort raised)
@@ -273,6 +310,38 @@ __device__ __forceinline__ int wait_verdict(const ResidentArgs& a, BlockShared& 
     return sh.verdict[set];
 }
 
+// ... and its verdict: the first wave of the block to need it does the polling (an LDS fetch-max decides who) and puts it out in LDS,
+// the others wait for it there (bn_dag.hip dag_wait).
+__device__ __forceinline__ int wait_verdict_batch(const ResidentArgs& a, BlockShared& sh, int set, int it, int lane) {
+    int out = __hip_atomic_load(&sh.ver[set], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((out >> 2) == it) return out & 3;
+    int before = it;
+    if (lane == 0) before = __hip_atomic_fetch_max(&sh.poll_it[set], it, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_readfirstlane(before) < it && a.n_tile_blocks > 1) {
+        if (lane == 0) {
+            ResidentSync* sy = a.sync + set;
+            const unsigned gen = a.gen_base + unsigned(it) + 1u;
+            const int groups = a.n_tile_blocks < 8 ? a.n_tile_blocks : 8;
+            const int g = blockIdx.x % groups;
+            unsigned word = 0;
+            const bool ok = poll_until(a, [&] {
+                word = __hip_atomic_load(&sy->grp[g].gen, RLX_AGENT);
+                return (word & 0x3fffffffu) >= gen;
+            });
+            __hip_atomic_store(&sh.ver[set], it << 2 | (ok ? int(word >> 30) : kAbort), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned n = 1; ((out = __hip_atomic_load(&sh.ver[set], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >> 2) != it; ++n) {
+        if ((n & 63u) == 0 && wall_clock64() - t0 > 2 * a.timeout_ticks) {   // (the poller gives up first and says so here)
+            __hip_atomic_store(&a.sync->abort, 1u, RLX_AGENT);
+            return kAbort;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return out & 3;
+}
+
 // The service block (one wave; the launch has exactly one when it has more than one tile block): lane l
 // sweeps the granule pairs of tile blocks l, l + 64, l + 128, l + 192 until all carry the generation, the wave
 // reduces the residual, lane 0 decides and publishes.  It follows the same (iteration, set) order as the tile
@@ -321,7 +390,8 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
             int v = kGoOn;
             RSTAMP(0, it, lane, wave);
             if (it > 0) {
-                v = wait_verdict(a, sh, set, it - 1);
+                if (BATCH && a.direct == 0) v = wait_verdict_batch(a, sh, set, it - 1, lane);
+                else v = wait_verdict(a, sh, set, it - 1);
                 if (v == kAbort) return false;
             }
             RSTAMP(1, it, lane, wave);  // verdict of the previous iteration known
@@ -348,7 +418,8 @@ __device__ __forceinline__ bool resident_drive(const ResidentArgs& a, BlockShare
                 continue;
             }
             const double wres = phase(set, s);
-            arrive(a, sh, set, it, s, wres, lane, wave);
+            if (BATCH && a.direct == 0) arrive_batch(a, sh, set, it, s, wres, lane, wave);
+            else arrive(a, sh, set, it, s, wres, lane, wave);
             RSTAMP(6, it, lane, wave);  // granules published
         }
         if (active == 0) break;
@@ -1061,6 +1132,10 @@ __global__ __launch_bounds__(WMAX * kWave, WMAX == kResidentWaves ? 2 : 1) void 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) { sh.t_arrive = 0; sh.skew_ticks = 0; }
+    if constexpr (BATCH) {
+        if (threadIdx.x < kResidentMaxSets) { sh.arrived[threadIdx.x] = 0; sh.poll_it[threadIdx.x] = -1; sh.ver[threadIdx.x] = -1; }
+        __syncthreads();
+    }
     if constexpr (!FLOW) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {  // written now rather than kept in registers for the whole run
             const unsigned long long t_first = wall_clock64();
