@@ -843,13 +843,16 @@ MidArgs bn_eng::mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides&
     return a;
 }
 // launch + wait; BN_ERR_STATE: a grid wait gave up (the caller redoes the work on the tile kernels)
-int bn_eng::mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to) {
+// wait = false: enqueue only (the chunks of a batch, bn_engine_batch.cpp: the caller clears the abort word before the first, waits once
+// behind the last and looks at the abort word then)
+int bn_eng::mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to, bool wait) {
     hipStream_t s = e->stream;
-    *e->h_abort = 0;
+    if (wait) *e->h_abort = 0;
     HIPCHK(hipMemsetAsync(e->d_m_sync + size_t(a.slot_base) * kMidSyncBytes, 0, size_t(n_sets) * kMidSyncBytes, s));
     if (int code = launch_bp_mid(a, e->mid.waves, e->mid.rounds, e->mid.lds_bytes, n_sets, s))
         return fail(BN_ERR_HIP, std::string("bp_mid launch failed: ") + hipGetErrorString(hipError_t(code)));
     if (copy_to) HIPCHK(hipMemcpyAsync(copy_to, copy_from, sizeof(double) * e->plan.node_off[e->plan.n], hipMemcpyDeviceToHost, s));
+    if (!wait) return BN_OK;
     HIPCHK(hipStreamSynchronize(s));
     e->ev_upload_pending = false;
     if (*e->h_abort != 0) {

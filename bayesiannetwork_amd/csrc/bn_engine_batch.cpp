@@ -473,12 +473,26 @@ static int run_batch_mid(bn_engine* e, double eps, int32_t max_sweeps) {
         x.ev_meta = bt.d_ev_meta;
     };
     int32_t launches = 0;
-    for (int32_t first = 0; first < B; first += per_launch) {
-        const int32_t count = std::min(per_launch, B - first);
+    // the chunks follow each other on the stream (a chunk's sets use the state slots the previous chunk's kernel has left), one wait
+    *e->h_abort = 0;
+    for (int32_t first = 0; first < B && rc == BN_OK; first += per_launch) {
         MidArgs a = mid_args_of(e, b0, st, bt.h_ctl_dev, eps, max_sweeps, 0, first, 0);
         evidence_of(a);
-        if ((rc = mid_launch(e, a, count, nullptr, nullptr))) return rc;
-        ++launches;
+        rc = mid_launch(e, a, std::min(per_launch, B - first), nullptr, nullptr, false);
+        if (rc == BN_OK) ++launches;
+    }
+    {   // (also after a failed enqueue: what is on the stream writes into the batch's buffers)
+        const hipError_t drained = hipStreamSynchronize(e->stream);
+        if (drained != hipSuccess && rc == BN_OK) rc = fail(BN_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(drained));
+    }
+    e->ev_upload_pending = false;
+    if (*e->h_abort != 0) {
+        *e->h_abort = 0;
+        if (rc == BN_OK) rc = fail(BN_ERR_STATE, "a workgroup of the mid-size kernel gave up its grid wait");
+    }
+    if (rc != BN_OK) return rc;
+    for (int32_t first = 0; first < B; first += per_launch) {
+        const int32_t count = std::min(per_launch, B - first);
         for (int32_t q = first; q < first + count; ++q) {
             if (bt.h_ctl[q].done < 0) return fail(BN_ERR_STATE, "a workgroup of the mid-size kernel gave up its grid wait");
             if (bt.h_ctl[q].run_id != e->run_id) return fail(BN_ERR_HIP, "bp_mid kernel did not report (stale control block)");

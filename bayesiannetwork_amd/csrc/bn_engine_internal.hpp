@@ -342,7 +342,7 @@ inline int dalloc(T** dst, size_t count) {
 
 bool dag_applies(const bn_engine* e);
 SmallArgs small_args_of(bn_engine* e, const BpBuffers& b, double eps, int32_t max_sweeps, int32_t begin, Ctl* host_ctl);
-int mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to);
+int mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to, bool wait = true);
 MidArgs mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides& st, Ctl* h_ctl_dev, double eps, int32_t max_sweeps,
                            int32_t begin, int32_t set_base, int32_t slot_base);
 bool mid_applies(const bn_engine* e);
