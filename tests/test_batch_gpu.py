@@ -122,6 +122,21 @@ def test_batch_more_sets_than_one_resident_launch_walks(Engine):
             assert out["sweeps"][q] == r["sweeps"] and np.array_equal(out["beliefs"][q], r["beliefs"])
 
 
+def test_batch_resident_runs_beyond_one_launch(Engine):
+    """Runs of more than a launch's 1 024 iterations, in a batch of two chunks on the resident path: all chunks' first launches are
+    enqueued behind each other (one host wait), the sets that are not finished go on chunk by chunk -- sweep counts, bits and residual
+    histories of the single runs (eps = 0: every set is capped at 1 030 sweeps)."""
+    from bayesiannetwork_amd import synth
+    g = synth.grid(24, 24, 4, seed=8)
+    evs = [synth.random_evidence(g, 0.02 * (q % 3), seed=40 + q) for q in range(6)]
+    with Engine(g) as eng:
+        eng.set_option("mid", 0)
+        eng.set_option("small", 0)
+        _check_batch(eng, evs, 0.0, max_sweeps=1030, want_path=2, reps=1)
+        assert eng.bp_stats()["sweep_launches"] == 4    # two chunks, two launches each
+        _check_batch(eng, evs, 1e-9, want_path=2, reps=1)   # (and an ordinary batch on the same engine afterwards)
+
+
 def test_mirror_class_run_batch(bnlib):
     """BeliefPropagation.run_batch (the Python spelling of the drop-in's run_batch extension): entry q == bp(queries[q])."""
     from bayesiannetwork_amd import synth
