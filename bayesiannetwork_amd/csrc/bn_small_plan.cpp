@@ -136,12 +136,14 @@ static void build_plan_of_range(const Plan& p, int v0, int v1, bool part, SmallP
     // As many waves as the largest kind needs for one round, but 12 rather than 16: three waves per SIMD instead of four
     // measured faster even where the entry items then take a second round (27-node network: 58.7 vs 61.5 us per query; ALARM-
     // shaped: 49 vs 51) -- unless the entry items already take three or more rounds at 16 waves and 12 would add another
-    // (48-node network: 73 vs 65; 8 x 8 grid, k = 4: not eligible at 12).
+    // (48-node network: 73 vs 65; 8 x 8 grid, k = 4: not eligible at 12).  A workgroup's share of a network spread over several
+    // (part): 16 waves also where they take the entry items from three rounds to two (10 k-node mixed-arity network, 213 workgroups:
+    // 9.0 -> 8.4 us per sweep; the smaller networks' parts need one round either way).
     int waves = std::max(1, std::min(kSmallPreferredWaves, std::max(ne_rows, std::max(nb, nc))));
     {
         const int re12 = (ne_rows + kSmallPreferredWaves - 1) / kSmallPreferredWaves, re16 = (ne_rows + kSmallMaxWaves - 1) / kSmallMaxWaves;
         const int rb12 = (nb + kSmallPreferredWaves - 1) / kSmallPreferredWaves, rc12 = (nc + kSmallPreferredWaves - 1) / kSmallPreferredWaves;
-        if ((re12 > re16 && re16 >= 3) || re12 > kSmallMaxRounds || rb12 > kSmallMaxRounds || rc12 > kSmallMaxRounds) {
+        if ((re12 > re16 && (re16 >= 3 || (part && re12 >= 3))) || re12 > kSmallMaxRounds || rb12 > kSmallMaxRounds || rc12 > kSmallMaxRounds) {
             waves = kSmallMaxWaves;
             nb = pack_rows(bv, true, kSmallMaxWaves);  // (more rows of like runs fit one round now)
         }
