@@ -338,11 +338,23 @@ void build_mid_plan(const Plan& p, MidPlan& mp) {
         const int64_t nparts_want = std::max<int64_t>(2, (total + target - 1) / target);
         if (nparts_want > kMidMaxParts) continue;
         const int64_t per = (total + nparts_want - 1) / nparts_want;
-        std::vector<int> cut{0};
-        int64_t acc = 0;
-        for (int v = 0; v < n; ++v) {
-            if (acc > 0 && acc + est[v] > per && int(cut.size()) < kMidMaxParts) { cut.push_back(v); acc = 0; }
-            acc += est[v];
+        // Large parts: also cut where the part's CPT entries would go beyond two rounds of entry items at sixteen waves -- the staged-term
+        // estimate balances the accumulator work, but a part of 2 070 entries takes a third round and the whole grid waits for it at the
+        // barrier (10 k-node mixed-arity network: arrival skew 0.64 us median).  Without that cut where it would need more workgroups
+        // than there are.
+        constexpr int64_t kTwoRounds = 2 * kSmallMaxWaves * kWave;
+        std::vector<int> cut;
+        for (int capped = (per > 6000 ? 1 : 0); capped >= 0; --capped) {
+            cut.assign(1, 0);
+            int64_t acc = 0, ent = 0;
+            for (int v = 0; v < n; ++v) {
+                const int64_t ev = p.cpt_off[v + 1] - p.cpt_off[v];
+                const bool over = acc + est[v] > per || (capped && ent + ev > kTwoRounds);
+                if (acc > 0 && over && int(cut.size()) < kMidMaxParts) { cut.push_back(v); acc = 0; ent = 0; }
+                acc += est[v];
+                ent += ev;
+            }
+            if (int(cut.size()) < kMidMaxParts) break;   // (at kMidMaxParts the last part took whatever was left)
         }
         cut.push_back(n);
         std::vector<SmallPlan> parts(cut.size() - 1);
