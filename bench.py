@@ -161,7 +161,7 @@ def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
     # (untimed, before the W warm-up steps: a quarter of a second of the same run, so that the clocks the timed steps see are the
     # steady ones -- W = 5 steps are 0.7 ms on the headline workload, less than the power state takes to settle after an idle spell)
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.25:
+    while time.perf_counter() - t_settle < 0.25 and os.environ.get("BN_BENCH_NO_SETTLE") != "1":   # (scripts/profile_bench.sh: every dispatch is a row of its traces)
         eng.bp_run_device(eps)
     for _ in range(max(warmup, 1)):
         r = eng.bp_run_device(eps)

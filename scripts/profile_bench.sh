@@ -9,6 +9,7 @@ set -u
 TAG=${1:-r05}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
+export BN_BENCH_NO_SETTLE=1   # bench.py's quarter second of untimed runs before the warm-up steps would be thousands of rows in every trace
 mkdir -p $OUT
 : > $OUT/failed_passes.txt
 sha256sum bayesiannetwork_amd/libbn_mi355x.so | cut -d' ' -f1 > $OUT/lib_sha256.txt
