@@ -36,7 +36,7 @@ constexpr int kDagMaxParents = 5;
 constexpr int kDagMaxChildren = 1024;   // per node: DagParentLane::deg_tpos holds count | rank << 16 (signed), wide items cost deg^2 loads
 constexpr int64_t kDagMaxImageBytes = int64_t(256) << 20;   // padded CPT image (registers, or re-read per sweep in stream form)
 constexpr int kDagRegChildren = 8;
-constexpr int kDagMaxSets = 8;      // evidence sets one launch can walk (bn_bp_run_batch): per-set state, marks, barrier words; the CPT registers serve all      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
+constexpr int kDagMaxSets = 16;     // evidence sets one launch can walk (bn_bp_run_batch): per-set state, marks, barrier words; the CPT registers serve all      // out-edge ids a parent item keeps in registers (more: re-read every iteration)
 
 enum : int32_t { kDagChild0 = 0, /* 1..5: child tile of nodes with that many parents */ kDagParent = 8, kDagParentWide = 9 };
 

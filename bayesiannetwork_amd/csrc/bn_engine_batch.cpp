@@ -636,8 +636,10 @@ static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
     int32_t launches = 0, max_sw = 0;
     double dev_ms = 0.0;
     std::vector<char> left(size_t(bt.n_sets), 0);
-    // how many sets share a launch (BN_DAG_SETS, default 8; 1 = one after another).  Config 2, us per set-sweep at B = 16: 8.7 / 6.9 / 6.2 / 5.9
-    // with 1 / 2 / 4 / 8 sets per launch (scripts/time_dag_batch.py)
+    // how many sets share a launch (BN_DAG_SETS, default 16; 1 = one after another).  Config 2, us per set-sweep at B = 16: 8.7 / 6.9 / 6.2 / 5.9
+    // with 1 / 2 / 4 / 8 sets per launch in round 4; round 5 (a turn's arrival behind the next turn's loads, one evidence launch per
+    // chunk, one host wait): 4.65 with 8, 4.49 with 16 -- the pace inside the kernel is a wave's set-turn, but a launch's ramp, its
+    // evidence launch and the tail where few sets are left come once instead of twice (scripts/time_dag_batch.py)
     static const int per_launch = std::max(1, std::min(kDagMaxSets, std::getenv("BN_DAG_SETS") ? std::atoi(std::getenv("BN_DAG_SETS")) : kDagMaxSets));
     if (per_launch > 1 && bt.n_sets > 1) {
         std::vector<DagChunk> chunks;

@@ -167,12 +167,13 @@ def test_dag_100k_nodes_stream_form(Engine, oracle_mod):
 
 
 def test_dag_batch_shares_launches(Engine, oracle_mod):
-    """Several sets per launch (the sets take turns inside an iteration; up to 8 share the CPT registers): 11 sets = two launches, sets
+    """Several sets per launch (the sets take turns inside an iteration; up to 16 share the CPT registers): 19 sets = two launches, sets
     that stop on different sweeps, caps; every set keeps the sweep count, the bits and the residual history of its single run, and a
     set that needs more than one launch's 1 024 iterations is finished on its own."""
     from bayesiannetwork_amd import synth
     g = synth.random_dag(600, 4, 48, 4, seed=43)
-    evs = [synth.random_evidence(g, f, seed=50 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1, 0.3, 0.02, 0.15, 0.0, 0.4, 0.07])]
+    evs = [synth.random_evidence(g, f, seed=50 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1, 0.3, 0.02, 0.15, 0.0, 0.4, 0.07,
+                                                                          0.03, 0.25, 0.0, 0.12, 0.06, 0.35, 0.01, 0.09])]
     with Engine(g) as eng:
         singles, hists = [], []
         for ev in evs:
