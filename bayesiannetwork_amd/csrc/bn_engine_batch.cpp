@@ -176,6 +176,7 @@ extern "C" int bn_bp_set_evidence_batch(bn_engine* e, int32_t n_sets, const int3
     bt.ev_b_node = b_node; bt.ev_b_off = b_off; bt.ev_b_val = b_val;
     bt.ev_node_at = node_at; bt.ev_off_at = off_at; bt.ev_val_at = val_at;
     bt.ev_deferred = true;
+    bt.dag_ev_applied = false;
     bt.beliefs_on_host = false;
     if (e->small_ok || e->mid_ok || dag_applies(e)) {
         // Small networks: the block is page-locked host memory that the kernels read in place -- the one-workgroup kernel (one
@@ -549,12 +550,19 @@ static int enqueue_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps,
         bt.dag_mark = 0;
         bt.dag_sync_dirty = true;
     }
-    if (bt.dag_mark == 255) {  // the mark values are used up: start over
-        HIPCHK(hipMemsetAsync(bt.d_g_frz, 0, size_t(dp.n) * kDagMaxSets, s));
-        bt.dag_mark = 0;
+    // The evidence of a batch that fits the state slots (one chunk) on a network without padding stays where the first run put it: the
+    // sweeps carry an observed node's vectors over and sweep 0 reads nothing else of the old state (the single query's dag_ev_applied).
+    const bool keeps = dp.uniform4 && first == 0 && count == bt.n_sets;
+    const bool apply = !(keeps && bt.dag_ev_applied);
+    bt.dag_ev_applied = keeps;
+    if (apply) {
+        if (bt.dag_mark == 255) {  // the mark values are used up: start over
+            HIPCHK(hipMemsetAsync(bt.d_g_frz, 0, size_t(dp.n) * kDagMaxSets, s));
+            bt.dag_mark = 0;
+        }
+        ++bt.dag_mark;
     }
-    ++bt.dag_mark;
-    {   // pi(v) = lambda(v) = the given vector in both buffers, node marked (:68-73): every set of the chunk in one launch
+    if (apply) {   // pi(v) = lambda(v) = the given vector in both buffers, node marked (:68-73): every set of the chunk in one launch
         DagEvidenceBatch eb{};
         DagInitBatch ib{};
         for (int32_t q = 0; q < count; ++q) {
@@ -615,7 +623,7 @@ static int collect_batch_dag_chunk(bn_engine* e, const DagChunk& chunk, std::vec
         gave_up = gave_up || bt.h_ctl[first + q].done < 0;
         stale = stale || bt.h_ctl[first + q].run_id != chunk.run_id;
     }
-    if (gave_up || stale) bt.dag_sync_dirty = true;
+    if (gave_up || stale) { bt.dag_sync_dirty = true; bt.dag_ev_applied = false; }
     if (gave_up) return fail(BN_ERR_STATE, "a block of the register-resident DAG kernel gave up its grid wait");
     if (stale) return fail(BN_ERR_HIP, "bp_dag kernel did not report (stale control block)");
     dev_ms += double(bt.h_ctl[first].t_last - bt.h_ctl[first].t_first) * 1e-5;

@@ -190,6 +190,8 @@ struct bn_engine {
         ResidentSync* d_g_sync = nullptr;
         int32_t dag_sets = 0;
         uint8_t dag_mark = 0;
+        bool dag_ev_applied = false;  // state slot q holds set q's evidence under mark dag_mark (a batch of at most kDagMaxSets sets on a network
+                                      // without padding: an observed node's vectors are carried over by every sweep, so they outlive the run)
         bool dag_sync_dirty = true;
         uint32_t dag_gen_base = 0;
         bool ev_deferred = false;     // the sets' evidence sits in d_ev only (read there by that kernel); d_ev_meta: per set {count, first node / offset / value}

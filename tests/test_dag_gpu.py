@@ -196,6 +196,39 @@ def test_dag_batch_shares_launches(Engine, oracle_mod):
             assert long["sweeps"][q] == 1030 == r["sweeps"] and np.array_equal(long["beliefs"][q], r["beliefs"])
 
 
+def test_dag_batch_rerun_on_staged_evidence(Engine):
+    """bn_bp_run_batch_device again and again on ONE bn_bp_set_evidence_batch (what a caller with standing evidence sets does, and what
+    bench.py times): a batch that fits one launch leaves its evidence in the state slots between runs (an observed node's vectors are
+    carried over by every sweep) -- every run gives the single runs' bits; staging other evidence, fewer sets or more sets than a launch
+    holds, and a single query in between, each take effect."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(700, 4, 48, 4, seed=47)
+    evs = [synth.random_evidence(g, f, seed=80 + q) for q, f in enumerate([0.0, 0.05, 0.2, 0.01, 0.1, 0.3, 0.02])]
+    other = [synth.random_evidence(g, f, seed=95 + q) for q, f in enumerate([0.1, 0.0, 0.25, 0.04, 0.15, 0.02, 0.3])]
+    many = [synth.random_evidence(g, 0.01 * (q % 7), seed=120 + q) for q in range(21)]   # two launches: the slots are shared by the chunks
+    with Engine(g) as eng:
+        single = lambda ev: eng.bp_run(ev, 1e-6)   # noqa: E731
+        want = {id(ev): single(ev) for ev in evs + other + many}
+        assert eng.last_path() == 5
+
+        def check(sets, runs):
+            eng.bp_set_evidence_batch(sets)
+            for _ in range(runs):
+                out = eng.bp_run_batch_device(1e-6)
+                bel = eng.bp_beliefs_batch()
+                assert eng.last_path() == 5 and eng.info("dag_aborts") == 0
+                for q, ev in enumerate(sets):
+                    assert out["sweeps"][q] == want[id(ev)]["sweeps"] and np.array_equal(bel[q], want[id(ev)]["beliefs"]), q
+        check(evs, 3)
+        check(other, 2)            # other evidence on the same nodes' slots
+        check(evs[:3], 2)          # fewer sets
+        check(many, 2)             # more than one launch holds: applied per chunk, every run
+        check(evs, 2)              # ... and back to a batch that stays
+        assert np.array_equal(single(other[2])["beliefs"], want[id(other[2])]["beliefs"])   # a single query in between (its own state)
+        out = eng.bp_run_batch_device(1e-6)
+        assert np.array_equal(eng.bp_beliefs_batch()[1], want[id(evs[1])]["beliefs"]) and out["sweeps"][1] == want[id(evs[1])]["sweeps"]
+
+
 @pytest.mark.parametrize("case", ["stream", "one_block"])
 def test_dag_batch_other_forms(Engine, oracle_mod, case):
     """The several-sets launch in the kernel's other two forms: the stream form (waves walking several tiles per iteration and set: a
