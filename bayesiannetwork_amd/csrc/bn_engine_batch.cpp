@@ -704,7 +704,7 @@ static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
         e->beliefs_override = keep_override;
     }
     if (rc != BN_OK) return rc;
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (any_left) HIPCHK(hipStreamSynchronize(e->stream));   // (the copies of the left-over sets' residual histories; the chunks were waited for above)
     bt.predicted_sweeps = max_sw;
     e->last_path = 5;
     e->stats.sweep_launches = launches;
