@@ -354,10 +354,10 @@ __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int l
 }
 
 // belief = normalize(pi % lambda) (:151-158) of `node` from the state after n sweeps
-__device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int node, int n, double* beliefs) {
+__device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int node, int snode, int n, double* beliefs) {
     double pv[4], lv[4], bel[4];
-    dag_ld4(rs, dag_off_npi(a.E, a.n, n & 1, node), pv);
-    dag_ld4(rs, dag_off_nlam(a.E, a.n, n & 1, node), lv);
+    dag_ld4(rs, dag_off_npi(a.E, a.n, n & 1, snode), pv);
+    dag_ld4(rs, dag_off_nlam(a.E, a.n, n & 1, snode), lv);
     double sum = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bel[i] = pv[i] * lv[i]; sum += bel[i]; }   // (padding entries are 0: they add nothing)
@@ -390,7 +390,8 @@ __device__ __forceinline__ unsigned dag_frozen_bits(const DagArgs& a, bool activ
 template <int M>
 struct DagChildU {
     static constexpr int K = 4, C = ipow(K, M), S = K * C, CB = (M > 0) ? C / K : 0;
-    int node, ebase;
+    int node, ebase;          // node id; state record of its first in-edge's messages (tile-major numbering, bn_dag.hpp)
+    int sdelta, estride;      // wave-uniform: slot of the node's vectors = ebase + sdelta; records between its consecutive in-edges' messages
     bool active, frozen;
     unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
     __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
@@ -399,7 +400,9 @@ struct DagChildU {
         const DagChildLane cl = a.cnode[t.lane_base + lane];
         active = cl.node >= 0;
         node = active ? cl.node : 0;  // idle lanes shadow node 0 and store nothing
-        ebase = active ? cl.ebase : 0;
+        ebase = __builtin_amdgcn_readfirstlane(t.rec_base) + (active ? lane : 0);   // (idle lanes shadow the tile's first node)
+        sdelta = __builtin_amdgcn_readfirstlane(t.slot_base - t.rec_base);
+        estride = __builtin_amdgcn_readfirstlane(t.n_active);
         frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
         const double2_t* cp = reinterpret_cast<const double2_t*>(a.cpt_img) + t.cpt_base + lane;
 #pragma unroll
@@ -423,13 +426,13 @@ struct DagChildU {
         if (!first) {
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                dag_ld4(rs, dag_off_pim(a.E, a.n, cur, ebase + j), pim[j]);
-                dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + j), lold[j]);
+                dag_ld4(rs, dag_off_pim(a.E, a.n, cur, ebase + j * estride), pim[j]);
+                dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + j * estride), lold[j]);
             }
         }
         if (!first || frozen) {  // evidence nodes hold their vector as pi and lambda in both buffers (:68-73)
-            dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), lav);
-            dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), pold);
+            dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, ebase + sdelta), lav);
+            dag_ld4(rs, dag_off_npi(a.E, a.n, cur, ebase + sdelta), pold);
         }
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
@@ -490,15 +493,15 @@ struct DagChildU {
 #pragma unroll
             for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(out[jt][i] - lold[jt][i]));
         if (active) {
-            if (frozen) dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), pold);   // evidence nodes keep pi (:177)
-            else dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), pin);
+            if (frozen) dag_st4(rs, dag_off_npi(a.E, a.n, nxt, ebase + sdelta), pold);   // evidence nodes keep pi (:177)
+            else dag_st4(rs, dag_off_npi(a.E, a.n, nxt, ebase + sdelta), pin);
 #pragma unroll
-            for (int jt = 0; jt < M; ++jt) dag_st4(rs, dag_off_lam(a.E, a.n, nxt, ebase + jt), out[jt]);
+            for (int jt = 0; jt < M; ++jt) dag_st4(rs, dag_off_lam(a.E, a.n, nxt, ebase + jt * estride), out[jt]);
         }
         return active ? wres : 0.0;
     }
     __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n, double* beliefs) {
-        if (active) dag_belief(a, rs, node, n, beliefs);
+        if (active) dag_belief(a, rs, node, ebase + sdelta, n, beliefs);
     }
 };
 
@@ -537,7 +540,8 @@ template <int D>
 struct DagChildG {
     static constexpr int K = 4, M = D + 2, G = 1 << (2 * D), NPT = kWave / G;
     static_assert(G >= M + 1, "a group has a lane per finished vector");
-    int node, ebase, nl, g;
+    int node, ebase, nl, g;   // (ebase: state record of the first in-edge's messages, tile-major numbering, bn_dag.hpp)
+    int sdelta, estride;      // wave-uniform: slot of the node's vectors = ebase + sdelta; records between its consecutive in-edges' messages
     bool active, frozen;
     unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
     __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
@@ -547,7 +551,9 @@ struct DagChildG {
         nl = lane / G; g = lane % G;
         active = cl.node >= 0;
         node = active ? cl.node : 0;
-        ebase = active ? cl.ebase : 0;
+        ebase = __builtin_amdgcn_readfirstlane(t.rec_base) + (active ? nl : 0);
+        sdelta = __builtin_amdgcn_readfirstlane(t.slot_base - t.rec_base);
+        estride = __builtin_amdgcn_readfirstlane(t.n_active);
         frozen_bits = dag_frozen_bits(a, active, node); frozen = (frozen_bits & 1u) != 0;
         const double2_t* cp = reinterpret_cast<const double2_t*>(a.cpt_img) + t.cpt_base + lane;
 #pragma unroll
@@ -573,16 +579,16 @@ struct DagChildG {
             const int h = g + q * G;
             mine[q].x = 1.0; mine[q].y = 1.0;
             if (h < 2 * M) {
-                if (!first) mine[q] = dag_ld(rs, dag_off_pim(a.E, a.n, cur, ebase + (h >> 1)) + (h & 1));
+                if (!first) mine[q] = dag_ld(rs, dag_off_pim(a.E, a.n, cur, ebase + (h >> 1) * estride) + (h & 1));
             } else if (h < HN) {
-                if (!first || frozen) mine[q] = dag_ld(rs, dag_off_nlam(a.E, a.n, cur, node) + (h - 2 * M));
+                if (!first || frozen) mine[q] = dag_ld(rs, dag_off_nlam(a.E, a.n, cur, ebase + sdelta) + (h - 2 * M));
             }
         }
         // lane 0 of the group finishes pi(v), lane 1 + jt the lambda-message to parent jt: each requests the previous value
         // of ITS vector now (residual :105-131; an evidence node's pi is carried over, :177)
         const bool fin_msg = g >= 1 && g <= M;
-        if (fin_msg && !first) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + g - 1), fold);
-        if (g == 0 && frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), fold);
+        if (fin_msg && !first) dag_ld4(rs, dag_off_lam(a.E, a.n, cur, ebase + (g - 1) * estride), fold);
+        if (g == 0 && frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, ebase + sdelta), fold);
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
         request(a, rs, s);
@@ -686,18 +692,18 @@ struct DagChildG {
         if (active && g <= M) {
             normalize_k<K>(o);
             if (g == 0) {
-                if (frozen) dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), fold);
-                else dag_st4(rs, dag_off_npi(a.E, a.n, nxt, node), o);
+                if (frozen) dag_st4(rs, dag_off_npi(a.E, a.n, nxt, ebase + sdelta), fold);
+                else dag_st4(rs, dag_off_npi(a.E, a.n, nxt, ebase + sdelta), o);
             } else {
 #pragma unroll
                 for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(o[i] - fold[i]));
-                dag_st4(rs, dag_off_lam(a.E, a.n, nxt, ebase + g - 1), o);
+                dag_st4(rs, dag_off_lam(a.E, a.n, nxt, ebase + (g - 1) * estride), o);
             }
         }
         return wres;
     }
     __device__ __forceinline__ void belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int n, double* beliefs) {
-        if (active && g == 0) dag_belief(a, rs, node, n, beliefs);
+        if (active && g == 0) dag_belief(a, rs, node, ebase + sdelta, n, beliefs);
     }
 };
 
@@ -705,15 +711,16 @@ struct DagChildG {
 // in ascending order, the target left out -- the reference's multiplication sequence
 struct DagParent {
     static constexpr int K = 4, RC = kDagRegChildren;
-    int node, tedge, obeg, deg, tpos, dmax, kv;
+    int node, snode, tedge, obeg, deg, tpos, dmax, kv;   // (tedge, the out-edges: state records; snode: slot of the node's vectors)
     bool active, frozen;
     unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
     __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
     int oe[RC];  // the first out-edges' CSR ids
     __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane) {
-        const DagParentLane it = a.pitem[t.lane_base + lane];
+        const DagParentLaneDev it = a.pitem[t.lane_base + lane];
         active = it.node >= 0;
         node = active ? it.node : 0;
+        snode = active ? it.snode : 0;
         tedge = it.tedge;
         obeg = it.obeg;
         deg = active ? (it.deg_tpos & 0xffff) : 0;
@@ -738,14 +745,14 @@ struct DagParent {
             for (int i = 0; i < K; ++i) lk[x][i] = 1.0;
         // a pi-message starts from pi(v) (:207): the previous sweep's, or in sweep 0 the initial one (1.0, a root's CPT row, the evidence)
         if (is_msg) {
-            if (!first || frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), acc);
+            if (!first || frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, snode), acc);
             else {
 #pragma unroll
                 for (int i = 0; i < K; ++i) acc[i] = a.npi_init[int64_t(node) * 4 + i];
             }
             if (!first) dag_ld4(rs, dag_off_pim(a.E, a.n, cur, tedge), old);
         } else if (frozen) {
-            dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), old);  // an evidence node's lambda is carried over (:223)
+            dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, snode), old);  // an evidence node's lambda is carried over (:223)
         }
         if (!first) {
 #pragma unroll
@@ -793,9 +800,9 @@ struct DagParent {
                 for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(acc[i] - old[i]));
                 dag_st4(rs, dag_off_pim(a.E, a.n, nxt, tedge), acc);
             } else if (frozen) {
-                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), old);
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, snode), old);
             } else {
-                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), acc);
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, snode), acc);
             }
         }
         return wres;
@@ -807,15 +814,16 @@ struct DagParent {
 // read each other's through the wave's scratch: 4 vector-memory instructions per lane and iteration whatever the child count.
 struct DagParentX {
     static constexpr int K = 4;
-    int node, tedge, deg, tpos, first_lane, dmax, lane, kv;
+    int node, snode, tedge, deg, tpos, first_lane, dmax, lane, kv;   // (tedge: a state record; snode: slot of the node's vectors)
     bool active, frozen;
     unsigned frozen_bits;   // bit q: the node is an evidence node of set q (frozen: of the set whose turn it is)
     __device__ __forceinline__ void turn(int q) { frozen = ((frozen_bits >> q) & 1u) != 0; }
     __device__ __forceinline__ void init(const DagArgs& a, const DagTile& t, int lane_) {
-        const DagParentLane it = a.pitem[t.lane_base + lane_];
+        const DagParentLaneDev it = a.pitem[t.lane_base + lane_];
         lane = lane_;
         active = it.node >= 0;
         node = active ? it.node : 0;
+        snode = active ? it.snode : 0;
         tedge = active ? it.tedge : -1;
         deg = active ? (it.deg_tpos & 0xffff) : 0;
         tpos = active ? (it.deg_tpos >> 16) : -1;   // -1: the lambda(v) item, the first of its node's lanes
@@ -839,12 +847,12 @@ struct DagParentX {
             }
         } else {
             // pi(v): the previous sweep's, or in sweep 0 the initial one (1.0, a root's CPT row, the evidence)
-            if (!first || frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, node), rec);
+            if (!first || frozen) dag_ld4(rs, dag_off_npi(a.E, a.n, cur, snode), rec);
             else if (active) {
 #pragma unroll
                 for (int i = 0; i < K; ++i) rec[i] = a.npi_init[int64_t(node) * 4 + i];
             }
-            if (frozen) dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, node), old);  // an evidence node's lambda is carried over (:223)
+            if (frozen) dag_ld4(rs, dag_off_nlam(a.E, a.n, cur, snode), old);  // an evidence node's lambda is carried over (:223)
         }
     }
     __device__ __forceinline__ double sweep(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int s, double2_t* xch) {
@@ -884,9 +892,9 @@ struct DagParentX {
                 for (int i = 0; i < K; ++i) wres = res_acc(wres, fabs(acc[i] - old[i]));
                 dag_st4(rs, dag_off_pim(a.E, a.n, nxt, tedge), acc);
             } else if (frozen) {
-                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), old);
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, snode), old);
             } else {
-                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, node), acc);
+                dag_st4(rs, dag_off_nlam(a.E, a.n, nxt, snode), acc);
             }
         }
         return wres;
@@ -989,12 +997,13 @@ __device__ __forceinline__ void dag_apply_evidence(const DagEvidenceArgs& a) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.ne) return;
     const int v = a.ev_node[j];
+    const int sv = a.nperm[v];   // the slot of its vectors
     const int kv = a.node_k ? a.node_k[v] : 4;
     for (int i = 0; i < 4; ++i) {
         const double x = i < kv ? a.ev_val[a.ev_off[j] + i] : 0.0;
         for (int par = 0; par < 2; ++par) {
-            a.state[dag_off_npi(a.E, a.n, par, v) * 2 + i] = x;
-            a.state[dag_off_nlam(a.E, a.n, par, v) * 2 + i] = x;
+            a.state[dag_off_npi(a.E, a.n, par, sv) * 2 + i] = x;
+            a.state[dag_off_nlam(a.E, a.n, par, sv) * 2 + i] = x;
         }
     }
     a.frz[v] = a.frz_mark;
@@ -1006,17 +1015,19 @@ __device__ __forceinline__ void dag_apply_init(const DagInitArgs& a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < a.E) {   // both messages of edge t: ones over the states of its PARENT
         const int kp = a.node_k[a.in_idx[t]];
+        const int rec = a.eperm[t];
         for (int i = 0; i < 4; ++i) {
             const double x = i < kp ? 1.0 : 0.0;
-            a.state[dag_off_pim(a.E, a.n, 0, t) * 2 + i] = x;
-            a.state[dag_off_lam(a.E, a.n, 0, t) * 2 + i] = x;
+            a.state[dag_off_pim(a.E, a.n, 0, rec) * 2 + i] = x;
+            a.state[dag_off_lam(a.E, a.n, 0, rec) * 2 + i] = x;
         }
     }
     if (t < a.n && a.frz[t] != a.frz_mark) {
         const int kv = a.node_k[t];
+        const int st = a.nperm[t];
         for (int i = 0; i < 4; ++i) {
-            a.state[dag_off_npi(a.E, a.n, 0, t) * 2 + i] = a.npi_init[int64_t(t) * 4 + i];
-            a.state[dag_off_nlam(a.E, a.n, 0, t) * 2 + i] = i < kv ? 1.0 : 0.0;
+            a.state[dag_off_npi(a.E, a.n, 0, st) * 2 + i] = a.npi_init[int64_t(t) * 4 + i];
+            a.state[dag_off_nlam(a.E, a.n, 0, st) * 2 + i] = i < kv ? 1.0 : 0.0;
         }
     }
 }

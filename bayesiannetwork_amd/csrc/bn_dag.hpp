@@ -48,13 +48,25 @@ struct DagTile {
     int32_t lane_base;  // first entry of the tile in the per-lane tables (cnode / pitem): 64 per tile
     int32_t cpt_base;   // child tile: first double2 of its CPT image; entry pair q of lane l at cpt_base + q * 64 + l
     int32_t dmax;       // parent tile: largest child count among its items
-    int32_t pad_[3];
+    int32_t rec_base;   // child tile, device copy only (build_dag_device_tables): state record of in-edge 0 of its first node -- record j of
+    int32_t slot_base;  // its i-th node at rec_base + j * n_active + i -- and the slot of that node's vectors (the i-th node's: slot_base + i)
+    int32_t pad_;
 };
 static_assert(sizeof(DagTile) == 32, "DagTile is loaded as two 16-byte words");
 
 struct DagChildLane { int32_t node, ebase; };                 // node id (-1: idle lane), CSR id of its first in-edge
 struct DagParentLane { int32_t node, tedge, obeg, deg_tpos; }; // node (-1: idle), CSR id of the target out-edge (-1: the lambda(v)
                                                               // item), first entry in oedge, child count | target's rank << 16
+
+// What the kernels read instead of the tile and parent-lane tables (built at upload, build_dag_device_tables): the same entries with
+// STATE RECORD numbers in place of CSR ids (a child tile's lanes need none of their own: tile bases + the lane's node index).  Message records and node-vector slots are numbered tile-major -- record j of the i-th node of a child
+// tile at tile_base + j * (nodes in the tile) + i -- so that a load instruction of a child tile (lane i, record j) touches consecutive
+// records instead of every M-th (CSR order: 64 lanes x 16 bytes out of 64 lanes x 32 M bytes; a CU's eight waves share one address
+// pipe, and the tiles with the heaviest arithmetic are the ones that ask for most records).  The plan, its getters and the CPU
+// emulator keep CSR ids; eperm / nperm (CSR edge id -> message record, node id -> vector slot) translate where the state is read
+// or written by id: evidence, the padded networks' initial state, bn_bp_messages.
+struct DagParentLaneDev { int32_t node, tedge, obeg, deg_tpos, snode, pad_[3]; };   // as DagParentLane, tedge = a record; slot of the node's vectors
+static_assert(sizeof(DagParentLaneDev) == 32, "loaded as 16-byte words");
 
 struct DagPlan {
     bool ok = false;
@@ -77,6 +89,12 @@ struct DagPlan {
 
 // cap_blocks: most blocks a launch may have (0.9 x CUs, rounded down to a multiple of 8; host-only engines: 224)
 void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp);
+struct DagDeviceTables {
+    std::vector<DagTile> tiles;
+    std::vector<DagParentLaneDev> pitem;
+    std::vector<int32_t> oedge, eperm, nperm;
+};
+void build_dag_device_tables(const DagPlan& dp, DagDeviceTables& dt);
 
 struct DagArgs {
     BpBuffers b;              // beliefs, res_hist / res_cap
@@ -91,7 +109,7 @@ struct DagArgs {
     const DagTile* tiles;
     const int32_t* slot_ptr;
     const DagChildLane* cnode;
-    const DagParentLane* pitem;
+    const DagParentLaneDev* pitem;
     const int32_t* oedge;
     const double* cpt_img;
     const double* npi_init;
@@ -122,6 +140,7 @@ struct DagEvidenceArgs {
     uint8_t* frz;
     uint8_t frz_mark;
     const int32_t* node_k;     // nullptr: every arity is 4
+    const int32_t* nperm;      // node id -> slot of its vectors in the state
 };
 // the initial state of a run of a padded network, buffer parity 0: messages = ones over the PARENT's states (:38-56), pi(v) = npi_init,
 // lambda(v) = ones over the node's states, zeros in the padding; nodes that carry the evidence mark keep their vectors
@@ -134,6 +153,8 @@ struct DagInitArgs {
     double* state;
     const uint8_t* frz;
     uint8_t frz_mark;
+    const int32_t* eperm;      // CSR edge id -> message record
+    const int32_t* nperm;      // node id -> slot of its vectors
 };
 // several evidence sets of a batch in one launch (blockIdx.y = the set): a launch per set cost a batch of 16 sets 0.1 ms per call
 struct DagEvidenceBatch { DagEvidenceArgs set[kDagMaxSets]; };

@@ -232,4 +232,41 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
     dp.ok = true;
 }
 
+// The lane tables as the kernels read them: CSR ids replaced by state records, numbered tile-major (bn_dag.hpp).
+void build_dag_device_tables(const DagPlan& dp, DagDeviceTables& dt) {
+    dt = DagDeviceTables();
+    dt.eperm.assign(size_t(dp.E), -1);
+    dt.nperm.assign(size_t(dp.n), -1);
+    dt.tiles = dp.tiles;
+    int32_t next_rec = 0, next_slot = 0;
+    for (DagTile& t : dt.tiles) {
+        if (t.kind >= kDagParent) continue;
+        t.rec_base = next_rec;
+        t.slot_base = next_slot;
+        const int M = t.kind;
+        const int G = M <= 2 ? 1 : 1 << (2 * (M - 2));   // lanes per node
+        const int act = t.n_active;                      // nodes of the tile: lane groups 0 .. act - 1
+        for (int i = 0; i < act; ++i) {
+            const DagChildLane& cl = dp.cnode[size_t(t.lane_base) + size_t(i) * G];
+            dt.nperm[size_t(cl.node)] = next_slot + i;
+            for (int j = 0; j < M; ++j) dt.eperm[size_t(cl.ebase) + j] = next_rec + j * act + i;
+        }
+        next_rec += M * act;
+        next_slot += act;
+    }
+    // (every node sits in exactly one child tile, every edge is an in-edge of one node: both numberings are complete)
+    dt.pitem.resize(dp.pitem.size());
+    for (size_t l = 0; l < dp.pitem.size(); ++l) {
+        const DagParentLane& it = dp.pitem[l];
+        DagParentLaneDev d{it.node, it.tedge, it.obeg, it.deg_tpos, 0, {0, 0, 0}};
+        if (it.node >= 0) {
+            d.snode = dt.nperm[size_t(it.node)];
+            if (it.tedge >= 0) d.tedge = dt.eperm[size_t(it.tedge)];
+        }
+        dt.pitem[l] = d;
+    }
+    dt.oedge.resize(dp.oedge.size());
+    for (size_t x = 0; x < dp.oedge.size(); ++x) dt.oedge[x] = dt.eperm[size_t(dp.oedge[x])];
+}
+
 }  // namespace bnmi

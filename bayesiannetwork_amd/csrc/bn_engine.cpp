@@ -52,7 +52,7 @@ void bn_eng::free_engine(bn_engine* e) {
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
                         e->d_m_parts, e->d_m_ent, e->d_m_cpt, e->d_m_term, e->d_m_clist, e->d_m_bslot, e->d_m_cslot, e->d_m_nvidx, e->d_m_nvslot,
                         e->d_m_init, e->d_m_nodeoff, e->d_m_msgfirst, e->d_m_state, e->d_m_frz, e->d_m_sync,
-                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync, e->d_g_k, e->d_g_inptr, e->d_g_inidx, e->d_g_noff,
+                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_eperm, e->d_g_nperm, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync, e->d_g_k, e->d_g_inptr, e->d_g_inidx, e->d_g_noff,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state,
                         e->batch.d_g_state, e->batch.d_g_frz, e->batch.d_g_sync};
@@ -362,11 +362,19 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         if (e->dag.ok) {
             const DagPlan& dp = e->dag;
             int r2;
-            if ((r2 = upload(&e->d_g_tiles, dp.tiles, e->stream))) return r2;
             if ((r2 = upload(&e->d_g_slotptr, dp.slot_ptr, e->stream))) return r2;
-            if ((r2 = upload(&e->d_g_cnode, dp.cnode, e->stream))) return r2;
-            if ((r2 = upload(&e->d_g_pitem, dp.pitem, e->stream))) return r2;
-            if ((r2 = upload(&e->d_g_oedge, dp.oedge, e->stream))) return r2;
+            {
+                DagDeviceTables dt;
+                build_dag_device_tables(dp, dt);
+                if ((r2 = upload(&e->d_g_tiles, dt.tiles, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_cnode, dp.cnode, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_pitem, dt.pitem, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_oedge, dt.oedge, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_eperm, dt.eperm, e->stream))) return r2;
+                if ((r2 = upload(&e->d_g_nperm, dt.nperm, e->stream))) return r2;
+                HIPCHK(hipStreamSynchronize(e->stream));   // (dt is a local)
+                e->dag_eperm.swap(dt.eperm);
+            }
             if ((r2 = upload(&e->d_g_cpt, dp.cpt_img, e->stream))) return r2;
             if ((r2 = upload(&e->d_g_init, dp.npi_init, e->stream))) return r2;
             if (!dp.uniform4) {
@@ -927,7 +935,7 @@ static int flush_dag_evidence(bn_engine* e) {
         e->dag_mark = 0;
     }
     ++e->dag_mark;
-    DagEvidenceArgs ea{e->ev_ne, e->dag.n, e->dag.E, e->d_ev_node, e->d_ev_off, e->d_ev_val, e->d_g_state, e->d_g_frz, e->dag_mark, e->d_g_k};
+    DagEvidenceArgs ea{e->ev_ne, e->dag.n, e->dag.E, e->d_ev_node, e->d_ev_off, e->d_ev_val, e->d_g_state, e->d_g_frz, e->dag_mark, e->d_g_k, e->d_g_nperm};
     if (int code = launch_dag_evidence(ea, e->stream))
         return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));
     e->dag_ev_applied = true;
@@ -947,7 +955,7 @@ int bn_eng::run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_t
     double dev_ticks = 0.0;
     const BpBuffers b = buffers_of(e);
     if (!dp.uniform4) {   // arities below 4: the run's initial state stands in memory (zeros in the padding), bn_dag_plan.cpp
-        DagInitArgs ia{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, e->d_g_state, e->d_g_frz, e->dag_mark};
+        DagInitArgs ia{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, e->d_g_state, e->d_g_frz, e->dag_mark, e->d_g_eperm, e->d_g_nperm};
         if (int code = launch_dag_init(ia, s))
             return fail(BN_ERR_HIP, std::string("dag_init launch failed: ") + hipGetErrorString(hipError_t(code)));
     }
@@ -1414,19 +1422,16 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
     if (e->last_path == 5) {  // bn_dag.hip: CSR edge order, four doubles per edge, two buffers: the run stopped in buffer n_sweeps & 1
         const int64_t E = e->dag.E, n = e->dag.n;
         const int par = e->last_ctl.n_sweeps & 1;
-        if (e->dag.uniform4) {
-            HIPCHK(hipMemcpy(pi_msg_out, e->d_g_state + 2 * dag_off_pim(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(lambda_msg_out, e->d_g_state + 2 * dag_off_lam(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
-            return BN_OK;
-        }
-        // arities below 4: the padded records, of which edge e's first k(parent of e) entries exist
+        // the records (tile-major in the state, bn_dag.hpp) back in CSR edge order; arities below 4: of a padded record edge e's first
+        // k(parent of e) entries exist
         std::vector<double> pm(size_t(E) * 4), lm(size_t(E) * 4);
         HIPCHK(hipMemcpy(pm.data(), e->d_g_state + 2 * dag_off_pim(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(lm.data(), e->d_g_state + 2 * dag_off_lam(E, n, par, 0), sizeof(double) * 4 * size_t(E), hipMemcpyDeviceToHost));
         size_t at = 0;
         for (int64_t ed = 0; ed < E; ++ed) {
-            const int kp = e->plan.k[e->plan.in_idx[ed]];
-            for (int i = 0; i < kp; ++i, ++at) { pi_msg_out[at] = pm[size_t(ed) * 4 + i]; lambda_msg_out[at] = lm[size_t(ed) * 4 + i]; }
+            const int kp = e->dag.uniform4 ? 4 : e->plan.k[e->plan.in_idx[ed]];
+            const size_t rec = size_t(e->dag_eperm[size_t(ed)]);
+            for (int i = 0; i < kp; ++i, ++at) { pi_msg_out[at] = pm[rec * 4 + i]; lambda_msg_out[at] = lm[rec * 4 + i]; }
         }
         return BN_OK;
     }

@@ -570,9 +570,9 @@ static int enqueue_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps,
             eb.set[q] = DagEvidenceArgs{bt.ne[g], dp.n, dp.E, reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_node) + bt.ev_node_at[g],
                                         reinterpret_cast<int32_t*>(bt.ev_base + bt.ev_b_off) + bt.ev_off_at[g],
                                         reinterpret_cast<double*>(bt.ev_base + bt.ev_b_val) + bt.ev_val_at[g], bt.d_g_state + size_t(q) * state_d,
-                                        bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark, e->d_g_k};
+                                        bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark, e->d_g_k, e->d_g_nperm};
             ib.set[q] = DagInitArgs{dp.n, dp.E, e->d_g_inptr, e->d_g_inidx, e->d_g_k, e->d_g_init, bt.d_g_state + size_t(q) * state_d,
-                                    bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark};
+                                    bt.d_g_frz + size_t(q) * dp.n, bt.dag_mark, e->d_g_eperm, e->d_g_nperm};
         }
         if (int code = launch_dag_evidence_batch(eb, count, s))
             return fail(BN_ERR_HIP, std::string("dag_evidence launch failed: ") + hipGetErrorString(hipError_t(code)));

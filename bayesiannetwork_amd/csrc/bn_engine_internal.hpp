@@ -269,9 +269,12 @@ struct bn_engine {
     int32_t dag_cooldown = 0, dag_aborts = 0;   // runs left on the tile kernels after a grid wait gave up; how often that happened
     DagTile* d_g_tiles = nullptr;
     int32_t* d_g_slotptr = nullptr;
-    DagChildLane* d_g_cnode = nullptr;
-    DagParentLane* d_g_pitem = nullptr;
+    DagChildLane* d_g_cnode = nullptr;      // (tiles, parent lanes and out-edges: with state records in place of CSR ids, build_dag_device_tables)
+    DagParentLaneDev* d_g_pitem = nullptr;
     int32_t* d_g_oedge = nullptr;
+    int32_t* d_g_eperm = nullptr;           // CSR edge id -> message record, node id -> slot of its vectors
+    int32_t* d_g_nperm = nullptr;
+    std::vector<int32_t> dag_eperm;         // (host copy: bn_bp_messages)
     double* d_g_cpt = nullptr;
     double* d_g_init = nullptr;
     int32_t* d_g_k = nullptr;       // networks with arities below 4 (DagPlan::uniform4 == false): arity, in-edge CSR and marginal offsets for the padded form
