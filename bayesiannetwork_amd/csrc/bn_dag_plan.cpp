@@ -266,7 +266,7 @@ void build_dag_device_tables(const DagPlan& dp, DagDeviceTables& dt) {
         dt.pitem[l] = d;
     }
     dt.oedge.resize(dp.oedge.size());
-    for (size_t x = 0; x < dp.oedge.size(); ++x) dt.oedge[x] = dt.eperm[size_t(dp.oedge[x])];
+    for (size_t x = 0; x < dp.oedge.size(); ++x) dt.oedge[x] = dp.E > 0 ? dt.eperm[size_t(dp.oedge[x])] : 0;   // (a network without edges keeps one unused entry)
 }
 
 }  // namespace bnmi

@@ -145,6 +145,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     if (p.nranks == 1 && !std::getenv("BN_NO_DAG")) {  // k = 4, <= 5 parents: register-resident child tiles + parent items (bn_dag.hpp)
         try {
             build_dag_plan(p, kDagDefaultCap, e->dag);
+            if (e->dag.ok) build_dag_device_tables(e->dag, e->dag_tables);
         } catch (const std::bad_alloc&) {   // the other paths can still run the network
             e->dag = DagPlan();
             e->dag.why = "out of host memory while building the plan";
@@ -353,6 +354,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             if (cap != kDagDefaultCap) {
                 try {
                     build_dag_plan(p, cap, e->dag);
+                    if (e->dag.ok) build_dag_device_tables(e->dag, e->dag_tables);
                 } catch (const std::bad_alloc&) {
                     e->dag = DagPlan();
                     e->dag.why = "out of host memory while building the plan";
@@ -364,16 +366,13 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             int r2;
             if ((r2 = upload(&e->d_g_slotptr, dp.slot_ptr, e->stream))) return r2;
             {
-                DagDeviceTables dt;
-                build_dag_device_tables(dp, dt);
+                const DagDeviceTables& dt = e->dag_tables;
                 if ((r2 = upload(&e->d_g_tiles, dt.tiles, e->stream))) return r2;
                 if ((r2 = upload(&e->d_g_cnode, dp.cnode, e->stream))) return r2;
                 if ((r2 = upload(&e->d_g_pitem, dt.pitem, e->stream))) return r2;
                 if ((r2 = upload(&e->d_g_oedge, dt.oedge, e->stream))) return r2;
                 if ((r2 = upload(&e->d_g_eperm, dt.eperm, e->stream))) return r2;
                 if ((r2 = upload(&e->d_g_nperm, dt.nperm, e->stream))) return r2;
-                HIPCHK(hipStreamSynchronize(e->stream));   // (dt is a local)
-                e->dag_eperm.swap(dt.eperm);
             }
             if ((r2 = upload(&e->d_g_cpt, dp.cpt_img, e->stream))) return r2;
             if ((r2 = upload(&e->d_g_init, dp.npi_init, e->stream))) return r2;
@@ -1430,7 +1429,7 @@ extern "C" int bn_bp_messages(bn_engine* e, double* pi_msg_out, double* lambda_m
         size_t at = 0;
         for (int64_t ed = 0; ed < E; ++ed) {
             const int kp = e->dag.uniform4 ? 4 : e->plan.k[e->plan.in_idx[ed]];
-            const size_t rec = size_t(e->dag_eperm[size_t(ed)]);
+            const size_t rec = size_t(e->dag_tables.eperm[size_t(ed)]);
             for (int i = 0; i < kp; ++i, ++at) { pi_msg_out[at] = pm[rec * 4 + i]; lambda_msg_out[at] = lm[rec * 4 + i]; }
         }
         return BN_OK;

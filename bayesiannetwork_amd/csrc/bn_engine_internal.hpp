@@ -274,7 +274,7 @@ struct bn_engine {
     int32_t* d_g_oedge = nullptr;
     int32_t* d_g_eperm = nullptr;           // CSR edge id -> message record, node id -> slot of its vectors
     int32_t* d_g_nperm = nullptr;
-    std::vector<int32_t> dag_eperm;         // (host copy: bn_bp_messages)
+    DagDeviceTables dag_tables;             // (host copy, built with the plan -- also on host-only engines, where the CPU sanitizer run walks it; bn_bp_messages reads eperm)
     double* d_g_cpt = nullptr;
     double* d_g_init = nullptr;
     int32_t* d_g_k = nullptr;       // networks with arities below 4 (DagPlan::uniform4 == false): arity, in-edge CSR and marginal offsets for the padded form
