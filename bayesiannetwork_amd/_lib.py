@@ -92,6 +92,7 @@ SYMBOLS = [
     ("bn_bp_step_finish", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, i32p, i32p,
                                          f64p]),
     ("bn_debug_allgather", ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int32]),
+    ("bn_debug_stream", ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, f64p]),
     ("bn_bp_last_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(BpStats)]),
     ("bn_lw_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, i32p, i32p, ctypes.c_uint64, ctypes.c_uint64,
                                  ctypes.c_uint64, f64p]),

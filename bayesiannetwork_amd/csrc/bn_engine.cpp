@@ -25,6 +25,7 @@ int bn_eng::load_rccl() {
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(h, "ncclCommCount"));
     if (!a.AllReduce || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.GetErrorString)
         return fail(BN_ERR_COMM, "librccl lacks a required symbol");
     g_rccl = a;
@@ -1277,6 +1278,11 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "nbr_max") == 0) return e->plan.nbr_max;
     if (std::strcmp(name, "nbr_chunks") == 0) return e->plan.nbr.empty() ? 0 : e->plan.nbr_chunks;
     if (std::strcmp(name, "shard_flow") == 0) return e->shard_flow_ok ? 1 : 0;
+    if (std::strcmp(name, "rccl_ranks") == 0) {   // what the communicator itself reports (0: none initialised)
+        int n = 0;
+        if (e->comm && g_rccl.CommCount && g_rccl.CommCount(e->comm, &n) != ncclSuccess) n = -1;
+        return n;
+    }
     if (std::strcmp(name, "n_boundary_nodes") == 0) return int64_t(e->plan.boundary_node.size());
     if (std::strcmp(name, "resident_blocks") == 0) return e->grid_resident;
     if (std::strcmp(name, "resident_waves") == 0) return e->resident_waves;

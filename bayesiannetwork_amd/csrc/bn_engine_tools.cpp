@@ -355,3 +355,23 @@ extern "C" int bn_lw_states(bn_engine* e, uint64_t n, uint8_t* states_out, doubl
     if (rc) return fail(rc, err);
     return BN_OK;
 }
+
+// The achievable-HBM yardstick (csrc/bn_stream.hip): SURVEY 8(d) -- "measure the achievable figure with a stream-triad kernel on the
+// box and report against both".  Stateless; device = HIP ordinal or BN_DEVICE_CURRENT.
+double bn_stream_measure(int mode, size_t bytes, int reps, double* check_out);
+extern "C" int bn_debug_stream(int32_t device, int32_t mode, int64_t bytes, int32_t reps, double* gbs_out) {
+    if (!gbs_out) return fail(BN_ERR_ARG, "null argument");
+    if (mode < 0 || mode > 1) return fail(BN_ERR_ARG, "mode: 0 copy, 1 triad");
+    if (bytes < (1 << 20) || bytes > (int64_t(16) << 30) || reps < 1 || reps > 100) return fail(BN_ERR_ARG, "bytes in 1 MiB..16 GiB, reps in 1..100");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(BN_ERR_NO_DEVICE, "no HIP device");
+    DeviceGuard guard;
+    if (device != BN_DEVICE_CURRENT) HIPCHK(guard.enter(device));
+    double check = 0.0;
+    const double g = bn_stream_measure(mode, size_t(bytes), reps, &check);
+    if (g < 0) return fail(BN_ERR_HIP, std::string("bn_debug_stream: ") + hipGetErrorString(hipError_t(int(-g))));
+    // copy of {1, 2} -> 3; triad {1, 2} + 0.5 * {2, 3} -> 5.5
+    if (check != (mode == 0 ? 3.0 : 5.5)) return fail(BN_ERR_STATE, "bn_debug_stream: the kernel's output is wrong");
+    *gbs_out = g;
+    return BN_OK;
+}

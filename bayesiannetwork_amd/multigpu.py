@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from . import synth
+from . import benchline, synth
 from .engine import Engine
 
 
@@ -249,6 +249,9 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
                                    "run over 4 evidence sets x 3 runs before timing; BN_PEER_EXCHANGE=1 makes it the headline")
     li = eng.layout()
     seg = li["segment_bytes"]
+    rccl_ranks = int(eng.info("rccl_ranks"))
+    if have_rccl and rccl_ranks != world:
+        raise SystemExit(f"rank {rank}: the RCCL communicator reports {rccl_ranks} ranks in a world of {world}")
     if rank == 0:
         msgs = g.messages_per_sweep() * sweeps
         per_launch_s = kern_ms * 1e-3 / max(launches, 1)
@@ -264,7 +267,9 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
                                        f"peer's exchange region over xGMI, per-tile generation granules, per-rank residual granules "
                                        f"(one launch per rank and run, no collective)") if in_kernel else
                                       (f"edge-cut x{world}, 1 in-place RCCL all-gather per sweep ({seg} B per rank incl. residual slots)"),
-                       "exchange": "in-kernel (peer-mapped memory)" if in_kernel else "rccl all-gather per sweep"},
+                       "exchange": "in-kernel (peer-mapped memory)" if in_kernel else "rccl all-gather per sweep",
+                       # what the RCCL communicator itself reports (0: none was created -- BN_NO_RCCL)
+                       "rccl_ranks": rccl_ranks, "world_size": world, "in_kernel_exchange_verified": bool(verified)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": achieved / (8000.0 * world), "traffic": None,
                          "kernel": "bp_sweep_kernel (interior | cut-touching tiles) + all-gather on a second stream"
@@ -317,10 +322,19 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
                             f"a different evidence set per rank, no collective",
                 "value": g.messages_per_sweep() * float(tot[0]) / dtr, "unit": "edge-messages/s",
                 "ms_per_query": dtr / a.steps * 1e3, "path": "resident tiles, one launch per run" if rpath == 2 else "one launch per sweep"}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     dist.barrier()
     dog.cancel()
+    _finish(dist)
+    if rank == 0:
+        benchline.emit(out)   # the contract line is the LAST thing this job prints
+
+
+def _finish(dist) -> None:
+    """Leave the control plane before the result is printed: whatever the process group has to say on shutdown comes first."""
+    try:
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def bench_lw_main(a, rank: int, world: int, local_rank: int) -> None:
@@ -353,14 +367,17 @@ def bench_lw_main(a, rank: int, world: int, local_rank: int) -> None:
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     if rank == 0:
         rate = total * steps / float(dt[0])
-        print(json.dumps({
+        out = {
             "metric": "weighted samples/sec (likelihood weighting)", "value": rate, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": float(dt[0]) / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
                                    f"{a.samples} samples per GPU and step (BASELINE.json configs[4])",
                        "parallelism": f"sample ranges x{world}, one RCCL all-reduce of {int(d.k.sum())} doubles per step",
-                       "node_samples_per_s": rate * d.n}}), flush=True)
+                       "node_samples_per_s": rate * d.n, "rccl_ranks": int(eng.info("rccl_ranks")), "world_size": world}}
     eng.close()
     dist.barrier()
     dog.cancel()
+    _finish(dist)
+    if rank == 0:
+        benchline.emit(out)

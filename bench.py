@@ -30,6 +30,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from bayesiannetwork_amd import benchline  # noqa: E402  (numpy only: no torch, no library, no GPU call)
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -127,9 +129,21 @@ def cpu_reference_small():
                                            "bn::inference::belief_propagation unmodified, 1 thread"}
 
 
-def measured_stream_gbs(torch):
-    """Achievable HBM rate on this box (report against the nominal peak AND a measured
-    stream figure): device-to-device copy of 1 GiB (read + write), best of 5, outside the timed region."""
+def measured_stream_gbs(torch, device=0):
+    """Achievable HBM rate on this box (report against the nominal peak AND a measured stream figure), outside the
+    timed region: the library's own streaming kernels (bn_debug_stream: 16 bytes per lane, non-temporal, 1 GiB arrays -- copy and
+    triad, best of 5), and torch's device-to-device copy_ of the same size beside them (what rounds 1-5 quoted).
+    -> {"copy": GB/s, "triad": GB/s, "torch_copy": GB/s} (a leg that fails is None)."""
+    import ctypes
+    from bayesiannetwork_amd import _lib
+    out = {"copy": None, "triad": None, "torch_copy": None}
+    for mode, key in ((0, "copy"), (1, "triad")):
+        g = ctypes.c_double(0.0)
+        try:
+            _lib.check(_lib.lib().bn_debug_stream(device, mode, 1 << 30, 5, ctypes.byref(g)))
+            out[key] = g.value
+        except Exception:  # noqa: BLE001 - informational only
+            pass
     try:
         n = 1 << 27  # doubles
         src = torch.ones(n, dtype=torch.float64, device="cuda")
@@ -143,9 +157,10 @@ def measured_stream_gbs(torch):
             e1.synchronize()
             best = max(best, 2 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
         del src, dst
-        return best
+        out["torch_copy"] = best
     except Exception:  # noqa: BLE001 - informational only
-        return None
+        pass
+    return out
 
 
 def time_bp(eng, g, eps, steps, warmup, torch, event_steps=None):
@@ -335,17 +350,23 @@ def time_host_to_host(eng, g, evs, eps, steps):
     # per-call clock, MEDIAN over the calls (this process also hosts torch's and the profiler's threads: the mean of 20 calls moved by
     # +-10 % from run to run, 0.227-0.242 ms, where the same loop alone in a process gives 0.202 +- 0.002 --
     # scripts/experiments/h2h_probe.py); the mean is reported beside it
+    # ONE statistic: the median over the calls of (messages of call i) / (time of call i) -- the sets of the cycle need different sweep counts
     steps = max(steps, 96)
-    sweeps, per_call = 0, []
+    sweeps, per_call, rates = 0, [], []
     for i in range(steps):
         t0 = time.perf_counter()
-        sweeps += eng.bp_run_view(evs[i % len(evs)], eps)["sweeps"]
-        per_call.append(time.perf_counter() - t0)
+        sw = eng.bp_run_view(evs[i % len(evs)], eps)["sweeps"]
+        dt = time.perf_counter() - t0
+        sweeps += sw
+        per_call.append(dt)
+        rates.append(g.messages_per_sweep() * sw / dt)
     per_call.sort()
+    rates.sort()
     med = per_call[len(per_call) // 2]
-    out = {"value": g.messages_per_sweep() * (sweeps / steps) / med, "unit": "edge-messages/s", "ms_per_step": med * 1e3,
+    out = {"value": rates[len(rates) // 2], "unit": "edge-messages/s", "ms_per_step": med * 1e3,
            "ms_per_step_mean": sum(per_call) / steps * 1e3, "steps": steps, "evidence_sets_cycled": len(evs), "sweeps_per_step": sweeps / steps,
-           "what": "bn_bp_run_view: evidence H2D + run to convergence + beliefs D2H (pinned), one sync, host wall clock; median over the calls"}
+           "what": "bn_bp_run_view: evidence H2D + run to convergence + beliefs D2H (pinned), one sync, host wall clock; value = median over the "
+                   "calls of messages_i / t_i, ms_per_step = median t_i"}
     # the plain entry point with a caller-owned (pageable) array, for comparison
     eng.bp_run(evs[0], eps)
     t0 = time.perf_counter()
@@ -795,9 +816,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        # no GPU call has been made yet: an error exit is safe (never re-exec after HIP initialisation)
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 as `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # `python bench.py --gpus N` typed plainly: this process -- which has made no GPU call, has not imported torch and has
+            # not loaded the library -- starts the N ranks as fresh children under torch's launcher (the command the driver uses),
+            # relays their output and exits with their code.  (Never exec or fork from a process that has initialised HIP.)
+            raise SystemExit(benchline.launch_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world and --gpus must agree")
 
     import torch  # device plumbing only: barrier / synchronize around the timed region
     from bayesiannetwork_amd import synth
@@ -820,7 +844,7 @@ def main():
                "roofline": leg["roofline"]}
         if "cpu_baseline" in leg:
             out["cpu_baseline"] = leg["cpu_baseline"]
-        print(json.dumps(out))
+        benchline.emit(out)
         return
     if a.workload in ("batch", "dagbatch"):
         # 16 evidence sets per call (bn_bp_run_batch_device) on the headline grid / on BASELINE configs[1]: the legs `batch` and
@@ -841,7 +865,7 @@ def main():
                             "frac_survey_8d": b["algorithmic_gbs"] / HBM_PEAK_GBS, "must_move_bytes_per_set_sweep": must_move,
                             "floor_hbm_us": floor_us, "note": "frac = message + node-vector bytes of a set-sweep at the HBM peak / measured time per set-sweep "
                                                               "(the CPTs stay on chip and serve every set)"}}
-        print(json.dumps(out))
+        benchline.emit(out)
         return
     if a.workload == "alarm":
         leg = leg_alarm(a, local_rank, torch)
@@ -854,7 +878,7 @@ def main():
         for k in ("tile_kernels", "batch", "cpu_baseline", "cpu_reference"):
             if k in leg:
                 out[k] = leg[k]
-        print(json.dumps(out))
+        benchline.emit(out)
         return
     if a.workload == "mid":
         leg = leg_mid(a, local_rank, torch)
@@ -866,7 +890,7 @@ def main():
         for k in ("workgroups", "tile_kernels", "batch_B64", "cpu_baseline", "mixed10k"):
             if k in leg:
                 out[k] = leg[k]
-        print(json.dumps(out))
+        benchline.emit(out)
         return
     if a.workload == "dag":
         g = synth.random_dag(10000, 4, 64, 4, seed=1)
@@ -885,7 +909,13 @@ def main():
     if label == "dag10k" and t["path"] == 0:
         label = "dag10k_launch"   # ... of the DAG with one launch per sweep (BN_DAG=0)
     roof = roofline_of(t, label)
-    roof["hbm_stream_gbs_measured"] = measured_stream_gbs(torch)
+    stream = measured_stream_gbs(torch, local_rank)
+    # the yardstick beside the nominal 8 TB/s: the better of the library's copy and triad kernels; torch's copy_ beside it
+    roof["hbm_stream_gbs_measured"] = max([v for v in (stream["copy"], stream["triad"]) if v] or [0.0]) or None
+    roof["hbm_stream_gbs_copy"], roof["hbm_stream_gbs_triad"] = stream["copy"], stream["triad"]
+    roof["hbm_stream_gbs_torch_copy"] = stream["torch_copy"]
+    if roof["hbm_stream_gbs_measured"] and roof.get("traffic_gbs"):
+        roof["frac_of_measured_stream"] = roof["traffic_gbs"] / roof["hbm_stream_gbs_measured"]   # counter traffic per second over what a pure stream reaches
     out = {
         "metric": "edge-messages/sec to BP convergence", "value": t["msgs"] / t["dt"], "unit": "edge-messages/s",
         "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t["dt"] / a.steps * 1e3,
@@ -941,7 +971,7 @@ def main():
                 out[key] = fn(a, local_rank, torch)
             except Exception as ex:  # noqa: BLE001 - an extra must never lose the headline
                 out[key] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
-    print(json.dumps(out))
+    benchline.emit(out)
 
 
 if __name__ == "__main__":

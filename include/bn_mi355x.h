@@ -232,7 +232,7 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   form).  0 = never, 1 = where measured faster (default: networks with 3-5-parent nodes, and networks of <= 2-parent nodes that fit
  *   the chip at one tile per wave -- unless the one-workgroup path takes the network, or less than a quarter of the padded tables
  *   is real: binary networks of <= 2-parent nodes), 2 = wherever eligible.
- *   bn_bp_run_batch on such a network: up to 8 evidence sets share a launch and its CPT registers, taking turns inside an iteration;
+ *   bn_bp_run_batch on such a network: up to 16 evidence sets share a launch and its CPT registers, taking turns inside an iteration;
  *   every set keeps the sweep count and the bits of its single run.
  *   bn_get_info "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts".
  * "autotune" 1 -- the NEXT run first times every execution path the engine is eligible for on the evidence in force (one warm-up and
@@ -247,7 +247,7 @@ int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
  * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
- * exchange set up), "n_boundary_nodes", "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path", "lw_small" (1 once a sampler call has run: the straight-line sampling kernel for networks whose every node has <= 4 parents, <= 256 CPT rows and <= 4 states is in use); unknown name: BN_ERR_ARG.
+ * exchange set up), "n_boundary_nodes", "rccl_ranks" (what the RCCL communicator of a sharded engine reports; 0: none), "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path", "lw_small" (1 once a sampler call has run: the straight-line sampling kernel for networks whose every node has <= 4 parents, <= 256 CPT rows and <= 4 states is in use); unknown name: BN_ERR_ARG.
  * When a one-launch path gives up a bounded wait (its workgroups were not all on the chip: another engine, stream or process uses the
  * GPU) the run is repeated on a slower path; the first such event of an engine prints ONE line on stderr, all are counted. */
 int64_t bn_get_info(bn_engine *eng, const char *name);
@@ -264,6 +264,12 @@ int bn_bp_step_sweep_part(bn_engine *eng, int32_t sweep, double eps, int32_t par
 int bn_bp_step_finish(bn_engine *eng, int32_t launched, int32_t final_batch, double eps,
                       int32_t *done_out, int32_t *sweeps_out, double *residual_out);
 int bn_debug_allgather(bn_engine **engs, int32_t n, int32_t sweep);
+/* The achievable HBM rate of a device, measured by the library's own streaming kernels (csrc/bn_stream.hip; 16 bytes per lane,
+ * non-temporal loads and stores, HIP events on a stream of its own): mode 0 = copy (bytes read + bytes written), mode 1 = triad
+ * (dst = a + s * b: 2 reads + 1 write); `bytes` = size of ONE array (take it well beyond the 256 MiB Infinity Cache); best of `reps`.
+ * The yardstick SURVEY.md 8(d) asks for beside the nominal 8 TB/s; the reference has no counterpart.  device = HIP ordinal or
+ * BN_DEVICE_CURRENT.  *gbs_out in GB/s. */
+int bn_debug_stream(int32_t device, int32_t mode, int64_t bytes, int32_t reps, double *gbs_out);
 
 typedef struct bn_bp_stats {
     int32_t sweeps;            /* iterations of the last run                                */

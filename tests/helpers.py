@@ -65,3 +65,18 @@ def hub_network(n_children, seed=77):
         at += rows * 4
         cpts.append((r / r.sum(axis=1, keepdims=True)).ravel().tolist())
     return from_parent_lists(k=[4] * len(parents), parents=parents, cpts=cpts, name=f"hub{n_children}")
+
+
+def parse_bench_output(stdout):
+    """bench.py's stdout -> (contract line as a dict, {extra name: record}).  The contract line is the LAST line of the
+    output (what the driver parses); the extras are the `{"extra": ..., "record": ...}` lines before it."""
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    line = json.loads(lines[-1])
+    assert "metric" in line, "the last stdout line is not the contract line"
+    extras = {}
+    for ln in lines[:-1]:
+        if ln.startswith('{"extra"'):
+            d = json.loads(ln)
+            extras[d["extra"]] = d["record"]
+    return line, extras

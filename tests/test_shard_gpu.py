@@ -136,9 +136,45 @@ def test_bench_multi_gpu_code_path_on_one_rank():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                         "--rows", "48", "--cols", "48"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    from helpers import parse_bench_output
+    assert p.stdout.strip().splitlines()[-1].startswith('{"metric"'), p.stdout[-1500:]
+    line, extras = parse_bench_output(p.stdout)   # the LAST stdout line is the contract line
+    assert len(p.stdout.strip().splitlines()[-1].encode()) <= 4096
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["unit"] == "edge-messages/s"
-    assert line["weak_scaling"]["value"] > 0
-    assert line["replicated_queries"]["value"] > 0
+    assert extras["weak_scaling"]["value"] > 0
+    assert extras["replicated_queries"]["value"] > 0
     for k in ("metric", "steps", "warmup", "ms_per_step", "scaling", "roofline", "config"):
         assert k in line
+    # what the communicator itself reports, and the exchange in force
+    assert line["config"]["rccl_ranks"] == 1 and line["config"]["world_size"] == 1
+    assert line["config"]["exchange"] in ("rccl all-gather per sweep", "in-kernel (peer-mapped memory)")
+
+
+def test_bench_default_line_is_the_contract_and_small():
+    """`python bench.py --gpus 1` as the driver types it (reduced steps, no CPU legs, headline only): the last stdout line is
+    the contract line -- every contract key, scalar roofline with frac and frac_survey_8d, config.workload = configs[2],
+    dtype f64 -- in at most 4 KB, with the full records on the lines before it."""
+    import os
+    import subprocess
+    import sys
+    from bayesiannetwork_amd import benchline
+    from helpers import parse_bench_output
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BN_FORCE_MULTI")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) <= benchline.MAX_LINE_BYTES
+    line, extras = parse_bench_output(p.stdout)
+    assert list(line.keys()) == [k for k in benchline.CONTRACT_KEYS if k in line]
+    for k in benchline.CONTRACT_KEYS:
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert "configs[2]" in line["config"]["workload"] and line["value"] > 1e9
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "valu") and 0 < roof["frac"] <= 1.0 and roof["frac_survey_8d"] > 0 and roof["kernel"] == "bp_resident_kernel"
+    assert roof["avg_launch_us"] > 0 and roof["sweeps_per_launch"] >= 1 and roof["hbm_stream_gbs_measured"] > 1000
+    assert all(not isinstance(v, (dict, list)) for v in roof.values())
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["value"] > 0
+    assert "roofline_full" in extras

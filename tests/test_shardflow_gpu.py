@@ -116,8 +116,26 @@ def test_bench_two_ranks_on_one_device():
            "--rows", "96", "--cols", "80"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    from helpers import parse_bench_output
+    line, extras = parse_bench_output(p.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["config"]["exchange"].startswith("in-kernel"), line["config"]
-    assert line["weak_scaling"]["exchange"].startswith("in-kernel") and line["weak_scaling"]["value"] > 0
-    assert line["replicated_queries"]["value"] > 0
+    assert extras["weak_scaling"]["exchange"].startswith("in-kernel") and extras["weak_scaling"]["value"] > 0
+    assert extras["replicated_queries"]["value"] > 0
+
+
+def test_bench_gpus_2_typed_plainly():
+    """`python bench.py --gpus 2` with no launcher around it (the form of the driver's N = 1 command): the parent starts the two
+    ranks itself as fresh processes (benchline.launch_ranks), relays rank 0's line as its own last line and exits 0.  Both ranks
+    on device 0 (BN_BENCH_SAME_DEVICE, BN_NO_RCCL): the only arrangement a one-GPU box allows."""
+    from helpers import parse_bench_output
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BN_BENCH_SAME_DEVICE="1", BN_NO_RCCL="1", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--rows", "96",
+                        "--cols", "80", "--no-weak", "--no-replicas"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert len(p.stdout.strip().splitlines()[-1].encode()) <= 4096
+    line, _ = parse_bench_output(p.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 5 and line["warmup"] == 2
+    assert line["config"]["world_size"] == 2 and line["config"]["rccl_ranks"] == 0   # (BN_NO_RCCL: no communicator was created)
+    assert line["config"]["exchange"].startswith("in-kernel")
