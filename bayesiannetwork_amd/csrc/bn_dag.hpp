@@ -70,6 +70,7 @@ static_assert(sizeof(DagParentLaneDev) == 32, "loaded as 16-byte words");
 
 struct DagPlan {
     bool ok = false;
+    bool light = false;                    // built without the CPT image (build_dag_plan's `light`)
     std::string why;
     int32_t n = 0, E = 0;
     std::vector<DagTile> tiles;            // in slot order: the tiles of wave slot s are [slot_ptr[s], slot_ptr[s + 1])
@@ -82,13 +83,15 @@ struct DagPlan {
     std::vector<DagChildLane> cnode;       // [n_tiles * 64] (child tiles' entries)
     std::vector<DagParentLane> pitem;      // [n_tiles * 64] (parent tiles' entries)
     std::vector<int32_t> oedge;            // out-edges (CSR edge ids) of every node, children ascending
-    std::vector<double> cpt_img;           // child tiles' images, double2 units x 2
+    BigVec cpt_img;                        // child tiles' images, double2 units x 2
     std::vector<double> npi_init;          // [n][4] initial pi(v): the CPT row of a root (:58-64, not normalised), else 1.0; 0 beyond the node's arity
     int32_t n_child_tiles = 0, n_parent_tiles = 0;
 };
 
 // cap_blocks: most blocks a launch may have (0.9 x CUs, rounded down to a multiple of 8; host-only engines: 224)
-void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp);
+// light: everything but the CPT image (cpt_img stays empty) -- what the default-path policy and the layout getters need; the engine
+// fills the image, builds the device tables and uploads them when the path is first wanted (bn_eng::ensure_dag)
+void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp, bool light = false);
 struct DagDeviceTables {
     std::vector<DagTile> tiles;
     std::vector<DagParentLaneDev> pitem;

@@ -29,8 +29,9 @@ inline double cost_of(const DagTile& t) {
 }
 }  // namespace
 
-void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
+void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp, bool light) {
     dp = DagPlan();
+    dp.light = light;
     const int32_t n = p.n;
     if (p.nranks != 1) { dp.why = "sharded engine"; return; }
     if (n < 1) { dp.why = "empty network"; return; }
@@ -87,7 +88,8 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
     std::vector<DagTile> tiles;
     std::vector<DagChildLane> cnode;
     std::vector<DagParentLane> pitem;
-    std::vector<double> img;
+    BigVec img;
+    size_t img_doubles = 0;
     auto new_tile = [&](int32_t kind) -> DagTile& {
         DagTile t{};
         t.kind = kind;
@@ -98,46 +100,58 @@ void build_dag_plan(const Plan& p, int32_t cap_blocks, DagPlan& dp) {
         return tiles.back();
     };
     for (int m = 0; m <= kDagMaxParents; ++m) {
-        const int G = lanes_of(m), npt = kWave / G, epl = entries_of(m), D = m > 2 ? m - 2 : 0;
+        const int G = lanes_of(m), npt = kWave / G, epl = entries_of(m);
         std::vector<int32_t> nodes;
         for (int32_t v = 0; v < n; ++v)
             if (p.in_ptr[v + 1] - p.in_ptr[v] == m) nodes.push_back(v);
         for (size_t at = 0; at < nodes.size(); at += size_t(npt)) {
             DagTile& t = new_tile(m);
             t.n_active = int32_t(std::min<size_t>(npt, nodes.size() - at));
-            t.cpt_base = int32_t(img.size() / 2);
-            img.resize(img.size() + size_t(epl) * kWave, 0.0);
-            double* im = img.data() + size_t(t.cpt_base) * 2;
-            for (int nl = 0; nl < t.n_active; ++nl) {
-                const int32_t v = nodes[at + nl];
-                const double* cpt = p.cpt_flat.data() + p.cpt_off[v];
-                for (int g = 0; g < G; ++g) {
-                    const int lane = nl * G + g;
-                    cnode[size_t(t.lane_base) + lane] = DagChildLane{v, p.in_ptr[v]};
-                    // the lane's leading-parent digits (first parent most significant) are the digits of g; its entries run
-                    // over the trailing parents (the last one fastest) and the own state: entry cl * 4 + i
-                    const int trailing = m < 2 ? m : 2, ncl = 1 << (2 * trailing);
-                    const int kv = p.k[v];
-                    for (int cl = 0; cl < ncl; ++cl)
-                        for (int i = 0; i < 4; ++i) {
-                            // the assignment in base 4, first parent most significant; the entry it names in the node's REAL table
-                            // (mixed radix of the parents' arities), or none: a parent state or an own state that does not exist
-                            const int64_t row4 = (int64_t(g) << (2 * trailing)) | cl;
-                            int64_t row = 0;
-                            bool real = i < kv;
-                            for (int j = 0; j < m; ++j) {
-                                const int digit = int((row4 >> (2 * (m - 1 - j))) & 3);
-                                const int kj = p.k[p.in_idx[p.in_ptr[v] + j]];
-                                real = real && digit < kj;
-                                row = row * kj + digit;
+            t.cpt_base = int32_t(img_doubles / 2);
+            img_doubles += size_t(epl) * kWave;
+            for (int nl = 0; nl < t.n_active; ++nl)
+                for (int g = 0; g < G; ++g) cnode[size_t(t.lane_base) + nl * G + g] = DagChildLane{nodes[at + nl], p.in_ptr[nodes[at + nl]]};
+        }
+    }
+    if (!light) {
+        // The image (light plans: the policy's features and the tile tables only -- the image is filled when the path is first used).
+        // Every child tile fills its own run: tiles are independent (parallel_for).
+        img.assign(img_doubles, 0.0);
+        const int64_t n_child = int64_t(tiles.size());
+        parallel_for(n_child, 64, [&](int64_t t_begin, int64_t t_end) {
+            for (int64_t ti = t_begin; ti < t_end; ++ti) {
+                const DagTile& t = tiles[size_t(ti)];
+                const int m = t.kind, G = lanes_of(m);
+                double* im = img.data() + size_t(t.cpt_base) * 2;
+                for (int nl = 0; nl < t.n_active; ++nl) {
+                    const int32_t v = cnode[size_t(t.lane_base) + size_t(nl) * G].node;
+                    const double* cpt = p.cpt_flat.data() + p.cpt_off[v];
+                    for (int g = 0; g < G; ++g) {
+                        const int lane = nl * G + g;
+                        // the lane's leading-parent digits (first parent most significant) are the digits of g; its entries run
+                        // over the trailing parents (the last one fastest) and the own state: entry cl * 4 + i
+                        const int trailing = m < 2 ? m : 2, ncl = 1 << (2 * trailing);
+                        const int kv = p.k[v];
+                        for (int cl = 0; cl < ncl; ++cl)
+                            for (int i = 0; i < 4; ++i) {
+                                // the assignment in base 4, first parent most significant; the entry it names in the node's REAL table
+                                // (mixed radix of the parents' arities), or none: a parent state or an own state that does not exist
+                                const int64_t row4 = (int64_t(g) << (2 * trailing)) | cl;
+                                int64_t row = 0;
+                                bool real = i < kv;
+                                for (int j = 0; j < m; ++j) {
+                                    const int digit = int((row4 >> (2 * (m - 1 - j))) & 3);
+                                    const int kj = p.k[p.in_idx[p.in_ptr[v] + j]];
+                                    real = real && digit < kj;
+                                    row = row * kj + digit;
+                                }
+                                const int q = cl * 4 + i;
+                                im[size_t(q >> 1) * (2 * kWave) + size_t(lane) * 2 + (q & 1)] = real ? cpt[row * kv + i] : 0.0;
                             }
-                            const int q = cl * 4 + i;
-                            im[size_t(q >> 1) * (2 * kWave) + size_t(lane) * 2 + (q & 1)] = real ? cpt[row * kv + i] : 0.0;
-                        }
-                    (void)D;
+                    }
                 }
             }
-        }
+        });
     }
     dp.n_child_tiles = int32_t(tiles.size());
     {

@@ -3,6 +3,8 @@
 // and the samplers' entry points: bn_engine_batch.cpp, bn_engine_shard.cpp, bn_engine_tools.cpp (bn_engine_internal.hpp has the map).
 #include "bn_engine_internal.hpp"
 
+#include <mutex>
+
 thread_local std::string bn_eng::g_err;
 RcclApi bn_eng::g_rccl;
 
@@ -32,6 +34,32 @@ int bn_eng::load_rccl() {
     return BN_OK;
 }
 
+
+// Streams of destroyed engines, kept for the next bn_create on the same device: creating a non-blocking stream costs 1.5-4 ms on an
+// MI355X box (scripts/experiments/create_split.py) -- most of what constructing a functor on an ALARM-sized network takes once the
+// runtime is up.  A parked stream is idle (free_engine synchronises it first); at most eight per process.
+namespace {
+struct ParkedStream { int device; hipStream_t stream; };
+std::mutex g_stream_mu;
+std::vector<ParkedStream> g_parked_streams;
+hipStream_t take_parked_stream(int device) {
+    std::lock_guard<std::mutex> lock(g_stream_mu);
+    for (size_t i = 0; i < g_parked_streams.size(); ++i)
+        if (g_parked_streams[i].device == device) {
+            hipStream_t s = g_parked_streams[i].stream;
+            g_parked_streams.erase(g_parked_streams.begin() + i);
+            return s;
+        }
+    return nullptr;
+}
+void park_stream(int device, hipStream_t s) {
+    if (hipStreamSynchronize(s) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        if (g_parked_streams.size() < 8) { g_parked_streams.push_back(ParkedStream{device, s}); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace
 
 void bn_eng::free_engine(bn_engine* e) {
     if (!e) return;
@@ -67,7 +95,7 @@ void bn_eng::free_engine(bn_engine* e) {
         if (e->h_ev) (void)hipHostFree(e->h_ev);
         if (e->h_beliefs) (void)hipHostFree(e->h_beliefs);
         for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-        if (e->stream) (void)hipStreamDestroy(e->stream);
+        if (e->stream) park_stream(e->device, e->stream);
     }
     delete e;
 }
@@ -102,6 +130,59 @@ int bn_eng::mid_reserve_slots(bn_engine* e, int32_t slots) {
     return BN_OK;
 }
 
+// The register-resident DAG path's full plan (padded CPT image), its device tables and their upload -- at the first use of the path.
+// bn_create builds the LIGHT plan only (tile tables + the features dag_applies reads): on the 316 x 316 grid, where the resident tiles
+// are the default, the image alone is 51 MB and 140 ms of host work nobody asked for (missing #5).
+int bn_eng::ensure_dag(bn_engine* e) {
+    if (!e->dag.ok) return fail(BN_ERR_STATE, "not eligible for the register-resident DAG path: " + (e->dag.why.empty() ? std::string("disabled") : e->dag.why));
+    if (e->dag.light) {
+        try {
+            DagPlan full;
+            build_dag_plan(e->plan, e->dag_cap, full, false);
+            if (!full.ok || full.tiles.size() != e->dag.tiles.size() || full.blocks != e->dag.blocks || full.slot_ptr != e->dag.slot_ptr)
+                return fail(BN_ERR_STATE, "the register-resident DAG plan changed between its light and its full build");
+            e->dag = std::move(full);
+            build_dag_device_tables(e->dag, e->dag_tables);
+        } catch (const std::bad_alloc&) {
+            return fail(BN_ERR_ALLOC, "out of host memory while building the register-resident DAG plan");
+        }
+    }
+    if (e->host_only || e->dag_ready) return BN_OK;
+    ON_DEVICE(e);
+    const Plan& p = e->plan;
+    const DagPlan& dp = e->dag;
+    int r2;
+    if ((r2 = upload(&e->d_g_slotptr, dp.slot_ptr, e->stream))) return r2;
+    {
+        const DagDeviceTables& dt = e->dag_tables;
+        if ((r2 = upload(&e->d_g_tiles, dt.tiles, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_cnode, dp.cnode, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_pitem, dt.pitem, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_oedge, dt.oedge, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_eperm, dt.eperm, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_nperm, dt.nperm, e->stream))) return r2;
+    }
+    if ((r2 = upload(&e->d_g_cpt, dp.cpt_img, e->stream))) return r2;
+    if ((r2 = upload(&e->d_g_init, dp.npi_init, e->stream))) return r2;
+    if (!dp.uniform4) {
+        if ((r2 = upload(&e->d_g_k, p.k, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_inptr, p.in_ptr, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_inidx, p.in_idx, e->stream))) return r2;
+        if ((r2 = upload(&e->d_g_noff, p.node_off, e->stream))) return r2;
+    }
+    const size_t sd = size_t(dag_state_doubles(dp.E, dp.n));
+    if ((r2 = dalloc(&e->d_g_state, sd))) return r2;
+    HIPCHK(hipMemsetAsync(e->d_g_state, 0, std::max<size_t>(sd, 1) * 8, e->stream));
+    if ((r2 = dalloc(&e->d_g_frz, size_t(dp.n)))) return r2;
+    HIPCHK(hipMemsetAsync(e->d_g_frz, 0, size_t(dp.n), e->stream));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_g_sync), sizeof(ResidentSync)));
+    HIPCHK(hipStreamSynchronize(e->stream));   // (upload() copies from the plan's vectors: they stay, but the order against a reload is then plain)
+    e->dag_sync_dirty = true;
+    e->dag_ev_applied = false;
+    e->dag_ready = true;
+    return BN_OK;
+}
+
 static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_engine** out) {
     if (!desc || !out) return fail(BN_ERR_ARG, "null argument");
     if (std::getenv("BN_DEBUG")) signal(SIGSEGV, debug_segv_handler);
@@ -110,6 +191,12 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     if (!e) return fail(BN_ERR_ALLOC, "out of host memory");
     if (const char* t = std::getenv("BN_TIMING")) e->timing = std::atoi(t) != 0;  // default off, see bn_engine::timing
     std::string err;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto lap = [&](int which) {   // bn_get_info "create_us_*": where the construction of this engine went
+        const auto now = std::chrono::steady_clock::now();
+        e->create_us[which] += std::chrono::duration_cast<std::chrono::microseconds>(now - t_phase).count();
+        t_phase = now;
+    };
     try {
         err = build_plan(*desc, shard, e->plan);
     } catch (const std::bad_alloc&) {
@@ -121,6 +208,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         return fail(BN_ERR_ARG, err);
     }
     const Plan& p = e->plan;
+    lap(0);
     e->grid_tiles = std::max(1, (int(p.tiles.size()) + kWavesPerBlock - 1) / kWavesPerBlock);
     // one wave past the tiles does the residual bookkeeping -> at least one spare wave
     e->stats.algorithmic_bytes_per_sweep = p.algorithmic_bytes;
@@ -134,6 +222,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             return fail(BN_ERR_ALLOC, "out of host memory while building the small-network plan");
         }
     }
+    lap(1);
     if (p.nranks == 1 && !e->small.ok && !std::getenv("BN_NO_MID")) {  // ... spread over several workgroups (bn_mid.hip)
         try {
             build_mid_plan(p, e->mid);
@@ -142,16 +231,20 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             return fail(BN_ERR_ALLOC, "out of host memory while building the mid-size plan");
         }
     }
+    lap(2);
     constexpr int32_t kDagDefaultCap = 224;  // 0.9 x 256 CUs, a multiple of 8 (rebuilt below when the device has another count)
     if (p.nranks == 1 && !std::getenv("BN_NO_DAG")) {  // k = 4, <= 5 parents: register-resident child tiles + parent items (bn_dag.hpp)
         try {
-            build_dag_plan(p, kDagDefaultCap, e->dag);
-            if (e->dag.ok) build_dag_device_tables(e->dag, e->dag_tables);
+            // LIGHT: the tile tables and the features the default-path policy reads (dag_applies) -- not the padded CPT image, not the
+            // device tables: those come with the first use of the path (ensure_dag), at once below where it is the default
+            build_dag_plan(p, kDagDefaultCap, e->dag, true);
+            e->dag_cap = kDagDefaultCap;
         } catch (const std::bad_alloc&) {   // the other paths can still run the network
             e->dag = DagPlan();
             e->dag.why = "out of host memory while building the plan";
         }
     }
+    lap(3);
     if (desc->device == BN_DEVICE_HOST_ONLY) {
         *out = e;
         return BN_OK;
@@ -163,6 +256,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
     }
     e->host_only = false;
     DeviceGuard guard;
+    const bool dev_timing = std::getenv("BN_CREATE_TIMING") != nullptr;   // where the device side of bn_create goes, one line per step on stderr
+    auto dev_t0 = std::chrono::steady_clock::now();
+    auto dev_lap = [&](const char* what) {
+        if (!dev_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bn_create] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - dev_t0).count());
+        dev_t0 = now;
+    };
     int rc = [&]() -> int {
         if (desc->device >= 0) {
             if (desc->device >= ndev) return fail(BN_ERR_ARG, "device ordinal out of range");
@@ -171,7 +272,10 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             HIPCHK(hipGetDevice(&e->device));
         }
         HIPCHK(guard.enter(e->device));
-        HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        dev_lap("device + guard");
+        e->stream = take_parked_stream(e->device);
+        if (!e->stream) HIPCHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        dev_lap("stream");
         if (p.nranks > 1) {
             HIPCHK(hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&e->ev_swept, hipEventDisableTiming));
@@ -189,6 +293,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         if ((r = upload(&e->d_slot_boff, p.slot_boff, e->stream))) return r;
         if ((r = upload(&e->d_node_tile, p.node_tile, e->stream))) return r;
         if ((r = upload(&e->d_node_nl, p.node_nl, e->stream))) return r;
+        dev_lap("tile tables + image upload");
         // shards: peers store cut-edge halves straight into these buffers from inside their kernels -> fine-grained
         // (system-coherent) allocations; BN_SHARD_COARSE=1 keeps plain hipMalloc (A/B on one device)
         e->fine_grained = p.nranks > 1 && !std::getenv("BN_SHARD_COARSE");
@@ -210,12 +315,15 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         HIPCHK(hipMemsetAsync(e->d_ctl, 0, sizeof(Ctl), e->stream));  // done_run = 0: no run is marked done
         if ((r = dalloc(&e->d_beliefs, size_t(p.node_off[p.n])))) return r;
         HIPCHK(hipMemsetAsync(e->d_beliefs, 0, std::max<size_t>(p.node_off[p.n], 1) * 8, e->stream));
+        dev_lap("state buffers");
         HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->h_ctl), sizeof(Ctl), hipHostMallocMapped));
         std::memset(e->h_ctl, 0, sizeof(Ctl));
         HIPCHK(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->h_ctl_dev), e->h_ctl, 0));
         {   // resident path (bn_resident.hip): one-lane tiles (<= 2 parents, <= 8 children per node), one wave per tile, every block co-resident (one 512-thread block of <= 256 VGPRs per CU)
+            dev_lap("h_ctl (mapped host)");
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, e->device));
+            dev_lap("hipGetDeviceProperties");
             e->n_cus = prop.multiProcessorCount;
             const int64_t nt = int64_t(p.tiles.size());
             // One 8-wave block per CU is two waves per SIMD sharing its issue slots.  A network whose tiles fit the chip at
@@ -284,6 +392,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             if (const char* f = std::getenv("BN_RESIDENT_DELAY")) e->resident_poll_margin = std::max(-1, std::min(std::atoi(f), 1000));
             if (const char* z = std::getenv("BN_POLL_SLEEP")) e->poll_sleep = std::max(0, std::min(std::atoi(z), 64));
         }
+        dev_lap("resident setup");
         {
             if (e->small.ok) {
                 const SmallPlan& sp = e->small;
@@ -304,6 +413,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
                 e->small_ok = true;
             }
         }
+        dev_lap("small path");
         if (e->mid.ok && e->n_cus > 0 && int64_t(e->mid.parts.size()) > int64_t(e->n_cus) * 9 / 10) {
             e->mid.ok = false;  // the workgroups of a run wait for each other: one per CU, with room to spare
             e->mid.why = "more workgroups than 0.9 x the device's CUs";
@@ -349,13 +459,14 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             if (const char* mm = std::getenv("BN_MID")) e->mid_mode = std::atoi(mm) != 0;
             e->mid_ok = true;
         }
+        dev_lap("mid path");
         if (e->dag.ok) {
             int32_t cap = int32_t((int64_t(e->n_cus) * 9 / 10) & ~int64_t(7));
             if (const char* c = std::getenv("BN_DAG_CAP")) cap = std::max(8, std::min(cap, std::atoi(c) & ~7));   // experiments: fewer blocks
             if (cap != kDagDefaultCap) {
                 try {
-                    build_dag_plan(p, cap, e->dag);
-                    if (e->dag.ok) build_dag_device_tables(e->dag, e->dag_tables);
+                    build_dag_plan(p, cap, e->dag, true);
+                    e->dag_cap = cap;
                 } catch (const std::bad_alloc&) {
                     e->dag = DagPlan();
                     e->dag.why = "out of host memory while building the plan";
@@ -363,38 +474,23 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
             }
         }
         if (e->dag.ok) {
-            const DagPlan& dp = e->dag;
-            int r2;
-            if ((r2 = upload(&e->d_g_slotptr, dp.slot_ptr, e->stream))) return r2;
-            {
-                const DagDeviceTables& dt = e->dag_tables;
-                if ((r2 = upload(&e->d_g_tiles, dt.tiles, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_cnode, dp.cnode, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_pitem, dt.pitem, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_oedge, dt.oedge, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_eperm, dt.eperm, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_nperm, dt.nperm, e->stream))) return r2;
-            }
-            if ((r2 = upload(&e->d_g_cpt, dp.cpt_img, e->stream))) return r2;
-            if ((r2 = upload(&e->d_g_init, dp.npi_init, e->stream))) return r2;
-            if (!dp.uniform4) {
-                if ((r2 = upload(&e->d_g_k, p.k, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_inptr, p.in_ptr, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_inidx, p.in_idx, e->stream))) return r2;
-                if ((r2 = upload(&e->d_g_noff, p.node_off, e->stream))) return r2;
-            }
-            const size_t sd = size_t(dag_state_doubles(dp.E, dp.n));
-            if ((r2 = dalloc(&e->d_g_state, sd))) return r2;
-            HIPCHK(hipMemsetAsync(e->d_g_state, 0, std::max<size_t>(sd, 1) * 8, e->stream));
-            if ((r2 = dalloc(&e->d_g_frz, size_t(dp.n)))) return r2;
-            HIPCHK(hipMemsetAsync(e->d_g_frz, 0, size_t(dp.n), e->stream));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_g_sync), sizeof(ResidentSync)));
             if (const char* dm = std::getenv("BN_DAG")) e->dag_mode = std::max(0, std::min(2, std::atoi(dm)));
-            e->dag_ok = true;
+            e->dag_ok = true;   // eligible on this device; image and tables: ensure_dag
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
+        lap(4);
+        // the register-resident DAG path where the defaults pick it: built and uploaded now (a functor's first query pays nothing);
+        // everywhere else with the first run that wants it ("dag" 2, "autotune", a batch)
+        if (dag_applies(e) && !std::getenv("BN_LAZY_ALL")) {
+            int r2;
+            if ((r2 = ensure_dag(e))) return r2;
+        }
+        lap(3);
+        dev_lap("dag path");
         HIPCHK(hipStreamSynchronize(e->stream));
-        std::vector<double>().swap(e->plan.cpt_striped);  // the image now lives in HBM
+        dev_lap("final synchronise");
+        BigVec().swap(e->plan.cpt_striped);  // the image now lives in HBM
+        lap(4);
         return BN_OK;
     }();
     if (rc != BN_OK) {
@@ -929,6 +1025,7 @@ bool bn_eng::dag_applies(const bn_engine* e) {
 
 // The evidence in force (staging block) -> the state arrays of the DAG path: marks of this set's own value, vectors in both buffers.
 static int flush_dag_evidence(bn_engine* e) {
+    if (int rc = ensure_dag(e)) return rc;
     if (e->dag_ev_applied) return BN_OK;
     if (e->dag_mark == 255) {  // the mark values are used up: start over
         HIPCHK(hipMemsetAsync(e->d_g_frz, 0, size_t(e->dag.n), e->stream));
@@ -946,6 +1043,7 @@ static int flush_dag_evidence(bn_engine* e) {
 // One launch runs the whole query (more only beyond kDagBudget iterations).  BN_ERR_STATE: a grid wait gave up.
 int bn_eng::run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_to) {
     hipStream_t s = e->stream;
+    if (int rc = ensure_dag(e)) return rc;   // (first use of the path on this engine: full plan, device tables, upload)
     const DagPlan& dp = e->dag;
     if (int rc = flush_dag_evidence(e)) return rc;
     ++e->run_id;
@@ -1278,6 +1376,12 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "nbr_max") == 0) return e->plan.nbr_max;
     if (std::strcmp(name, "nbr_chunks") == 0) return e->plan.nbr.empty() ? 0 : e->plan.nbr_chunks;
     if (std::strcmp(name, "shard_flow") == 0) return e->shard_flow_ok ? 1 : 0;
+    if (std::strncmp(name, "create_us_", 10) == 0) {   // construction split: host plans (tile / one-workgroup / several-workgroup / DAG), device side
+        static const char* const kPhase[] = {"plan", "small", "mid", "dag", "device"};
+        for (int i = 0; i < 5; ++i)
+            if (std::strcmp(name + 10, kPhase[i]) == 0) return e->create_us[i];
+        return fail(BN_ERR_ARG, std::string("unknown info ") + name);
+    }
     if (std::strcmp(name, "rccl_ranks") == 0) {   // what the communicator itself reports (0: none initialised)
         int n = 0;
         if (e->comm && g_rccl.CommCount && g_rccl.CommCount(e->comm, &n) != ncclSuccess) n = -1;

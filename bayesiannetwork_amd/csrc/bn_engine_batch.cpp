@@ -554,7 +554,7 @@ static int enqueue_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps,
     // sweeps carry an observed node's vectors over and sweep 0 reads nothing else of the old state (the single query's dag_ev_applied).
     const bool keeps = dp.uniform4 && first == 0 && count == bt.n_sets;
     const bool apply = !(keeps && bt.dag_ev_applied);
-    bt.dag_ev_applied = keeps;
+    bt.dag_ev_applied = false;   // (true again only once every launch of this chunk is on the stream: an error return below leaves no claim behind)
     if (apply) {
         if (bt.dag_mark == 255) {  // the mark values are used up: start over
             HIPCHK(hipMemsetAsync(bt.d_g_frz, 0, size_t(dp.n) * kDagMaxSets, s));
@@ -611,6 +611,7 @@ static int enqueue_batch_dag_chunk(bn_engine* e, double eps, int32_t max_sweeps,
     if (int code = launch_bp_dag(a, dp.stream, s))
         return fail(BN_ERR_HIP, std::string("bp_dag launch failed: ") + hipGetErrorString(hipError_t(code)));
     bt.dag_gen_base += kDagBudget + 1;
+    bt.dag_ev_applied = keeps;
     return BN_OK;
 }
 
@@ -638,6 +639,7 @@ static int collect_batch_dag_chunk(bn_engine* e, const DagChunk& chunk, std::vec
 }
 
 static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
+    if (int rc0 = ensure_dag(e)) return rc0;   // (first use of the path on this engine)
     bn_engine::Batch& bt = e->batch;
     const Plan& p = e->plan;
     int rc = BN_OK;
@@ -660,6 +662,7 @@ static int run_batch_dag(bn_engine* e, double eps, int32_t max_sweeps) {
         // (also after a failed enqueue: what is on the stream writes into the batch's buffers)
         const hipError_t drained = hipStreamSynchronize(e->stream);
         if (drained != hipSuccess && rc == BN_OK) rc = fail(BN_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(drained));
+        if (rc != BN_OK) bt.dag_ev_applied = false;   // (a failed enqueue or drain: the state slots may not hold this batch's evidence)
         launches += int32_t(chunks.size());
         for (const DagChunk& c : chunks) {
             const int rc_c = collect_batch_dag_chunk(e, c, left, dev_ms, max_sw);

@@ -84,6 +84,7 @@ struct RcclApi {
 struct bn_engine {
     Plan plan;
     bool host_only = true;
+    int64_t create_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bn_get_info "create_us_{plan,small,mid,dag,device}"
     bool poisoned = false;          // a bn_reload_cpt upload failed half-way: device images of mixed age, every compute call is refused
     int device = -1;
     hipStream_t stream = nullptr;
@@ -265,7 +266,9 @@ struct bn_engine {
     // k = 4 networks with up to 5 parents per node (BASELINE configs[1]): child tiles with the CPT in registers + parent items on
     // waves of their own, state in device memory, one launch per run (bn_dag.hip)
     DagPlan dag;
-    bool dag_ok = false;
+    bool dag_ok = false;            // eligible on this device (the LIGHT plan is in e->dag)
+    bool dag_ready = false;         // full plan built, device tables and image uploaded (ensure_dag)
+    int32_t dag_cap = 224;          // the block cap the plan was built for
     int dag_mode = 1;               // option "dag": 0 never, 1 where eligible and no other one-launch path takes the network, 2 wherever eligible
     int32_t dag_cooldown = 0, dag_aborts = 0;   // runs left on the tile kernels after a grid wait gave up; how often that happened
     DagTile* d_g_tiles = nullptr;
@@ -331,8 +334,8 @@ namespace bn_eng __attribute__((visibility("hidden"))) {
 extern RcclApi g_rccl;
 int load_rccl();
 
-template <class T>
-inline int upload(T** dst, const std::vector<T>& src, hipStream_t s) {
+template <class T, class A>
+inline int upload(T** dst, const std::vector<T, A>& src, hipStream_t s) {
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
     HIPCHK(hipMalloc(reinterpret_cast<void**>(dst), bytes));
     if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
@@ -347,6 +350,7 @@ inline int dalloc(T** dst, size_t count) {
 
 
 bool dag_applies(const bn_engine* e);
+int ensure_dag(bn_engine* e);
 SmallArgs small_args_of(bn_engine* e, const BpBuffers& b, double eps, int32_t max_sweeps, int32_t begin, Ctl* host_ctl);
 int mid_launch(bn_engine* e, const MidArgs& a, int32_t n_sets, const double* copy_from, double* copy_to, bool wait = true);
 MidArgs mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides& st, Ctl* h_ctl_dev, double eps, int32_t max_sweeps,

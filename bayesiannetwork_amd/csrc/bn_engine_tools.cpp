@@ -46,8 +46,8 @@ static int small_plan_copy(const SmallPlan& sp, const SmallPlan& tables, int32_t
 extern "C" int bn_dag_plan_get(bn_engine* e, int32_t* dims_out, int32_t* tiles, int32_t* slot_ptr, int32_t* cnode, int32_t* pitem,
                                int32_t* oedge, double* cpt_img, double* npi_init) {
     if (!e) return fail(BN_ERR_ARG, "null engine");
+    if (int rc = ensure_dag(e)) return rc;   // (bn_create keeps the light plan until the path or its plan is asked for)
     const DagPlan& dp = e->dag;
-    if (!dp.ok) return fail(BN_ERR_STATE, "not eligible for the register-resident DAG path: " + (dp.why.empty() ? std::string("disabled") : dp.why));
     if (dims_out) {
         const int32_t d[8] = {dp.n, dp.E, int32_t(dp.tiles.size()), dp.blocks, dp.stream ? 1 : 0, dp.n_child_tiles, dp.n_parent_tiles,
                               int32_t(dp.cpt_img.size())};
@@ -68,8 +68,8 @@ extern "C" int bn_dag_plan_get(bn_engine* e, int32_t* dims_out, int32_t* tiles, 
 // Re-derives every image that holds CPT values -- the lane-striped tile image, the entry tables of the item kernels, the
 // register image of the DAG path, the initial pi(v) of the roots -- from the new flat array and copies them over the old ones;
 // the sampler state is rebuilt at its next call.  No allocation changes size.
-template <class T>
-static int reupload(T* dst, const std::vector<T>& src, size_t expect, hipStream_t s, const char* what) {
+template <class T, class A>
+static int reupload(T* dst, const std::vector<T, A>& src, size_t expect, hipStream_t s, const char* what) {
     if (src.size() != expect) return fail(BN_ERR_STATE, std::string("bn_reload_cpt: the ") + what + " changed size (structure changed?)");
     if (!src.empty()) HIPCHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return BN_OK;
@@ -84,7 +84,7 @@ extern "C" int bn_reload_cpt(bn_engine* e, const double* cpt, int64_t n_entries)
     // Two phases.  (1) every host plan that holds CPT values is rebuilt from the new array into TEMPORARIES and checked against
     // the one in use; a mismatch returns with the engine exactly as it was.  (2) the temporaries are swapped in and the device
     // images overwritten; a HIP failure there leaves device images of mixed age, so the engine is marked unusable.
-    std::vector<double> old_flat;
+    BigVec old_flat;
     bool swapped_flat = false;
     try {
         old_flat.assign(cpt, cpt + want);
@@ -110,15 +110,22 @@ extern "C" int bn_reload_cpt(bn_engine* e, const double* cpt, int64_t n_entries)
             if (!same) return refuse("the plan of the several-workgroup path changed");
         }
         if (e->dag.ok) {
-            build_dag_plan(p, e->host_only ? 224 : std::max(e->dag.blocks, 8), n_dag);   // (the same cap gives the same plan; only the values differ)
-            if (!n_dag.ok || n_dag.cpt_img.size() != e->dag.cpt_img.size() || n_dag.blocks != e->dag.blocks || n_dag.npi_init.size() != e->dag.npi_init.size())
-                return refuse("the plan of the register-resident DAG path changed");
+            build_dag_plan(p, e->dag_cap, n_dag, e->dag.light);   // (the same cap gives the same plan; only the values differ.  A plan that is still light stays light)
+            bool same = n_dag.ok && n_dag.cpt_img.size() == e->dag.cpt_img.size() && n_dag.blocks == e->dag.blocks &&
+                        n_dag.npi_init.size() == e->dag.npi_init.size() && n_dag.tiles.size() == e->dag.tiles.size() && n_dag.slot_ptr == e->dag.slot_ptr;
+            // the device tables (tile-major record numbers, eperm / nperm) were derived from the plan in use and stay: the new image must
+            // belong to the very same tiles
+            for (size_t t = 0; same && t < n_dag.tiles.size(); ++t) {
+                const DagTile &x = n_dag.tiles[t], &y = e->dag.tiles[t];
+                same = x.kind == y.kind && x.n_active == y.n_active && x.lane_base == y.lane_base && x.cpt_base == y.cpt_base;
+            }
+            if (!same) return refuse("the plan of the register-resident DAG path changed");
         }
         if (!e->host_only) {
             ON_DEVICE(e);
             if (hipStreamSynchronize(e->stream) != hipSuccess) return refuse("the engine's stream reports an error");   // nothing of the old tables is in use any more
             stripe_cpt(p, cpt);
-            if (p.cpt_striped.size() != size_t(p.cpt_doubles)) { std::vector<double>().swap(p.cpt_striped); return refuse("the tile image changed size"); }
+            if (p.cpt_striped.size() != size_t(p.cpt_doubles)) { BigVec().swap(p.cpt_striped); return refuse("the tile image changed size"); }
         }
         // ---- commit
         if (e->small.ok) e->small = std::move(n_small);
@@ -142,12 +149,12 @@ extern "C" int bn_reload_cpt(bn_engine* e, const double* cpt, int64_t n_entries)
             HIPCHK(hipStreamSynchronize(s));   // `all` is a local
             if ((rc = reupload(e->d_m_init, e->mid.parts[0].npi_init, e->mid.parts[0].npi_init.size(), s, "initial pi"))) return rc;
         }
-        if (e->dag_ok) {
+        if (e->dag_ready) {
             if ((rc = reupload(e->d_g_cpt, e->dag.cpt_img, e->dag.cpt_img.size(), s, "register image"))) return rc;
             if ((rc = reupload(e->d_g_init, e->dag.npi_init, e->dag.npi_init.size(), s, "initial pi"))) return rc;
         }
         HIPCHK(hipStreamSynchronize(s));
-        std::vector<double>().swap(p.cpt_striped);
+        BigVec().swap(p.cpt_striped);
         lw_free(e->lw);   // the sampler uploads its copy of the tables at its next call
         e->poisoned = false;
     } catch (const std::bad_alloc&) {

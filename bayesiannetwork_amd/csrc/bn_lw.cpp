@@ -223,6 +223,8 @@ static int lw_prepare(LwState& s, const Plan& p, hipStream_t st, uint64_t want_s
         if (s.d_weights) (void)hipFree(s.d_weights);
         s.d_states = nullptr;
         s.d_weights = nullptr;
+        s.batch = 0;    // (a failure below leaves nothing that claims to be allocated: the next call starts over)
+        s.stride = 0;
         // Row stride = the row's bytes + 33 x 128: never a power of two.  With rows exactly 2^21 bytes apart the histogram pass, whose 64
         // lanes read 64 consecutive rows at the same offset, ran 48 % slower per sample (4.1 vs 2.7 ns) -- every lane's line in the
         // same cache set / memory channel.

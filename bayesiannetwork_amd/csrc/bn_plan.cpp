@@ -8,6 +8,10 @@
 #include <numeric>
 #include <unordered_map>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 namespace bnmi {
 
 static inline int32_t round_even(int32_t x) { return (x + 1) & ~1; }
@@ -44,7 +48,9 @@ void default_owner(const bn_model_desc& d, int32_t nranks, std::vector<int32_t>&
 void stripe_cpt(Plan& p, const double* cpt) {
     const int32_t n = p.n;
     p.cpt_striped.assign(size_t(p.cpt_doubles), 0.0);
-    for (int32_t v = 0; v < n; ++v) {
+    // (every node writes its own lanes of its tile's run: chunks of nodes are independent)
+    parallel_for(n, 4096, [&](int64_t v_begin, int64_t v_end) {
+    for (int32_t v = int32_t(v_begin); v < int32_t(v_end); ++v) {
         if (p.node_class[v] < 0) continue;
         const ClassDesc& c = p.classes[p.node_class[v]];
         const TileDesc& td = p.tiles[p.node_tile[v]];
@@ -70,12 +76,21 @@ void stripe_cpt(Plan& p, const double* cpt) {
                 }
         }
     }
+    });
 }
 
 std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& p) {
     // lanes_per_node: 0 automatic, 2 dense (automatic without the any-arity rule for nodes with many children),
     // 3 / 4 = 0 / 2 plus the wide lane-group split on small networks (bn_mi355x.h)
     bn_model_desc d = d_in;
+    const bool plan_timing = std::getenv("BN_PLAN_TIMING") != nullptr;   // where build_plan's time goes, one line per section on stderr
+    auto plan_t0 = std::chrono::steady_clock::now();
+    auto plan_lap = [&](const char* what) {
+        if (!plan_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bn_plan] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - plan_t0).count());
+        plan_t0 = now;
+    };
     const bool latency_rules = d_in.lanes_per_node == 0 || d_in.lanes_per_node == 3;
     const bool wide_requested = d_in.lanes_per_node == 3 || d_in.lanes_per_node == 4;
     if (d.lanes_per_node >= 2 && d.lanes_per_node <= 4) d.lanes_per_node = 0;
@@ -126,6 +141,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     p.msg_off.assign(p.E + 1, 0);
     for (int64_t e = 0; e < p.E; ++e) p.msg_off[e + 1] = p.msg_off[e] + p.k[p.in_idx[e]];
 
+    plan_lap("validate");
     // ---- ownership
     const int32_t me = p.rank;
     if (p.nranks > 1) {
@@ -142,6 +158,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     for (int32_t v = 0; v < n; ++v)
         for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e) edge_child[e] = v;
 
+    plan_lap("ownership");
     // ---- children (ascending) with the CSR edge id of each out-edge
     std::vector<int32_t> out_ptr(n + 1, 0), out_edge(std::max<int64_t>(p.E, 1));
     for (int64_t e = 0; e < p.E; ++e) out_ptr[p.in_idx[e] + 1]++;
@@ -184,6 +201,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
         p.group_wide = group_wide;
     }
 
+    plan_lap("children");
     // ---- which nodes have a templated variant, which can take the any-arity variant
     auto shape_of = [&](int32_t v, bool& templated, bool& flat_ok) {
         const int32_t kv = p.k[v], m = p.in_ptr[v + 1] - p.in_ptr[v];
@@ -222,6 +240,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
         prefer_flat = n_flat_only >= 2 * n_templ && n_convertible == n_templ && n_flat_only > 0;
     }
 
+    plan_lap("variants");
     // ---- shape classes over the owned nodes
     std::map<std::vector<int32_t>, int32_t> sig2cls;
     p.node_class.assign(n, -1);
@@ -323,6 +342,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
         p.g_max = std::max(p.g_max, p.classes[it->second].G);
     }
 
+    plan_lap("classes");
     // ---- tiles: per class, ascending node id, NPT nodes each; tile order by first node id
     struct ProtoTile { int32_t cls; std::vector<int32_t> nodes; bool boundary; };
     std::vector<ProtoTile> proto;
@@ -422,6 +442,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
             p.slot_boff[p.node_slot[v]] = p.node_off[v];
         }
 
+    plan_lap("tiles");
     // ---- exchange region: every rank derives the same segment layout from the global graph.
     // Halves are enumerated in CSR edge order; the pi-half of a cut edge belongs to the parent's
     // owner, the lambda-half to the child's owner.
@@ -452,14 +473,16 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
     p.rec_total_doubles = rec_cur + 2 * p.seg_d2 * p.nranks;
     if (cpt_cur / 2 > INT32_MAX || p.rec_total_doubles / 2 > INT32_MAX) return "model too large for 32-bit record indices";
 
+    plan_lap("exchange");
     // ---- CPT image: i-major per node, assignments split over the G lanes of the node
-    p.cpt_striped.assign(cpt_cur, 0.0);
-    p.cpt_doubles = cpt_cur;
+    p.cpt_doubles = cpt_cur;   // (stripe_cpt sizes and fills p.cpt_striped)
     if (n > 0) p.cpt_off.assign(d.cpt_off, d.cpt_off + n + 1);
     else p.cpt_off.assign(1, 0);
     p.cpt_flat.assign(d.cpt, d.cpt + (n ? d.cpt_off[n] : 0));
+    plan_lap("cpt flat copy");
     stripe_cpt(p, d.cpt);
 
+    plan_lap("cpt image");
     // ---- where each edge's messages live on this rank
     auto seg_index = [&](int32_t r, int64_t off) { return int32_t(p.g_base + int64_t(r) * p.seg_d2 + off); };
     p.edge_ref.assign(std::max<int64_t>(p.E, 1), MsgRef{-1, 0});
@@ -491,6 +514,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
                 p.in_refs[td.in_ref_base + int64_t(j) * c.npt + p.node_nl[v]] = p.edge_ref[p.in_ptr[v] + j];
     }
 
+    plan_lap("edge refs");
     // ---- neighbour tiles (dataflow form of the resident kernel): the tiles of the parents and children of a tile's
     // nodes on this rank, ascending, without the tile itself; across a cut edge the peer's node stands in for its
     // tile until the peer's export blob names it (bn_engine_shard.cpp: bn_peer_import)
@@ -528,6 +552,7 @@ std::string build_plan(const bn_model_desc& d_in, const ShardSpec& shard, Plan& 
         (void)err;  // too many neighbours: nbr stays empty, the plan is not eligible for the dataflow form
     }
 
+    plan_lap("neighbour tiles");
     // ---- metrics, this rank's share: CPT of owned nodes once; every message it
     // produces and every owned node vector read once and written once
     int64_t vec = 0, cpt_owned = 0, msgs = 0;

@@ -36,6 +36,15 @@
 // same sweep.  With one rank the region holds just the residual slots.
 #pragma once
 
+#include <sys/mman.h>
+
+#include <new>
+#include <algorithm>
+#include <cstdlib>
+#include <exception>
+#include <mutex>
+#include <system_error>
+#include <thread>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -43,6 +52,62 @@
 #include "../../include/bn_mi355x.h"
 
 namespace bnmi {
+
+// Host buffers of tens of MB (the model's flat CPT copy, the lane-striped tile image, the DAG path's padded image): on 4 KiB pages
+// a fresh 51 MB vector costs 12 500 first-touch faults -- 30 ms each on the boxes this was measured on, three of them per bn_create of
+// the 316 x 316 grid.  Allocations of 4 MiB and more are 2 MiB-aligned and marked MADV_HUGEPAGE (transparent huge pages in `madvise`
+// mode: 26 faults instead); smaller ones go to malloc as before.
+template <class T>
+struct HugeAlloc {
+    typedef T value_type;
+    HugeAlloc() = default;
+    template <class U> HugeAlloc(const HugeAlloc<U>&) {}
+    static constexpr size_t kHuge = size_t(2) << 20;
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        void* q = nullptr;
+        if (bytes >= 2 * kHuge) {
+            const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+            q = std::aligned_alloc(kHuge, rounded);
+            if (q) (void)madvise(q, rounded, MADV_HUGEPAGE);
+        } else {
+            q = std::malloc(bytes ? bytes : 1);
+        }
+        if (!q) throw std::bad_alloc();
+        return static_cast<T*>(q);
+    }
+    void deallocate(T* q, size_t) { std::free(q); }
+    template <class U> bool operator==(const HugeAlloc<U>&) const { return true; }
+    template <class U> bool operator!=(const HugeAlloc<U>&) const { return false; }
+};
+typedef std::vector<double, HugeAlloc<double>> BigVec;
+
+// Host-side loops over independent nodes / tiles (the CPT images: tens of MB of scattered copies at 10^5 nodes) on a few threads:
+// fn(begin, end) over [0, n) in contiguous chunks of at least `grain`; BN_HOST_THREADS caps the count (default: up to 8).
+// An exception in a worker (bad_alloc) is rethrown in the caller after all have joined.
+template <class F>
+inline void parallel_for(int64_t n, int64_t grain, F&& fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t T = std::min<int64_t>(hw ? hw : 1, 8);
+    if (const char* t = std::getenv("BN_HOST_THREADS")) T = std::max(1, std::atoi(t));
+    T = std::min<int64_t>(T, grain > 0 ? n / grain : n);
+    if (T <= 1) { fn(int64_t(0), n); return; }
+    std::vector<std::thread> th;
+    std::exception_ptr err;
+    std::mutex mu;
+    const int64_t per = (n + T - 1) / T;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t b = t * per, e = std::min(n, b + per);
+        if (b >= e) break;
+        auto body = [&, b, e] {
+            try { fn(b, e); } catch (...) { std::lock_guard<std::mutex> g(mu); if (!err) err = std::current_exception(); }
+        };
+        try { th.emplace_back(body); } catch (const std::system_error&) { body(); }   // (no thread to be had: the caller does the chunk)
+    }
+    for (std::thread& x : th) x.join();
+    if (err) std::rethrow_exception(err);
+}
+
 
 constexpr int kWave = 64;
 constexpr int kResSlots = 256;              // residual slots per rank (spread the atomics)
@@ -161,10 +226,10 @@ struct Plan {
     int64_t seg_data_d2 = 0;         // message halves per segment (max over ranks, padded)
     std::vector<int64_t> seg_used_d2;  // [nranks] halves actually produced by each rank
     // device images
-    std::vector<double> cpt_striped;  // released after upload (cpt_doubles keeps the size)
+    BigVec cpt_striped;  // released after upload (cpt_doubles keeps the size)
     int64_t cpt_doubles = 0;
     std::vector<int64_t> cpt_off;     // [n+1] reference-order flat CPT (kept for likelihood weighting)
-    std::vector<double> cpt_flat;
+    BigVec cpt_flat;
     std::vector<MsgRef> out_refs;    // per tile [c][nl]
     std::vector<MsgRef> in_refs;     // per boundary tile [j][nl]
     int64_t rec_doubles = 0;         // tile records only

@@ -14,27 +14,31 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 constexpr int kThreads = 256;
 constexpr int kUnroll = 4;   // 16-byte loads in flight per lane before the first store
 
-// mode 0: dst = src (one read, one write per element); mode 1: dst = a + s * b (two reads, one write)
+// mode 0: dst = src (one read, one write per element); mode 1: dst = a + s * b (two reads, one write).
+// One workgroup = one contiguous run of kUnroll x 256 elements (16 KiB per array), all of its loads in flight before the first store,
+// no loop: of the forms scripts/experiments/stream_probe.hip compares (grid-stride with 256 .. 65 536 workgroups, contiguous chunks
+// per workgroup, plain / non-temporal on either side) this one reaches the most on an MI355X -- 6.1-6.3 TB/s copy, 6.0-6.5 triad on
+// 1-2 GiB arrays; persistent grid-stride workgroups stay at 4.7-5.4, hipMemcpyAsync and torch's copy_ at 5.0-5.6.
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void stream_kernel(v2d* __restrict__ dst, const v2d* __restrict__ a, const v2d* __restrict__ b,
                                                           double s, size_t n) {
-    const size_t stride = size_t(gridDim.x) * kThreads;
-    size_t i = size_t(blockIdx.x) * kThreads + threadIdx.x;
-    for (; i + (kUnroll - 1) * stride < n; i += kUnroll * stride) {
+    const size_t base = size_t(blockIdx.x) * (kUnroll * kThreads) + threadIdx.x;
+    if (base + (kUnroll - 1) * kThreads < n) {
         v2d x[kUnroll], y[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            x[u] = __builtin_nontemporal_load(a + i + u * stride);
-            if (MODE == 1) y[u] = __builtin_nontemporal_load(b + i + u * stride);
+            x[u] = __builtin_nontemporal_load(a + base + u * kThreads);
+            if (MODE == 1) y[u] = __builtin_nontemporal_load(b + base + u * kThreads);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             v2d r = x[u];
             if (MODE == 1) r = x[u] + s * y[u];
-            __builtin_nontemporal_store(r, dst + i + u * stride);
+            __builtin_nontemporal_store(r, dst + base + u * kThreads);
         }
+        return;
     }
-    for (; i < n; i += stride) {
+    for (size_t i = base; i < n; i += kThreads) {   // the last, partial run
         v2d r = __builtin_nontemporal_load(a + i);
         if (MODE == 1) r = r + s * __builtin_nontemporal_load(b + i);
         __builtin_nontemporal_store(r, dst + i);
@@ -60,9 +64,9 @@ double bn_stream_measure(int mode, size_t bytes, int reps, double* check_out) {
         if (done(hipMalloc(&d, n * sizeof(v2d))) || done(hipMalloc(&a, n * sizeof(v2d)))) break;
         if (mode == 1 && done(hipMalloc(&b, n * sizeof(v2d)))) break;
         if (done(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) || done(hipEventCreate(&e0)) || done(hipEventCreate(&e1))) break;
-        const int grid = 256 * 8;   // eight 256-thread workgroups per CU: every SIMD holds two waves of loads
-        stream_fill_kernel<<<grid, kThreads, 0, st>>>(a, n, 1.0);
-        if (b) stream_fill_kernel<<<grid, kThreads, 0, st>>>(b, n, 2.0);
+        const int grid = int((n + kUnroll * kThreads - 1) / (kUnroll * kThreads));
+        stream_fill_kernel<<<2048, kThreads, 0, st>>>(a, n, 1.0);
+        if (b) stream_fill_kernel<<<2048, kThreads, 0, st>>>(b, n, 2.0);
         for (int r = 0; r < reps + 1; ++r) {   // (the first repetition also pages the code object in: not counted)
             if (done(hipEventRecord(e0, st))) break;
             if (mode == 1) stream_kernel<1><<<grid, kThreads, 0, st>>>(d, a, b, 0.5, n);

@@ -664,46 +664,61 @@ def leg_mid(a, local_rank, torch):
     return out
 
 
-def leg_lw(a, local_rank, torch):
-    """BASELINE configs[4] on one GPU: weighted samples/s on the 10 k-node DAG with 1 % evidence."""
+def measured_valu_issue_peak():
+    """G wave-instructions/s this chip sustains on dependent integer code under load (scripts/experiments/valu_clock.hip), read from the
+    committed experiment output (profiles/valu_issue.json) rather than quoted as a literal; None when absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu_issue.json")))["g_wave_insts_per_s"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def leg_lw(a, local_rank, torch, generic=False):
+    """BASELINE configs[4] on one GPU: weighted samples/s on the 10 k-node DAG with 1 % evidence (the straight-line sampling kernel:
+    every node <= 4 states, <= 4 parents, <= 256 rows).  generic=True: the GENERIC sampling kernel (lw_sample_kernel + lw_hist_kernel)
+    on `mixed10k` -- 10 000 nodes of arities 2-5, outside the straight-line kernel's domain -- 10^6 samples per call
+    (reference likelihood_weighting.hpp:122-193)."""
     from bayesiannetwork_amd import synth
     from bayesiannetwork_amd.engine import Engine
-    d = synth.random_dag(10000, 4, 64, 4, seed=1)
+    if generic:
+        d = synth.random_dag(10000, 3, 16, [2, 3, 4, 3, 2, 4, 5], seed=20)
+        samples, label = min(a.samples, 1000000), "lwgen"
+    else:
+        d = synth.random_dag(10000, 4, 64, 4, seed=1)
+        samples, label = a.samples, "lw"
     ev = synth.random_evidence(d, a.evidence, seed=7).hard_states(d)
     steps = max(1, min(a.steps, 5))
     with Engine(d, device=local_rank) as eng:
         for w in range(2):
-            eng.lw_run(ev, a.samples, seed=1, sample_begin=w * a.samples)
+            eng.lw_run(ev, samples, seed=1, sample_begin=w * samples)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            eng.lw_run(ev, a.samples, seed=1, sample_begin=(i + 2) * a.samples)
+            eng.lw_run(ev, samples, seed=1, sample_begin=(i + 2) * samples)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         small_kernel = bool(eng.info("lw_small"))
-    rate = a.samples * steps / dt
+    assert small_kernel != generic, "the sampling kernel that ran is not the one this leg is about"
+    rate = samples * steps / dt
     # What bounds the sampler: not HBM (the CPTs are cache-resident, SURVEY 8(d)) but the vector ALU and the row gathers.  The
     # bound reported is VALU ISSUE: vector instructions per second (SQ_INSTS_VALU of the committed counter pass, per sample, x the
     # measured sample rate) against what the chip can issue (CUs x 4 SIMDs x clock / 4 cycles per 64-lane instruction).
     bytes_per_sample = (d.n * 2 + d.n_edges) // (4 if small_kernel else 1)   # state written, parents' states read, re-read by the histogram pass (informational); two bits per state on the straight-line kernel
     peak_ginst = 256 * 4 * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_INST    # G wave-instructions / s
     roof = {"bound": "valu", "peak": peak_ginst, "unit": "G wave-instructions/s", "achieved": None, "frac": None,
-            "kernel": ("lw_sample_small_kernel" if small_kernel else "lw_sample_kernel") + " + lw_hist_kernel", "hbm_algorithmic_bytes_per_sample": bytes_per_sample,
-            "hbm_algorithmic_gbs": rate * bytes_per_sample / 1e9,
-            "limiter": "vector issue (frac), after memory traffic (two bits per state, bounded table copies) and latency (loads two positions ahead) "
-                       "were taken out of the way; the histogram pass runs at ~80 % of its fp64 issue rate",
-            "peak_measured_integer_issue": 700.0,
+            "kernel": ("lw_sample_small_kernel + lw_hist2_kernel" if small_kernel else "lw_sample_kernel + lw_hist_kernel"),
+            "hbm_algorithmic_bytes_per_sample": bytes_per_sample, "hbm_algorithmic_gbs": rate * bytes_per_sample / 1e9,
+            "peak_measured_integer_issue": measured_valu_issue_peak(),
             "note": "frac = vector instructions issued per second (SQ_INSTS_VALU per sample of the committed SQ pass, sampling + histogram kernels, x measured "
-                    "samples/s) over one instruction per SIMD and four cycles at 2.4 GHz; on dependent integer code this chip sustains 700 G/s "
-                    "(scripts/experiments/valu_clock.hip).  What bounds the sampler is in `limiter` (DESIGN.md section 4.7)"}
-    roof.update(profiled_traffic("lw"))
+                    "samples/s) over one instruction per SIMD and four cycles at 2.4 GHz (DESIGN.md section 4.7)"}
+    roof.update(profiled_traffic(label))
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if name.endswith("_summary.json"):
             dd = json.load(open(os.path.join(pdir, name)))
-            sq = dd.get("lw_sq_counters_per_launch") or {}
-            per_launch = dd.get("lw_samples_per_launch")
-            hq = dd.get("lw_hist_sq_counters_per_launch") or {}
+            sq = dd.get(f"{label}_sq_counters_per_launch") or {}
+            per_launch = dd.get(f"{label}_samples_per_launch")
+            hq = dd.get(f"{label}_hist_sq_counters_per_launch") or {}
             if sq.get("SQ_INSTS_VALU") and per_launch:
                 inst_per_sample = (sq["SQ_INSTS_VALU"] + hq.get("SQ_INSTS_VALU", 0.0)) / per_launch   # (both kernels run once per launch of samples)
                 roof["valu_insts_per_sample_sampler"] = sq["SQ_INSTS_VALU"] / per_launch
@@ -712,9 +727,11 @@ def leg_lw(a, local_rank, torch):
                              "achieved": rate * inst_per_sample / 1e9, "frac": rate * inst_per_sample / 1e9 / peak_ginst,
                              "valu_source": f"profiles/{name}",
                              "valu_stale": not (dd.get("lib_sha256") is not None and dd.get("lib_sha256") == lib_sha256())})
-    out = {"workload": f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
-                       f"{a.samples} samples per call = per step (BASELINE.json configs[4]: 10 M weighted samples)",
-           "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+    what = (f"likelihood weighting (generic sampling kernel), 10 k-node random DAG of arities 2-5, <= 3 parents, {int((ev >= 0).sum())} evidence nodes, "
+            f"{samples} samples per call = per step" if generic else
+            f"likelihood weighting, 10 k-node random DAG, {int((ev >= 0).sum())} evidence nodes, "
+            f"{samples} samples per call = per step (BASELINE.json configs[4]: 10 M weighted samples)")
+    out = {"workload": what, "value": rate, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
            "node_samples_per_s": rate * d.n, "roofline": roof}
     if not a.no_cpu:
         import oracle
@@ -724,10 +741,15 @@ def leg_lw(a, local_rank, torch):
         dtc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n_cpu / dtc, "unit": "samples/s", "cores": 1, "kind": "port",
                                "sample": f"{n_cpu} samples of the same workload, oracle/lw_oracle.c, 1 thread"}
+    if not generic and not getattr(a, "no_extras", False) and a.workload != "lw":
+        try:
+            out["generic_mixed10k"] = leg_lw(a, local_rank, torch, generic=True)
+        except Exception as ex:  # noqa: BLE001
+            out["generic_mixed10k"] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
     return out
 
 
-def time_batches(eng, g, a, torch, sizes):
+def time_batches(eng, g, a, torch, sizes, cycled=True):
     """Throughput of bn_bp_run_batch_device over all sets of a call, for each batch size in `sizes`."""
     from bayesiannetwork_amd import synth
     out = {}
@@ -748,7 +770,27 @@ def time_batches(eng, g, a, torch, sizes):
         st = eng.bp_stats()
         out[f"B{B}"] = {"value": g.messages_per_sweep() * sweeps / dt, "unit": "edge-messages/s", "ms_per_call": dt / steps * 1e3,
                        "set_sweeps_per_call": sweeps / steps, "us_per_set_sweep": dt / sweeps * 1e6,
-                       "algorithmic_gbs": st["algorithmic_bytes_per_sweep"] * sweeps / dt / 1e9, "path": PATH_NAME.get(eng.last_path())}
+                       "algorithmic_gbs": st["algorithmic_bytes_per_sweep"] * sweeps / dt / 1e9, "path": PATH_NAME.get(eng.last_path()),
+                       "what": "the SAME staged batch run again and again (a one-launch DAG batch then finds its evidence in place)"}
+        if cycled:
+            # two DIFFERENT batches alternate: every call has to put its evidence in force (a stream of different queries); staging
+            # (bn_bp_set_evidence_batch: H2D of the packed sets) outside the clock, the clock around bn_bp_run_batch_device only
+            evs2 = [synth.random_evidence(g, a.evidence, seed=1007 + q) for q in range(B)]
+            for i in range(4):
+                eng.bp_set_evidence_batch(evs2 if i & 1 else evs)
+                eng.bp_run_batch_device(a.eps)
+            dtc, swc = 0.0, 0
+            for i in range(steps):
+                eng.bp_set_evidence_batch(evs2 if i & 1 else evs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = eng.bp_run_batch_device(a.eps)
+                dtc += time.perf_counter() - t0
+                swc += int(r["sweeps"].sum())
+            out[f"B{B}"]["cycled"] = {"value": g.messages_per_sweep() * swc / dtc, "unit": "edge-messages/s", "ms_per_call": dtc / steps * 1e3,
+                                     "set_sweeps_per_call": swc / steps, "us_per_set_sweep": dtc / swc * 1e6, "batches_cycled": 2,
+                                     "what": "two different staged batches alternate (every call applies its evidence); staging outside the "
+                                             "clock, the clock around bn_bp_run_batch_device only"}
     return out
 
 
@@ -797,7 +839,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["grid", "dag", "lw", "alarm", "mid", "batch", "dagbatch"], default="grid",
+    ap.add_argument("--workload", choices=["grid", "dag", "lw", "lwgen", "alarm", "mid", "batch", "dagbatch"], default="grid",
                     help="grid = BASELINE configs[2] (headline); dag = configs[1], 10 k-node random DAG; "
                          "lw = configs[4], likelihood weighting on the 10 k-node DAG")
     ap.add_argument("--samples", type=int, default=10000000, help="lw: weighted samples per step = per bn_lw_run call (BASELINE configs[4]: 10 M)")
@@ -835,8 +877,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     default_run = a.workload == "grid" and (a.rows, a.cols) == (316, 316)
-    if a.workload == "lw":
-        leg = leg_lw(a, local_rank, torch)
+    if a.workload in ("lw", "lwgen"):
+        leg = leg_lw(a, local_rank, torch, generic=a.workload == "lwgen")
         out = {"metric": "weighted samples/sec (likelihood weighting)", "value": leg["value"], "unit": "samples/s",
                "n_gpus": 1, "steps": leg["steps"], "warmup": 2, "ms_per_step": leg["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

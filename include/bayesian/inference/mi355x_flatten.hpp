@@ -12,9 +12,15 @@
 #ifndef BN_MI355X_FLATTEN_HPP
 #define BN_MI355X_FLATTEN_HPP
 
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <exception>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -96,8 +102,41 @@ struct flat_model {
     }
 };
 
+// fn(begin, end) over [0, n) in contiguous chunks on a few threads (BN_HOST_THREADS caps the count; default up to 32, one
+// thread below `grain` items per thread).  An exception in a worker is rethrown in the caller after all have joined.
+template <class F>
+inline void for_chunks(std::size_t const n, std::size_t const grain, F&& fn)
+{
+    std::size_t threads = std::min<std::size_t>(std::max(1u, std::thread::hardware_concurrency()), 32);
+    if(char const* t = std::getenv("BN_HOST_THREADS")) threads = static_cast<std::size_t>(std::max(1, std::atoi(t)));
+    threads = std::min(threads, grain ? n / grain : n);
+    if(threads <= 1) { fn(std::size_t(0), n); return; }
+    std::vector<std::thread> pool;
+    std::exception_ptr error;
+    std::mutex guard;
+    std::size_t const per = (n + threads - 1) / threads;
+    for(std::size_t t = 0; t < threads; ++t)
+    {
+        std::size_t const b = t * per, e = std::min(n, b + per);
+        if(b >= e) break;
+        auto body = [&, b, e]
+        {
+            try { fn(b, e); }
+            catch(...) { std::lock_guard<std::mutex> lock(guard); if(!error) error = std::current_exception(); }
+        };
+        try { pool.emplace_back(body); }
+        catch(std::system_error const&) { body(); }   // no thread to be had: this one does the chunk
+    }
+    for(auto& th : pool) th.join();
+    if(error) std::rethrow_exception(error);
+}
+
 // Structure only (arities, parents, CPT offsets); fm.cpt stays empty.  with_cpt = true also reads
 // every CPT row.
+// Reading the rows is what a functor's construction costs: cpt_t's interface hands out ONE row per call, keyed by a condition_t (an
+// unordered_map) that operator[] takes BY VALUE (graph.hpp:108) -- a map copy, its hash and a find per row, 1.6 M times on the
+// 316 x 316 grid (0.3 s on one core).  The rows of different nodes are independent and the graph is only read: nodes are spread
+// over a few threads, and a node's condition is kept and stepped like an odometer instead of being rebuilt per row.
 inline flat_model flatten_impl(graph_t const& graph, bool const with_cpt)
 {
     flat_model fm;
@@ -119,39 +158,47 @@ inline flat_model flatten_impl(graph_t const& graph, bool const with_cpt)
     for(std::size_t i = 0; i < n; ++i)
     {
         auto const parents = graph.in_vertexes(fm.nodes[i]);
-        std::vector<std::int32_t> radix;
+        std::size_t rows = 1;
         for(auto const& p : parents)
         {
             auto const it = fm.index.find(p);
             if(it == fm.index.end()) throw std::runtime_error("bn::mi355x::flatten: parent is not in vertex_list()");
             fm.in_idx.push_back(it->second);
-            radix.push_back(fm.k[it->second]);
+            rows *= static_cast<std::size_t>(fm.k[it->second]);
         }
         fm.in_ptr[i + 1] = static_cast<std::int32_t>(fm.in_idx.size());
-
-        std::size_t rows = 1;
-        for(auto r : radix) rows *= static_cast<std::size_t>(r);
         fm.cpt_off[i + 1] = fm.cpt_off[i] + static_cast<std::int64_t>(rows) * fm.k[i];
-        if(!with_cpt) continue;
+    }
+    if(!with_cpt) return fm;
 
-        // every parent assignment, first parent slowest
-        std::vector<int> state(parents.size(), 0);
-        for(std::size_t row = 0; row < rows; ++row)
+    fm.cpt.resize(static_cast<std::size_t>(fm.cpt_off[n]));
+    for_chunks(n, 256, [&](std::size_t const begin, std::size_t const end)
+    {
+        for(std::size_t i = begin; i < end; ++i)
         {
+            std::size_t const m = static_cast<std::size_t>(fm.in_ptr[i + 1] - fm.in_ptr[i]);
+            std::int32_t const* const par = fm.in_idx.data() + fm.in_ptr[i];
+            std::size_t const kv = static_cast<std::size_t>(fm.k[i]);
+            // every parent assignment, first parent slowest
+            std::vector<int> state(m, 0);
             condition_t cond;
-            for(std::size_t j = 0; j < parents.size(); ++j) cond[parents[j]] = state[j];
-            auto const entry = fm.nodes[i]->cpt[cond];
-            if(!entry.first || entry.second.size() != static_cast<std::size_t>(fm.k[i]))
-                throw std::runtime_error("bn::mi355x::flatten: CPT row missing or of wrong length at node "
-                                         + std::to_string(i));
-            fm.cpt.insert(fm.cpt.end(), entry.second.begin(), entry.second.end());
-            for(std::size_t j = parents.size(); j-- > 0;)
+            for(std::size_t j = 0; j < m; ++j) cond[fm.nodes[par[j]]] = 0;
+            double* out = fm.cpt.data() + fm.cpt_off[i];
+            for(std::int64_t o = fm.cpt_off[i]; o < fm.cpt_off[i + 1]; o += fm.k[i], out += kv)
             {
-                if(++state[j] < radix[j]) break;
-                state[j] = 0;
+                auto const entry = fm.nodes[i]->cpt[cond];
+                if(!entry.first || entry.second.size() != kv)
+                    throw std::runtime_error("bn::mi355x::flatten: CPT row missing or of wrong length at node " + std::to_string(i));
+                std::copy(entry.second.begin(), entry.second.end(), out);
+                for(std::size_t j = m; j-- > 0;)   // the next assignment: only the digits that change are written
+                {
+                    if(++state[j] < fm.k[par[j]]) { cond[fm.nodes[par[j]]] = state[j]; break; }
+                    state[j] = 0;
+                    cond[fm.nodes[par[j]]] = 0;
+                }
             }
         }
-    }
+    });
     return fm;
 }
 

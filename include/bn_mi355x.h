@@ -247,7 +247,7 @@ int bn_set_option(bn_engine *eng, const char *name, int32_t value);
 int bn_bp_last_path(bn_engine *eng);
 /* Named integer properties (tests, tools): "resident_eligible", "flow_eligible", "last_flow" (1: the last run
  * used the dataflow form), "nbr_max", "nbr_chunks", "resident_blocks", "resident_aborts", "shard_flow" (in-kernel
- * exchange set up), "n_boundary_nodes", "rccl_ranks" (what the RCCL communicator of a sharded engine reports; 0: none), "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path", "lw_small" (1 once a sampler call has run: the straight-line sampling kernel for networks whose every node has <= 4 parents, <= 256 CPT rows and <= 4 states is in use); unknown name: BN_ERR_ARG.
+ * exchange set up), "n_boundary_nodes", "rccl_ranks" (what the RCCL communicator of a sharded engine reports; 0: none), "small_eligible", "small_waves", "small_lds_bytes", "mid_eligible", "mid_parts", "mid_aborts", "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts", "autotuned", "autotuned_path", "create_us_plan" / "create_us_small" / "create_us_mid" / "create_us_dag" / "create_us_device" (microseconds bn_create spent on the host plans -- tile layout, one-workgroup, several-workgroup, register-resident DAG -- and on the device side: allocations + uploads; bn_create builds the plan and image of the register-resident DAG path only where the defaults pick that path, elsewhere its image is filled and uploaded by the first run that wants it -- "dag" 2, "autotune", a batch), "lw_small" (1 once a sampler call has run: the straight-line sampling kernel for networks whose every node has <= 4 parents, <= 256 CPT rows and <= 4 states is in use); unknown name: BN_ERR_ARG.
  * When a one-launch path gives up a bounded wait (its workgroups were not all on the chip: another engine, stream or process uses the
  * GPU) the run is repeated on a slower path; the first such event of an engine prints ONE line on stderr, all are counted. */
 int64_t bn_get_info(bn_engine *eng, const char *name);

@@ -6,7 +6,7 @@
 # Every pass puts the program itself after `--` (no env / shell hop); switches travel as exported
 # environment variables.  A pass that fails is recorded in failed_passes.txt and reported by the summary.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 export BN_BENCH_NO_SETTLE=1   # bench.py's quarter second of untimed runs before the warm-up steps would be thousands of rows in every trace
@@ -62,6 +62,12 @@ pmc fetch_lw FETCH_SIZE $B --workload lw --steps 2
 pmc write_lw WRITE_SIZE $B --workload lw --steps 2
 pmc sq_lw "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload lw --steps 2
 pmc sq2_lw "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload lw --steps 2
+# ... and the generic sampling kernel (mixed10k: arities 2-5), 10^6 samples per call
+trace trace_lwgen $B --workload lwgen --steps 3
+pmc fetch_lwgen FETCH_SIZE $B --workload lwgen --steps 2
+pmc write_lwgen WRITE_SIZE $B --workload lwgen --steps 2
+pmc sq_lwgen "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" $B --workload lwgen --steps 2
+pmc sq2_lwgen "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" $B --workload lwgen --steps 2
 # several evidence sets per call on the headline grid and on the 10 k-node DAG (bn_bp_run_batch_device, B = 16): bench.py --workload batch / dagbatch
 trace trace_batch_grid316 $B --workload batch --steps 10 --warmup 3
 pmc fetch_batch_grid316 FETCH_SIZE $B --workload batch --steps 4 --warmup 2
@@ -77,4 +83,7 @@ pmc sq2_batch_dag10k "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM
 trace trace_grid2048 $B --rows 2048 --cols 2048 --steps 3 --warmup 1
 pmc fetch_grid2048 FETCH_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1
 pmc write_grid2048 WRITE_SIZE $B --rows 2048 --cols 2048 --steps 2 --warmup 1
+# what the vector ALUs issue on dependent integer code (the sampler's measured issue peak)
+mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/experiments/valu_clock.hip -o build/valu_clock > /dev/null 2>&1 \
+    && timeout 120 build/valu_clock > $OUT/valu_clock.txt 2>&1
 python3 scripts/summarize_profile.py $OUT $TAG

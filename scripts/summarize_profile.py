@@ -18,7 +18,7 @@ import statistics
 import sys
 
 DOMINANT = {"grid316": ["bp_resident_kernel"], "grid316_launch": ["bp_sweep_kernel"], "dag10k": ["bp_dag_kernel"], "dag10k_launch": ["bp_sweep_kernel"],
-            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"],
+            "grid2048": ["bp_sweep_kernel"], "lw": ["lw_sample", "lw_hist"], "lwgen": ["lw_sample", "lw_hist"], "alarm": ["bp_small_kernel"], "mid": ["bp_mid_kernel"],
             "batch_grid316": ["bp_resident_kernel"], "batch_dag10k": ["bp_dag_kernel"]}
 
 
@@ -121,16 +121,16 @@ def main():
                     sq[name] = v
         if sq:
             summary[f"{label}_sq_counters_per_launch"] = sq
-        if label == "lw":   # the histogram pass is part of a sample's cost: its counters beside the sampler's
+        if label in ("lw", "lwgen"):   # the histogram pass is part of a sample's cost: its counters beside the sampler's
             hq = {}
-            for sq_dir in (os.path.join(src, "sq_lw"), os.path.join(src, "sq2_lw")):
+            for sq_dir in (os.path.join(src, "sq_" + label), os.path.join(src, "sq2_" + label)):
                 if os.path.isdir(sq_dir):
                     for name in sorted({r["Counter_Name"] for r in rows_of(sq_dir, "*counter_collection.csv")}):
                         v = counter_per_launch(sq_dir, "lw_hist", name)
                         if v is not None:
                             hq[name] = v
             if hq:
-                summary["lw_hist_sq_counters_per_launch"] = hq
+                summary[f"{label}_hist_sq_counters_per_launch"] = hq
         log = os.path.join(src, f"trace_{label}.log")
         if os.path.exists(log):
             lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
@@ -139,13 +139,19 @@ def main():
                 spl = (summary[f"{label}_bench_line"].get("roofline") or {}).get("sweeps_per_launch")
                 if spl:
                     summary[f"{label}_sweeps_per_launch"] = spl   # the counters above are per launch: bench.py divides by this
-                if label == "lw":   # samples one launch of the sample kernel draws (a call is cut into launches of at most 32 GiB of states)
+                if label in ("lw", "lwgen"):   # samples one launch of the sample kernel draws (a call is cut into launches of at most 32 GiB of states)
                     import re
                     m = re.search(r"(\d+) samples per call", summary[f"{label}_bench_line"].get("config", {}).get("workload", ""))
-                    launches = (summary.get("lw_lw_sample") or {}).get("launches")
+                    launches = (summary.get(f"{label}_lw_sample") or {}).get("launches")
                     steps = summary[f"{label}_bench_line"].get("steps")
                     if m and launches and steps:
-                        summary["lw_samples_per_launch"] = int(m.group(1)) * (steps + 2) / launches   # (+ 2 warm-up calls)
+                        summary[f"{label}_samples_per_launch"] = int(m.group(1)) * (steps + 2) / launches   # (+ 2 warm-up calls)
+    vc = os.path.join(src, "valu_clock.txt")
+    if os.path.exists(vc):   # scripts/experiments/valu_clock.hip: what the vector ALUs issue on dependent integer code (bench.py: peak_measured_integer_issue)
+        rows = [json.loads(ln) for ln in open(vc).read().splitlines() if ln.startswith("{")]
+        if rows:
+            json.dump({"g_wave_insts_per_s": max(r["G_wave_insts_per_s"] for r in rows), "runs": rows, "tag": tag,
+                       "source": "scripts/experiments/valu_clock.hip"}, open(os.path.join(dst, "valu_issue.json"), "w"), indent=1)
     json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if not k.endswith("_bench_line")}, indent=1))
 

@@ -194,7 +194,9 @@ bool checksum_only = false;
 // --checksum (no GPU): the flat model and the evidence of query 0, for comparison with bayesiannetwork_amd/synth.py
 void print_checksums(char const* name, bn::graph_t const& g, double const ev_frac, bool const last)
 {
+    double const t_flat = now_ms();
     auto const fm = bn::mi355x::flatten(g);
+    double const flatten_ms = now_ms() - t_flat;
     auto const ev = random_evidence(g, ev_frac, 7);
     std::vector<std::int32_t> pairs;   // (node, state) ascending by node
     for(auto const& p : ev)
@@ -204,8 +206,8 @@ void print_checksums(char const* name, bn::graph_t const& g, double const ev_fra
         pairs.push_back(fm.index.at(p.first) * 256 + st);
     }
     std::sort(pairs.begin(), pairs.end());
-    std::printf("\"%s\":{\"nodes\":%zu,\"edges\":%zu,\"in_idx\":\"%016llx\",\"cpt\":\"%016llx\",\"evidence\":\"%016llx\"}%s", name,
-                fm.k.size(), fm.in_idx.size(),
+    std::printf("\"%s\":{\"nodes\":%zu,\"edges\":%zu,\"flatten_ms\":%.3f,\"in_idx\":\"%016llx\",\"cpt\":\"%016llx\",\"evidence\":\"%016llx\"}%s", name,
+                fm.k.size(), fm.in_idx.size(), flatten_ms,
                 static_cast<unsigned long long>(wsum64(fm.in_idx.data(), fm.in_idx.size())),
                 static_cast<unsigned long long>(wsum64(fm.cpt.data(), fm.cpt.size())),
                 static_cast<unsigned long long>(wsum64(pairs.data(), pairs.size())), last ? "" : ",");
@@ -223,9 +225,28 @@ void bench_network(char const* name, bn::graph_t const& g, double const graph_bu
     std::vector<evidence_map> evs;
     for(int q = 0; q < 8; ++q) evs.push_back(random_evidence(g, ev_frac, 7 + q));
 
-    // the C ABI alone, on arrays marshalled beforehand (a second engine on the same flat model)
+    // what the constructor did, split (reference belief_propagation.hpp:16-19 copies a graph): flattening graph_t through its public
+    // interface, then bn_create -- host planning (the layout of the default path; the others' come with their first use) and the
+    // device side (allocations, uploads).  This second engine on the same flat model is a steady-state construction: the runtime,
+    // the code objects and the allocator's pools exist by now.
+    t0 = now_ms();
     auto const fm = bn::mi355x::flatten(g);
+    double const flatten_ms = now_ms() - t0;
+    t0 = now_ms();
     bn::mi355x::engine_handle raw(fm);
+    double const create_ms = now_ms() - t0;
+    double create_host_ms = 0.0, create_device_ms = 0.0;
+    {
+        char const* const host_keys[] = {"create_us_plan", "create_us_small", "create_us_mid", "create_us_dag"};
+        for(char const* k : host_keys) create_host_ms += static_cast<double>(bn_get_info(raw.get(), k)) * 1e-3;
+        create_device_ms = static_cast<double>(bn_get_info(raw.get(), "create_us_device")) * 1e-3;
+    }
+    double construct_again_ms = 0.0;
+    {   // ... and a second functor, whole (flatten + bn_create + the graph copy), destroyed again outside the clock
+        t0 = now_ms();
+        bn::inference::belief_propagation again(g);
+        construct_again_ms = now_ms() - t0;
+    }
     std::vector<flat_evidence> flat(evs.size());
     for(std::size_t q = 0; q < evs.size(); ++q)
     {
@@ -353,12 +374,13 @@ void bench_network(char const* name, bn::graph_t const& g, double const graph_bu
     }
     double const raw_ms = median(t_raw), run_ms = median(t_run);
     std::printf("\"%s\":{\"nodes\":%zu,\"edges\":%zu,\"evidence_nodes\":%zu,\"eps\":%g,\"reps\":%d,\"sweeps_per_query\":%.3f,"
-                "\"graph_build_ms\":%.3f,\"functor_construct_ms\":%.3f,"
+                "\"graph_build_ms\":%.3f,\"functor_construct_ms\":%.3f,\"functor_construct_again_ms\":%.3f,\"flatten_ms\":%.3f,\"bn_create_ms\":%.3f,"
+                "\"bn_create_host_ms\":%.3f,\"bn_create_device_ms\":%.3f,"
                 "\"run_view_ms\":%.5f,\"run_prepared_ms\":%.5f,\"c_abi_ms\":%.5f,\"marshal_ms\":%.5f,\"map_build_ms\":%.5f,\"map_destroy_ms\":%.5f,"
                 "\"operator_ms\":%.5f,\"map_build_copy_assign_ms\":%.5f,"
                 "\"sweeps_query0\":%d,\"wsum64_query0\":\"%016llx\",\"map_equals_view\":%s}%s",
                 name, n, g.edge_list().size(), evs[0].size(), eps, reps, static_cast<double>(sweeps) / reps,
-                graph_build_ms, construct_ms, run_ms, median(t_prep), raw_ms, std::max(0.0, run_ms - raw_ms), median(t_build), median(t_destroy),
+                graph_build_ms, construct_ms, construct_again_ms, flatten_ms, create_ms, create_host_ms, create_device_ms, run_ms, median(t_prep), raw_ms, std::max(0.0, run_ms - raw_ms), median(t_build), median(t_destroy),
                 median(t_op), median(t_old), sweeps0, static_cast<unsigned long long>(sum_view), map_equals_view ? "true" : "false",
                 last ? "" : ",");
 }
