@@ -353,6 +353,175 @@ __device__ __forceinline__ bool dag_drive(const DagArgs& a, DagShared& sh, int l
     return true;
 }
 
+// ---- the dataflow form of a single query: no grid barrier (bn_dag.hpp, DagFlowSync; the protocol of bn_resident.hip's flow form) ----
+// Why here: a sweep of config 2 under the barrier is the slowest wave of the whole grid (a 4-parent child tile: round trip, 1.8 us of
+// arithmetic, drain) PLUS the barrier's hand-off (every block's granules gathered by every block: 2.5 us from a wave's arrival to
+// the verdict) -- 5.6 us, 0.87 of the wave cycles waiting.  Jacobi iteration i + 1 of a tile reads what its NEIGHBOUR tiles wrote in
+// iteration i and overwrites what they read in i, nothing else (belief_propagation.hpp:78-101 read the old maps, :135-143 commit):
+// it may start as soon as those tiles have finished i.  A heavy tile then holds up its handful of neighbours, not 1 800 waves, and
+// the hand-off is one granule read by the lanes of one wave.  The stop decision (:147) needs the maximum over ALL tiles, so it
+// lags: the service block gathers the granules of i while the tiles compute i + 1; a tile starts i + 2 only once the verdict of i is
+// out.  When it says "stop after i" a tile has at most executed i + 1 as well -- into the OTHER buffer: the state the run ends in is
+// intact, and the beliefs are formed from it.  One speculative iteration per run is the price.
+__device__ __forceinline__ unsigned long long* dag_flow_slot(DagFlowSync* f, int n_tiles, int par, int tile) {
+    return reinterpret_cast<unsigned long long*>(f + 1) + (size_t(par) * n_tiles + tile) * 2;
+}
+__device__ __forceinline__ unsigned long long dag_granule(unsigned gen, unsigned half) { return (unsigned long long)gen << 32 | half; }
+__device__ __forceinline__ void dag_flow_raise_abort(const DagArgs& a) {
+    const unsigned long long w = (unsigned long long)(a.gen_base + 1u) | ((unsigned long long)kDagFlowAbort << 32);
+    for (int q = 0; q < 8; ++q) __hip_atomic_store(&a.flow->verdict[q].word, w, RLX_AGENT);
+    if (a.host_abort) __hip_atomic_store(a.host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Waits until this tile may run iteration `it`; returns the verdict that ends the run for it (kDagFlowGoOn: run the iteration) and,
+// with a stop verdict, the number of iterations of this launch the run consists of in n_it.
+__device__ __forceinline__ unsigned dag_flow_wait(const DagArgs& a, int nbr, int it, int lane, int& n_it) {
+    n_it = 0;
+    if (it == 0) return kDagFlowGoOn;
+    DagFlowSync* f = a.flow;
+    const unsigned long long* vword = &f->verdict[blockIdx.x & 7].word;
+    // a neighbour's slot of this parity carries EXACTLY the generation of iteration it - 1 once it has finished it: it cannot finish
+    // it + 1 before this tile has finished `it`
+    const unsigned want_nb = a.gen_base + unsigned(it);
+    const unsigned want_v = a.gen_base + unsigned(it) - 1u;   // iteration it - 2 is decided
+    const unsigned long long* g = dag_flow_slot(f, a.n_tiles, (it - 1) & 1, nbr >= 0 ? nbr : 0);
+    unsigned long long t0 = 0;
+    for (unsigned polls = 0;; ++polls) {
+        // the neighbours' granules and the verdict word in ONE round trip
+        const unsigned long long gw = nbr >= 0 ? __hip_atomic_load(g, RLX_AGENT) : 0ull;
+        const unsigned long long w = __hip_atomic_load(vword, RLX_AGENT);
+        const bool nb_ok = nbr < 0 || unsigned(gw >> 32) == want_nb;
+        const unsigned gen = unsigned(w), kind = unsigned(w >> 32);
+        const bool ours = gen - (a.gen_base + 1u) < unsigned(kDagBudget);   // published by THIS launch (generations count on across launches)
+        if (ours && kind != kDagFlowGoOn) {
+            n_it = int(gen - a.gen_base);
+            return kind;
+        }
+        const bool v_ok = it < 2 || (ours && gen >= want_v);
+        if (it < a.budget && v_ok && __all(nb_ok)) return kDagFlowGoOn;
+        if ((polls & 31u) == 31u) {   // (the 100 MHz clock is a memory read of its own: it bounds the wait, looked at on every 32nd poll)
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > a.timeout_ticks) {
+                if (lane == 0) dag_flow_raise_abort(a);
+                return kDagFlowAbort;
+            }
+        }
+        for (int z = 0; z < a.flow_sleep; ++z) __builtin_amdgcn_s_sleep(8);
+    }
+}
+// a tile's loop over iterations.  finalize(q = 0, n, done): as in dag_drive.
+template <class Request, class Finish, class Finalize>
+__device__ __forceinline__ bool dag_flow_drive(const DagArgs& a, int tile, int lane, int wave, Request&& request, Finish&& finish, Finalize&& finalize) {
+    const int nbr = a.nbr[int64_t(tile) * kWave + lane];
+    for (int it = 0;; ++it) {
+        DSTAMP(0, it);
+        int n_it;
+        const unsigned v = dag_flow_wait(a, nbr, it, lane, n_it);
+        DSTAMP(1, it);
+        if (v == kDagFlowAbort) return false;
+        if (v != kDagFlowGoOn) {   // the run consists of n_it iterations of this launch (this wave has executed n_it or n_it + 1)
+            finalize(0, a.sweep_begin + n_it, v == kDagFlowBudget ? 0 : int(v));
+            return true;
+        }
+        const int s = a.sweep_begin + it;
+        request(0, s);
+        DSTAMP(9, it);
+        const unsigned long long bits = dag_wave_residual(finish(0, s));
+        DSTAMP(3, it);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have reached memory
+        DSTAMP(4, it);
+        if (lane == 0) {
+            const unsigned gen = a.gen_base + unsigned(it) + 1u;
+            unsigned long long* g = dag_flow_slot(a.flow, a.n_tiles, it & 1, tile);
+            __hip_atomic_store(g, dag_granule(gen, unsigned(bits >> 32)), RLX_AGENT);
+            __hip_atomic_store(g + 1, dag_granule(gen, unsigned(bits)), RLX_AGENT);
+        }
+        DSTAMP(6, it);
+    }
+}
+// The service block (block n_blocks of the launch), all its waves: thread x sweeps the granule pairs of tiles x, x + 512, ... of the
+// iteration in hand until they carry its generation; the block reduces, thread 0 decides and publishes.
+__device__ __forceinline__ void dag_flow_service(const DagArgs& a, DagShared& sh, int lane, int wave) {
+    DagFlowSync* f = a.flow;
+    const int nt = a.n_tiles;
+    const unsigned long long t_first = wall_clock64();
+    DagSetShared& ss = sh.set[0];
+    if (threadIdx.x == 0) ss.arrived = 0;   // (here: some wave's sweep gave up)
+    __syncthreads();
+    int n_it = 0;
+    unsigned v = kDagFlowGoOn;
+    for (int it = 0; it < a.budget; ++it) {
+        const unsigned gen = a.gen_base + unsigned(it) + 1u;
+        unsigned long long m = 0, t0 = 0;
+        bool ok = true;
+        for (unsigned polls = 0;; ++polls) {
+            bool mine = true;
+            unsigned long long acc = 0;
+            for (int t = threadIdx.x; t < nt; t += kDagWaves * kWave) {
+                const unsigned long long* g = dag_flow_slot(f, nt, it & 1, t);
+                const unsigned long long hi = __hip_atomic_load(g, RLX_AGENT);
+                const unsigned long long lo = __hip_atomic_load(g + 1, RLX_AGENT);
+                mine = mine && unsigned(hi >> 32) == gen && unsigned(lo >> 32) == gen;
+                const unsigned long long x = (hi << 32) | (lo & 0xffffffffull);
+                acc = x > acc ? x : acc;
+            }
+            m = acc;
+            if (__all(mine)) break;
+            const unsigned long long w = __hip_atomic_load(&f->verdict[0].word, RLX_AGENT);
+            if (unsigned(w >> 32) == kDagFlowAbort && unsigned(w) - (a.gen_base + 1u) < unsigned(kDagBudget)) { ok = false; break; }
+            if ((polls & 31u) == 31u) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > a.timeout_ticks) {
+                    if (lane == 0) dag_flow_raise_abort(a);
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        m = wave_umax64_dpp(m);
+        if (lane == 0) {
+            ss.slot[wave] = m;
+            if (!ok) ss.arrived = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned decision = kDagFlowAbort;
+            if (ss.arrived == 0) {
+                unsigned long long mm = 0;
+                for (int w = 0; w < kDagWaves; ++w) mm = ss.slot[w] > mm ? ss.slot[w] : mm;
+                decision = unsigned(dag_verdict_of(a, dag_residual_of(mm), a.sweep_begin + it + 1));
+                if (decision == kDagFlowGoOn && it == a.budget - 1) decision = kDagFlowBudget;
+                __hip_atomic_store(&f->res[it], mm, RLX_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual is recorded before anyone learns the verdict
+                const unsigned long long word = (unsigned long long)gen | ((unsigned long long)decision << 32);
+                for (int q = 0; q < 8; ++q) __hip_atomic_store(&f->verdict[q].word, word, RLX_AGENT);
+            }
+            ss.verdict = int(decision);
+        }
+        __syncthreads();
+        v = unsigned(ss.verdict);
+        n_it = it + 1;
+        if (v != kDagFlowGoOn) break;
+    }
+    if (wave != 0) return;
+    if (v != kDagFlowAbort) {   // report: residual history, outcome, device clock
+        double* hist = a.b.res_hist;
+        for (int q = lane; q < n_it; q += kWave)
+            if (a.sweep_begin + q < a.b.res_cap) hist[a.sweep_begin + q] = dag_residual_of(__hip_atomic_load(&f->res[q], RLX_AGENT));
+    }
+    if (lane == 0) {
+        Ctl* hc = a.host_ctl;
+        hc->last_res = (v != kDagFlowAbort && n_it > 0) ? dag_residual_of(__hip_atomic_load(&f->res[n_it - 1], RLX_AGENT)) : 0.0;
+        hc->n_sweeps = a.sweep_begin + n_it;
+        hc->t_first = t_first;
+        hc->t_last = wall_clock64();
+        hc->run_id = a.run_id;
+        hc->done = v == kDagFlowAbort ? -1 : (v == kDagFlowBudget ? 0 : int(v));
+    }
+}
+
 // belief = normalize(pi % lambda) (:151-158) of `node` from the state after n sweeps
 __device__ __forceinline__ void dag_belief(const DagArgs& a, __amdgpu_buffer_rsrc_t rs, int node, int snode, int n, double* beliefs) {
     double pv[4], lv[4], bel[4];
@@ -921,11 +1090,31 @@ template <> struct dag_has_belief<DagParentX> { static constexpr bool value = fa
 
 // STREAM = false: at most one tile per wave, its static state (CPT, ids, marks) in registers for the whole run.
 // STREAM = true: a wave walks its tiles [slot_ptr[slot], slot_ptr[slot + 1]) every iteration, setting each up again.
-template <bool STREAM, bool BATCH>
+// FLOW (single query, one tile per wave): the dataflow form -- no grid barrier, one more block serves the stop decision.
+template <bool STREAM, bool BATCH, bool FLOW = false>
 __global__ __launch_bounds__(kDagWaves * kWave) void bp_dag_kernel(DagArgs a) {
+    static_assert(!FLOW || (!STREAM && !BATCH), "the dataflow form runs one evidence set at one tile per wave");
     __shared__ DagShared sh;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (FLOW) {
+        if (int(blockIdx.x) == a.n_blocks) { dag_flow_service(a, sh, lane, wave); return; }
+        const int slot_f = blockIdx.x * kDagWaves + wave;
+        const int tf0 = a.slot_ptr[slot_f], tf1 = a.slot_ptr[slot_f + 1];
+        if (tf1 <= tf0) return;   // (a wave without a tile has no part in the protocol)
+        const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(a.state, 0, int(dag_state_doubles(a.E, a.n) * 8), 0x00020000);
+        const DagTile tdf = a.tiles[tf0];
+        dag_with_tile(a, tdf, lane, [&](auto& st) {
+            (void)dag_flow_drive(a, tf0, lane, wave, [&](int, int s) { st.request(a, rsf, s); },
+                                 [&](int, int s) { return st.finish(a, rsf, s, sh.xch[wave]); },
+                                 [&](int, int n, int done) {
+                                     if constexpr (dag_has_belief<std::remove_reference_t<decltype(st)>>::value) {
+                                         if (done != 0) st.belief(a, rsf, n, a.b.beliefs);
+                                     }
+                                 });
+        });
+        return;   // (a wave that gave up has raised the abort word and the host's flag itself; the service block reports)
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned long long now = wall_clock64();
         for (int q = 0; q < a.n_sets; ++q) a.host_ctl[q].t_first = now;
@@ -1060,9 +1249,11 @@ int launch_dag_init(const DagInitArgs& a, void* stream_handle) {
 }
 int launch_bp_dag(const DagArgs& a, bool stream, void* stream_handle) {
     (void)hipGetLastError();
-    const dim3 g(a.n_blocks), t(kDagWaves * kWave);
     const bool batch = a.n_sets > 1;
-    if (stream && batch) hipLaunchKernelGGL((bp_dag_kernel<true, true>), g, t, 0, (hipStream_t)stream_handle, a);
+    const bool flow = a.flow != nullptr && !stream && !batch && a.n_blocks > 1;
+    const dim3 g(a.n_blocks + (flow ? 1 : 0)), t(kDagWaves * kWave);
+    if (flow) hipLaunchKernelGGL((bp_dag_kernel<false, false, true>), g, t, 0, (hipStream_t)stream_handle, a);
+    else if (stream && batch) hipLaunchKernelGGL((bp_dag_kernel<true, true>), g, t, 0, (hipStream_t)stream_handle, a);
     else if (stream) hipLaunchKernelGGL((bp_dag_kernel<true, false>), g, t, 0, (hipStream_t)stream_handle, a);
     else if (batch) hipLaunchKernelGGL((bp_dag_kernel<false, true>), g, t, 0, (hipStream_t)stream_handle, a);
     else hipLaunchKernelGGL((bp_dag_kernel<false, false>), g, t, 0, (hipStream_t)stream_handle, a);

@@ -99,6 +99,28 @@ struct DagDeviceTables {
 };
 void build_dag_device_tables(const DagPlan& dp, DagDeviceTables& dt);
 
+// ---- dataflow form of the single query (bn_dag.hip "flow"): no grid barrier.  Every tile (= wave) publishes a granule pair
+// {generation | residual half} per iteration; a tile starts its next iteration once its neighbour tiles (DagFlowTables::nbr) carry
+// the generation of the previous one; one more block -- the service block -- collects all tiles' granules of iteration i while the
+// tiles compute i + 1 and publishes {generation, verdict}; a tile starts i + 2 only once the verdict of i is known, so the state the
+// run stops in is intact when it does (the one speculative iteration writes the OTHER buffer).  bn_resident.hip's protocol.
+struct DagFlowTables {
+    bool ok = false;
+    int32_t max_nbr = 0;
+    std::vector<int32_t> nbr;   // [tiles][kWave] tile indices (the plan's tile order), -1 = none
+};
+void build_dag_flow_tables(const DagPlan& dp, const Plan& p, DagFlowTables& ft);
+enum : unsigned { kDagFlowGoOn = 0, kDagFlowConverged = 1, kDagFlowCapped = 2, kDagFlowAbort = 3, kDagFlowBudget = 4 };
+struct DagFlowSync {            // zeroed at creation, after an aborted launch and before the generation would wrap
+    struct Line {
+        unsigned long long word;        // low 32 bits: generation of the last decided iteration; high 32: its verdict (kDagFlow*)
+        unsigned long long pad_[15];
+    } verdict[8];                       // copies on lines of their own: tile blocks poll copy blockIdx % 8
+    unsigned long long res[kDagBudget]; // per-iteration maximum_difference, bit patterns
+    // then: granule pairs [2 iteration parities][tiles][2]
+};
+inline size_t dag_flow_sync_bytes(size_t tiles) { return sizeof(DagFlowSync) + sizeof(unsigned long long) * 2 * tiles * 2; }
+
 struct DagArgs {
     BpBuffers b;              // beliefs, res_hist / res_cap
     double eps;
@@ -133,6 +155,11 @@ struct DagArgs {
     int32_t state_init;
     const int32_t* node_k;     // nullptr: every arity is 4
     const int64_t* node_off;
+    // dataflow form (flow != nullptr: a single query on a plan with DagFlowTables::ok; the launch has n_blocks + 1 blocks)
+    DagFlowSync* flow;
+    const int32_t* nbr;        // [tiles][kWave]
+    int32_t n_tiles;
+    int32_t flow_sleep;        // pause between two polls of a tile's neighbours, x 8 x 64 cycles
 };
 struct DagEvidenceArgs {
     int32_t ne, n, E;

@@ -283,4 +283,50 @@ void build_dag_device_tables(const DagPlan& dp, DagDeviceTables& dt) {
     for (size_t x = 0; x < dp.oedge.size(); ++x) dt.oedge[x] = dp.E > 0 ? dt.eperm[size_t(dp.oedge[x])] : 0;   // (a network without edges keeps one unused entry)
 }
 
+// The tiles a tile exchanges messages with (dataflow form of bp_dag_kernel, bn_dag.hip): a child tile reads the pi-messages its
+// nodes' parents' items produce and the lambda(v) its nodes' own items produce; a parent tile reads pi(u) of its nodes and the
+// lambda-messages of their children -- the relation is symmetric (who reads from a tile is read by it), so ONE list per tile
+// covers both what it waits for (its inputs) and whom it must not overtake (the readers of what it overwrites).
+// nbr [tiles][kWave], -1 = none; ok = false when some tile has more than kWave neighbours (a lane polls one neighbour), when the
+// plan is in stream form (several tiles per wave) or runs in one block (no barrier to replace).
+void build_dag_flow_tables(const DagPlan& dp, const Plan& p, DagFlowTables& ft) {
+    ft = DagFlowTables();
+    if (!dp.ok || dp.light || dp.stream || dp.blocks < 2) return;
+    const size_t nt = dp.tiles.size();
+    const int32_t n = dp.n;
+    std::vector<int32_t> ctile(size_t(n), -1);                 // the child tile of a node
+    std::vector<std::vector<int32_t>> ptiles{size_t(n)};       // the parent tile(s) that hold a node's items (several: > 63 children)
+    for (size_t t = 0; t < nt; ++t) {
+        const DagTile& td = dp.tiles[t];
+        for (int l = 0; l < kWave; ++l) {
+            if (td.kind < kDagParent) {
+                const int32_t v = dp.cnode[size_t(td.lane_base) + l].node;
+                if (v >= 0) ctile[size_t(v)] = int32_t(t);
+            } else {
+                const int32_t u = dp.pitem[size_t(td.lane_base) + l].node;
+                if (u >= 0 && (ptiles[size_t(u)].empty() || ptiles[size_t(u)].back() != int32_t(t))) ptiles[size_t(u)].push_back(int32_t(t));
+            }
+        }
+    }
+    std::vector<std::vector<int32_t>> nbr(nt);
+    auto link = [&](int32_t a, int32_t b) { nbr[size_t(a)].push_back(b); nbr[size_t(b)].push_back(a); };
+    for (int32_t v = 0; v < n; ++v) {
+        const int32_t c = ctile[size_t(v)];
+        if (c < 0) return;   // (every node sits in a child tile: a plan that says otherwise is not one to run)
+        for (int32_t t : ptiles[size_t(v)]) link(c, t);
+        for (int32_t e = p.in_ptr[v]; e < p.in_ptr[v + 1]; ++e)
+            for (int32_t t : ptiles[size_t(p.in_idx[e])]) link(c, t);
+    }
+    ft.nbr.assign(nt * kWave, -1);
+    for (size_t t = 0; t < nt; ++t) {
+        std::vector<int32_t>& l = nbr[t];
+        std::sort(l.begin(), l.end());
+        l.erase(std::unique(l.begin(), l.end()), l.end());
+        ft.max_nbr = std::max<int32_t>(ft.max_nbr, int32_t(l.size()));
+        if (l.size() > size_t(kWave)) { ft.nbr.clear(); return; }
+        std::copy(l.begin(), l.end(), ft.nbr.begin() + t * kWave);
+    }
+    ft.ok = true;
+}
+
 }  // namespace bnmi

@@ -52,6 +52,26 @@ hipStream_t take_parked_stream(int device) {
         }
     return nullptr;
 }
+// The FIRST device engine of a process on a device also parks a few spare streams: with another engine's stream alive, creating one more
+// costs 5-11 ms (scripts/experiments/create_split_alive.py) -- nearly all of a functor's construction on an ALARM-sized network --
+// while that first bn_create spends 80-240 ms bringing the runtime up anyway.
+constexpr int kSpareStreams = 3;
+std::vector<int> g_primed_devices;
+void prime_spare_streams(int device) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        for (int d : g_primed_devices)
+            if (d == device) return;
+        g_primed_devices.push_back(device);
+    }
+    if (std::getenv("BN_NO_SPARE_STREAMS")) return;
+    for (int i = 0; i < kSpareStreams; ++i) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        g_parked_streams.push_back(ParkedStream{device, s});
+    }
+}
 void park_stream(int device, hipStream_t s) {
     if (hipStreamSynchronize(s) == hipSuccess) {
         std::lock_guard<std::mutex> lock(g_stream_mu);
@@ -81,7 +101,7 @@ void bn_eng::free_engine(bn_engine* e) {
                         e->d_s_ent, e->d_s_cpt, e->d_s_term, e->d_s_clist, e->d_s_bslot, e->d_s_cslot, e->d_s_nvidx, e->d_s_nvslot, e->d_s_init, e->d_s_state, e->d_s_nodeoff,
                         e->d_m_parts, e->d_m_ent, e->d_m_cpt, e->d_m_term, e->d_m_clist, e->d_m_bslot, e->d_m_cslot, e->d_m_nvidx, e->d_m_nvslot,
                         e->d_m_init, e->d_m_nodeoff, e->d_m_msgfirst, e->d_m_state, e->d_m_frz, e->d_m_sync,
-                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_eperm, e->d_g_nperm, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync, e->d_g_k, e->d_g_inptr, e->d_g_inidx, e->d_g_noff,
+                        e->d_g_tiles, e->d_g_slotptr, e->d_g_cnode, e->d_g_pitem, e->d_g_oedge, e->d_g_eperm, e->d_g_nperm, e->d_g_cpt, e->d_g_init, e->d_g_state, e->d_g_frz, e->d_g_sync, e->d_g_k, e->d_g_inptr, e->d_g_inidx, e->d_g_noff, e->d_g_nbr, e->d_g_flow,
                         e->batch.d_rec[0], e->batch.d_rec[1], e->batch.d_node[0], e->batch.d_node[1], e->batch.d_frozen,
                         e->batch.d_beliefs, e->batch.d_res_hist, e->batch.d_sync, e->batch.d_ev, e->batch.d_ctl, e->batch.d_s_state,
                         e->batch.d_g_state, e->batch.d_g_frz, e->batch.d_g_sync};
@@ -176,6 +196,17 @@ int bn_eng::ensure_dag(bn_engine* e) {
     if ((r2 = dalloc(&e->d_g_frz, size_t(dp.n)))) return r2;
     HIPCHK(hipMemsetAsync(e->d_g_frz, 0, size_t(dp.n), e->stream));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_g_sync), sizeof(ResidentSync)));
+    {   // the dataflow form of a single query (bn_dag.hip): neighbour tiles, granule table + verdict words
+        DagFlowTables ft;
+        try { build_dag_flow_tables(dp, p, ft); } catch (const std::bad_alloc&) { ft = DagFlowTables(); }
+        e->dag_flow_ok = ft.ok && int64_t(dp.blocks) + 1 <= int64_t(e->n_cus);   // (+ the service block: every block co-resident)
+        e->dag_flow_max_nbr = ft.max_nbr;
+        if (e->dag_flow_ok) {
+            if ((r2 = upload(&e->d_g_nbr, ft.nbr, e->stream))) return r2;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->d_g_flow), dag_flow_sync_bytes(dp.tiles.size())));
+            HIPCHK(hipStreamSynchronize(e->stream));   // (`ft` is a local)
+        }
+    }
     HIPCHK(hipStreamSynchronize(e->stream));   // (upload() copies from the plan's vectors: they stay, but the order against a reload is then plain)
     e->dag_sync_dirty = true;
     e->dag_ev_applied = false;
@@ -475,6 +506,7 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         }
         if (e->dag.ok) {
             if (const char* dm = std::getenv("BN_DAG")) e->dag_mode = std::max(0, std::min(2, std::atoi(dm)));
+            if (const char* df = std::getenv("BN_DAG_FLOW")) e->dag_flow = std::atoi(df) != 0;
             e->dag_ok = true;   // eligible on this device; image and tables: ensure_dag
         }
         if (const char* m = std::getenv("BN_MULTISWEEP")) e->multisweep = std::max(0, std::min(2, std::atoi(m)));
@@ -489,6 +521,8 @@ static int create_impl(const bn_model_desc* desc, const ShardSpec& shard, bn_eng
         dev_lap("dag path");
         HIPCHK(hipStreamSynchronize(e->stream));
         dev_lap("final synchronise");
+        if (p.nranks == 1) prime_spare_streams(e->device);   // (first engine of the process on this device only)
+        dev_lap("spare streams");
         BigVec().swap(e->plan.cpt_striped);  // the image now lives in HBM
         lap(4);
         return BN_OK;
@@ -943,6 +977,8 @@ MidArgs bn_eng::mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides&
     a.res = reinterpret_cast<unsigned long long*>(e->d_m_sync + 8);
     a.abort = e->h_abort_dev;
     a.timeout_ticks = 5000000ull;  // one wait: 50 ms of the 100 MHz clock
+    static const int mid_first_delay = std::getenv("BN_MID_DELAY") ? std::atoi(std::getenv("BN_MID_DELAY")) : 0;   // 10 ns ticks behind the predicted last arrival; -1: poll from the own arrival on (rounds 3-5).  mixed10k, us per sweep: 8.30 at -1, 8.17 at 0, 8.80 at 30, 9.08 at 60
+    a.first_poll_delay = mid_first_delay;
     a.sets = st; a.set_base = set_base; a.slot_base = slot_base;
     return a;
 }
@@ -1061,11 +1097,19 @@ int bn_eng::run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_t
         // polled words: generations count on from launch to launch; zeroed at creation, after an abort and before they would wrap
         if (e->dag_sync_dirty || e->dag_gen_base > (1u << 29)) {
             HIPCHK(hipMemsetAsync(e->d_g_sync, 0, sizeof(ResidentSync), s));
+            if (e->d_g_flow) HIPCHK(hipMemsetAsync(e->d_g_flow, 0, dag_flow_sync_bytes(dp.tiles.size()), s));
             e->dag_sync_dirty = false;
             e->dag_gen_base = 0;
         }
         *e->h_abort = 0;
         DagArgs a{};
+        // the dataflow form where the plan allows it ("dagflow" 1; a run that gave up a wait stays on the barrier for a while)
+        const bool flow = e->dag_flow_ok && e->dag_flow != 0 && !dp.stream && dp.blocks > 1 && e->dag_flow_pause == 0;
+        if (flow) {
+            static const int flow_sleep = std::getenv("BN_DAG_FLOW_SLEEP") ? std::atoi(std::getenv("BN_DAG_FLOW_SLEEP")) : 0;
+            a.flow = e->d_g_flow; a.nbr = e->d_g_nbr; a.n_tiles = int32_t(dp.tiles.size()); a.flow_sleep = flow_sleep;
+        }
+        e->last_dag_flow = flow ? 1 : 0;
         a.b = b; a.eps = eps; a.max_sweeps = max_sweeps; a.sweep_begin = begin; a.budget = kDagBudget; a.run_id = e->run_id;
         a.gen_base = e->dag_gen_base;
         a.timeout_ticks = 5000000ull;  // one wait: 50 ms of the 100 MHz clock
@@ -1097,9 +1141,11 @@ int bn_eng::run_dag(bn_engine* e, double eps, int32_t max_sweeps, double* copy_t
         if (e->h_ctl->run_id != e->run_id || gave_up) e->dag_sync_dirty = true;
         if (gave_up) {
             *e->h_abort = 0;
+            if (flow) e->dag_flow_pause = 64;   // (the barrier form next time the path is tried)
             return fail(BN_ERR_STATE, "a block of the register-resident DAG kernel gave up its grid wait");
         }
         if (e->h_ctl->run_id != e->run_id) return fail(BN_ERR_HIP, "bp_dag kernel did not report (stale control block)");
+        if (!flow && e->dag_flow_pause > 0) --e->dag_flow_pause;
         if (e->timing) {
             float t = 0.f;
             HIPCHK(hipEventElapsedTime(&t, e->events[0], e->events[1]));
@@ -1360,6 +1406,7 @@ extern "C" int bn_set_option(bn_engine* e, const char* name, int32_t value) {
     if (std::strcmp(name, "flow") == 0) { e->flow = value != 0; return BN_OK; }
     if (std::strcmp(name, "direct") == 0) { e->resident_direct = value != 0; return BN_OK; }
     if (std::strcmp(name, "mid") == 0) { e->mid_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
+    if (std::strcmp(name, "dagflow") == 0) { e->dag_flow = value != 0; return BN_OK; }
     if (std::strcmp(name, "dag") == 0) { e->dag_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
     if (std::strcmp(name, "autotune") == 0) { e->autotune_pending = value != 0; if (value == 0) e->autotuned_path = -1; return BN_OK; }
     if (std::strcmp(name, "small") == 0) { e->small_mode = value < 0 ? 0 : (value > 2 ? 2 : value); return BN_OK; }
@@ -1402,6 +1449,9 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "dag_stream") == 0) return e->dag.ok && e->dag.stream ? 1 : 0;
     if (std::strcmp(name, "lw_small") == 0) return e->lw.ready && e->lw.small ? 1 : 0;   // (known after the first sampler call)
     if (std::strcmp(name, "dag_aborts") == 0) return e->dag_aborts;
+    if (std::strcmp(name, "dag_flow_eligible") == 0) return e->dag_flow_ok ? 1 : 0;     // (known once the path has been set up: ensure_dag)
+    if (std::strcmp(name, "dag_flow_max_nbr") == 0) return e->dag_flow_max_nbr;
+    if (std::strcmp(name, "last_dag_flow") == 0) return e->last_path == 5 ? e->last_dag_flow : 0;
     if (std::strcmp(name, "small_eligible") == 0) return e->small.ok ? 1 : 0;
     if (std::strcmp(name, "small_waves") == 0) return e->small.ok ? e->small.waves : 0;
     if (std::strcmp(name, "small_lds_bytes") == 0) return e->small.ok ? int64_t(e->small.lds_bytes) : 0;

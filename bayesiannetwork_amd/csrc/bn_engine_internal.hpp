@@ -267,6 +267,13 @@ struct bn_engine {
     // waves of their own, state in device memory, one launch per run (bn_dag.hip)
     DagPlan dag;
     bool dag_ok = false;            // eligible on this device (the LIGHT plan is in e->dag)
+    bool dag_flow_ok = false;       // the plan has a dataflow form (<= 64 neighbour tiles per tile, one tile per wave, > 1 block) and the service block fits
+    int dag_flow = 0;               // option "dagflow" 1: single queries take the dataflow form where it exists (default 0: measured slower, EXPERIMENTS R6.2)
+    int32_t dag_flow_pause = 0;     // runs left on the barrier form after a dataflow launch gave up a wait
+    int32_t dag_flow_max_nbr = 0;
+    int last_dag_flow = 0;
+    int32_t* d_g_nbr = nullptr;
+    DagFlowSync* d_g_flow = nullptr;
     bool dag_ready = false;         // full plan built, device tables and image uploaded (ensure_dag)
     int32_t dag_cap = 224;          // the block cap the plan was built for
     int dag_mode = 1;               // option "dag": 0 never, 1 where eligible and no other one-launch path takes the network, 2 wherever eligible

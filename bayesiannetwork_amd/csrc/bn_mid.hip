@@ -144,9 +144,21 @@ __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds&
         unsigned long long res_bits = 0;
         if (red_slot >= 0) res_bits = wave_umax64_dpp<true>(L.red[red_slot + (tid & 15)]);
         unsigned long long* tbl = reinterpret_cast<unsigned long long*>(a.bar + 32) + (gen & 1u) * (2 * kMidMaxParts);
+        // The second granule word also carries the workgroup's ARRIVAL TIME (16 bits of the 100 MHz clock above the low 16 bits of the
+        // generation -- enough to tell a torn pair: a slot is reused every second generation).  The work of an iteration is static, so
+        // the lag of the LAST workgroup behind this one repeats from iteration to iteration: the first poll is placed where that
+        // workgroup is expected (own arrival + the previous barrier's lag + a margin) instead of at the own arrival -- a poll is a
+        // ~1 us round trip, and one that leaves just before the last granule becomes visible costs a whole second trip (the form
+        // bn_dag.hip and bn_resident.hip have had since round 4; DESIGN section 7 listed it as not yet applied here).
+        const unsigned long long t_arr = wall_clock64();
+        const unsigned own16 = unsigned(t_arr) & 0xffffu;
         if (tid == 0) {
             __hip_atomic_store(tbl + 2 * blockIdx.x, ((unsigned long long)gen << 32) | unsigned(res_bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(tbl + 2 * blockIdx.x + 1, ((unsigned long long)gen << 32) | unsigned(res_bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tbl + 2 * blockIdx.x + 1, ((unsigned long long)((own16 << 16) | (gen & 0xffffu)) << 32) | unsigned(res_bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.first_poll_delay >= 0 && a.nparts > 1) {
+            const unsigned long long first_at = t_arr + L.red[33] + (unsigned long long)a.first_poll_delay;
+            while (wall_clock64() < first_at) __builtin_amdgcn_s_sleep(1);
         }
         static_assert(kMidMaxParts <= 4 * kWave, "a poll reads every workgroup's granule: lane l those of workgroups l, l + 64, l + 128, l + 192");
         const int np = a.nparts;
@@ -154,8 +166,9 @@ __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds&
         const unsigned long long t0 = wall_clock64();
         unsigned polls = 0, give_up = 0;
         unsigned long long mx = 0;
+        int late = 0;
         for (;;) {
-            mid_u32x4 r0, r1, r2, r3;   // words of a granule: {residual high half, generation, residual low half, generation}
+            mid_u32x4 r0, r1, r2, r3;   // words of a granule: {residual high half, generation, residual low half, arrival time << 16 | generation & 0xffff}
             if (np <= kWave)
                 asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(voff), "s"(tbl) : "memory");
             else
@@ -167,11 +180,14 @@ __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds&
                              : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(voff), "s"(tbl) : "memory");
             bool mine = true;
             mx = 0;
+            late = 0;
             auto take = [&](const mid_u32x4& r, int part) {
                 if (part < np) {
-                    mine = mine && r.y == gen && r.w == gen;
+                    mine = mine && r.y == gen && (r.w & 0xffffu) == (gen & 0xffffu);
                     const unsigned long long v = (unsigned long long)r.x << 32 | r.z;
                     mx = v > mx ? v : mx;
+                    const int d = int(short((r.w >> 16) - own16));   // that workgroup's arrival after this one's, ticks (wraps every 655 us)
+                    late = d > late ? d : late;
                 }
             };
             take(r0, tid);
@@ -188,7 +204,8 @@ __device__ __forceinline__ bool mid_grid_barrier(const MidArgs& a, const MidLds&
             }
         }
         mx = wave_umax64_dpp(mx);
-        if (tid == 0) { *L.flag = give_up; L.red[32] = mx; }
+        const unsigned lag = wave_umax32_dpp(unsigned(late));   // (late >= 0) the latest arrival of this barrier: the next one's prediction
+        if (tid == 0) { *L.flag = give_up; L.red[32] = mx; L.red[33] = give_up ? 0ull : (unsigned long long)(lag < 400u ? lag : 400u); }
     }
     __syncthreads();
     *res_out = L.red[32];
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
     for (int t = tid; t < pt.TT; t += nt) L.term[t] = a.term[pt.term_off + t];
     for (int t = tid; t < pt.CL; t += nt) L.clist[t] = a.clist[pt.clist_off + t];
     for (int t = tid; t < pt.T; t += nt) L.stg[t] = 0.0;  // the padding of the runs stays zero for the whole run
-    if (tid < 32) L.red[tid] = 0ull;
+    if (tid < 34) L.red[tid] = 0ull;   // ([33]: the barrier's lag prediction)
     if (tid == 0) *L.flag = 0u;
 
     // ---- initial state (:33-73) of this workgroup's nodes [v0, v1): their vectors, the messages on their in-edges

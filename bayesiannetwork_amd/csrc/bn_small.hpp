@@ -150,6 +150,7 @@ struct MidArgs {
     unsigned long long* res;     // (unused since round 5: maximum_difference travels in the granules)
     unsigned* abort;             // page-locked host word
     unsigned long long timeout_ticks;
+    int32_t first_poll_delay;    // 10 ns ticks between the predicted arrival of the last workgroup and a workgroup's first poll (-1: poll from the own arrival on)
     // several evidence sets in one launch (gridDim.y): set blockIdx.y of the launch is set `set_base + blockIdx.y` of the batch
     // (its beliefs, residual history, control block, evidence header) and works in state slot `slot_base + blockIdx.y`
     // (state, marks and barrier words, `state_stride` doubles / N bytes / 64 bytes apart)

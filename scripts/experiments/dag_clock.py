@@ -17,6 +17,8 @@ ev = synth.random_evidence(g, 0.01, seed=7)
 L = _lib.lib()
 with Engine(g) as e:
     e.set_option("dag", 2)
+    FLOW = os.environ.get("DAGFLOW") == "1"   # the dataflow form (no grid barrier): stamps 0 start, 1 neighbours + verdict there, 2 inputs, 3 stores issued, 4 drained, 6 published
+    e.set_option("dagflow", 1 if FLOW else 0)
     e.bp_set_evidence(ev)
     for _ in range(3):
         r = e.bp_run_device(1e-3)
@@ -37,6 +39,10 @@ with Engine(g) as e:
     # stamps: 0 iteration start, 1 verdict known, 2 inputs arrived, 3 stores issued, 4 drained, 5 block synced, 6 published
     names = ["wait verdict", "loads", "compute + stores issued", "drain", "block sync", "publish"]
     order = [0, 1, 2, 3, 4, 5, 6]
+    if FLOW:
+        names = ["wait neighbours + verdict", "loads", "compute + stores issued", "drain", "publish", "-"]
+        order = [0, 1, 2, 3, 4, 6, 6]
+        print("dataflow form:", e.info("last_dag_flow"))
     for kind in (-1, 0, 1, 2, 3, 4, 5, 8):
         sel = ok & (kinds == kind)
         if not sel.any():

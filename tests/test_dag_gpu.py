@@ -90,6 +90,80 @@ def test_dag_soft_and_zero_evidence_and_a_two_launch_run(Engine, oracle_mod):
         assert np.abs(eng.bp_residuals()[:1100] - o["residuals"]).max() < 1e-12
 
 
+@pytest.mark.parametrize("name", ["grid40", "dag300", "dag3000", "hub70"])
+def test_dag_dataflow_form(Engine, oracle_mod, name):
+    """Option "dagflow" 1: the single query WITHOUT a grid barrier -- a tile waits for its neighbour tiles' granules, a service block
+    takes the stop decision one iteration behind (csrc/bn_dag.hip, dag_flow_drive).  One speculative iteration per run, written to
+    the other buffer: the same sweep count, residual history, messages and marginals as the barrier form bit for bit (and as the
+    oracle on networks of <= 2-parent nodes), also with a sweep cap, a run beyond one launch's budget, NaNs and repeated runs."""
+    from bayesiannetwork_amd import Evidence, synth
+    g, exact = {n: (m, x) for n, m, x in _nets()}[name]
+    with Engine(g) as eng:
+        eng.set_option("dag", 2)
+        eng.bp_run(None, 1e-3)   # (the path is set up by its first use: eligibility of the dataflow form is known after it)
+        if not eng.info("dag_flow_eligible"):
+            assert eng.info("dag_blocks") < 2 or eng.info("dag_flow_max_nbr") > 64
+            pytest.skip("one block, or a tile with more than 64 neighbour tiles: the barrier form is the only one")
+        cases = [(Evidence.none(), 1e-6, 0), (synth.random_evidence(g, 0.1, seed=3), 1e-9, 0), (synth.random_evidence(g, 0.05, seed=6), 1e-12, 3),
+                 (synth.random_evidence(g, 0.05, seed=6), 1e-12, 1), (Evidence.from_dict(g, {5: np.zeros(4)}), 1e-6, 6)]
+        for ev, eps, cap in cases:
+            o = oracle_mod.bp_run(g, ev, eps, cap, dump_msgs=True)
+            got = {}
+            for flow in (0, 1, 1):
+                eng.set_option("dagflow", flow)
+                r = eng.bp_run(ev, eps, cap)
+                assert eng.last_path() == 5 and eng.info("last_dag_flow") == flow and eng.info("dag_aborts") == 0
+                assert eng.bp_stats()["sweep_launches"] == 1
+                pi, lam = eng.bp_messages()
+                got[flow] = (r["sweeps"], r["residual"], r["beliefs"].copy(), eng.bp_residuals().copy(), pi, lam)
+            b, f = got[0], got[1]
+            assert b[0] == f[0] == o["sweeps"]
+            assert b[1] == f[1] or (np.isnan(b[1]) and np.isnan(f[1]))
+            for x, y in zip(b[2:], f[2:]):
+                assert np.array_equal(x, y, equal_nan=True)
+            if exact:
+                assert np.array_equal(f[2], o["beliefs"], equal_nan=True) and np.array_equal(f[3], o["residuals"], equal_nan=True)
+                assert np.array_equal(f[4], o["pi_msg"], equal_nan=True) and np.array_equal(f[5], o["lambda_msg"], equal_nan=True)
+            else:
+                assert rel_err(f[2], o["beliefs"]) < 1e-9
+        # beyond one launch's budget (1 024 iterations): the second launch continues from the state in memory, no speculation across the cut
+        ev = synth.random_evidence(g, 0.05, seed=1)
+        eng.set_option("dagflow", 0)
+        want = eng.bp_run(ev, 0.0, 1100)
+        want_res = eng.bp_residuals().copy()
+        eng.set_option("dagflow", 1)
+        r = eng.bp_run(ev, 0.0, 1100)
+        assert eng.info("last_dag_flow") == 1 and eng.bp_stats()["sweep_launches"] == 2 and r["sweeps"] == want["sweeps"] == 1100
+        assert np.array_equal(r["beliefs"], want["beliefs"]) and np.array_equal(eng.bp_residuals(), want_res)
+        # staged evidence, device-resident runs, alternating forms
+        eng.bp_set_evidence(synth.random_evidence(g, 0.1, seed=3))
+        first = None
+        for flow in (1, 0, 1, 1, 0):
+            eng.set_option("dagflow", flow)
+            rr = eng.bp_run_device(1e-6)
+            cur = (rr["sweeps"], eng.bp_beliefs().copy())
+            first = first or cur
+            assert cur[0] == first[0] and np.array_equal(cur[1], first[1])
+
+
+def test_dag_dataflow_form_at_config2_size(Engine, oracle_mod):
+    """... on BASELINE configs[1] itself (1 189 tiles on 224 blocks + the service block, up to 40 neighbour tiles per tile): the same bits as
+    the barrier form; the default stays the barrier form (the dataflow form is the slower one there: EXPERIMENTS R6.2)."""
+    from bayesiannetwork_amd import synth
+    g = synth.random_dag(10000, 4, 64, 4, seed=1)
+    ev = synth.random_evidence(g, 0.01, seed=7)
+    o = oracle_mod.bp_run(g, ev, 1e-3)
+    with Engine(g) as eng:
+        r0 = eng.bp_run(ev, 1e-3)
+        assert eng.last_path() == 5 and eng.info("last_dag_flow") == 0 and eng.info("dag_flow_eligible") == 1
+        eng.set_option("dagflow", 1)
+        for _ in range(3):
+            r1 = eng.bp_run(ev, 1e-3)
+            assert eng.info("last_dag_flow") == 1 and eng.info("dag_aborts") == 0
+            assert r1["sweeps"] == r0["sweeps"] == o["sweeps"] and np.array_equal(r1["beliefs"], r0["beliefs"])
+        assert np.abs(r1["beliefs"] - o["beliefs"]).max() < 1e-12
+
+
 def test_dag_view_and_functor(Engine, oracle_mod):
     """bn_bp_run_view (the drop-in's host path: marginals written straight into the mapped host buffer) on this path."""
     from bayesiannetwork_amd import synth

@@ -315,6 +315,10 @@ def test_hot_kernels_do_not_spill(bnlib):
     for name, r in kr.kernel_resources(os.path.join(csrc, "bn_mid.o")).items():   # the same items over several workgroups
         rounds = int(re.search(r"bp_mid_kernel<(\d+)>", name).group(1))
         assert r["vgpr"] <= 128 and (r["spill"] == 0 if rounds <= 2 else r["spill"] <= 32), (name, r)
+    dag = kr.kernel_resources(os.path.join(csrc, "bn_dag.o"))   # register-resident DAG path: the single query, with the barrier and in its dataflow form
+    for inst in ("bp_dag_kernel<false, false, false>", "bp_dag_kernel<false, false, true>"):
+        hit = [r for name, r in dag.items() if inst in name]
+        assert len(hit) == 1 and hit[0]["spill"] == 0 and hit[0]["scratch"] == 0 and hit[0]["vgpr"] <= 256, (inst, hit)
     small = kr.kernel_resources(os.path.join(csrc, "bn_small.o"))   # one workgroup per run, state in LDS (small networks)
     assert len(small) == 3
     for name, r in small.items():
@@ -494,10 +498,10 @@ def test_dag_plan_invariants(bnlib):
         kr = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(kr)
         res = {k: v for k, v in kr.kernel_resources(obj).items() if "bp_dag_kernel" in k}
-        assert len(res) == 4          # {resident, stream form} x {a single query, several evidence sets per launch}
+        assert len(res) == 5          # {resident, stream form} x {a single query, several evidence sets per launch} + the single query's dataflow form
         for name, r in res.items():   # two waves per SIMD: 256 registers each, the 64 CPT entries of a lane among them
             assert r["vgpr"] <= 256, (name, r)
-            if ", false>" in name:    # what a single query runs: nothing spilled
+            if re.search(r"bp_dag_kernel<(true|false), false, (true|false)>", name):    # what a single query runs: nothing spilled
                 assert r["spill"] == 0 and r["scratch"] == 0, (name, r)
             else:                     # the walk over a batch's sets: a handful of dwords
                 assert r["spill"] <= 16, (name, r)
@@ -531,6 +535,51 @@ def test_reload_cpt_rebuilds_every_plan_host_only(bnlib, oracle_mod):
             assert np.abs(got["beliefs"] - want["beliefs"]).max() < 1e-12
         else:
             assert np.array_equal(got["beliefs"], want["beliefs"])
+
+
+def test_dag_plan_is_light_until_asked_for(bnlib, oracle_mod):
+    """bn_create builds the LIGHT plan of the register-resident DAG path (tile tables and the features the default-path policy reads);
+    the padded CPT image is filled by the first use -- here bn_dag_plan_get.  A reload BEFORE that first use and one AFTER it both
+    end in the plan a fresh engine builds from the new tables; the construction split is reported (bn_get_info "create_us_*")."""
+    import dag_emulator
+    from bayesiannetwork_amd import FlatModel, _lib, engine, synth
+    from bayesiannetwork_amd.synth import _random_cpts
+    a = synth.random_dag(400, 4, 32, [4, 3, 4, 2], seed=21)
+    _, cpt = _random_cpts(a.k, a.in_ptr, a.in_idx, 5)
+    b = FlatModel(a.k, a.in_ptr, a.in_idx, a.cpt_off, cpt)
+    ev = synth.random_evidence(a, 0.05, seed=2)
+    want = oracle_mod.bp_run(b, ev, 1e-6)
+    with engine.Engine(b, device=_lib.BN_DEVICE_HOST_ONLY) as fresh:
+        ref = fresh.dag_plan()
+    for reload_first in (True, False):
+        with engine.Engine(a, device=_lib.BN_DEVICE_HOST_ONLY) as e:
+            assert e.info("dag_eligible") == 1 and e.info("dag_tiles") == ref["n_tiles"] and e.info("dag_blocks") == ref["blocks"]
+            for k in ("plan", "small", "mid", "dag", "device"):
+                assert e.info("create_us_" + k) >= 0
+            assert e.info("create_us_device") == 0   # host-only: nothing was uploaded
+            if not reload_first:
+                assert e.dag_plan()["cpt_img"].size == ref["cpt_img"].size   # (first use: the full plan)
+            e.reload_cpt(b.cpt)
+            plan = e.dag_plan()
+        for key in ("tiles", "slot_ptr", "cnode", "pitem", "oedge", "cpt_img", "npi_init"):
+            assert np.array_equal(plan[key], ref[key]), (reload_first, key)
+        got = dag_emulator.emulate(plan, b, ev, 1e-6)
+        assert got["sweeps"] == want["sweeps"] and np.abs(got["beliefs"] - want["beliefs"]).max() < 1e-12
+    with pytest.raises(_lib.BnError, match="unknown info"):
+        engine.Engine(a, device=_lib.BN_DEVICE_HOST_ONLY).info("create_us_nothing")
+
+
+def test_debug_stream_argument_checks(bnlib):
+    """bn_debug_stream (the achievable-HBM yardstick of bench.py): arguments are checked before any device call; without a GPU it says so."""
+    import ctypes
+    from bayesiannetwork_amd import _lib
+    g = ctypes.c_double(0.0)
+    assert bnlib.bn_debug_stream(0, 0, 1 << 30, 3, None) == _lib.BN_ERR_ARG
+    assert bnlib.bn_debug_stream(0, 2, 1 << 30, 3, ctypes.byref(g)) == _lib.BN_ERR_ARG
+    assert bnlib.bn_debug_stream(0, 0, 1000, 3, ctypes.byref(g)) == _lib.BN_ERR_ARG
+    assert bnlib.bn_debug_stream(0, 0, 1 << 30, 0, ctypes.byref(g)) == _lib.BN_ERR_ARG
+    if not os.path.exists("/dev/kfd"):
+        assert bnlib.bn_debug_stream(0, 0, 1 << 30, 3, ctypes.byref(g)) == _lib.BN_ERR_NO_DEVICE
 
 
 def test_small_plan_invariants(bnlib):

@@ -144,3 +144,33 @@ def test_step_api_after_a_view_run(Engine, oracle_mod):
         assert np.abs(bel - o["beliefs"]).max() < 1e-12 and np.abs(bel - va).max() > 1e-3
         pi, lam = eng.bp_messages()
         assert np.abs(pi - o["pi_msg"]).max() < 1e-12 and np.abs(lam - o["lambda_msg"]).max() < 1e-12
+
+
+def test_debug_stream_measures_a_plausible_rate(bnlib):
+    """bn_debug_stream: the library's own copy / triad kernels reach a few TB/s on an MI355X (bench.py's `hbm_stream_gbs_measured`) and
+    check their own output."""
+    import ctypes
+    for mode in (0, 1):
+        g = ctypes.c_double(0.0)
+        assert bnlib.bn_debug_stream(-1, mode, 1 << 29, 3, ctypes.byref(g)) == 0
+        assert 2000.0 < g.value < 8000.0, (mode, g.value)
+
+
+def test_construction_split_is_reported(bnlib):
+    """bn_get_info "create_us_*" on a device engine: the host plans and the device side add up to (most of) the time bn_create took; a second
+    engine of the process -- the runtime is up, a parked stream is at hand -- is created in a few milliseconds."""
+    import time
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+    g = synth.random_dag(30, 4, 12, [2, 3, 4, 3], seed=7)
+    with Engine(g) as first:
+        first.bp_run(None, 1e-6)
+    for _ in range(3):
+        t0 = time.perf_counter()
+        e = Engine(g)
+        dt_ms = (time.perf_counter() - t0) * 1e3
+        parts = {k: e.info("create_us_" + k) / 1e3 for k in ("plan", "small", "mid", "dag", "device")}
+        e.close()
+        assert all(v >= 0 for v in parts.values()) and parts["device"] > 0
+        assert sum(parts.values()) <= dt_ms + 0.5
+    assert dt_ms < 20.0, (dt_ms, parts)   # (measured: 1.8-2.5 ms; the bound leaves room for a loaded host)

@@ -77,3 +77,31 @@ def test_reload_argument_errors(Engine):
     with Engine(a) as eng:
         with pytest.raises(_lib.BnError, match="entries given"):
             eng.reload_cpt(a.cpt[:-1])
+
+
+def test_reload_before_the_dag_path_is_first_used(Engine):
+    """bn_create keeps the register-resident DAG path LIGHT where another path is the default (a 180 x 180 grid: beyond one tile per wave,
+    the resident tiles keep it): no padded image on the host, nothing of it on the device.  A reload in that state, then the path's first
+    use ("dag" 2), must run the NEW tables; so must "autotune", which tries every eligible path."""
+    from bayesiannetwork_amd import synth
+    a = synth.grid(180, 180, 4, seed=5)
+    b = _with_other_cpts(a, seed=77)
+    ev = synth.random_evidence(a, 0.05, seed=3)
+    with Engine(a) as eng, Engine(b) as fresh:
+        first = eng.bp_run(ev, 1e-6)
+        assert eng.last_path() != 5 and eng.info("dag_eligible") == 1
+        fresh.set_option("dag", 2)
+        want = fresh.bp_run(ev, 1e-6)
+        assert fresh.last_path() == 5
+        eng.reload_cpt(b.cpt)                    # (the DAG plan is still light here)
+        eng.set_option("dag", 2)
+        got = eng.bp_run(ev, 1e-6)               # first use: image filled from the NEW tables, uploaded
+        assert eng.last_path() == 5 and got["sweeps"] == want["sweeps"] and np.array_equal(got["beliefs"], want["beliefs"])
+        assert np.abs(got["beliefs"] - first["beliefs"]).max() > 1e-3
+        eng.reload_cpt(a.cpt)                    # (now the full plan is re-derived and re-uploaded)
+        back = eng.bp_run(ev, 1e-6)
+        assert eng.last_path() == 5 and back["sweeps"] == first["sweeps"] and np.array_equal(back["beliefs"], first["beliefs"])
+    with Engine(a) as eng:                       # autotune on an engine whose DAG path was never set up
+        eng.set_option("autotune", 1)
+        r = eng.bp_run(ev, 1e-6)
+        assert eng.info("autotuned") == 1 and r["sweeps"] == first["sweeps"] and np.array_equal(r["beliefs"], first["beliefs"])
