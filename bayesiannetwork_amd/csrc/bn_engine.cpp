@@ -977,7 +977,11 @@ MidArgs bn_eng::mid_args_of(bn_engine* e, const BpBuffers& b0, const SetStrides&
     a.res = reinterpret_cast<unsigned long long*>(e->d_m_sync + 8);
     a.abort = e->h_abort_dev;
     a.timeout_ticks = 5000000ull;  // one wait: 50 ms of the 100 MHz clock
-    static const int mid_first_delay = std::getenv("BN_MID_DELAY") ? std::atoi(std::getenv("BN_MID_DELAY")) : 0;   // 10 ns ticks behind the predicted last arrival; -1: poll from the own arrival on (rounds 3-5).  mixed10k, us per sweep: 8.30 at -1, 8.17 at 0, 8.80 at 30, 9.08 at 60
+    // first poll of the grid barrier placed by the previous barrier's lag (arrival times in the granules, as bn_dag.hip / bn_resident.hip do):
+    // BN_MID_DELAY = margin in 10 ns ticks, -1 (default) = poll from the own arrival on.  mixed10k, us per sweep: 8.30 off, 8.17 at 0,
+    // 8.80 at 30, 9.08 at 60 (round 6; round 5 measured 8.5 / 8.7 / 9.1): the polling wave has nothing else to do and polls back to
+    // back, so a poll placed by prediction can only be later -- at margin 0 it is within the run-to-run spread, with any margin slower
+    static const int mid_first_delay = std::getenv("BN_MID_DELAY") ? std::atoi(std::getenv("BN_MID_DELAY")) : -1;
     a.first_poll_delay = mid_first_delay;
     a.sets = st; a.set_base = set_base; a.slot_base = slot_base;
     return a;
