@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kSmallMaxWaves * kWave) void bp_mid_kernel(MidArgs 
         // element a pi-message starts from, the first four children's lambda-messages): a trip to L2 costs about as much as a
         // whole phase here, and these travel while the entry items run
         MID_STAMP(0);
-        constexpr bool kPreload = ROUNDS == 1;
+        constexpr bool kPreload = ROUNDS == 1;   // (ROUNDS == 2 as well, 103 -> 127 VGPRs: 8.43 against 8.2-8.3 us per sweep on mixed10k -- the entry phase pays what the accumulators gain; round 6)
         double pre_b[ROUNDS], pre_c[ROUNDS], pre_v[ROUNDS], pre_f[ROUNDS][4];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
