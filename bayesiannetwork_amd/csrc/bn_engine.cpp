@@ -172,6 +172,16 @@ int bn_eng::ensure_dag(bn_engine* e) {
     const Plan& p = e->plan;
     const DagPlan& dp = e->dag;
     int r2;
+    {   // (an earlier attempt that failed half-way -- out of device memory -- must not leak what it had got)
+        void** mine[] = {reinterpret_cast<void**>(&e->d_g_slotptr), reinterpret_cast<void**>(&e->d_g_tiles), reinterpret_cast<void**>(&e->d_g_cnode),
+                         reinterpret_cast<void**>(&e->d_g_pitem), reinterpret_cast<void**>(&e->d_g_oedge), reinterpret_cast<void**>(&e->d_g_eperm),
+                         reinterpret_cast<void**>(&e->d_g_nperm), reinterpret_cast<void**>(&e->d_g_cpt), reinterpret_cast<void**>(&e->d_g_init),
+                         reinterpret_cast<void**>(&e->d_g_k), reinterpret_cast<void**>(&e->d_g_inptr), reinterpret_cast<void**>(&e->d_g_inidx),
+                         reinterpret_cast<void**>(&e->d_g_noff), reinterpret_cast<void**>(&e->d_g_state), reinterpret_cast<void**>(&e->d_g_frz),
+                         reinterpret_cast<void**>(&e->d_g_sync), reinterpret_cast<void**>(&e->d_g_nbr), reinterpret_cast<void**>(&e->d_g_flow)};
+        for (void** q : mine)
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
+    }
     if ((r2 = upload(&e->d_g_slotptr, dp.slot_ptr, e->stream))) return r2;
     {
         const DagDeviceTables& dt = e->dag_tables;
