@@ -235,6 +235,12 @@ int bn_bp_messages(bn_engine *eng, double *pi_msg_out, double *lambda_msg_out);
  *   bn_bp_run_batch on such a network: up to 16 evidence sets share a launch and its CPT registers, taking turns inside an iteration;
  *   every set keeps the sweep count and the bits of its single run.
  *   bn_get_info "dag_eligible", "dag_blocks", "dag_tiles", "dag_stream", "dag_aborts".
+ * "dagflow" 1 -- single queries on that path run in its DATAFLOW form where the plan has one (one tile per wave, more than one block, at
+ *   most 64 neighbour tiles per tile): no grid barrier -- a tile starts its next iteration when the tiles it exchanges messages with
+ *   have finished the previous one, one more block takes the stop decision one iteration behind, the one speculative iteration writes
+ *   the other buffer.  Same sweep counts and bits as the barrier form.  0 (default): the barrier form -- measured faster on every
+ *   network tried but a 64 x 64 grid (EXPERIMENTS.md R6.2).  bn_get_info "dag_flow_eligible" (known once the path has run or its plan
+ *   was asked for), "dag_flow_max_nbr", "last_dag_flow".
  * "autotune" 1 -- the NEXT run first times every execution path the engine is eligible for on the evidence in force (one warm-up and
  *   two timed runs of 6 sweeps each, host wall clock) and keeps the fastest for all later runs: the built-in choice between the
  *   paths rests on thresholds measured on a handful of networks on one pool of machines.  The choice is written into the options
