@@ -139,3 +139,18 @@ def test_bench_gpus_2_typed_plainly():
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 5 and line["warmup"] == 2
     assert line["config"]["world_size"] == 2 and line["config"]["rccl_ranks"] == 0   # (BN_NO_RCCL: no communicator was created)
     assert line["config"]["exchange"].startswith("in-kernel")
+
+
+def test_bench_gpus_4_typed_plainly():
+    """... and with four ranks (three stripe cuts, every rank both a producer and a consumer of two neighbours): the N-rank blobs, the
+    verification against the unsharded run on every rank, the timed runs and the extras, all on device 0."""
+    from helpers import parse_bench_output
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BN_BENCH_SAME_DEVICE="1", BN_NO_RCCL="1", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "2", "--rows", "128",
+                        "--cols", "80"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line, extras = parse_bench_output(p.stdout)
+    assert line["n_gpus"] == 4 and line["value"] > 0 and line["config"]["world_size"] == 4
+    assert line["config"]["exchange"].startswith("in-kernel") and line["config"]["in_kernel_exchange_verified"] is True
+    assert extras["replicated_queries"]["value"] > 0
