@@ -157,3 +157,23 @@ def test_bench_gpus_n_without_a_launcher_starts_one(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=120)
     assert p.returncode != 0 and "must agree" in p.stderr
+
+
+def test_design_figures_script_runs_on_the_committed_profiles():
+    """scripts/design_figures.py (the figures DESIGN.md quotes) reads profiles/r06_summary.json + r06_bench_line.json: it runs, names the
+    profiled library, and prices the headline kernel and the grid batch the way DESIGN section 4.2 states them."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "design_figures.py"), "r06"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = p.stdout
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r06_summary.json")))
+    assert summary["failed_passes"] == [] and summary["lib_sha256"][:16] in out
+    assert "bp_resident_kernel" in out and "bp_dag_kernel" in out and "grid batch:" in out and "configs[1]:" in out
+    batch = next(ln for ln in out.splitlines() if ln.startswith("batch_grid316"))
+    assert "per set-sweep" in batch and "of the measured stream" in batch and "x must-move" in batch
+    # the full record of the round's default run is itself a valid input of the line builder
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_line.json")))
+    line = json.loads(benchline.contract_line(full))
+    assert line["roofline"]["hbm_stream_gbs_measured"] > 5500 and line["roofline"]["traffic"] > 0 and "configs[2]" in line["config"]["workload"]
+    for k in ("batch", "config2_dag", "config5_lw", "grid2048", "config1_alarm", "mid_mixed300", "dropin_cpp"):
+        assert k in full and "error" not in full[k], k
+    assert full["batch"]["B16"]["cycled"]["value"] > 3e10 and full["config5_lw"]["generic_mixed10k"]["value"] > 1e7
