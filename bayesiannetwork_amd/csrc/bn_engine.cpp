@@ -1055,6 +1055,12 @@ bool bn_eng::dag_applies(const bn_engine* e) {
     // 60 nodes of mixed arity with <= 3 parents (three rounds) 72.3 / 64.6.  Chains and trees the resident tiles run in ONE block
     // stay there (200-node chain: 71.9 resident, 81.6 this path, 113.6 one workgroup).
     if (e->small_ok && e->small.re <= 2) return false;   // (two rounds: not measured; the one-workgroup path also keeps the reference's order for >= 3 parents)
+    // ... and where the two paths' BITS differ -- some node has >= 3 parents: lane groups re-associate, the one-workgroup path keeps the
+    // reference's order -- the small network stays on the one-workgroup path whatever its rounds: a batch of such a network runs one
+    // workgroup per set (bn_engine_batch.cpp), and a set's answer must not depend on whether it was asked alone or in a batch
+    // (scripts/soak_gpu.py found a 30-node network where the two differed by 2e-16; round 6).  Price: 60 nodes of mixed arity, <= 3
+    // parents: 72 instead of 65 us per query.
+    if (e->small_ok && e->dag.has_groups) return false;
     if (e->small_ok && e->small.mmax <= 1 && e->resident_ok && e->grid_resident == 1) return false;
     // Arities below 4 (padded form), us per sweep, this path / the default before (scripts/time_dag_mixed.py): mixed arities 2-4 with
     // <= 3 parents 300 / 3 000 / 10 000 nodes 4.6 / 5.4, 5.7 / 7.1, 6.5 / 9.2 (item kernels); <= 4 parents, 10 000 nodes (723 k entries:

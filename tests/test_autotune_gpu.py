@@ -111,8 +111,8 @@ def test_two_functors_on_one_device_from_two_threads(Engine, oracle_mod, capfd):
 @pytest.mark.gpu
 def test_default_path_of_small_networks(bnlib, oracle_mod):
     """Which one-launch path a SMALL network takes by default (bn_engine.cpp dag_applies; timings in profiles/r05_paths.json): one or
-    two rounds of entry items -> one workgroup, state in LDS (path 3: ALARM-sized); three or more with arities <= 4 -> the
-    register-resident DAG path (path 5: 8 x 8 grid, k = 4, 64 vs 86 us per query); a chain the resident tiles run in one block stays
+    two rounds of entry items -> one workgroup, state in LDS (path 3: ALARM-sized); three or more with arities <= 4 and <= 2 parents per
+    node -> the register-resident DAG path (path 5: 8 x 8 grid, k = 4, 64 vs 86 us per query); a chain the resident tiles run in one block stays
     there (path 2).  Whatever the path, the oracle's sweep count and marginals."""
     import os
     from bayesiannetwork_amd import synth
@@ -129,3 +129,21 @@ def test_default_path_of_small_networks(bnlib, oracle_mod):
             assert eng.last_path() == want_path, (g.name, eng.last_path())
             assert r["sweeps"] == o["sweeps"]
             assert np.array_equal(r["beliefs"], o["beliefs"]) if exact else np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+    # A small network with >= 3-parent nodes stays on the one-workgroup path WHATEVER its rounds of entry items: that path keeps the
+    # reference's order for any parent count (the DAG path's lane groups re-associate), and a batch of such a network runs one workgroup
+    # per set -- a set's answer must not depend on whether it was asked alone or in a batch (scripts/soak_gpu.py, round 6: a 30-node
+    # network of arities {4, 2} with <= 4 parents differed by 2e-16 between the two).
+    g = synth.random_dag(30, 4, 8, [4, 2], seed=398548165)
+    assert int(np.diff(g.in_ptr).max()) >= 3
+    sets = [synth.random_evidence(g, 0.1, seed=3), synth.random_evidence(g, 0.05, seed=5), synth.random_evidence(g, 0.2, seed=6)]
+    with Engine(g) as eng:
+        assert eng.info("small_eligible") == 1 and eng.info("dag_eligible") == 1
+        out = eng.bp_run_batch(sets, 1e-9, 0)
+        for q, ev in enumerate(sets):
+            o = oracle_mod.bp_run(g, ev, 1e-9)
+            r = eng.bp_run(ev, 1e-9)
+            assert eng.last_path() == 3 and r["sweeps"] == o["sweeps"] == int(out["sweeps"][q])
+            assert np.array_equal(r["beliefs"], o["beliefs"]) and np.array_equal(out["beliefs"][q], r["beliefs"])
+        eng.set_option("dag", 2)     # (forced, the DAG path still runs it: to rounding)
+        r5 = eng.bp_run(sets[0], 1e-9)
+        assert eng.last_path() == 5 and np.abs(r5["beliefs"] - out["beliefs"][0]).max() < 1e-12
