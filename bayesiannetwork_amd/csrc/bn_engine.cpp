@@ -1469,6 +1469,8 @@ extern "C" int64_t bn_get_info(bn_engine* e, const char* name) {
     if (std::strcmp(name, "dag_stream") == 0) return e->dag.ok && e->dag.stream ? 1 : 0;
     if (std::strcmp(name, "lw_small") == 0) return e->lw.ready && e->lw.small ? 1 : 0;   // (known after the first sampler call)
     if (std::strcmp(name, "dag_aborts") == 0) return e->dag_aborts;
+    if (std::strcmp(name, "batch_dense_refused") == 0) return e->dense_refused ? 1 : 0;   // (known after the first batch of >= 2 sets)
+    if (std::strcmp(name, "batch_on_dense") == 0) return e->batch_on_dense ? 1 : 0;
     if (std::strcmp(name, "dag_flow_eligible") == 0) return e->dag_flow_ok ? 1 : 0;     // (known once the path has been set up: ensure_dag)
     if (std::strcmp(name, "dag_flow_max_nbr") == 0) return e->dag_flow_max_nbr;
     if (std::strcmp(name, "last_dag_flow") == 0) return e->last_path == 5 ? e->last_dag_flow : 0;

@@ -72,6 +72,7 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
     if (e->small_ok && e->small_mode != 0 && e->multisweep != 0) return nullptr;  // one workgroup per set (bn_small.hip): the layout plays no part
     if (mid_applies(e)) return nullptr;                                           // ... or a few per set (bn_mid.hip)
     if (dag_applies(e)) return nullptr;                                           // ... or the register-resident DAG path, set by set (bn_dag.hip)
+    if (e->dense_refused) return nullptr;
     if (!e->dense) {
         const Plan& p = e->plan;
         bn_model_desc d;
@@ -82,6 +83,24 @@ static bn_engine* dense_engine_for_batch(bn_engine* e, int32_t n_sets, int& rc) 
         d.lanes_per_node = p.group_wide ? 4 : 2;  // same lane-group split: same bits as this engine's single queries
         rc = bn_create(&d, &e->dense);
         if (rc) { e->dense = nullptr; return nullptr; }
+        // "each set gets exactly the result its single query gives it" (bn_mi355x.h): the two layouts may put a node on DIFFERENT tile
+        // variants (the latency layout gives nodes with many children the any-arity tiles), and for tables beyond 128 entries -- >= 3
+        // parents, or two parents of arity >= 6 -- the variants sum in different orders (each within 1e-12 of the reference, but not the
+        // same bits; scripts/soak_gpu.py, round 6: a 200-node network of arities {4, 6} differed by 1e-16 between a batch and its single
+        // queries).  Where that happens to some node the batch runs on this engine's own layout.
+        const Plan &p0 = e->plan, &p1 = e->dense->plan;
+        bool same_bits = p1.n == p0.n;
+        for (int32_t v = 0; same_bits && v < p0.n; ++v) {
+            if (p0.node_class[v] < 0 || p1.node_class[v] < 0) continue;
+            const ClassDesc &c0 = p0.classes[p0.node_class[v]], &c1 = p1.classes[p1.node_class[v]];
+            if ((c0.variant != c1.variant || c0.G != c1.G) && int64_t(c0.kv) * c0.rows > 128) same_bits = false;
+        }
+        if (!same_bits) {
+            free_engine(e->dense);
+            e->dense = nullptr;
+            e->dense_refused = true;
+            return nullptr;
+        }
     }
     e->dense->multisweep = e->multisweep;
     e->dense->small_mode = e->small_mode;

@@ -223,6 +223,7 @@ struct bn_engine {
         bool have_run = false;
     } batch;
     bool batch_on_dense = false;    // the current batch lives in `dense`
+    bool dense_refused = false;     // the dense layout would give some node's sums another order than this engine's single queries: batches stay here
     bn_engine* dense = nullptr;     // a second engine with the dense layout: batches on a network whose own layout trades
                                     // wavefront count for one query's latency (Plan::latency_rules_applied) run there
     // small networks: the whole run in ONE workgroup with the state in LDS (bn_small.hip)

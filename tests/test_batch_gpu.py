@@ -166,3 +166,27 @@ def test_batch_beyond_64_sets_on_every_path(Engine):
     with Engine(g) as eng:
         eng.set_option("mid", 0)
         _check_batch(eng, evs, 1e-4, want_path=2, reps=1)
+
+
+def test_batch_keeps_single_query_bits_where_the_dense_layout_would_not(bnlib, oracle_mod):
+    """"Each set gets exactly the result its single query gives it" (bn_mi355x.h).  Batches of a network whose layout was built for the
+    latency of one query normally run on a second engine with the dense layout; where the two layouts put a node with a table of more
+    than 128 entries on different tile variants (they sum in different orders) the batch stays on the engine's own layout instead
+    (scripts/soak_gpu.py found a 200-node network of arities {4, 6} whose batch differed from its single queries by 1e-16; round 6)."""
+    import numpy as np
+    from bayesiannetwork_amd import synth
+    from bayesiannetwork_amd.engine import Engine
+    refused = 0
+    for seed in range(1, 9):
+        g = synth.random_dag(200, 4, 32, [4, 6, 4], seed=seed)
+        sets = [synth.random_evidence(g, f, seed=10 * seed + q) for q, f in enumerate((0.02, 0.05, 0.2))]
+        with Engine(g) as eng:
+            out = eng.bp_run_batch(sets, 1e-9, 3)
+            refused += eng.info("batch_dense_refused")
+            for q, ev in enumerate(sets):
+                r = eng.bp_run(ev, 1e-9, 3)
+                o = oracle_mod.bp_run(g, ev, 1e-9, 3)
+                assert r["sweeps"] == o["sweeps"] == int(out["sweeps"][q])
+                assert np.array_equal(out["beliefs"][q], r["beliefs"]), (seed, q, float(np.abs(out["beliefs"][q] - r["beliefs"]).max()))
+                assert np.abs(r["beliefs"] - o["beliefs"]).max() < 1e-12
+    assert refused >= 1   # (at least one of these networks is of the kind the rule is for)
