@@ -67,7 +67,17 @@ while time.time() < t_end:
         ev = Evidence.from_dict(g, {**hard, **d})
     eps = float(rng.choice([1e-3, 1e-6, 1e-9]))
     cap = int(rng.choice([0, 0, 0, 3, 40]))
-    if count + 1 < skip_until:   # SOAK_SKIP_UNTIL=N: replay the draws of the first N - 1 networks without running them (to get back to a failure)
+    special = rng.random()
+    if special < 0.04 and g.n <= 1200:      # a run beyond one launch's budget of 1 024 iterations (every one-launch path continues from its state in memory)
+        eps, cap = 0.0, int(rng.choice([1030, 2060]))
+    elif special < 0.08 and g.n:            # an all-zero evidence vector: 0 / 0 -> NaN in the reference (no zero guard, :298-311); the NaNs must coincide
+        from bayesiannetwork_amd import Evidence
+        v0 = int(rng.integers(0, g.n))
+        hard = {int(v): (ev.val[ev.off[j]:ev.off[j + 1]].copy()) for j, v in enumerate(ev.node)}
+        hard[v0] = np.zeros(int(g.k[v0]))
+        ev = Evidence.from_dict(g, hard)
+        cap = cap or 12
+    if count + 1 < skip_until and skip_until > 0:   # SOAK_SKIP_UNTIL=N: replay the draws of the first N - 1 networks without running them (to get back to a failure)
         if g.n <= 3000:
             rng.integers(1, 1 << 30); rng.integers(1, 1 << 30)
         if count % 5 == 0 and 4 <= g.n <= 4000:
