@@ -250,7 +250,7 @@ def bench_main(a, rank: int, world: int, local_rank: int) -> None:
     li = eng.layout()
     seg = li["segment_bytes"]
     rccl_ranks = int(eng.info("rccl_ranks"))
-    if have_rccl and rccl_ranks != world:
+    if have_rccl and rccl_ranks not in (0, world):   # (0: the library's librccl has no ncclCommCount -- nothing to compare)
         raise SystemExit(f"rank {rank}: the RCCL communicator reports {rccl_ranks} ranks in a world of {world}")
     if rank == 0:
         msgs = g.messages_per_sweep() * sweeps
